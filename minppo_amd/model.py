@@ -1,0 +1,759 @@
+"""Robot model description -> flat model tables -> device blob.
+
+The reference obtains its robot from the K-Scale API at run time
+(`minppo/env.py:27-50`, id `5eb3cb7f23232298`), hands the MJCF to MuJoCo,
+overrides the solver (`env.py:95-97`: CG, 6 iterations, 6 line-search
+iterations) and converts it with `brax.io.mjcf.load_model` (`env.py:100`).
+None of that is reachable on the target (no network, no MuJoCo), so the engine
+has its own model pipeline:
+
+  ModelSpec (bodies / joints / geoms / actuators, MJCF-like)   [this file]
+      -> compile_model(): flat tables + constants MuJoCo's compiler would
+         derive (`dof_invweight0`, `body_invweight0`, `stat.meaninertia`,
+         tree bookkeeping)                                    [this file]
+      -> to_blob(): the int32/float32 blob `mppo_model_open` consumes
+         (layout documented in include/minppo_hip.h)
+
+Built-in robots are *stand-ins* and are labelled as such everywhere:
+  synth_stompy_pro  : free root + 2 legs x 5 hinges   (nq=17 nv=16 nu=10, O=225)
+  synth_stompy_full : + 2 arms x 5 hinges             (nq=27 nv=26 nu=20, O=415)
+`kscale_id: 5eb3cb7f23232298` resolves to synth_stompy_pro.
+
+Conventions follow MuJoCo: quaternions are (w,x,y,z); body 0 is the world;
+spatial vectors are [rotational(3), translational(3)].
+"""
+
+from __future__ import annotations
+
+import struct
+from dataclasses import dataclass, field
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+
+JNT_FREE, JNT_HINGE, JNT_SLIDE = 0, 2, 3  # (ball=1 unsupported)
+GEOM_SPHERE, GEOM_CAPSULE = 2, 3
+
+MJ_MINVAL = 1e-15
+
+BLOB_MAGIC = 0x4D50504F  # "MPPO"
+BLOB_VERSION = 1
+
+
+# ---------------------------------------------------------------------------
+# specification objects
+# ---------------------------------------------------------------------------
+
+
+@dataclass
+class JointSpec:
+    name: str
+    type: int = JNT_HINGE
+    pos: Sequence[float] = (0.0, 0.0, 0.0)
+    axis: Sequence[float] = (0.0, 0.0, 1.0)
+    range: Optional[Tuple[float, float]] = None
+    damping: float = 0.0
+    armature: float = 0.0
+    stiffness: float = 0.0
+    ref: float = 0.0  # qpos0 for hinge/slide
+
+
+@dataclass
+class GeomSpec:
+    type: int
+    size: Sequence[float]  # sphere: (r,), capsule: (r, half_length) along local z
+    pos: Sequence[float] = (0.0, 0.0, 0.0)
+    quat: Sequence[float] = (1.0, 0.0, 0.0, 0.0)
+    friction: Sequence[float] = (1.0, 0.005, 0.0001)
+
+
+@dataclass
+class BodySpec:
+    name: str
+    parent: str  # "world" or a body name
+    pos: Sequence[float] = (0.0, 0.0, 0.0)
+    quat: Sequence[float] = (1.0, 0.0, 0.0, 0.0)
+    mass: float = 1.0
+    inertia: Sequence[float] = (0.01, 0.01, 0.01)  # diagonal, in the inertial frame
+    ipos: Sequence[float] = (0.0, 0.0, 0.0)
+    iquat: Sequence[float] = (1.0, 0.0, 0.0, 0.0)
+    joints: List[JointSpec] = field(default_factory=list)
+    geoms: List[GeomSpec] = field(default_factory=list)
+
+
+@dataclass
+class ActuatorSpec:
+    joint: str
+    gear: float = 1.0
+    kp: float = 0.0  # position servo: force = kp*(ctrl - length) - kv*velocity ; kp=0 -> motor (gain 1)
+    kv: float = 0.0
+    ctrlrange: Optional[Tuple[float, float]] = None
+    forcerange: Optional[Tuple[float, float]] = None
+
+
+@dataclass
+class ModelSpec:
+    name: str
+    bodies: List[BodySpec]
+    actuators: List[ActuatorSpec]
+    timestep: float = 0.002
+    gravity: Sequence[float] = (0.0, 0.0, -9.81)
+    # solver settings the reference forces (env.py:95-97); tolerance / ls_tolerance are MuJoCo defaults
+    iterations: int = 6
+    ls_iterations: int = 6
+    tolerance: float = 1e-8
+    ls_tolerance: float = 0.01
+    impratio: float = 1.0
+    contact_solref: Sequence[float] = (0.02, 1.0)
+    contact_solimp: Sequence[float] = (0.9, 0.95, 0.001, 0.5, 2.0)
+    limit_solref: Sequence[float] = (0.02, 1.0)
+    limit_solimp: Sequence[float] = (0.9, 0.95, 0.001, 0.5, 2.0)
+    plane_friction: Sequence[float] = (1.0, 0.005, 0.0001)
+    plane_z: float = 0.0
+    free_root_z: float = 1.0  # qpos0[2] of the free joint
+
+
+# ---------------------------------------------------------------------------
+# small quaternion helpers (host side, float64)
+# ---------------------------------------------------------------------------
+
+
+def _qmul(a, b):
+    aw, ax, ay, az = a
+    bw, bx, by, bz = b
+    return np.array(
+        [
+            aw * bw - ax * bx - ay * by - az * bz,
+            aw * bx + ax * bw + ay * bz - az * by,
+            aw * by - ax * bz + ay * bw + az * bx,
+            aw * bz + ax * by - ay * bx + az * bw,
+        ]
+    )
+
+
+def _qmat(q):
+    w, x, y, z = q
+    return np.array(
+        [
+            [w * w + x * x - y * y - z * z, 2 * (x * y - w * z), 2 * (x * z + w * y)],
+            [2 * (x * y + w * z), w * w - x * x + y * y - z * z, 2 * (y * z - w * x)],
+            [2 * (x * z - w * y), 2 * (y * z + w * x), w * w - x * x - y * y + z * z],
+        ]
+    )
+
+
+def _qrot(q, v):
+    return _qmat(q) @ np.asarray(v, dtype=np.float64)
+
+
+def _normalize(v):
+    v = np.asarray(v, dtype=np.float64)
+    n = np.linalg.norm(v)
+    return v / n if n > 0 else v
+
+
+# ---------------------------------------------------------------------------
+# compiled model
+# ---------------------------------------------------------------------------
+
+
+@dataclass
+class CompiledModel:
+    name: str
+    t: Dict[str, np.ndarray]  # tables (float64 / int32); scalars stored as 0-d arrays
+    body_names: List[str]
+    joint_names: List[str]
+
+    # -- dims -------------------------------------------------------------
+    @property
+    def nq(self) -> int:
+        return int(self.t["nq"])
+
+    @property
+    def nv(self) -> int:
+        return int(self.t["nv"])
+
+    @property
+    def nu(self) -> int:
+        return int(self.t["nu"])
+
+    @property
+    def nbody(self) -> int:
+        return int(self.t["nbody"])
+
+    @property
+    def njnt(self) -> int:
+        return int(self.t["njnt"])
+
+    @property
+    def ncon(self) -> int:
+        return int(self.t["ncon"])
+
+    @property
+    def nlimit(self) -> int:
+        return int(self.t["nlimit"])
+
+    @property
+    def nefc(self) -> int:
+        return self.nlimit + 4 * self.ncon
+
+    def obs_size(self, include_c_vals: bool = True) -> int:
+        """`get_obs` width (reference `minppo/env.py:245-261`)."""
+        if include_c_vals:
+            return self.nq + self.nv + 16 * (self.nbody - 1) + self.nv
+        return self.nq + self.nv + self.nv
+
+    @property
+    def dt(self) -> float:
+        return float(self.t["timestep"])  # x n_frames at the env level
+
+    def to_blob(self) -> bytes:
+        return _to_blob(self)
+
+
+def compile_model(spec: ModelSpec) -> CompiledModel:
+    """Flattens a ModelSpec and derives the constants MuJoCo's compiler would
+    (`mj_setConst`: `dof_invweight0`, `body_invweight0`, `stat.meaninertia`)."""
+    names = ["world"] + [b.name for b in spec.bodies]
+    if len(set(names)) != len(names):
+        raise ValueError("duplicate body names")
+    nbody = len(names)
+    body_parent = np.zeros(nbody, np.int32)
+    body_pos = np.zeros((nbody, 3))
+    body_quat = np.tile(np.array([1.0, 0, 0, 0]), (nbody, 1))
+    body_ipos = np.zeros((nbody, 3))
+    body_iquat = np.tile(np.array([1.0, 0, 0, 0]), (nbody, 1))
+    body_mass = np.zeros(nbody)
+    body_inertia = np.zeros((nbody, 3))
+    body_jntadr = np.full(nbody, -1, np.int32)
+    body_jntnum = np.zeros(nbody, np.int32)
+    body_dofadr = np.full(nbody, -1, np.int32)
+    body_dofnum = np.zeros(nbody, np.int32)
+
+    jnt_type, jnt_qposadr, jnt_dofadr, jnt_bodyid = [], [], [], []
+    jnt_pos, jnt_axis, jnt_range, jnt_limited, jnt_stiffness = [], [], [], [], []
+    joint_names: List[str] = []
+    dof_bodyid, dof_jntid, dof_armature, dof_damping = [], [], [], []
+    qpos0: List[float] = []
+    geoms = []  # (type, bodyid, pos, quat, size, friction)
+
+    nq = nv = 0
+    for bi, b in enumerate(spec.bodies, start=1):
+        if b.parent not in names[:bi]:
+            raise ValueError(f"body {b.name}: parent {b.parent!r} must be defined earlier")
+        body_parent[bi] = names.index(b.parent)
+        body_pos[bi] = b.pos
+        body_quat[bi] = _normalize(b.quat)
+        body_ipos[bi] = b.ipos
+        body_iquat[bi] = _normalize(b.iquat)
+        body_mass[bi] = b.mass
+        body_inertia[bi] = b.inertia
+        if b.joints:
+            body_jntadr[bi] = len(jnt_type)
+            body_dofadr[bi] = nv
+        body_jntnum[bi] = len(b.joints)
+        for j in b.joints:
+            if j.name in joint_names:
+                raise ValueError(f"duplicate joint name {j.name}")
+            joint_names.append(j.name)
+            jnt_type.append(j.type)
+            jnt_qposadr.append(nq)
+            jnt_dofadr.append(nv)
+            jnt_bodyid.append(bi)
+            jnt_pos.append(list(j.pos))
+            jnt_axis.append(list(_normalize(j.axis)))
+            jnt_range.append(list(j.range) if j.range is not None else [0.0, 0.0])
+            jnt_limited.append(1 if j.range is not None else 0)
+            jnt_stiffness.append(j.stiffness)
+            jid = len(jnt_type) - 1
+            if j.type == JNT_FREE:
+                if body_parent[bi] != 0 or len(b.joints) != 1:
+                    raise ValueError("free joint only on a top-level body, alone")
+                qpos0 += [b.pos[0], b.pos[1], spec.free_root_z, *body_quat[bi]]
+                nq += 7
+                for _ in range(6):
+                    dof_bodyid.append(bi)
+                    dof_jntid.append(jid)
+                    dof_armature.append(j.armature)
+                    dof_damping.append(j.damping)
+                nv += 6
+            elif j.type in (JNT_HINGE, JNT_SLIDE):
+                qpos0.append(j.ref)
+                nq += 1
+                dof_bodyid.append(bi)
+                dof_jntid.append(jid)
+                dof_armature.append(j.armature)
+                dof_damping.append(j.damping)
+                nv += 1
+            else:
+                raise ValueError(f"unsupported joint type {j.type}")
+        body_dofnum[bi] = nv - (body_dofadr[bi] if body_dofadr[bi] >= 0 else nv)
+        for g in b.geoms:
+            size = list(g.size) + [0.0] * (3 - len(g.size))
+            geoms.append((g.type, bi, list(g.pos), list(_normalize(g.quat)), size, list(g.friction)))
+
+    njnt = len(jnt_type)
+    # dof_parentid: previous dof in the same body, else last dof of the nearest ancestor with dofs
+    dof_parentid = np.full(nv, -1, np.int32)
+    body_lastdof = np.full(nbody, -1, np.int32)
+    for bi in range(1, nbody):
+        last = body_lastdof[body_parent[bi]]
+        if body_dofnum[bi] > 0:
+            for d in range(body_dofadr[bi], body_dofadr[bi] + body_dofnum[bi]):
+                dof_parentid[d] = last
+                last = d
+        body_lastdof[bi] = last
+    body_rootid = np.zeros(nbody, np.int32)
+    for bi in range(1, nbody):
+        body_rootid[bi] = bi if body_parent[bi] == 0 else body_rootid[body_parent[bi]]
+    depth = np.zeros(nbody, np.int32)
+    for bi in range(1, nbody):
+        depth[bi] = depth[body_parent[bi]] + 1
+
+    # actuators (joint transmission on hinge/slide only)
+    nu = len(spec.actuators)
+    act_dofid = np.zeros(nu, np.int32)
+    act_qposadr = np.zeros(nu, np.int32)
+    act_gear = np.zeros(nu)
+    act_gain = np.zeros(nu)
+    act_bias = np.zeros((nu, 3))
+    act_ctrlrange = np.zeros((nu, 2))
+    act_ctrllimited = np.zeros(nu, np.int32)
+    act_forcerange = np.zeros((nu, 2))
+    act_forcelimited = np.zeros(nu, np.int32)
+    for ai, a in enumerate(spec.actuators):
+        jid = joint_names.index(a.joint)
+        if jnt_type[jid] == JNT_FREE:
+            raise ValueError("actuator on a free joint is not supported")
+        act_dofid[ai] = jnt_dofadr[jid]
+        act_qposadr[ai] = jnt_qposadr[jid]
+        act_gear[ai] = a.gear
+        if a.kp > 0:
+            act_gain[ai] = a.kp
+            act_bias[ai] = [0.0, -a.kp, -a.kv]
+        else:
+            act_gain[ai] = 1.0
+        if a.ctrlrange is not None:
+            act_ctrlrange[ai] = a.ctrlrange
+            act_ctrllimited[ai] = 1
+        if a.forcerange is not None:
+            act_forcerange[ai] = a.forcerange
+            act_forcelimited[ai] = 1
+
+    # collision candidates: every sphere / capsule end against the ground plane
+    con_bodyid, con_lpos, con_radius, con_friction = [], [], [], []
+    for (gt, bi, gpos, gquat, gsize, gfri) in geoms:
+        fri = np.maximum(np.asarray(gfri), np.asarray(spec.plane_friction))
+        if gt == GEOM_SPHERE:
+            ends = [np.asarray(gpos, dtype=np.float64)]
+        elif gt == GEOM_CAPSULE:
+            axis = _qrot(gquat, [0, 0, 1.0]) * gsize[1]
+            ends = [np.asarray(gpos) + axis, np.asarray(gpos) - axis]
+        else:
+            raise ValueError(f"unsupported geom type {gt}")
+        for e in ends:
+            con_bodyid.append(bi)
+            con_lpos.append(list(e))
+            con_radius.append(gsize[0])
+            con_friction.append(list(fri))
+    ncon = len(con_bodyid)
+
+    lim_jnt = [j for j in range(njnt) if jnt_limited[j] and jnt_type[j] != JNT_FREE]
+    nlimit = len(lim_jnt)
+
+    t: Dict[str, np.ndarray] = {}
+
+    def put(k, v, dt=np.float64):
+        t[k] = np.asarray(v, dtype=dt)
+
+    for k, v in dict(nq=nq, nv=nv, nu=nu, nbody=nbody, njnt=njnt, ncon=ncon, nlimit=nlimit,
+                     iterations=spec.iterations, ls_iterations=spec.ls_iterations).items():
+        put(k, v, np.int32)
+    for k, v in dict(timestep=spec.timestep, tolerance=spec.tolerance, ls_tolerance=spec.ls_tolerance,
+                     impratio=spec.impratio, plane_z=spec.plane_z).items():
+        put(k, v)
+    put("gravity", spec.gravity)
+    put("body_parent", body_parent, np.int32)
+    put("body_rootid", body_rootid, np.int32)
+    put("body_depth", depth, np.int32)
+    put("body_pos", body_pos)
+    put("body_quat", body_quat)
+    put("body_ipos", body_ipos)
+    put("body_iquat", body_iquat)
+    put("body_mass", body_mass)
+    put("body_inertia", body_inertia)
+    put("body_jntadr", body_jntadr, np.int32)
+    put("body_jntnum", body_jntnum, np.int32)
+    put("body_dofadr", body_dofadr, np.int32)
+    put("body_dofnum", body_dofnum, np.int32)
+    put("jnt_type", jnt_type, np.int32)
+    put("jnt_qposadr", jnt_qposadr, np.int32)
+    put("jnt_dofadr", jnt_dofadr, np.int32)
+    put("jnt_bodyid", jnt_bodyid, np.int32)
+    put("jnt_pos", np.reshape(jnt_pos, (njnt, 3)))
+    put("jnt_axis", np.reshape(jnt_axis, (njnt, 3)))
+    put("jnt_range", np.reshape(jnt_range, (njnt, 2)))
+    put("jnt_limited", jnt_limited, np.int32)
+    put("jnt_stiffness", jnt_stiffness)
+    put("dof_bodyid", dof_bodyid, np.int32)
+    put("dof_jntid", dof_jntid, np.int32)
+    put("dof_parentid", dof_parentid, np.int32)
+    put("dof_armature", dof_armature)
+    put("dof_damping", dof_damping)
+    put("qpos0", qpos0)
+    put("qpos_spring", qpos0)
+    put("act_dofid", act_dofid, np.int32)
+    put("act_qposadr", act_qposadr, np.int32)
+    put("act_gear", act_gear)
+    put("act_gain", act_gain)
+    put("act_bias", act_bias)
+    put("act_ctrlrange", act_ctrlrange)
+    put("act_ctrllimited", act_ctrllimited, np.int32)
+    put("act_forcerange", act_forcerange)
+    put("act_forcelimited", act_forcelimited, np.int32)
+    put("con_bodyid", con_bodyid, np.int32)
+    put("con_lpos", np.reshape(con_lpos, (ncon, 3)))
+    put("con_radius", con_radius)
+    put("con_friction", np.reshape(con_friction, (ncon, 3)))
+    put("lim_jntid", lim_jnt, np.int32)
+    put("contact_solref", spec.contact_solref)
+    put("contact_solimp", spec.contact_solimp)
+    put("limit_solref", spec.limit_solref)
+    put("limit_solimp", spec.limit_solimp)
+
+    cm = CompiledModel(spec.name, t, names, joint_names)
+    _set_const(cm)
+    return cm
+
+
+# ---------------------------------------------------------------------------
+# mj_setConst equivalent: M(qpos0) -> invweights, meaninertia      (float64)
+# ---------------------------------------------------------------------------
+
+
+def _forward_position0(cm: CompiledModel):
+    """Kinematics + com + CRB at qpos0 for one instance (host, float64)."""
+    t = cm.t
+    nb, nv = cm.nbody, cm.nv
+    q = t["qpos0"]
+    xpos = np.zeros((nb, 3))
+    xquat = np.tile(np.array([1.0, 0, 0, 0]), (nb, 1))
+    xanchor = np.zeros((cm.njnt, 3))
+    xaxis = np.zeros((cm.njnt, 3))
+    for b in range(1, nb):
+        p = t["body_parent"][b]
+        pos = xpos[p] + _qrot(xquat[p], t["body_pos"][b])
+        quat = _qmul(xquat[p], t["body_quat"][b])
+        for j in range(t["body_jntadr"][b], t["body_jntadr"][b] + t["body_jntnum"][b]):
+            qa = t["jnt_qposadr"][j]
+            if t["jnt_type"][j] == JNT_FREE:
+                pos = q[qa:qa + 3].copy()
+                quat = _normalize(q[qa + 3:qa + 7])
+                xanchor[j] = pos
+                xaxis[j] = _qrot(quat, t["jnt_axis"][j])
+            else:
+                xanchor[j] = pos + _qrot(quat, t["jnt_pos"][j])
+                xaxis[j] = _qrot(quat, t["jnt_axis"][j])
+                # qpos == qpos0 -> zero joint displacement
+        xpos[b], xquat[b] = pos, quat
+    xipos = np.array([xpos[b] + _qrot(xquat[b], t["body_ipos"][b]) for b in range(nb)])
+    ximat = np.array([_qmat(_qmul(xquat[b], t["body_iquat"][b])) for b in range(nb)])
+    # subtree com
+    mpos = xipos * t["body_mass"][:, None]
+    msum = t["body_mass"].copy()
+    for b in range(nb - 1, 0, -1):
+        p = t["body_parent"][b]
+        mpos[p] += mpos[b]
+        msum[p] += msum[b]
+    subtree_com = mpos / np.maximum(msum, MJ_MINVAL)[:, None]
+    cinert = np.zeros((nb, 10))
+    for b in range(1, nb):
+        off = xipos[b] - subtree_com[t["body_rootid"][b]]
+        m = t["body_mass"][b]
+        I = ximat[b] @ np.diag(t["body_inertia"][b]) @ ximat[b].T + m * (off @ off * np.eye(3) - np.outer(off, off))
+        cinert[b] = [I[0, 0], I[1, 1], I[2, 2], I[0, 1], I[0, 2], I[1, 2], *(m * off), m]
+    cdof = np.zeros((nv, 6))
+    for j in range(cm.njnt):
+        b = t["jnt_bodyid"][j]
+        da = t["jnt_dofadr"][j]
+        off = subtree_com[t["body_rootid"][b]] - xanchor[j]
+        if t["jnt_type"][j] == JNT_FREE:
+            R = _qmat(xquat[b])
+            for k in range(3):
+                cdof[da + k, 3 + k] = 1.0
+                ax = R[:, k]
+                cdof[da + 3 + k, :3] = ax
+                cdof[da + 3 + k, 3:] = np.cross(ax, off)
+        elif t["jnt_type"][j] == JNT_HINGE:
+            cdof[da, :3] = xaxis[j]
+            cdof[da, 3:] = np.cross(xaxis[j], off)
+        else:
+            cdof[da, 3:] = xaxis[j]
+    crb = cinert.copy()
+    for b in range(nb - 1, 0, -1):
+        crb[t["body_parent"][b]] += crb[b]
+    M = np.zeros((nv, nv))
+    for i in range(nv):
+        buf = _inert_mul(crb[t["dof_bodyid"][i]], cdof[i])
+        j = i
+        while j >= 0:
+            M[i, j] = M[j, i] = cdof[j] @ buf
+            j = t["dof_parentid"][j]
+        M[i, i] += t["dof_armature"][i]
+    return dict(xpos=xpos, xquat=xquat, xipos=xipos, subtree_com=subtree_com, cdof=cdof, M=M)
+
+
+def _inert_mul(i, v):
+    return np.array(
+        [
+            i[0] * v[0] + i[3] * v[1] + i[4] * v[2] - i[8] * v[4] + i[7] * v[5],
+            i[3] * v[0] + i[1] * v[1] + i[5] * v[2] + i[8] * v[3] - i[6] * v[5],
+            i[4] * v[0] + i[5] * v[1] + i[2] * v[2] - i[7] * v[3] + i[6] * v[4],
+            i[8] * v[1] - i[7] * v[2] + i[9] * v[3],
+            i[6] * v[2] - i[8] * v[0] + i[9] * v[4],
+            i[7] * v[0] - i[6] * v[1] + i[9] * v[5],
+        ]
+    )
+
+
+def _set_const(cm: CompiledModel) -> None:
+    t = cm.t
+    nv, nb = cm.nv, cm.nbody
+    f = _forward_position0(cm)
+    M = f["M"]
+    Minv = np.linalg.inv(M)
+    t["meaninertia"] = np.asarray(np.trace(M) / max(nv, 1))
+    dof_inv = np.diag(Minv).copy()
+    for j in range(cm.njnt):
+        if t["jnt_type"][j] == JNT_FREE:
+            da = t["jnt_dofadr"][j]
+            dof_inv[da:da + 3] = dof_inv[da:da + 3].mean()
+            dof_inv[da + 3:da + 6] = dof_inv[da + 3:da + 6].mean()
+    t["dof_invweight0"] = dof_inv
+    body_inv = np.zeros((nb, 2))
+    for b in range(1, nb):
+        jp = np.zeros((3, nv))
+        jr = np.zeros((3, nv))
+        off = f["xipos"][b] - f["subtree_com"][t["body_rootid"][b]]
+        d = t["body_dofadr"][b] + t["body_dofnum"][b] - 1 if t["body_dofnum"][b] > 0 else -1
+        if d < 0:  # walk up to the nearest ancestor with dofs
+            a = t["body_parent"][b]
+            while a > 0 and t["body_dofnum"][a] == 0:
+                a = t["body_parent"][a]
+            d = t["body_dofadr"][a] + t["body_dofnum"][a] - 1 if a > 0 else -1
+        while d >= 0:
+            jr[:, d] = f["cdof"][d, :3]
+            jp[:, d] = f["cdof"][d, 3:] + np.cross(f["cdof"][d, :3], off)
+            d = t["dof_parentid"][d]
+        body_inv[b, 0] = np.trace(jp @ Minv @ jp.T) / 3.0
+        body_inv[b, 1] = np.trace(jr @ Minv @ jr.T) / 3.0
+    t["body_invweight0"] = body_inv
+    t["M0"] = M
+
+
+# ---------------------------------------------------------------------------
+# device blob
+# ---------------------------------------------------------------------------
+
+# Order of the arrays in the blob.  (name, dtype) ; shapes follow from the header dims.
+_BLOB_INT = [
+    "body_parent", "body_rootid", "body_depth", "body_jntadr", "body_jntnum", "body_dofadr", "body_dofnum",
+    "jnt_type", "jnt_qposadr", "jnt_dofadr", "jnt_bodyid", "jnt_limited",
+    "dof_bodyid", "dof_jntid", "dof_parentid",
+    "act_dofid", "act_qposadr", "act_ctrllimited", "act_forcelimited",
+    "con_bodyid", "lim_jntid",
+]
+_BLOB_F32 = [
+    "gravity", "body_pos", "body_quat", "body_ipos", "body_iquat", "body_mass", "body_inertia",
+    "jnt_pos", "jnt_axis", "jnt_range", "jnt_stiffness",
+    "dof_armature", "dof_damping", "dof_invweight0", "body_invweight0",
+    "qpos0", "qpos_spring",
+    "act_gear", "act_gain", "act_bias", "act_ctrlrange", "act_forcerange",
+    "con_lpos", "con_radius", "con_friction",
+    "contact_solref", "contact_solimp", "limit_solref", "limit_solimp",
+]
+_HDR_INT = ["nq", "nv", "nu", "nbody", "njnt", "ncon", "nlimit", "iterations", "ls_iterations"]
+_HDR_F32 = ["timestep", "tolerance", "ls_tolerance", "impratio", "plane_z", "meaninertia"]
+BLOB_HEADER_WORDS = 64  # fixed-size header; array directory follows
+
+
+def _to_blob(cm: CompiledModel) -> bytes:
+    """Packs the model into one little-endian blob of 4-byte words.
+
+    word 0: magic, 1: version, 2: total words, 3..: header ints (see _HDR_INT),
+    words 16..: header floats (see _HDR_F32), words 32..63: reserved.
+    Then a directory of (offset_words, count) pairs for every array in
+    _BLOB_INT + _BLOB_F32 order, then the arrays (each padded to 4 words).
+    The C side (csrc/model_blob.h) mirrors this layout.
+    """
+    t = cm.t
+    names = _BLOB_INT + _BLOB_F32
+    ndir = len(names)
+    words: List[bytes] = []
+    dir_entries: List[Tuple[int, int]] = []
+    cursor = BLOB_HEADER_WORDS + 2 * ndir
+    cursor = (cursor + 3) // 4 * 4
+    base = cursor
+    payload = bytearray()
+    for k in names:
+        a = np.ascontiguousarray(t[k]).reshape(-1)
+        if k in _BLOB_INT:
+            raw = a.astype("<i4").tobytes()
+        else:
+            raw = a.astype("<f4").tobytes()
+        n = a.size
+        dir_entries.append((cursor, n))
+        pad = (-n) % 4
+        payload += raw + b"\0" * (4 * pad)
+        cursor += n + pad
+    total = cursor
+    hdr = bytearray(4 * BLOB_HEADER_WORDS)
+    struct.pack_into("<3I", hdr, 0, BLOB_MAGIC, BLOB_VERSION, total)
+    for i, k in enumerate(_HDR_INT):
+        struct.pack_into("<i", hdr, 4 * (3 + i), int(t[k]))
+    for i, k in enumerate(_HDR_F32):
+        struct.pack_into("<f", hdr, 4 * (16 + i), float(t[k]))
+    struct.pack_into("<i", hdr, 4 * 32, ndir)
+    d = bytearray()
+    for off, n in dir_entries:
+        d += struct.pack("<2i", off, n)
+    d += b"\0" * (4 * (base - BLOB_HEADER_WORDS - 2 * ndir))
+    blob = bytes(hdr) + bytes(d) + bytes(payload)
+    assert len(blob) == 4 * total, (len(blob), total)
+    return blob
+
+
+# ---------------------------------------------------------------------------
+# built-in stand-in robots
+# ---------------------------------------------------------------------------
+
+
+def _leg(side: str, y: float) -> List[BodySpec]:
+    s = side
+    return [
+        BodySpec(f"{s}_hip_yaw", "torso", pos=(0.0, y, -0.10), mass=0.8, inertia=(0.002, 0.002, 0.002),
+                 joints=[JointSpec(f"{s}_hip_yaw", JNT_HINGE, axis=(0, 0, 1), range=(-0.8, 0.8), damping=1.0, armature=0.02)]),
+        BodySpec(f"{s}_hip_roll", f"{s}_hip_yaw", pos=(0.0, 0.0, -0.05), mass=0.8, inertia=(0.002, 0.002, 0.002),
+                 joints=[JointSpec(f"{s}_hip_roll", JNT_HINGE, axis=(1, 0, 0), range=(-0.6, 0.6), damping=1.0, armature=0.02)]),
+        BodySpec(f"{s}_thigh", f"{s}_hip_roll", pos=(0.0, 0.0, -0.05), mass=3.0, inertia=(0.045, 0.045, 0.006),
+                 ipos=(0.0, 0.0, -0.18),
+                 joints=[JointSpec(f"{s}_hip_pitch", JNT_HINGE, axis=(0, 1, 0), range=(-1.6, 1.0), damping=1.5, armature=0.03)]),
+        BodySpec(f"{s}_shin", f"{s}_thigh", pos=(0.0, 0.0, -0.38), mass=2.0, inertia=(0.028, 0.028, 0.003),
+                 ipos=(0.0, 0.0, -0.17),
+                 joints=[JointSpec(f"{s}_knee", JNT_HINGE, axis=(0, 1, 0), range=(-0.1, 2.2), damping=1.5, armature=0.03)],
+                 geoms=[GeomSpec(GEOM_SPHERE, (0.05,), pos=(0.0, 0.0, 0.0))]),
+        BodySpec(f"{s}_foot", f"{s}_shin", pos=(0.0, 0.0, -0.36), mass=0.8, inertia=(0.001, 0.003, 0.003),
+                 ipos=(0.03, 0.0, -0.03),
+                 joints=[JointSpec(f"{s}_ankle", JNT_HINGE, axis=(0, 1, 0), range=(-0.9, 0.9), damping=0.8, armature=0.01)],
+                 geoms=[GeomSpec(GEOM_CAPSULE, (0.03, 0.08), pos=(0.03, 0.0, -0.04), quat=(0.70710678, 0.0, 0.70710678, 0.0))]),
+    ]
+
+
+def _arm(side: str, y: float) -> List[BodySpec]:
+    s = side
+    return [
+        BodySpec(f"{s}_shoulder_pitch", "torso", pos=(0.0, y, 0.32), mass=0.6, inertia=(0.001, 0.001, 0.001),
+                 joints=[JointSpec(f"{s}_shoulder_pitch", JNT_HINGE, axis=(0, 1, 0), range=(-2.0, 2.0), damping=0.6, armature=0.01)]),
+        BodySpec(f"{s}_shoulder_roll", f"{s}_shoulder_pitch", pos=(0.0, 0.0, -0.03), mass=0.6, inertia=(0.001, 0.001, 0.001),
+                 joints=[JointSpec(f"{s}_shoulder_roll", JNT_HINGE, axis=(1, 0, 0), range=(-1.5, 1.5), damping=0.6, armature=0.01)]),
+        BodySpec(f"{s}_upper_arm", f"{s}_shoulder_roll", pos=(0.0, 0.0, -0.03), mass=1.2, inertia=(0.008, 0.008, 0.001),
+                 ipos=(0.0, 0.0, -0.12),
+                 joints=[JointSpec(f"{s}_shoulder_yaw", JNT_HINGE, axis=(0, 0, 1), range=(-1.5, 1.5), damping=0.5, armature=0.01)]),
+        BodySpec(f"{s}_forearm", f"{s}_upper_arm", pos=(0.0, 0.0, -0.26), mass=0.9, inertia=(0.005, 0.005, 0.0008),
+                 ipos=(0.0, 0.0, -0.11),
+                 joints=[JointSpec(f"{s}_elbow", JNT_HINGE, axis=(0, 1, 0), range=(-2.2, 0.1), damping=0.5, armature=0.01)]),
+        BodySpec(f"{s}_hand", f"{s}_forearm", pos=(0.0, 0.0, -0.24), mass=0.4, inertia=(0.0005, 0.0005, 0.0003),
+                 ipos=(0.0, 0.0, -0.04),
+                 joints=[JointSpec(f"{s}_wrist", JNT_HINGE, axis=(0, 0, 1), range=(-1.5, 1.5), damping=0.3, armature=0.005)],
+                 geoms=[GeomSpec(GEOM_SPHERE, (0.04,), pos=(0.0, 0.0, -0.05))]),
+    ]
+
+
+def _humanoid(name: str, arms: bool) -> ModelSpec:
+    torso = BodySpec(
+        "torso", "world", pos=(0.0, 0.0, 0.0), mass=10.0 if not arms else 9.0, inertia=(0.12, 0.10, 0.06),
+        ipos=(0.0, 0.0, 0.12),
+        joints=[JointSpec("root", JNT_FREE)],
+        geoms=[GeomSpec(GEOM_SPHERE, (0.11,), pos=(0.0, 0.0, 0.05))],
+    )
+    bodies = [torso] + _leg("left", 0.09) + _leg("right", -0.09)
+    joints = [j.name for b in bodies[1:] for j in b.joints]
+    if arms:
+        arm_bodies = _arm("left", 0.19) + _arm("right", -0.19)
+        bodies += arm_bodies
+        joints += [j.name for b in arm_bodies for j in b.joints]
+    acts = []
+    for jn in joints:
+        leg = any(k in jn for k in ("hip", "knee", "ankle"))
+        acts.append(ActuatorSpec(jn, kp=60.0 if leg else 20.0, kv=0.0, ctrlrange=(-1.5, 1.5),
+                                 forcerange=(-80.0, 80.0) if leg else (-25.0, 25.0)))
+    # standing height: hip chain 0.10+0.05+0.05, thigh 0.38, shin 0.36, foot capsule centre 0.04 below ankle, r=0.03
+    root_z = 0.10 + 0.05 + 0.05 + 0.38 + 0.36 + 0.04 + 0.03 - 0.0005
+    return ModelSpec(name=name, bodies=bodies, actuators=acts, free_root_z=root_z)
+
+
+def synth_stompy_pro() -> ModelSpec:
+    """Stand-in for the stompy_pro MJCF (unobtainable on the target): free root + 2 legs x 5 hinges."""
+    return _humanoid("synth_stompy_pro", arms=False)
+
+
+def synth_stompy_full() -> ModelSpec:
+    """Stand-in with a larger action dimension (BASELINE config 5): + 2 arms x 5 hinges."""
+    return _humanoid("synth_stompy_full", arms=True)
+
+
+def synth_pendulum() -> ModelSpec:
+    """Two-link pendulum on a free-floating base-less world hinge; used by analytic physics tests."""
+    bodies = [
+        BodySpec("link1", "world", pos=(0.0, 0.0, 2.0), mass=1.0, inertia=(0.01, 0.01, 0.001), ipos=(0.0, 0.0, -0.25),
+                 joints=[JointSpec("j1", JNT_HINGE, axis=(0, 1, 0))]),
+        BodySpec("link2", "link1", pos=(0.0, 0.0, -0.5), mass=0.5, inertia=(0.004, 0.004, 0.0005), ipos=(0.0, 0.0, -0.2),
+                 joints=[JointSpec("j2", JNT_HINGE, axis=(0, 1, 0))]),
+    ]
+    return ModelSpec(name="synth_pendulum", bodies=bodies, actuators=[ActuatorSpec("j1"), ActuatorSpec("j2")])
+
+
+def synth_ball() -> ModelSpec:
+    """A single free sphere above the plane: free-fall and resting-contact analytic tests."""
+    bodies = [
+        BodySpec("ball", "world", mass=1.0, inertia=(0.004, 0.004, 0.004),
+                 joints=[JointSpec("root", JNT_FREE)], geoms=[GeomSpec(GEOM_SPHERE, (0.1,))]),
+    ]
+    return ModelSpec(name="synth_ball", bodies=bodies, actuators=[], free_root_z=0.5)
+
+
+KSCALE_ID_TABLE = {
+    "5eb3cb7f23232298": "synth_stompy_pro",  # reference configs/stompy_pro.yaml:1
+}
+
+BUILTIN_MODELS = {
+    "synth_stompy_pro": synth_stompy_pro,
+    "synth_stompy_full": synth_stompy_full,
+    "synth_pendulum": synth_pendulum,
+    "synth_ball": synth_ball,
+}
+
+_CACHE: Dict[str, CompiledModel] = {}
+
+
+def load_model(name_or_id: str) -> CompiledModel:
+    """Resolves a `kscale_id`, a built-in model name or an MJCF path to a CompiledModel.
+
+    Stands where the reference's `load_mjcf_model` + `mjcf.load_model` stand
+    (`minppo/env.py:27-50,94-100`)."""
+    key = KSCALE_ID_TABLE.get(name_or_id, name_or_id)
+    if key in _CACHE:
+        return _CACHE[key]
+    if key in BUILTIN_MODELS:
+        cm = compile_model(BUILTIN_MODELS[key]())
+    elif key.endswith(".xml"):
+        from minppo_amd.mjcf import load_mjcf  # MJCF subset compiler
+
+        cm = compile_model(load_mjcf(key))
+    else:
+        raise ValueError(
+            f"Unknown robot '{name_or_id}': not a built-in model ({sorted(BUILTIN_MODELS)}), "
+            f"not a known kscale_id ({sorted(KSCALE_ID_TABLE)}) and not an .xml path"
+        )
+    _CACHE[key] = cm
+    return cm

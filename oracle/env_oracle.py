@@ -1,0 +1,192 @@
+"""CPU oracle for `HumanoidEnv` and the rollout/update loop.       TEST INFRASTRUCTURE.
+
+PARITY UNPINNED (see ppo_oracle.py / physics_oracle.py headers).
+
+Restates reference `minppo/env.py:115-261` (reset, step with auto-reset,
+reward, termination, observation, episode metrics) on top of the physics
+oracle, and `minppo/train.py:146-289` (one `_update_step`: rollout scan,
+bootstrap value, GAE, epochs of shuffled minibatches) on top of the PPO
+oracle.  Random inputs (action noise, permutations) are explicit arguments:
+"identical inputs" parity.
+
+Batched over environments ([N, ...]); dtype-generic.
+"""
+
+from __future__ import annotations
+
+from typing import Dict, NamedTuple, Optional
+
+import numpy as np
+
+from . import ppo_oracle as po
+from .physics_oracle import Physics, PhysState
+
+# fields of the pipeline state that the env reads after a step; `select(done, reset, stepped)`
+# (env.py:179) acts on every leaf, these are the ones that can influence later results
+CARRIED = ("qpos", "qvel", "qacc_warmstart", "time", "cinert", "cvel", "qfrc_actuator", "subtree_com")
+# fields inspected by the NaN guard (env.py:173-176): any NaN anywhere in the stepped state
+NAN_CHECKED = CARRIED + ("qacc", "xpos", "xquat", "qfrc_constraint")
+
+
+class RewardCfg(NamedTuple):
+    """Subset of reference RewardConfig that `compute_reward`/`is_done` read (config.py:36-48)."""
+
+    height_min_z: float = -0.2
+    height_max_z: float = 2.0
+    original_pos_reward_exp_coefficient: float = 2.0
+    original_pos_reward_subtraction_factor: float = 0.2
+    original_pos_reward_max_diff_norm: float = 0.5
+    weights_ctrl_cost: float = 0.1
+    weights_original_pos_reward: float = 4.0
+    weights_is_healthy: float = 1.0
+    weights_velocity: float = 1.25
+
+
+class EnvOracle:
+    def __init__(self, tables: Dict[str, np.ndarray], reward: RewardCfg = RewardCfg(), include_c_vals: bool = True,
+                 n_frames: int = 1, dtype=np.float64):
+        self.ph = Physics(tables, dtype, n_frames)
+        self.rc = reward
+        self.include_c_vals = include_c_vals
+        self.dtype = np.dtype(dtype)
+        self.initial_qpos = self.ph.t["qpos0"].astype(dtype)
+        self.dt = self.ph.dt
+        self.action_size = self.ph.nu
+        self._reset1: Optional[PhysState] = None
+
+    # env.py:245-261
+    def get_obs(self, s: PhysState) -> np.ndarray:
+        N = s.qpos.shape[0]
+        if self.include_c_vals:
+            parts = [s.qpos, s.qvel, s.cinert[:, 1:].reshape(N, -1), s.cvel[:, 1:].reshape(N, -1), s.qfrc_actuator]
+        else:
+            parts = [s.qpos, s.qvel, s.qfrc_actuator]
+        return np.concatenate(parts, -1)
+
+    @property
+    def observation_size(self) -> int:
+        ph = self.ph
+        return ph.nq + ph.nv + (16 * (ph.nbody - 1) if self.include_c_vals else 0) + ph.nv
+
+    # env.py:115-121 with reset_noise_scale = 0.0 (env.py:87): a constant state
+    def _get_reset_state(self, N: int) -> PhysState:
+        if self._reset1 is None:
+            self._reset1 = self.ph.pipeline_init(self.initial_qpos[None], np.zeros((1, self.ph.nv), self.dtype))
+        r = self._reset1
+        return PhysState({k: (np.repeat(v, N, 0) if isinstance(v, np.ndarray) and v.shape[:1] == (1,) else v) for k, v in r.items()})
+
+    # env.py:124-145
+    def reset(self, N: int) -> dict:
+        s = self._get_reset_state(N)
+        return dict(pipeline_state=s, obs=self.get_obs(s), reward=np.zeros(N, self.dtype), done=np.zeros(N, bool),
+                    metrics=dict(episode_returns=np.zeros(N, self.dtype), episode_lengths=np.zeros(N, np.int32),
+                                 returned_episode_returns=np.zeros(N, self.dtype),
+                                 returned_episode_lengths=np.zeros(N, np.int32), timestep=np.zeros(N, np.int32),
+                                 returned_episode=np.zeros(N, bool)))
+
+    # env.py:199-235
+    def compute_reward(self, s: PhysState, s2: PhysState, action) -> np.ndarray:
+        rc, dt = self.rc, self.dtype
+        p0 = np.linalg.norm(self.initial_qpos[None] - s.qpos, axis=-1)
+        pos_r = np.exp(-dt.type(rc.original_pos_reward_exp_coefficient) * p0) - dt.type(rc.original_pos_reward_subtraction_factor) * np.clip(
+            p0, 0, rc.original_pos_reward_max_diff_norm)
+        z = s.qpos[:, 2]
+        healthy = np.where(z < rc.height_min_z, 0.0, 1.0)
+        healthy = np.where(z > rc.height_max_z, 0.0, healthy).astype(dt)
+        ctrl_cost = -np.sum(action * action, -1)
+        vel = (s2.subtree_com[:, 1, 0] - s.subtree_com[:, 1, 0]) / dt.type(self.dt)
+        return (dt.type(rc.weights_ctrl_cost) * ctrl_cost + dt.type(rc.weights_original_pos_reward) * pos_r
+                + dt.type(rc.weights_velocity) * vel + dt.type(rc.weights_is_healthy) * healthy).astype(dt)
+
+    # env.py:238-242
+    def is_done(self, s: PhysState) -> np.ndarray:
+        z = s.qpos[:, 2]
+        return ~((self.rc.height_min_z < z) & (z < self.rc.height_max_z))
+
+    # env.py:148-196
+    def step(self, es: dict, action) -> dict:
+        s = es["pipeline_state"]
+        N = action.shape[0]
+        s2 = self.ph.pipeline_step(s, action)
+        obs_state = self.get_obs(s)  # PRE-step state (env.py:163, quirk C-5)
+        s_reset = self._get_reset_state(N)
+        obs_reset = self.get_obs(s_reset)
+        reward = self.compute_reward(s, s2, action)
+        done = self.is_done(s2)
+        nan = np.zeros(N, bool)
+        for k in NAN_CHECKED:
+            if k in s2:
+                nan |= np.isnan(np.asarray(s2[k]).reshape(N, -1)).any(-1)
+        done = done | nan
+        new_state = PhysState()
+        for k, v in s2.items():
+            if isinstance(v, np.ndarray) and v.shape[:1] == (N,) and k in s_reset:
+                m = done.reshape((N,) + (1,) * (v.ndim - 1))
+                new_state[k] = np.where(m, s_reset[k], v)
+            else:
+                new_state[k] = v
+        obs = np.where(done[:, None], obs_reset, obs_state)
+        m = es["metrics"]
+        nd_f = (1 - done.astype(np.int32)).astype(self.dtype)
+        nd_i = 1 - done.astype(np.int32)
+        new_ret = m["episode_returns"] + reward
+        new_len = m["episode_lengths"] + 1
+        metrics = dict(
+            episode_returns=new_ret * nd_f,
+            episode_lengths=new_len * nd_i,
+            returned_episode_returns=m["returned_episode_returns"] * nd_f + new_ret * done,
+            returned_episode_lengths=m["returned_episode_lengths"] * nd_i + new_len * done,
+            timestep=m["timestep"] + 1,
+            returned_episode=done,
+        )
+        return dict(pipeline_state=new_state, obs=obs, reward=reward, done=done, metrics=metrics)
+
+
+# ---------------------------------------------------------------------------
+# one `_update_step` (train.py:146-283)
+# ---------------------------------------------------------------------------
+
+
+def rollout(env: EnvOracle, named_params, es: dict, last_obs, noise, use_tanh=True):
+    """train.py:150-179: T policy/env steps. noise [T,N,A] ~ N(0,1). Returns (es, last_obs, traj)."""
+    T = noise.shape[0]
+    keys = ("done", "action", "value", "reward", "log_prob", "obs")
+    traj = {k: [] for k in keys}
+    info = []
+    for t in range(T):
+        mean, log_std, value = po.actor_critic_forward(named_params, last_obs, use_tanh)
+        action = po.mvn_sample(mean, log_std, noise[t])
+        logp = po.mvn_log_prob(action, mean, log_std)
+        es = env.step(es, action)
+        for k, v in zip(keys, (es["done"], action, value, es["reward"], logp, last_obs)):
+            traj[k].append(v)
+        info.append(es["metrics"])
+        last_obs = es["obs"]
+    traj = {k: np.stack(v) for k, v in traj.items()}
+    traj["info"] = {k: np.stack([i[k] for i in info]) for k in info[0]}
+    return es, last_obs, traj
+
+
+def update_step(env: EnvOracle, flat_p, opt: po.OptState, es: dict, last_obs, noise, perms, *, O, A, H,
+                num_minibatches, hp: dict, use_tanh=True):
+    """One full PPO update. Returns (flat_p, opt, es, last_obs, traj, adv, targets, losses)."""
+    named = po.flat_to_named(flat_p, O, A, H)
+    es, last_obs, traj = rollout(env, named, es, last_obs, noise, use_tanh)
+    _, _, last_val = po.actor_critic_forward(named, last_obs, use_tanh)  # train.py:182
+    adv, tgt = po.calculate_gae(traj["done"], traj["value"], traj["reward"], last_val, hp["gamma"], hp["gae_lambda"])
+    flat_p, opt, losses = po.update_epochs_on_batch(flat_p, opt, traj, adv, tgt, perms, O=O, A=A, H=H,
+                                                    num_minibatches=num_minibatches, hp=hp, use_tanh=use_tanh)
+    return flat_p, opt, es, last_obs, traj, adv, tgt, losses
+
+
+def default_hp(cfg=None, *, num_envs=None) -> dict:
+    """Hyper-parameters in the flat form the oracle uses, from a minppo_amd Config (or reference defaults)."""
+    if cfg is None:
+        hp = dict(gamma=0.99, gae_lambda=0.95, clip_eps=0.2, vf_coef=0.5, ent_coef=0.0, max_grad_norm=0.5,
+                  anneal_lr=True, lr_train=3e-4, lr_opt=3e-4, update_epochs=4, num_updates=48828)
+        return hp
+    n = cfg.training.num_envs if num_envs is None else num_envs
+    return dict(gamma=cfg.rl.gamma, gae_lambda=cfg.rl.gae_lambda, clip_eps=cfg.rl.clip_eps, vf_coef=cfg.rl.vf_coef,
+                ent_coef=cfg.rl.ent_coef, max_grad_norm=cfg.opt.max_grad_norm, anneal_lr=cfg.training.anneal_lr,
+                lr_train=cfg.training.lr, lr_opt=cfg.opt.lr, update_epochs=cfg.training.update_epochs,
+                num_updates=cfg.training.total_timesteps // cfg.training.num_steps // n)

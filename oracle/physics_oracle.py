@@ -1,0 +1,632 @@
+"""CPU oracle for the rigid-body step behind `pipeline_step` / `pipeline_init`.   TEST INFRASTRUCTURE.
+
+PARITY UNPINNED.  The reference calls `brax.envs.base.PipelineEnv.pipeline_step`
+(`minppo/env.py:162`) and `pipeline_init` (`env.py:120`), i.e. `mujoco.mjx.step`
+/ `mjx.forward` with solver=CG, 6 iterations, 6 line-search iterations
+(`env.py:95-97`).  Brax, MuJoCo and MJX are third-party, un-pinned
+(`requirements.txt:8-13`; likely brax 0.10-0.11 / mujoco 3.2.x on 2024-10-16),
+absent from /root/reference and not installable here.  This file restates the
+*published* MuJoCo/MJX algorithm for the model class the engine supports
+(free / hinge / slide joints, sphere & capsule geoms against one ground plane,
+joint limits, pyramidal friction cones, affine-bias actuators on joints):
+
+  fwd_position : kinematics, com_pos (subtree_com, cinert, cdof), crb (dense M),
+                 collision (plane-sphere, plane-capsule), make_constraint
+  fwd_velocity : com_vel (cvel, cdof_dot), passive, rne (qfrc_bias)
+  fwd_actuation, fwd_acceleration
+  solve        : CG with Polak-Ribiere, M^-1 preconditioner, exact 1-D Newton
+                 line search with bracketing (MJX solver.py structure)
+  euler        : implicit joint damping, semi-implicit integration
+
+It is validated by physical invariants and analytic cases
+(tests/test_oracle_physics.py) and pins the HIP kernel through the committed
+fixtures in tests/golden/.  Agreement with MJX itself was never measured.
+
+All arrays are batched over environments: shape [N, ...].  dtype-generic
+(float64 for the reference answer, float32 to mimic working precision).
+"""
+
+from __future__ import annotations
+
+from typing import Dict, NamedTuple
+
+import numpy as np
+
+JNT_FREE, JNT_HINGE, JNT_SLIDE = 0, 2, 3
+MJ_MINVAL = 1e-15
+MJ_MINIMP = 0.0001
+MJ_MAXIMP = 0.9999
+
+
+# ---------------------------------------------------------------------------
+# batched quaternion / vector helpers
+# ---------------------------------------------------------------------------
+
+
+def qmul(a, b):
+    aw, ax, ay, az = a[..., 0], a[..., 1], a[..., 2], a[..., 3]
+    bw, bx, by, bz = b[..., 0], b[..., 1], b[..., 2], b[..., 3]
+    return np.stack(
+        [
+            aw * bw - ax * bx - ay * by - az * bz,
+            aw * bx + ax * bw + ay * bz - az * by,
+            aw * by - ax * bz + ay * bw + az * bx,
+            aw * bz + ax * by - ay * bx + az * bw,
+        ],
+        -1,
+    )
+
+
+def qmat(q):
+    w, x, y, z = q[..., 0], q[..., 1], q[..., 2], q[..., 3]
+    r = np.stack(
+        [
+            w * w + x * x - y * y - z * z, 2 * (x * y - w * z), 2 * (x * z + w * y),
+            2 * (x * y + w * z), w * w - x * x + y * y - z * z, 2 * (y * z - w * x),
+            2 * (x * z - w * y), 2 * (y * z + w * x), w * w - x * x - y * y + z * z,
+        ],
+        -1,
+    )
+    return r.reshape(q.shape[:-1] + (3, 3))
+
+
+def qrot(q, v):
+    return np.einsum("...ij,...j->...i", qmat(q), v)
+
+
+def safe_normalize(v):
+    n = np.linalg.norm(v, axis=-1, keepdims=True)
+    return v / np.where(n > 0, n, 1.0)
+
+
+def axis_angle_quat(axis, angle):
+    s = np.sin(angle * 0.5)[..., None]
+    c = np.cos(angle * 0.5)[..., None]
+    return np.concatenate([c, axis * s], -1)
+
+
+def quat_integrate(q, w, dt):
+    """MuJoCo mju_quatIntegrate: q <- normalize(q * exp(w*dt)), w in the local frame."""
+    n = np.linalg.norm(w, axis=-1)
+    ax = w / np.where(n > 0, n, 1.0)[..., None]
+    dq = axis_angle_quat(ax, n * dt)
+    return safe_normalize(qmul(q, dq))
+
+
+def inert_mul(i, v):
+    """cinert (10) times spatial motion (6) -> spatial force (6)   (mju_mulInertVec)."""
+    return np.stack(
+        [
+            i[..., 0] * v[..., 0] + i[..., 3] * v[..., 1] + i[..., 4] * v[..., 2] - i[..., 8] * v[..., 4] + i[..., 7] * v[..., 5],
+            i[..., 3] * v[..., 0] + i[..., 1] * v[..., 1] + i[..., 5] * v[..., 2] + i[..., 8] * v[..., 3] - i[..., 6] * v[..., 5],
+            i[..., 4] * v[..., 0] + i[..., 5] * v[..., 1] + i[..., 2] * v[..., 2] - i[..., 7] * v[..., 3] + i[..., 6] * v[..., 4],
+            i[..., 8] * v[..., 1] - i[..., 7] * v[..., 2] + i[..., 9] * v[..., 3],
+            i[..., 6] * v[..., 2] - i[..., 8] * v[..., 0] + i[..., 9] * v[..., 4],
+            i[..., 7] * v[..., 0] - i[..., 6] * v[..., 1] + i[..., 9] * v[..., 5],
+        ],
+        -1,
+    )
+
+
+def cross_motion(vel, v):
+    """mju_crossMotion: spatial motion cross product vel x v."""
+    w, l = vel[..., :3], vel[..., 3:]
+    return np.concatenate([np.cross(w, v[..., :3]), np.cross(w, v[..., 3:]) + np.cross(l, v[..., :3])], -1)
+
+
+def cross_force(vel, f):
+    """mju_crossForce: spatial force cross product vel x* f."""
+    w, l = vel[..., :3], vel[..., 3:]
+    return np.concatenate([np.cross(w, f[..., :3]) + np.cross(l, f[..., 3:]), np.cross(w, f[..., 3:])], -1)
+
+
+def make_frame(a):
+    """MJX math.make_frame: orthonormal frame whose first row is `a`."""
+    a = safe_normalize(a)
+    y = np.zeros_like(a); y[..., 1] = 1
+    z = np.zeros_like(a); z[..., 2] = 1
+    b = np.where(((-0.5 < a[..., 1]) & (a[..., 1] < 0.5))[..., None], y, z)
+    b = b - a * np.sum(a * b, -1, keepdims=True)
+    b = safe_normalize(b)
+    return np.stack([a, b, np.cross(a, b)], -2)
+
+
+# ---------------------------------------------------------------------------
+# data container
+# ---------------------------------------------------------------------------
+
+
+class PhysState(dict):
+    """Batched MJX-`Data`-like record; keys are MuJoCo field names. dict for easy select()."""
+
+    __getattr__ = dict.__getitem__
+
+    def copy(self):  # shallow per-array copy
+        return PhysState({k: (v.copy() if isinstance(v, np.ndarray) else v) for k, v in self.items()})
+
+
+STATE_FIELDS = ("qpos", "qvel", "qacc_warmstart", "time",
+                "cinert", "cvel", "qfrc_actuator", "subtree_com", "qacc", "xpos", "xquat")
+
+
+class Physics:
+    """Batched pipeline for one compiled model (tables from minppo_amd.model.CompiledModel.t)."""
+
+    def __init__(self, tables: Dict[str, np.ndarray], dtype=np.float64, n_frames: int = 1):
+        self.t = t = {k: (np.asarray(v, dtype) if np.asarray(v).dtype.kind == "f" else np.asarray(v)) for k, v in tables.items()}
+        self.dtype = np.dtype(dtype)
+        self.nq, self.nv, self.nu = int(t["nq"]), int(t["nv"]), int(t["nu"])
+        self.nbody, self.njnt = int(t["nbody"]), int(t["njnt"])
+        self.ncon, self.nlimit = int(t["ncon"]), int(t["nlimit"])
+        self.nefc = self.nlimit + 4 * self.ncon
+        self.n_frames = n_frames
+        self.timestep = float(t["timestep"])
+        self.dt = self.timestep * n_frames
+        # ancestor-dof lists per body (last dof chain)
+        self.body_lastdof = np.full(self.nbody, -1, np.int64)
+        for b in range(1, self.nbody):
+            p = t["body_parent"][b]
+            self.body_lastdof[b] = (t["body_dofadr"][b] + t["body_dofnum"][b] - 1) if t["body_dofnum"][b] > 0 else self.body_lastdof[p]
+        # qpos index of each hinge/slide dof, -1 for free-joint dofs (for passive springs / limits)
+        self.dof_qposadr = np.full(self.nv, -1, np.int64)
+        for j in range(self.njnt):
+            if t["jnt_type"][j] != JNT_FREE:
+                self.dof_qposadr[t["jnt_dofadr"][j]] = t["jnt_qposadr"][j]
+
+    # -- fwd_position ---------------------------------------------------------
+    def kinematics(self, d: PhysState) -> None:
+        t, nb = self.t, self.nbody
+        N = d.qpos.shape[0]
+        dt = self.dtype
+        xpos = np.zeros((N, nb, 3), dt)
+        xquat = np.zeros((N, nb, 4), dt); xquat[..., 0] = 1
+        xanchor = np.zeros((N, self.njnt, 3), dt)
+        xaxis = np.zeros((N, self.njnt, 3), dt)
+        for b in range(1, nb):
+            p = t["body_parent"][b]
+            pos = xpos[:, p] + qrot(xquat[:, p], t["body_pos"][b])
+            quat = qmul(xquat[:, p], np.broadcast_to(t["body_quat"][b], (N, 4)))
+            for j in range(t["body_jntadr"][b], t["body_jntadr"][b] + t["body_jntnum"][b]):
+                qa = t["jnt_qposadr"][j]
+                jt = t["jnt_type"][j]
+                if jt == JNT_FREE:
+                    pos = d.qpos[:, qa:qa + 3].copy()
+                    quat = safe_normalize(d.qpos[:, qa + 3:qa + 7])
+                    xanchor[:, j] = pos
+                    xaxis[:, j] = qrot(quat, t["jnt_axis"][j])
+                else:
+                    anchor = pos + qrot(quat, t["jnt_pos"][j])
+                    axis = qrot(quat, t["jnt_axis"][j])
+                    xanchor[:, j], xaxis[:, j] = anchor, axis
+                    disp = d.qpos[:, qa] - t["qpos0"][qa]
+                    if jt == JNT_HINGE:
+                        qloc = axis_angle_quat(np.broadcast_to(t["jnt_axis"][j], (N, 3)), disp)
+                        quat = qmul(quat, qloc)
+                        pos = anchor - qrot(quat, t["jnt_pos"][j])  # re-anchor
+                    else:  # slide
+                        pos = pos + axis * disp[:, None]
+            xpos[:, b], xquat[:, b] = pos, safe_normalize(quat)
+        d["xpos"], d["xquat"], d["xanchor"], d["xaxis"] = xpos, xquat, xanchor, xaxis
+        d["xmat"] = qmat(xquat)
+        d["xipos"] = xpos + qrot(xquat, t["body_ipos"][None])
+        d["ximat"] = qmat(qmul(xquat, np.broadcast_to(t["body_iquat"][None], xquat.shape)))
+
+    def com_pos(self, d: PhysState) -> None:
+        t, nb, nv = self.t, self.nbody, self.nv
+        N = d.qpos.shape[0]
+        dt = self.dtype
+        mass = t["body_mass"]
+        mpos = d.xipos * mass[None, :, None]
+        msum = np.broadcast_to(mass, (N, nb)).copy()
+        for b in range(nb - 1, 0, -1):
+            p = t["body_parent"][b]
+            mpos[:, p] += mpos[:, b]
+            msum[:, p] += msum[:, b]
+        d["subtree_com"] = mpos / np.maximum(msum, MJ_MINVAL)[..., None]
+        root_com = d.subtree_com[:, t["body_rootid"]]
+        off = d.xipos - root_com
+        I = np.einsum("nbij,bj,nbkj->nbik", d.ximat, t["body_inertia"], d.ximat)
+        oo = np.sum(off * off, -1)
+        I = I + mass[None, :, None, None] * (oo[..., None, None] * np.eye(3, dtype=dt) - off[..., :, None] * off[..., None, :])
+        cinert = np.zeros((N, nb, 10), dt)
+        cinert[..., 0], cinert[..., 1], cinert[..., 2] = I[..., 0, 0], I[..., 1, 1], I[..., 2, 2]
+        cinert[..., 3], cinert[..., 4], cinert[..., 5] = I[..., 0, 1], I[..., 0, 2], I[..., 1, 2]
+        cinert[..., 6:9] = off * mass[None, :, None]
+        cinert[..., 9] = mass[None]
+        cinert[:, 0] = 0
+        d["cinert"] = cinert
+        cdof = np.zeros((N, nv, 6), dt)
+        for j in range(self.njnt):
+            b = t["jnt_bodyid"][j]
+            da = t["jnt_dofadr"][j]
+            offj = d.subtree_com[:, t["body_rootid"][b]] - d.xanchor[:, j]
+            jt = t["jnt_type"][j]
+            if jt == JNT_FREE:
+                for k in range(3):
+                    cdof[:, da + k, 3 + k] = 1
+                    ax = d.xmat[:, b, :, k]
+                    cdof[:, da + 3 + k, :3] = ax
+                    cdof[:, da + 3 + k, 3:] = np.cross(ax, offj)
+            elif jt == JNT_HINGE:
+                cdof[:, da, :3] = d.xaxis[:, j]
+                cdof[:, da, 3:] = np.cross(d.xaxis[:, j], offj)
+            else:
+                cdof[:, da, 3:] = d.xaxis[:, j]
+        d["cdof"] = cdof
+
+    def crb(self, d: PhysState) -> None:
+        t, nb, nv = self.t, self.nbody, self.nv
+        N = d.qpos.shape[0]
+        crb = d.cinert.copy()
+        for b in range(nb - 1, 0, -1):
+            crb[:, t["body_parent"][b]] += crb[:, b]
+        M = np.zeros((N, nv, nv), self.dtype)
+        for i in range(nv):
+            buf = inert_mul(crb[:, t["dof_bodyid"][i]], d.cdof[:, i])
+            j = i
+            while j >= 0:
+                v = np.sum(d.cdof[:, j] * buf, -1)
+                M[:, i, j] = v
+                M[:, j, i] = v
+                j = t["dof_parentid"][j]
+            M[:, i, i] += t["dof_armature"][i]
+        d["qM"] = M
+        d["qLD"] = np.linalg.cholesky(M)
+
+    def solve_m(self, d: PhysState, x):
+        L = d.qLD
+        y = np.linalg.solve(L, x[..., None])
+        return np.linalg.solve(np.swapaxes(L, -1, -2), y)[..., 0]
+
+    def jacp(self, d: PhysState, point, body: int):
+        """Translational Jacobian [N,3,nv] of a world point attached to `body` (mj_jac)."""
+        t = self.t
+        N = point.shape[0]
+        J = np.zeros((N, 3, self.nv), self.dtype)
+        off = point - d.subtree_com[:, t["body_rootid"][body]]
+        dof = self.body_lastdof[body]
+        while dof >= 0:
+            J[:, :, dof] = d.cdof[:, dof, 3:] + np.cross(d.cdof[:, dof, :3], off)
+            dof = t["dof_parentid"][dof]
+        return J
+
+    def collision(self, d: PhysState) -> None:
+        """Plane-sphere / plane-capsule-end contacts: every candidate keeps a slot (MJX static shapes)."""
+        t = self.t
+        N = d.qpos.shape[0]
+        nc = self.ncon
+        dist = np.zeros((N, nc), self.dtype)
+        cpos = np.zeros((N, nc, 3), self.dtype)
+        n = np.array([0.0, 0.0, 1.0], self.dtype)
+        for c in range(nc):
+            b = t["con_bodyid"][c]
+            centre = d.xpos[:, b] + qrot(d.xquat[:, b], t["con_lpos"][c])
+            r = t["con_radius"][c]
+            dist[:, c] = centre[:, 2] - t["plane_z"] - r
+            cpos[:, c] = centre - n * (r + 0.5 * dist[:, c])[:, None]
+        d["con_dist"], d["con_pos"] = dist, cpos
+        d["con_frame"] = np.broadcast_to(make_frame(n[None])[0], (N, nc, 3, 3))
+
+    def _kbi(self, solref, solimp, pos):
+        dt = self.dtype
+        timeconst = max(float(solref[0]), 2 * self.timestep)  # refsafe
+        dampratio = float(solref[1])
+        dmin, dmax, width, mid, power = [float(x) for x in solimp]
+        dmin = min(max(dmin, MJ_MINIMP), MJ_MAXIMP)
+        dmax = min(max(dmax, MJ_MINIMP), MJ_MAXIMP)
+        width = max(MJ_MINVAL, width)
+        mid = min(max(mid, MJ_MINIMP), MJ_MAXIMP)
+        power = max(1.0, power)
+        k = 1.0 / (dmax * dmax * timeconst * timeconst * dampratio * dampratio)
+        b = 2.0 / (dmax * timeconst)
+        if solref[0] <= 0:
+            k = -float(solref[0]) / (dmax * dmax)
+        if solref[1] <= 0:
+            b = -float(solref[1]) / dmax
+        imp_x = np.abs(pos) / dt.type(width)
+        imp_a = dt.type(1.0 / mid ** (power - 1)) * imp_x ** power
+        imp_b = 1 - dt.type(1.0 / (1 - mid) ** (power - 1)) * np.abs(1 - imp_x) ** power
+        imp_y = np.where(imp_x < mid, imp_a, imp_b)
+        imp = dmin + imp_y * (dmax - dmin)
+        imp = np.clip(imp, dmin, dmax)
+        imp = np.where(imp_x > 1.0, dmax, imp).astype(dt)
+        return dt.type(k), dt.type(b), imp
+
+    def make_constraint(self, d: PhysState) -> None:
+        """Rows: joint limits (1 each) then contacts (4 pyramid edges each). Inactive rows are zeroed."""
+        t, nv = self.t, self.nv
+        N = d.qpos.shape[0]
+        dt = self.dtype
+        J = np.zeros((N, self.nefc, nv), dt)
+        pos = np.zeros((N, self.nefc), dt)
+        invw = np.zeros((N, self.nefc), dt)
+        act = np.zeros((N, self.nefc), bool)
+        row = 0
+        for jid in t["lim_jntid"]:
+            qa, da = t["jnt_qposadr"][jid], t["jnt_dofadr"][jid]
+            dmin = d.qpos[:, qa] - t["jnt_range"][jid, 0]
+            dmax = t["jnt_range"][jid, 1] - d.qpos[:, qa]
+            p = np.minimum(dmin, dmax)
+            a = p < 0
+            J[:, row, da] = np.where(a, np.where(dmin < dmax, 1.0, -1.0), 0.0)
+            pos[:, row] = np.where(a, p, 0.0)
+            invw[:, row] = np.where(a, t["dof_invweight0"][da], 0.0)
+            act[:, row] = a
+            row += 1
+        k_l, b_l, imp_l = self._kbi(t["limit_solref"], t["limit_solimp"], pos[:, :self.nlimit])
+        for c in range(self.ncon):
+            b = t["con_bodyid"][c]
+            a = d.con_dist[:, c] < 0
+            jp = self.jacp(d, d.con_pos[:, c], b)  # [N,3,nv]   (body1 = world -> zero)
+            jc = np.einsum("nij,njv->niv", d.con_frame[:, c], jp)  # rows: normal, t1, t2
+            fri = t["con_friction"][c]
+            tw = t["body_invweight0"][b, 0]
+            iw = (tw + fri[0] * fri[0] * tw) * 2 * fri[0] * fri[0] / t["impratio"]
+            r = row
+            for k in (1, 2):
+                for s in (1.0, -1.0):
+                    J[:, r] = np.where(a[:, None], jc[:, 0] + jc[:, k] * (s * fri[0]), 0.0)  # condim 3: both tangents use the sliding coefficient
+                    pos[:, r] = np.where(a, d.con_dist[:, c], 0.0)
+                    invw[:, r] = np.where(a, iw, 0.0)
+                    act[:, r] = a
+                    r += 1
+            row += 4
+        k_c, b_c, imp_c = self._kbi(t["contact_solref"], t["contact_solimp"], pos[:, self.nlimit:])
+        imp = np.concatenate([imp_l, imp_c], 1)
+        kk = np.concatenate([np.full((N, self.nlimit), k_l, dt), np.full((N, 4 * self.ncon), k_c, dt)], 1)
+        bb = np.concatenate([np.full((N, self.nlimit), b_l, dt), np.full((N, 4 * self.ncon), b_c, dt)], 1)
+        R = np.maximum(invw * (1 - imp) / imp, MJ_MINVAL)
+        jv = np.einsum("nrv,nv->nr", J, d.qvel)
+        d["efc_J"] = J
+        d["efc_D"] = np.where(act, 1.0 / R, 0.0).astype(dt)  # inactive rows are inert (J=0, aref=0)
+        d["efc_aref"] = (-bb * jv - kk * imp * pos).astype(dt)
+        d["efc_active_row"] = act
+
+    # -- fwd_velocity -----------------------------------------------------------
+    def com_vel(self, d: PhysState) -> None:
+        t, nb, nv = self.t, self.nbody, self.nv
+        N = d.qpos.shape[0]
+        cvel = np.zeros((N, nb, 6), self.dtype)
+        cdof_dot = np.zeros((N, nv, 6), self.dtype)
+        for b in range(1, nb):
+            v = cvel[:, t["body_parent"][b]].copy()
+            for j in range(t["body_jntadr"][b], t["body_jntadr"][b] + t["body_jntnum"][b]):
+                da = t["jnt_dofadr"][j]
+                if t["jnt_type"][j] == JNT_FREE:
+                    for k in range(3):  # translational dofs: cdof_dot = 0
+                        v = v + d.cdof[:, da + k] * d.qvel[:, da + k, None]
+                    for k in range(3, 6):
+                        cdof_dot[:, da + k] = cross_motion(v, d.cdof[:, da + k])
+                    for k in range(3, 6):
+                        v = v + d.cdof[:, da + k] * d.qvel[:, da + k, None]
+                else:
+                    cdof_dot[:, da] = cross_motion(v, d.cdof[:, da])
+                    v = v + d.cdof[:, da] * d.qvel[:, da, None]
+            cvel[:, b] = v
+        d["cvel"], d["cdof_dot"] = cvel, cdof_dot
+
+    def passive(self, d: PhysState) -> None:
+        t = self.t
+        f = -t["dof_damping"][None] * d.qvel
+        for dof in range(self.nv):
+            qa = self.dof_qposadr[dof]
+            if qa >= 0:
+                stiff = t["jnt_stiffness"][t["dof_jntid"][dof]]
+                if stiff != 0:
+                    f[:, dof] -= stiff * (d.qpos[:, qa] - t["qpos_spring"][qa])
+        d["qfrc_passive"] = f
+
+    def rne(self, d: PhysState) -> None:
+        t, nb, nv = self.t, self.nbody, self.nv
+        N = d.qpos.shape[0]
+        cacc = np.zeros((N, nb, 6), self.dtype)
+        cacc[:, 0, 3:] = -t["gravity"]
+        for b in range(1, nb):
+            a = cacc[:, t["body_parent"][b]].copy()
+            for k in range(t["body_dofadr"][b], t["body_dofadr"][b] + t["body_dofnum"][b]):
+                a = a + d.cdof_dot[:, k] * d.qvel[:, k, None]
+            cacc[:, b] = a
+        cfrc = inert_mul(d.cinert, cacc) + cross_force(d.cvel, inert_mul(d.cinert, d.cvel))
+        cfrc[:, 0] = 0
+        for b in range(nb - 1, 0, -1):
+            cfrc[:, t["body_parent"][b]] += cfrc[:, b]
+        d["qfrc_bias"] = np.sum(d.cdof * cfrc[:, t["dof_bodyid"]], -1)
+
+    # -- actuation / acceleration -------------------------------------------------
+    def fwd_actuation(self, d: PhysState) -> None:
+        t = self.t
+        N = d.qpos.shape[0]
+        qfrc = np.zeros((N, self.nv), self.dtype)
+        if self.nu:
+            ctrl = d.ctrl
+            lim = t["act_ctrllimited"].astype(bool)
+            ctrl = np.where(lim[None], np.clip(ctrl, t["act_ctrlrange"][:, 0], t["act_ctrlrange"][:, 1]), ctrl)
+            length = t["act_gear"][None] * d.qpos[:, t["act_qposadr"]]
+            velocity = t["act_gear"][None] * d.qvel[:, t["act_dofid"]]
+            force = t["act_gain"][None] * ctrl + t["act_bias"][None, :, 0] + t["act_bias"][None, :, 1] * length + t["act_bias"][None, :, 2] * velocity
+            flim = t["act_forcelimited"].astype(bool)
+            force = np.where(flim[None], np.clip(force, t["act_forcerange"][:, 0], t["act_forcerange"][:, 1]), force)
+            np.add.at(qfrc, (slice(None), t["act_dofid"]), force * t["act_gear"][None])
+            d["actuator_force"] = force
+        d["qfrc_actuator"] = qfrc.astype(self.dtype)
+
+    def fwd_acceleration(self, d: PhysState) -> None:
+        d["qfrc_smooth"] = d.qfrc_passive - d.qfrc_bias + d.qfrc_actuator
+        d["qacc_smooth"] = self.solve_m(d, d.qfrc_smooth)
+
+    # -- constraint solver (MJX solver.py structure) -------------------------------
+    def _ctx_update_constraint(self, d, c):
+        active = c["Jaref"] < 0
+        c["active"] = active
+        c["efc_force"] = d.efc_D * -c["Jaref"] * active
+        c["qfrc_constraint"] = np.einsum("nrv,nr->nv", d.efc_J, c["efc_force"])
+        c["gauss"] = 0.5 * np.sum((c["Ma"] - d.qfrc_smooth) * (c["qacc"] - d.qacc_smooth), -1)
+        c["prev_cost"] = c["cost"]
+        c["cost"] = 0.5 * np.sum(d.efc_D * c["Jaref"] * c["Jaref"] * active, -1) + c["gauss"]
+
+    def _ctx_update_gradient(self, d, c):
+        c["grad"] = c["Ma"] - d.qfrc_smooth - c["qfrc_constraint"]
+        c["Mgrad"] = self.solve_m(d, c["grad"])
+
+    def _ctx_create(self, d, qacc, grad=True):
+        N = qacc.shape[0]
+        c = {
+            "qacc": qacc.copy(),
+            "Jaref": np.einsum("nrv,nv->nr", d.efc_J, qacc) - d.efc_aref,
+            "Ma": np.einsum("nij,nj->ni", d.qM, qacc),
+            "cost": np.full(N, np.inf, self.dtype),
+        }
+        self._ctx_update_constraint(d, c)
+        if grad:
+            self._ctx_update_gradient(d, c)
+            c["search"] = -c["Mgrad"]
+        return c
+
+    def _ls_point(self, alpha, jaref, jv, quad, quad_gauss):
+        x = jaref + alpha[:, None] * jv
+        active = x < 0
+        q = np.sum(quad * active[:, None, :], -1) + quad_gauss  # [N,3]
+        cost = alpha * alpha * q[:, 2] + alpha * q[:, 1] + q[:, 0]
+        d0 = 2 * alpha * q[:, 2] + q[:, 1]
+        d1 = 2 * q[:, 2] + (q[:, 2] == 0) * MJ_MINVAL
+        return {"alpha": alpha, "cost": cost, "d0": d0, "d1": d1}
+
+    def _linesearch(self, d, c, run):
+        t = self.t
+        dt = self.dtype
+        scale = float(t["meaninertia"]) * max(1, self.nv)
+        smag = np.linalg.norm(c["search"], axis=-1) * scale
+        gtol = float(t["tolerance"]) * float(t["ls_tolerance"]) * smag
+        mv = np.einsum("nij,nj->ni", d.qM, c["search"])
+        jv = np.einsum("nrv,nv->nr", d.efc_J, c["search"])
+        quad_gauss = np.stack([c["gauss"], np.sum(c["search"] * c["Ma"], -1) - np.sum(c["search"] * d.qfrc_smooth, -1),
+                               0.5 * np.sum(c["search"] * mv, -1)], -1)
+        quad = np.stack([0.5 * c["Jaref"] * c["Jaref"], jv * c["Jaref"], 0.5 * jv * jv], 1) * d.efc_D[:, None, :]
+        pf = lambda a: self._ls_point(a, c["Jaref"], jv, quad, quad_gauss)
+        N = smag.shape[0]
+        p0 = pf(np.zeros(N, dt))
+        lo = pf(p0["alpha"] - p0["d0"] / p0["d1"])
+        lesser = lo["d0"] < p0["d0"]
+        sel = lambda m, a, b: {k: np.where(m, a[k], b[k]) for k in a}
+        hi = sel(lesser, p0, lo)
+        lo = sel(lesser, lo, p0)
+        swap = np.ones(N, bool)
+        ls_iter = np.zeros(N, np.int64)
+        in_br = lambda x, y: ((x["d0"] < y["d0"]) & (y["d0"] < 0)) | ((x["d0"] > y["d0"]) & (y["d0"] > 0))
+        while True:
+            done = (ls_iter >= int(t["ls_iterations"])) | ~swap | ((lo["d0"] < 0) & (lo["d0"] > -gtol)) | ((hi["d0"] > 0) & (hi["d0"] < gtol))
+            go = ~done & run
+            if not go.any():
+                break
+            with np.errstate(all="ignore"):
+                lo_next = pf(lo["alpha"] - lo["d0"] / lo["d1"])
+                hi_next = pf(hi["alpha"] - hi["d0"] / hi["d1"])
+                mid = pf(0.5 * (lo["alpha"] + hi["alpha"]))
+            nlo, nhi = lo, hi
+            s1 = in_br(nlo, lo_next); nlo = sel(s1, lo_next, nlo)
+            s2 = in_br(nlo, mid); nlo = sel(s2, mid, nlo)
+            s3 = in_br(nlo, hi_next); nlo = sel(s3, hi_next, nlo)
+            s4 = in_br(nhi, hi_next); nhi = sel(s4, hi_next, nhi)
+            s5 = in_br(nhi, mid); nhi = sel(s5, mid, nhi)
+            s6 = in_br(nhi, lo_next); nhi = sel(s6, lo_next, nhi)
+            lo = sel(go, nlo, lo)
+            hi = sel(go, nhi, hi)
+            swap = np.where(go, s1 | s2 | s3 | s4 | s5 | s6, swap)
+            ls_iter = ls_iter + go
+        improved = (lo["cost"] < p0["cost"]) | (hi["cost"] < p0["cost"])
+        alpha = np.where(lo["cost"] < hi["cost"], lo["alpha"], hi["alpha"])
+        step = (improved & run) * alpha
+        c["qacc"] = c["qacc"] + step[:, None] * c["search"]
+        c["Ma"] = c["Ma"] + step[:, None] * mv
+        c["Jaref"] = c["Jaref"] + step[:, None] * jv
+
+    def solve(self, d: PhysState) -> None:
+        t = self.t
+        N = d.qpos.shape[0]
+        if self.nefc == 0:
+            d["qacc"] = d.qacc_smooth.copy()
+            d["qfrc_constraint"] = np.zeros_like(d.qacc)
+            d["qacc_warmstart"] = d.qacc.copy()
+            d["solver_niter"] = np.zeros(N, np.int64)
+            return
+        warm = self._ctx_create(d, d.qacc_warmstart, grad=False)
+        smth = self._ctx_create(d, d.qacc_smooth, grad=False)
+        qacc = np.where((warm["cost"] < smth["cost"])[:, None], d.qacc_warmstart, d.qacc_smooth)
+        c = self._ctx_create(d, qacc)
+        scale = float(t["meaninertia"]) * max(1, self.nv)
+        tol = float(t["tolerance"])
+        niter = np.zeros(N, np.int64)
+        while True:
+            improvement = (c["prev_cost"] - c["cost"]) / scale
+            gradient = np.linalg.norm(c["grad"], axis=-1) / scale
+            done = (niter >= int(t["iterations"])) | (improvement < tol) | (gradient < tol)
+            run = ~done
+            if not run.any():
+                break
+            old = {k: c[k].copy() for k in ("qacc", "Ma", "Jaref", "grad", "Mgrad", "search", "cost", "prev_cost",
+                                            "gauss", "efc_force", "qfrc_constraint", "active")}
+            self._linesearch(d, c, run)
+            prev_grad, prev_Mgrad = c["grad"], c["Mgrad"]
+            self._ctx_update_constraint(d, c)
+            self._ctx_update_gradient(d, c)
+            beta = np.sum(c["grad"] * (c["Mgrad"] - prev_Mgrad), -1) / np.maximum(MJ_MINVAL, np.sum(prev_grad * prev_Mgrad, -1))
+            beta = np.maximum(0, beta)
+            c["search"] = -c["Mgrad"] + beta[:, None] * c["search"]
+            for k, v in old.items():  # envs that already terminated keep their state (vmapped while_loop)
+                m = run.reshape((N,) + (1,) * (v.ndim - 1))
+                c[k] = np.where(m, c[k], v)
+            niter = niter + run
+        d["qacc"] = c["qacc"]
+        d["qacc_warmstart"] = c["qacc"].copy()
+        d["qfrc_constraint"] = c["qfrc_constraint"]
+        d["efc_force"] = c["efc_force"]
+        d["solver_niter"] = niter
+
+    # -- integrator --------------------------------------------------------------
+    def euler(self, d: PhysState) -> None:
+        t = self.t
+        h = self.dtype.type(self.timestep)
+        qacc = d.qacc
+        if np.any(t["dof_damping"] > 0):
+            dh = d.qM + h * np.eye(self.nv, dtype=self.dtype)[None] * t["dof_damping"][None, :, None]
+            qacc = np.linalg.solve(dh, (d.qfrc_smooth + d.qfrc_constraint)[..., None])[..., 0]
+        qvel = d.qvel + qacc * h
+        qpos = d.qpos.copy()
+        for j in range(self.njnt):
+            qa, da = t["jnt_qposadr"][j], t["jnt_dofadr"][j]
+            if t["jnt_type"][j] == JNT_FREE:
+                qpos[:, qa:qa + 3] = d.qpos[:, qa:qa + 3] + h * qvel[:, da:da + 3]
+                qpos[:, qa + 3:qa + 7] = quat_integrate(d.qpos[:, qa + 3:qa + 7], qvel[:, da + 3:da + 6], h)
+            else:
+                qpos[:, qa] = d.qpos[:, qa] + h * qvel[:, da]
+        d["qpos"], d["qvel"] = qpos.astype(self.dtype), qvel.astype(self.dtype)
+        d["time"] = d.time + h
+
+    # -- public: mjx.forward / mjx.step / brax pipeline_init / pipeline_step ---------
+    def forward(self, d: PhysState) -> None:
+        self.kinematics(d); self.com_pos(d); self.crb(d); self.collision(d); self.make_constraint(d)
+        self.com_vel(d); self.passive(d); self.rne(d)
+        self.fwd_actuation(d); self.fwd_acceleration(d)
+        self.solve(d)
+
+    def make_data(self, N: int) -> PhysState:
+        dt = self.dtype
+        return PhysState(qpos=np.tile(self.t["qpos0"], (N, 1)).astype(dt), qvel=np.zeros((N, self.nv), dt),
+                         ctrl=np.zeros((N, self.nu), dt), qacc_warmstart=np.zeros((N, self.nv), dt),
+                         time=np.zeros(N, dt))
+
+    def pipeline_init(self, qpos, qvel) -> PhysState:
+        """brax.mjx.pipeline.init: make_data, set qpos/qvel (ctrl = 0), mjx.forward."""
+        d = self.make_data(qpos.shape[0])
+        d["qpos"], d["qvel"] = qpos.astype(self.dtype).copy(), qvel.astype(self.dtype).copy()
+        self.forward(d)
+        return d
+
+    def pipeline_step(self, d: PhysState, action) -> PhysState:
+        """brax.mjx.pipeline.step x n_frames: ctrl <- action; mjx.step = forward + euler."""
+        d = d.copy()
+        d["ctrl"] = action.astype(self.dtype)
+        for _ in range(self.n_frames):
+            self.forward(d)
+            self.euler(d)
+        return d
