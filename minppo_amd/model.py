@@ -632,19 +632,19 @@ def _leg(side: str, y: float) -> List[BodySpec]:
     s = side
     return [
         BodySpec(f"{s}_hip_yaw", "torso", pos=(0.0, y, -0.10), mass=0.8, inertia=(0.002, 0.002, 0.002),
-                 joints=[JointSpec(f"{s}_hip_yaw", JNT_HINGE, axis=(0, 0, 1), range=(-0.8, 0.8), damping=1.0, armature=0.02)]),
+                 joints=[JointSpec(f"{s}_hip_yaw", JNT_HINGE, axis=(0, 0, 1), range=(-0.8, 0.8), damping=2.0, armature=0.1)]),
         BodySpec(f"{s}_hip_roll", f"{s}_hip_yaw", pos=(0.0, 0.0, -0.05), mass=0.8, inertia=(0.002, 0.002, 0.002),
-                 joints=[JointSpec(f"{s}_hip_roll", JNT_HINGE, axis=(1, 0, 0), range=(-0.6, 0.6), damping=1.0, armature=0.02)]),
+                 joints=[JointSpec(f"{s}_hip_roll", JNT_HINGE, axis=(1, 0, 0), range=(-0.6, 0.6), damping=2.0, armature=0.1)]),
         BodySpec(f"{s}_thigh", f"{s}_hip_roll", pos=(0.0, 0.0, -0.05), mass=3.0, inertia=(0.045, 0.045, 0.006),
                  ipos=(0.0, 0.0, -0.18),
-                 joints=[JointSpec(f"{s}_hip_pitch", JNT_HINGE, axis=(0, 1, 0), range=(-1.6, 1.0), damping=1.5, armature=0.03)]),
+                 joints=[JointSpec(f"{s}_hip_pitch", JNT_HINGE, axis=(0, 1, 0), range=(-1.6, 1.0), damping=2.0, armature=0.1)]),
         BodySpec(f"{s}_shin", f"{s}_thigh", pos=(0.0, 0.0, -0.38), mass=2.0, inertia=(0.028, 0.028, 0.003),
                  ipos=(0.0, 0.0, -0.17),
-                 joints=[JointSpec(f"{s}_knee", JNT_HINGE, axis=(0, 1, 0), range=(-0.1, 2.2), damping=1.5, armature=0.03)],
+                 joints=[JointSpec(f"{s}_knee", JNT_HINGE, axis=(0, 1, 0), range=(-0.1, 2.2), damping=2.0, armature=0.1)],
                  geoms=[GeomSpec(GEOM_SPHERE, (0.05,), pos=(0.0, 0.0, 0.0))]),
-        BodySpec(f"{s}_foot", f"{s}_shin", pos=(0.0, 0.0, -0.36), mass=0.8, inertia=(0.001, 0.003, 0.003),
+        BodySpec(f"{s}_foot", f"{s}_shin", pos=(0.0, 0.0, -0.36), mass=1.2, inertia=(0.004, 0.008, 0.008),
                  ipos=(0.03, 0.0, -0.03),
-                 joints=[JointSpec(f"{s}_ankle", JNT_HINGE, axis=(0, 1, 0), range=(-0.9, 0.9), damping=0.8, armature=0.01)],
+                 joints=[JointSpec(f"{s}_ankle", JNT_HINGE, axis=(0, 1, 0), range=(-0.9, 0.9), damping=2.0, armature=0.1)],
                  geoms=[GeomSpec(GEOM_CAPSULE, (0.03, 0.08), pos=(0.03, 0.0, -0.04), quat=(0.70710678, 0.0, 0.70710678, 0.0))]),
     ]
 
@@ -653,18 +653,18 @@ def _arm(side: str, y: float) -> List[BodySpec]:
     s = side
     return [
         BodySpec(f"{s}_shoulder_pitch", "torso", pos=(0.0, y, 0.32), mass=0.6, inertia=(0.001, 0.001, 0.001),
-                 joints=[JointSpec(f"{s}_shoulder_pitch", JNT_HINGE, axis=(0, 1, 0), range=(-2.0, 2.0), damping=0.6, armature=0.01)]),
+                 joints=[JointSpec(f"{s}_shoulder_pitch", JNT_HINGE, axis=(0, 1, 0), range=(-2.0, 2.0), damping=1.0, armature=0.05)]),
         BodySpec(f"{s}_shoulder_roll", f"{s}_shoulder_pitch", pos=(0.0, 0.0, -0.03), mass=0.6, inertia=(0.001, 0.001, 0.001),
-                 joints=[JointSpec(f"{s}_shoulder_roll", JNT_HINGE, axis=(1, 0, 0), range=(-1.5, 1.5), damping=0.6, armature=0.01)]),
+                 joints=[JointSpec(f"{s}_shoulder_roll", JNT_HINGE, axis=(1, 0, 0), range=(-1.5, 1.5), damping=1.0, armature=0.05)]),
         BodySpec(f"{s}_upper_arm", f"{s}_shoulder_roll", pos=(0.0, 0.0, -0.03), mass=1.2, inertia=(0.008, 0.008, 0.001),
                  ipos=(0.0, 0.0, -0.12),
-                 joints=[JointSpec(f"{s}_shoulder_yaw", JNT_HINGE, axis=(0, 0, 1), range=(-1.5, 1.5), damping=0.5, armature=0.01)]),
+                 joints=[JointSpec(f"{s}_shoulder_yaw", JNT_HINGE, axis=(0, 0, 1), range=(-1.5, 1.5), damping=1.0, armature=0.05)]),
         BodySpec(f"{s}_forearm", f"{s}_upper_arm", pos=(0.0, 0.0, -0.26), mass=0.9, inertia=(0.005, 0.005, 0.0008),
                  ipos=(0.0, 0.0, -0.11),
-                 joints=[JointSpec(f"{s}_elbow", JNT_HINGE, axis=(0, 1, 0), range=(-2.2, 0.1), damping=0.5, armature=0.01)]),
+                 joints=[JointSpec(f"{s}_elbow", JNT_HINGE, axis=(0, 1, 0), range=(-2.2, 0.1), damping=1.0, armature=0.05)]),
         BodySpec(f"{s}_hand", f"{s}_forearm", pos=(0.0, 0.0, -0.24), mass=0.4, inertia=(0.0005, 0.0005, 0.0003),
                  ipos=(0.0, 0.0, -0.04),
-                 joints=[JointSpec(f"{s}_wrist", JNT_HINGE, axis=(0, 0, 1), range=(-1.5, 1.5), damping=0.3, armature=0.005)],
+                 joints=[JointSpec(f"{s}_wrist", JNT_HINGE, axis=(0, 0, 1), range=(-1.5, 1.5), damping=0.5, armature=0.02)],
                  geoms=[GeomSpec(GEOM_SPHERE, (0.04,), pos=(0.0, 0.0, -0.05))]),
     ]
 
@@ -685,8 +685,8 @@ def _humanoid(name: str, arms: bool) -> ModelSpec:
     acts = []
     for jn in joints:
         leg = any(k in jn for k in ("hip", "knee", "ankle"))
-        acts.append(ActuatorSpec(jn, kp=60.0 if leg else 20.0, kv=0.0, ctrlrange=(-1.5, 1.5),
-                                 forcerange=(-80.0, 80.0) if leg else (-25.0, 25.0)))
+        acts.append(ActuatorSpec(jn, kp=40.0 if leg else 15.0, kv=0.0, ctrlrange=(-1.5, 1.5),
+                                 forcerange=(-60.0, 60.0) if leg else (-20.0, 20.0)))
     # standing height: hip chain 0.10+0.05+0.05, thigh 0.38, shin 0.36, foot capsule centre 0.04 below ankle, r=0.03
     root_z = 0.10 + 0.05 + 0.05 + 0.38 + 0.36 + 0.04 + 0.03 - 0.0005
     return ModelSpec(name=name, bodies=bodies, actuators=acts, free_root_z=root_z)

@@ -1,0 +1,246 @@
+"""Pins the physics + env oracle by physical invariants and analytic cases.
+
+MJX / MuJoCo / the stompy_pro MJCF are unobtainable here, so these are the anchors: closed-form
+trajectories, energy / momentum identities that tie kinematics, CRB, RNE and the Jacobians together,
+and solver properties.  Env-wrapper behaviour follows reference `minppo/env.py:148-261`."""
+
+import numpy as np
+import pytest
+
+from minppo_amd.model import load_model
+from oracle.env_oracle import EnvOracle, RewardCfg
+from oracle.physics_oracle import Physics, PhysState, qrot, quat_integrate
+
+
+def _rand_state(m, ph, N, rng, scale=0.3):
+    qpos = np.tile(m.t["qpos0"], (N, 1))
+    qvel = scale * rng.standard_normal((N, ph.nv))
+    for j in range(ph.njnt):
+        qa = m.t["jnt_qposadr"][j]
+        if m.t["jnt_type"][j] == 0:
+            qpos[:, qa:qa + 3] += 0.1 * rng.standard_normal((N, 3))
+            q = qpos[:, qa + 3:qa + 7] + 0.3 * rng.standard_normal((N, 4))
+            qpos[:, qa + 3:qa + 7] = q / np.linalg.norm(q, axis=-1, keepdims=True)
+        else:
+            qpos[:, qa] += scale * rng.standard_normal(N)
+    return qpos, qvel
+
+
+def _integrate_q(m, ph, qpos, qvel, h):
+    out = qpos.copy()
+    for j in range(ph.njnt):
+        qa, da = m.t["jnt_qposadr"][j], m.t["jnt_dofadr"][j]
+        if m.t["jnt_type"][j] == 0:
+            out[:, qa:qa + 3] += h * qvel[:, da:da + 3]
+            out[:, qa + 3:qa + 7] = quat_integrate(qpos[:, qa + 3:qa + 7], qvel[:, da + 3:da + 6], h)
+        else:
+            out[:, qa] += h * qvel[:, da]
+    return out
+
+
+def _kin(ph, qpos):
+    d = PhysState(qpos=qpos, qvel=np.zeros((qpos.shape[0], ph.nv)))
+    ph.kinematics(d); ph.com_pos(d)
+    return d
+
+
+def test_free_fall_and_rest():
+    m = load_model("synth_ball"); ph = Physics(m.t)
+    d = ph.pipeline_init(m.t["qpos0"][None], np.zeros((1, 6)))
+    np.testing.assert_allclose(d.qacc[0], [0, 0, -9.81, 0, 0, 0], atol=1e-12)
+    for _ in range(100):
+        d = ph.pipeline_step(d, np.zeros((1, 0)))
+    h = 0.002
+    assert d.qpos[0, 2] == pytest.approx(0.5 - 9.81 * h * h * (100 * 101 / 2), abs=1e-12)  # semi-implicit Euler
+    for _ in range(600):
+        d = ph.pipeline_step(d, np.zeros((1, 0)))
+    assert 0.095 < d.qpos[0, 2] < 0.1001 and abs(d.qvel[0, 2]) < 1e-6  # rests on the plane, tiny penetration
+    assert np.all(d.efc_force >= 0)
+
+
+@pytest.mark.parametrize("name", ["synth_stompy_pro", "synth_pendulum"])
+def test_mass_matrix_is_kinetic_energy(name):
+    """0.5 v'Mv == sum_b 0.5 m|v_com|^2 + 0.5 w'Iw with body velocities from finite-differenced kinematics."""
+    m = load_model(name); ph = Physics(m.t)
+    rng = np.random.default_rng(0)
+    N = 6
+    qpos, qvel = _rand_state(m, ph, N, rng)
+    d = PhysState(qpos=qpos, qvel=qvel); ph.kinematics(d); ph.com_pos(d); ph.crb(d)
+    M = d.qM
+    np.testing.assert_allclose(M, np.swapaxes(M, 1, 2), atol=1e-14)
+    assert np.linalg.eigvalsh(M).min() > 0
+    arm = 0.5 * np.sum(m.t["dof_armature"][None] * qvel * qvel, -1)
+    ke_m = 0.5 * np.einsum("ni,nij,nj->n", qvel, M, qvel) - arm
+    eps = 1e-6
+    dp = _kin(ph, _integrate_q(m, ph, qpos, qvel, eps)); dm = _kin(ph, _integrate_q(m, ph, qpos, qvel, -eps))
+    vcom = (dp.xipos - dm.xipos) / (2 * eps)
+    Rdot = (dp.ximat - dm.ximat) / (2 * eps)
+    W = np.einsum("nbij,nbkj->nbik", Rdot, d.ximat)  # [w]x = Rdot R^T
+    w = np.stack([W[..., 2, 1], W[..., 0, 2], W[..., 1, 0]], -1)
+    wl = np.einsum("nbji,nbj->nbi", d.ximat, w)  # to the inertial frame
+    ke = 0.5 * np.sum(m.t["body_mass"][None] * np.sum(vcom * vcom, -1), -1) + 0.5 * np.sum(m.t["body_inertia"][None] * wl * wl, (-1, -2))
+    np.testing.assert_allclose(ke_m, ke, rtol=1e-7)
+
+
+@pytest.mark.parametrize("name", ["synth_stompy_pro", "synth_pendulum"])
+def test_bias_force_is_potential_gradient_at_rest(name):
+    """At qvel = 0, qfrc_bias = dV/dq with V = sum m g z (ties kinematics, cdof and RNE together)."""
+    m = load_model(name); ph = Physics(m.t)
+    rng = np.random.default_rng(1)
+    qpos, _ = _rand_state(m, ph, 3, rng)
+    zero = np.zeros((3, ph.nv))
+    d = PhysState(qpos=qpos, qvel=zero); ph.kinematics(d); ph.com_pos(d); ph.com_vel(d); ph.rne(d)
+
+    def V(q):
+        k = _kin(ph, q)
+        return 9.81 * np.sum(m.t["body_mass"][None] * k.xipos[..., 2], -1)
+
+    eps = 1e-6
+    for dof in range(ph.nv):
+        e = zero.copy(); e[:, dof] = 1
+        g = (V(_integrate_q(m, ph, qpos, e, eps)) - V(_integrate_q(m, ph, qpos, e, -eps))) / (2 * eps)
+        np.testing.assert_allclose(d.qfrc_bias[:, dof], g, rtol=1e-6, atol=1e-7, err_msg=f"dof {dof}")
+
+
+def test_forward_dynamics_residual_and_energy():
+    """M qacc_smooth = passive - bias + actuator; undamped pendulum conserves energy to O(h)."""
+    m = load_model("synth_pendulum"); ph = Physics(m.t)
+    qpos = np.array([[0.7, -0.4]]); qvel = np.array([[0.3, -0.2]])
+    d = ph.pipeline_init(qpos, qvel)
+    res = np.einsum("nij,nj->ni", d.qM, d.qacc_smooth) - (d.qfrc_passive - d.qfrc_bias + d.qfrc_actuator)
+    assert np.abs(res).max() < 1e-12
+
+    def energy(d):
+        k = _kin(ph, d.qpos)
+        ph.crb(k)
+        return 0.5 * np.einsum("ni,nij,nj->n", d.qvel, k.qM, d.qvel) + 9.81 * np.sum(m.t["body_mass"][None] * k.xipos[..., 2], -1)
+
+    e0 = energy(d)
+    for _ in range(500):
+        d = ph.pipeline_step(d, np.zeros((1, 2)))
+    assert abs(energy(d) - e0)[0] < 2e-2 * abs(e0[0])
+
+
+def test_contact_jacobian_and_solver_properties():
+    m = load_model("synth_stompy_pro"); ph = Physics(m.t)
+    rng = np.random.default_rng(2)
+    N = 5
+    qpos, qvel = _rand_state(m, ph, N, rng, 0.2)
+    qpos[:, 2] -= 0.05  # push the feet into the ground
+    d = ph.pipeline_init(qpos, qvel)
+    assert d.efc_active_row.any()
+    # normal-row Jacobian (mean of the +/- pyramid pair) times qvel == d(dist)/dt by finite differences
+    eps = 1e-6
+    def dist(q):
+        k = _kin(ph, q); ph.collision(k); return k.con_dist
+    ddist = (dist(_integrate_q(m, ph, qpos, qvel, eps)) - dist(_integrate_q(m, ph, qpos, qvel, -eps))) / (2 * eps)
+    for c in range(ph.ncon):
+        r = ph.nlimit + 4 * c
+        jn = 0.5 * (d.efc_J[:, r] + d.efc_J[:, r + 1])
+        act = d.con_dist[:, c] < 0
+        np.testing.assert_allclose((jn @ np.zeros(ph.nv) + np.sum(jn * qvel, -1))[act], ddist[act, c], rtol=1e-5, atol=1e-7)
+    assert np.all(d.efc_force >= 0) and np.all(d.solver_niter <= 6)
+    # the solution is no worse than both candidate starting points (cost is monotone in CG)
+    def cost(qacc):
+        jar = np.einsum("nrv,nv->nr", d.efc_J, qacc) - d.efc_aref
+        Ma = np.einsum("nij,nj->ni", d.qM, qacc)
+        return 0.5 * np.sum(d.efc_D * jar * jar * (jar < 0), -1) + 0.5 * np.sum((Ma - d.qfrc_smooth) * (qacc - d.qacc_smooth), -1)
+    assert np.all(cost(d.qacc) <= cost(d.qacc_smooth) + 1e-9)
+    # inactive rows are inert
+    assert np.all(d.efc_force[~d.efc_active_row] == 0)
+
+
+def _solver_cost(d, qacc):
+    qacc = qacc.astype(np.float64)
+    jar = np.einsum("nrv,nv->nr", d.efc_J, qacc) - d.efc_aref
+    Ma = np.einsum("nij,nj->ni", d.qM, qacc)
+    return 0.5 * np.sum(d.efc_D * jar * jar * (jar < 0), -1) + 0.5 * np.sum((Ma - d.qfrc_smooth) * (qacc - d.qacc_smooth), -1)
+
+
+def test_float32_tracks_float64_per_step():
+    """The reference's 6-iteration CG is not converged (it sits 0.1-0.5 % above the optimal cost and is
+    loose in flat directions), so two float32 evaluations agree on `qacc` only loosely.  What is tight:
+    everything before the solver, and the *cost* the solver reaches.  The HIP parity tests use the
+    same criteria (tests/test_gpu_physics.py)."""
+    m = load_model("synth_stompy_pro")
+    ph64, ph32 = Physics(m.t, np.float64), Physics(m.t, np.float32)
+    N = 6
+    rng = np.random.default_rng(3)
+    d64 = ph64.pipeline_init(np.tile(m.t["qpos0"], (N, 1)), np.zeros((N, 16)))
+    to32 = lambda d: PhysState({k: (v.astype(np.float32) if isinstance(v, np.ndarray) and v.dtype == np.float64 else v) for k, v in d.items()})
+    for _ in range(10):
+        a = 0.3 * rng.standard_normal((N, 10))
+        d32 = ph32.pipeline_step(to32(d64), a.astype(np.float32))
+        d64 = ph64.pipeline_step(d64, a)
+        assert np.isfinite(d64.qpos).all() and d32.qpos.dtype == np.float32
+        for k, tol in (("qM", 1e-5), ("qfrc_bias", 1e-4), ("qfrc_actuator", 1e-5), ("qacc_smooth", 2e-4), ("efc_J", 1e-5),
+                       ("efc_aref", 2e-4), ("cinert", 1e-5), ("cvel", 1e-4)):
+            scale = np.abs(d64[k]).max() + 1e-9
+            assert np.abs(d32[k] - d64[k]).max() <= tol * scale, k
+        c32, c64 = _solver_cost(d64, d32.qacc), _solver_cost(d64, d64.qacc)
+        np.testing.assert_allclose(c32, c64, rtol=5e-2)
+        assert np.all(c32 <= _solver_cost(d64, d64.qacc_smooth))
+
+
+# ---------------------------------------------------------------------------
+# env wrapper (reference env.py:148-261)
+# ---------------------------------------------------------------------------
+
+
+def test_env_obs_layout_lag_and_reward_terms():
+    m = load_model("synth_stompy_pro")
+    env = EnvOracle(m.t)
+    assert env.observation_size == 225 and env.action_size == 10
+    N = 3
+    es = env.reset(N)
+    s0 = es["pipeline_state"]
+    obs0 = es["obs"]
+    assert obs0.shape == (N, 225)
+    np.testing.assert_array_equal(obs0[:, :17], s0.qpos)
+    np.testing.assert_array_equal(obs0[:, 33:33 + 110], s0.cinert[:, 1:].reshape(N, -1))
+    np.testing.assert_array_equal(obs0[:, -16:], s0.qfrc_actuator)
+    rng = np.random.default_rng(0)
+    a = 0.5 * rng.standard_normal((N, 10))
+    es1 = env.step(es, a)
+    # quirk C-5: obs after the first step is the PRE-step observation == reset observation
+    np.testing.assert_array_equal(es1["obs"], obs0)
+    s1 = es1["pipeline_state"]
+    # reward reads the pre-step pose/height, post-step subtree_com (quirk C-6)
+    p0 = np.linalg.norm(env.initial_qpos[None] - s0.qpos, axis=-1)
+    vel = (s1.subtree_com[:, 1, 0] - s0.subtree_com[:, 1, 0]) / env.dt
+    want = 0.1 * -np.sum(a * a, -1) + 4 * (np.exp(-2 * p0) - 0.2 * np.clip(p0, 0, 0.5)) + 1.25 * vel + 1.0
+    np.testing.assert_allclose(es1["reward"], want, rtol=1e-12)
+    es2 = env.step(es1, a)
+    assert not np.array_equal(es2["obs"], obs0)
+    np.testing.assert_array_equal(es2["obs"][:, :17], s1.qpos)
+    assert list(es2["metrics"]["timestep"]) == [2] * N and list(es2["metrics"]["episode_lengths"]) == [2] * N
+    np.testing.assert_allclose(es2["metrics"]["episode_returns"], es1["reward"] + es2["reward"])
+
+
+def test_env_done_thresholds_nan_and_metric_rollover():
+    m = load_model("synth_stompy_pro")
+    env = EnvOracle(m.t, RewardCfg(height_min_z=1.0, height_max_z=1.02))
+    N = 4
+    es = env.reset(N)
+    a = np.zeros((N, 10))
+    s = es["pipeline_state"]
+    s["qpos"][0, 2] = 0.9      # below min_z: healthy term 0, done after the step
+    s["qvel"][2, 2] = 20.0     # shoots above max_z during the step
+    s["qvel"][3, 0] = np.nan   # NaN guard (env.py:173-176)
+    es1 = env.step(es, a)
+    assert list(es1["done"]) == [True, False, True, True]
+    reset_obs = env.reset(1)["obs"][0]
+    for i in (0, 2, 3):
+        np.testing.assert_array_equal(es1["obs"][i], reset_obs)
+        np.testing.assert_array_equal(es1["pipeline_state"].qpos[i], env.initial_qpos)
+    m1 = es1["metrics"]
+    assert list(m1["episode_lengths"]) == [0, 1, 0, 0] and list(m1["returned_episode_lengths"]) == [1, 0, 1, 1]
+    assert m1["episode_returns"][0] == 0 and m1["returned_episode_returns"][0] == pytest.approx(es1["reward"][0])
+    assert list(m1["returned_episode"]) == [True, False, True, True]
+    # healthy term: env 0 was below min_z before the step (strict <), env 1 healthy
+    assert es1["reward"][1] - es1["reward"][0] > 0.9
+    # boundary: exactly min_z is "healthy" for the reward (strict <) but "done" for is_done (strict <, negated)
+    es_b = env.reset(1); es_b["pipeline_state"]["qpos"][0, 2] = 1.0
+    s_b = es_b["pipeline_state"]
+    assert env.compute_reward(s_b, s_b, np.zeros((1, 10)))[0] == pytest.approx(4 * (np.exp(-2 * 0.0095) - 0.2 * 0.0095) + 1.0, rel=1e-6)
+    assert env.is_done(s_b)[0]
