@@ -1,0 +1,244 @@
+/*
+ * minppo_hip.h — C ABI of libminppo_hip.so, the MI355X (gfx950) engine behind the
+ * minppo train / env surface.
+ *
+ * The reference (kscalelabs/minppo @ 2024-10-16) exposes NO FFI / plugin interface: its hot
+ * path is one jitted JAX program reached through plain Python callables.  The
+ * entry points below are therefore the boundary a maintainer would bind (ctypes / cffi ABI
+ * mode) to replace the stages of that program; each one cites the
+ * reference lines it replaces.  All paths are relative to /root/reference/.
+ *
+ * Conventions
+ *   - every function returns 0 (MPPO_OK) or a negative MPPO_E* code; the message of the last
+ *     failure on the calling thread is returned by mppo_last_error().
+ *   - `stream` is a hipStream_t passed as void* (NULL = the default stream).  No function
+ *     allocates device memory, synchronises the host with the device or touches the default
+ *     stream behind the caller's back, unless stated.  Device pointers are owned by the caller
+ *     (torch tensors) and must outlive the enqueued work.
+ *   - all device arrays are float32 unless stated; matrices are row-major.
+ *   - flat parameter vector layout (P = 2(O*H + H + H*H + H) + H*A + 2A + H + 1 floats):
+ *       actor : W1[O,H] b1[H] W2[H,H] b2[H] W3[H,A] b3[A]  log_std[A]
+ *       critic: W1[O,H] b1[H] W2[H,H] b2[H] W3[H,1] b3[1]
+ *     (`kernel [in,out]`, `bias [out]`: the Flax layout of train.py:63,68; two hidden layers,
+ *     config.py:53.)
+ *   - trajectories are time-major [T,N,...]; flat sample index = t*N + n (train.py:260).
+ *   - observation rows are padded to OP = round_up(O, 4) floats (pad = 0) so that every row
+ *     starts 16-byte aligned.
+ */
+#ifndef MINPPO_HIP_H
+#define MINPPO_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MPPO_OK 0
+#define MPPO_EINVAL (-1)   /* bad argument / shape the kernels do not support            */
+#define MPPO_EHIP (-2)     /* a HIP runtime call failed (message has hipGetErrorString)   */
+#define MPPO_EMODEL (-3)   /* malformed model blob                                        */
+#define MPPO_ESTATE (-4)   /* call order violated (e.g. update before reset)              */
+#define MPPO_ENCCL (-5)    /* an RCCL call failed                                         */
+#define MPPO_ENOMEM (-6)   /* caller-provided workspace too small                         */
+
+#define MPPO_ABI_VERSION 1
+
+const char* mppo_last_error(void);
+int32_t mppo_abi_version(void);
+
+/* ------------------------------------------------------------------------------------------
+ * Robot model.  Replaces `load_mjcf_model` + `mjcf.load_model` + the solver override
+ * (minppo/env.py:27-50, 94-100): the host compiles an MJCF-like description into one
+ * little-endian blob of 4-byte words (minppo_amd/model.py: _to_blob documents the layout);
+ * the same bytes must be resident in device memory at `dev_blob` for the model's lifetime.
+ * ---------------------------------------------------------------------------------------- */
+typedef struct mppo_model mppo_model_t;
+
+typedef struct mppo_model_dims {
+  int32_t nq, nv, nu, nbody, njnt, ncon, nlimit, nefc;
+  int32_t obs_dim;      /* O  = nq + 2 nv + 16 (nbody-1)     (env.py:245-253, include_c_vals) */
+  int32_t obs_pad;      /* OP = round_up(O, 4)                                                */
+  int32_t rec_dim;      /* floats per env in the persistent state record                      */
+  int32_t lds_bytes;    /* dynamic LDS of one env_step workgroup                              */
+  float timestep;
+} mppo_model_dims_t;
+
+int32_t mppo_model_open(const void* host_blob, size_t nbytes, const void* dev_blob, mppo_model_t** out);
+int32_t mppo_model_close(mppo_model_t* m);
+int32_t mppo_model_get_dims(const mppo_model_t* m, mppo_model_dims_t* out);
+
+/* Reward / termination constants read by compute_reward and is_done (env.py:199-242,
+ * config.py:36-48). */
+typedef struct mppo_reward_cfg {
+  float height_min_z, height_max_z;
+  float exp_coefficient, subtraction_factor, max_diff_norm;
+  float w_ctrl_cost, w_original_pos, w_is_healthy, w_velocity;
+} mppo_reward_cfg_t;
+
+/* Per-env episode bookkeeping, `EnvMetrics` (env.py:53-59), structure-of-arrays, each [N]. */
+typedef struct mppo_env_metrics {
+  float* episode_returns;
+  int32_t* episode_lengths;
+  float* returned_episode_returns;
+  int32_t* returned_episode_lengths;
+  int32_t* timestep;
+  uint8_t* returned_episode;
+} mppo_env_metrics_t;
+
+/* Persistent per-env record, [N, rec_dim] floats:
+ *   [0,O)        the observation of this state: qpos, qvel, cinert[1:], cvel[1:], qfrc_actuator
+ *                (derived fields are those of the forward pass that produced the state, env.py:245-261)
+ *   [OP,OP+nv)   qacc_warmstart
+ *   OP+nv        subtree_com[1].x  (env.py:222-223)     OP+nv+1  time
+ * `reset_rec` [rec_dim] is the constant reset state (reset_noise_scale = 0, env.py:87,115-121).
+ *
+ * mppo_env_reset : `HumanoidEnv.reset` vmapped over N (env.py:124-145; train.py:133-143):
+ *                  pipeline_init at qpos0 / zero velocity / zero ctrl, zero metrics, obs [N,OP].
+ * mppo_env_step  : `HumanoidEnv.step` vmapped over N (env.py:148-196; train.py:138-140,165):
+ *                  n_frames x mjx.step, pre-step observation, reward, done (height or NaN),
+ *                  auto-reset, metrics.  action is [N, act_ld] with nu valid columns. */
+int32_t mppo_env_reset(const mppo_model_t* m, int32_t N, float* state, float* reset_rec, float* obs, int32_t obs_ld,
+                       float* reward, uint8_t* done, const mppo_env_metrics_t* metrics, void* stream);
+int32_t mppo_env_step(const mppo_model_t* m, int32_t N, int32_t n_frames, const mppo_reward_cfg_t* rc, float* state,
+                      const float* reset_rec, const float* action, int32_t act_ld, float* obs, int32_t obs_ld,
+                      float* reward, uint8_t* done, const mppo_env_metrics_t* metrics, void* stream);
+/* Debug / parity probe: one mjx.forward on caller-given (qpos,qvel,ctrl,qacc_warmstart) [N,*]
+ * with every intermediate the parity tests compare exported.  Any output pointer may be NULL.
+ * M [N,nv,nv]; efc_* [N,nefc]; J [N,nefc,nv]; cinert [N,nbody,10]; cvel [N,nbody,6]. */
+typedef struct mppo_forward_probe {
+  float *qM, *qfrc_bias, *qfrc_passive, *qfrc_actuator, *qacc_smooth, *efc_J, *efc_D, *efc_aref, *qacc, *cinert, *cvel,
+      *subtree_com1, *xpos, *qacc_euler;
+  int32_t* solver_niter;
+} mppo_forward_probe_t;
+int32_t mppo_physics_forward(const mppo_model_t* m, int32_t N, const float* qpos, const float* qvel, const float* ctrl,
+                             const float* qacc_warmstart, const mppo_forward_probe_t* out, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * PPO stages
+ * ---------------------------------------------------------------------------------------- */
+
+/* Network geometry + activation choice (train.py:56-83; config.py:52-55). */
+typedef struct mppo_net {
+  int32_t O, OP, A, H;
+  int32_t use_tanh;  /* actor activation; the critic is always ReLU (train.py:82) */
+  int32_t bf16;      /* 0: exact f32 MFMA; 1: bf16-in/f32-accumulate MFMA for the hidden GEMMs */
+} mppo_net_t;
+
+size_t mppo_param_count(const mppo_net_t* net);
+
+/* `ActorCritic.__call__` + sample + log_prob on n rows (train.py:157-160, 79-83):
+ *   mean = actor(obs); value = critic(obs); action = mean + exp(log_std)*noise;
+ *   log_prob = MVNDiag.log_prob(action).  noise may be NULL (then action/log_prob are not
+ *   written: the bootstrap-value call, train.py:182).  ws: workspace, >= mppo_policy_ws_bytes. */
+size_t mppo_policy_ws_bytes(const mppo_net_t* net, int32_t n);
+int32_t mppo_policy_forward(const mppo_net_t* net, const float* params, int32_t n, const float* obs, int32_t obs_ld,
+                            const float* noise, float* action, float* log_prob, float* value, float* mean_out,
+                            void* ws, size_t ws_bytes, void* stream);
+
+/* `_calculate_gae` (train.py:185-205): reverse scan over T, independent per env. */
+int32_t mppo_gae(int32_t T, int32_t N, float gamma, float lam, const float* reward, const float* value,
+                 const uint8_t* done, const float* last_val, float* adv, float* target, void* stream);
+
+/* One `_update_minibatch` gradient (train.py:213-247): gathers rows idx[0..mb) of the flat
+ * [B,...] batch, forward, clipped-PPO loss with the given advantage statistics
+ * (adv_stat = {mean, 1/(std+1e-8)}; per-minibatch population statistics, train.py:235),
+ * backward.  grad [P] receives d(total_loss)/d(params) with every row weighted by inv_count
+ * (1/mb on one GPU, 1/(mb*world) when ranks are summed afterwards).  loss4 = {total, value,
+ * actor, entropy} partial sums weighted the same way. */
+typedef struct mppo_batch {
+  const float* obs;       int32_t obs_ld;   /* [B,OP]        */
+  const float* action;    int32_t act_ld;   /* [B,act_ld]    */
+  const float* value;                        /* [B] old value */
+  const float* log_prob;                     /* [B] old logp  */
+  const float* adv;                          /* [B]           */
+  const float* target;                       /* [B]           */
+} mppo_batch_t;
+typedef struct mppo_loss_cfg { float clip_eps, vf_coef, ent_coef; } mppo_loss_cfg_t;
+size_t mppo_grad_ws_bytes(const mppo_net_t* net, int32_t mb);
+int32_t mppo_minibatch_grad(const mppo_net_t* net, const float* params, const mppo_batch_t* batch, const int32_t* idx,
+                            int32_t mb, const float* adv_stat, float inv_count, const mppo_loss_cfg_t* lc, float* grad,
+                            float* loss4, void* ws, size_t ws_bytes, void* stream);
+
+/* Per-minibatch advantage statistics for all E*M minibatches of an update in one launch:
+ * sums[k] = {sum adv, sum adv^2} (float64) over rows idx[k*mb .. (k+1)*mb); then
+ * mppo_adv_stats_finalize turns (possibly all-reduced) sums into {mean, 1/(std+1e-8)}. */
+int32_t mppo_adv_sums(const float* adv, const int32_t* idx, int32_t num_minibatches_total, int32_t mb, double* sums,
+                      void* stream);
+int32_t mppo_adv_stats_finalize(const double* sums, int32_t num_minibatches_total, double count, float* stats,
+                                void* stream);
+
+/* `optax.chain(clip_by_global_norm(max_norm), adam(lr_schedule, eps))` + apply (train.py:98-101,
+ * 115-124, 248).  The step index is count_base[0] + step_offset (device int32 + host int, so
+ * that the call can be captured in a hipGraph); lr = anneal ? lr*(1 - (count // sched_div)/num_updates)
+ * : lr  with sched_div = minibatch_size*update_epochs as written in the reference (quirk C-2).
+ * ws: >= mppo_adam_ws_bytes(P). */
+typedef struct mppo_adam_cfg {
+  float lr, max_grad_norm, b1, b2, eps;
+  int32_t anneal, sched_div, num_updates;
+} mppo_adam_cfg_t;
+size_t mppo_adam_ws_bytes(size_t P);
+int32_t mppo_clip_adam(size_t P, float* params, float* m, float* v, const float* grad, const int32_t* count_base,
+                       int32_t step_offset, const mppo_adam_cfg_t* cfg, void* ws, size_t ws_bytes, void* stream);
+
+/* Counter-based RNG (Philox4x32-10), the engine's own stream (not JAX threefry).
+ * mppo_normal_fill: out[i] ~ N(0,1), i in [0,n), a pure function of (seed, stream_id, i).
+ * mppo_permutation: idx = a uniformly random permutation of [0,B) (sort of random keys, as
+ * jax.random.permutation does; train.py:258).  ws >= mppo_permutation_ws_bytes(B). */
+int32_t mppo_normal_fill(uint64_t seed, uint64_t stream_id, size_t n, float* out, void* stream);
+size_t mppo_permutation_ws_bytes(int32_t B);
+int32_t mppo_permutation(uint64_t seed, uint64_t stream_id, int32_t B, int32_t* idx, void* ws, size_t ws_bytes,
+                         void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Engine: the whole `_update_step` (train.py:146-283) as one call, launches enqueued from
+ * C++ (optionally replayed from a hipGraph), gradients summed over ranks with RCCL.
+ * ---------------------------------------------------------------------------------------- */
+typedef struct mppo_engine mppo_engine_t;
+
+typedef struct mppo_engine_cfg {
+  int32_t num_envs;          /* N on THIS rank                                     */
+  int32_t num_steps;         /* T  (rl.num_env_steps == training.num_steps)        */
+  int32_t num_minibatches;   /* M                                                   */
+  int32_t update_epochs;     /* E                                                   */
+  int32_t n_frames;
+  int32_t num_updates;       /* for the LR schedule (train.py:93)                  */
+  int32_t world_size, rank;
+  float gamma, gae_lambda;
+  mppo_loss_cfg_t loss;
+  mppo_adam_cfg_t adam;      /* sched_div / num_updates are filled by the engine   */
+  mppo_reward_cfg_t reward;
+  mppo_net_t net;
+  uint64_t seed;
+  int32_t use_graph;         /* capture the update in a hipGraph and replay it      */
+  int32_t external_random;   /* 1: noise / permutations are written by the caller into the arena (parity tests) */
+} mppo_engine_cfg_t;
+
+/* Arena: ONE device allocation owned by the caller (a torch uint8 tensor); the engine lays
+ * every buffer out inside it.  mppo_engine_arena_bytes gives the size; named regions can be
+ * located with mppo_engine_region (offset in bytes, size in bytes) to view them as tensors:
+ * "params" "adam_m" "adam_v" "grad" "count" "state" "reset_rec" "obs" "action" "value" "reward"
+ * "log_prob" "done" "last_val" "adv" "target" "noise" "perm" "adv_stats" "losses" "metrics_sum" ... */
+int32_t mppo_engine_arena_bytes(const mppo_model_t* m, const mppo_engine_cfg_t* cfg, size_t* out);
+int32_t mppo_engine_create(const mppo_model_t* m, const mppo_engine_cfg_t* cfg, void* arena, size_t arena_bytes,
+                           mppo_engine_t** out);
+int32_t mppo_engine_destroy(mppo_engine_t* e);
+int32_t mppo_engine_region(const mppo_engine_t* e, const char* name, size_t* offset, size_t* nbytes);
+/* RCCL: rank 0 makes an id (128 bytes), the caller broadcasts it, every rank calls comm_init.
+ * Collective on the engine's stream: one sum all-reduce of the [P] gradient per optimizer step
+ * and one of the [E*M*2] float64 advantage sums per update. */
+int32_t mppo_comm_unique_id(void* id128);
+int32_t mppo_engine_comm_init(mppo_engine_t* e, const void* id128);
+/* env reset (train.py:142-144) */
+int32_t mppo_engine_reset(mppo_engine_t* e, void* stream);
+/* one full update: T rollout steps, bootstrap value, GAE, E epochs x M minibatches */
+int32_t mppo_engine_update(mppo_engine_t* e, void* stream);
+/* pieces of the update, for stage-wise parity tests */
+int32_t mppo_engine_rollout(mppo_engine_t* e, void* stream);
+int32_t mppo_engine_learn(mppo_engine_t* e, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MINPPO_HIP_H */

@@ -1,0 +1,996 @@
+// k_physics.hip — the vectorised environment step as ONE kernel.
+//
+// Replaces, for N environments at once, reference `HumanoidEnv.step` / `.reset`
+// (minppo/env.py:124-196) including the third-party `pipeline_step` / `pipeline_init` it calls
+// (env.py:120,162 -> brax.mjx.pipeline -> mujoco.mjx.step/forward with solver = CG, 6 iterations,
+// 6 line-search iterations, env.py:95-97), `compute_reward` (env.py:199-235), `is_done`
+// (env.py:238-242), the NaN guard (env.py:173-176), the auto-reset select (env.py:179-180),
+// `get_obs` (env.py:245-261) and the episode metrics (env.py:183-194).
+//
+// Mapping (MI355X): 16 lanes (one DPP row) cooperate on one environment, 4 environments per
+// 64-wide wavefront, one wavefront per workgroup -> N/4 workgroups (1024 at N = 4096 = one wave
+// per SIMD on 256 CUs).  Every per-environment array lives in LDS (about 9.5 KB per environment
+// for the 16-dof stand-in, four workgroups per CU); lanes own dofs / bodies / constraint rows
+// with stride 16, reductions run as DPP row rotations (wave_ops.h), and the only sequential
+// parts are the kinematic-tree levels and the Cholesky columns.  All tree recursions of
+// MuJoCo (composite inertia, body velocities, RNE) are evaluated in closed form over ancestor /
+// subtree bitmasks from the model blob, so they need no level-by-level synchronisation.
+// HBM traffic per environment step: the state record in and out, the action in, the observation
+// out (about 2.9 KB at O = 225).  The kernel is latency-bound, not bandwidth-bound.
+#include "model_view.h"
+#include "mppo_common.h"
+#include <wave_ops.h>
+
+namespace mppo {
+
+struct EnvArgs {
+  int N, mode, n_frames;  // mode 0: reset (pipeline_init), 1: step, 2: probe (one forward on given inputs)
+  float* state;
+  const float* reset_in;
+  float* reset_out;
+  const float* action;
+  int act_ld;
+  float* obs;
+  int obs_ld;
+  float* reward;
+  unsigned char* done;
+  mppo_env_metrics_t met;
+  mppo_reward_cfg_t rc;
+  const float *p_qpos, *p_qvel, *p_ctrl, *p_warm;
+  mppo_forward_probe_t probe;
+};
+
+#define SYNC() __syncthreads()
+#define FOR_G(i, n) for (int i = g; i < (n); i += kGroupLanes)
+
+// ---- small vector helpers (registers) -------------------------------------------------------
+struct V3 { float x, y, z; };
+struct Q4 { float w, x, y, z; };
+__device__ __forceinline__ V3 ld3(const float* p) { return {p[0], p[1], p[2]}; }
+__device__ __forceinline__ void st3(float* p, V3 v) { p[0] = v.x; p[1] = v.y; p[2] = v.z; }
+__device__ __forceinline__ Q4 ld4(const float* p) { return {p[0], p[1], p[2], p[3]}; }
+__device__ __forceinline__ void st4(float* p, Q4 q) { p[0] = q.w; p[1] = q.x; p[2] = q.y; p[3] = q.z; }
+__device__ __forceinline__ V3 add3(V3 a, V3 b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
+__device__ __forceinline__ V3 sub3(V3 a, V3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
+__device__ __forceinline__ V3 mul3(V3 a, float s) { return {a.x * s, a.y * s, a.z * s}; }
+__device__ __forceinline__ float dot3(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+__device__ __forceinline__ V3 cross3(V3 a, V3 b) { return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x}; }
+__device__ __forceinline__ Q4 qmul(Q4 a, Q4 b) {
+  return {a.w * b.w - a.x * b.x - a.y * b.y - a.z * b.z, a.w * b.x + a.x * b.w + a.y * b.z - a.z * b.y,
+          a.w * b.y - a.x * b.z + a.y * b.w + a.z * b.x, a.w * b.z + a.x * b.y - a.y * b.x + a.z * b.w};
+}
+__device__ __forceinline__ Q4 qnormalize(Q4 q) {
+  const float n = sqrtf(q.w * q.w + q.x * q.x + q.y * q.y + q.z * q.z);
+  const float s = n > 0.f ? 1.f / n : 1.f;
+  return {q.w * s, q.x * s, q.y * s, q.z * s};
+}
+// rotation matrix of a (unit) quaternion, row-major in m[9]
+__device__ __forceinline__ void qmat(Q4 q, float* m) {
+  const float w = q.w, x = q.x, y = q.y, z = q.z;
+  m[0] = w * w + x * x - y * y - z * z; m[1] = 2.f * (x * y - w * z);         m[2] = 2.f * (x * z + w * y);
+  m[3] = 2.f * (x * y + w * z);         m[4] = w * w - x * x + y * y - z * z; m[5] = 2.f * (y * z - w * x);
+  m[6] = 2.f * (x * z - w * y);         m[7] = 2.f * (y * z + w * x);         m[8] = w * w - x * x - y * y + z * z;
+}
+__device__ __forceinline__ V3 qrot(Q4 q, V3 v) {
+  float m[9];
+  qmat(q, m);
+  return {m[0] * v.x + m[1] * v.y + m[2] * v.z, m[3] * v.x + m[4] * v.y + m[5] * v.z, m[6] * v.x + m[7] * v.y + m[8] * v.z};
+}
+__device__ __forceinline__ Q4 axis_angle(V3 axis, float angle) {
+  float s, c;
+  sincosf(0.5f * angle, &s, &c);
+  return {c, axis.x * s, axis.y * s, axis.z * s};
+}
+// cinert (10) x spatial motion (6) -> spatial force (6)      (mju_mulInertVec)
+__device__ __forceinline__ void inert_mul(const float* i, const float* v, float* r) {
+  r[0] = i[0] * v[0] + i[3] * v[1] + i[4] * v[2] - i[8] * v[4] + i[7] * v[5];
+  r[1] = i[3] * v[0] + i[1] * v[1] + i[5] * v[2] + i[8] * v[3] - i[6] * v[5];
+  r[2] = i[4] * v[0] + i[5] * v[1] + i[2] * v[2] - i[7] * v[3] + i[6] * v[4];
+  r[3] = i[8] * v[1] - i[7] * v[2] + i[9] * v[3];
+  r[4] = i[6] * v[2] - i[8] * v[0] + i[9] * v[4];
+  r[5] = i[7] * v[0] - i[6] * v[1] + i[9] * v[5];
+}
+// spatial motion cross product vel x v (mju_crossMotion)
+__device__ __forceinline__ void cross_motion(const float* vel, const float* v, float* r) {
+  const V3 w = ld3(vel), l = ld3(vel + 3), a = ld3(v), b = ld3(v + 3);
+  st3(r, cross3(w, a));
+  st3(r + 3, add3(cross3(w, b), cross3(l, a)));
+}
+// spatial force cross product vel x* f (mju_crossForce)
+__device__ __forceinline__ void cross_force(const float* vel, const float* f, float* r) {
+  const V3 w = ld3(vel), l = ld3(vel + 3), a = ld3(f), b = ld3(f + 3);
+  st3(r, add3(cross3(w, a), cross3(l, b)));
+  st3(r + 3, cross3(w, b));
+}
+
+// x = (L L^T)^-1 b given Linv = L^-1 (lower triangular, row-major, leading dim ldm).
+// `tmp` and `x` are nv-vectors in LDS; b may alias neither.  Contains two barriers.
+__device__ __forceinline__ void solve_linv(const float* Linv, int ldm, int nv, const float* b, float* tmp, float* x, int g) {
+  FOR_G(i, nv) {
+    float s = 0.f;
+    for (int k = 0; k <= i; ++k) s += Linv[i * ldm + k] * b[k];
+    tmp[i] = s;
+  }
+  SYNC();
+  FOR_G(i, nv) {
+    float s = 0.f;
+    for (int k = i; k < nv; ++k) s += Linv[k * ldm + i] * tmp[k];
+    x[i] = s;
+  }
+  SYNC();
+}
+
+struct LsPoint { float alpha, cost, d0, d1; };
+
+__device__ __forceinline__ LsPoint ls_make(float alpha, float q0, float q1, float q2) {
+  LsPoint p;
+  p.alpha = alpha;
+  p.cost = alpha * alpha * q2 + alpha * q1 + q0;
+  p.d0 = 2.f * alpha * q2 + q1;
+  p.d1 = 2.f * q2 + (q2 == 0.f ? MJ_MINVAL : 0.f);
+  return p;
+}
+__device__ __forceinline__ bool in_bracket(const LsPoint& x, const LsPoint& y) {
+  return ((x.d0 < y.d0) && (y.d0 < 0.f)) || ((x.d0 > y.d0) && (y.d0 > 0.f));
+}
+__device__ __forceinline__ LsPoint ls_sel(bool c, const LsPoint& a, const LsPoint& b) { return c ? a : b; }
+
+// impedance / reference (MuJoCo solref + solimp -> k, b, imp), pos = signed distance - margin
+__device__ __forceinline__ void kbi(const float* solref, const float* solimp, float timestep, float pos, float& k, float& b, float& imp) {
+  const float timeconst = fmaxf(solref[0], 2.f * timestep);  // refsafe
+  const float dampratio = solref[1];
+  const float dmin = fminf(fmaxf(solimp[0], MJ_MINIMP), MJ_MAXIMP);
+  const float dmax = fminf(fmaxf(solimp[1], MJ_MINIMP), MJ_MAXIMP);
+  const float width = fmaxf(MJ_MINVAL, solimp[2]);
+  const float mid = fminf(fmaxf(solimp[3], MJ_MINIMP), MJ_MAXIMP);
+  const float power = fmaxf(1.f, solimp[4]);
+  k = 1.f / (dmax * dmax * timeconst * timeconst * dampratio * dampratio);
+  b = 2.f / (dmax * timeconst);
+  if (solref[0] <= 0.f) k = -solref[0] / (dmax * dmax);
+  if (solref[1] <= 0.f) b = -solref[1] / dmax;
+  const float x = fabsf(pos) / width;
+  const float a = (1.f / powf(mid, power - 1.f)) * powf(x, power);
+  const float c = 1.f - (1.f / powf(1.f - mid, power - 1.f)) * powf(fabsf(1.f - x), power);
+  const float y = x < mid ? a : c;
+  imp = dmin + y * (dmax - dmin);
+  imp = fminf(fmaxf(imp, dmin), dmax);
+  if (x > 1.f) imp = dmax;
+}
+
+__global__ void __launch_bounds__(kEnvBlock) env_kernel(ModelView mv, EnvArgs a, PhysLds P) {
+  MPPO_DYN_SMEM(smem_raw);
+  const int tid = threadIdx.x;
+  const int g = tid & (kGroupLanes - 1);
+  const int el = tid / kGroupLanes;
+  int env = blockIdx.x * kEnvsPerBlock + el;
+  const bool valid = env < a.N;
+  if (!valid) env = a.N - 1;  // surplus groups shadow the last environment and never store
+  float* S = reinterpret_cast<float*>(smem_raw) + (size_t)el * P.total;
+
+  const int nq = mv.nq, nv = mv.nv, nu = mv.nu, nb = mv.nbody, njnt = mv.njnt, ncon = mv.ncon, nlim = mv.nlimit, nefc = mv.nefc;
+  const int ldm = P.ldm, ldj = P.ldj;
+  const float h = mv.timestep;
+  const int O = mv.obs_dim, OP = mv.obs_pad;
+  float* qpos = S + P.qpos; float* qvel = S + P.qvel; float* ctrl = S + P.ctrl; float* warm = S + P.warm;
+  float* xpos = S + P.xpos; float* xquat = S + P.xquat; float* xipos = S + P.xipos; float* rootcom = S + P.rootcom;
+  float* cinert = S + P.cinert; float* cdof = S + P.cdof; float* cvel = S + P.cvel;
+  float* M = S + P.M; float* Li = S + P.Li; float* Le = S + P.Le;
+  float* qfs = S + P.qfs; float* qas = S + P.qas; float* qact = S + P.qact; float* qacc = S + P.qacc; float* Ma = S + P.Ma;
+  float* grad = S + P.grad; float* Mgrad = S + P.Mgrad; float* search = S + P.search; float* mvv = S + P.mv; float* qfc = S + P.qfc;
+  float* t0 = S + P.t0; float* t1 = S + P.t1;
+  float* eD = S + P.D; float* earef = S + P.aref; float* jaref = S + P.jaref; float* jv = S + P.jv; float* force = S + P.force;
+  float* conpos = S + P.conpos; float* condist = S + P.condist;
+  float* ximat = S + P.ximat; float* xmat = S + P.xmat; float* xanchor = S + P.xanchor; float* xaxis = S + P.xaxis;
+  float* C1 = S + P.C1; float* C2 = S + P.C2; float* cdofdot = S + P.cdofdot; float* cfrc = S + P.cfrc; float* J = S + P.J;
+
+  const float* rec = a.state ? a.state + (size_t)env * mv.rec_dim : nullptr;
+
+  // ---- P0: load the state ------------------------------------------------------------------
+  if (a.mode == 1) {
+    FOR_G(i, nq) qpos[i] = rec[i];
+    FOR_G(i, nv) { qvel[i] = rec[nq + i]; warm[i] = rec[OP + i]; }
+    FOR_G(i, nu) ctrl[i] = a.action[(size_t)env * a.act_ld + i];
+  } else if (a.mode == 0) {
+    FOR_G(i, nq) qpos[i] = mv.qpos0[i];
+    FOR_G(i, nv) { qvel[i] = 0.f; warm[i] = 0.f; }
+    FOR_G(i, nu) ctrl[i] = 0.f;
+  } else {
+    FOR_G(i, nq) qpos[i] = a.p_qpos[(size_t)env * nq + i];
+    FOR_G(i, nv) { qvel[i] = a.p_qvel[(size_t)env * nv + i]; warm[i] = a.p_warm[(size_t)env * nv + i]; }
+    FOR_G(i, nu) ctrl[i] = a.p_ctrl[(size_t)env * nu + i];
+  }
+  // pre-step quantities the reward needs (env.py:212-217, 222)
+  float pre_p0 = 0.f, pre_z = 0.f, pre_comx = 0.f, time_in = 0.f;
+  if (a.mode == 1) {
+    float s = 0.f;
+    FOR_G(i, nq) { const float d = mv.qpos0[i] - rec[i]; s += d * d; }
+    pre_p0 = sqrtf(group16_sum(s));
+    pre_z = rec[2];
+    pre_comx = rec[OP + nv];
+    time_in = rec[OP + nv + 1];
+  }
+  if (g == 0) { st3(xpos, {0.f, 0.f, 0.f}); st4(xquat, {1.f, 0.f, 0.f, 0.f}); }
+  SYNC();
+
+  float new_comx = 0.f;
+  int niter_out = 0;
+  const int frames = a.mode == 1 ? a.n_frames : 1;
+  for (int frame = 0; frame < frames; ++frame) {
+    // ================= fwd_position: kinematics (level-synchronous over the tree) =================
+    for (int lv = 0; lv < mv.nlevel; ++lv) {
+      const int adr = mv.level_adr[lv], cnt = mv.level_adr[lv + 1] - adr;
+      FOR_G(ii, cnt) {
+        const int b = mv.level_body[adr + ii];
+        const int p = mv.body_parent[b];
+        const Q4 pq = ld4(xquat + 4 * p);
+        V3 pos = add3(ld3(xpos + 3 * p), qrot(pq, ld3(mv.body_pos + 3 * b)));
+        Q4 quat = qmul(pq, ld4(mv.body_quat + 4 * b));
+        const int j0 = mv.body_jntadr[b], j1 = j0 + mv.body_jntnum[b];
+        for (int j = j0; j < j1; ++j) {
+          const int qa = mv.jnt_qposadr[j], jt = mv.jnt_type[j];
+          if (jt == JNT_FREE) {
+            pos = ld3(qpos + qa);
+            quat = qnormalize(ld4(qpos + qa + 3));
+            st3(xanchor + 3 * j, pos);
+            st3(xaxis + 3 * j, qrot(quat, ld3(mv.jnt_axis + 3 * j)));
+          } else {
+            const V3 anchor = add3(pos, qrot(quat, ld3(mv.jnt_pos + 3 * j)));
+            const V3 axis = qrot(quat, ld3(mv.jnt_axis + 3 * j));
+            st3(xanchor + 3 * j, anchor);
+            st3(xaxis + 3 * j, axis);
+            const float disp = qpos[qa] - mv.qpos0[qa];
+            if (jt == JNT_HINGE) {
+              quat = qmul(quat, axis_angle(ld3(mv.jnt_axis + 3 * j), disp));
+              pos = sub3(anchor, qrot(quat, ld3(mv.jnt_pos + 3 * j)));
+            } else {
+              pos = add3(pos, mul3(axis, disp));
+            }
+          }
+        }
+        quat = qnormalize(quat);
+        st3(xpos + 3 * b, pos);
+        st4(xquat + 4 * b, quat);
+        qmat(quat, xmat + 9 * b);
+        st3(xipos + 3 * b, add3(pos, qrot(quat, ld3(mv.body_ipos + 3 * b))));
+        qmat(qmul(quat, ld4(mv.body_iquat + 4 * b)), ximat + 9 * b);
+      }
+      SYNC();
+    }
+    // ---- com_pos: centre of mass of every kinematic tree; contact candidates --------------------
+    for (int r = 0; r < mv.nroot; ++r) {
+      const u64 mask = mv.body_subtree_mask[mv.root_body[r]];
+      float sx = 0.f, sy = 0.f, sz = 0.f, sm = 0.f;
+      FOR_G(b, nb) {
+        if ((mask >> b) & 1ull) {
+          const float m = mv.body_mass[b];
+          sx += m * xipos[3 * b]; sy += m * xipos[3 * b + 1]; sz += m * xipos[3 * b + 2]; sm += m;
+        }
+      }
+      sx = group16_sum(sx); sy = group16_sum(sy); sz = group16_sum(sz); sm = group16_sum(sm);
+      const float inv = 1.f / fmaxf(sm, MJ_MINVAL);
+      if (g == 0) st3(rootcom + 3 * r, {sx * inv, sy * inv, sz * inv});
+      if (r == 0) new_comx = sx * inv;  // subtree_com[1].x: body 1 is the first root (env.py:222-223)
+    }
+    FOR_G(c, ncon) {
+      const int b = mv.con_bodyid[c];
+      const V3 centre = add3(ld3(xpos + 3 * b), qrot(ld4(xquat + 4 * b), ld3(mv.con_lpos + 3 * c)));
+      const float rad = mv.con_radius[c];
+      const float dist = centre.z - mv.plane_z - rad;
+      condist[c] = dist;
+      st3(conpos + 3 * c, {centre.x, centre.y, centre.z - (rad + 0.5f * dist)});
+    }
+    SYNC();
+    // ---- cinert (per body), cdof (per joint) -------------------------------------------------------
+    FOR_G(b, nb) {
+      float* ci = cinert + 10 * b;
+      if (b == 0) {
+        for (int k = 0; k < 10; ++k) ci[k] = 0.f;
+      } else {
+        int ri = 0;
+        for (int r = 0; r < mv.nroot; ++r) if (mv.root_body[r] == mv.body_rootid[b]) ri = r;
+        const V3 off = sub3(ld3(xipos + 3 * b), ld3(rootcom + 3 * ri));
+        const float m = mv.body_mass[b];
+        const float* R = ximat + 9 * b;
+        const float d0 = mv.body_inertia[3 * b], d1 = mv.body_inertia[3 * b + 1], d2 = mv.body_inertia[3 * b + 2];
+        const float oo = dot3(off, off);
+        ci[0] = R[0] * R[0] * d0 + R[1] * R[1] * d1 + R[2] * R[2] * d2 + m * (oo - off.x * off.x);
+        ci[1] = R[3] * R[3] * d0 + R[4] * R[4] * d1 + R[5] * R[5] * d2 + m * (oo - off.y * off.y);
+        ci[2] = R[6] * R[6] * d0 + R[7] * R[7] * d1 + R[8] * R[8] * d2 + m * (oo - off.z * off.z);
+        ci[3] = R[0] * R[3] * d0 + R[1] * R[4] * d1 + R[2] * R[5] * d2 - m * off.x * off.y;
+        ci[4] = R[0] * R[6] * d0 + R[1] * R[7] * d1 + R[2] * R[8] * d2 - m * off.x * off.z;
+        ci[5] = R[3] * R[6] * d0 + R[4] * R[7] * d1 + R[5] * R[8] * d2 - m * off.y * off.z;
+        ci[6] = m * off.x; ci[7] = m * off.y; ci[8] = m * off.z; ci[9] = m;
+      }
+    }
+    FOR_G(j, njnt) {
+      const int b = mv.jnt_bodyid[j], da = mv.jnt_dofadr[j], jt = mv.jnt_type[j];
+      int ri = 0;
+      for (int r = 0; r < mv.nroot; ++r) if (mv.root_body[r] == mv.body_rootid[b]) ri = r;
+      const V3 off = sub3(ld3(rootcom + 3 * ri), ld3(xanchor + 3 * j));
+      if (jt == JNT_FREE) {
+        const float* R = xmat + 9 * b;
+        for (int k = 0; k < 3; ++k) {
+          float* c = cdof + 6 * (da + k);
+          c[0] = c[1] = c[2] = 0.f;
+          c[3] = k == 0 ? 1.f : 0.f; c[4] = k == 1 ? 1.f : 0.f; c[5] = k == 2 ? 1.f : 0.f;
+          const V3 ax = {R[k], R[3 + k], R[6 + k]};
+          float* cr = cdof + 6 * (da + 3 + k);
+          st3(cr, ax);
+          st3(cr + 3, cross3(ax, off));
+        }
+      } else if (jt == JNT_HINGE) {
+        const V3 ax = ld3(xaxis + 3 * j);
+        st3(cdof + 6 * da, ax);
+        st3(cdof + 6 * da + 3, cross3(ax, off));
+      } else {
+        st3(cdof + 6 * da, {0.f, 0.f, 0.f});
+        st3(cdof + 6 * da + 3, ld3(xaxis + 3 * j));
+      }
+    }
+    FOR_G(i, nv) for (int k = 0; k < nv; ++k) M[i * ldm + k] = 0.f;
+    SYNC();
+    // ---- crb: composite inertia over the subtree mask, dense M ------------------------------------
+    FOR_G(i, nv) {
+      const int bi = mv.dof_bodyid[i];
+      u64 mask = mv.body_subtree_mask[bi];
+      float crb[10];
+      for (int k = 0; k < 10; ++k) crb[k] = 0.f;
+      while (mask) {
+        const int c = __ffsll((long long)mask) - 1;
+        mask &= mask - 1;
+        for (int k = 0; k < 10; ++k) crb[k] += cinert[10 * c + k];
+      }
+      float buf[6];
+      inert_mul(crb, cdof + 6 * i, buf);
+      int j = i;
+      while (j >= 0) {
+        const float* cj = cdof + 6 * j;
+        float v = cj[0] * buf[0] + cj[1] * buf[1] + cj[2] * buf[2] + cj[3] * buf[3] + cj[4] * buf[4] + cj[5] * buf[5];
+        if (j == i) v += mv.dof_armature[i];
+        M[i * ldm + j] = v;
+        M[j * ldm + i] = v;
+        j = mv.dof_parentid[j];
+      }
+    }
+    SYNC();
+    // work copies for the two factorisations (region A2; the kinematics temporaries are dead)
+    FOR_G(i, nv) {
+      for (int k = 0; k < nv; ++k) {
+        const float v = M[i * ldm + k];
+        C1[i * ldm + k] = v;
+        C2[i * ldm + k] = (k == i) ? v + h * mv.dof_damping[i] : v;  // implicit joint damping (Euler)
+        Li[i * ldm + k] = 0.f;
+        Le[i * ldm + k] = 0.f;
+      }
+    }
+    // ---- factor_m: Cholesky of M and of M + h*diag(damping), both in the same column sweep ---------
+    // The diagonal keeps L_kk^2 (never overwritten), so a column needs only two barriers.
+    for (int k = 0; k < nv; ++k) {
+      SYNC();  // trailing update of column k-1 (or the copy) is complete
+      const float r1 = rsqrtf(fmaxf(C1[k * ldm + k], MJ_MINVAL)), r2 = rsqrtf(fmaxf(C2[k * ldm + k], MJ_MINVAL));
+      FOR_G(i, nv) if (i > k) { C1[i * ldm + k] *= r1; C2[i * ldm + k] *= r2; }
+      SYNC();
+      FOR_G(i, nv) {
+        if (i > k) {
+          const float l1 = C1[i * ldm + k], l2 = C2[i * ldm + k];
+          for (int j = k + 1; j <= i; ++j) {
+            C1[i * ldm + j] -= l1 * C1[j * ldm + k];
+            C2[i * ldm + j] -= l2 * C2[j * ldm + k];
+          }
+        }
+      }
+    }
+    SYNC();
+    // ---- triangular inverses, one column per lane (no cross-lane dependency inside a column) -------
+    FOR_G(j, nv) {
+      Li[j * ldm + j] = rsqrtf(fmaxf(C1[j * ldm + j], MJ_MINVAL));
+      Le[j * ldm + j] = rsqrtf(fmaxf(C2[j * ldm + j], MJ_MINVAL));
+      for (int i = j + 1; i < nv; ++i) {
+        float s1 = 0.f, s2 = 0.f;
+        for (int k = j; k < i; ++k) { s1 += C1[i * ldm + k] * Li[k * ldm + j]; s2 += C2[i * ldm + k] * Le[k * ldm + j]; }
+        Li[i * ldm + j] = -s1 * rsqrtf(fmaxf(C1[i * ldm + i], MJ_MINVAL));
+        Le[i * ldm + j] = -s2 * rsqrtf(fmaxf(C2[i * ldm + i], MJ_MINVAL));
+      }
+    }
+    SYNC();
+    // ================= fwd_velocity: com_vel, passive, rne (closed forms over ancestor masks) =======
+    FOR_G(b, nb) {
+      float v[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+      u64 mask = b ? mv.body_ancdof_mask[b] : 0ull;
+      while (mask) {
+        const int d = __ffsll((long long)mask) - 1;
+        mask &= mask - 1;
+        const float qd = qvel[d];
+        for (int k = 0; k < 6; ++k) v[k] += cdof[6 * d + k] * qd;
+      }
+      for (int k = 0; k < 6; ++k) cvel[6 * b + k] = v[k];
+    }
+    FOR_G(d, nv) {
+      const int j = mv.dof_jntid[d];
+      float* out = cdofdot + 6 * d;
+      if (mv.jnt_type[j] == JNT_FREE && d - mv.jnt_dofadr[j] < 3) {
+        for (int k = 0; k < 6; ++k) out[k] = 0.f;
+      } else {
+        float v[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        u64 mask = mv.dof_velmask[d];
+        while (mask) {
+          const int e = __ffsll((long long)mask) - 1;
+          mask &= mask - 1;
+          const float qd = qvel[e];
+          for (int k = 0; k < 6; ++k) v[k] += cdof[6 * e + k] * qd;
+        }
+        cross_motion(v, cdof + 6 * d, out);
+      }
+    }
+    SYNC();
+    FOR_G(b, nb) {
+      float* f = cfrc + 6 * b;
+      if (b == 0) {
+        for (int k = 0; k < 6; ++k) f[k] = 0.f;
+      } else {
+        float acc[6] = {0.f, 0.f, 0.f, -mv.gravity[0], -mv.gravity[1], -mv.gravity[2]};
+        u64 mask = mv.body_ancdof_mask[b];
+        while (mask) {
+          const int d = __ffsll((long long)mask) - 1;
+          mask &= mask - 1;
+          const float qd = qvel[d];
+          for (int k = 0; k < 6; ++k) acc[k] += cdofdot[6 * d + k] * qd;
+        }
+        float ia[6], iv[6], cf[6];
+        inert_mul(cinert + 10 * b, acc, ia);
+        inert_mul(cinert + 10 * b, cvel + 6 * b, iv);
+        cross_force(cvel + 6 * b, iv, cf);
+        for (int k = 0; k < 6; ++k) f[k] = ia[k] + cf[k];
+      }
+    }
+    SYNC();
+    // ---- qfrc_bias, passive, actuation -> qfrc_smooth -------------------------------------------------
+    FOR_G(d, nv) {
+      float f[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+      u64 mask = mv.body_subtree_mask[mv.dof_bodyid[d]];
+      while (mask) {
+        const int c = __ffsll((long long)mask) - 1;
+        mask &= mask - 1;
+        for (int k = 0; k < 6; ++k) f[k] += cfrc[6 * c + k];
+      }
+      const float* cd = cdof + 6 * d;
+      const float bias = cd[0] * f[0] + cd[1] * f[1] + cd[2] * f[2] + cd[3] * f[3] + cd[4] * f[4] + cd[5] * f[5];
+      float passive = -mv.dof_damping[d] * qvel[d];
+      const int qa = mv.dof_qposadr[d];
+      if (qa >= 0) {
+        const float stiff = mv.jnt_stiffness[mv.dof_jntid[d]];
+        if (stiff != 0.f) passive -= stiff * (qpos[qa] - mv.qpos_spring[qa]);
+      }
+      float act = 0.f;
+      for (int u = 0; u < nu; ++u) {
+        if (mv.act_dofid[u] == d) {
+          float c = ctrl[u];
+          if (mv.act_ctrllimited[u]) c = fminf(fmaxf(c, mv.act_ctrlrange[2 * u]), mv.act_ctrlrange[2 * u + 1]);
+          const float gear = mv.act_gear[u];
+          const float len = gear * qpos[mv.act_qposadr[u]], vel = gear * qvel[d];
+          float fo = mv.act_gain[u] * c + mv.act_bias[3 * u] + mv.act_bias[3 * u + 1] * len + mv.act_bias[3 * u + 2] * vel;
+          if (mv.act_forcelimited[u]) fo = fminf(fmaxf(fo, mv.act_forcerange[2 * u]), mv.act_forcerange[2 * u + 1]);
+          act += fo * gear;
+        }
+      }
+      qact[d] = act;
+      qfs[d] = passive - bias + act;
+      if (a.mode == 2) {
+        if (valid && a.probe.qfrc_bias) a.probe.qfrc_bias[(size_t)env * nv + d] = bias;
+        if (valid && a.probe.qfrc_passive) a.probe.qfrc_passive[(size_t)env * nv + d] = passive;
+      }
+    }
+    SYNC();  // cfrc / cdofdot (region A3) are dead from here: the Jacobian (A4) may overwrite them
+    solve_linv(Li, ldm, nv, qfs, t0, qas, g);  // fwd_acceleration: qacc_smooth = M^-1 qfrc_smooth
+    // ================= make_constraint ===================================================================
+    FOR_G(r, nefc) for (int k = 0; k < nv; ++k) J[r * ldj + k] = 0.f;
+    SYNC();
+    FOR_G(r, nlim) {  // joint limits: one row each
+      const int jid = mv.lim_jntid[r];
+      const int qa = mv.jnt_qposadr[jid], da = mv.jnt_dofadr[jid];
+      const float dlo = qpos[qa] - mv.jnt_range[2 * jid], dhi = mv.jnt_range[2 * jid + 1] - qpos[qa];
+      const float pos = fminf(dlo, dhi);
+      const bool act = pos < 0.f;
+      if (act) J[r * ldj + da] = dlo < dhi ? 1.f : -1.f;
+      jv[r] = act ? pos : 0.f;               // pos, parked in jv until the row parameters are built
+      force[r] = act ? mv.dof_invweight0[da] : 0.f;  // invweight, parked in force
+    }
+    for (int item = g; item < ncon * nv; item += kGroupLanes) {  // contacts: 4 pyramid rows, (contact, dof) per item
+      const int c = item / nv, d = item - c * nv;
+      const int b = mv.con_bodyid[c];
+      const bool act = condist[c] < 0.f;
+      if (act && ((mv.body_ancdof_mask[b] >> d) & 1ull)) {
+        int ri = 0;
+        for (int r = 0; r < mv.nroot; ++r) if (mv.root_body[r] == mv.body_rootid[b]) ri = r;
+        const V3 off = sub3(ld3(conpos + 3 * c), ld3(rootcom + 3 * ri));
+        const V3 jp = add3(ld3(cdof + 6 * d + 3), cross3(ld3(cdof + 6 * d), off));
+        // contact frame of the +z ground plane (make_frame): normal z, t1 = +y, t2 = -x
+        const float jn = jp.z, jt1 = jp.y, jt2 = -jp.x;
+        const float mu = mv.con_friction[3 * c];
+        const int r0 = nlim + 4 * c;
+        J[(r0 + 0) * ldj + d] = jn + mu * jt1;
+        J[(r0 + 1) * ldj + d] = jn - mu * jt1;
+        J[(r0 + 2) * ldj + d] = jn + mu * jt2;
+        J[(r0 + 3) * ldj + d] = jn - mu * jt2;
+      }
+    }
+    FOR_G(c, ncon) {
+      const bool act = condist[c] < 0.f;
+      const float mu = mv.con_friction[3 * c];
+      const float tw = mv.body_invweight0[2 * mv.con_bodyid[c]];
+      const float iw = (tw + mu * mu * tw) * 2.f * mu * mu / mv.impratio;
+      for (int k = 0; k < 4; ++k) {
+        jv[nlim + 4 * c + k] = act ? condist[c] : 0.f;
+        force[nlim + 4 * c + k] = act ? iw : 0.f;
+      }
+    }
+    SYNC();
+    FOR_G(r, nefc) {
+      const float pos = jv[r], iw = force[r];
+      const bool act = iw > 0.f;  // inactive rows are inert: J = 0, aref = 0, D = 0
+      float k, b, imp;
+      if (r < nlim) kbi(mv.limit_solref, mv.limit_solimp, h, pos, k, b, imp);
+      else kbi(mv.contact_solref, mv.contact_solimp, h, pos, k, b, imp);
+      float s = 0.f;
+      for (int d = 0; d < nv; ++d) s += J[r * ldj + d] * qvel[d];
+      const float R = fmaxf(iw * (1.f - imp) / imp, MJ_MINVAL);
+      eD[r] = act ? 1.f / R : 0.f;
+      earef[r] = act ? -b * s - k * imp * pos : 0.f;
+    }
+    SYNC();
+    // ================= solve: CG (Polak-Ribiere, M^-1 preconditioner) =====================================
+    const float scale = mv.meaninertia * (float)(nv > 1 ? nv : 1);
+    float cost = 0.f, prev_cost = 0.f, gauss = 0.f;
+    int niter = 0;
+    if (nefc == 0) {
+      FOR_G(i, nv) { qacc[i] = qas[i]; qfc[i] = 0.f; }
+      SYNC();
+    } else {
+      // Context.create(qacc): Ma = M qacc, Jaref = J qacc - aref, cost; only groups with `take` are modified.
+      auto ctx_eval = [&](const float* src, bool take, float& gs_out, float& cs_out) {
+        if (take) FOR_G(i, nv) qacc[i] = src[i];
+        SYNC();
+        if (take) {
+          FOR_G(i, nv) { float s = 0.f; for (int k = 0; k < nv; ++k) s += M[i * ldm + k] * qacc[k]; Ma[i] = s; }
+          FOR_G(r, nefc) { float s = 0.f; for (int k = 0; k < nv; ++k) s += J[r * ldj + k] * qacc[k]; jaref[r] = s - earef[r]; }
+        }
+        SYNC();
+        float gs = 0.f, cs = 0.f;
+        FOR_G(i, nv) gs += (Ma[i] - qfs[i]) * (qacc[i] - qas[i]);
+        FOR_G(r, nefc) { const float x = jaref[r]; if (x < 0.f) cs += eD[r] * x * x; }
+        gs = 0.5f * group16_sum(gs);
+        cs = 0.5f * group16_sum(cs) + gs;
+        if (take) { gs_out = gs; cs_out = cs; }
+        SYNC();
+      };
+      // warm start: keep qacc_warmstart if its cost beats qacc_smooth's (MJX solver.solve)
+      float cost_w = 0.f, gauss_w = 0.f;
+      ctx_eval(warm, true, gauss_w, cost_w);
+      ctx_eval(qas, true, gauss, cost);
+      const bool use_warm = cost_w < cost;
+      if (wave_any(use_warm)) ctx_eval(warm, use_warm, gauss, cost);
+      prev_cost = INFINITY;  // MJX Context.create: cost starts at inf, so the first improvement is inf
+      // update_constraint + update_gradient at the starting point
+      FOR_G(r, nefc) { const float x = jaref[r]; force[r] = x < 0.f ? -eD[r] * x : 0.f; }
+      SYNC();
+      FOR_G(i, nv) { float s = 0.f; for (int r = 0; r < nefc; ++r) s += J[r * ldj + i] * force[r]; qfc[i] = s; grad[i] = Ma[i] - qfs[i] - s; }
+      SYNC();
+      solve_linv(Li, ldm, nv, grad, t0, Mgrad, g);
+      FOR_G(i, nv) search[i] = -Mgrad[i];
+      SYNC();
+      for (int it = 0; it < mv.iterations; ++it) {
+        float gn = 0.f;
+        FOR_G(i, nv) gn += grad[i] * grad[i];
+        gn = sqrtf(group16_sum(gn)) / scale;
+        const float improvement = (prev_cost - cost) / scale;
+        const bool run = !((niter >= mv.iterations) || (improvement < mv.tolerance) || (gn < mv.tolerance));
+        if (!wave_any(run)) break;
+        // ---------------- line search ----------------
+        float sn = 0.f, sMa = 0.f, sq = 0.f;
+        FOR_G(i, nv) { float s = 0.f; for (int k = 0; k < nv; ++k) s += M[i * ldm + k] * search[k]; mvv[i] = s; }
+        FOR_G(r, nefc) { float s = 0.f; for (int k = 0; k < nv; ++k) s += J[r * ldj + k] * search[k]; jv[r] = s; }
+        FOR_G(i, nv) { sn += search[i] * search[i]; sMa += search[i] * Ma[i]; sq += search[i] * qfs[i]; }
+        SYNC();
+        float smv = 0.f;
+        FOR_G(i, nv) smv += search[i] * mvv[i];
+        sn = group16_sum(sn); sMa = group16_sum(sMa); sq = group16_sum(sq); smv = group16_sum(smv);
+        const float gtol = mv.tolerance * mv.ls_tolerance * sqrtf(sn) * scale;
+        const float qg0 = gauss, qg1 = sMa - sq, qg2 = 0.5f * smv;
+        // three trial steps at once: sums of the active rows' quadratics
+        auto eval3 = [&](float a0, float a1, float a2, LsPoint& o0, LsPoint& o1, LsPoint& o2) {
+          float q[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+          FOR_G(r, nefc) {
+            const float ja = jaref[r], v = jv[r], d = eD[r];
+            const float c0 = 0.5f * ja * ja * d, c1 = v * ja * d, c2 = 0.5f * v * v * d;
+            if (ja + a0 * v < 0.f) { q[0] += c0; q[1] += c1; q[2] += c2; }
+            if (ja + a1 * v < 0.f) { q[3] += c0; q[4] += c1; q[5] += c2; }
+            if (ja + a2 * v < 0.f) { q[6] += c0; q[7] += c1; q[8] += c2; }
+          }
+          for (int k = 0; k < 9; ++k) q[k] = group16_sum(q[k]);
+          o0 = ls_make(a0, q[0] + qg0, q[1] + qg1, q[2] + qg2);
+          o1 = ls_make(a1, q[3] + qg0, q[4] + qg1, q[5] + qg2);
+          o2 = ls_make(a2, q[6] + qg0, q[7] + qg1, q[8] + qg2);
+        };
+        LsPoint p0, lo, hi, tmpa, tmpb;
+        eval3(0.f, 0.f, 0.f, p0, tmpa, tmpb);
+        eval3(p0.alpha - p0.d0 / p0.d1, 0.f, 0.f, lo, tmpa, tmpb);
+        {
+          const bool lesser = lo.d0 < p0.d0;
+          const LsPoint nlo = ls_sel(lesser, lo, p0), nhi = ls_sel(lesser, p0, lo);
+          lo = nlo; hi = nhi;
+        }
+        bool swap = true;
+        int ls_iter = 0;
+        for (int li = 0; li < mv.ls_iterations; ++li) {
+          const bool done = (ls_iter >= mv.ls_iterations) || !swap || ((lo.d0 < 0.f) && (lo.d0 > -gtol)) || ((hi.d0 > 0.f) && (hi.d0 < gtol));
+          const bool go = !done && run;
+          if (!wave_any(go)) break;
+          LsPoint lo_next, hi_next, mid;
+          eval3(lo.alpha - lo.d0 / lo.d1, hi.alpha - hi.d0 / hi.d1, 0.5f * (lo.alpha + hi.alpha), lo_next, hi_next, mid);
+          LsPoint nlo = lo, nhi = hi;
+          const bool s1 = in_bracket(nlo, lo_next); nlo = ls_sel(s1, lo_next, nlo);
+          const bool s2 = in_bracket(nlo, mid);     nlo = ls_sel(s2, mid, nlo);
+          const bool s3 = in_bracket(nlo, hi_next); nlo = ls_sel(s3, hi_next, nlo);
+          const bool s4 = in_bracket(nhi, hi_next); nhi = ls_sel(s4, hi_next, nhi);
+          const bool s5 = in_bracket(nhi, mid);     nhi = ls_sel(s5, mid, nhi);
+          const bool s6 = in_bracket(nhi, lo_next); nhi = ls_sel(s6, lo_next, nhi);
+          if (go) { lo = nlo; hi = nhi; swap = s1 || s2 || s3 || s4 || s5 || s6; ls_iter += 1; }
+        }
+        const bool improved = (lo.cost < p0.cost) || (hi.cost < p0.cost);
+        const float alpha = (lo.cost < hi.cost) ? lo.alpha : hi.alpha;
+        if (improved && run) {
+          FOR_G(i, nv) { qacc[i] += alpha * search[i]; Ma[i] += alpha * mvv[i]; }
+          FOR_G(r, nefc) jaref[r] += alpha * jv[r];
+        }
+        SYNC();
+        // ---------------- update_constraint, update_gradient, Polak-Ribiere ----------------
+        FOR_G(i, nv) { t1[i] = Mgrad[i]; }  // previous Mgrad (previous grad is re-read below before being overwritten)
+        FOR_G(r, nefc) { const float x = jaref[r]; force[r] = x < 0.f ? -eD[r] * x : 0.f; }
+        SYNC();
+        float gs = 0.f, cs = 0.f, pgm = 0.f;
+        FOR_G(i, nv) gs += (Ma[i] - qfs[i]) * (qacc[i] - qas[i]);
+        FOR_G(r, nefc) { const float x = jaref[r]; if (x < 0.f) cs += eD[r] * x * x; }
+        FOR_G(i, nv) pgm += grad[i] * Mgrad[i];
+        gs = 0.5f * group16_sum(gs);
+        cs = 0.5f * group16_sum(cs) + gs;
+        pgm = group16_sum(pgm);
+        if (run) { prev_cost = cost; cost = cs; gauss = gs; }
+        FOR_G(i, nv) {
+          float s = 0.f;
+          for (int r = 0; r < nefc; ++r) s += J[r * ldj + i] * force[r];
+          if (run) { qfc[i] = s; grad[i] = Ma[i] - qfs[i] - s; }
+        }
+        SYNC();
+        solve_linv(Li, ldm, nv, grad, t0, mvv, g);  // candidate Mgrad (mvv is free again)
+        float num = 0.f;
+        FOR_G(i, nv) num += grad[i] * (mvv[i] - t1[i]);
+        num = group16_sum(num);
+        const float beta = fmaxf(0.f, num / fmaxf(MJ_MINVAL, pgm));
+        if (run) {
+          FOR_G(i, nv) { Mgrad[i] = mvv[i]; search[i] = -mvv[i] + beta * search[i]; }
+          niter += 1;
+        }
+        SYNC();
+      }
+    }
+    niter_out = niter;
+    // ---- probe outputs (parity tests) ---------------------------------------------------------------------
+    if (a.mode == 2 && valid) {
+      const mppo_forward_probe_t& pr = a.probe;
+      if (pr.qM) FOR_G(i, nv) for (int k = 0; k < nv; ++k) pr.qM[((size_t)env * nv + i) * nv + k] = M[i * ldm + k];
+      if (pr.qfrc_actuator) FOR_G(i, nv) pr.qfrc_actuator[(size_t)env * nv + i] = qact[i];
+      if (pr.qacc_smooth) FOR_G(i, nv) pr.qacc_smooth[(size_t)env * nv + i] = qas[i];
+      if (pr.qacc) FOR_G(i, nv) pr.qacc[(size_t)env * nv + i] = qacc[i];
+      if (pr.efc_J) FOR_G(r, nefc) for (int k = 0; k < nv; ++k) pr.efc_J[((size_t)env * nefc + r) * nv + k] = J[r * ldj + k];
+      if (pr.efc_D) FOR_G(r, nefc) pr.efc_D[(size_t)env * nefc + r] = eD[r];
+      if (pr.efc_aref) FOR_G(r, nefc) pr.efc_aref[(size_t)env * nefc + r] = earef[r];
+      if (pr.cinert) FOR_G(i, nb * 10) pr.cinert[(size_t)env * nb * 10 + i] = cinert[i];
+      if (pr.cvel) FOR_G(i, nb * 6) pr.cvel[(size_t)env * nb * 6 + i] = cvel[i];
+      if (pr.xpos) FOR_G(i, nb * 3) pr.xpos[(size_t)env * nb * 3 + i] = xpos[i];
+      if (pr.subtree_com1 && g == 0) pr.subtree_com1[env] = new_comx;
+      if (pr.solver_niter && g == 0) pr.solver_niter[env] = niter;
+    }
+    if (a.mode == 0) break;  // pipeline_init = forward only
+    // ================= euler: implicit damping, semi-implicit integration ====================================
+    FOR_G(i, nv) t1[i] = qfs[i] + qfc[i];
+    SYNC();
+    solve_linv(Le, ldm, nv, t1, t0, mvv, g);  // mvv = (M + h D)^-1 (qfrc_smooth + qfrc_constraint)
+    if (a.mode == 2) {
+      if (valid && a.probe.qacc_euler) FOR_G(i, nv) a.probe.qacc_euler[(size_t)env * nv + i] = mvv[i];
+      break;
+    }
+    FOR_G(i, nv) { qvel[i] += h * mvv[i]; warm[i] = qacc[i]; }  // qacc_warmstart <- solver qacc
+    SYNC();
+    FOR_G(j, njnt) {
+      const int qa = mv.jnt_qposadr[j], da = mv.jnt_dofadr[j];
+      if (mv.jnt_type[j] == JNT_FREE) {
+        for (int k = 0; k < 3; ++k) qpos[qa + k] += h * qvel[da + k];
+        const V3 w = ld3(qvel + da + 3);
+        const float n = sqrtf(dot3(w, w));
+        const V3 ax = n > 0.f ? mul3(w, 1.f / n) : w;
+        st4(qpos + qa + 3, qnormalize(qmul(ld4(qpos + qa + 3), axis_angle(ax, n * h))));
+      } else {
+        qpos[qa] += h * qvel[da];
+      }
+    }
+    SYNC();
+  }
+
+  if (a.mode == 2) return;
+
+  // ================= epilogue: observation, reward, done, auto-reset, metrics, new record ====================
+  // The new record's derived fields (cinert, cvel, qfrc_actuator, subtree_com) are those of the LAST forward
+  // pass, i.e. they belong to the pre-integration pose: exactly what the MJX data carries.
+  float* recw = a.state + (size_t)env * mv.rec_dim;
+  if (a.mode == 0) {
+    // reset: record = [qpos0, 0, cinert[1:], cvel[1:], qfrc_actuator | pad | qacc_warmstart = qacc | com_x | time = 0]
+    const int o_ci = nq + nv, o_cv = o_ci + 10 * (nb - 1), o_qa = o_cv + 6 * (nb - 1);
+    FOR_G(i, mv.rec_dim) {
+      float v = 0.f;
+      if (i < nq) v = qpos[i];
+      else if (i < o_ci) v = 0.f;
+      else if (i < o_cv) v = cinert[10 + (i - o_ci)];
+      else if (i < o_qa) v = cvel[6 + (i - o_cv)];
+      else if (i < O) v = qact[i - o_qa];
+      else if (i < OP) v = 0.f;
+      else if (i < OP + nv) v = qacc[i - OP];
+      else if (i == OP + nv) v = new_comx;
+      if (valid) {
+        recw[i] = v;
+        if (env == 0 && a.reset_out) a.reset_out[i] = v;
+        if (i < OP && a.obs) a.obs[(size_t)env * a.obs_ld + i] = v;
+      }
+    }
+    if (valid && g == 0) {
+      if (a.reward) a.reward[env] = 0.f;
+      if (a.done) a.done[env] = 0;
+      if (a.met.episode_returns) {
+        a.met.episode_returns[env] = 0.f; a.met.episode_lengths[env] = 0; a.met.returned_episode_returns[env] = 0.f;
+        a.met.returned_episode_lengths[env] = 0; a.met.timestep[env] = 0; a.met.returned_episode[env] = 0;
+      }
+    }
+    return;
+  }
+  // ---- step ----
+  float asq = 0.f;
+  FOR_G(i, nu) { const float c = a.action[(size_t)env * a.act_ld + i]; asq += c * c; }
+  asq = group16_sum(asq);
+  const mppo_reward_cfg_t& rc = a.rc;
+  const float pos_r = expf(-rc.exp_coefficient * pre_p0) - rc.subtraction_factor * fminf(fmaxf(pre_p0, 0.f), rc.max_diff_norm);
+  float healthy = pre_z < rc.height_min_z ? 0.f : 1.f;
+  healthy = pre_z > rc.height_max_z ? 0.f : healthy;
+  const float dt_env = h * (float)a.n_frames;
+  const float vel = (new_comx - pre_comx) / dt_env;
+  const float reward = rc.w_ctrl_cost * (-asq) + rc.w_original_pos * pos_r + rc.w_velocity * vel + rc.w_is_healthy * healthy;
+  // done: height window on the POST-step state (env.py:171,238-242) or any NaN in the stepped state (env.py:173-176)
+  const float z = qpos[2];
+  bool bad = false;
+  FOR_G(i, nq) bad = bad || isnan(qpos[i]);
+  FOR_G(i, nv) bad = bad || isnan(qvel[i]) || isnan(warm[i]) || isnan(qact[i]);
+  FOR_G(i, 10 * nb) bad = bad || isnan(cinert[i]);
+  FOR_G(i, 6 * nb) bad = bad || isnan(cvel[i]);
+  bad = bad || isnan(new_comx);
+  const bool done = !((rc.height_min_z < z) && (z < rc.height_max_z)) || group16_any(bad);
+  const int o_ci = nq + nv, o_cv = o_ci + 10 * (nb - 1), o_qa = o_cv + 6 * (nb - 1);
+  FOR_G(i, mv.rec_dim) {
+    // observation = the PRE-step record (env.py:163, quirk C-5), or the reset observation when done (env.py:180)
+    const float old = recw[i];
+    const float rst = a.reset_in[i];
+    float v = 0.f;
+    if (i < nq) v = qpos[i];
+    else if (i < o_ci) v = qvel[i - nq];
+    else if (i < o_cv) v = cinert[10 + (i - o_ci)];
+    else if (i < o_qa) v = cvel[6 + (i - o_cv)];
+    else if (i < O) v = qact[i - o_qa];
+    else if (i < OP) v = 0.f;
+    else if (i < OP + nv) v = warm[i - OP];
+    else if (i == OP + nv) v = new_comx;
+    else if (i == OP + nv + 1) v = time_in + dt_env;
+    if (valid) {
+      if (i < OP) a.obs[(size_t)env * a.obs_ld + i] = done ? rst : old;
+      recw[i] = done ? rst : v;
+    }
+  }
+  if (valid && g == 0) {
+    a.reward[env] = reward;
+    a.done[env] = done ? 1 : 0;
+    if (a.met.episode_returns) {
+      const float nd = done ? 0.f : 1.f;
+      const int ndi = done ? 0 : 1;
+      const float new_ret = a.met.episode_returns[env] + reward;
+      const int new_len = a.met.episode_lengths[env] + 1;
+      a.met.episode_returns[env] = new_ret * nd;
+      a.met.episode_lengths[env] = new_len * ndi;
+      a.met.returned_episode_returns[env] = a.met.returned_episode_returns[env] * nd + new_ret * (done ? 1.f : 0.f);
+      a.met.returned_episode_lengths[env] = a.met.returned_episode_lengths[env] * ndi + new_len * (done ? 1 : 0);
+      a.met.timestep[env] = a.met.timestep[env] + 1;
+      a.met.returned_episode[env] = done ? 1 : 0;
+    }
+  }
+}
+
+}  // namespace mppo
+
+// =================================================================================================
+// host side: model handle + launch wrappers (C ABI)
+// =================================================================================================
+struct mppo_model {
+  mppo::ModelView mv;
+  mppo::PhysLds lds;
+  int lds_bytes;
+};
+
+namespace mppo {
+const ModelView& model_view(const mppo_model* m) { return m->mv; }
+}
+
+extern "C" int32_t mppo_model_open(const void* host_blob, size_t nbytes, const void* dev_blob, mppo_model_t** out) {
+  using namespace mppo;
+  if (!host_blob || !dev_blob || !out) return fail(MPPO_EINVAL, "mppo_model_open: null argument");
+  if (nbytes < 4 * (size_t)kBlobHeaderWords || (nbytes & 3)) return fail(MPPO_EMODEL, "model blob too small or not word-sized (%zu bytes)", nbytes);
+  if ((reinterpret_cast<uintptr_t>(dev_blob) & 15) != 0) return fail(MPPO_EINVAL, "device blob must be 16-byte aligned");
+  const uint32_t* w = static_cast<const uint32_t*>(host_blob);
+  const int32_t* wi = static_cast<const int32_t*>(host_blob);
+  const float* wf = static_cast<const float*>(host_blob);
+  if (w[0] != kBlobMagic) return fail(MPPO_EMODEL, "bad model blob magic 0x%08x", w[0]);
+  if (w[1] != kBlobVersion) return fail(MPPO_EMODEL, "unsupported model blob version %u", w[1]);
+  const size_t total = w[2];
+  if (total * 4 != nbytes) return fail(MPPO_EMODEL, "model blob size mismatch: header says %zu words, got %zu bytes", total, nbytes);
+  if (wi[32] != BLOB_ARRAY_COUNT) return fail(MPPO_EMODEL, "model blob has %d arrays, engine expects %d", wi[32], (int)BLOB_ARRAY_COUNT);
+  mppo_model* m = new mppo_model();
+  ModelView& v = m->mv;
+  v.nq = wi[3]; v.nv = wi[4]; v.nu = wi[5]; v.nbody = wi[6]; v.njnt = wi[7]; v.ncon = wi[8]; v.nlimit = wi[9];
+  v.iterations = wi[10]; v.ls_iterations = wi[11]; v.nlevel = wi[12]; v.nroot = wi[13];
+  v.nefc = v.nlimit + 4 * v.ncon;
+  v.timestep = wf[16]; v.tolerance = wf[17]; v.ls_tolerance = wf[18]; v.impratio = wf[19]; v.plane_z = wf[20]; v.meaninertia = wf[21];
+  auto bad = [&](const char* what) { delete m; return fail(MPPO_EMODEL, "model blob: %s", what); };
+  if (v.nq < 1 || v.nv < 1 || v.nbody < 2 || v.nbody > 64 || v.nv > 64 || v.nq > 128 || v.nu < 0 || v.nu > v.nv || v.njnt < 1 ||
+      v.ncon < 0 || v.nlimit < 0 || v.nroot < 1 || v.nlevel < 1 || v.iterations < 0 || v.ls_iterations < 0)
+    return bad("dimension out of the supported range (nbody<=64, nv<=64)");
+  if (!(v.timestep > 0.f) || !(v.meaninertia > 0.f) || !(v.impratio > 0.f)) return bad("non-positive timestep / meaninertia / impratio");
+  const int32_t* dir = wi + kBlobHeaderWords;
+  const size_t expect[BLOB_ARRAY_COUNT] = {
+      (size_t)v.nbody, (size_t)v.nbody, (size_t)v.nbody, (size_t)v.nbody, (size_t)v.nbody, (size_t)v.nbody, (size_t)v.nbody,
+      (size_t)v.njnt, (size_t)v.njnt, (size_t)v.njnt, (size_t)v.njnt, (size_t)v.njnt,
+      (size_t)v.nv, (size_t)v.nv, (size_t)v.nv,
+      (size_t)v.nu, (size_t)v.nu, (size_t)v.nu, (size_t)v.nu,
+      (size_t)v.ncon, (size_t)v.nlimit,
+      (size_t)v.nlevel + 1, (size_t)v.nbody - 1, (size_t)v.nroot, 2 * (size_t)v.nbody, 2 * (size_t)v.nbody, 2 * (size_t)v.nv, (size_t)v.nv,
+      3, 3 * (size_t)v.nbody, 4 * (size_t)v.nbody, 3 * (size_t)v.nbody, 4 * (size_t)v.nbody, (size_t)v.nbody, 3 * (size_t)v.nbody,
+      3 * (size_t)v.njnt, 3 * (size_t)v.njnt, 2 * (size_t)v.njnt, (size_t)v.njnt,
+      (size_t)v.nv, (size_t)v.nv, (size_t)v.nv, 2 * (size_t)v.nbody,
+      (size_t)v.nq, (size_t)v.nq,
+      (size_t)v.nu, (size_t)v.nu, 3 * (size_t)v.nu, 2 * (size_t)v.nu, 2 * (size_t)v.nu,
+      3 * (size_t)v.ncon, (size_t)v.ncon, 3 * (size_t)v.ncon,
+      2, 5, 2, 5};
+  const size_t dir_end = kBlobHeaderWords + 2 * (size_t)BLOB_ARRAY_COUNT;
+  if (dir_end > total) return bad("directory past the end");
+  for (int k = 0; k < BLOB_ARRAY_COUNT; ++k) {
+    const long off = dir[2 * k], cnt = dir[2 * k + 1];
+    if (off < (long)dir_end || cnt < 0 || (size_t)(off + cnt) > total || (off & 3)) return bad("array directory entry out of range");
+    if ((size_t)cnt != expect[k]) { delete m; return fail(MPPO_EMODEL, "model blob: array %d has %ld entries, expected %zu", k, cnt, expect[k]); }
+  }
+  auto HI = [&](int k) { return wi + dir[2 * k]; };
+  // index tables are validated here so that the kernel never dereferences out of range
+  auto in_range = [&](int k, long lo, long hi_excl) {
+    const int32_t* p = HI(k);
+    for (long i = 0; i < dir[2 * k + 1]; ++i) if (p[i] < lo || p[i] >= hi_excl) return false;
+    return true;
+  };
+  if (!in_range(BI_body_parent, 0, v.nbody) || !in_range(BI_body_rootid, 0, v.nbody) || !in_range(BI_jnt_bodyid, 1, v.nbody) ||
+      !in_range(BI_jnt_qposadr, 0, v.nq) || !in_range(BI_jnt_dofadr, 0, v.nv) || !in_range(BI_dof_bodyid, 1, v.nbody) ||
+      !in_range(BI_dof_jntid, 0, v.njnt) || !in_range(BI_dof_parentid, -1, v.nv) || !in_range(BI_dof_qposadr, -1, v.nq) ||
+      !in_range(BI_act_dofid, 0, v.nv) || !in_range(BI_act_qposadr, 0, v.nq) || !in_range(BI_con_bodyid, 1, v.nbody) ||
+      !in_range(BI_lim_jntid, 0, v.njnt) || !in_range(BI_level_adr, 0, v.nbody) || !in_range(BI_level_body, 1, v.nbody) ||
+      !in_range(BI_root_body, 1, v.nbody) || !in_range(BI_body_jntnum, 0, v.njnt + 1) || !in_range(BI_body_jntadr, -1, v.njnt))
+    return bad("index table entry out of range");
+  {
+    const int32_t *jt = HI(BI_jnt_type), *qa = HI(BI_jnt_qposadr), *da = HI(BI_jnt_dofadr), *jn = HI(BI_body_jntnum), *ja = HI(BI_body_jntadr),
+                  *par = HI(BI_body_parent), *dp = HI(BI_dof_parentid), *la = HI(BI_level_adr);
+    for (int j = 0; j < v.njnt; ++j) {
+      if (jt[j] != JNT_FREE && jt[j] != JNT_HINGE && jt[j] != JNT_SLIDE) return bad("unsupported joint type");
+      if (jt[j] == JNT_FREE && (qa[j] + 7 > v.nq || da[j] + 6 > v.nv)) return bad("free joint address out of range");
+    }
+    for (int b = 1; b < v.nbody; ++b) {
+      if (par[b] >= b) return bad("bodies are not topologically ordered");
+      if (jn[b] > 0 && (ja[b] < 0 || ja[b] + jn[b] > v.njnt)) return bad("body joint range out of bounds");
+    }
+    for (int d = 0; d < v.nv; ++d) if (dp[d] >= d) return bad("dof_parentid must point to an earlier dof");
+    for (int l = 0; l < v.nlevel; ++l) if (la[l + 1] < la[l] || la[l + 1] > v.nbody - 1) return bad("level_adr not monotone");
+    if (HI(BI_root_body)[0] != 1) return bad("body 1 must be the first tree root");
+    if (v.nq < 3) return bad("nq < 3: the height test reads qpos[2] (env.py:239)");
+  }
+  const int32_t* dI = static_cast<const int32_t*>(dev_blob);
+  const float* dF = static_cast<const float*>(dev_blob);
+  auto DI = [&](int k) { return dI + dir[2 * k]; };
+  auto DF = [&](int k) { return dF + dir[2 * k]; };
+  auto DU = [&](int k) { return reinterpret_cast<const u64*>(dI + dir[2 * k]); };
+  v.body_parent = DI(BI_body_parent); v.body_rootid = DI(BI_body_rootid); v.body_jntadr = DI(BI_body_jntadr); v.body_jntnum = DI(BI_body_jntnum);
+  v.body_dofadr = DI(BI_body_dofadr); v.body_dofnum = DI(BI_body_dofnum);
+  v.jnt_type = DI(BI_jnt_type); v.jnt_qposadr = DI(BI_jnt_qposadr); v.jnt_dofadr = DI(BI_jnt_dofadr); v.jnt_bodyid = DI(BI_jnt_bodyid);
+  v.dof_bodyid = DI(BI_dof_bodyid); v.dof_jntid = DI(BI_dof_jntid); v.dof_parentid = DI(BI_dof_parentid); v.dof_qposadr = DI(BI_dof_qposadr);
+  v.act_dofid = DI(BI_act_dofid); v.act_qposadr = DI(BI_act_qposadr); v.act_ctrllimited = DI(BI_act_ctrllimited); v.act_forcelimited = DI(BI_act_forcelimited);
+  v.con_bodyid = DI(BI_con_bodyid); v.lim_jntid = DI(BI_lim_jntid); v.level_adr = DI(BI_level_adr); v.level_body = DI(BI_level_body); v.root_body = DI(BI_root_body);
+  v.body_subtree_mask = DU(BI_body_subtree_mask); v.body_ancdof_mask = DU(BI_body_ancdof_mask); v.dof_velmask = DU(BI_dof_velmask);
+  v.gravity = DF(BF_gravity); v.body_pos = DF(BF_body_pos); v.body_quat = DF(BF_body_quat); v.body_ipos = DF(BF_body_ipos); v.body_iquat = DF(BF_body_iquat);
+  v.body_mass = DF(BF_body_mass); v.body_inertia = DF(BF_body_inertia);
+  v.jnt_pos = DF(BF_jnt_pos); v.jnt_axis = DF(BF_jnt_axis); v.jnt_range = DF(BF_jnt_range); v.jnt_stiffness = DF(BF_jnt_stiffness);
+  v.dof_armature = DF(BF_dof_armature); v.dof_damping = DF(BF_dof_damping); v.dof_invweight0 = DF(BF_dof_invweight0); v.body_invweight0 = DF(BF_body_invweight0);
+  v.qpos0 = DF(BF_qpos0); v.qpos_spring = DF(BF_qpos_spring);
+  v.act_gear = DF(BF_act_gear); v.act_gain = DF(BF_act_gain); v.act_bias = DF(BF_act_bias); v.act_ctrlrange = DF(BF_act_ctrlrange); v.act_forcerange = DF(BF_act_forcerange);
+  v.con_lpos = DF(BF_con_lpos); v.con_radius = DF(BF_con_radius); v.con_friction = DF(BF_con_friction);
+  v.contact_solref = DF(BF_contact_solref); v.contact_solimp = DF(BF_contact_solimp); v.limit_solref = DF(BF_limit_solref); v.limit_solimp = DF(BF_limit_solimp);
+  v.obs_dim = v.nq + 2 * v.nv + 16 * (v.nbody - 1);
+  v.obs_pad = (v.obs_dim + 3) & ~3;
+  v.rec_dim = v.obs_pad + ((v.nv + 2 + 3) & ~3);
+  m->lds = make_phys_lds(v.nq, v.nv, v.nu, v.nbody, v.njnt, v.ncon, v.nefc, v.nroot);
+  m->lds_bytes = m->lds.total * 4 * kEnvsPerBlock;
+  if (m->lds_bytes > 160 * 1024) { delete m; return fail(MPPO_EMODEL, "model needs %d bytes of LDS per workgroup (limit 163840)", m->lds_bytes); }
+  *out = m;
+  return MPPO_OK;
+}
+
+extern "C" int32_t mppo_model_close(mppo_model_t* m) {
+  delete m;
+  return MPPO_OK;
+}
+
+extern "C" int32_t mppo_model_get_dims(const mppo_model_t* m, mppo_model_dims_t* o) {
+  if (!m || !o) return mppo::fail(MPPO_EINVAL, "mppo_model_get_dims: null argument");
+  const mppo::ModelView& v = m->mv;
+  o->nq = v.nq; o->nv = v.nv; o->nu = v.nu; o->nbody = v.nbody; o->njnt = v.njnt; o->ncon = v.ncon; o->nlimit = v.nlimit; o->nefc = v.nefc;
+  o->obs_dim = v.obs_dim; o->obs_pad = v.obs_pad; o->rec_dim = v.rec_dim; o->lds_bytes = m->lds_bytes; o->timestep = v.timestep;
+  return MPPO_OK;
+}
+
+namespace mppo {
+static int32_t launch_env(const mppo_model_t* m, const EnvArgs& a, hipStream_t stream) {
+  static thread_local bool attr_set = false;
+  if (!attr_set && m->lds_bytes > 64 * 1024) {
+    MPPO_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(env_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, m->lds_bytes));
+    attr_set = true;
+  }
+  const int blocks = cdiv(a.N, kEnvsPerBlock);
+  hipLaunchKernelGGL(env_kernel, dim3(blocks), dim3(kEnvBlock), m->lds_bytes, stream, m->mv, a, m->lds);
+  MPPO_CHECK_LAUNCH("env_kernel");
+  return MPPO_OK;
+}
+}  // namespace mppo
+
+extern "C" int32_t mppo_env_reset(const mppo_model_t* m, int32_t N, float* state, float* reset_rec, float* obs, int32_t obs_ld,
+                                  float* reward, uint8_t* done, const mppo_env_metrics_t* metrics, void* stream) {
+  using namespace mppo;
+  MPPO_REQUIRE(m && state && reset_rec, "mppo_env_reset: null model / state / reset_rec");
+  MPPO_REQUIRE(N >= 1, "mppo_env_reset: N = %d", N);
+  MPPO_REQUIRE(!obs || obs_ld >= m->mv.obs_pad, "mppo_env_reset: obs_ld %d < padded observation width %d", obs_ld, m->mv.obs_pad);
+  EnvArgs a{};
+  a.N = N; a.mode = 0; a.n_frames = 1; a.state = state; a.reset_out = reset_rec; a.obs = obs; a.obs_ld = obs_ld; a.reward = reward; a.done = done;
+  if (metrics) a.met = *metrics;
+  return launch_env(m, a, static_cast<hipStream_t>(stream));
+}
+
+extern "C" int32_t mppo_env_step(const mppo_model_t* m, int32_t N, int32_t n_frames, const mppo_reward_cfg_t* rc, float* state,
+                                 const float* reset_rec, const float* action, int32_t act_ld, float* obs, int32_t obs_ld, float* reward,
+                                 uint8_t* done, const mppo_env_metrics_t* metrics, void* stream) {
+  using namespace mppo;
+  MPPO_REQUIRE(m && rc && state && reset_rec && action && obs && reward && done, "mppo_env_step: null argument");
+  MPPO_REQUIRE(N >= 1 && n_frames >= 1, "mppo_env_step: N = %d, n_frames = %d", N, n_frames);
+  MPPO_REQUIRE(act_ld >= m->mv.nu, "mppo_env_step: act_ld %d < nu %d", act_ld, m->mv.nu);
+  MPPO_REQUIRE(obs_ld >= m->mv.obs_pad, "mppo_env_step: obs_ld %d < padded observation width %d", obs_ld, m->mv.obs_pad);
+  EnvArgs a{};
+  a.N = N; a.mode = 1; a.n_frames = n_frames; a.state = state; a.reset_in = reset_rec; a.action = action; a.act_ld = act_ld;
+  a.obs = obs; a.obs_ld = obs_ld; a.reward = reward; a.done = done; a.rc = *rc;
+  if (metrics) a.met = *metrics;
+  return launch_env(m, a, static_cast<hipStream_t>(stream));
+}
+
+extern "C" int32_t mppo_physics_forward(const mppo_model_t* m, int32_t N, const float* qpos, const float* qvel, const float* ctrl,
+                                        const float* qacc_warmstart, const mppo_forward_probe_t* out, void* stream) {
+  using namespace mppo;
+  MPPO_REQUIRE(m && qpos && qvel && qacc_warmstart && out, "mppo_physics_forward: null argument");
+  MPPO_REQUIRE(ctrl || m->mv.nu == 0, "mppo_physics_forward: ctrl is null but the model has actuators");
+  MPPO_REQUIRE(N >= 1, "mppo_physics_forward: N = %d", N);
+  EnvArgs a{};
+  a.N = N; a.mode = 2; a.n_frames = 1; a.p_qpos = qpos; a.p_qvel = qvel; a.p_ctrl = ctrl; a.p_warm = qacc_warmstart; a.probe = *out;
+  return launch_env(m, a, static_cast<hipStream_t>(stream));
+}

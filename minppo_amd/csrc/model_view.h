@@ -1,0 +1,103 @@
+// ModelView: the robot model as the physics kernel sees it (dims + device pointers into the
+// blob), and the per-environment LDS layout derived from the dims.
+// Blob layout: minppo_amd/model.py (_to_blob).  Array order must match _BLOB_INT + _BLOB_F32.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+namespace mppo {
+
+enum BlobInt {
+  BI_body_parent, BI_body_rootid, BI_body_depth, BI_body_jntadr, BI_body_jntnum, BI_body_dofadr, BI_body_dofnum,
+  BI_jnt_type, BI_jnt_qposadr, BI_jnt_dofadr, BI_jnt_bodyid, BI_jnt_limited,
+  BI_dof_bodyid, BI_dof_jntid, BI_dof_parentid,
+  BI_act_dofid, BI_act_qposadr, BI_act_ctrllimited, BI_act_forcelimited,
+  BI_con_bodyid, BI_lim_jntid,
+  BI_level_adr, BI_level_body, BI_root_body, BI_body_subtree_mask, BI_body_ancdof_mask, BI_dof_velmask, BI_dof_qposadr,
+  BI_COUNT
+};
+enum BlobF32 {
+  BF_gravity = BI_COUNT, BF_body_pos, BF_body_quat, BF_body_ipos, BF_body_iquat, BF_body_mass, BF_body_inertia,
+  BF_jnt_pos, BF_jnt_axis, BF_jnt_range, BF_jnt_stiffness,
+  BF_dof_armature, BF_dof_damping, BF_dof_invweight0, BF_body_invweight0,
+  BF_qpos0, BF_qpos_spring,
+  BF_act_gear, BF_act_gain, BF_act_bias, BF_act_ctrlrange, BF_act_forcerange,
+  BF_con_lpos, BF_con_radius, BF_con_friction,
+  BF_contact_solref, BF_contact_solimp, BF_limit_solref, BF_limit_solimp,
+  BLOB_ARRAY_COUNT
+};
+
+constexpr uint32_t kBlobMagic = 0x4D50504F;
+constexpr uint32_t kBlobVersion = 1;
+constexpr int kBlobHeaderWords = 64;
+constexpr int JNT_FREE = 0, JNT_HINGE = 2, JNT_SLIDE = 3;
+constexpr float MJ_MINVAL = 1e-15f, MJ_MINIMP = 0.0001f, MJ_MAXIMP = 0.9999f;
+
+typedef unsigned long long u64;
+
+struct ModelView {
+  int nq, nv, nu, nbody, njnt, ncon, nlimit, nefc, iterations, ls_iterations, nlevel, nroot;
+  int obs_dim, obs_pad, rec_dim;
+  float timestep, tolerance, ls_tolerance, impratio, plane_z, meaninertia;
+  const int *body_parent, *body_rootid, *body_jntadr, *body_jntnum, *body_dofadr, *body_dofnum;
+  const int *jnt_type, *jnt_qposadr, *jnt_dofadr, *jnt_bodyid;
+  const int *dof_bodyid, *dof_jntid, *dof_parentid, *dof_qposadr;
+  const int *act_dofid, *act_qposadr, *act_ctrllimited, *act_forcelimited;
+  const int *con_bodyid, *lim_jntid, *level_adr, *level_body, *root_body;
+  const u64 *body_subtree_mask, *body_ancdof_mask, *dof_velmask;
+  const float *gravity, *body_pos, *body_quat, *body_ipos, *body_iquat, *body_mass, *body_inertia;
+  const float *jnt_pos, *jnt_axis, *jnt_range, *jnt_stiffness;
+  const float *dof_armature, *dof_damping, *dof_invweight0, *body_invweight0, *qpos0, *qpos_spring;
+  const float *act_gear, *act_gain, *act_bias, *act_ctrlrange, *act_forcerange;
+  const float *con_lpos, *con_radius, *con_friction;
+  const float *contact_solref, *contact_solimp, *limit_solref, *limit_solimp;
+};
+
+// Per-environment LDS layout (offsets in floats).  Region "A" is time-shared: kinematics
+// temporaries and the RNE scratch live there until the constraint Jacobian is built.
+struct PhysLds {
+  int qpos, qvel, ctrl, warm;
+  int xpos, xquat, xipos, rootcom;
+  int cinert, cdof, cvel;
+  int M, Li, Le, ldm;
+  int qfs, qas, qact, qacc, Ma, grad, Mgrad, search, mv, qfc, t0, t1;
+  int D, aref, jaref, jv, force;
+  int conpos, condist;
+  int A, ximat, xmat, xanchor, xaxis, C1, C2, cdofdot, cfrc, J, ldj;
+  int total;
+};
+
+__host__ __device__ inline int imax_(int a, int b) { return a > b ? a : b; }
+
+__host__ __device__ inline PhysLds make_phys_lds(int nq, int nv, int nu, int nbody, int njnt, int ncon, int nefc, int nroot) {
+  PhysLds p;
+  int o = 0;
+  auto take = [&](int n) { int r = o; o += (n + 3) & ~3; return r; };
+  p.qpos = take(nq); p.qvel = take(nv); p.ctrl = take(nu > 0 ? nu : 1); p.warm = take(nv);
+  p.xpos = take(3 * nbody); p.xquat = take(4 * nbody); p.xipos = take(3 * nbody); p.rootcom = take(3 * (nroot > 0 ? nroot : 1));
+  p.cinert = take(10 * nbody); p.cdof = take(6 * nv); p.cvel = take(6 * nbody);
+  p.ldm = nv + 1;
+  p.M = take(nv * p.ldm); p.Li = take(nv * p.ldm); p.Le = take(nv * p.ldm);
+  p.qfs = take(nv); p.qas = take(nv); p.qact = take(nv); p.qacc = take(nv); p.Ma = take(nv); p.grad = take(nv);
+  p.Mgrad = take(nv); p.search = take(nv); p.mv = take(nv); p.qfc = take(nv); p.t0 = take(nv); p.t1 = take(nv);
+  const int ne = nefc > 0 ? nefc : 1;
+  p.D = take(ne); p.aref = take(ne); p.jaref = take(ne); p.jv = take(ne); p.force = take(ne);
+  p.conpos = take(3 * (ncon > 0 ? ncon : 1)); p.condist = take(ncon > 0 ? ncon : 1);
+  // region A, four lifetimes (separated by workgroup barriers in the kernel):
+  //   A1 kinematics temporaries | A2 Cholesky work copies | A3 velocity/RNE scratch | A4 constraint Jacobian
+  p.A = o;
+  p.ximat = take(9 * nbody); p.xmat = take(9 * nbody); p.xanchor = take(3 * njnt); p.xaxis = take(3 * njnt);
+  int end = o;
+  o = p.A; p.C1 = take(nv * p.ldm); p.C2 = take(nv * p.ldm); end = imax_(end, o);
+  o = p.A; p.cdofdot = take(6 * nv); p.cfrc = take(6 * nbody); end = imax_(end, o);
+  o = p.A; p.ldj = nv + 1; p.J = take(ne * p.ldj); end = imax_(end, o);
+  p.total = (end + 3) & ~3;
+  return p;
+}
+
+constexpr int kGroupLanes = 16;                      // lanes that cooperate on one environment
+constexpr int kEnvBlock = 64;                        // one wavefront per workgroup
+constexpr int kEnvsPerBlock = kEnvBlock / kGroupLanes;
+
+}  // namespace mppo

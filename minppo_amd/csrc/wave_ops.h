@@ -1,0 +1,64 @@
+// wave_ops.h — the only place where gfx950 cross-lane / matrix-core builtins appear.
+// Kernels talk to the hardware through these helpers (64-wide wavefronts, DPP row
+// operations inside 16-lane rows, f32-input MFMA).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#define MPPO_DYN_SMEM(name) extern __shared__ __attribute__((aligned(16))) unsigned char name[]
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef short bf16x8 __attribute__((ext_vector_type(8)));
+
+// D(32x32) += A(32x2) * B(2x32), exact f32 (v_mfma_f32_32x32x2_f32).
+// lane l supplies A[i = l&31][k = l>>5] and B[k = l>>5][j = l&31];
+// acc[r] is D[row = (r&3) + 8*(r>>2) + 4*(l>>5)][col = l&31].
+__device__ __forceinline__ void mfma_f32_32x32x2(float a, float b, f32x16& acc) {
+  acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+}
+
+// D(32x32) += A(32x16) * B(16x32), bf16 inputs, f32 accumulate (v_mfma_f32_32x32x16_bf16).
+// lane l (r = l&31, h = l>>5) supplies A[r][k = 8h + j] and B[k = 8h + j][r], j = 0..7.
+__device__ __forceinline__ void mfma_bf16_32x32x16(bf16x8 a, bf16x8 b, f32x16& acc) {
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc, 0, 0, 0);
+}
+
+template <int CTRL>
+__device__ __forceinline__ float dpp_row(float x) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), CTRL, 0xf, 0xf, false));
+}
+
+// All-reduce inside each 16-lane DPP row: every lane of the row gets the row's sum (row_ror 8,4,2,1).
+__device__ __forceinline__ float group16_sum(float x) {
+  x += dpp_row<0x128>(x);
+  x += dpp_row<0x124>(x);
+  x += dpp_row<0x122>(x);
+  x += dpp_row<0x121>(x);
+  return x;
+}
+__device__ __forceinline__ float group16_max(float x) {
+  x = fmaxf(x, dpp_row<0x128>(x));
+  x = fmaxf(x, dpp_row<0x124>(x));
+  x = fmaxf(x, dpp_row<0x122>(x));
+  x = fmaxf(x, dpp_row<0x121>(x));
+  return x;
+}
+// true in every lane of the wave if pred holds in any lane of the wave
+__device__ __forceinline__ bool wave_any(bool pred) { return __any(pred); }
+// true in every lane of a 16-lane row if pred holds in any lane of that row
+__device__ __forceinline__ bool group16_any(bool pred) {
+  const unsigned long long m = __ballot(pred);
+  const int row = (threadIdx.x & 63) >> 4;
+  return ((m >> (16 * row)) & 0xffffull) != 0ull;
+}
+// full-wave sum, result in every lane
+__device__ __forceinline__ float wave_sum(float x) {
+  x = group16_sum(x);
+  x += __shfl_xor(x, 16);
+  x += __shfl_xor(x, 32);
+  return x;
+}
+__device__ __forceinline__ double wave_sum_f64(double x) {
+  for (int m = 1; m < 64; m <<= 1) x += __shfl_xor(x, m);
+  return x;
+}

@@ -310,6 +310,55 @@ def compile_model(spec: ModelSpec) -> CompiledModel:
     for bi in range(1, nbody):
         depth[bi] = depth[body_parent[bi]] + 1
 
+    if nbody > 64 or nv > 64:
+        raise ValueError("the physics kernel supports at most 64 bodies and 64 dofs (bitmask topology tables)")
+    # bodies grouped by depth (level-synchronous kinematics)
+    nlevel = int(depth.max()) if nbody > 1 else 0
+    level_adr = np.zeros(nlevel + 1, np.int32)
+    level_body: List[int] = []
+    for lv in range(1, nlevel + 1):
+        level_adr[lv - 1] = len(level_body)
+        level_body += [b for b in range(1, nbody) if depth[b] == lv]
+    level_adr[nlevel] = len(level_body)
+    root_body = [b for b in range(1, nbody) if body_parent[b] == 0]
+    # bitmask topology: subtree(b) as a set of bodies; ancestor-or-own dofs of body b;
+    # dofs whose motion precedes dof j in mj_comVel (used for cdof_dot)
+    subtree = np.zeros(nbody, np.uint64)
+    for b in range(nbody - 1, 0, -1):
+        subtree[b] |= np.uint64(1) << np.uint64(b)
+        subtree[body_parent[b]] |= subtree[b]
+    ancdof = np.zeros(nbody, np.uint64)
+    for b in range(1, nbody):
+        ancdof[b] = ancdof[body_parent[b]]
+        for d in range(body_dofadr[b], body_dofadr[b] + body_dofnum[b]) if body_dofnum[b] > 0 else []:
+            ancdof[b] |= np.uint64(1) << np.uint64(d)
+    velmask = np.zeros(nv, np.uint64)
+    for j in range(njnt):
+        b, da = jnt_bodyid[j], jnt_dofadr[j]
+        before = ancdof[body_parent[b]]
+        for jj in range(body_jntadr[b], j):  # earlier joints of the same body
+            nd = 6 if jnt_type[jj] == JNT_FREE else 1
+            for d in range(jnt_dofadr[jj], jnt_dofadr[jj] + nd):
+                before |= np.uint64(1) << np.uint64(d)
+        if jnt_type[j] == JNT_FREE:
+            for k in range(3):
+                velmask[da + k] = before  # value unused: translational cdof_dot is 0
+            trans = before
+            for k in range(3):
+                trans |= np.uint64(1) << np.uint64(da + k)
+            for k in range(3, 6):
+                velmask[da + k] = trans  # all three rotational cdof_dot use the velocity after translation only
+        else:
+            velmask[da] = before
+    dof_qposadr = np.full(nv, -1, np.int32)
+    for j in range(njnt):
+        if jnt_type[j] != JNT_FREE:
+            dof_qposadr[jnt_dofadr[j]] = jnt_qposadr[j]
+
+    def _m64(a):
+        a = np.asarray(a, np.uint64)
+        return np.stack([(a & np.uint64(0xFFFFFFFF)).astype(np.uint32), (a >> np.uint64(32)).astype(np.uint32)], -1).astype(np.uint32).view(np.int32).reshape(-1)
+
     # actuators (joint transmission on hinge/slide only)
     nu = len(spec.actuators)
     act_dofid = np.zeros(nu, np.int32)
@@ -376,6 +425,15 @@ def compile_model(spec: ModelSpec) -> CompiledModel:
     put("body_parent", body_parent, np.int32)
     put("body_rootid", body_rootid, np.int32)
     put("body_depth", depth, np.int32)
+    put("nlevel", nlevel, np.int32)
+    put("nroot", len(root_body), np.int32)
+    put("level_adr", level_adr, np.int32)
+    put("level_body", level_body, np.int32)
+    put("root_body", root_body, np.int32)
+    put("body_subtree_mask", _m64(subtree), np.int32)
+    put("body_ancdof_mask", _m64(ancdof), np.int32)
+    put("dof_velmask", _m64(velmask), np.int32)
+    put("dof_qposadr", dof_qposadr, np.int32)
     put("body_pos", body_pos)
     put("body_quat", body_quat)
     put("body_ipos", body_ipos)
@@ -562,6 +620,7 @@ _BLOB_INT = [
     "dof_bodyid", "dof_jntid", "dof_parentid",
     "act_dofid", "act_qposadr", "act_ctrllimited", "act_forcelimited",
     "con_bodyid", "lim_jntid",
+    "level_adr", "level_body", "root_body", "body_subtree_mask", "body_ancdof_mask", "dof_velmask", "dof_qposadr",
 ]
 _BLOB_F32 = [
     "gravity", "body_pos", "body_quat", "body_ipos", "body_iquat", "body_mass", "body_inertia",
@@ -572,7 +631,7 @@ _BLOB_F32 = [
     "con_lpos", "con_radius", "con_friction",
     "contact_solref", "contact_solimp", "limit_solref", "limit_solimp",
 ]
-_HDR_INT = ["nq", "nv", "nu", "nbody", "njnt", "ncon", "nlimit", "iterations", "ls_iterations"]
+_HDR_INT = ["nq", "nv", "nu", "nbody", "njnt", "ncon", "nlimit", "iterations", "ls_iterations", "nlevel", "nroot"]
 _HDR_F32 = ["timestep", "tolerance", "ls_tolerance", "impratio", "plane_z", "meaninertia"]
 BLOB_HEADER_WORDS = 64  # fixed-size header; array directory follows
 

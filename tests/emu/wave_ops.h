@@ -1,0 +1,105 @@
+// TEST INFRASTRUCTURE — CPU stand-in for minppo_amd/csrc/wave_ops.h (same API).
+// Cross-lane operations go through a scratch buffer bracketed by workgroup barriers.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#define MPPO_DYN_SMEM(name) unsigned char* name = ::emu::g_dyn_smem
+
+typedef float f32x16 __attribute__((vector_size(64)));
+typedef float f32x4 __attribute__((vector_size(16)));
+typedef short bf16x8 __attribute__((vector_size(16)));
+
+inline float emu_bf16_to_f32(short h) { unsigned u = ((unsigned)(unsigned short)h) << 16; float f; memcpy(&f, &u, 4); return f; }
+
+// lane l supplies A[i = l&31][k = l>>5], B[k = l>>5][j = l&31]; acc[r] = D[(r&3) + 8*(r>>2) + 4*(l>>5)][l&31]
+inline void mfma_f32_32x32x2(float a, float b, f32x16& acc) {
+  const int t = emu::tid(), lane = t & 63, wave = t >> 6;
+  float* A = reinterpret_cast<float*>(emu::g_xchg) + wave * 128;
+  float* B = A + 64;
+  A[lane] = a; B[lane] = b;
+  __syncthreads();
+  const int col = lane & 31, hi = lane >> 5;
+  for (int r = 0; r < 16; ++r) {
+    const int row = (r & 3) + 8 * (r >> 2) + 4 * hi;
+    float c = acc[r];
+    c = fmaf(A[row], B[col], c);            // k = 0
+    c = fmaf(A[32 + row], B[32 + col], c);  // k = 1
+    acc[r] = c;
+  }
+  __syncthreads();
+}
+
+// lane l (r = l&31, h = l>>5) supplies A[r][k = 8h+j], B[k = 8h+j][r], j = 0..7
+inline void mfma_bf16_32x32x16(bf16x8 a, bf16x8 b, f32x16& acc) {
+  const int t = emu::tid(), lane = t & 63, wave = t >> 6;
+  float* A = reinterpret_cast<float*>(emu::g_xchg) + wave * 1024;  // [k][row]
+  float* B = A + 512;                                             // [k][col]
+  const int r = lane & 31, h = lane >> 5;
+  for (int j = 0; j < 8; ++j) { A[(8 * h + j) * 32 + r] = emu_bf16_to_f32(a[j]); B[(8 * h + j) * 32 + r] = emu_bf16_to_f32(b[j]); }
+  __syncthreads();
+  for (int q = 0; q < 16; ++q) {
+    const int row = (q & 3) + 8 * (q >> 2) + 4 * h;
+    float c = acc[q];
+    for (int k = 0; k < 16; ++k) c += A[k * 32 + row] * B[k * 32 + r];
+    acc[q] = c;
+  }
+  __syncthreads();
+}
+
+inline float group16_sum(float x) {
+  float* s = reinterpret_cast<float*>(emu::g_xchg);
+  const int t = emu::tid();
+  s[t] = x;
+  __syncthreads();
+  float r = 0.f;
+  const int base = t & ~15;
+  for (int k = 0; k < 16; ++k) r += s[base + k];
+  __syncthreads();
+  return r;
+}
+inline float group16_max(float x) {
+  float* s = reinterpret_cast<float*>(emu::g_xchg);
+  const int t = emu::tid();
+  s[t] = x;
+  __syncthreads();
+  float r = s[t & ~15];
+  for (int k = 1; k < 16; ++k) r = fmaxf(r, s[(t & ~15) + k]);
+  __syncthreads();
+  return r;
+}
+inline bool emu_any(bool pred, int width) {
+  float* s = reinterpret_cast<float*>(emu::g_xchg);
+  const int t = emu::tid();
+  s[t] = pred ? 1.f : 0.f;
+  __syncthreads();
+  bool r = false;
+  const int base = t & ~(width - 1);
+  const int n = (int)(blockDim.x * blockDim.y * blockDim.z);
+  for (int k = 0; k < width && base + k < n; ++k) r = r || (s[base + k] != 0.f);
+  __syncthreads();
+  return r;
+}
+inline bool wave_any(bool pred) { return emu_any(pred, 64); }
+inline bool group16_any(bool pred) { return emu_any(pred, 16); }
+inline float wave_sum(float x) {
+  float* s = reinterpret_cast<float*>(emu::g_xchg);
+  const int t = emu::tid();
+  s[t] = x;
+  __syncthreads();
+  float r = 0.f;
+  const int n = (int)(blockDim.x * blockDim.y * blockDim.z);
+  for (int k = 0; k < 64 && (t & ~63) + k < n; ++k) r += s[(t & ~63) + k];
+  __syncthreads();
+  return r;
+}
+inline double wave_sum_f64(double x) {
+  double* s = emu::g_xchg;
+  const int t = emu::tid();
+  s[t] = x;
+  __syncthreads();
+  double r = 0.0;
+  const int n = (int)(blockDim.x * blockDim.y * blockDim.z);
+  for (int k = 0; k < 64 && (t & ~63) + k < n; ++k) r += s[(t & ~63) + k];
+  __syncthreads();
+  return r;
+}
