@@ -1,0 +1,42 @@
+// k_perm.hip — random permutation of [0,B): sort of Philox keys (what jax.random.permutation does,
+// reference minppo/train.py:258), using rocPRIM's device radix sort for the plain key/value sort.
+#include <hip/hip_runtime.h>
+
+#include <cstring>
+
+#include <rocprim/device/device_radix_sort.hpp>
+
+#include "mppo_common.h"
+#include "ppo_layout.h"
+
+namespace mppo {
+static size_t sort_temp_bytes(int B) {
+  size_t bytes = 0;
+  (void)rocprim::radix_sort_pairs(nullptr, bytes, static_cast<unsigned*>(nullptr), static_cast<unsigned*>(nullptr), static_cast<int*>(nullptr),
+                            static_cast<int*>(nullptr), (size_t)B, 0, 32, nullptr);
+  return bytes;
+}
+}  // namespace mppo
+
+extern "C" size_t mppo_permutation_ws_bytes(int32_t B) {
+  if (B < 1) return 0;
+  // keys_in, keys_out, vals_in  +  rocPRIM temporary storage
+  return 3 * mppo::align_up((size_t)B * 4, 256) + mppo::align_up(mppo::sort_temp_bytes(B), 256);
+}
+
+extern "C" int32_t mppo_permutation(uint64_t seed, uint64_t stream_id, int32_t B, int32_t* idx, void* ws, size_t ws_bytes, void* stream) {
+  using namespace mppo;
+  MPPO_REQUIRE(B >= 1 && idx && ws, "mppo_permutation: bad argument");
+  if (ws_bytes < mppo_permutation_ws_bytes(B)) return fail(MPPO_ENOMEM, "mppo_permutation: workspace %zu < %zu bytes", ws_bytes, mppo_permutation_ws_bytes(B));
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const size_t chunk = align_up((size_t)B * 4, 256);
+  unsigned char* w = static_cast<unsigned char*>(ws);
+  unsigned* keys_in = reinterpret_cast<unsigned*>(w);
+  unsigned* keys_out = reinterpret_cast<unsigned*>(w + chunk);
+  int* vals_in = reinterpret_cast<int*>(w + 2 * chunk);
+  void* temp = w + 3 * chunk;
+  size_t temp_bytes = ws_bytes - 3 * chunk;
+  MPPO_TRY(perm_fill_keys(seed, stream_id, B, keys_in, vals_in, s));
+  MPPO_CHECK_HIP(rocprim::radix_sort_pairs(temp, temp_bytes, keys_in, keys_out, vals_in, idx, (size_t)B, 0, 32, s));
+  return MPPO_OK;
+}

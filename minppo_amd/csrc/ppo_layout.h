@@ -1,0 +1,89 @@
+// ppo_layout.h — flat parameter layout and workspace carving shared by the PPO stages and the engine.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstddef>
+#include <cstdint>
+
+#include "../../include/minppo_hip.h"
+
+namespace mppo {
+
+// Offsets (floats) inside the flat parameter / gradient / Adam-moment vectors (include/minppo_hip.h).
+struct ParamLayout {
+  int a_w1, a_b1, a_w2, a_b2, a_w3, a_b3, log_std, c_w1, c_b1, c_w2, c_b2, c_w3, c_b3, total;
+};
+inline ParamLayout param_layout(int O, int A, int H) {
+  ParamLayout L;
+  int o = 0;
+  L.a_w1 = o; o += O * H; L.a_b1 = o; o += H; L.a_w2 = o; o += H * H; L.a_b2 = o; o += H; L.a_w3 = o; o += H * A; L.a_b3 = o; o += A;
+  L.log_std = o; o += A;
+  L.c_w1 = o; o += O * H; L.c_b1 = o; o += H; L.c_w2 = o; o += H * H; L.c_b2 = o; o += H; L.c_w3 = o; o += H; L.c_b3 = o; o += 1;
+  L.total = o;
+  return L;
+}
+
+inline size_t pad4(size_t n) { return (n + 3) & ~(size_t)3; }
+
+// activations of one forward pass over n rows
+struct FwdBufs {
+  float *h1a, *h2a, *h1c, *h2c, *mean, *value;
+  int AP;
+};
+inline size_t fwd_bufs_floats(const mppo_net_t& net, int n) {
+  const size_t AP = pad4((size_t)net.A);
+  return 4 * pad4((size_t)n * net.H) + pad4((size_t)n * AP) + pad4((size_t)n);
+}
+inline FwdBufs carve_fwd(const mppo_net_t& net, int n, float* ws) {
+  FwdBufs f;
+  f.AP = (int)pad4((size_t)net.A);
+  const size_t nh = pad4((size_t)n * net.H);
+  f.h1a = ws; ws += nh; f.h2a = ws; ws += nh; f.h1c = ws; ws += nh; f.h2c = ws; ws += nh;
+  f.mean = ws; ws += pad4((size_t)n * f.AP);
+  f.value = ws;
+  return f;
+}
+
+constexpr int kGradKSplit = 4;
+
+// everything one minibatch gradient needs beyond the forward activations
+struct GradBufs {
+  FwdBufs f;
+  float *dmean, *dv, *dz2a, *dz2c, *dz1a, *dz1c, *partial, *slabs;
+  int ksplit;
+  size_t slab_stride;
+};
+inline size_t grad_bufs_floats(const mppo_net_t& net, int mb) {
+  const size_t AP = pad4((size_t)net.A), nh = pad4((size_t)mb * net.H);
+  const size_t P = pad4((size_t)param_layout(net.O, net.A, net.H).total);
+  const size_t nblk = (size_t)(mb + 255) / 256;
+  return fwd_bufs_floats(net, mb) + pad4((size_t)mb * AP) + pad4((size_t)mb) + 4 * nh + pad4(nblk * (4 + AP)) + (size_t)kGradKSplit * P;
+}
+inline GradBufs carve_grad(const mppo_net_t& net, int mb, float* ws) {
+  GradBufs g;
+  g.f = carve_fwd(net, mb, ws);
+  ws += fwd_bufs_floats(net, mb);
+  const size_t AP = (size_t)g.f.AP, nh = pad4((size_t)mb * net.H);
+  g.dmean = ws; ws += pad4((size_t)mb * AP);
+  g.dv = ws; ws += pad4((size_t)mb);
+  g.dz2a = ws; ws += nh; g.dz2c = ws; ws += nh; g.dz1a = ws; ws += nh; g.dz1c = ws; ws += nh;
+  const size_t nblk = (size_t)(mb + 255) / 256;
+  g.partial = ws; ws += pad4(nblk * (4 + AP));
+  g.slabs = ws;
+  g.ksplit = kGradKSplit;
+  g.slab_stride = pad4((size_t)param_layout(net.O, net.A, net.H).total);
+  return g;
+}
+
+// stage launchers (k_ppo.hip)
+int32_t mlp_forward(const mppo_net_t& net, const float* params, int n, const float* obs, int obs_ld, const int* gather, const FwdBufs& fb, hipStream_t stream);
+int32_t policy_sample(const mppo_net_t& net, const float* params, int n, const FwdBufs& fb, const float* noise, float* action, float* log_prob, hipStream_t stream);
+int32_t minibatch_grad(const mppo_net_t& net, const float* params, const mppo_batch_t& batch, const int* idx, int mb, const float* adv_stat, float inv_count,
+                       const mppo_loss_cfg_t& lc, float* grad, float* loss4, const GradBufs& gbuf, hipStream_t stream);
+int32_t clip_adam(size_t P, float* params, float* m, float* v, const float* grad, const int* count_base, int step_offset, const mppo_adam_cfg_t& cfg, float* ws,
+                  hipStream_t stream);
+int32_t gae_launch(int T, int N, float gamma, float lam, const float* reward, const float* value, const unsigned char* done, const float* last_val, float* adv,
+                   float* target, hipStream_t stream);
+int32_t perm_fill_keys(unsigned long long seed, unsigned long long stream_id, int B, unsigned* keys, int* vals, hipStream_t stream);
+
+}  // namespace mppo
