@@ -137,6 +137,20 @@ int32_t mppo_policy_forward(const mppo_net_t* net, const float* params, int32_t 
                             const float* noise, float* action, float* log_prob, float* value, float* mean_out,
                             void* ws, size_t ws_bytes, void* stream);
 
+/* The dense contraction every MLP layer goes through (`nn.Dense` forward, train.py:63,68, and the
+ * two products its backward needs), as a batched launch of up to 6 problems on the f32 matrix cores.
+ *   variant 0: C = act(A.B + bias)                A [M,K] (rows optionally gathered), B [K,N]
+ *   variant 1: C = (A.B^T) * act'(aux)            B stored [N,K]
+ *   variant 2: C = A^T.B  (split-K slabs)         A stored [K,M] (rows = samples, optionally gathered);
+ *              with ones_row the logical last row of A^T is all ones (bias gradient)
+ * act: 0 none, 1 tanh, 2 relu.  Exposed so that benchmarks can time exactly the kernel the engine runs. */
+typedef struct mppo_gemm_desc {
+  const float* A; const float* B; float* C; const float* bias; const float* aux; const int32_t* gather;
+  int32_t M, N, K, lda, ldb, ldc, ldaux, act, ones_row;
+} mppo_gemm_desc_t;
+int32_t mppo_gemm_batch(const mppo_gemm_desc_t* probs, int32_t count, int32_t variant, int32_t ksplit, size_t slab_stride,
+                        int32_t bf16, void* stream);
+
 /* `_calculate_gae` (train.py:185-205): reverse scan over T, independent per env. */
 int32_t mppo_gae(int32_t T, int32_t N, float gamma, float lam, const float* reward, const float* value,
                  const uint8_t* done, const float* last_val, float* adv, float* target, void* stream);

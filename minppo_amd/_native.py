@@ -62,6 +62,10 @@ class Batch(C.Structure):
                 ("adv", c_vp), ("target", c_vp)]
 
 
+class GemmDesc(C.Structure):
+    _fields_ = [(n, c_vp) for n in ("A", "B", "C", "bias", "aux", "gather")] + [(n, c_i32) for n in ("M", "N", "K", "lda", "ldb", "ldc", "ldaux", "act", "ones_row")]
+
+
 class LossCfg(C.Structure):
     _fields_ = [("clip_eps", c_f), ("vf_coef", c_f), ("ent_coef", c_f)]
 
@@ -94,6 +98,7 @@ SIGNATURES = {
     "mppo_param_count": (c_sz, [P(Net)]),
     "mppo_policy_ws_bytes": (c_sz, [P(Net), c_i32]),
     "mppo_policy_forward": (c_i32, [P(Net), c_vp, c_i32, c_vp, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_sz, c_vp]),
+    "mppo_gemm_batch": (c_i32, [P(GemmDesc), c_i32, c_i32, c_i32, c_sz, c_i32, c_vp]),
     "mppo_gae": (c_i32, [c_i32, c_i32, c_f, c_f, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "mppo_grad_ws_bytes": (c_sz, [P(Net), c_i32]),
     "mppo_minibatch_grad": (c_i32, [P(Net), c_vp, P(Batch), c_vp, c_i32, c_vp, c_f, P(LossCfg), c_vp, c_vp, c_vp, c_sz,

@@ -1,0 +1,315 @@
+// engine.hip — one PPO `_update_step` (reference minppo/train.py:146-283) as a single C call.
+//
+// The reference is ONE jitted XLA program; here the same dependency chain is a fixed sequence of
+// kernel launches enqueued from C++ on the caller's stream (about 1.3k launches per update at the
+// default 4 epochs x 32 minibatches), optionally captured once into a hipGraph and replayed, so
+// that Python is out of the loop.  All buffers live in one caller-owned HBM arena whose layout is
+// fixed at creation time (so the captured graph stays valid); dynamic quantities the graph must
+// not bake in (Adam step index, RNG stream position) live in the arena's `count` words and are
+// advanced by a kernel at the end of every update.
+//
+// Multi-GPU (one process per GPU): environments shard across ranks, parameters are replicated.
+// Per optimizer step the flat gradient [P] is sum-all-reduced with RCCL on the same stream; per
+// update the [E*M*2] float64 advantage sums are all-reduced once, so that every rank normalises
+// with the statistics of the global minibatch.  Rows are weighted 1/(mb*world).
+#include <wave_ops.h>
+
+#include "mppo_common.h"
+#include "model_view.h"
+#include "ppo_layout.h"
+#include "platform.h"
+
+#include <cstring>
+#include <string>
+#include <vector>
+
+namespace mppo {
+const ModelView& model_view(const mppo_model* m);
+
+__global__ void advance_counters_kernel(int* count, int opt_steps) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) { count[0] += opt_steps; count[1] += 1; }
+}
+
+// per-update rollout statistics (device-side reduction of what the reference returns as the
+// full [T,N] metrics history, train.py:283): {sum reward, #done, sum returned_episode_returns
+// over done steps, sum returned_episode_lengths over done steps}
+__global__ void __launch_bounds__(256) rollout_stats_kernel(int n, const float* __restrict__ reward, const unsigned char* __restrict__ done,
+                                                            float* __restrict__ out) {
+  __shared__ float red[4][2];
+  float sr = 0.f, sd = 0.f;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) { sr += reward[i]; sd += done[i] ? 1.f : 0.f; }
+  sr = wave_sum(sr); sd = wave_sum(sd);
+  if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6][0] = sr; red[threadIdx.x >> 6][1] = sd; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    atomicAdd(out + 0, red[0][0] + red[1][0] + red[2][0] + red[3][0]);
+    atomicAdd(out + 1, red[0][1] + red[1][1] + red[2][1] + red[3][1]);
+  }
+}
+
+struct Region { std::string name; size_t off, bytes; };
+}  // namespace mppo
+
+struct mppo_engine {
+  const mppo_model* model;
+  mppo_engine_cfg_t cfg;
+  mppo::ModelView mv;
+  unsigned char* arena;
+  size_t arena_bytes;
+  std::vector<mppo::Region> regions;
+  int N, T, B, mb, M, E, O, OP, A, H, P;
+  float *params, *adam_m, *adam_v, *grad;
+  int* count;
+  float *state, *reset_rec, *obs, *action, *value, *reward, *log_prob, *last_val, *adv, *target, *noise, *adv_stats, *losses, *stats;
+  unsigned char* done;
+  int* perm;
+  double* adv_sums;
+  mppo_env_metrics_t met;
+  float *fwd_ws, *grad_ws, *adam_ws;
+  void* perm_ws;
+  size_t perm_ws_bytes;
+  mppo::Comm* comm;
+  mppo::GraphExec* graph;
+  bool graph_failed, was_reset;
+};
+
+namespace mppo {
+
+static size_t layout(mppo_engine* e, bool assign) {
+  size_t off = 0;
+  e->regions.clear();
+  auto take = [&](const char* name, size_t bytes) -> unsigned char* {
+    off = align_up(off, 256);
+    e->regions.push_back({name, off, bytes});
+    unsigned char* p = assign ? e->arena + off : nullptr;
+    off += bytes;
+    return p;
+  };
+  const size_t N = e->N, T = e->T, B = e->B, A = e->A, OP = e->OP, P = e->P, EM = (size_t)e->E * e->M;
+  const mppo_net_t& net = e->cfg.net;
+  e->params = (float*)take("params", P * 4);
+  e->adam_m = (float*)take("adam_m", P * 4);
+  e->adam_v = (float*)take("adam_v", P * 4);
+  e->grad = (float*)take("grad", P * 4);
+  e->count = (int*)take("count", 4 * 4);
+  e->state = (float*)take("state", N * e->mv.rec_dim * 4);
+  e->reset_rec = (float*)take("reset_rec", (size_t)e->mv.rec_dim * 4);
+  e->obs = (float*)take("obs", (T + 1) * N * OP * 4);
+  e->action = (float*)take("action", T * N * A * 4);
+  e->value = (float*)take("value", B * 4);
+  e->reward = (float*)take("reward", B * 4);
+  e->log_prob = (float*)take("log_prob", B * 4);
+  e->done = (unsigned char*)take("done", B);
+  e->last_val = (float*)take("last_val", N * 4);
+  e->adv = (float*)take("adv", B * 4);
+  e->target = (float*)take("target", B * 4);
+  e->noise = (float*)take("noise", T * N * A * 4);
+  e->perm = (int*)take("perm", (size_t)e->E * B * 4);
+  e->adv_sums = (double*)take("adv_sums", EM * 2 * 8);
+  e->adv_stats = (float*)take("adv_stats", EM * 2 * 4);
+  e->losses = (float*)take("losses", EM * 4 * 4);
+  e->stats = (float*)take("rollout_stats", 4 * 4);
+  e->met.episode_returns = (float*)take("episode_returns", N * 4);
+  e->met.episode_lengths = (int32_t*)take("episode_lengths", N * 4);
+  e->met.returned_episode_returns = (float*)take("returned_episode_returns", N * 4);
+  e->met.returned_episode_lengths = (int32_t*)take("returned_episode_lengths", N * 4);
+  e->met.timestep = (int32_t*)take("timestep", N * 4);
+  e->met.returned_episode = (uint8_t*)take("returned_episode", N);
+  e->fwd_ws = (float*)take("fwd_ws", fwd_bufs_floats(net, (int)N) * 4);
+  e->grad_ws = (float*)take("grad_ws", grad_bufs_floats(net, e->mb) * 4);
+  e->adam_ws = (float*)take("adam_ws", mppo_adam_ws_bytes(P));
+  e->perm_ws_bytes = mppo_permutation_ws_bytes((int)B);
+  e->perm_ws = take("perm_ws", e->perm_ws_bytes);
+  return align_up(off, 256);
+}
+
+static int32_t validate_cfg(const mppo_model* m, const mppo_engine_cfg_t* c) {
+  MPPO_REQUIRE(m && c, "engine: null model / cfg");
+  const ModelView& mv = model_view(m);
+  MPPO_REQUIRE(c->num_envs >= 1 && c->num_steps >= 1 && c->num_minibatches >= 1 && c->update_epochs >= 1 && c->n_frames >= 1, "engine: non-positive size in cfg");
+  MPPO_REQUIRE(c->world_size >= 1 && c->rank >= 0 && c->rank < c->world_size, "engine: bad rank %d / world %d", c->rank, c->world_size);
+  const long B = (long)c->num_envs * c->num_steps;
+  // the reference raises ValueError here (train.py:253-255)
+  MPPO_REQUIRE(B % c->num_minibatches == 0, "`batch_size` must be equal to `num_steps * num_envs` (num_envs*num_steps = %ld is not divisible by num_minibatches = %d)", B,
+               c->num_minibatches);
+  MPPO_REQUIRE(c->net.O == mv.obs_dim && c->net.OP == mv.obs_pad, "engine: net O/OP (%d/%d) do not match the model's observation (%d/%d)", c->net.O, c->net.OP,
+               mv.obs_dim, mv.obs_pad);
+  MPPO_REQUIRE(c->net.A == mv.nu, "engine: net A = %d but the model has %d actuators", c->net.A, mv.nu);
+  MPPO_REQUIRE(c->net.A >= 1 && c->net.A <= 32 && c->net.H >= 4 && c->net.H % 4 == 0, "engine: unsupported A / H");
+  MPPO_REQUIRE(c->num_updates >= 1, "engine: num_updates must be >= 1 (total_timesteps too small)");
+  return MPPO_OK;
+}
+
+static void fill_dims(mppo_engine* e) {
+  const mppo_engine_cfg_t& c = e->cfg;
+  e->N = c.num_envs; e->T = c.num_steps; e->B = e->N * e->T; e->M = c.num_minibatches; e->E = c.update_epochs; e->mb = e->B / e->M;
+  e->O = c.net.O; e->OP = c.net.OP; e->A = c.net.A; e->H = c.net.H; e->P = param_layout(e->O, e->A, e->H).total;
+}
+
+constexpr unsigned long long kStreamNoise = 0x4E4F495345ull << 24;  // "NOISE"
+constexpr unsigned long long kStreamPerm = 0x5045524Dull << 24;     // "PERM"
+
+
+static int32_t do_rollout(mppo_engine* e, hipStream_t s) {
+  const mppo_engine_cfg_t& c = e->cfg;
+  const size_t N = e->N, OP = e->OP, A = e->A;
+  if (!c.external_random)
+    MPPO_TRY(normal_fill_ctr(c.seed, kStreamNoise + ((unsigned long long)c.rank << 16), e->count + 1, (size_t)e->T * N * A, e->noise, s));
+  FwdBufs fb = carve_fwd(c.net, e->N, e->fwd_ws);
+  for (int t = 0; t < e->T; ++t) {
+    const float* obs_t = e->obs + (size_t)t * N * OP;
+    fb.value = e->value + (size_t)t * N;
+    MPPO_TRY(mlp_forward(c.net, e->params, e->N, obs_t, e->OP, nullptr, fb, s));                                        // train.py:157
+    MPPO_TRY(policy_sample(c.net, e->params, e->N, fb, e->noise + t * N * A, e->action + t * N * A, e->log_prob + t * N, s));  // :158-160
+    MPPO_TRY(mppo_env_step(e->model, e->N, c.n_frames, &c.reward, e->state, e->reset_rec, e->action + t * N * A, e->A, e->obs + (size_t)(t + 1) * N * OP,
+                           e->OP, e->reward + t * N, e->done + t * N, &e->met, s));                                  // :165
+  }
+  fb.value = e->last_val;
+  MPPO_TRY(mlp_forward(c.net, e->params, e->N, e->obs + (size_t)e->T * N * OP, e->OP, nullptr, fb, s));  // bootstrap value, train.py:182
+  MPPO_TRY(gae_launch(e->T, e->N, c.gamma, c.gae_lambda, e->reward, e->value, e->done, e->last_val, e->adv, e->target, s));
+  MPPO_CHECK_HIP(hipMemsetAsync(e->stats, 0, 16, s));
+  hipLaunchKernelGGL(rollout_stats_kernel, dim3(64), dim3(256), 0, s, e->B, e->reward, e->done, e->stats);
+  MPPO_CHECK_LAUNCH("rollout_stats_kernel");
+  return MPPO_OK;
+}
+
+static int32_t do_learn(mppo_engine* e, hipStream_t s) {
+  const mppo_engine_cfg_t& c = e->cfg;
+  const int EM = e->E * e->M;
+  if (!c.external_random)
+    for (int ep = 0; ep < e->E; ++ep)
+      MPPO_TRY(permutation_ctr(c.seed, kStreamPerm + ((unsigned long long)c.rank << 16) + (unsigned long long)ep, e->count + 1, e->B, e->perm + (size_t)ep * e->B,
+                               e->perm_ws, e->perm_ws_bytes, s));                                                    // train.py:258
+  MPPO_TRY(mppo_adv_sums(e->adv, e->perm, EM, e->mb, e->adv_sums, s));
+  if (c.world_size > 1) MPPO_TRY(comm_allreduce_f64(e->comm, e->adv_sums, (size_t)EM * 2, s));
+  MPPO_TRY(mppo_adv_stats_finalize(e->adv_sums, EM, (double)e->mb * c.world_size, e->adv_stats, s));
+  mppo_batch_t batch;
+  batch.obs = e->obs; batch.obs_ld = e->OP; batch.action = e->action; batch.act_ld = e->A; batch.value = e->value; batch.log_prob = e->log_prob;
+  batch.adv = e->adv; batch.target = e->target;
+  const GradBufs gb = carve_grad(c.net, e->mb, e->grad_ws);
+  const float inv_count = 1.f / ((float)e->mb * (float)c.world_size);
+  mppo_adam_cfg_t ac = c.adam;
+  ac.sched_div = e->mb * c.world_size * e->E;  // minibatch_size * update_epochs of the GLOBAL batch (train.py:94,100)
+  ac.num_updates = c.num_updates;
+  for (int ep = 0; ep < e->E; ++ep) {
+    for (int k = 0; k < e->M; ++k) {
+      const int st = ep * e->M + k;
+      MPPO_TRY(minibatch_grad(c.net, e->params, batch, e->perm + (size_t)ep * e->B + (size_t)k * e->mb, e->mb, e->adv_stats + 2 * st, inv_count, c.loss, e->grad,
+                              e->losses + 4 * st, gb, s));                                                           // train.py:246-247
+      if (c.world_size > 1) MPPO_TRY(comm_allreduce_f32(e->comm, e->grad, (size_t)e->P, s));
+      MPPO_TRY(clip_adam((size_t)e->P, e->params, e->adam_m, e->adam_v, e->grad, e->count, st, ac, e->adam_ws, s));  // train.py:248
+    }
+  }
+  hipLaunchKernelGGL(advance_counters_kernel, dim3(1), dim3(64), 0, s, e->count, EM);
+  MPPO_CHECK_LAUNCH("advance_counters_kernel");
+  // carry last_obs into slot 0 of the next rollout (RunnerState.last_obs, train.py:174,279)
+  MPPO_CHECK_HIP(hipMemcpyAsync(e->obs, e->obs + (size_t)e->T * e->N * e->OP, (size_t)e->N * e->OP * 4, hipMemcpyDeviceToDevice, s));
+  return MPPO_OK;
+}
+
+}  // namespace mppo
+
+using namespace mppo;
+
+extern "C" int32_t mppo_engine_arena_bytes(const mppo_model_t* m, const mppo_engine_cfg_t* cfg, size_t* out) {
+  MPPO_TRY(validate_cfg(m, cfg));
+  MPPO_REQUIRE(out, "mppo_engine_arena_bytes: null out");
+  mppo_engine tmp{};
+  tmp.model = m; tmp.cfg = *cfg; tmp.mv = model_view(m);
+  fill_dims(&tmp);
+  *out = layout(&tmp, false);
+  return MPPO_OK;
+}
+
+extern "C" int32_t mppo_engine_create(const mppo_model_t* m, const mppo_engine_cfg_t* cfg, void* arena, size_t arena_bytes, mppo_engine_t** out) {
+  MPPO_TRY(validate_cfg(m, cfg));
+  MPPO_REQUIRE(arena && out, "mppo_engine_create: null arena / out");
+  MPPO_REQUIRE((reinterpret_cast<uintptr_t>(arena) & 255) == 0, "mppo_engine_create: arena must be 256-byte aligned");
+  mppo_engine* e = new mppo_engine();
+  e->model = m; e->cfg = *cfg; e->mv = model_view(m);
+  e->arena = static_cast<unsigned char*>(arena);
+  e->arena_bytes = arena_bytes;
+  fill_dims(e);
+  const size_t need = layout(e, true);
+  if (arena_bytes < need) { delete e; return fail(MPPO_ENOMEM, "mppo_engine_create: arena %zu < %zu bytes", arena_bytes, need); }
+  e->comm = nullptr; e->graph = nullptr; e->graph_failed = false; e->was_reset = false;
+  *out = e;
+  return MPPO_OK;
+}
+
+extern "C" int32_t mppo_engine_destroy(mppo_engine_t* e) {
+  if (!e) return MPPO_OK;
+  if (e->graph) graph_destroy(e->graph);
+  if (e->comm) comm_destroy(e->comm);
+  delete e;
+  return MPPO_OK;
+}
+
+extern "C" int32_t mppo_engine_region(const mppo_engine_t* e, const char* name, size_t* offset, size_t* nbytes) {
+  MPPO_REQUIRE(e && name && offset && nbytes, "mppo_engine_region: null argument");
+  for (const Region& r : e->regions)
+    if (r.name == name) { *offset = r.off; *nbytes = r.bytes; return MPPO_OK; }
+  return fail(MPPO_EINVAL, "mppo_engine_region: no region named '%s'", name);
+}
+
+extern "C" int32_t mppo_comm_unique_id(void* id128) {
+  MPPO_REQUIRE(id128, "mppo_comm_unique_id: null");
+  return comm_unique_id(id128);
+}
+
+extern "C" int32_t mppo_engine_comm_init(mppo_engine_t* e, const void* id128) {
+  MPPO_REQUIRE(e && id128, "mppo_engine_comm_init: null argument");
+  MPPO_REQUIRE(!e->comm, "mppo_engine_comm_init: communicator already initialised");
+  return comm_create(id128, e->cfg.rank, e->cfg.world_size, &e->comm);
+}
+
+extern "C" int32_t mppo_engine_reset(mppo_engine_t* e, void* stream) {
+  MPPO_REQUIRE(e, "mppo_engine_reset: null engine");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  MPPO_CHECK_HIP(hipMemsetAsync(e->count, 0, 16, s));
+  MPPO_CHECK_HIP(hipMemsetAsync(e->adam_m, 0, (size_t)e->P * 4, s));
+  MPPO_CHECK_HIP(hipMemsetAsync(e->adam_v, 0, (size_t)e->P * 4, s));
+  MPPO_CHECK_HIP(hipMemsetAsync(e->obs, 0, (size_t)(e->T + 1) * e->N * e->OP * 4, s));
+  MPPO_TRY(mppo_env_reset(e->model, e->N, e->state, e->reset_rec, e->obs, e->OP, nullptr, nullptr, &e->met, s));  // train.py:142-144
+  e->was_reset = true;
+  return MPPO_OK;
+}
+
+static int32_t require_ready(mppo_engine_t* e) {
+  MPPO_REQUIRE(e, "null engine");
+  if (!e->was_reset) return fail(MPPO_ESTATE, "engine: call mppo_engine_reset before stepping");
+  if (e->cfg.world_size > 1 && !e->comm) return fail(MPPO_ESTATE, "engine: world_size = %d but mppo_engine_comm_init was not called", e->cfg.world_size);
+  return MPPO_OK;
+}
+
+extern "C" int32_t mppo_engine_rollout(mppo_engine_t* e, void* stream) {
+  MPPO_TRY(require_ready(e));
+  return do_rollout(e, static_cast<hipStream_t>(stream));
+}
+
+extern "C" int32_t mppo_engine_learn(mppo_engine_t* e, void* stream) {
+  MPPO_TRY(require_ready(e));
+  return do_learn(e, static_cast<hipStream_t>(stream));
+}
+
+extern "C" int32_t mppo_engine_update(mppo_engine_t* e, void* stream) {
+  MPPO_TRY(require_ready(e));
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const bool want_graph = e->cfg.use_graph && !e->graph_failed && e->cfg.world_size == 1 && s != nullptr;
+  if (want_graph) {
+    if (!e->graph) {
+      // capture once; every pointer and size in the sequence is fixed by the arena layout
+      if (graph_begin(s) == MPPO_OK) {
+        int32_t r = do_rollout(e, s);
+        if (r == MPPO_OK) r = do_learn(e, s);
+        const int32_t r2 = graph_end(s, &e->graph);
+        if (r != MPPO_OK || r2 != MPPO_OK) { e->graph = nullptr; e->graph_failed = true; }
+      } else {
+        e->graph_failed = true;
+      }
+    }
+    if (e->graph) return graph_launch(e->graph, s);
+  }
+  MPPO_TRY(do_rollout(e, s));
+  return do_learn(e, s);
+}

@@ -156,3 +156,20 @@ int32_t gemm_launch(const GemmBatch& gb, int a_t, int b_t, int epi, int bf16, hi
 }
 
 }  // namespace mppo
+
+extern "C" int32_t mppo_gemm_batch(const mppo_gemm_desc_t* probs, int32_t count, int32_t variant, int32_t ksplit, size_t slab_stride, int32_t bf16,
+                                   void* stream) {
+  using namespace mppo;
+  MPPO_REQUIRE(probs && count >= 1 && count <= kGemmMaxProb, "mppo_gemm_batch: 1..%d problems", kGemmMaxProb);
+  MPPO_REQUIRE(variant >= 0 && variant <= 2, "mppo_gemm_batch: variant %d", variant);
+  GemmBatch gb{};
+  gb.count = count; gb.ksplit = ksplit < 1 ? 1 : ksplit; gb.slab_stride = slab_stride;
+  for (int i = 0; i < count; ++i) {
+    const mppo_gemm_desc_t& d = probs[i];
+    GemmProb& p = gb.p[i];
+    p.A = d.A; p.B = d.B; p.C = d.C; p.bias = d.bias; p.aux = d.aux; p.gather = d.gather; p.M = d.M; p.N = d.N; p.K = d.K;
+    p.lda = d.lda; p.ldb = d.ldb; p.ldc = d.ldc; p.ldaux = d.ldaux; p.act = d.act; p.ones_row = d.ones_row;
+  }
+  static const int at[3] = {0, 0, 1}, bt[3] = {0, 1, 0}, ep[3] = {EPI_BIAS_ACT, EPI_DACT, EPI_STORE};
+  return gemm_launch(gb, at[variant], bt[variant], ep[variant], bf16, static_cast<hipStream_t>(stream));
+}

@@ -24,11 +24,10 @@ extern "C" size_t mppo_permutation_ws_bytes(int32_t B) {
   return 3 * mppo::align_up((size_t)B * 4, 256) + mppo::align_up(mppo::sort_temp_bytes(B), 256);
 }
 
-extern "C" int32_t mppo_permutation(uint64_t seed, uint64_t stream_id, int32_t B, int32_t* idx, void* ws, size_t ws_bytes, void* stream) {
-  using namespace mppo;
+namespace mppo {
+int32_t permutation_ctr(unsigned long long seed, unsigned long long stream_id, const int* ctr, int B, int* idx, void* ws, size_t ws_bytes, hipStream_t s) {
   MPPO_REQUIRE(B >= 1 && idx && ws, "mppo_permutation: bad argument");
   if (ws_bytes < mppo_permutation_ws_bytes(B)) return fail(MPPO_ENOMEM, "mppo_permutation: workspace %zu < %zu bytes", ws_bytes, mppo_permutation_ws_bytes(B));
-  hipStream_t s = static_cast<hipStream_t>(stream);
   const size_t chunk = align_up((size_t)B * 4, 256);
   unsigned char* w = static_cast<unsigned char*>(ws);
   unsigned* keys_in = reinterpret_cast<unsigned*>(w);
@@ -36,7 +35,12 @@ extern "C" int32_t mppo_permutation(uint64_t seed, uint64_t stream_id, int32_t B
   int* vals_in = reinterpret_cast<int*>(w + 2 * chunk);
   void* temp = w + 3 * chunk;
   size_t temp_bytes = ws_bytes - 3 * chunk;
-  MPPO_TRY(perm_fill_keys(seed, stream_id, B, keys_in, vals_in, s));
+  MPPO_TRY(perm_fill_keys(seed, stream_id, ctr, B, keys_in, vals_in, s));
   MPPO_CHECK_HIP(rocprim::radix_sort_pairs(temp, temp_bytes, keys_in, keys_out, vals_in, idx, (size_t)B, 0, 32, s));
   return MPPO_OK;
+}
+}  // namespace mppo
+
+extern "C" int32_t mppo_permutation(uint64_t seed, uint64_t stream_id, int32_t B, int32_t* idx, void* ws, size_t ws_bytes, void* stream) {
+  return mppo::permutation_ctr(seed, stream_id, nullptr, B, idx, ws, ws_bytes, static_cast<hipStream_t>(stream));
 }

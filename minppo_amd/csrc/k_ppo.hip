@@ -235,10 +235,13 @@ __host__ __device__ inline U4 philox4x32(unsigned c0, unsigned c1, unsigned c2, 
   return {c0, c1, c2, c3};
 }
 
-__global__ void __launch_bounds__(256) normal_fill_kernel(unsigned long long seed, unsigned long long stream_id, size_t n, float* __restrict__ out) {
+// `ctr` (optional, device int): the engine's update index; it takes the place of the high counter word so that a
+// captured launch draws a fresh sub-stream every replay.
+__global__ void __launch_bounds__(256) normal_fill_kernel(unsigned long long seed, unsigned long long stream_id, const int* __restrict__ ctr, size_t n,
+                                                          float* __restrict__ out) {
   const size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (4 * q >= n) return;
-  const U4 r = philox4x32((unsigned)q, (unsigned)(q >> 32), (unsigned)stream_id, (unsigned)(stream_id >> 32), (unsigned)seed, (unsigned)(seed >> 32));
+  const U4 r = philox4x32((unsigned)q, ctr ? (unsigned)ctr[0] : (unsigned)(q >> 32), (unsigned)stream_id, (unsigned)(stream_id >> 32), (unsigned)seed, (unsigned)(seed >> 32));
   const float u0 = ((float)r.x + 0.5f) * 2.3283064365386963e-10f, u1 = ((float)r.y + 0.5f) * 2.3283064365386963e-10f;
   const float u2 = ((float)r.z + 0.5f) * 2.3283064365386963e-10f, u3 = ((float)r.w + 0.5f) * 2.3283064365386963e-10f;
   const float ra = sqrtf(-2.f * logf(fminf(fmaxf(u0, 1e-10f), 1.f))), rb = sqrtf(-2.f * logf(fminf(fmaxf(u2, 1e-10f), 1.f)));
@@ -249,18 +252,24 @@ __global__ void __launch_bounds__(256) normal_fill_kernel(unsigned long long see
   for (int k = 0; k < 4; ++k) if (4 * q + k < n) out[4 * q + k] = z[k];
 }
 
-__global__ void __launch_bounds__(256) perm_keys_kernel(unsigned long long seed, unsigned long long stream_id, int B, unsigned* __restrict__ keys,
-                                                        int* __restrict__ vals) {
+__global__ void __launch_bounds__(256) perm_keys_kernel(unsigned long long seed, unsigned long long stream_id, const int* __restrict__ ctr, int B,
+                                                        unsigned* __restrict__ keys, int* __restrict__ vals) {
   const int q = blockIdx.x * blockDim.x + threadIdx.x;
   if (4 * q >= B) return;
-  const U4 r = philox4x32((unsigned)q, 0u, (unsigned)stream_id, (unsigned)(stream_id >> 32) ^ 0x5045524Du, (unsigned)seed, (unsigned)(seed >> 32));
+  const U4 r = philox4x32((unsigned)q, ctr ? (unsigned)ctr[0] : 0u, (unsigned)stream_id, (unsigned)(stream_id >> 32) ^ 0x5045524Du, (unsigned)seed, (unsigned)(seed >> 32));
   const unsigned z[4] = {r.x, r.y, r.z, r.w};
   for (int k = 0; k < 4; ++k) if (4 * q + k < B) { keys[4 * q + k] = z[k]; vals[4 * q + k] = 4 * q + k; }
 }
 
-int32_t perm_fill_keys(unsigned long long seed, unsigned long long stream_id, int B, unsigned* keys, int* vals, hipStream_t stream) {
-  hipLaunchKernelGGL(perm_keys_kernel, dim3(cdiv(cdiv(B, 4), 256)), dim3(256), 0, stream, seed, stream_id, B, keys, vals);
+int32_t perm_fill_keys(unsigned long long seed, unsigned long long stream_id, const int* ctr, int B, unsigned* keys, int* vals, hipStream_t stream) {
+  hipLaunchKernelGGL(perm_keys_kernel, dim3(cdiv(cdiv(B, 4), 256)), dim3(256), 0, stream, seed, stream_id, ctr, B, keys, vals);
   MPPO_CHECK_LAUNCH("perm_keys_kernel");
+  return MPPO_OK;
+}
+
+int32_t normal_fill_ctr(unsigned long long seed, unsigned long long stream_id, const int* ctr, size_t n, float* out, hipStream_t stream) {
+  hipLaunchKernelGGL(normal_fill_kernel, dim3(cdiv((long)((n + 3) / 4), 256)), dim3(256), 0, stream, seed, stream_id, ctr, n, out);
+  MPPO_CHECK_LAUNCH("normal_fill_kernel");
   return MPPO_OK;
 }
 
@@ -446,8 +455,5 @@ extern "C" int32_t mppo_clip_adam(size_t P, float* params, float* m, float* v, c
 
 extern "C" int32_t mppo_normal_fill(uint64_t seed, uint64_t stream_id, size_t n, float* out, void* stream) {
   MPPO_REQUIRE(out && n >= 1, "mppo_normal_fill: bad argument");
-  hipLaunchKernelGGL(normal_fill_kernel, dim3(cdiv((long)((n + 3) / 4), 256)), dim3(256), 0, static_cast<hipStream_t>(stream), (unsigned long long)seed,
-                     (unsigned long long)stream_id, n, out);
-  MPPO_CHECK_LAUNCH("normal_fill_kernel");
-  return MPPO_OK;
+  return normal_fill_ctr(seed, stream_id, nullptr, n, out, static_cast<hipStream_t>(stream));
 }

@@ -84,6 +84,8 @@ int32_t clip_adam(size_t P, float* params, float* m, float* v, const float* grad
                   hipStream_t stream);
 int32_t gae_launch(int T, int N, float gamma, float lam, const float* reward, const float* value, const unsigned char* done, const float* last_val, float* adv,
                    float* target, hipStream_t stream);
-int32_t perm_fill_keys(unsigned long long seed, unsigned long long stream_id, int B, unsigned* keys, int* vals, hipStream_t stream);
+int32_t perm_fill_keys(unsigned long long seed, unsigned long long stream_id, const int* ctr, int B, unsigned* keys, int* vals, hipStream_t stream);
+int32_t normal_fill_ctr(unsigned long long seed, unsigned long long stream_id, const int* ctr, size_t n, float* out, hipStream_t stream);
+int32_t permutation_ctr(unsigned long long seed, unsigned long long stream_id, const int* ctr, int B, int* idx, void* ws, size_t ws_bytes, hipStream_t stream);
 
 }  // namespace mppo

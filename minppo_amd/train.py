@@ -1,0 +1,433 @@
+"""Train a model with a specified environment module — MI355X-native engine.
+
+Same surface as the reference's `minppo/train.py`: `make_train(config) -> train(rng) -> TrainOutput`,
+`main(args)`, `save_model(params, filename)`, the `Memory / RunnerState / UpdateState / TrainOutput`
+records.  What differs is what runs underneath: instead of one jitted JAX program
+(`minppo/train.py:306,310`) every update is one call into libminppo_hip.so, which enqueues the
+rollout (policy MLP on f32 MFMA -> sample -> cooperative rigid-body step) and the PPO update (GAE ->
+E x M minibatches of forward / clipped-PPO loss / backward -> global-norm clip -> Adam) as HIP kernels,
+captured into a hipGraph and replayed.  PyTorch only holds the device arena, the stream and (for
+multi-GPU) the rendezvous used to hand the RCCL id around.
+
+Deviations from the reference, all deliberate and documented in DESIGN.md:
+  * `rng` is an integer seed (or a 2-word key whose words are folded into one); the random streams
+    are the engine's Philox streams, not JAX threefry.
+  * `TrainOutput.metrics` holds per-update device-side reductions, not the full
+    `[num_updates, T, N]` history of six fields the reference returns (`train.py:283,287`).
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+import logging
+import math
+import os
+import pickle
+import sys
+import time
+from typing import Any, Callable, Dict, NamedTuple, Optional, Sequence
+
+import numpy as np
+
+from minppo_amd import _native as nat
+from minppo_amd.config import Config, load_config_from_cli, require
+from minppo_amd.model import CompiledModel, load_model
+
+logger = logging.getLogger(__name__)
+
+
+class Memory(NamedTuple):
+    done: Any
+    action: Any
+    value: Any
+    reward: Any
+    log_prob: Any
+    obs: Any
+    info: Any
+
+
+class TrainState(NamedTuple):
+    """Stands where `flax.training.train_state.TrainState` stands (`train.py:126-130`)."""
+
+    step: int
+    params: dict
+    opt_state: dict
+
+
+class RunnerState(NamedTuple):
+    train_state: TrainState
+    env_state: Any
+    last_obs: Any
+    rng: Any
+
+
+class UpdateState(NamedTuple):
+    train_state: TrainState
+    mem_batch: "Memory"
+    advantages: Any
+    targets: Any
+    rng: Any
+
+
+class TrainOutput(NamedTuple):
+    runner_state: RunnerState
+    metrics: Any
+
+
+def save_model(params: dict, filename: str) -> None:
+    """Same contract as the reference (`train.py:86-89`): pickle of the nested parameter dict."""
+    d = os.path.dirname(filename)
+    if d:
+        os.makedirs(d, exist_ok=True)
+    with open(filename, "wb") as f:
+        pickle.dump(params, f)
+
+
+# ---------------------------------------------------------------------------
+# parameters
+# ---------------------------------------------------------------------------
+
+
+def param_slices(O: int, A: int, H: int):
+    """name -> (offset, shape) of the flat parameter vector (include/minppo_hip.h)."""
+    out, off = {}, 0
+    for name, shape in (("a_w1", (O, H)), ("a_b1", (H,)), ("a_w2", (H, H)), ("a_b2", (H,)), ("a_w3", (H, A)), ("a_b3", (A,)),
+                        ("log_std", (A,)), ("c_w1", (O, H)), ("c_b1", (H,)), ("c_w2", (H, H)), ("c_b2", (H,)), ("c_w3", (H, 1)),
+                        ("c_b3", (1,))):
+        out[name] = (off, shape)
+        off += int(np.prod(shape))
+    return out, off
+
+
+def _orthogonal(rng: np.random.Generator, n_in: int, n_out: int, scale: float) -> np.ndarray:
+    rows, cols = max(n_in, n_out), min(n_in, n_out)
+    q, r = np.linalg.qr(rng.standard_normal((rows, cols)))
+    q *= np.sign(np.diag(r))[None, :]
+    return (scale * (q.T if n_in < n_out else q)).astype(np.float32)
+
+
+def init_flat_params(seed: int, O: int, A: int, H: int) -> np.ndarray:
+    """`ActorCritic.init` (`train.py:63,68,80,112`): orthogonal kernels (gain sqrt 2 hidden, 0.01 heads),
+    zero biases, zero log_std.  The generator is NumPy's PCG64 seeded with `seed` (not JAX threefry)."""
+    rng = np.random.default_rng(seed)
+    sl, total = param_slices(O, A, H)
+    flat = np.zeros(total, np.float32)
+    g = math.sqrt(2.0)
+    for pref, last in (("a", A), ("c", 1)):
+        for name, (n_in, n_out, sc) in ((f"{pref}_w1", (O, H, g)), (f"{pref}_w2", (H, H, g)), (f"{pref}_w3", (H, last, 0.01))):
+            off, shape = sl[name]
+            flat[off:off + n_in * n_out] = _orthogonal(rng, n_in, n_out, sc).reshape(-1)
+    return flat
+
+
+def flat_to_tree(flat: np.ndarray, O: int, A: int, H: int) -> dict:
+    """The nested dict the reference pickles (`train.py:314`; Flax naming)."""
+    sl, _ = param_slices(O, A, H)
+
+    def get(name):
+        off, shape = sl[name]
+        return np.array(flat[off:off + int(np.prod(shape))].reshape(shape))
+
+    def mlp(p):
+        return {f"Dense_{i}": {"kernel": get(f"{p}_w{i + 1}"), "bias": get(f"{p}_b{i + 1}")} for i in range(3)}
+
+    return {"params": {"MLP_0": mlp("a"), "log_std": get("log_std"), "MLP_1": mlp("c")}}
+
+
+def tree_to_flat(tree: dict, O: int, A: int, H: int) -> np.ndarray:
+    sl, total = param_slices(O, A, H)
+    flat = np.zeros(total, np.float32)
+    t = tree["params"]
+
+    def put(name, arr):
+        off, shape = sl[name]
+        arr = np.asarray(arr, np.float32)
+        if arr.shape != shape:
+            raise ValueError(f"{name}: expected shape {shape}, got {arr.shape}")
+        flat[off:off + arr.size] = arr.reshape(-1)
+
+    put("log_std", t["log_std"])
+    for p, key in (("a", "MLP_0"), ("c", "MLP_1")):
+        for i in range(3):
+            put(f"{p}_w{i + 1}", t[key][f"Dense_{i}"]["kernel"])
+            put(f"{p}_b{i + 1}", t[key][f"Dense_{i}"]["bias"])
+    return flat
+
+
+# ---------------------------------------------------------------------------
+# engine wrapper
+# ---------------------------------------------------------------------------
+
+_REGION_DTYPES = {
+    "count": "int32", "done": "uint8", "perm": "int32", "adv_sums": "float64", "episode_lengths": "int32",
+    "returned_episode_lengths": "int32", "timestep": "int32", "returned_episode": "uint8",
+}
+
+
+def reward_cfg(config: Config) -> nat.RewardCfg:
+    r = config.reward
+    return nat.RewardCfg(r.height_min_z, r.height_max_z, r.original_pos_reward_exp_coefficient, r.original_pos_reward_subtraction_factor,
+                         r.original_pos_reward_max_diff_norm, r.weights_ctrl_cost, r.weights_original_pos_reward, r.weights_is_healthy,
+                         r.weights_velocity)
+
+
+def resolve_model(config: Config) -> CompiledModel:
+    name = config.environment.model or require(config.kscale_id, "kscale_id")
+    return load_model(name)
+
+
+class Trainer:
+    """One rank of the engine: robot model, HBM arena, engine handle and tensor views of its regions."""
+
+    def __init__(self, config: Config, *, lib: Optional[nat.Lib] = None, device: Any = None, rank: int = 0, world_size: int = 1,
+                 seed: Optional[int] = None, use_graph: bool = True, external_random: bool = False, stream: Any = None,
+                 num_envs_local: Optional[int] = None, xp: str = "torch"):
+        self.config = config
+        self.lib = lib if lib is not None else nat.load()
+        self.xp = xp
+        self.rank, self.world_size = rank, world_size
+        tr, rl = config.training, config.rl
+        if rl.num_env_steps != tr.num_steps:
+            # the reference would fail at the reshape (`train.py:260`; quirk C-1)
+            raise ValueError(f"rl.num_env_steps ({rl.num_env_steps}) must equal training.num_steps ({tr.num_steps})")
+        if config.model.num_layers != 2:
+            raise ValueError("the MI355X engine lays out exactly two hidden layers (reference default, config.py:53)")
+        if not config.environment.include_c_vals:
+            raise ValueError("environment.include_c_vals=false is not supported by the fused observation record")
+        if tr.num_envs % world_size != 0:
+            raise ValueError(f"training.num_envs ({tr.num_envs}) must be divisible by the number of ranks ({world_size})")
+        self.num_envs_global = tr.num_envs
+        self.N = num_envs_local if num_envs_local is not None else tr.num_envs // world_size
+        self.T, self.M, self.E = tr.num_steps, tr.num_minibatches, tr.update_epochs
+        # train.py:93-94 (global quantities)
+        self.num_updates = tr.total_timesteps // tr.num_steps // tr.num_envs
+        self.minibatch_size = tr.num_envs * tr.num_steps // tr.num_minibatches
+        if self.minibatch_size * tr.num_minibatches != tr.num_steps * tr.num_envs:
+            raise ValueError("`batch_size` must be equal to `num_steps * num_envs`")  # train.py:254-255
+        self.seed = tr.seed if seed is None else int(seed)
+
+        self.cm = resolve_model(config)
+        blob = np.frombuffer(self.cm.to_blob(), np.uint8)
+        self._blob_host = blob.copy()
+        if xp == "torch":
+            import torch
+
+            self.torch = torch
+            self.device = torch.device(device if device is not None else f"cuda:{torch.cuda.current_device()}")
+            self._blob_dev = torch.from_numpy(self._blob_host.copy()).to(self.device)
+            self.stream = stream if stream is not None else torch.cuda.Stream(device=self.device)
+            self._stream_ptr = self.stream.cuda_stream
+        else:  # numpy "device" memory: the CPU emulator build used by the test-suite
+            self.torch = None
+            self.device = "cpu-emulator"
+            buf = np.zeros(blob.size + 256, np.uint8)
+            o = (-buf.ctypes.data) % 256
+            self._blob_dev = buf[o:o + blob.size]
+            self._blob_dev[:] = blob
+            self.stream, self._stream_ptr = None, None
+        self._model = C.c_void_p()
+        self.lib.model_open(self._blob_host.ctypes.data, self._blob_host.size, nat.ptr(self._blob_dev), C.byref(self._model))
+        self.dims = nat.ModelDims()
+        self.lib.model_get_dims(self._model, C.byref(self.dims))
+        self.O, self.OP, self.A, self.H = self.dims.obs_dim, self.dims.obs_pad, self.dims.nu, config.model.hidden_size
+        self.net = nat.Net(self.O, self.OP, self.A, self.H, int(config.model.use_tanh), int(tr.mlp_dtype == "bf16"))
+        lr = tr.lr if tr.anneal_lr else config.opt.lr  # train.py:101 vs :123 (quirk C-3)
+        self.ecfg = nat.EngineCfg(
+            num_envs=self.N, num_steps=self.T, num_minibatches=self.M, update_epochs=self.E, n_frames=config.environment.n_frames,
+            num_updates=max(self.num_updates, 1), world_size=world_size, rank=rank, gamma=rl.gamma, gae_lambda=rl.gae_lambda,
+            loss=nat.LossCfg(rl.clip_eps, rl.vf_coef, rl.ent_coef),
+            adam=nat.AdamCfg(lr, config.opt.max_grad_norm, 0.9, 0.999, 1e-5, int(tr.anneal_lr), 0, 0),
+            reward=reward_cfg(config), net=self.net, seed=self.seed, use_graph=int(use_graph), external_random=int(external_random))
+        nbytes = C.c_size_t()
+        self.lib.engine_arena_bytes(self._model, C.byref(self.ecfg), C.byref(nbytes))
+        self.arena_bytes = nbytes.value
+        if xp == "torch":
+            self.arena = self.torch.zeros(self.arena_bytes + 256, dtype=self.torch.uint8, device=self.device)
+            o = (-self.arena.data_ptr()) % 256
+            self.arena = self.arena[o:o + self.arena_bytes]
+        else:
+            raw = np.zeros(self.arena_bytes + 256, np.uint8)
+            o = (-raw.ctypes.data) % 256
+            self.arena = raw[o:o + self.arena_bytes]
+        self._engine = C.c_void_p()
+        self.lib.engine_create(self._model, C.byref(self.ecfg), nat.ptr(self.arena), self.arena_bytes, C.byref(self._engine))
+        self.P = int(self.lib.param_count(C.byref(self.net)))
+        self.updates_done = 0
+        self.set_params_flat(init_flat_params(self.seed, self.O, self.A, self.H))
+
+    # -- arena views ----------------------------------------------------------
+    def region(self, name: str, shape: Optional[Sequence[int]] = None):
+        off, nb = C.c_size_t(), C.c_size_t()
+        self.lib.engine_region(self._engine, name.encode(), C.byref(off), C.byref(nb))
+        dt = _REGION_DTYPES.get(name, "float32")
+        raw = self.arena[off.value:off.value + nb.value]
+        if self.xp == "torch":
+            v = raw.view(getattr(self.torch, dt))
+        else:
+            v = raw.view(np.dtype(dt))
+        return v.reshape(*shape) if shape is not None else v
+
+    def traj(self) -> Dict[str, Any]:
+        T, N = self.T, self.N
+        return dict(obs=self.region("obs", (T + 1, N, self.OP)), action=self.region("action", (T, N, self.A)),
+                    value=self.region("value", (T, N)), reward=self.region("reward", (T, N)), log_prob=self.region("log_prob", (T, N)),
+                    done=self.region("done", (T, N)), adv=self.region("adv", (T, N)), target=self.region("target", (T, N)),
+                    last_val=self.region("last_val", (N,)))
+
+    def _to_host(self, x) -> np.ndarray:
+        return x.detach().cpu().numpy() if self.xp == "torch" else np.array(x)
+
+    def _sync(self) -> None:
+        if self.xp == "torch":
+            self.stream.synchronize()
+
+    def set_params_flat(self, flat: np.ndarray) -> None:
+        flat = np.ascontiguousarray(flat, np.float32)
+        if flat.size != self.P:
+            raise ValueError(f"expected {self.P} parameters, got {flat.size}")
+        dst = self.region("params")
+        if self.xp == "torch":
+            self._sync()
+            dst.copy_(self.torch.from_numpy(flat))
+            self.torch.cuda.synchronize(self.device)
+        else:
+            dst[:] = flat
+
+    def params_flat(self) -> np.ndarray:
+        self._sync()
+        return self._to_host(self.region("params")).copy()
+
+    @property
+    def params(self) -> dict:
+        return flat_to_tree(self.params_flat(), self.O, self.A, self.H)
+
+    # -- multi-GPU ---------------------------------------------------------------
+    def init_comm(self) -> None:
+        """Creates the engine's RCCL communicator; the 128-byte id travels through torch.distributed."""
+        if self.world_size == 1:
+            return
+        import torch.distributed as dist
+
+        idbuf = self.torch.zeros(128, dtype=self.torch.uint8)
+        if self.rank == 0:
+            host = np.zeros(128, np.uint8)
+            self.lib.comm_unique_id(host.ctypes.data)
+            idbuf = self.torch.from_numpy(host)
+        idbuf = idbuf.to(self.device)
+        dist.broadcast(idbuf, src=0)
+        host = idbuf.cpu().numpy().copy()
+        with self.torch.cuda.device(self.device):
+            self.lib.engine_comm_init(self._engine, host.ctypes.data)
+
+    # -- stepping ----------------------------------------------------------------
+    def reset(self) -> None:
+        self.lib.engine_reset(self._engine, self._stream_ptr)
+
+    def update(self) -> None:
+        self.lib.engine_update(self._engine, self._stream_ptr)
+        self.updates_done += 1
+
+    def rollout(self) -> None:
+        self.lib.engine_rollout(self._engine, self._stream_ptr)
+
+    def learn(self) -> None:
+        self.lib.engine_learn(self._engine, self._stream_ptr)
+        self.updates_done += 1
+
+    def rollout_stats(self) -> Dict[str, float]:
+        self._sync()
+        s = self._to_host(self.region("rollout_stats"))
+        n = float(self.T * self.N)
+        return {"mean_reward": float(s[0]) / n, "done_fraction": float(s[1]) / n}
+
+    def losses(self) -> np.ndarray:
+        self._sync()
+        return self._to_host(self.region("losses", (self.E, self.M, 4))).copy()
+
+    def close(self) -> None:
+        if getattr(self, "_engine", None) is not None and self._engine:
+            self._sync()
+            self.lib.engine_destroy(self._engine)
+            self._engine = None
+        if getattr(self, "_model", None) is not None and self._model:
+            self.lib.model_close(self._model)
+            self._model = None
+
+    def __del__(self):  # pragma: no cover - best effort
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def _seed_from_rng(rng: Any) -> int:
+    if rng is None:
+        return 0
+    a = np.asarray(rng)
+    if a.ndim == 0:
+        return int(a)
+    a = a.astype(np.uint64).reshape(-1)
+    s = 0
+    for w in a:
+        s = (s * 0x100000001B3 + int(w)) & 0xFFFFFFFFFFFFFFFF
+    return s
+
+
+def make_train(config: Config, **trainer_kwargs: Any) -> Callable[[Any], TrainOutput]:
+    """`make_train(config) -> train(rng)` (`minppo/train.py:92-291`)."""
+    num_updates = config.training.total_timesteps // config.training.num_steps // config.training.num_envs
+    minibatch_size = config.training.num_envs * config.training.num_steps // config.training.num_minibatches
+    if minibatch_size * config.training.num_minibatches != config.training.num_steps * config.training.num_envs:
+        raise ValueError("`batch_size` must be equal to `num_steps * num_envs`")
+
+    def train(rng: Any, max_updates: Optional[int] = None, log_every: int = 0) -> TrainOutput:
+        tr = Trainer(config, seed=_seed_from_rng(rng), **trainer_kwargs)
+        tr.init_comm()
+        tr.reset()
+        n = num_updates if max_updates is None else min(num_updates, max_updates)
+        metrics = {"mean_reward": [], "done_fraction": [], "total_loss": [], "value_loss": [], "actor_loss": [], "entropy": []}
+        t0 = time.time()
+        for u in range(n):
+            tr.update()
+            if log_every and ((u + 1) % log_every == 0 or u + 1 == n):
+                st, lo = tr.rollout_stats(), tr.losses().reshape(-1, 4).mean(0)
+                for k, v in st.items():
+                    metrics[k].append(v)
+                for k, v in zip(("total_loss", "value_loss", "actor_loss", "entropy"), lo):
+                    metrics[k].append(float(v))
+                sps = (u + 1) * tr.T * tr.N * tr.world_size / (time.time() - t0)
+                logger.info("update %d/%d  reward %.3f  done %.4f  loss %.4f  %.0f env-steps/s", u + 1, n, st["mean_reward"], st["done_fraction"],
+                            lo[0], sps)
+        params = tr.params
+        count = int(tr._to_host(tr.region("count"))[0]) if n else 0
+        state = TrainState(step=count, params=params, opt_state={"mu": flat_to_tree(tr._to_host(tr.region("adam_m")), tr.O, tr.A, tr.H),
+                                                                   "nu": flat_to_tree(tr._to_host(tr.region("adam_v")), tr.O, tr.A, tr.H), "count": count})
+        last_obs = tr._to_host(tr.region("obs", (tr.T + 1, tr.N, tr.OP))[0, :, :tr.O])
+        rs = RunnerState(train_state=state, env_state=tr._to_host(tr.region("state", (tr.N, tr.dims.rec_dim))), last_obs=last_obs, rng=rng)
+        out = TrainOutput(runner_state=rs, metrics={k: np.asarray(v) for k, v in metrics.items()})
+        tr.close()
+        return out
+
+    return train
+
+
+def main(args: Sequence[str] | None = None) -> None:
+    logging.basicConfig(level=logging.INFO, format="%(asctime)s - %(levelname)s - %(message)s")
+    if args is None:
+        args = sys.argv[1:]
+    config = load_config_from_cli(args)
+    logger.info("Configuration loaded")
+    rng = config.training.seed
+    logger.info(f"Random seed set to {config.training.seed}")
+    train = make_train(config)
+    logger.info("Training function bound to the MI355X engine")
+    logger.info("Starting training...")
+    out = train(rng, log_every=max(1, (config.training.total_timesteps // config.training.num_steps // config.training.num_envs) // 100))
+    logger.info("Training completed")
+    logger.info(f"Saving model to {config.training.model_save_path}")
+    save_model(out.runner_state.train_state.params, config.training.model_save_path)
+    logger.info("Model saved successfully")
+
+
+if __name__ == "__main__":
+    main()
