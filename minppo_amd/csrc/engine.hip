@@ -275,25 +275,25 @@ extern "C" int32_t mppo_engine_reset(mppo_engine_t* e, void* stream) {
   return MPPO_OK;
 }
 
-static int32_t require_ready(mppo_engine_t* e) {
+static int32_t require_ready(mppo_engine_t* e, bool needs_comm) {
   MPPO_REQUIRE(e, "null engine");
   if (!e->was_reset) return fail(MPPO_ESTATE, "engine: call mppo_engine_reset before stepping");
-  if (e->cfg.world_size > 1 && !e->comm) return fail(MPPO_ESTATE, "engine: world_size = %d but mppo_engine_comm_init was not called", e->cfg.world_size);
+  if (needs_comm && e->cfg.world_size > 1 && !e->comm) return fail(MPPO_ESTATE, "engine: world_size = %d but mppo_engine_comm_init was not called", e->cfg.world_size);
   return MPPO_OK;
 }
 
 extern "C" int32_t mppo_engine_rollout(mppo_engine_t* e, void* stream) {
-  MPPO_TRY(require_ready(e));
+  MPPO_TRY(require_ready(e, false));  // the rollout needs no communication: environments are independent
   return do_rollout(e, static_cast<hipStream_t>(stream));
 }
 
 extern "C" int32_t mppo_engine_learn(mppo_engine_t* e, void* stream) {
-  MPPO_TRY(require_ready(e));
+  MPPO_TRY(require_ready(e, true));
   return do_learn(e, static_cast<hipStream_t>(stream));
 }
 
 extern "C" int32_t mppo_engine_update(mppo_engine_t* e, void* stream) {
-  MPPO_TRY(require_ready(e));
+  MPPO_TRY(require_ready(e, true));
   hipStream_t s = static_cast<hipStream_t>(stream);
   const bool want_graph = e->cfg.use_graph && !e->graph_failed && e->cfg.world_size == 1 && s != nullptr;
   if (want_graph) {

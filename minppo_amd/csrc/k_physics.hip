@@ -898,7 +898,6 @@ extern "C" int32_t mppo_model_open(const void* host_blob, size_t nbytes, const v
     for (int d = 0; d < v.nv; ++d) if (dp[d] >= d) return bad("dof_parentid must point to an earlier dof");
     for (int l = 0; l < v.nlevel; ++l) if (la[l + 1] < la[l] || la[l + 1] > v.nbody - 1) return bad("level_adr not monotone");
     if (HI(BI_root_body)[0] != 1) return bad("body 1 must be the first tree root");
-    if (v.nq < 3) return bad("nq < 3: the height test reads qpos[2] (env.py:239)");
   }
   const int32_t* dI = static_cast<const int32_t*>(dev_blob);
   const float* dF = static_cast<const float*>(dev_blob);
@@ -962,6 +961,7 @@ extern "C" int32_t mppo_env_reset(const mppo_model_t* m, int32_t N, float* state
   using namespace mppo;
   MPPO_REQUIRE(m && state && reset_rec, "mppo_env_reset: null model / state / reset_rec");
   MPPO_REQUIRE(N >= 1, "mppo_env_reset: N = %d", N);
+  MPPO_REQUIRE(m->mv.nq >= 3, "mppo_env_reset: the environment reads qpos[2] as the height (env.py:239); nq = %d", m->mv.nq);
   MPPO_REQUIRE(!obs || obs_ld >= m->mv.obs_pad, "mppo_env_reset: obs_ld %d < padded observation width %d", obs_ld, m->mv.obs_pad);
   EnvArgs a{};
   a.N = N; a.mode = 0; a.n_frames = 1; a.state = state; a.reset_out = reset_rec; a.obs = obs; a.obs_ld = obs_ld; a.reward = reward; a.done = done;
@@ -975,6 +975,7 @@ extern "C" int32_t mppo_env_step(const mppo_model_t* m, int32_t N, int32_t n_fra
   using namespace mppo;
   MPPO_REQUIRE(m && rc && state && reset_rec && action && obs && reward && done, "mppo_env_step: null argument");
   MPPO_REQUIRE(N >= 1 && n_frames >= 1, "mppo_env_step: N = %d, n_frames = %d", N, n_frames);
+  MPPO_REQUIRE(m->mv.nq >= 3, "mppo_env_step: the environment reads qpos[2] as the height (env.py:239); nq = %d", m->mv.nq);
   MPPO_REQUIRE(act_ld >= m->mv.nu, "mppo_env_step: act_ld %d < nu %d", act_ld, m->mv.nu);
   MPPO_REQUIRE(obs_ld >= m->mv.obs_pad, "mppo_env_step: obs_ld %d < padded observation width %d", obs_ld, m->mv.obs_pad);
   EnvArgs a{};

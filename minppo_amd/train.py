@@ -334,6 +334,46 @@ class Trainer:
         self.lib.engine_learn(self._engine, self._stream_ptr)
         self.updates_done += 1
 
+    def learn_host_driven(self, allreduce_sum=None) -> None:
+        """The learn phase with the collectives supplied by the caller: `allreduce_sum(array_view)` must sum the
+        view in place over ranks.  Same stage calls, same order and same weighting as the engine's own
+        `mppo_engine_learn` (csrc/engine.hip: do_learn); it exists so that the sharding arithmetic can be
+        exercised with torch.distributed/gloo where RCCL is not available, and as a reference for integrators
+        who drive the stages themselves.  Requires external_random-style permutations already in "perm"."""
+        E, M, mb, B, W = self.E, self.M, (self.T * self.N) // self.M, self.T * self.N, self.world_size
+        lib, s = self.lib, self._stream_ptr
+        reg = {k: self.region(k) for k in ("adv", "perm", "adv_sums", "adv_stats", "params", "adam_m", "adam_v", "grad", "count", "losses", "obs",
+                                           "action", "value", "log_prob", "target", "grad_ws", "adam_ws")}
+        p = {k: nat.ptr(v) for k, v in reg.items()}
+        lib.adv_sums(p["adv"], p["perm"], E * M, mb, p["adv_sums"], s)
+        if W > 1:
+            self._sync()
+            allreduce_sum(reg["adv_sums"])
+        lib.adv_stats_finalize(p["adv_sums"], E * M, float(mb * W), p["adv_stats"], s)
+        batch = nat.Batch(p["obs"], self.OP, p["action"], self.A, p["value"], p["log_prob"], p["adv"], p["target"])
+        lc = self.ecfg.loss
+        ac = nat.AdamCfg(self.ecfg.adam.lr, self.ecfg.adam.max_grad_norm, 0.9, 0.999, 1e-5, self.ecfg.adam.anneal, mb * W * E, self.ecfg.num_updates)
+        wsb = lib.grad_ws_bytes(C.byref(self.net), mb)
+        for e in range(E):
+            for k in range(M):
+                st = e * M + k
+                lib.minibatch_grad(C.byref(self.net), p["params"], C.byref(batch), p["perm"] + 4 * (e * B + k * mb), mb, p["adv_stats"] + 8 * st,
+                                   1.0 / (mb * W), C.byref(lc), p["grad"], p["losses"] + 16 * st, p["grad_ws"], wsb, s)
+                if W > 1:
+                    self._sync()
+                    allreduce_sum(reg["grad"])
+                lib.clip_adam(self.P, p["params"], p["adam_m"], p["adam_v"], p["grad"], p["count"], st, C.byref(ac), p["adam_ws"], 512, s)
+        self._sync()
+        cnt = self.region("count")
+        cnt[0] += E * M
+        cnt[1] += 1
+        obs = self.region("obs", (self.T + 1, self.N, self.OP))
+        if self.xp == "torch":
+            obs[0].copy_(obs[self.T])
+        else:
+            obs[0] = obs[self.T]
+        self.updates_done += 1
+
     def rollout_stats(self) -> Dict[str, float]:
         self._sync()
         s = self._to_host(self.region("rollout_stats"))

@@ -1,0 +1,43 @@
+"""Config surface: same fields / defaults / override grammar as the reference (`minppo/config.py:16-127`)."""
+import pytest
+
+from minppo_amd.config import MISSING, Config, MissingMandatoryValue, load_config_from_cli, make_config, require, to_yaml
+
+
+def test_defaults_match_the_reference():
+    c = Config()
+    assert (c.training.lr, c.training.seed, c.training.num_envs, c.training.total_timesteps) == (3e-4, 1337, 2048, 1_000_000_000)
+    assert (c.training.num_minibatches, c.training.num_steps, c.training.update_epochs, c.training.anneal_lr) == (32, 10, 4, True)
+    assert c.training.model_save_path == "trained_model.pkl"
+    assert (c.rl.num_env_steps, c.rl.gamma, c.rl.gae_lambda, c.rl.clip_eps, c.rl.ent_coef, c.rl.vf_coef) == (10, 0.99, 0.95, 0.2, 0.0, 0.5)
+    assert (c.opt.lr, c.opt.max_grad_norm) == (3e-4, 0.5)
+    assert (c.model.hidden_size, c.model.num_layers, c.model.use_tanh) == (256, 2, True)
+    assert (c.environment.n_frames, c.environment.backend, c.environment.include_c_vals) == (1, "mjx", True)
+    r = c.reward
+    assert (r.height_min_z, r.height_max_z, r.original_pos_reward_exp_coefficient, r.original_pos_reward_subtraction_factor) == (-0.2, 2.0, 2, 0.2)
+    assert (r.original_pos_reward_max_diff_norm, r.weights_ctrl_cost, r.weights_original_pos_reward, r.weights_is_healthy, r.weights_velocity) == (0.5, 0.1, 4, 1, 1.25)
+    assert c.kscale_id is MISSING and c.visualization.camera_name is MISSING and c.inference.model_path is MISSING and c.debug is True
+
+
+def test_cli_name_path_and_dotlist(tmp_path):
+    c = load_config_from_cli(["stompy_pro", "training.num_envs=4096", "rl.gamma=0.9", "training.anneal_lr=false", "reward.height_min_z=-1"])
+    assert c.kscale_id == "5eb3cb7f23232298" and c.visualization.camera_name == "track" and c.training.num_minibatches == 32
+    assert c.training.num_envs == 4096 and c.rl.gamma == 0.9 and c.training.anneal_lr is False and c.reward.height_min_z == -1.0
+    p = tmp_path / "x.yaml"
+    p.write_text("kscale_id: abc\ntraining:\n  lr: 1.0e-3\n  total_timesteps: 1e6\n")
+    c = load_config_from_cli([str(p), "model.hidden_size=64"])
+    assert c.kscale_id == "abc" and c.training.lr == 1e-3 and c.training.total_timesteps == 1_000_000 and c.model.hidden_size == 64
+    assert "hidden_size: 64" in to_yaml(c)
+
+
+def test_errors_follow_the_reference():
+    with pytest.raises(ValueError, match="Usage"):
+        load_config_from_cli([])
+    with pytest.raises(ValueError, match="Config file not found"):
+        load_config_from_cli(["no_such_config"])
+    with pytest.raises(ValueError, match="not in the config schema"):
+        make_config({}, ["training.bogus=1"])
+    with pytest.raises(ValueError):
+        make_config({}, ["training.num_envs=abc"])
+    with pytest.raises(MissingMandatoryValue):
+        require(Config().kscale_id, "kscale_id")

@@ -1,0 +1,177 @@
+"""The engine (`mppo_engine_*`: one `_update_step`, reference minppo/train.py:146-283) against the oracle.
+
+Stage-wise "identical inputs" parity: noise and permutations are written into the arena; the physics is
+chaotic at float32 (see test_kernels_physics.py), so the PPO half is checked on the engine's OWN
+trajectory, and the rollout is checked step-by-step against the env oracle driven by the engine's actions."""
+import numpy as np
+import pytest
+
+from minppo_amd import _native as nat
+from minppo_amd.config import make_config
+from oracle import ppo_oracle as po
+from oracle.env_oracle import EnvOracle, RewardCfg, default_hp
+
+BASE = {"kscale_id": "5eb3cb7f23232298", "visualization": {"camera_name": "track"}}
+
+
+def _cfg(*over):
+    return make_config(BASE, list(over))
+
+
+def _small(be):
+    if be.name == "emu":
+        return ["training.num_envs=8", "training.num_steps=4", "rl.num_env_steps=4", "training.num_minibatches=2", "training.update_epochs=2",
+                "model.hidden_size=32", "training.total_timesteps=100000"]
+    return ["training.num_envs=256", "training.num_minibatches=8", "training.update_epochs=2", "training.total_timesteps=100000000"]
+
+
+def test_update_matches_oracle_stage_by_stage(be):
+    cfg = _cfg(*_small(be))
+    tr = be.trainer(cfg, external_random=True, use_graph=False)
+    tr.reset()
+    N, T, A, H, O, OP, E, M = tr.N, tr.T, tr.A, tr.H, tr.O, tr.OP, tr.E, tr.M
+    rng = np.random.default_rng(0)
+    env = EnvOracle(tr.cm.t, RewardCfg())
+    hp = default_hp(cfg)
+    p = tr.params_flat().astype(np.float64)
+    opt = po.OptState(np.zeros_like(p), np.zeros_like(p), 0)
+    for u in range(2):
+        noise = rng.standard_normal((T, N, A)).astype(np.float32)
+        perms = np.stack([rng.permutation(N * T) for _ in range(E)]).astype(np.int32)
+        be.put(tr.region("noise", (T, N, A)), noise)
+        be.put(tr.region("perm", (E, N * T)), perms)
+        tr.rollout()
+        tr._sync()
+        tj = {k: be.host(v).copy() for k, v in tr.traj().items()}
+        obs = tj["obs"][:, :, :O].astype(np.float64)
+        named = po.flat_to_named(p, O, A, H)
+        # policy on the engine's observations (every t), sample + log-prob with the given noise
+        for t in range(T):
+            mean, ls, val = po.actor_critic_forward(named, obs[t])
+            act = po.mvn_sample(mean, ls, noise[t].astype(np.float64))
+            np.testing.assert_allclose(tj["action"][t], act, atol=5e-5)
+            np.testing.assert_allclose(tj["value"][t], val, atol=5e-5)
+            np.testing.assert_allclose(tj["log_prob"][t], po.mvn_log_prob(act, mean, ls), atol=2e-4)
+        _, _, lv = po.actor_critic_forward(named, obs[T])
+        np.testing.assert_allclose(tj["last_val"], lv, atol=5e-5)
+        # environment: the oracle driven by the engine's actions tracks the engine's rollout
+        if u == 0:
+            es = env.reset(N)
+            np.testing.assert_allclose(obs[0], es["obs"], atol=1e-5)
+            for t in range(T):
+                es = env.step(es, tj["action"][t].astype(np.float64))
+                assert (tj["done"][t].astype(bool) == es["done"]).all()
+                np.testing.assert_allclose(obs[t + 1], es["obs"], atol=0.5 if t else 1e-4)  # obs(t+1) shows state t (lag): chaotic drift after t = 0
+                np.testing.assert_allclose(tj["reward"][t], es["reward"], atol=0.25)
+        # GAE on the engine's trajectory
+        adv, tgt = po.calculate_gae(tj["done"].astype(bool), tj["value"].astype(np.float64), tj["reward"].astype(np.float64), tj["last_val"].astype(np.float64),
+                                    cfg.rl.gamma, cfg.rl.gae_lambda)
+        np.testing.assert_allclose(tj["adv"], adv, rtol=1e-4, atol=1e-4)
+        np.testing.assert_allclose(tj["target"], tgt, rtol=1e-4, atol=1e-4)
+        # E x M optimizer steps
+        tr.learn()
+        traj = dict(obs=obs[:T], action=tj["action"].astype(np.float64), value=tj["value"].astype(np.float64), log_prob=tj["log_prob"].astype(np.float64))
+        p_new, opt, losses = po.update_epochs_on_batch(p, opt, traj, adv, tgt, perms, O=O, A=A, H=H, num_minibatches=M, hp=hp)
+        step = np.abs(p_new - p).max()
+        got = tr.params_flat()
+        assert np.abs(got - p_new).max() < 2e-2 * step + 1e-7, (np.abs(got - p_new).max(), step)
+        np.testing.assert_allclose(tr.losses(), losses, rtol=2e-3, atol=2e-4)
+        cnt = be.host(tr.region("count"))
+        assert cnt[0] == (u + 1) * E * M and cnt[1] == u + 1
+        # carried last_obs: slot 0 of the next rollout is slot T of this one
+        np.testing.assert_array_equal(be.host(tr.region("obs", (T + 1, N, OP)))[0], tj["obs"][T])
+        p = got.astype(np.float64)  # continue from the engine's parameters (identical inputs for the next update)
+        opt = po.OptState(be.host(tr.region("adam_m")).astype(np.float64), be.host(tr.region("adam_v")).astype(np.float64), opt.count)
+    st = tr.rollout_stats()
+    assert np.isfinite(st["mean_reward"]) and st["done_fraction"] == 0.0
+    tr.close()
+
+
+def test_internal_rng_update_is_deterministic_and_learns_something(be):
+    cfg = _cfg(*_small(be))
+    outs = []
+    for rep in range(2):
+        tr = be.trainer(cfg, use_graph=False)
+        tr.reset()
+        p0 = tr.params_flat()
+        for _ in range(2):
+            tr.update()
+        outs.append(tr.params_flat())
+        perm = be.host(tr.region("perm", (tr.E, tr.T * tr.N)))
+        assert all((np.sort(perm[e]) == np.arange(tr.T * tr.N)).all() for e in range(tr.E))
+        noise = be.host(tr.region("noise"))
+        assert abs(noise.mean()) < 0.2 and 0.8 < noise.std() < 1.2
+        lo = tr.losses()
+        assert np.isfinite(lo).all() and np.allclose(lo[..., 3], 0.5 * tr.A * (1 + np.log(2 * np.pi)), atol=0.5)
+        tr.close()
+    np.testing.assert_array_equal(outs[0], outs[1])  # same seed -> bitwise the same parameters
+    assert np.abs(outs[0] - p0).max() > 1e-5
+
+
+def test_engine_errors(be):
+    with pytest.raises(ValueError, match="batch_size"):  # the reference's ValueError (train.py:253-255)
+        be.trainer(_cfg("training.num_envs=6", "training.num_minibatches=4", "training.num_steps=1", "rl.num_env_steps=1"))
+    with pytest.raises(ValueError, match="num_env_steps"):
+        be.trainer(_cfg("rl.num_env_steps=1000"))  # the README's own example would break the reference too (quirk C-1)
+    tr = be.trainer(_cfg(*_small(be)))
+    with pytest.raises(nat.NativeError, match="reset"):
+        tr.update()
+    with pytest.raises(nat.NativeError, match="no region"):
+        tr.region("no_such_region")
+    with pytest.raises(ValueError, match="parameters"):
+        tr.set_params_flat(np.zeros(3, np.float32))
+    tr.close()
+
+
+@pytest.mark.gpu
+def test_hipgraph_replay_equals_eager_launches():
+    """The captured update replays the same launch sequence: parameters are bitwise equal to the eager run."""
+    from backends import get_backend
+
+    be = get_backend("hip")
+    cfg = _cfg("training.num_envs=512", "training.num_minibatches=8", "training.update_epochs=2", "training.total_timesteps=100000000")
+    res = []
+    for graph in (False, True):
+        tr = be.trainer(cfg, use_graph=graph)
+        tr.reset()
+        for _ in range(3):
+            tr.update()
+        res.append((tr.params_flat(), be.host(tr.region("count")).copy(), be.host(tr.region("reward")).copy()))
+        tr.close()
+    np.testing.assert_array_equal(res[0][1], res[1][1])
+    np.testing.assert_array_equal(res[0][2], res[1][2])
+    np.testing.assert_array_equal(res[0][0], res[1][0])
+
+
+@pytest.mark.gpu
+def test_full_size_properties_on_gpu():
+    """BASELINE configs[1] size (4096 envs): size-independent properties of one full update."""
+    from backends import get_backend
+
+    be = get_backend("hip")
+    cfg = _cfg("training.num_envs=4096")
+    tr = be.trainer(cfg, use_graph=True)
+    tr.reset()
+    for _ in range(2):
+        tr.update()
+    tr._sync()
+    T, N, E, M = tr.T, tr.N, tr.E, tr.M
+    tj = {k: be.host(v) for k, v in tr.traj().items()}
+    assert all(np.isfinite(tj[k]).all() for k in ("obs", "action", "value", "reward", "log_prob", "adv", "target"))
+    np.testing.assert_allclose(tj["target"], tj["adv"] + tj["value"], rtol=1e-6, atol=1e-6)  # targets = adv + value (train.py:205)
+    perm = be.host(tr.region("perm", (E, T * N)))
+    for e in range(E):
+        assert (np.sort(perm[e]) == np.arange(T * N)).all()  # every sample used exactly once per epoch
+    stats = be.host(tr.region("adv_stats", (E * M, 2)))
+    mb = T * N // M
+    adv = tj["adv"].reshape(-1)
+    for k in (0, E * M - 1):
+        g = adv[perm.reshape(-1)[k * mb:(k + 1) * mb]].astype(np.float64)
+        np.testing.assert_allclose(stats[k], [g.mean(), 1 / (g.std() + 1e-8)], rtol=1e-5)
+    assert be.host(tr.region("count"))[0] == 2 * E * M
+    ts = be.host(tr.region("timestep"))
+    assert (ts == 2 * T).all()  # every env stepped exactly T times per update
+    lo = tr.losses()
+    assert np.isfinite(lo).all()
+    np.testing.assert_allclose(lo[..., 0], lo[..., 2] + cfg.rl.vf_coef * lo[..., 1] - cfg.rl.ent_coef * lo[..., 3], rtol=1e-5, atol=1e-5)
+    tr.close()

@@ -1,0 +1,218 @@
+"""Parity of the PPO stage kernels (k_ppo.hip, k_gemm.hip, k_perm.hip) with the oracle, through the C ABI.
+
+Backends: CPU emulator build of the kernel sources (default) and MI355X (-m gpu).
+Tolerances (float32 kernels vs float64 oracle; SURVEY 8c proposal):
+  GAE rtol 1e-5 / atol 1e-5; policy outputs atol 2e-5; loss scalars rtol 1e-5;
+  gradients rtol 1e-4 of each tensor's max + atol 1e-7; Adam after 3 steps atol 1e-6.
+"""
+
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from minppo_amd import _native as nat
+from oracle import ppo_oracle as po
+
+f32 = np.float32
+
+
+def _net(O, A, H, tanh=1):
+    return nat.Net(O, (O + 3) // 4 * 4, A, H, tanh, 0)
+
+
+def _params(rng, O, A, H, jitter=0.05):
+    named = po.init_params(3, O, A, H)
+    for k in named:
+        named[k] = named[k] + jitter * rng.standard_normal(named[k].shape)
+    flat = po.named_to_flat(named, O, A, H).astype(f32)
+    return flat, {k: v.astype(np.float64) for k, v in po.flat_to_named(flat, O, A, H).items()}
+
+
+@pytest.mark.parametrize("T,N", [(10, 37), (1, 1), (3, 300)])
+def test_gae(be, T, N):
+    rng = np.random.default_rng(0)
+    rew, val, lv = rng.standard_normal((T, N)).astype(f32), rng.standard_normal((T, N)).astype(f32), rng.standard_normal(N).astype(f32)
+    for done in ((rng.random((T, N)) < 0.2), np.ones((T, N), bool), np.zeros((T, N), bool)):
+        d = [be.arr(x) for x in (rew, val, done.astype(np.uint8), lv)]
+        adv, tgt = be.zeros((T, N)), be.zeros((T, N))
+        be.lib.gae(T, N, 0.99, 0.95, *[be.ptr(x) for x in d], be.ptr(adv), be.ptr(tgt), be.stream)
+        a64, t64 = po.calculate_gae(done, val.astype(np.float64), rew.astype(np.float64), lv.astype(np.float64), 0.99, 0.95)
+        np.testing.assert_allclose(be.host(adv), a64, rtol=1e-5, atol=1e-5)
+        np.testing.assert_allclose(be.host(tgt), t64, rtol=1e-5, atol=1e-5)
+    with pytest.raises(nat.NativeError):
+        be.lib.gae(0, N, 0.99, 0.95, 0, 0, 0, 0, 0, 0, be.stream)
+
+
+@pytest.mark.parametrize("O,A,H,n,tanh", [(225, 10, 256, 150, 1), (37, 3, 64, 70, 0), (415, 20, 256, 33, 1)])
+def test_policy_forward_sample_logprob(be, O, A, H, n, tanh):
+    rng = np.random.default_rng(1)
+    net = _net(O, A, H, tanh)
+    OP, AP = net.OP, (A + 3) // 4 * 4
+    flat, n64 = _params(rng, O, A, H)
+    assert be.lib.param_count(C.byref(net)) == flat.size
+    obs = np.zeros((n, OP), f32); obs[:, :O] = rng.standard_normal((n, O))
+    noise = rng.standard_normal((n, A)).astype(f32)
+    d_flat, d_obs, d_noise = be.arr(flat), be.arr(obs), be.arr(noise)
+    act, logp, value, mean = be.zeros((n, A)), be.zeros((n,)), be.zeros((n,)), be.zeros((n, AP))
+    wsb = be.lib.policy_ws_bytes(C.byref(net), n)
+    ws = be.full((wsb // 4 + 4,), np.nan)
+    be.lib.policy_forward(C.byref(net), be.ptr(d_flat), n, be.ptr(d_obs), OP, be.ptr(d_noise), be.ptr(act), be.ptr(logp), be.ptr(value), be.ptr(mean),
+                          be.ptr(ws), wsb, be.stream)
+    m64, ls64, v64 = po.actor_critic_forward(n64, obs[:, :O].astype(np.float64), bool(tanh))
+    a64 = po.mvn_sample(m64, ls64, noise.astype(np.float64))
+    np.testing.assert_allclose(be.host(mean)[:, :A], m64, atol=2e-5)
+    np.testing.assert_allclose(be.host(value), v64, atol=2e-5)
+    np.testing.assert_allclose(be.host(act), a64, atol=2e-5)
+    np.testing.assert_allclose(be.host(logp), po.mvn_log_prob(a64, m64, ls64), atol=5e-5)
+    # bootstrap-value form: noise = NULL leaves action / log_prob untouched
+    value2 = be.zeros((n,))
+    be.lib.policy_forward(C.byref(net), be.ptr(d_flat), n, be.ptr(d_obs), OP, 0, 0, 0, be.ptr(value2), 0, be.ptr(ws), wsb, be.stream)
+    np.testing.assert_array_equal(be.host(value2), be.host(value))
+    with pytest.raises(nat.NativeError, match="workspace"):
+        be.lib.policy_forward(C.byref(net), be.ptr(d_flat), n, be.ptr(d_obs), OP, 0, 0, 0, be.ptr(value2), 0, be.ptr(ws), 16, be.stream)
+
+
+@pytest.mark.parametrize("O,A,H,B,mb,tanh,ent", [(225, 10, 256, 400, 200, 1, 0.01), (37, 3, 64, 129, 129, 0, 0.0), (225, 10, 256, 1280, 1280, 1, 0.0)])
+def test_minibatch_grad_matches_oracle(be, O, A, H, B, mb, tanh, ent):
+    if be.name == "emu" and mb > 400:
+        pytest.skip("full-size minibatch only on the GPU")
+    rng = np.random.default_rng(2)
+    net = _net(O, A, H, tanh)
+    OP = net.OP
+    flat, n64 = _params(rng, O, A, H)
+    bobs = np.zeros((B, OP), f32); bobs[:, :O] = rng.standard_normal((B, O))
+    bact = rng.standard_normal((B, A)).astype(f32)
+    m_, ls_, v_ = po.actor_critic_forward(n64, bobs[:, :O].astype(np.float64), bool(tanh))
+    bval = (v_ + 0.3 * rng.standard_normal(B)).astype(f32)
+    blp = (po.mvn_log_prob(bact.astype(np.float64), m_, ls_) + 0.3 * rng.standard_normal(B)).astype(f32)
+    badv = (rng.standard_normal(B) * 3 + 1).astype(f32)
+    btgt = rng.standard_normal(B).astype(f32)
+    idx = rng.permutation(B)[:mb].astype(np.int32)
+    d = {k: be.arr(v) for k, v in dict(flat=flat, obs=bobs, act=bact, val=bval, lp=blp, adv=badv, tgt=btgt, idx=idx).items()}
+    sums, stats = be.zeros((2,), np.float64), be.zeros((2,))
+    be.lib.adv_sums(be.ptr(d["adv"]), be.ptr(d["idx"]), 1, mb, be.ptr(sums), be.stream)
+    be.lib.adv_stats_finalize(be.ptr(sums), 1, float(mb), be.ptr(stats), be.stream)
+    g = badv[idx].astype(np.float64)
+    np.testing.assert_allclose(be.host(stats), [g.mean(), 1 / (g.std() + 1e-8)], rtol=1e-6)
+    batch = nat.Batch(be.ptr(d["obs"]), OP, be.ptr(d["act"]), A, be.ptr(d["val"]), be.ptr(d["lp"]), be.ptr(d["adv"]), be.ptr(d["tgt"]))
+    lc = nat.LossCfg(0.2, 0.5, ent)
+    grad, loss4 = be.full((flat.size,), np.nan), be.zeros((4,))
+    wsb = be.lib.grad_ws_bytes(C.byref(net), mb)
+    ws = be.full((wsb // 4 + 4,), np.nan)
+    be.lib.minibatch_grad(C.byref(net), be.ptr(d["flat"]), C.byref(batch), be.ptr(d["idx"]), mb, be.ptr(stats), 1.0 / mb, C.byref(lc), be.ptr(grad),
+                          be.ptr(loss4), be.ptr(ws), wsb, be.stream)
+    lo, gr = po.loss_and_grad(n64, bobs[idx][:, :O].astype(np.float64), bact[idx].astype(np.float64), bval[idx].astype(np.float64),
+                              blp[idx].astype(np.float64), g, btgt[idx].astype(np.float64), 0.2, 0.5, ent, bool(tanh))
+    np.testing.assert_allclose(be.host(loss4), lo, rtol=1e-5, atol=1e-6)
+    got, g64 = be.host(grad), po.named_to_flat(gr, O, A, H)
+    assert not np.isnan(got).any()
+    for k, (o, s) in po.param_slices(O, A, H).items():
+        sz = int(np.prod(s))
+        np.testing.assert_allclose(got[o:o + sz], g64[o:o + sz], rtol=0, atol=1e-4 * np.abs(g64[o:o + sz]).max() + 1e-7, err_msg=k)
+    # the ratio really leaves the clip range on both sides in this batch (both gradient branches exercised)
+    ratio = np.exp(po.mvn_log_prob(bact[idx].astype(np.float64), m_[idx], ls_) - blp[idx])
+    assert (ratio > 1.2).any() and (ratio < 0.8).any()
+    # identity gather (idx = NULL) on the first mb rows gives the same result as an explicit arange
+    ar = be.arr(np.arange(mb, dtype=np.int32))
+    g1, g2 = be.zeros((flat.size,)), be.zeros((flat.size,))
+    be.lib.minibatch_grad(C.byref(net), be.ptr(d["flat"]), C.byref(batch), 0, mb, be.ptr(stats), 1.0 / mb, C.byref(lc), be.ptr(g1), 0, be.ptr(ws), wsb, be.stream)
+    be.lib.minibatch_grad(C.byref(net), be.ptr(d["flat"]), C.byref(batch), be.ptr(ar), mb, be.ptr(stats), 1.0 / mb, C.byref(lc), be.ptr(g2), 0, be.ptr(ws), wsb, be.stream)
+    np.testing.assert_array_equal(be.host(g1), be.host(g2))
+
+
+def test_clip_adam_and_schedule(be):
+    rng = np.random.default_rng(3)
+    P = 5003
+    p0 = rng.standard_normal(P).astype(f32)
+    for gscale, anneal, count0 in ((1.0, 1, 5119), (1e-4, 0, 0), (3.0, 1, 0)):
+        grad = (gscale * rng.standard_normal(P)).astype(f32)
+        p, m, v, g = be.arr(p0), be.zeros((P,)), be.zeros((P,)), be.arr(grad)
+        cnt = be.arr(np.array([count0, 0, 0, 0], np.int32))
+        cfg = nat.AdamCfg(3e-4, 0.5, 0.9, 0.999, 1e-5, anneal, 5120, 24414)
+        ws = be.zeros((128,))
+        p64, opt = p0.astype(np.float64), po.OptState(np.zeros(P), np.zeros(P), count0)
+        for s in range(3):
+            be.lib.clip_adam(P, be.ptr(p), be.ptr(m), be.ptr(v), be.ptr(g), be.ptr(cnt), s, C.byref(cfg), be.ptr(ws), 512, be.stream)
+            p64, opt = po.optimizer_update(p64, opt, grad.astype(np.float64), max_grad_norm=0.5, anneal_lr=bool(anneal), lr_train=3e-4, lr_opt=3e-4,
+                                           minibatch_size=1280, update_epochs=4, num_updates=24414)
+        np.testing.assert_allclose(be.host(p), p64, atol=1e-6)
+        np.testing.assert_allclose(be.host(m), opt.m, rtol=1e-4, atol=1e-9)
+        np.testing.assert_allclose(be.host(v), opt.v, rtol=1e-4, atol=1e-12)
+    # known answers: ||g|| = 1 clipped to 0.5 then first Adam step = -lr * g/(|g| + eps) (per element, m-hat/sqrt(v-hat))
+    g1 = np.zeros(4, f32); g1[0], g1[1] = 0.6, 0.8
+    p, m, v, g = be.zeros((4,)), be.zeros((4,)), be.zeros((4,)), be.arr(g1)
+    cnt = be.zeros((4,), np.int32)
+    cfg = nat.AdamCfg(1e-3, 0.5, 0.9, 0.999, 1e-5, 0, 1, 1)
+    be.lib.clip_adam(4, be.ptr(p), be.ptr(m), be.ptr(v), be.ptr(g), be.ptr(cnt), 0, C.byref(cfg), be.ptr(be.zeros((128,))), 512, be.stream)
+    gc = g1 / 2
+    np.testing.assert_allclose(be.host(p)[:2], -1e-3 * gc[:2] / (np.abs(gc[:2]) + 1e-5), rtol=1e-5)
+    assert (be.host(p)[2:] == 0).all()
+
+
+def test_philox_normal_and_permutation(be):
+    n = 100003
+    z = be.zeros((n,))
+    be.lib.normal_fill(1337, 7, n, be.ptr(z), be.stream)
+    zh = be.host(z)
+    assert abs(zh.mean()) < 0.02 and abs(zh.std() - 1) < 0.02 and abs((zh ** 4).mean() - 3) < 0.15
+    z2 = be.zeros((1000,))
+    be.lib.normal_fill(1337, 7, 1000, be.ptr(z2), be.stream)
+    np.testing.assert_array_equal(be.host(z2), zh[:1000])  # counter-based: a prefix is a prefix
+    z3 = be.zeros((1000,))
+    be.lib.normal_fill(1337, 8, 1000, be.ptr(z3), be.stream)
+    assert np.abs(be.host(z3) - zh[:1000]).max() > 0.1  # another stream
+    for B in (40960, 1, 777):
+        idx = be.zeros((B,), np.int32)
+        wsb = be.lib.permutation_ws_bytes(B)
+        ws = be.zeros((wsb // 4 + 4,), np.int32)
+        be.lib.permutation(1337, 3, B, be.ptr(idx), be.ptr(ws), wsb, be.stream)
+        got = be.host(idx)
+        assert (np.sort(got) == np.arange(B)).all()
+        if B > 100:
+            assert (got != np.arange(B)).mean() > 0.9
+    # golden prefix: the Philox stream is part of the engine's contract (same on emulator and GPU)
+    idx = be.zeros((16,), np.int32)
+    wsb = be.lib.permutation_ws_bytes(16)
+    be.lib.permutation(1337, 3, 16, be.ptr(idx), be.ptr(be.zeros((wsb // 4 + 4,), np.int32)), wsb, be.stream)
+    golden = np.load(str(__import__("pathlib").Path(__file__).parent / "golden" / "philox.npz"))
+    np.testing.assert_array_equal(be.host(idx), golden["perm16"])
+    np.testing.assert_allclose(zh[:8], golden["normal8"], rtol=2e-6, atol=1e-6)
+
+
+def test_gemm_batch_variants(be):
+    """The MFMA GEMM launcher against NumPy on ragged shapes (tile edges, K not a multiple of 16, gather, ones-row)."""
+    rng = np.random.default_rng(4)
+    M, N, K = 150, 70, 45
+    A = rng.standard_normal((200, 48)).astype(f32)      # lda = 48 > K
+    Bm = rng.standard_normal((K, 72)).astype(f32)       # ldb = 72 > N
+    bias = rng.standard_normal(N).astype(f32)
+    gather = rng.permutation(200)[:M].astype(np.int32)
+    dA, dB, dbias, dg = be.arr(A), be.arr(Bm), be.arr(bias), be.arr(gather)
+    Cc = be.full((M, 80), np.nan)
+    desc = (nat.GemmDesc * 1)(nat.GemmDesc(be.ptr(dA), be.ptr(dB), be.ptr(Cc), be.ptr(dbias), 0, be.ptr(dg), M, N, K, 48, 72, 80, 0, 1, 0))
+    be.lib.gemm_batch(desc, 1, 0, 1, 0, 0, be.stream)
+    want = np.tanh(A[gather][:, :K].astype(np.float64) @ Bm[:, :N].astype(np.float64) + bias)
+    got = be.host(Cc)
+    np.testing.assert_allclose(got[:, :N], want, atol=1e-5)
+    assert np.isnan(got[:, N:]).all()  # nothing written outside [M,N]
+    # variant 1: C = (A . B^T) * relu'(aux)
+    Bt = rng.standard_normal((N, 48)).astype(f32)
+    aux = rng.standard_normal((M, N)).astype(f32)
+    dBt, daux = be.arr(Bt), be.arr(aux)
+    C1 = be.zeros((M, N))
+    desc = (nat.GemmDesc * 1)(nat.GemmDesc(be.ptr(dA), be.ptr(dBt), be.ptr(C1), 0, be.ptr(daux), 0, M, N, K, 48, 48, N, N, 2, 0))
+    be.lib.gemm_batch(desc, 1, 1, 1, 0, 0, be.stream)
+    np.testing.assert_allclose(be.host(C1), (A[:M, :K].astype(np.float64) @ Bt[:, :K].T) * (aux > 0), atol=1e-5)
+    # variant 2: [W; b] = [A^T; 1] . dZ with split-K slabs, gathered sample rows
+    Ksamp, Min, Nout = 130, 45, 20
+    dZ = rng.standard_normal((Ksamp, Nout)).astype(f32)
+    g2 = rng.permutation(200)[:Ksamp].astype(np.int32)
+    ddZ, dg2 = be.arr(dZ), be.arr(g2)
+    slabs = be.full((3, 1000), np.nan)
+    desc = (nat.GemmDesc * 1)(nat.GemmDesc(be.ptr(dA), be.ptr(ddZ), be.ptr(slabs), 0, 0, be.ptr(dg2), Min + 1, Nout, Ksamp, 48, Nout, Nout, 0, 0, 1))
+    be.lib.gemm_batch(desc, 1, 2, 3, 1000, 0, be.stream)
+    s = be.host(slabs)[:, :(Min + 1) * Nout].sum(0).reshape(Min + 1, Nout)
+    X = A[g2][:, :Min].astype(np.float64)
+    np.testing.assert_allclose(s[:Min], X.T @ dZ, atol=2e-5)
+    np.testing.assert_allclose(s[Min], dZ.sum(0), atol=2e-5)
