@@ -64,7 +64,7 @@ def gemm_probe(tr, reps: int = 200):
     c = torch.empty(2, mb, H, device=dev)
     descs = (nat.GemmDesc * 2)()
     for i in range(2):
-        descs[i] = nat.GemmDesc(a[i].data_ptr(), w[i].data_ptr(), c[i].data_ptr(), b[i].data_ptr(), 0, 0, mb, H, H, H, H, H, 0, 1 if i == 0 else 2, 0)
+        descs[i] = nat.GemmDesc(a[i].data_ptr(), w[i].data_ptr(), c[i].data_ptr(), b[i].data_ptr(), 0, 0, 0, mb, H, H, H, H, H, 0, 1 if i == 0 else 2)
     s = tr.stream
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     for _ in range(20):

@@ -142,11 +142,11 @@ int32_t mppo_policy_forward(const mppo_net_t* net, const float* params, int32_t 
  *   variant 0: C = act(A.B + bias)                A [M,K] (rows optionally gathered), B [K,N]
  *   variant 1: C = (A.B^T) * act'(aux)            B stored [N,K]
  *   variant 2: C = A^T.B  (split-K slabs)         A stored [K,M] (rows = samples, optionally gathered);
- *              with ones_row the logical last row of A^T is all ones (bias gradient)
+ *              bias_out (optional) receives the column sums of B (the bias gradient), one slab per split
  * act: 0 none, 1 tanh, 2 relu.  Exposed so that benchmarks can time exactly the kernel the engine runs. */
 typedef struct mppo_gemm_desc {
-  const float* A; const float* B; float* C; const float* bias; const float* aux; const int32_t* gather;
-  int32_t M, N, K, lda, ldb, ldc, ldaux, act, ones_row;
+  const float* A; const float* B; float* C; const float* bias; const float* aux; const int32_t* gather; float* bias_out;
+  int32_t M, N, K, lda, ldb, ldc, ldaux, act;
 } mppo_gemm_desc_t;
 int32_t mppo_gemm_batch(const mppo_gemm_desc_t* probs, int32_t count, int32_t variant, int32_t ksplit, size_t slab_stride,
                         int32_t bf16, void* stream);

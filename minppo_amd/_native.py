@@ -63,7 +63,7 @@ class Batch(C.Structure):
 
 
 class GemmDesc(C.Structure):
-    _fields_ = [(n, c_vp) for n in ("A", "B", "C", "bias", "aux", "gather")] + [(n, c_i32) for n in ("M", "N", "K", "lda", "ldb", "ldc", "ldaux", "act", "ones_row")]
+    _fields_ = [(n, c_vp) for n in ("A", "B", "C", "bias", "aux", "gather", "bias_out")] + [(n, c_i32) for n in ("M", "N", "K", "lda", "ldb", "ldc", "ldaux", "act")]
 
 
 class LossCfg(C.Structure):

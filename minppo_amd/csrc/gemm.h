@@ -16,7 +16,8 @@ enum GemmEpi {
 
 // One problem C[M,N] = op(A)[M,K] . op(B)[K,N].
 //   a_t = 0 : A(m,k) = A[row(m)*lda + k]        row(m) = gather ? gather[m] : m
-//   a_t = 1 : A(m,k) = A[row(k)*lda + m]        (A^T stored [K,M]); logical row m == M-1 is all ones when ones_row
+//   a_t = 1 : A(m,k) = A[row(k)*lda + m]        (A^T stored [K,M])
+//   bias_out (EPI_STORE): also writes the column sums of B (sum over k of B(k,n)) to bias_out[n] (per split-K slab)
 //   b_t = 0 : B(k,n) = B[k*ldb + n]
 //   b_t = 1 : B(k,n) = B[n*ldb + k]
 struct GemmProb {
@@ -29,7 +30,7 @@ struct GemmProb {
   int M, N, K;
   int lda, ldb, ldc, ldaux;
   int act;
-  int ones_row;
+  float* bias_out;
 };
 
 constexpr int kGemmMaxProb = 6;

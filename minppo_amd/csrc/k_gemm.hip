@@ -9,9 +9,10 @@
 // Shape regime: M = 1280 (minibatch) or 4096 (rollout) rows, N = K = 256 and smaller.  A
 // workgroup = 4 waves = one 64x64 tile of C (each wave one 32x32 MFMA accumulator); the two
 // networks (and all six weight gradients) share one launch through blockIdx.z so that a launch
-// carries 160-1100 workgroups.  Operand tiles are staged through LDS k-major (As[k][m],
-// Bs[k][n], row stride 68 floats): the MFMA operand fetch is then one conflict-free ds_read_b32
-// per operand per MFMA, negligible beside the 64-cycle f32 MFMA.  The f32 MFMA rate
+// carries 160-300 workgroups.  Operand tiles (64 x 32) are staged global -> registers -> LDS one k-tile
+// ahead (double-buffered LDS, one barrier per k-tile), k-major (As[k][m], Bs[k][n], row stride 68
+// floats): the MFMA operand fetch is one conflict-free ds_read_b32 per operand per MFMA, negligible
+// beside the 64-cycle f32 MFMA, and the global-load latency hides under the 16 MFMAs of the current tile.  The f32 MFMA rate
 // (157 TFLOP/s) is the roofline for these kernels; at these sizes the achieved fraction is set by
 // tile count / wave occupancy rather than by memory.
 #include <wave_ops.h>
@@ -21,56 +22,108 @@
 
 namespace mppo {
 
-constexpr int BM = 64, BN = 64, BK = 16, LDT = 68, GEMM_THREADS = 256;
+constexpr int BM = 64, BN = 64, BK = 32, LDT = 68, GEMM_THREADS = 256;
+constexpr int TILE_F = BK * LDT;  // floats of one staged operand tile
 
-// Tile loader, memory contiguous along k: element (r, k) at base[row(r)*ld + k]; LDS image T[k][r].
-__device__ __forceinline__ void load_tile_kc(float* T, const float* base, int ld, const int* gather, int r0, int R, int k0, int kend, int t) {
-  const int r = t >> 2, kq = (t & 3) * 4;
-  const int gr = r0 + r;
-  float v[4] = {0.f, 0.f, 0.f, 0.f};
-  if (gr < R) {
+// ---- global -> register staging (issued one k-tile ahead), register -> LDS (k-major image T[k][r]) ----
+// Two loaders per memory orientation: `fast` is branch-free (16-byte aligned rows, unconditional float4 loads, row /
+// column indices clamped into the allocation so that out-of-tile lanes re-read valid data which the epilogue never
+// stores); `slow` predicates every element and serves ragged shapes and the partial last k-tile.
+
+// "kc": memory contiguous along k, element (r,k) at base[row(r)*ld + k].  A thread owns row r = t>>2 and the two
+// k-quads kq = 4*(t&3) and kq+16 (so that the transposed LDS stores of a wave hit each bank at most twice).
+struct StageKC {
+  float v[8];
+  const float* ptr;  // row(r) base + kq, fixed for the whole K loop
+  bool row_ok;
+  __device__ __forceinline__ void init(const float* base, int ld, const int* gather, int r0, int R, int t) {
+    const int r = t >> 2, kq = (t & 3) * 4;
+    int gr = r0 + r;
+    row_ok = gr < R;
+    gr = row_ok ? gr : R - 1;
     const long row = gather ? gather[gr] : gr;
-    const float* ptr = base + row * (long)ld + k0 + kq;
-    const bool vec = (k0 + kq + 3 < kend) && ((ld & 3) == 0) && ((reinterpret_cast<uintptr_t>(base) & 15) == 0);
-    if (vec) {
-      const float4 q = *reinterpret_cast<const float4*>(ptr);
-      v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w;
-    } else {
-      for (int c = 0; c < 4; ++c) if (k0 + kq + c < kend) v[c] = ptr[c];
-    }
+    ptr = base + row * (long)ld + kq;
   }
-  for (int c = 0; c < 4; ++c) T[(kq + c) * LDT + r] = v[c];
-}
-
-// Tile loader, memory contiguous along r: element (r, k) at base[row(k)*ld + r]; LDS image T[k][r].
-// Rmem = number of r-columns that exist in memory; logical column R-1 (>= Rmem) is all ones when ones_row.
-__device__ __forceinline__ void load_tile_rc(float* T, const float* base, int ld, const int* gather, int r0, int R, int Rmem, bool ones_row,
-                                             int k0, int kend, int t) {
-  const int k = t >> 4, rq = (t & 15) * 4;
-  const int gk = k0 + k;
-  float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (gk < kend) {
-    const long row = gather ? gather[gk] : gk;
-    const float* ptr = base + row * (long)ld + r0 + rq;
-    const bool vec = (r0 + rq + 3 < Rmem) && ((ld & 3) == 0) && ((reinterpret_cast<uintptr_t>(base) & 15) == 0);
-    if (vec) {
-      q = *reinterpret_cast<const float4*>(ptr);
-    } else {
-      float v[4];
+  __device__ __forceinline__ void load_fast(int k0) {
+    const float4 a = *reinterpret_cast<const float4*>(ptr + k0);
+    const float4 b = *reinterpret_cast<const float4*>(ptr + k0 + 16);
+    v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+  }
+  __device__ __forceinline__ void load_slow(int k0, int kend, int t) {
+    const int kq = (t & 3) * 4;
+    for (int hq = 0; hq < 2; ++hq)
       for (int c = 0; c < 4; ++c) {
-        const int rr = r0 + rq + c;
-        v[c] = rr < Rmem ? ptr[c] : ((ones_row && rr == R - 1) ? 1.f : 0.f);
+        const int kk = k0 + kq + 16 * hq + c;
+        v[4 * hq + c] = (row_ok && kk < kend) ? ptr[k0 + 16 * hq + c] : 0.f;
       }
-      q = make_float4(v[0], v[1], v[2], v[3]);
+  }
+  __device__ __forceinline__ void store(float* T, int t) const {
+    const int r = t >> 2, kq = (t & 3) * 4;
+    for (int hq = 0; hq < 2; ++hq)
+      for (int c = 0; c < 4; ++c) T[(kq + 16 * hq + c) * LDT + r] = v[4 * hq + c];
+  }
+};
+
+// "rc": memory contiguous along r, element (r,k) at base[row(k)*ld + r].  A thread owns the r-quad rq = 4*(t&15) of the
+// two k-rows k = t>>4 and k+16.  With a gather the row indices of the NEXT tile are fetched one tile early.
+struct StageRC {
+  float4 q[2];
+  const float* colptr;  // base + clamped column
+  const int* gather;
+  int ld, col, Rmem, kend;
+  int nxt[2];
+  __device__ __forceinline__ void init(const float* base, int ld_, const int* gather_, int r0, int Rmem_, int k0, int kend_, int t, bool fast) {
+    ld = ld_; gather = gather_; Rmem = Rmem_; kend = kend_;
+    col = r0 + (t & 15) * 4;
+    const int cmax = (ld & ~3) - 4;
+    colptr = base + (fast ? (col < cmax ? col : cmax) : col);
+    if (gather) prefetch_idx(k0, t);
+  }
+  __device__ __forceinline__ void prefetch_idx(int k0, int t) {
+    for (int hq = 0; hq < 2; ++hq) {
+      int gk = k0 + (t >> 4) + 16 * hq;
+      gk = gk < kend ? gk : kend - 1;
+      nxt[hq] = gather[gk];
     }
   }
-  *reinterpret_cast<float4*>(T + k * LDT + rq) = q;
+  __device__ __forceinline__ void load_fast(int k0, int t) {  // every k-row of the tile is < kend
+    for (int hq = 0; hq < 2; ++hq) {
+      const long row = gather ? nxt[hq] : k0 + (t >> 4) + 16 * hq;
+      q[hq] = *reinterpret_cast<const float4*>(colptr + row * (long)ld);
+    }
+    if (gather) prefetch_idx(k0 + BK, t);
+  }
+  __device__ __forceinline__ void load_slow(int k0, int t) {
+    for (int hq = 0; hq < 2; ++hq) {
+      const int gk = k0 + (t >> 4) + 16 * hq;
+      float v[4] = {0.f, 0.f, 0.f, 0.f};
+      if (gk < kend) {
+        const long row = gather ? gather[gk] : gk;
+        const float* ptr = colptr + row * (long)ld;  // colptr == base + col on the slow path
+        for (int c = 0; c < 4; ++c) if (col + c < Rmem) v[c] = ptr[c];
+      }
+      q[hq] = make_float4(v[0], v[1], v[2], v[3]);
+    }
+  }
+  __device__ __forceinline__ void store(float* T, int t) const {
+    const int k = t >> 4, rq = (t & 15) * 4;
+    *reinterpret_cast<float4*>(T + k * LDT + rq) = q[0];
+    *reinterpret_cast<float4*>(T + (k + 16) * LDT + rq) = q[1];
+  }
+};
+
+__device__ __forceinline__ float fast_tanh(float x) {
+  // tanh(x) = 1 - 2/(exp(2x)+1); |abs error| < 2e-7 on the whole range, saturates cleanly for large |x|
+  const float e = __expf(2.f * x);
+  return 1.f - __fdividef(2.f, e + 1.f);
 }
 
-template <bool A_T, bool B_T, int EPI>
+// Pipeline: the global loads of k-tile i+1 are in flight while the 16 MFMAs per wave of k-tile i run; the MFMA operands
+// of a k-tile are all fetched from LDS into registers before the MFMA chain starts; one workgroup barrier per k-tile.
+template <bool A_T, bool B_T, int EPI, bool FAST>
 __global__ void __launch_bounds__(GEMM_THREADS) gemm_kernel(GemmBatch gb) {
-  __shared__ __attribute__((aligned(16))) float As[BK * LDT];
-  __shared__ __attribute__((aligned(16))) float Bs[BK * LDT];
+  __shared__ __attribute__((aligned(16))) float As[2 * TILE_F];
+  __shared__ __attribute__((aligned(16))) float Bs[2 * TILE_F];
   const int z = blockIdx.z;
   const int pi = z / gb.ksplit, ks = z - pi * gb.ksplit;
   const GemmProb p = gb.p[pi];
@@ -82,23 +135,61 @@ __global__ void __launch_bounds__(GEMM_THREADS) gemm_kernel(GemmBatch gb) {
   kper = (kper + BK - 1) / BK * BK;
   const int kb = ks * kper;
   const int ke = p.K < kb + kper ? p.K : kb + kper;
-  const int MA = (A_T && p.ones_row) ? p.M - 1 : p.M;  // rows of op(A) that exist in memory
+
+  StageKC a_kc, b_kc;
+  StageRC a_rc, b_rc;
+  if (A_T) a_rc.init(p.A, p.lda, p.gather, m0, p.M, kb, ke, t, FAST);
+  else a_kc.init(p.A, p.lda, p.gather, m0, p.M, t);
+  if (B_T) b_kc.init(p.B, p.ldb, nullptr, n0, p.N, t);
+  else b_rc.init(p.B, p.ldb, nullptr, n0, p.N, kb, ke, t, FAST);
+  auto load_tiles = [&](int k0) {
+    const bool full = FAST && (k0 + BK <= ke);  // workgroup-uniform
+    if (full) {
+      if (A_T) a_rc.load_fast(k0, t); else a_kc.load_fast(k0);
+      if (B_T) b_kc.load_fast(k0); else b_rc.load_fast(k0, t);
+    } else {
+      if (A_T) a_rc.load_slow(k0, t); else a_kc.load_slow(k0, ke, t);
+      if (B_T) b_kc.load_slow(k0, ke, t); else b_rc.load_slow(k0, t);
+    }
+  };
+  auto store_tiles = [&](int b) {
+    if (A_T) a_rc.store(As + b * TILE_F, t); else a_kc.store(As + b * TILE_F, t);
+    if (B_T) b_kc.store(Bs + b * TILE_F, t); else b_rc.store(Bs + b * TILE_F, t);
+  };
 
   f32x16 acc;
   for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  float colsum = 0.f;  // EPI_STORE with bias_out: column sums of the B tile (= bias gradient), m-tile 0 only
+  const bool do_colsum = (EPI == EPI_STORE) && p.bias_out && blockIdx.y == 0 && t < BN;
 
+  int buf = 0;
+  if (kb < ke) {
+    load_tiles(kb);
+    store_tiles(0);
+  }
+  __syncthreads();
   for (int k0 = kb; k0 < ke; k0 += BK) {
-    if (A_T) load_tile_rc(As, p.A, p.lda, p.gather, m0, p.M, MA, p.ones_row != 0, k0, ke, t);
-    else load_tile_kc(As, p.A, p.lda, p.gather, m0, p.M, k0, ke, t);
-    if (B_T) load_tile_kc(Bs, p.B, p.ldb, nullptr, n0, p.N, k0, ke, t);
-    else load_tile_rc(Bs, p.B, p.ldb, nullptr, n0, p.N, p.N, false, k0, ke, t);
-    __syncthreads();
-    for (int kk = 0; kk < BK; kk += 2) {
-      const float a = As[(kk + hi) * LDT + wr * 32 + l31];
-      const float b = Bs[(kk + hi) * LDT + wc * 32 + l31];
-      mfma_f32_32x32x2(a, b, acc);
+    const bool more = k0 + BK < ke;
+    if (more) load_tiles(k0 + BK);
+    const float* Ab = As + buf * TILE_F + wr * 32 + l31 + hi * LDT;
+    const float* Bb = Bs + buf * TILE_F + wc * 32 + l31 + hi * LDT;
+    float av[BK / 2], bv[BK / 2];
+#pragma unroll
+    for (int i = 0; i < BK / 2; ++i) { av[i] = Ab[2 * i * LDT]; bv[i] = Bb[2 * i * LDT]; }
+    const int nk2 = ((ke - k0 < BK ? ke - k0 : BK) + 1) >> 1;  // MFMAs that carry data (k-rows past ke are zeros)
+#pragma unroll
+    for (int i = 0; i < BK / 2; ++i)
+      if (i < nk2) mfma_f32_32x32x2(av[i], bv[i], acc);
+    if (do_colsum) {
+      const float* Bc = Bs + buf * TILE_F + t;
+      float cs = 0.f;
+#pragma unroll
+      for (int kk = 0; kk < BK; ++kk) cs += Bc[kk * LDT];  // rows past ke were staged as zeros
+      colsum += cs;
     }
+    if (more) store_tiles(buf ^ 1);
     __syncthreads();
+    buf ^= 1;
   }
 
   float* C = p.C + (EPI == EPI_STORE ? (size_t)ks * gb.slab_stride : 0);
@@ -112,7 +203,7 @@ __global__ void __launch_bounds__(GEMM_THREADS) gemm_kernel(GemmBatch gb) {
         float v = acc[r];
         if (EPI == EPI_BIAS_ACT) {
           v += bias;
-          if (p.act == ACT_TANH) v = tanhf(v);
+          if (p.act == ACT_TANH) v = fast_tanh(v);
           else if (p.act == ACT_RELU) v = fmaxf(v, 0.f);
         } else if (EPI == EPI_DACT) {
           const float hval = p.aux[(size_t)row * p.ldaux + col];
@@ -123,17 +214,24 @@ __global__ void __launch_bounds__(GEMM_THREADS) gemm_kernel(GemmBatch gb) {
       }
     }
   }
+  if (do_colsum && n0 + t < p.N) p.bias_out[(size_t)ks * gb.slab_stride + n0 + t] = colsum;
 }
 
 template <bool A_T, bool B_T, int EPI>
 static int32_t launch_t(const GemmBatch& gb, hipStream_t stream) {
   int maxM = 0, maxN = 0;
+  bool fast = true;  // every problem has 16-byte aligned operands with row strides that are multiples of 4 floats
   for (int i = 0; i < gb.count; ++i) {
-    maxM = gb.p[i].M > maxM ? gb.p[i].M : maxM;
-    maxN = gb.p[i].N > maxN ? gb.p[i].N : maxN;
+    const GemmProb& p = gb.p[i];
+    maxM = p.M > maxM ? p.M : maxM;
+    maxN = p.N > maxN ? p.N : maxN;
+    const bool al = ((reinterpret_cast<uintptr_t>(p.A) | reinterpret_cast<uintptr_t>(p.B)) & 15) == 0 && (p.lda & 3) == 0 && (p.ldb & 3) == 0 && p.lda >= 4 &&
+                    p.ldb >= 4;
+    fast = fast && al;
   }
   dim3 grid(cdiv(maxN, BN), cdiv(maxM, BM), gb.count * gb.ksplit);
-  hipLaunchKernelGGL((gemm_kernel<A_T, B_T, EPI>), grid, dim3(GEMM_THREADS), 0, stream, gb);
+  if (fast) hipLaunchKernelGGL((gemm_kernel<A_T, B_T, EPI, true>), grid, dim3(GEMM_THREADS), 0, stream, gb);
+  else hipLaunchKernelGGL((gemm_kernel<A_T, B_T, EPI, false>), grid, dim3(GEMM_THREADS), 0, stream, gb);
   MPPO_CHECK_LAUNCH("gemm_kernel");
   return MPPO_OK;
 }
@@ -146,7 +244,7 @@ int32_t gemm_launch(const GemmBatch& gb, int a_t, int b_t, int epi, int bf16, hi
     const GemmProb& p = gb.p[i];
     MPPO_REQUIRE(p.A && p.B && p.C && p.M >= 1 && p.N >= 1 && p.K >= 1, "gemm_launch: problem %d malformed (M=%d N=%d K=%d)", i, p.M, p.N, p.K);
     MPPO_REQUIRE(epi != EPI_DACT || p.aux, "gemm_launch: EPI_DACT needs aux");
-    MPPO_REQUIRE(!p.ones_row || a_t, "gemm_launch: ones_row needs a transposed A");
+    MPPO_REQUIRE(!p.bias_out || epi == EPI_STORE, "gemm_launch: bias_out only with EPI_STORE");
   }
   const int v = a_t * 2 + b_t;
   if (epi == EPI_BIAS_ACT && v == 0) return launch_t<false, false, EPI_BIAS_ACT>(gb, stream);
@@ -168,7 +266,7 @@ extern "C" int32_t mppo_gemm_batch(const mppo_gemm_desc_t* probs, int32_t count,
     const mppo_gemm_desc_t& d = probs[i];
     GemmProb& p = gb.p[i];
     p.A = d.A; p.B = d.B; p.C = d.C; p.bias = d.bias; p.aux = d.aux; p.gather = d.gather; p.M = d.M; p.N = d.N; p.K = d.K;
-    p.lda = d.lda; p.ldb = d.ldb; p.ldc = d.ldc; p.ldaux = d.ldaux; p.act = d.act; p.ones_row = d.ones_row;
+    p.lda = d.lda; p.ldb = d.ldb; p.ldc = d.ldc; p.ldaux = d.ldaux; p.act = d.act; p.bias_out = d.bias_out;
   }
   static const int at[3] = {0, 0, 1}, bt[3] = {0, 1, 0}, ep[3] = {EPI_BIAS_ACT, EPI_DACT, EPI_STORE};
   return gemm_launch(gb, at[variant], bt[variant], ep[variant], bf16, static_cast<hipStream_t>(stream));

@@ -42,6 +42,10 @@ struct EnvArgs {
 
 #define SYNC() __syncthreads()
 #define FOR_G(i, n) for (int i = g; i < (n); i += kGroupLanes)
+// model tables in LDS (see the staging copy at the top of the kernel)
+#define TI(name) (tabI + mv.o[BI_##name])
+#define TF(name) (tabF + mv.o[BF_##name])
+#define TU(name) (reinterpret_cast<const u64*>(tabI + mv.o[BI_##name]))
 
 // ---- small vector helpers (registers) -------------------------------------------------------
 struct V3 { float x, y, z; };
@@ -103,18 +107,21 @@ __device__ __forceinline__ void cross_force(const float* vel, const float* f, fl
   st3(r + 3, cross3(w, b));
 }
 
-// x = (L L^T)^-1 b given Linv = L^-1 (lower triangular, row-major, leading dim ldm).
+// x = (L L^T)^-1 b from the packed inverse factors LL (leading dim ldm):
+//   EUL = false: L^-1 of M          , element [i][k] (k <= i) at LL[i*ldm + k]
+//   EUL = true : L^-1 of M + h*damp , element [i][k] (k <= i) at LL[k*ldm + i + 1]
 // `tmp` and `x` are nv-vectors in LDS; b may alias neither.  Contains two barriers.
-__device__ __forceinline__ void solve_linv(const float* Linv, int ldm, int nv, const float* b, float* tmp, float* x, int g) {
+template <bool EUL>
+__device__ __forceinline__ void solve_linv(const float* LL, int ldm, int nv, const float* b, float* tmp, float* x, int g) {
   FOR_G(i, nv) {
     float s = 0.f;
-    for (int k = 0; k <= i; ++k) s += Linv[i * ldm + k] * b[k];
+    for (int k = 0; k <= i; ++k) s += (EUL ? LL[k * ldm + i + 1] : LL[i * ldm + k]) * b[k];
     tmp[i] = s;
   }
   SYNC();
   FOR_G(i, nv) {
     float s = 0.f;
-    for (int k = i; k < nv; ++k) s += Linv[k * ldm + i] * tmp[k];
+    for (int k = i; k < nv; ++k) s += (EUL ? LL[i * ldm + k + 1] : LL[k * ldm + i]) * tmp[k];
     x[i] = s;
   }
   SYNC();
@@ -149,8 +156,14 @@ __device__ __forceinline__ void kbi(const float* solref, const float* solimp, fl
   if (solref[0] <= 0.f) k = -solref[0] / (dmax * dmax);
   if (solref[1] <= 0.f) b = -solref[1] / dmax;
   const float x = fabsf(pos) / width;
-  const float a = (1.f / powf(mid, power - 1.f)) * powf(x, power);
-  const float c = 1.f - (1.f / powf(1.f - mid, power - 1.f)) * powf(fabsf(1.f - x), power);
+  float a, c;
+  if (power == 2.f) {  // MuJoCo's default solimp power: no transcendental needed
+    a = x * x / mid;
+    c = 1.f - (1.f - x) * (1.f - x) / (1.f - mid);
+  } else {
+    a = (1.f / powf(mid, power - 1.f)) * powf(x, power);
+    c = 1.f - (1.f / powf(1.f - mid, power - 1.f)) * powf(fabsf(1.f - x), power);
+  }
   const float y = x < mid ? a : c;
   imp = dmin + y * (dmax - dmin);
   imp = fminf(fmaxf(imp, dmin), dmax);
@@ -165,7 +178,16 @@ __global__ void __launch_bounds__(kEnvBlock) env_kernel(ModelView mv, EnvArgs a,
   int env = blockIdx.x * kEnvsPerBlock + el;
   const bool valid = env < a.N;
   if (!valid) env = a.N - 1;  // surplus groups shadow the last environment and never store
-  float* S = reinterpret_cast<float*>(smem_raw) + (size_t)el * P.total;
+  // model tables: one coalesced copy of the blob into LDS per workgroup, then every table read is a ds_read
+  int* tabI = reinterpret_cast<int*>(smem_raw);
+  const float* tabF = reinterpret_cast<const float*>(smem_raw);
+  {
+    const float4* src = reinterpret_cast<const float4*>(mv.blob);
+    float4* dst = reinterpret_cast<float4*>(smem_raw);
+    for (int i = tid; i < mv.blob_words / 4; i += kEnvBlock) dst[i] = src[i];
+  }
+  SYNC();
+  float* S = reinterpret_cast<float*>(smem_raw) + mv.blob_words + (size_t)el * P.total;
 
   const int nq = mv.nq, nv = mv.nv, nu = mv.nu, nb = mv.nbody, njnt = mv.njnt, ncon = mv.ncon, nlim = mv.nlimit, nefc = mv.nefc;
   const int ldm = P.ldm, ldj = P.ldj;
@@ -174,7 +196,7 @@ __global__ void __launch_bounds__(kEnvBlock) env_kernel(ModelView mv, EnvArgs a,
   float* qpos = S + P.qpos; float* qvel = S + P.qvel; float* ctrl = S + P.ctrl; float* warm = S + P.warm;
   float* xpos = S + P.xpos; float* xquat = S + P.xquat; float* xipos = S + P.xipos; float* rootcom = S + P.rootcom;
   float* cinert = S + P.cinert; float* cdof = S + P.cdof; float* cvel = S + P.cvel;
-  float* M = S + P.M; float* Li = S + P.Li; float* Le = S + P.Le;
+  float* M = S + P.M; float* LL = S + P.LL;
   float* qfs = S + P.qfs; float* qas = S + P.qas; float* qact = S + P.qact; float* qacc = S + P.qacc; float* Ma = S + P.Ma;
   float* grad = S + P.grad; float* Mgrad = S + P.Mgrad; float* search = S + P.search; float* mvv = S + P.mv; float* qfc = S + P.qfc;
   float* t0 = S + P.t0; float* t1 = S + P.t1;
@@ -191,7 +213,7 @@ __global__ void __launch_bounds__(kEnvBlock) env_kernel(ModelView mv, EnvArgs a,
     FOR_G(i, nv) { qvel[i] = rec[nq + i]; warm[i] = rec[OP + i]; }
     FOR_G(i, nu) ctrl[i] = a.action[(size_t)env * a.act_ld + i];
   } else if (a.mode == 0) {
-    FOR_G(i, nq) qpos[i] = mv.qpos0[i];
+    FOR_G(i, nq) qpos[i] = TF(qpos0)[i];
     FOR_G(i, nv) { qvel[i] = 0.f; warm[i] = 0.f; }
     FOR_G(i, nu) ctrl[i] = 0.f;
   } else {
@@ -203,7 +225,7 @@ __global__ void __launch_bounds__(kEnvBlock) env_kernel(ModelView mv, EnvArgs a,
   float pre_p0 = 0.f, pre_z = 0.f, pre_comx = 0.f, time_in = 0.f;
   if (a.mode == 1) {
     float s = 0.f;
-    FOR_G(i, nq) { const float d = mv.qpos0[i] - rec[i]; s += d * d; }
+    FOR_G(i, nq) { const float d = TF(qpos0)[i] - rec[i]; s += d * d; }
     pre_p0 = sqrtf(group16_sum(s));
     pre_z = rec[2];
     pre_comx = rec[OP + nv];
@@ -218,30 +240,30 @@ __global__ void __launch_bounds__(kEnvBlock) env_kernel(ModelView mv, EnvArgs a,
   for (int frame = 0; frame < frames; ++frame) {
     // ================= fwd_position: kinematics (level-synchronous over the tree) =================
     for (int lv = 0; lv < mv.nlevel; ++lv) {
-      const int adr = mv.level_adr[lv], cnt = mv.level_adr[lv + 1] - adr;
+      const int adr = TI(level_adr)[lv], cnt = TI(level_adr)[lv + 1] - adr;
       FOR_G(ii, cnt) {
-        const int b = mv.level_body[adr + ii];
-        const int p = mv.body_parent[b];
+        const int b = TI(level_body)[adr + ii];
+        const int p = TI(body_parent)[b];
         const Q4 pq = ld4(xquat + 4 * p);
-        V3 pos = add3(ld3(xpos + 3 * p), qrot(pq, ld3(mv.body_pos + 3 * b)));
-        Q4 quat = qmul(pq, ld4(mv.body_quat + 4 * b));
-        const int j0 = mv.body_jntadr[b], j1 = j0 + mv.body_jntnum[b];
+        V3 pos = add3(ld3(xpos + 3 * p), qrot(pq, ld3(TF(body_pos) + 3 * b)));
+        Q4 quat = qmul(pq, ld4(TF(body_quat) + 4 * b));
+        const int j0 = TI(body_jntadr)[b], j1 = j0 + TI(body_jntnum)[b];
         for (int j = j0; j < j1; ++j) {
-          const int qa = mv.jnt_qposadr[j], jt = mv.jnt_type[j];
+          const int qa = TI(jnt_qposadr)[j], jt = TI(jnt_type)[j];
           if (jt == JNT_FREE) {
             pos = ld3(qpos + qa);
             quat = qnormalize(ld4(qpos + qa + 3));
             st3(xanchor + 3 * j, pos);
-            st3(xaxis + 3 * j, qrot(quat, ld3(mv.jnt_axis + 3 * j)));
+            st3(xaxis + 3 * j, qrot(quat, ld3(TF(jnt_axis) + 3 * j)));
           } else {
-            const V3 anchor = add3(pos, qrot(quat, ld3(mv.jnt_pos + 3 * j)));
-            const V3 axis = qrot(quat, ld3(mv.jnt_axis + 3 * j));
+            const V3 anchor = add3(pos, qrot(quat, ld3(TF(jnt_pos) + 3 * j)));
+            const V3 axis = qrot(quat, ld3(TF(jnt_axis) + 3 * j));
             st3(xanchor + 3 * j, anchor);
             st3(xaxis + 3 * j, axis);
-            const float disp = qpos[qa] - mv.qpos0[qa];
+            const float disp = qpos[qa] - TF(qpos0)[qa];
             if (jt == JNT_HINGE) {
-              quat = qmul(quat, axis_angle(ld3(mv.jnt_axis + 3 * j), disp));
-              pos = sub3(anchor, qrot(quat, ld3(mv.jnt_pos + 3 * j)));
+              quat = qmul(quat, axis_angle(ld3(TF(jnt_axis) + 3 * j), disp));
+              pos = sub3(anchor, qrot(quat, ld3(TF(jnt_pos) + 3 * j)));
             } else {
               pos = add3(pos, mul3(axis, disp));
             }
@@ -251,18 +273,18 @@ __global__ void __launch_bounds__(kEnvBlock) env_kernel(ModelView mv, EnvArgs a,
         st3(xpos + 3 * b, pos);
         st4(xquat + 4 * b, quat);
         qmat(quat, xmat + 9 * b);
-        st3(xipos + 3 * b, add3(pos, qrot(quat, ld3(mv.body_ipos + 3 * b))));
-        qmat(qmul(quat, ld4(mv.body_iquat + 4 * b)), ximat + 9 * b);
+        st3(xipos + 3 * b, add3(pos, qrot(quat, ld3(TF(body_ipos) + 3 * b))));
+        qmat(qmul(quat, ld4(TF(body_iquat) + 4 * b)), ximat + 9 * b);
       }
       SYNC();
     }
     // ---- com_pos: centre of mass of every kinematic tree; contact candidates --------------------
     for (int r = 0; r < mv.nroot; ++r) {
-      const u64 mask = mv.body_subtree_mask[mv.root_body[r]];
+      const u64 mask = TU(body_subtree_mask)[TI(root_body)[r]];
       float sx = 0.f, sy = 0.f, sz = 0.f, sm = 0.f;
       FOR_G(b, nb) {
         if ((mask >> b) & 1ull) {
-          const float m = mv.body_mass[b];
+          const float m = TF(body_mass)[b];
           sx += m * xipos[3 * b]; sy += m * xipos[3 * b + 1]; sz += m * xipos[3 * b + 2]; sm += m;
         }
       }
@@ -272,9 +294,9 @@ __global__ void __launch_bounds__(kEnvBlock) env_kernel(ModelView mv, EnvArgs a,
       if (r == 0) new_comx = sx * inv;  // subtree_com[1].x: body 1 is the first root (env.py:222-223)
     }
     FOR_G(c, ncon) {
-      const int b = mv.con_bodyid[c];
-      const V3 centre = add3(ld3(xpos + 3 * b), qrot(ld4(xquat + 4 * b), ld3(mv.con_lpos + 3 * c)));
-      const float rad = mv.con_radius[c];
+      const int b = TI(con_bodyid)[c];
+      const V3 centre = add3(ld3(xpos + 3 * b), qrot(ld4(xquat + 4 * b), ld3(TF(con_lpos) + 3 * c)));
+      const float rad = TF(con_radius)[c];
       const float dist = centre.z - mv.plane_z - rad;
       condist[c] = dist;
       st3(conpos + 3 * c, {centre.x, centre.y, centre.z - (rad + 0.5f * dist)});
@@ -287,11 +309,11 @@ __global__ void __launch_bounds__(kEnvBlock) env_kernel(ModelView mv, EnvArgs a,
         for (int k = 0; k < 10; ++k) ci[k] = 0.f;
       } else {
         int ri = 0;
-        for (int r = 0; r < mv.nroot; ++r) if (mv.root_body[r] == mv.body_rootid[b]) ri = r;
+        for (int r = 0; r < mv.nroot; ++r) if (TI(root_body)[r] == TI(body_rootid)[b]) ri = r;
         const V3 off = sub3(ld3(xipos + 3 * b), ld3(rootcom + 3 * ri));
-        const float m = mv.body_mass[b];
+        const float m = TF(body_mass)[b];
         const float* R = ximat + 9 * b;
-        const float d0 = mv.body_inertia[3 * b], d1 = mv.body_inertia[3 * b + 1], d2 = mv.body_inertia[3 * b + 2];
+        const float d0 = TF(body_inertia)[3 * b], d1 = TF(body_inertia)[3 * b + 1], d2 = TF(body_inertia)[3 * b + 2];
         const float oo = dot3(off, off);
         ci[0] = R[0] * R[0] * d0 + R[1] * R[1] * d1 + R[2] * R[2] * d2 + m * (oo - off.x * off.x);
         ci[1] = R[3] * R[3] * d0 + R[4] * R[4] * d1 + R[5] * R[5] * d2 + m * (oo - off.y * off.y);
@@ -303,9 +325,9 @@ __global__ void __launch_bounds__(kEnvBlock) env_kernel(ModelView mv, EnvArgs a,
       }
     }
     FOR_G(j, njnt) {
-      const int b = mv.jnt_bodyid[j], da = mv.jnt_dofadr[j], jt = mv.jnt_type[j];
+      const int b = TI(jnt_bodyid)[j], da = TI(jnt_dofadr)[j], jt = TI(jnt_type)[j];
       int ri = 0;
-      for (int r = 0; r < mv.nroot; ++r) if (mv.root_body[r] == mv.body_rootid[b]) ri = r;
+      for (int r = 0; r < mv.nroot; ++r) if (TI(root_body)[r] == TI(body_rootid)[b]) ri = r;
       const V3 off = sub3(ld3(rootcom + 3 * ri), ld3(xanchor + 3 * j));
       if (jt == JNT_FREE) {
         const float* R = xmat + 9 * b;
@@ -331,8 +353,8 @@ __global__ void __launch_bounds__(kEnvBlock) env_kernel(ModelView mv, EnvArgs a,
     SYNC();
     // ---- crb: composite inertia over the subtree mask, dense M ------------------------------------
     FOR_G(i, nv) {
-      const int bi = mv.dof_bodyid[i];
-      u64 mask = mv.body_subtree_mask[bi];
+      const int bi = TI(dof_bodyid)[i];
+      u64 mask = TU(body_subtree_mask)[bi];
       float crb[10];
       for (int k = 0; k < 10; ++k) crb[k] = 0.f;
       while (mask) {
@@ -346,10 +368,10 @@ __global__ void __launch_bounds__(kEnvBlock) env_kernel(ModelView mv, EnvArgs a,
       while (j >= 0) {
         const float* cj = cdof + 6 * j;
         float v = cj[0] * buf[0] + cj[1] * buf[1] + cj[2] * buf[2] + cj[3] * buf[3] + cj[4] * buf[4] + cj[5] * buf[5];
-        if (j == i) v += mv.dof_armature[i];
+        if (j == i) v += TF(dof_armature)[i];
         M[i * ldm + j] = v;
         M[j * ldm + i] = v;
-        j = mv.dof_parentid[j];
+        j = TI(dof_parentid)[j];
       }
     }
     SYNC();
@@ -358,9 +380,7 @@ __global__ void __launch_bounds__(kEnvBlock) env_kernel(ModelView mv, EnvArgs a,
       for (int k = 0; k < nv; ++k) {
         const float v = M[i * ldm + k];
         C1[i * ldm + k] = v;
-        C2[i * ldm + k] = (k == i) ? v + h * mv.dof_damping[i] : v;  // implicit joint damping (Euler)
-        Li[i * ldm + k] = 0.f;
-        Le[i * ldm + k] = 0.f;
+        C2[i * ldm + k] = (k == i) ? v + h * TF(dof_damping)[i] : v;  // implicit joint damping (Euler)
       }
     }
     // ---- factor_m: Cholesky of M and of M + h*diag(damping), both in the same column sweep ---------
@@ -383,20 +403,20 @@ __global__ void __launch_bounds__(kEnvBlock) env_kernel(ModelView mv, EnvArgs a,
     SYNC();
     // ---- triangular inverses, one column per lane (no cross-lane dependency inside a column) -------
     FOR_G(j, nv) {
-      Li[j * ldm + j] = rsqrtf(fmaxf(C1[j * ldm + j], MJ_MINVAL));
-      Le[j * ldm + j] = rsqrtf(fmaxf(C2[j * ldm + j], MJ_MINVAL));
+      LL[j * ldm + j] = rsqrtf(fmaxf(C1[j * ldm + j], MJ_MINVAL));      // Li[j][j]
+      LL[j * ldm + j + 1] = rsqrtf(fmaxf(C2[j * ldm + j], MJ_MINVAL));  // Le[j][j] (transposed slot)
       for (int i = j + 1; i < nv; ++i) {
         float s1 = 0.f, s2 = 0.f;
-        for (int k = j; k < i; ++k) { s1 += C1[i * ldm + k] * Li[k * ldm + j]; s2 += C2[i * ldm + k] * Le[k * ldm + j]; }
-        Li[i * ldm + j] = -s1 * rsqrtf(fmaxf(C1[i * ldm + i], MJ_MINVAL));
-        Le[i * ldm + j] = -s2 * rsqrtf(fmaxf(C2[i * ldm + i], MJ_MINVAL));
+        for (int k = j; k < i; ++k) { s1 += C1[i * ldm + k] * LL[k * ldm + j]; s2 += C2[i * ldm + k] * LL[j * ldm + k + 1]; }
+        LL[i * ldm + j] = -s1 * rsqrtf(fmaxf(C1[i * ldm + i], MJ_MINVAL));      // Li[i][j]
+        LL[j * ldm + i + 1] = -s2 * rsqrtf(fmaxf(C2[i * ldm + i], MJ_MINVAL));  // Le[i][j]
       }
     }
     SYNC();
     // ================= fwd_velocity: com_vel, passive, rne (closed forms over ancestor masks) =======
     FOR_G(b, nb) {
       float v[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-      u64 mask = b ? mv.body_ancdof_mask[b] : 0ull;
+      u64 mask = b ? TU(body_ancdof_mask)[b] : 0ull;
       while (mask) {
         const int d = __ffsll((long long)mask) - 1;
         mask &= mask - 1;
@@ -406,13 +426,13 @@ __global__ void __launch_bounds__(kEnvBlock) env_kernel(ModelView mv, EnvArgs a,
       for (int k = 0; k < 6; ++k) cvel[6 * b + k] = v[k];
     }
     FOR_G(d, nv) {
-      const int j = mv.dof_jntid[d];
+      const int j = TI(dof_jntid)[d];
       float* out = cdofdot + 6 * d;
-      if (mv.jnt_type[j] == JNT_FREE && d - mv.jnt_dofadr[j] < 3) {
+      if (TI(jnt_type)[j] == JNT_FREE && d - TI(jnt_dofadr)[j] < 3) {
         for (int k = 0; k < 6; ++k) out[k] = 0.f;
       } else {
         float v[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        u64 mask = mv.dof_velmask[d];
+        u64 mask = TU(dof_velmask)[d];
         while (mask) {
           const int e = __ffsll((long long)mask) - 1;
           mask &= mask - 1;
@@ -428,8 +448,8 @@ __global__ void __launch_bounds__(kEnvBlock) env_kernel(ModelView mv, EnvArgs a,
       if (b == 0) {
         for (int k = 0; k < 6; ++k) f[k] = 0.f;
       } else {
-        float acc[6] = {0.f, 0.f, 0.f, -mv.gravity[0], -mv.gravity[1], -mv.gravity[2]};
-        u64 mask = mv.body_ancdof_mask[b];
+        float acc[6] = {0.f, 0.f, 0.f, -TF(gravity)[0], -TF(gravity)[1], -TF(gravity)[2]};
+        u64 mask = TU(body_ancdof_mask)[b];
         while (mask) {
           const int d = __ffsll((long long)mask) - 1;
           mask &= mask - 1;
@@ -447,7 +467,7 @@ __global__ void __launch_bounds__(kEnvBlock) env_kernel(ModelView mv, EnvArgs a,
     // ---- qfrc_bias, passive, actuation -> qfrc_smooth -------------------------------------------------
     FOR_G(d, nv) {
       float f[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-      u64 mask = mv.body_subtree_mask[mv.dof_bodyid[d]];
+      u64 mask = TU(body_subtree_mask)[TI(dof_bodyid)[d]];
       while (mask) {
         const int c = __ffsll((long long)mask) - 1;
         mask &= mask - 1;
@@ -455,21 +475,21 @@ __global__ void __launch_bounds__(kEnvBlock) env_kernel(ModelView mv, EnvArgs a,
       }
       const float* cd = cdof + 6 * d;
       const float bias = cd[0] * f[0] + cd[1] * f[1] + cd[2] * f[2] + cd[3] * f[3] + cd[4] * f[4] + cd[5] * f[5];
-      float passive = -mv.dof_damping[d] * qvel[d];
-      const int qa = mv.dof_qposadr[d];
+      float passive = -TF(dof_damping)[d] * qvel[d];
+      const int qa = TI(dof_qposadr)[d];
       if (qa >= 0) {
-        const float stiff = mv.jnt_stiffness[mv.dof_jntid[d]];
-        if (stiff != 0.f) passive -= stiff * (qpos[qa] - mv.qpos_spring[qa]);
+        const float stiff = TF(jnt_stiffness)[TI(dof_jntid)[d]];
+        if (stiff != 0.f) passive -= stiff * (qpos[qa] - TF(qpos_spring)[qa]);
       }
       float act = 0.f;
       for (int u = 0; u < nu; ++u) {
-        if (mv.act_dofid[u] == d) {
+        if (TI(act_dofid)[u] == d) {
           float c = ctrl[u];
-          if (mv.act_ctrllimited[u]) c = fminf(fmaxf(c, mv.act_ctrlrange[2 * u]), mv.act_ctrlrange[2 * u + 1]);
-          const float gear = mv.act_gear[u];
-          const float len = gear * qpos[mv.act_qposadr[u]], vel = gear * qvel[d];
-          float fo = mv.act_gain[u] * c + mv.act_bias[3 * u] + mv.act_bias[3 * u + 1] * len + mv.act_bias[3 * u + 2] * vel;
-          if (mv.act_forcelimited[u]) fo = fminf(fmaxf(fo, mv.act_forcerange[2 * u]), mv.act_forcerange[2 * u + 1]);
+          if (TI(act_ctrllimited)[u]) c = fminf(fmaxf(c, TF(act_ctrlrange)[2 * u]), TF(act_ctrlrange)[2 * u + 1]);
+          const float gear = TF(act_gear)[u];
+          const float len = gear * qpos[TI(act_qposadr)[u]], vel = gear * qvel[d];
+          float fo = TF(act_gain)[u] * c + TF(act_bias)[3 * u] + TF(act_bias)[3 * u + 1] * len + TF(act_bias)[3 * u + 2] * vel;
+          if (TI(act_forcelimited)[u]) fo = fminf(fmaxf(fo, TF(act_forcerange)[2 * u]), TF(act_forcerange)[2 * u + 1]);
           act += fo * gear;
         }
       }
@@ -481,32 +501,32 @@ __global__ void __launch_bounds__(kEnvBlock) env_kernel(ModelView mv, EnvArgs a,
       }
     }
     SYNC();  // cfrc / cdofdot (region A3) are dead from here: the Jacobian (A4) may overwrite them
-    solve_linv(Li, ldm, nv, qfs, t0, qas, g);  // fwd_acceleration: qacc_smooth = M^-1 qfrc_smooth
+    solve_linv<false>(LL, ldm, nv, qfs, t0, qas, g);  // fwd_acceleration: qacc_smooth = M^-1 qfrc_smooth
     // ================= make_constraint ===================================================================
     FOR_G(r, nefc) for (int k = 0; k < nv; ++k) J[r * ldj + k] = 0.f;
     SYNC();
     FOR_G(r, nlim) {  // joint limits: one row each
-      const int jid = mv.lim_jntid[r];
-      const int qa = mv.jnt_qposadr[jid], da = mv.jnt_dofadr[jid];
-      const float dlo = qpos[qa] - mv.jnt_range[2 * jid], dhi = mv.jnt_range[2 * jid + 1] - qpos[qa];
+      const int jid = TI(lim_jntid)[r];
+      const int qa = TI(jnt_qposadr)[jid], da = TI(jnt_dofadr)[jid];
+      const float dlo = qpos[qa] - TF(jnt_range)[2 * jid], dhi = TF(jnt_range)[2 * jid + 1] - qpos[qa];
       const float pos = fminf(dlo, dhi);
       const bool act = pos < 0.f;
       if (act) J[r * ldj + da] = dlo < dhi ? 1.f : -1.f;
       jv[r] = act ? pos : 0.f;               // pos, parked in jv until the row parameters are built
-      force[r] = act ? mv.dof_invweight0[da] : 0.f;  // invweight, parked in force
+      force[r] = act ? TF(dof_invweight0)[da] : 0.f;  // invweight, parked in force
     }
     for (int item = g; item < ncon * nv; item += kGroupLanes) {  // contacts: 4 pyramid rows, (contact, dof) per item
       const int c = item / nv, d = item - c * nv;
-      const int b = mv.con_bodyid[c];
+      const int b = TI(con_bodyid)[c];
       const bool act = condist[c] < 0.f;
-      if (act && ((mv.body_ancdof_mask[b] >> d) & 1ull)) {
+      if (act && ((TU(body_ancdof_mask)[b] >> d) & 1ull)) {
         int ri = 0;
-        for (int r = 0; r < mv.nroot; ++r) if (mv.root_body[r] == mv.body_rootid[b]) ri = r;
+        for (int r = 0; r < mv.nroot; ++r) if (TI(root_body)[r] == TI(body_rootid)[b]) ri = r;
         const V3 off = sub3(ld3(conpos + 3 * c), ld3(rootcom + 3 * ri));
         const V3 jp = add3(ld3(cdof + 6 * d + 3), cross3(ld3(cdof + 6 * d), off));
         // contact frame of the +z ground plane (make_frame): normal z, t1 = +y, t2 = -x
         const float jn = jp.z, jt1 = jp.y, jt2 = -jp.x;
-        const float mu = mv.con_friction[3 * c];
+        const float mu = TF(con_friction)[3 * c];
         const int r0 = nlim + 4 * c;
         J[(r0 + 0) * ldj + d] = jn + mu * jt1;
         J[(r0 + 1) * ldj + d] = jn - mu * jt1;
@@ -516,8 +536,8 @@ __global__ void __launch_bounds__(kEnvBlock) env_kernel(ModelView mv, EnvArgs a,
     }
     FOR_G(c, ncon) {
       const bool act = condist[c] < 0.f;
-      const float mu = mv.con_friction[3 * c];
-      const float tw = mv.body_invweight0[2 * mv.con_bodyid[c]];
+      const float mu = TF(con_friction)[3 * c];
+      const float tw = TF(body_invweight0)[2 * TI(con_bodyid)[c]];
       const float iw = (tw + mu * mu * tw) * 2.f * mu * mu / mv.impratio;
       for (int k = 0; k < 4; ++k) {
         jv[nlim + 4 * c + k] = act ? condist[c] : 0.f;
@@ -529,8 +549,8 @@ __global__ void __launch_bounds__(kEnvBlock) env_kernel(ModelView mv, EnvArgs a,
       const float pos = jv[r], iw = force[r];
       const bool act = iw > 0.f;  // inactive rows are inert: J = 0, aref = 0, D = 0
       float k, b, imp;
-      if (r < nlim) kbi(mv.limit_solref, mv.limit_solimp, h, pos, k, b, imp);
-      else kbi(mv.contact_solref, mv.contact_solimp, h, pos, k, b, imp);
+      if (r < nlim) kbi(TF(limit_solref), TF(limit_solimp), h, pos, k, b, imp);
+      else kbi(TF(contact_solref), TF(contact_solimp), h, pos, k, b, imp);
       float s = 0.f;
       for (int d = 0; d < nv; ++d) s += J[r * ldj + d] * qvel[d];
       const float R = fmaxf(iw * (1.f - imp) / imp, MJ_MINVAL);
@@ -575,7 +595,7 @@ __global__ void __launch_bounds__(kEnvBlock) env_kernel(ModelView mv, EnvArgs a,
       SYNC();
       FOR_G(i, nv) { float s = 0.f; for (int r = 0; r < nefc; ++r) s += J[r * ldj + i] * force[r]; qfc[i] = s; grad[i] = Ma[i] - qfs[i] - s; }
       SYNC();
-      solve_linv(Li, ldm, nv, grad, t0, Mgrad, g);
+      solve_linv<false>(LL, ldm, nv, grad, t0, Mgrad, g);
       FOR_G(i, nv) search[i] = -Mgrad[i];
       SYNC();
       for (int it = 0; it < mv.iterations; ++it) {
@@ -661,7 +681,7 @@ __global__ void __launch_bounds__(kEnvBlock) env_kernel(ModelView mv, EnvArgs a,
           if (run) { qfc[i] = s; grad[i] = Ma[i] - qfs[i] - s; }
         }
         SYNC();
-        solve_linv(Li, ldm, nv, grad, t0, mvv, g);  // candidate Mgrad (mvv is free again)
+        solve_linv<false>(LL, ldm, nv, grad, t0, mvv, g);  // candidate Mgrad (mvv is free again)
         float num = 0.f;
         FOR_G(i, nv) num += grad[i] * (mvv[i] - t1[i]);
         num = group16_sum(num);
@@ -694,7 +714,7 @@ __global__ void __launch_bounds__(kEnvBlock) env_kernel(ModelView mv, EnvArgs a,
     // ================= euler: implicit damping, semi-implicit integration ====================================
     FOR_G(i, nv) t1[i] = qfs[i] + qfc[i];
     SYNC();
-    solve_linv(Le, ldm, nv, t1, t0, mvv, g);  // mvv = (M + h D)^-1 (qfrc_smooth + qfrc_constraint)
+    solve_linv<true>(LL, ldm, nv, t1, t0, mvv, g);  // mvv = (M + h D)^-1 (qfrc_smooth + qfrc_constraint)
     if (a.mode == 2) {
       if (valid && a.probe.qacc_euler) FOR_G(i, nv) a.probe.qacc_euler[(size_t)env * nv + i] = mvv[i];
       break;
@@ -702,8 +722,8 @@ __global__ void __launch_bounds__(kEnvBlock) env_kernel(ModelView mv, EnvArgs a,
     FOR_G(i, nv) { qvel[i] += h * mvv[i]; warm[i] = qacc[i]; }  // qacc_warmstart <- solver qacc
     SYNC();
     FOR_G(j, njnt) {
-      const int qa = mv.jnt_qposadr[j], da = mv.jnt_dofadr[j];
-      if (mv.jnt_type[j] == JNT_FREE) {
+      const int qa = TI(jnt_qposadr)[j], da = TI(jnt_dofadr)[j];
+      if (TI(jnt_type)[j] == JNT_FREE) {
         for (int k = 0; k < 3; ++k) qpos[qa + k] += h * qvel[da + k];
         const V3 w = ld3(qvel + da + 3);
         const float n = sqrtf(dot3(w, w));
@@ -899,31 +919,15 @@ extern "C" int32_t mppo_model_open(const void* host_blob, size_t nbytes, const v
     for (int l = 0; l < v.nlevel; ++l) if (la[l + 1] < la[l] || la[l + 1] > v.nbody - 1) return bad("level_adr not monotone");
     if (HI(BI_root_body)[0] != 1) return bad("body 1 must be the first tree root");
   }
-  const int32_t* dI = static_cast<const int32_t*>(dev_blob);
-  const float* dF = static_cast<const float*>(dev_blob);
-  auto DI = [&](int k) { return dI + dir[2 * k]; };
-  auto DF = [&](int k) { return dF + dir[2 * k]; };
-  auto DU = [&](int k) { return reinterpret_cast<const u64*>(dI + dir[2 * k]); };
-  v.body_parent = DI(BI_body_parent); v.body_rootid = DI(BI_body_rootid); v.body_jntadr = DI(BI_body_jntadr); v.body_jntnum = DI(BI_body_jntnum);
-  v.body_dofadr = DI(BI_body_dofadr); v.body_dofnum = DI(BI_body_dofnum);
-  v.jnt_type = DI(BI_jnt_type); v.jnt_qposadr = DI(BI_jnt_qposadr); v.jnt_dofadr = DI(BI_jnt_dofadr); v.jnt_bodyid = DI(BI_jnt_bodyid);
-  v.dof_bodyid = DI(BI_dof_bodyid); v.dof_jntid = DI(BI_dof_jntid); v.dof_parentid = DI(BI_dof_parentid); v.dof_qposadr = DI(BI_dof_qposadr);
-  v.act_dofid = DI(BI_act_dofid); v.act_qposadr = DI(BI_act_qposadr); v.act_ctrllimited = DI(BI_act_ctrllimited); v.act_forcelimited = DI(BI_act_forcelimited);
-  v.con_bodyid = DI(BI_con_bodyid); v.lim_jntid = DI(BI_lim_jntid); v.level_adr = DI(BI_level_adr); v.level_body = DI(BI_level_body); v.root_body = DI(BI_root_body);
-  v.body_subtree_mask = DU(BI_body_subtree_mask); v.body_ancdof_mask = DU(BI_body_ancdof_mask); v.dof_velmask = DU(BI_dof_velmask);
-  v.gravity = DF(BF_gravity); v.body_pos = DF(BF_body_pos); v.body_quat = DF(BF_body_quat); v.body_ipos = DF(BF_body_ipos); v.body_iquat = DF(BF_body_iquat);
-  v.body_mass = DF(BF_body_mass); v.body_inertia = DF(BF_body_inertia);
-  v.jnt_pos = DF(BF_jnt_pos); v.jnt_axis = DF(BF_jnt_axis); v.jnt_range = DF(BF_jnt_range); v.jnt_stiffness = DF(BF_jnt_stiffness);
-  v.dof_armature = DF(BF_dof_armature); v.dof_damping = DF(BF_dof_damping); v.dof_invweight0 = DF(BF_dof_invweight0); v.body_invweight0 = DF(BF_body_invweight0);
-  v.qpos0 = DF(BF_qpos0); v.qpos_spring = DF(BF_qpos_spring);
-  v.act_gear = DF(BF_act_gear); v.act_gain = DF(BF_act_gain); v.act_bias = DF(BF_act_bias); v.act_ctrlrange = DF(BF_act_ctrlrange); v.act_forcerange = DF(BF_act_forcerange);
-  v.con_lpos = DF(BF_con_lpos); v.con_radius = DF(BF_con_radius); v.con_friction = DF(BF_con_friction);
-  v.contact_solref = DF(BF_contact_solref); v.contact_solimp = DF(BF_contact_solimp); v.limit_solref = DF(BF_limit_solref); v.limit_solimp = DF(BF_limit_solimp);
+  v.blob = static_cast<const int32_t*>(dev_blob);
+  v.blob_words = (int)((total + 3) & ~(size_t)3);
+  if ((size_t)v.blob_words != total) return bad("blob length must be a multiple of 4 words");
+  for (int k = 0; k < BLOB_ARRAY_COUNT; ++k) v.o[k] = dir[2 * k];
   v.obs_dim = v.nq + 2 * v.nv + 16 * (v.nbody - 1);
   v.obs_pad = (v.obs_dim + 3) & ~3;
   v.rec_dim = v.obs_pad + ((v.nv + 2 + 3) & ~3);
   m->lds = make_phys_lds(v.nq, v.nv, v.nu, v.nbody, v.njnt, v.ncon, v.nefc, v.nroot);
-  m->lds_bytes = m->lds.total * 4 * kEnvsPerBlock;
+  m->lds_bytes = (v.blob_words + m->lds.total * kEnvsPerBlock) * 4;
   if (m->lds_bytes > 160 * 1024) { delete m; return fail(MPPO_EMODEL, "model needs %d bytes of LDS per workgroup (limit 163840)", m->lds_bytes); }
   *out = m;
   return MPPO_OK;

@@ -337,19 +337,20 @@ int32_t minibatch_grad(const mppo_net_t& net, const float* params, const mppo_ba
     c.A = gbuf.dz2c; c.lda = H; c.M = mb; c.K = H; c.B = params + L.c_w2; c.ldb = H; c.N = H; c.aux = gbuf.f.h1c; c.ldaux = H; c.act = ACT_RELU; c.C = gbuf.dz1c; c.ldc = H;
   }
   MPPO_TRY(gemm_launch(gb, 0, 1, EPI_DACT, net.bf16, stream));
-  // weight gradients: [W; b] = [H_prev^T; 1^T] . dZ   (the flat layout stores b right after W, so one GEMM writes both)
+  // weight gradients dW = H_prev^T . dZ into split-K slabs; the bias gradients (column sums of dZ) ride along
   gb.count = 6; gb.ksplit = gbuf.ksplit; gb.slab_stride = gbuf.slab_stride;
-  auto wprob = [&](const float* Aprev, int lda, const int* gather, int Min, const float* dZ, int ldz, int N, int off) {
+  auto wprob = [&](const float* Aprev, int lda, const int* gather, int Min, const float* dZ, int ldz, int N, int off_w, int off_b) {
     GemmProb p{};
-    p.A = Aprev; p.lda = lda; p.gather = gather; p.M = Min + 1; p.ones_row = 1; p.K = mb; p.B = dZ; p.ldb = ldz; p.N = N; p.C = gbuf.slabs + off; p.ldc = N;
+    p.A = Aprev; p.lda = lda; p.gather = gather; p.M = Min; p.K = mb; p.B = dZ; p.ldb = ldz; p.N = N; p.C = gbuf.slabs + off_w; p.ldc = N;
+    p.bias_out = gbuf.slabs + off_b;
     return p;
   };
-  gb.p[0] = wprob(gbuf.f.h2a, H, nullptr, H, gbuf.dmean, AP, A, L.a_w3);
-  gb.p[1] = wprob(gbuf.f.h1a, H, nullptr, H, gbuf.dz2a, H, H, L.a_w2);
-  gb.p[2] = wprob(batch.obs, batch.obs_ld, idx, O, gbuf.dz1a, H, H, L.a_w1);
-  gb.p[3] = wprob(gbuf.f.h2c, H, nullptr, H, gbuf.dv, 1, 1, L.c_w3);
-  gb.p[4] = wprob(gbuf.f.h1c, H, nullptr, H, gbuf.dz2c, H, H, L.c_w2);
-  gb.p[5] = wprob(batch.obs, batch.obs_ld, idx, O, gbuf.dz1c, H, H, L.c_w1);
+  gb.p[0] = wprob(gbuf.f.h2a, H, nullptr, H, gbuf.dmean, AP, A, L.a_w3, L.a_b3);
+  gb.p[1] = wprob(gbuf.f.h1a, H, nullptr, H, gbuf.dz2a, H, H, L.a_w2, L.a_b2);
+  gb.p[2] = wprob(batch.obs, batch.obs_ld, idx, O, gbuf.dz1a, H, H, L.a_w1, L.a_b1);
+  gb.p[3] = wprob(gbuf.f.h2c, H, nullptr, H, gbuf.dv, 1, 1, L.c_w3, L.c_b3);
+  gb.p[4] = wprob(gbuf.f.h1c, H, nullptr, H, gbuf.dz2c, H, H, L.c_w2, L.c_b2);
+  gb.p[5] = wprob(batch.obs, batch.obs_ld, idx, O, gbuf.dz1c, H, H, L.c_w1, L.c_b1);
   MPPO_TRY(gemm_launch(gb, 1, 0, EPI_STORE, net.bf16, stream));
   const float ent_weight = (float)mb * inv_count;
   hipLaunchKernelGGL(grad_reduce_kernel, dim3(cdiv((long)L.total, 256)), dim3(256), 0, stream, (size_t)L.total, gbuf.ksplit, gbuf.slab_stride, gbuf.slabs,

@@ -36,22 +36,15 @@ constexpr float MJ_MINVAL = 1e-15f, MJ_MINIMP = 0.0001f, MJ_MAXIMP = 0.9999f;
 
 typedef unsigned long long u64;
 
+// Dims + where the blob lives.  The kernel copies the blob into LDS once per workgroup and reads every table
+// from there: o[k] is the word offset of array k (BlobInt / BlobF32 index) inside the blob.
 struct ModelView {
   int nq, nv, nu, nbody, njnt, ncon, nlimit, nefc, iterations, ls_iterations, nlevel, nroot;
   int obs_dim, obs_pad, rec_dim;
   float timestep, tolerance, ls_tolerance, impratio, plane_z, meaninertia;
-  const int *body_parent, *body_rootid, *body_jntadr, *body_jntnum, *body_dofadr, *body_dofnum;
-  const int *jnt_type, *jnt_qposadr, *jnt_dofadr, *jnt_bodyid;
-  const int *dof_bodyid, *dof_jntid, *dof_parentid, *dof_qposadr;
-  const int *act_dofid, *act_qposadr, *act_ctrllimited, *act_forcelimited;
-  const int *con_bodyid, *lim_jntid, *level_adr, *level_body, *root_body;
-  const u64 *body_subtree_mask, *body_ancdof_mask, *dof_velmask;
-  const float *gravity, *body_pos, *body_quat, *body_ipos, *body_iquat, *body_mass, *body_inertia;
-  const float *jnt_pos, *jnt_axis, *jnt_range, *jnt_stiffness;
-  const float *dof_armature, *dof_damping, *dof_invweight0, *body_invweight0, *qpos0, *qpos_spring;
-  const float *act_gear, *act_gain, *act_bias, *act_ctrlrange, *act_forcerange;
-  const float *con_lpos, *con_radius, *con_friction;
-  const float *contact_solref, *contact_solimp, *limit_solref, *limit_solimp;
+  const int* blob;   // device copy of the whole blob (16-byte aligned)
+  int blob_words;    // multiple of 4
+  int o[BLOB_ARRAY_COUNT];
 };
 
 // Per-environment LDS layout (offsets in floats).  Region "A" is time-shared: kinematics
@@ -60,7 +53,7 @@ struct PhysLds {
   int qpos, qvel, ctrl, warm;
   int xpos, xquat, xipos, rootcom;
   int cinert, cdof, cvel;
-  int M, Li, Le, ldm;
+  int M, LL, ldm;  // LL packs L^-1 of M (lower part, [i][k<=i]) and of M + h*D (stored transposed at [k][i+1])
   int qfs, qas, qact, qacc, Ma, grad, Mgrad, search, mv, qfc, t0, t1;
   int D, aref, jaref, jv, force;
   int conpos, condist;
@@ -78,7 +71,7 @@ __host__ __device__ inline PhysLds make_phys_lds(int nq, int nv, int nu, int nbo
   p.xpos = take(3 * nbody); p.xquat = take(4 * nbody); p.xipos = take(3 * nbody); p.rootcom = take(3 * (nroot > 0 ? nroot : 1));
   p.cinert = take(10 * nbody); p.cdof = take(6 * nv); p.cvel = take(6 * nbody);
   p.ldm = nv + 1;
-  p.M = take(nv * p.ldm); p.Li = take(nv * p.ldm); p.Le = take(nv * p.ldm);
+  p.M = take(nv * p.ldm); p.LL = take(nv * p.ldm);
   p.qfs = take(nv); p.qas = take(nv); p.qact = take(nv); p.qacc = take(nv); p.Ma = take(nv); p.grad = take(nv);
   p.Mgrad = take(nv); p.search = take(nv); p.mv = take(nv); p.qfc = take(nv); p.t0 = take(nv); p.t1 = take(nv);
   const int ne = nefc > 0 ? nefc : 1;

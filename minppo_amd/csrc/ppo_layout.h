@@ -44,7 +44,7 @@ inline FwdBufs carve_fwd(const mppo_net_t& net, int n, float* ws) {
   return f;
 }
 
-constexpr int kGradKSplit = 4;
+constexpr int kGradKSplit = 3;  // 72 weight-gradient tiles x 3 K-slices = 216 workgroups: one round on 256 CUs
 
 // everything one minibatch gradient needs beyond the forward activations
 struct GradBufs {

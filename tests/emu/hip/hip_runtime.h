@@ -84,3 +84,5 @@ struct float2 { float x, y; };
 inline float4 make_float4(float x, float y, float z, float w) { return {x, y, z, w}; }
 struct uint4 { unsigned x, y, z, w; };
 struct uint2 { unsigned x, y; };
+inline float __expf(float x) { return expf(x); }
+inline float __fdividef(float a, float b) { return a / b; }

@@ -61,7 +61,14 @@ def test_update_matches_oracle_stage_by_stage(be):
             for t in range(T):
                 es = env.step(es, tj["action"][t].astype(np.float64))
                 assert (tj["done"][t].astype(bool) == es["done"]).all()
-                np.testing.assert_allclose(obs[t + 1], es["obs"], atol=0.5 if t else 1e-4)  # obs(t+1) shows state t (lag): chaotic drift after t = 0
+                # obs(t+1) shows state t (one-step lag): exact-to-rounding at t = 0, then the unconverged CG makes the
+                # two float32/float64 trajectories drift (test_kernels_physics.py); positions stay close, velocities loosely
+                if t == 0:
+                    np.testing.assert_allclose(obs[1], es["obs"], atol=1e-4)
+                else:
+                    nq, nv = tr.cm.nq, tr.cm.nv
+                    np.testing.assert_allclose(obs[t + 1][:, :nq], es["obs"][:, :nq], atol=5e-3)
+                    np.testing.assert_allclose(obs[t + 1][:, nq:nq + nv], es["obs"][:, nq:nq + nv], atol=1.5)
                 np.testing.assert_allclose(tj["reward"][t], es["reward"], atol=0.25)
         # GAE on the engine's trajectory
         adv, tgt = po.calculate_gae(tj["done"].astype(bool), tj["value"].astype(np.float64), tj["reward"].astype(np.float64), tj["last_val"].astype(np.float64),

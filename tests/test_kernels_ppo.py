@@ -190,7 +190,7 @@ def test_gemm_batch_variants(be):
     gather = rng.permutation(200)[:M].astype(np.int32)
     dA, dB, dbias, dg = be.arr(A), be.arr(Bm), be.arr(bias), be.arr(gather)
     Cc = be.full((M, 80), np.nan)
-    desc = (nat.GemmDesc * 1)(nat.GemmDesc(be.ptr(dA), be.ptr(dB), be.ptr(Cc), be.ptr(dbias), 0, be.ptr(dg), M, N, K, 48, 72, 80, 0, 1, 0))
+    desc = (nat.GemmDesc * 1)(nat.GemmDesc(be.ptr(dA), be.ptr(dB), be.ptr(Cc), be.ptr(dbias), 0, be.ptr(dg), 0, M, N, K, 48, 72, 80, 0, 1))
     be.lib.gemm_batch(desc, 1, 0, 1, 0, 0, be.stream)
     want = np.tanh(A[gather][:, :K].astype(np.float64) @ Bm[:, :N].astype(np.float64) + bias)
     got = be.host(Cc)
@@ -201,16 +201,17 @@ def test_gemm_batch_variants(be):
     aux = rng.standard_normal((M, N)).astype(f32)
     dBt, daux = be.arr(Bt), be.arr(aux)
     C1 = be.zeros((M, N))
-    desc = (nat.GemmDesc * 1)(nat.GemmDesc(be.ptr(dA), be.ptr(dBt), be.ptr(C1), 0, be.ptr(daux), 0, M, N, K, 48, 48, N, N, 2, 0))
+    desc = (nat.GemmDesc * 1)(nat.GemmDesc(be.ptr(dA), be.ptr(dBt), be.ptr(C1), 0, be.ptr(daux), 0, 0, M, N, K, 48, 48, N, N, 2))
     be.lib.gemm_batch(desc, 1, 1, 1, 0, 0, be.stream)
     np.testing.assert_allclose(be.host(C1), (A[:M, :K].astype(np.float64) @ Bt[:, :K].T) * (aux > 0), atol=1e-5)
-    # variant 2: [W; b] = [A^T; 1] . dZ with split-K slabs, gathered sample rows
+    # variant 2: W = A^T . dZ with split-K slabs, gathered sample rows; bias_out = column sums of dZ
     Ksamp, Min, Nout = 130, 45, 20
     dZ = rng.standard_normal((Ksamp, Nout)).astype(f32)
     g2 = rng.permutation(200)[:Ksamp].astype(np.int32)
     ddZ, dg2 = be.arr(dZ), be.arr(g2)
     slabs = be.full((3, 1000), np.nan)
-    desc = (nat.GemmDesc * 1)(nat.GemmDesc(be.ptr(dA), be.ptr(ddZ), be.ptr(slabs), 0, 0, be.ptr(dg2), Min + 1, Nout, Ksamp, 48, Nout, Nout, 0, 0, 1))
+    desc = (nat.GemmDesc * 1)(nat.GemmDesc(be.ptr(dA), be.ptr(ddZ), be.ptr(slabs), 0, 0, be.ptr(dg2), be.ptr(slabs) + 4 * Min * Nout, Min, Nout, Ksamp, 48,
+                                           Nout, Nout, 0, 0))
     be.lib.gemm_batch(desc, 1, 2, 3, 1000, 0, be.stream)
     s = be.host(slabs)[:, :(Min + 1) * Nout].sum(0).reshape(Min + 1, Nout)
     X = A[g2][:, :Min].astype(np.float64)
