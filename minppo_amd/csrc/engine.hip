@@ -158,14 +158,12 @@ static int32_t do_rollout(mppo_engine* e, hipStream_t s) {
   FwdBufs fb = carve_fwd(c.net, e->N, e->fwd_ws);
   for (int t = 0; t < e->T; ++t) {
     const float* obs_t = e->obs + (size_t)t * N * OP;
-    fb.value = e->value + (size_t)t * N;
-    MPPO_TRY(mlp_forward(c.net, e->params, e->N, obs_t, e->OP, nullptr, fb, s));                                        // train.py:157
-    MPPO_TRY(policy_sample(c.net, e->params, e->N, fb, e->noise + t * N * A, e->action + t * N * A, e->log_prob + t * N, s));  // :158-160
+    MPPO_TRY(policy_forward(c.net, e->params, e->N, obs_t, e->OP, fb, e->noise + t * N * A, e->action + t * N * A, e->log_prob + t * N,
+                            e->value + (size_t)t * N, nullptr, s));                                                   // train.py:157-160
     MPPO_TRY(mppo_env_step(e->model, e->N, c.n_frames, &c.reward, e->state, e->reset_rec, e->action + t * N * A, e->A, e->obs + (size_t)(t + 1) * N * OP,
                            e->OP, e->reward + t * N, e->done + t * N, &e->met, s));                                  // :165
   }
-  fb.value = e->last_val;
-  MPPO_TRY(mlp_forward(c.net, e->params, e->N, e->obs + (size_t)e->T * N * OP, e->OP, nullptr, fb, s));  // bootstrap value, train.py:182
+  MPPO_TRY(policy_forward(c.net, e->params, e->N, e->obs + (size_t)e->T * N * OP, e->OP, fb, nullptr, nullptr, nullptr, e->last_val, nullptr, s));  // train.py:182
   MPPO_TRY(gae_launch(e->T, e->N, c.gamma, c.gae_lambda, e->reward, e->value, e->done, e->last_val, e->adv, e->target, s));
   MPPO_CHECK_HIP(hipMemsetAsync(e->stats, 0, 16, s));
   hipLaunchKernelGGL(rollout_stats_kernel, dim3(64), dim3(256), 0, s, e->B, e->reward, e->done, e->stats);
@@ -194,10 +192,11 @@ static int32_t do_learn(mppo_engine* e, hipStream_t s) {
   for (int ep = 0; ep < e->E; ++ep) {
     for (int k = 0; k < e->M; ++k) {
       const int st = ep * e->M + k;
+      const bool single = c.world_size == 1;  // then the reduce kernel's sums of squares are those of the final gradient
       MPPO_TRY(minibatch_grad(c.net, e->params, batch, e->perm + (size_t)ep * e->B + (size_t)k * e->mb, e->mb, e->adv_stats + 2 * st, inv_count, c.loss, e->grad,
-                              e->losses + 4 * st, gb, s));                                                           // train.py:246-247
-      if (c.world_size > 1) MPPO_TRY(comm_allreduce_f32(e->comm, e->grad, (size_t)e->P, s));
-      MPPO_TRY(clip_adam((size_t)e->P, e->params, e->adam_m, e->adam_v, e->grad, e->count, st, ac, e->adam_ws, s));  // train.py:248
+                              e->losses + 4 * st, single ? e->adam_ws : nullptr, gb, s));                            // train.py:246-247
+      if (!single) MPPO_TRY(comm_allreduce_f32(e->comm, e->grad, (size_t)e->P, s));
+      MPPO_TRY(clip_adam((size_t)e->P, e->params, e->adam_m, e->adam_v, e->grad, e->count, st, ac, e->adam_ws, single, s));  // train.py:248
     }
   }
   hipLaunchKernelGGL(advance_counters_kernel, dim3(1), dim3(64), 0, s, e->count, EM);

@@ -177,9 +177,14 @@ __global__ void __launch_bounds__(GEMM_THREADS) gemm_kernel(GemmBatch gb) {
 #pragma unroll
     for (int i = 0; i < BK / 2; ++i) { av[i] = Ab[2 * i * LDT]; bv[i] = Bb[2 * i * LDT]; }
     const int nk2 = ((ke - k0 < BK ? ke - k0 : BK) + 1) >> 1;  // MFMAs that carry data (k-rows past ke are zeros)
+    if (nk2 == BK / 2) {
 #pragma unroll
-    for (int i = 0; i < BK / 2; ++i)
-      if (i < nk2) mfma_f32_32x32x2(av[i], bv[i], acc);
+      for (int i = 0; i < BK / 2; ++i) mfma_f32_32x32x2(av[i], bv[i], acc);
+    } else {
+#pragma unroll
+      for (int i = 0; i < BK / 2; ++i)
+        if (i < nk2) mfma_f32_32x32x2(av[i], bv[i], acc);  // partial last k-tile only
+    }
     if (do_colsum) {
       const float* Bc = Bs + buf * TILE_F + t;
       float cs = 0.f;

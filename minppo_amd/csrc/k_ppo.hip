@@ -14,26 +14,6 @@ namespace mppo {
 constexpr float kLog2Pi = 1.8378770664093453f;
 
 // ------------------------------------------------------------------------------------------------
-// pi.sample + pi.log_prob (train.py:158-160; distrax MultivariateNormalDiag)
-// ------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) sample_kernel(int n, int A, int AP, const float* __restrict__ mean, const float* __restrict__ log_std,
-                                                     const float* __restrict__ noise, float* __restrict__ action, float* __restrict__ log_prob) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  float ss = 0.f, sl = 0.f;
-  for (int a = 0; a < A; ++a) {
-    const float ls = log_std[a];
-    const float mu = mean[(size_t)i * AP + a];
-    const float act = mu + expf(ls) * noise[(size_t)i * A + a];
-    action[(size_t)i * A + a] = act;
-    const float z = (act - mu) * expf(-ls);
-    ss += z * z;
-    sl += ls;
-  }
-  log_prob[i] = -0.5f * ss - sl - 0.5f * (float)A * kLog2Pi;
-}
-
-// ------------------------------------------------------------------------------------------------
 // _calculate_gae (train.py:185-205): reverse scan over t, one thread per environment.
 // HBM-streaming: 9 bytes read + 8 written per sample, coalesced over n.
 // ------------------------------------------------------------------------------------------------
@@ -57,78 +37,190 @@ __global__ void __launch_bounds__(256) gae_kernel(int T, int N, float gamma, flo
 }
 
 // ------------------------------------------------------------------------------------------------
-// _loss_fn on the network outputs (train.py:223-243) and d(loss)/d(mean, value, log_std).
-// One thread per minibatch row; per-workgroup partial sums go to `partial[blk][4 + AP]`:
-//   [0] sum -min(ratio*g, clip(ratio)*g) * w   [1] sum 0.5*max((v-t)^2,(vc-t)^2) * w   [4+a] d log_std[a]
-// with w = inv_count.  Tie / clip-boundary gradient conventions as in oracle/ppo_oracle.py.
+// Output layers fused with what consumes them.  One workgroup = RT = 256/LR rows; LR lanes (one or two DPP rows) per
+// row, lane o < A owns action dimension o, lane o == A owns the critic value.  W3 of both networks and the two h2 tiles
+// are staged in LDS; per-row reductions over the action dimensions are DPP row sums.
+//   head_sample_kernel : mean = h2a.W3a + b3a, value = h2c.W3c + b3c, action = mean + exp(log_std)*noise, log_prob
+//                        (train.py:79-83,157-160)
+//   head_loss_kernel   : the same heads, then `_loss_fn` on them (train.py:223-243), d(loss)/d(mean, value, log_std) and
+//                        the first backward product dZ2 = (dOut . W3^T) * act'(h2) for both networks.
+//                        dOut [mb, DP]: columns [0,A) = d mean, column AP = d value (DP = AP + 4), the layout the
+//                        weight-gradient GEMM reads.  Per-workgroup partial sums -> partial[blk][4 + AP].
 // ------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) loss_kernel(int mb, int A, int AP, const int* __restrict__ idx, const float* __restrict__ mean,
-                                                   const float* __restrict__ vnew, const float* __restrict__ log_std, mppo_batch_t b,
-                                                   const float* __restrict__ adv_stat, float inv_count, mppo_loss_cfg_t lc,
-                                                   float* __restrict__ dmean, float* __restrict__ dv, float* __restrict__ partial) {
-  __shared__ float red[4][40];
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  const bool on = i < mb;
-  float la = 0.f, lv = 0.f, dlogp = 0.f;
-  long row = 0;
-  if (on) {
-    row = idx ? idx[i] : i;
-    float ss = 0.f, sl = 0.f;
-    for (int a = 0; a < A; ++a) {
-      const float ls = log_std[a];
-      const float z = (b.action[row * b.act_ld + a] - mean[(size_t)i * AP + a]) * expf(-ls);
-      ss += z * z;
-      sl += ls;
-    }
-    const float logp = -0.5f * ss - sl - 0.5f * (float)A * kLog2Pi;
-    const float ratio = expf(logp - b.log_prob[row]);
-    const float g = (b.adv[row] - adv_stat[0]) * adv_stat[1];
-    const float la1 = ratio * g;
-    const float la2 = fminf(fmaxf(ratio, 1.f - lc.clip_eps), 1.f + lc.clip_eps) * g;
-    la = -fminf(la1, la2) * inv_count;
-    const bool unclipped = (ratio >= 1.f - lc.clip_eps) && (ratio <= 1.f + lc.clip_eps);
-    dlogp = (unclipped || la1 < la2) ? -g * ratio * inv_count : 0.f;
-    const float v = vnew[i], ov = b.value[row], tg = b.target[row];
-    const float vc = ov + fminf(fmaxf(v - ov, -lc.clip_eps), lc.clip_eps);
-    const float vl1 = (v - tg) * (v - tg), vl2 = (vc - tg) * (vc - tg);
-    lv = 0.5f * fmaxf(vl1, vl2) * inv_count;
-    const bool vin = fabsf(v - ov) <= lc.clip_eps;
-    dv[i] = (vin || vl1 > vl2) ? (v - tg) * inv_count * lc.vf_coef : 0.f;
+template <int LR>
+__device__ __forceinline__ float row_sum(float x) {
+  x = group16_sum(x);
+  if (LR == 32) x += __shfl_xor(x, 16);
+  return x;
+}
+
+struct HeadArgs {
+  int n, A, AP, DP, H, use_tanh;
+  const float *h2a, *h2c, *w3a, *b3a, *w3c, *b3c, *log_std;
+  // sample
+  const float* noise; float* action; float* log_prob; float* value; float* mean_out;
+  // loss
+  const int* idx; mppo_batch_t b; const float* adv_stat; float inv_count; mppo_loss_cfg_t lc;
+  float *dout, *dz2a, *dz2c, *partial;
+};
+
+template <int LR, bool LOSS>
+__global__ void __launch_bounds__(256) head_kernel(HeadArgs a) {
+  constexpr int RT = 256 / LR;
+  MPPO_DYN_SMEM(smem_raw);
+  float* sm = reinterpret_cast<float*>(smem_raw);
+  const int H = a.H, A = a.A, AP = a.AP;
+  float* s_h2a = sm;                  // [RT][H]
+  float* s_h2c = s_h2a + RT * H;      // [RT][H]
+  float* s_w3a = s_h2c + RT * H;      // [H][A]
+  float* s_w3c = s_w3a + H * A;       // [H]
+  float* s_do = s_w3c + H;            // [RT][LR]   d mean (cols < A), d value (col A)
+  float* s_red = s_do + RT * LR;      // [RT][LR]   per-row partials for the block reduction
+  const int t = threadIdx.x, r = t / LR, o = t % LR;
+  const int row0 = blockIdx.x * RT;
+  const int i = row0 + r;
+  const bool on = i < a.n;
+  // stage h2 tiles (rows past n are clamped, never stored) and the head weights
+  for (int e = t; e < RT * H / 4; e += 256) {
+    const int rr = (e * 4) / H, cc = (e * 4) % H;
+    const int gi = row0 + rr < a.n ? row0 + rr : a.n - 1;
+    reinterpret_cast<float4*>(s_h2a)[e] = *reinterpret_cast<const float4*>(a.h2a + (size_t)gi * H + cc);
+    reinterpret_cast<float4*>(s_h2c)[e] = *reinterpret_cast<const float4*>(a.h2c + (size_t)gi * H + cc);
   }
-  // block reduction of la, lv and the A log_std gradients
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  float r_la = wave_sum(la), r_lv = wave_sum(lv);
-  if (lane == 0) { red[wave][0] = r_la; red[wave][1] = r_lv; }
-  for (int a = 0; a < AP; ++a) {
-    float dm = 0.f, dls = 0.f;
-    if (on && a < A) {
-      const float inv_std = expf(-log_std[a]);
-      const float z = (b.action[row * b.act_ld + a] - mean[(size_t)i * AP + a]) * inv_std;
-      dm = dlogp * z * inv_std;
-      dls = dlogp * (z * z - 1.f);
-    }
-    if (on) dmean[(size_t)i * AP + a] = dm;
-    const float s = wave_sum(dls);
-    if (lane == 0) red[wave][4 + a] = s;
-  }
+  for (int e = t; e < H * A; e += 256) s_w3a[e] = a.w3a[e];
+  for (int e = t; e < H; e += 256) s_w3c[e] = a.w3c[e];
   __syncthreads();
-  if (threadIdx.x < 4 + AP) {
-    const int k = threadIdx.x;
-    float s = 0.f;
-    if (k < 2 || k >= 4) s = red[0][k] + red[1][k] + red[2][k] + red[3][k];
-    partial[(size_t)blockIdx.x * (4 + AP) + k] = s;
+  // head outputs: lane o < A -> mean[o], lane o == A -> value
+  float out = 0.f;
+  if (o < A) {
+    float s0 = 0.f, s1 = 0.f;
+    const float* hrow = s_h2a + r * H;
+    for (int k = 0; k < H; k += 2) { s0 += hrow[k] * s_w3a[k * A + o]; s1 += hrow[k + 1] * s_w3a[(k + 1) * A + o]; }
+    out = s0 + s1 + a.b3a[o];
+  } else if (o == A) {
+    float s0 = 0.f, s1 = 0.f;
+    const float* hrow = s_h2c + r * H;
+    for (int k = 0; k < H; k += 2) { s0 += hrow[k] * s_w3c[k]; s1 += hrow[k + 1] * s_w3c[k + 1]; }
+    out = s0 + s1 + a.b3c[0];
   }
+  const float ls = o < A ? a.log_std[o] : 0.f;
+  const float inv_std = __expf(-ls);
+  const float sum_ls = row_sum<LR>(ls);
+  if (!LOSS) {
+    // ---- pi.sample + pi.log_prob (train.py:158-160) ----
+    float z2 = 0.f;
+    if (a.noise && o < A && on) {
+      const float act = out + __expf(ls) * a.noise[(size_t)i * A + o];
+      a.action[(size_t)i * A + o] = act;
+      const float z = (act - out) * inv_std;
+      z2 = z * z;
+      if (a.mean_out) a.mean_out[(size_t)i * AP + o] = out;
+    }
+    const float ss = row_sum<LR>(z2);
+    if (on && o == 0 && a.noise) a.log_prob[i] = -0.5f * ss - sum_ls - 0.5f * (float)A * kLog2Pi;
+    if (on && o == A) a.value[i] = out;
+    return;
+  }
+  // ---- _loss_fn (train.py:223-243) ----
+  long row = 0;
+  float z = 0.f;
+  if (on) row = a.idx ? a.idx[i] : i;
+  if (on && o < A) z = (a.b.action[row * a.b.act_ld + o] - out) * inv_std;
+  const float ss = row_sum<LR>(z * z);
+  const float vnew = row_sum<LR>(o == A ? out : 0.f);  // broadcast the value to the row's lanes
+  float la = 0.f, lv = 0.f, dlogp = 0.f, dv = 0.f;
+  if (on) {
+    const float logp = -0.5f * ss - sum_ls - 0.5f * (float)A * kLog2Pi;
+    const float ratio = __expf(logp - a.b.log_prob[row]);
+    const float g = (a.b.adv[row] - a.adv_stat[0]) * a.adv_stat[1];
+    const float la1 = ratio * g;
+    const float la2 = fminf(fmaxf(ratio, 1.f - a.lc.clip_eps), 1.f + a.lc.clip_eps) * g;
+    la = -fminf(la1, la2) * a.inv_count;
+    const bool unclipped = (ratio >= 1.f - a.lc.clip_eps) && (ratio <= 1.f + a.lc.clip_eps);
+    dlogp = (unclipped || la1 < la2) ? -g * ratio * a.inv_count : 0.f;
+    const float ov = a.b.value[row], tg = a.b.target[row];
+    const float vc = ov + fminf(fmaxf(vnew - ov, -a.lc.clip_eps), a.lc.clip_eps);
+    const float vl1 = (vnew - tg) * (vnew - tg), vl2 = (vc - tg) * (vc - tg);
+    lv = 0.5f * fmaxf(vl1, vl2) * a.inv_count;
+    const bool vin = fabsf(vnew - ov) <= a.lc.clip_eps;
+    dv = (vin || vl1 > vl2) ? (vnew - tg) * a.inv_count * a.lc.vf_coef : 0.f;
+  }
+  const float dm = (o < A) ? dlogp * z * inv_std : (o == A ? dv : 0.f);
+  const float dls = (o < A) ? dlogp * (z * z - 1.f) : 0.f;
+  s_do[r * LR + o] = dm;
+  // per-row partials for the block sums: lane 0 carries la, lane 1 carries lv, lanes 2.. are free; dls by lane o
+  s_red[r * LR + o] = dls;
+  if (on) {
+    if (o < A) a.dout[(size_t)i * a.DP + o] = dm;
+    else if (o < AP) a.dout[(size_t)i * a.DP + o] = 0.f;
+    if (o == A) { a.dout[(size_t)i * a.DP + AP] = dv; a.dout[(size_t)i * a.DP + AP + 1] = 0.f; a.dout[(size_t)i * a.DP + AP + 2] = 0.f; a.dout[(size_t)i * a.DP + AP + 3] = 0.f; }
+  }
+  __shared__ float s_l[2][256 / 16];
+  if (o == 0) { s_l[0][r] = la; s_l[1][r] = lv; }
+  __syncthreads();
+  if (t < 4 + AP) {
+    float s = 0.f;
+    if (t == 0) for (int rr = 0; rr < RT; ++rr) s += s_l[0][rr];
+    else if (t == 1) for (int rr = 0; rr < RT; ++rr) s += s_l[1][rr];
+    else if (t >= 4 && t - 4 < A) for (int rr = 0; rr < RT; ++rr) s += s_red[rr * LR + (t - 4)];
+    a.partial[(size_t)blockIdx.x * (4 + AP) + t] = s;
+  }
+  // ---- dZ2 = (dOut . W3^T) * act'(h2): thread = hidden column n, loop over the RT rows ----
+  for (int n = t; n < H; n += 256) {
+    float acc[RT];
+#pragma unroll
+    for (int rr = 0; rr < RT; ++rr) acc[rr] = 0.f;
+    for (int k = 0; k < A; ++k) {
+      const float wk = s_w3a[n * A + k];
+#pragma unroll
+      for (int rr = 0; rr < RT; ++rr) acc[rr] += s_do[rr * LR + k] * wk;
+    }
+    const float wc = s_w3c[n];
+#pragma unroll
+    for (int rr = 0; rr < RT; ++rr) {
+      if (row0 + rr < a.n) {
+        const float ha = s_h2a[rr * H + n], hc = s_h2c[rr * H + n];
+        a.dz2a[(size_t)(row0 + rr) * H + n] = a.use_tanh ? acc[rr] * (1.f - ha * ha) : (ha > 0.f ? acc[rr] : 0.f);
+        a.dz2c[(size_t)(row0 + rr) * H + n] = hc > 0.f ? s_do[rr * LR + A] * wc : 0.f;
+      }
+    }
+  }
+}
+
+static size_t head_smem_bytes(int LR, int H, int A) { const int RT = 256 / LR; return sizeof(float) * ((size_t)2 * RT * H + (size_t)H * A + H + 2 * RT * LR); }
+
+int32_t head_launch(const HeadArgs& a, bool loss, hipStream_t stream) {
+  MPPO_REQUIRE(a.A + 1 <= 32 && (a.H % 4) == 0, "head kernel: A = %d must be <= 31 and H %% 4 == 0", a.A);
+  const int LR = a.A + 1 <= 16 ? 16 : 32;
+  const int RT = 256 / LR;
+  const size_t smem = head_smem_bytes(LR, a.H, a.A);
+  MPPO_REQUIRE(smem <= 64 * 1024, "head kernel: %zu bytes of LDS needed (H = %d too large)", smem, a.H);
+  dim3 grid(cdiv(a.n, RT));
+  if (LR == 16) {
+    if (loss) hipLaunchKernelGGL((head_kernel<16, true>), grid, dim3(256), smem, stream, a);
+    else hipLaunchKernelGGL((head_kernel<16, false>), grid, dim3(256), smem, stream, a);
+  } else {
+    if (loss) hipLaunchKernelGGL((head_kernel<32, true>), grid, dim3(256), smem, stream, a);
+    else hipLaunchKernelGGL((head_kernel<32, false>), grid, dim3(256), smem, stream, a);
+  }
+  MPPO_CHECK_LAUNCH("head_kernel");
+  return MPPO_OK;
 }
 
 // ------------------------------------------------------------------------------------------------
 // grad = sum of split-K slabs (+ log_std gradient from the loss partials); loss4 from the partials.
 // ------------------------------------------------------------------------------------------------
+constexpr int kNormBlocks = 128;
+
+// kNormBlocks workgroups, grid-stride over P; also leaves the per-workgroup sum of squares of the reduced gradient in
+// `sq_partial` (used by the clip when no all-reduce sits between this kernel and Adam).
 __global__ void __launch_bounds__(256) grad_reduce_kernel(size_t P, int ksplit, size_t slab_stride, const float* __restrict__ slabs, int ls_off, int A,
                                                           int AP, int nblk, const float* __restrict__ partial, const float* __restrict__ log_std,
                                                           float ent_coef, float vf_coef, float ent_weight, float* __restrict__ grad,
-                                                          float* __restrict__ loss4) {
-  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < P) {
+                                                          float* __restrict__ loss4, float* __restrict__ sq_partial) {
+  __shared__ float red[4];
+  float sq = 0.f;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < P; i += (size_t)gridDim.x * blockDim.x) {
     float s = 0.f;
     if (i >= (size_t)ls_off && i < (size_t)ls_off + A) {
       const int a = (int)(i - ls_off);
@@ -138,8 +230,13 @@ __global__ void __launch_bounds__(256) grad_reduce_kernel(size_t P, int ksplit, 
       for (int k = 0; k < ksplit; ++k) s += slabs[(size_t)k * slab_stride + i];
     }
     grad[i] = s;
+    sq += s * s;
   }
-  if (i == 0 && loss4) {
+  sq = wave_sum(sq);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = sq;
+  __syncthreads();
+  if (threadIdx.x == 0 && sq_partial) sq_partial[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+  if (blockIdx.x == 0 && threadIdx.x == 0 && loss4) {
     float la = 0.f, lv = 0.f, sl = 0.f;
     for (int k = 0; k < nblk; ++k) { la += partial[(size_t)k * (4 + AP)]; lv += partial[(size_t)k * (4 + AP) + 1]; }
     for (int a = 0; a < A; ++a) sl += log_std[a];
@@ -187,8 +284,6 @@ __global__ void __launch_bounds__(256) adv_finalize_kernel(const double* __restr
 // ------------------------------------------------------------------------------------------------
 // clip_by_global_norm + adam + apply (train.py:115-124,248); lr schedule train.py:98-101
 // ------------------------------------------------------------------------------------------------
-constexpr int kNormBlocks = 128;
-
 __global__ void __launch_bounds__(256) sumsq_kernel(size_t P, const float* __restrict__ g, float* __restrict__ partial) {
   __shared__ float red[4];
   float s = 0.f;
@@ -202,8 +297,10 @@ __global__ void __launch_bounds__(256) sumsq_kernel(size_t P, const float* __res
 __global__ void __launch_bounds__(256) adam_kernel(size_t P, float* __restrict__ p, float* __restrict__ m, float* __restrict__ v,
                                                    const float* __restrict__ g, const float* __restrict__ partial, const int* __restrict__ count_base,
                                                    int step_offset, mppo_adam_cfg_t c) {
-  float ss = 0.f;
-  for (int k = 0; k < kNormBlocks; ++k) ss += partial[k];  // same order in every workgroup: bitwise-identical scale
+  // every wave adds the same kNormBlocks (= 128) partials in the same order (two per lane, fixed reduction tree):
+  // bitwise-identical clip scale everywhere without a second pass
+  const int ln = threadIdx.x & 63;
+  const float ss = wave_sum(partial[ln] + partial[ln + 64]);
   const float norm = sqrtf(ss);
   const float scale = norm < c.max_grad_norm ? 1.f : c.max_grad_norm / norm;
   const int count = count_base[0] + step_offset;
@@ -282,9 +379,9 @@ static GemmProb fwd_prob(const float* A, int lda, const int* gather, int M, int 
   return p;
 }
 
-// actor + critic forward on n rows of `obs` (optionally gathered); outputs into the FwdBufs
-int32_t mlp_forward(const mppo_net_t& net, const float* params, int n, const float* obs, int obs_ld, const int* gather, const FwdBufs& fb,
-                    hipStream_t stream) {
+// hidden layers of actor + critic on n rows of `obs` (optionally gathered): h1, h2 of both networks into the FwdBufs
+int32_t mlp_hidden_forward(const mppo_net_t& net, const float* params, int n, const float* obs, int obs_ld, const int* gather, const FwdBufs& fb,
+                           hipStream_t stream) {
   const ParamLayout L = param_layout(net.O, net.A, net.H);
   const int H = net.H, act_a = net.use_tanh ? ACT_TANH : ACT_RELU;
   GemmBatch gb{};
@@ -295,40 +392,45 @@ int32_t mlp_forward(const mppo_net_t& net, const float* params, int n, const flo
   gb.p[0] = fwd_prob(fb.h1a, H, nullptr, n, H, params + L.a_w2, H, params + L.a_b2, act_a, fb.h2a, H);
   gb.p[1] = fwd_prob(fb.h1c, H, nullptr, n, H, params + L.c_w2, H, params + L.c_b2, ACT_RELU, fb.h2c, H);
   MPPO_TRY(gemm_launch(gb, 0, 0, EPI_BIAS_ACT, net.bf16, stream));
-  gb.p[0] = fwd_prob(fb.h2a, H, nullptr, n, H, params + L.a_w3, net.A, params + L.a_b3, ACT_NONE, fb.mean, fb.AP);
-  gb.p[1] = fwd_prob(fb.h2c, H, nullptr, n, H, params + L.c_w3, 1, params + L.c_b3, ACT_NONE, fb.value, 1);
-  MPPO_TRY(gemm_launch(gb, 0, 0, EPI_BIAS_ACT, 0, stream));  // heads stay f32
   return MPPO_OK;
 }
 
-int32_t policy_sample(const mppo_net_t& net, const float* params, int n, const FwdBufs& fb, const float* noise, float* action, float* log_prob,
-                      hipStream_t stream) {
+static HeadArgs head_args(const mppo_net_t& net, const float* params, int n, const FwdBufs& fb) {
   const ParamLayout L = param_layout(net.O, net.A, net.H);
-  hipLaunchKernelGGL(sample_kernel, dim3(cdiv(n, 256)), dim3(256), 0, stream, n, net.A, fb.AP, fb.mean, params + L.log_std, noise, action, log_prob);
-  MPPO_CHECK_LAUNCH("sample_kernel");
-  return MPPO_OK;
+  HeadArgs a{};
+  a.n = n; a.A = net.A; a.AP = fb.AP; a.DP = fb.AP + 4; a.H = net.H; a.use_tanh = net.use_tanh;
+  a.h2a = fb.h2a; a.h2c = fb.h2c; a.w3a = params + L.a_w3; a.b3a = params + L.a_b3; a.w3c = params + L.c_w3; a.b3c = params + L.c_b3;
+  a.log_std = params + L.log_std;
+  return a;
+}
+
+// full policy step on n rows: hidden layers, heads, sample + log-prob (noise may be null: value only)
+int32_t policy_forward(const mppo_net_t& net, const float* params, int n, const float* obs, int obs_ld, const FwdBufs& fb, const float* noise, float* action,
+                       float* log_prob, float* value, float* mean_out, hipStream_t stream) {
+  MPPO_TRY(mlp_hidden_forward(net, params, n, obs, obs_ld, nullptr, fb, stream));
+  HeadArgs a = head_args(net, params, n, fb);
+  a.noise = noise; a.action = action; a.log_prob = log_prob; a.value = value; a.mean_out = mean_out;
+  if (!noise) {  // value-only call (bootstrap, train.py:182): sample outputs go to the scratch `mean` buffer and are ignored
+    a.noise = nullptr; a.action = nullptr;
+  }
+  return head_launch(a, false, stream);
 }
 
 int32_t minibatch_grad(const mppo_net_t& net, const float* params, const mppo_batch_t& batch, const int* idx, int mb, const float* adv_stat,
-                       float inv_count, const mppo_loss_cfg_t& lc, float* grad, float* loss4, const GradBufs& gbuf, hipStream_t stream) {
+                       float inv_count, const mppo_loss_cfg_t& lc, float* grad, float* loss4, float* sq_partial, const GradBufs& gbuf, hipStream_t stream) {
   const ParamLayout L = param_layout(net.O, net.A, net.H);
-  const int H = net.H, A = net.A, AP = gbuf.f.AP, O = net.O;
+  const int H = net.H, A = net.A, AP = gbuf.f.AP, DP = AP + 4, O = net.O;
   const int act_a = net.use_tanh ? ACT_TANH : ACT_RELU;
-  MPPO_TRY(mlp_forward(net, params, mb, batch.obs, batch.obs_ld, idx, gbuf.f, stream));
-  const int nblk = cdiv(mb, 256);
-  hipLaunchKernelGGL(loss_kernel, dim3(nblk), dim3(256), 0, stream, mb, A, AP, idx, gbuf.f.mean, gbuf.f.value, params + L.log_std, batch, adv_stat,
-                     inv_count, lc, gbuf.dmean, gbuf.dv, gbuf.partial);
-  MPPO_CHECK_LAUNCH("loss_kernel");
+  MPPO_TRY(mlp_hidden_forward(net, params, mb, batch.obs, batch.obs_ld, idx, gbuf.f, stream));
+  // heads + loss + dZ2 (one launch)
+  HeadArgs ha = head_args(net, params, mb, gbuf.f);
+  ha.idx = idx; ha.b = batch; ha.adv_stat = adv_stat; ha.inv_count = inv_count; ha.lc = lc;
+  ha.dout = gbuf.dout; ha.dz2a = gbuf.dz2a; ha.dz2c = gbuf.dz2c; ha.partial = gbuf.partial;
+  MPPO_TRY(head_launch(ha, true, stream));
+  const int LR = A + 1 <= 16 ? 16 : 32;
+  const int nblk = cdiv(mb, 256 / LR);
   GemmBatch gb{};
   gb.count = 2; gb.ksplit = 1;
-  // dZ2 = (dOut . W3^T) * act'(h2)
-  {
-    GemmProb& a = gb.p[0]; a = GemmProb{};
-    a.A = gbuf.dmean; a.lda = AP; a.M = mb; a.K = A; a.B = params + L.a_w3; a.ldb = A; a.N = H; a.aux = gbuf.f.h2a; a.ldaux = H; a.act = act_a; a.C = gbuf.dz2a; a.ldc = H;
-    GemmProb& c = gb.p[1]; c = GemmProb{};
-    c.A = gbuf.dv; c.lda = 1; c.M = mb; c.K = 1; c.B = params + L.c_w3; c.ldb = 1; c.N = H; c.aux = gbuf.f.h2c; c.ldaux = H; c.act = ACT_RELU; c.C = gbuf.dz2c; c.ldc = H;
-  }
-  MPPO_TRY(gemm_launch(gb, 0, 1, EPI_DACT, 0, stream));
   // dZ1 = (dZ2 . W2^T) * act'(h1)
   {
     GemmProb& a = gb.p[0]; a = GemmProb{};
@@ -337,7 +439,8 @@ int32_t minibatch_grad(const mppo_net_t& net, const float* params, const mppo_ba
     c.A = gbuf.dz2c; c.lda = H; c.M = mb; c.K = H; c.B = params + L.c_w2; c.ldb = H; c.N = H; c.aux = gbuf.f.h1c; c.ldaux = H; c.act = ACT_RELU; c.C = gbuf.dz1c; c.ldc = H;
   }
   MPPO_TRY(gemm_launch(gb, 0, 1, EPI_DACT, net.bf16, stream));
-  // weight gradients dW = H_prev^T . dZ into split-K slabs; the bias gradients (column sums of dZ) ride along
+  // weight gradients dW = H_prev^T . dZ into split-K slabs; the bias gradients (column sums of dZ) ride along.
+  // dOut is [mb, DP] with d mean in columns [0,A) and d value in column AP: every operand is 16-byte aligned -> fast path.
   gb.count = 6; gb.ksplit = gbuf.ksplit; gb.slab_stride = gbuf.slab_stride;
   auto wprob = [&](const float* Aprev, int lda, const int* gather, int Min, const float* dZ, int ldz, int N, int off_w, int off_b) {
     GemmProb p{};
@@ -345,24 +448,26 @@ int32_t minibatch_grad(const mppo_net_t& net, const float* params, const mppo_ba
     p.bias_out = gbuf.slabs + off_b;
     return p;
   };
-  gb.p[0] = wprob(gbuf.f.h2a, H, nullptr, H, gbuf.dmean, AP, A, L.a_w3, L.a_b3);
+  gb.p[0] = wprob(gbuf.f.h2a, H, nullptr, H, gbuf.dout, DP, A, L.a_w3, L.a_b3);
   gb.p[1] = wprob(gbuf.f.h1a, H, nullptr, H, gbuf.dz2a, H, H, L.a_w2, L.a_b2);
   gb.p[2] = wprob(batch.obs, batch.obs_ld, idx, O, gbuf.dz1a, H, H, L.a_w1, L.a_b1);
-  gb.p[3] = wprob(gbuf.f.h2c, H, nullptr, H, gbuf.dv, 1, 1, L.c_w3, L.c_b3);
+  gb.p[3] = wprob(gbuf.f.h2c, H, nullptr, H, gbuf.dout + AP, DP, 1, L.c_w3, L.c_b3);
   gb.p[4] = wprob(gbuf.f.h1c, H, nullptr, H, gbuf.dz2c, H, H, L.c_w2, L.c_b2);
   gb.p[5] = wprob(batch.obs, batch.obs_ld, idx, O, gbuf.dz1c, H, H, L.c_w1, L.c_b1);
   MPPO_TRY(gemm_launch(gb, 1, 0, EPI_STORE, net.bf16, stream));
   const float ent_weight = (float)mb * inv_count;
-  hipLaunchKernelGGL(grad_reduce_kernel, dim3(cdiv((long)L.total, 256)), dim3(256), 0, stream, (size_t)L.total, gbuf.ksplit, gbuf.slab_stride, gbuf.slabs,
-                     L.log_std, A, AP, nblk, gbuf.partial, params + L.log_std, lc.ent_coef, lc.vf_coef, ent_weight, grad, loss4);
+  hipLaunchKernelGGL(grad_reduce_kernel, dim3(kNormBlocks), dim3(256), 0, stream, (size_t)L.total, gbuf.ksplit, gbuf.slab_stride, gbuf.slabs, L.log_std, A, AP, nblk,
+                     gbuf.partial, params + L.log_std, lc.ent_coef, lc.vf_coef, ent_weight, grad, loss4, sq_partial);
   MPPO_CHECK_LAUNCH("grad_reduce_kernel");
   return MPPO_OK;
 }
 
 int32_t clip_adam(size_t P, float* params, float* m, float* v, const float* grad, const int* count_base, int step_offset, const mppo_adam_cfg_t& cfg,
-                  float* ws, hipStream_t stream) {
-  hipLaunchKernelGGL(sumsq_kernel, dim3(kNormBlocks), dim3(256), 0, stream, P, grad, ws);
-  MPPO_CHECK_LAUNCH("sumsq_kernel");
+                  float* ws, bool have_sumsq, hipStream_t stream) {
+  if (!have_sumsq) {
+    hipLaunchKernelGGL(sumsq_kernel, dim3(kNormBlocks), dim3(256), 0, stream, P, grad, ws);
+    MPPO_CHECK_LAUNCH("sumsq_kernel");
+  }
   hipLaunchKernelGGL(adam_kernel, dim3(cdiv((long)P, 256)), dim3(256), 0, stream, P, params, m, v, grad, ws, count_base, step_offset, cfg);
   MPPO_CHECK_LAUNCH("adam_kernel");
   return MPPO_OK;
@@ -400,14 +505,10 @@ extern "C" int32_t mppo_policy_forward(const mppo_net_t* net, const float* param
   MPPO_REQUIRE(params && obs && value && ws && n >= 1, "mppo_policy_forward: null argument or n < 1");
   MPPO_REQUIRE(obs_ld >= net->O, "mppo_policy_forward: obs_ld %d < O %d", obs_ld, net->O);
   MPPO_REQUIRE(!noise || (action && log_prob), "mppo_policy_forward: noise given without action/log_prob outputs");
+  MPPO_REQUIRE(!mean_out || noise, "mppo_policy_forward: mean_out is only produced together with a sample (noise != NULL)");
   if (ws_bytes < mppo_policy_ws_bytes(net, n)) return fail(MPPO_ENOMEM, "mppo_policy_forward: workspace %zu < %zu bytes", ws_bytes, mppo_policy_ws_bytes(net, n));
-  hipStream_t s = static_cast<hipStream_t>(stream);
-  FwdBufs fb = carve_fwd(*net, n, static_cast<float*>(ws));
-  fb.value = value;
-  MPPO_TRY(mlp_forward(*net, params, n, obs, obs_ld, nullptr, fb, s));
-  if (noise) MPPO_TRY(policy_sample(*net, params, n, fb, noise, action, log_prob, s));
-  if (mean_out) MPPO_CHECK_HIP(hipMemcpyAsync(mean_out, fb.mean, (size_t)n * fb.AP * sizeof(float), hipMemcpyDeviceToDevice, s));
-  return MPPO_OK;
+  const FwdBufs fb = carve_fwd(*net, n, static_cast<float*>(ws));
+  return policy_forward(*net, params, n, obs, obs_ld, fb, noise, action, log_prob, value, mean_out, static_cast<hipStream_t>(stream));
 }
 
 extern "C" int32_t mppo_gae(int32_t T, int32_t N, float gamma, float lam, const float* reward, const float* value, const uint8_t* done,
@@ -427,7 +528,7 @@ extern "C" int32_t mppo_minibatch_grad(const mppo_net_t* net, const float* param
   MPPO_REQUIRE(batch->obs_ld >= net->O && batch->act_ld >= net->A, "mppo_minibatch_grad: leading dimensions too small");
   if (ws_bytes < mppo_grad_ws_bytes(net, mb)) return fail(MPPO_ENOMEM, "mppo_minibatch_grad: workspace %zu < %zu bytes", ws_bytes, mppo_grad_ws_bytes(net, mb));
   const GradBufs gb = carve_grad(*net, mb, static_cast<float*>(ws));
-  return minibatch_grad(*net, params, *batch, idx, mb, adv_stat, inv_count, *lc, grad, loss4, gb, static_cast<hipStream_t>(stream));
+  return minibatch_grad(*net, params, *batch, idx, mb, adv_stat, inv_count, *lc, grad, loss4, nullptr, gb, static_cast<hipStream_t>(stream));
 }
 
 extern "C" int32_t mppo_adv_sums(const float* adv, const int32_t* idx, int32_t nmb, int32_t mb, double* sums, void* stream) {
@@ -451,7 +552,7 @@ extern "C" int32_t mppo_clip_adam(size_t P, float* params, float* m, float* v, c
   MPPO_REQUIRE(P >= 1 && params && m && v && grad && count_base && cfg && ws, "mppo_clip_adam: null argument");
   MPPO_REQUIRE(!cfg->anneal || (cfg->sched_div >= 1 && cfg->num_updates >= 1), "mppo_clip_adam: anneal needs sched_div, num_updates >= 1");
   if (ws_bytes < mppo_adam_ws_bytes(P)) return fail(MPPO_ENOMEM, "mppo_clip_adam: workspace too small");
-  return clip_adam(P, params, m, v, grad, count_base, step_offset, *cfg, static_cast<float*>(ws), static_cast<hipStream_t>(stream));
+  return clip_adam(P, params, m, v, grad, count_base, step_offset, *cfg, static_cast<float*>(ws), false, static_cast<hipStream_t>(stream));
 }
 
 extern "C" int32_t mppo_normal_fill(uint64_t seed, uint64_t stream_id, size_t n, float* out, void* stream) {

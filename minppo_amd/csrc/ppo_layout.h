@@ -49,25 +49,24 @@ constexpr int kGradKSplit = 3;  // 72 weight-gradient tiles x 3 K-slices = 216 w
 // everything one minibatch gradient needs beyond the forward activations
 struct GradBufs {
   FwdBufs f;
-  float *dmean, *dv, *dz2a, *dz2c, *dz1a, *dz1c, *partial, *slabs;
+  float *dout, *dz2a, *dz2c, *dz1a, *dz1c, *partial, *slabs;  // dout [mb, AP+4]: d mean | d value
   int ksplit;
   size_t slab_stride;
 };
 inline size_t grad_bufs_floats(const mppo_net_t& net, int mb) {
   const size_t AP = pad4((size_t)net.A), nh = pad4((size_t)mb * net.H);
   const size_t P = pad4((size_t)param_layout(net.O, net.A, net.H).total);
-  const size_t nblk = (size_t)(mb + 255) / 256;
-  return fwd_bufs_floats(net, mb) + pad4((size_t)mb * AP) + pad4((size_t)mb) + 4 * nh + pad4(nblk * (4 + AP)) + (size_t)kGradKSplit * P;
+  const size_t nblk = (size_t)(mb + 7) / 8;  // head kernel: 8 or 16 rows per workgroup
+  return fwd_bufs_floats(net, mb) + pad4((size_t)mb * (AP + 4)) + 4 * nh + pad4(nblk * (4 + AP)) + (size_t)kGradKSplit * P;
 }
 inline GradBufs carve_grad(const mppo_net_t& net, int mb, float* ws) {
   GradBufs g;
   g.f = carve_fwd(net, mb, ws);
   ws += fwd_bufs_floats(net, mb);
   const size_t AP = (size_t)g.f.AP, nh = pad4((size_t)mb * net.H);
-  g.dmean = ws; ws += pad4((size_t)mb * AP);
-  g.dv = ws; ws += pad4((size_t)mb);
+  g.dout = ws; ws += pad4((size_t)mb * (AP + 4));
   g.dz2a = ws; ws += nh; g.dz2c = ws; ws += nh; g.dz1a = ws; ws += nh; g.dz1c = ws; ws += nh;
-  const size_t nblk = (size_t)(mb + 255) / 256;
+  const size_t nblk = (size_t)(mb + 7) / 8;
   g.partial = ws; ws += pad4(nblk * (4 + AP));
   g.slabs = ws;
   g.ksplit = kGradKSplit;
@@ -76,12 +75,13 @@ inline GradBufs carve_grad(const mppo_net_t& net, int mb, float* ws) {
 }
 
 // stage launchers (k_ppo.hip)
-int32_t mlp_forward(const mppo_net_t& net, const float* params, int n, const float* obs, int obs_ld, const int* gather, const FwdBufs& fb, hipStream_t stream);
-int32_t policy_sample(const mppo_net_t& net, const float* params, int n, const FwdBufs& fb, const float* noise, float* action, float* log_prob, hipStream_t stream);
+int32_t policy_forward(const mppo_net_t& net, const float* params, int n, const float* obs, int obs_ld, const FwdBufs& fb, const float* noise, float* action,
+                       float* log_prob, float* value, float* mean_out, hipStream_t stream);
+// sq_partial (optional): per-workgroup sums of squares of the reduced gradient, consumed by clip_adam(have_sumsq = true)
 int32_t minibatch_grad(const mppo_net_t& net, const float* params, const mppo_batch_t& batch, const int* idx, int mb, const float* adv_stat, float inv_count,
-                       const mppo_loss_cfg_t& lc, float* grad, float* loss4, const GradBufs& gbuf, hipStream_t stream);
+                       const mppo_loss_cfg_t& lc, float* grad, float* loss4, float* sq_partial, const GradBufs& gbuf, hipStream_t stream);
 int32_t clip_adam(size_t P, float* params, float* m, float* v, const float* grad, const int* count_base, int step_offset, const mppo_adam_cfg_t& cfg, float* ws,
-                  hipStream_t stream);
+                  bool have_sumsq, hipStream_t stream);
 int32_t gae_launch(int T, int N, float gamma, float lam, const float* reward, const float* value, const unsigned char* done, const float* last_val, float* adv,
                    float* target, hipStream_t stream);
 int32_t perm_fill_keys(unsigned long long seed, unsigned long long stream_id, const int* ctr, int B, unsigned* keys, int* vals, hipStream_t stream);

@@ -103,3 +103,12 @@ inline double wave_sum_f64(double x) {
   __syncthreads();
   return r;
 }
+inline float __shfl_xor(float x, int mask) {
+  float* s = reinterpret_cast<float*>(emu::g_xchg);
+  const int t = emu::tid();
+  s[t] = x;
+  __syncthreads();
+  const float r = s[((t & 63) ^ mask) | (t & ~63)];
+  __syncthreads();
+  return r;
+}
