@@ -9,10 +9,11 @@
 // Shape regime: M = 1280 (minibatch) or 4096 (rollout) rows, N = K = 256 and smaller.  A
 // workgroup = 4 waves = one 64x64 tile of C (each wave one 32x32 MFMA accumulator); the two
 // networks (and all six weight gradients) share one launch through blockIdx.z so that a launch
-// carries 160-300 workgroups.  Operand tiles (64 x 32) are staged global -> registers -> LDS one k-tile
-// ahead (double-buffered LDS, one barrier per k-tile), k-major (As[k][m], Bs[k][n], row stride 68
-// floats): the MFMA operand fetch is one conflict-free ds_read_b32 per operand per MFMA, negligible
-// beside the 64-cycle f32 MFMA, and the global-load latency hides under the 16 MFMAs of the current tile.  The f32 MFMA rate
+// carries 160-300 workgroups.  There is NO LDS staging and NO barrier: the f32 MFMA consumes only 8 bytes
+// of operands per lane per 64 cycles, so each wave streams its A and B fragments straight from L1/L2 into
+// registers in MFMA layout (see "direct-to-register operand streams" below), one 32-deep k-set ahead.
+// (Round 1 measured the LDS-staged version of this kernel: 40 % of its wave cycles sat in s_waitcnt /
+// s_barrier around the LDS round trip — profiles/r01_b_pmc_gemm_lds.txt.)  The f32 MFMA rate
 // (157 TFLOP/s) is the roofline for these kernels; at these sizes the achieved fraction is set by
 // tile count / wave occupancy rather than by memory.
 #include <wave_ops.h>
@@ -22,93 +23,82 @@
 
 namespace mppo {
 
-constexpr int BM = 64, BN = 64, BK = 32, LDT = 68, GEMM_THREADS = 256;
-constexpr int TILE_F = BK * LDT;  // floats of one staged operand tile
+constexpr int BM = 64, BN = 64, KS = 32, GEMM_THREADS = 256;  // workgroup tile, k-set (16 MFMAs), 4 waves as 2 x 2
 
-// ---- global -> register staging (issued one k-tile ahead), register -> LDS (k-major image T[k][r]) ----
-// Two loaders per memory orientation: `fast` is branch-free (16-byte aligned rows, unconditional float4 loads, row /
-// column indices clamped into the allocation so that out-of-tile lanes re-read valid data which the epilogue never
-// stores); `slow` predicates every element and serves ragged shapes and the partial last k-tile.
-
-// "kc": memory contiguous along k, element (r,k) at base[row(r)*ld + k].  A thread owns row r = t>>2 and the two
-// k-quads kq = 4*(t&3) and kq+16 (so that the transposed LDS stores of a wave hit each bank at most twice).
-struct StageKC {
-  float v[8];
-  const float* ptr;  // row(r) base + kq, fixed for the whole K loop
-  bool row_ok;
-  __device__ __forceinline__ void init(const float* base, int ld, const int* gather, int r0, int R, int t) {
-    const int r = t >> 2, kq = (t & 3) * 4;
-    int gr = r0 + r;
-    row_ok = gr < R;
-    gr = row_ok ? gr : R - 1;
-    const long row = gather ? gather[gr] : gr;
-    ptr = base + row * (long)ld + kq;
+// ---- direct-to-register operand streams --------------------------------------------------------------------------
+// v_mfma_f32_32x32x2_f32 takes, per lane l = (i = l&31, h = l>>5), ONE A value A[i][k_h] and ONE B value B[k_h][j=i]
+// and sums the two k's of the two lane halves.  Any assignment of k's to (MFMA, h) works as long as A and B use the
+// same one and every k is covered once.  We use, inside a set of 32 k's:  MFMA (g, c) of half h  <->  k = 8g + 4h + c
+// (g = 0..3, c = 0..3), so that a lane's four values of a group are 4 CONSECUTIVE k's: one float4 load where memory is
+// contiguous along k, four coalesced dword loads (128 B per half-wave) where it is contiguous along the row/column.
+// Operands are read straight from L1/L2 into registers (8 B/clk per wave, far below the L1 rate), double-buffered one
+// set ahead, so a wave never touches LDS and never meets a barrier.
+struct OperandK {  // memory contiguous along k:  element (r, k) at base[row(r)*ld + k]   (row = lane's own row, clamped)
+  const float* ptr;
+  bool ok, vec;
+  __device__ __forceinline__ void init(const float* base, int ld, const int* gather, int r, int R, int h) {
+    vec = ((ld & 3) == 0) && ((reinterpret_cast<uintptr_t>(base) & 15) == 0);  // problem-uniform: float4 loads are legal
+    ok = r < R;
+    const int rr = ok ? r : R - 1;
+    const long row = gather ? gather[rr] : rr;
+    ptr = base + row * (long)ld + 4 * h;
   }
-  __device__ __forceinline__ void load_fast(int k0) {
-    const float4 a = *reinterpret_cast<const float4*>(ptr + k0);
-    const float4 b = *reinterpret_cast<const float4*>(ptr + k0 + 16);
-    v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
-  }
-  __device__ __forceinline__ void load_slow(int k0, int kend, int t) {
-    const int kq = (t & 3) * 4;
-    for (int hq = 0; hq < 2; ++hq)
-      for (int c = 0; c < 4; ++c) {
-        const int kk = k0 + kq + 16 * hq + c;
-        v[4 * hq + c] = (row_ok && kk < kend) ? ptr[k0 + 16 * hq + c] : 0.f;
+  __device__ __forceinline__ void load(float (&v)[16], int k0) const {  // full set: k0 .. k0+31 all valid
+    if (vec) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const float4 q = *reinterpret_cast<const float4*>(ptr + k0 + 8 * g);
+        v[4 * g] = q.x; v[4 * g + 1] = q.y; v[4 * g + 2] = q.z; v[4 * g + 3] = q.w;
       }
+    } else {  // odd action dimension / unpadded rows: same data with dword loads
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) v[4 * g + c] = ptr[k0 + 8 * g + c];
+    }
   }
-  __device__ __forceinline__ void store(float* T, int t) const {
-    const int r = t >> 2, kq = (t & 3) * 4;
-    for (int hq = 0; hq < 2; ++hq)
-      for (int c = 0; c < 4; ++c) T[(kq + 16 * hq + c) * LDT + r] = v[4 * hq + c];
+  __device__ __forceinline__ void load_tail(float (&v)[16], int k0, int kend, int h) const {
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const int k = k0 + 8 * g + 4 * h + c;
+        v[4 * g + c] = (ok && k < kend) ? ptr[k0 + 8 * g + c] : 0.f;
+      }
   }
 };
 
-// "rc": memory contiguous along r, element (r,k) at base[row(k)*ld + r].  A thread owns the r-quad rq = 4*(t&15) of the
-// two k-rows k = t>>4 and k+16.  With a gather the row indices of the NEXT tile are fetched one tile early.
-struct StageRC {
-  float4 q[2];
-  const float* colptr;  // base + clamped column
+struct OperandR {  // memory contiguous along r:  element (r, k) at base[row(k)*ld + r]   (r = lane's own column)
+  const float* base;
   const int* gather;
-  int ld, col, Rmem, kend;
-  int nxt[2];
-  __device__ __forceinline__ void init(const float* base, int ld_, const int* gather_, int r0, int Rmem_, int k0, int kend_, int t, bool fast) {
-    ld = ld_; gather = gather_; Rmem = Rmem_; kend = kend_;
-    col = r0 + (t & 15) * 4;
-    const int cmax = (ld & ~3) - 4;
-    colptr = base + (fast ? (col < cmax ? col : cmax) : col);
-    if (gather) prefetch_idx(k0, t);
+  long ld;
+  int col, kend;
+  bool ok;
+  __device__ __forceinline__ void init(const float* base_, int ld_, const int* gather_, int r, int R, int kend_) {
+    ok = r < R;
+    col = ok ? r : R - 1;
+    base = base_ + col; ld = ld_; gather = gather_; kend = kend_;
   }
-  __device__ __forceinline__ void prefetch_idx(int k0, int t) {
-    for (int hq = 0; hq < 2; ++hq) {
-      int gk = k0 + (t >> 4) + 16 * hq;
-      gk = gk < kend ? gk : kend - 1;
-      nxt[hq] = gather[gk];
-    }
-  }
-  __device__ __forceinline__ void load_fast(int k0, int t) {  // every k-row of the tile is < kend
-    for (int hq = 0; hq < 2; ++hq) {
-      const long row = gather ? nxt[hq] : k0 + (t >> 4) + 16 * hq;
-      q[hq] = *reinterpret_cast<const float4*>(colptr + row * (long)ld);
-    }
-    if (gather) prefetch_idx(k0 + BK, t);
-  }
-  __device__ __forceinline__ void load_slow(int k0, int t) {
-    for (int hq = 0; hq < 2; ++hq) {
-      const int gk = k0 + (t >> 4) + 16 * hq;
-      float v[4] = {0.f, 0.f, 0.f, 0.f};
-      if (gk < kend) {
-        const long row = gather ? gather[gk] : gk;
-        const float* ptr = colptr + row * (long)ld;  // colptr == base + col on the slow path
-        for (int c = 0; c < 4; ++c) if (col + c < Rmem) v[c] = ptr[c];
+  __device__ __forceinline__ void load(float (&v)[16], int k0, int h) const {  // full set
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const int k = k0 + 8 * g + 4 * h + c;
+        const long row = gather ? gather[k] : k;
+        v[4 * g + c] = base[row * ld];
       }
-      q[hq] = make_float4(v[0], v[1], v[2], v[3]);
-    }
   }
-  __device__ __forceinline__ void store(float* T, int t) const {
-    const int k = t >> 4, rq = (t & 15) * 4;
-    *reinterpret_cast<float4*>(T + k * LDT + rq) = q[0];
-    *reinterpret_cast<float4*>(T + (k + 16) * LDT + rq) = q[1];
+  __device__ __forceinline__ void load_tail(float (&v)[16], int k0, int h) const {
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const int k = k0 + 8 * g + 4 * h + c;
+        float x = 0.f;
+        if (ok && k < kend) { const long row = gather ? gather[k] : k; x = base[row * ld]; }
+        v[4 * g + c] = x;
+      }
   }
 };
 
@@ -118,92 +108,72 @@ __device__ __forceinline__ float fast_tanh(float x) {
   return 1.f - __fdividef(2.f, e + 1.f);
 }
 
-// Pipeline: the global loads of k-tile i+1 are in flight while the 16 MFMAs per wave of k-tile i run; the MFMA operands
-// of a k-tile are all fetched from LDS into registers before the MFMA chain starts; one workgroup barrier per k-tile.
-template <bool A_T, bool B_T, int EPI, bool FAST>
+template <bool A_T, bool B_T, int EPI>
 __global__ void __launch_bounds__(GEMM_THREADS) gemm_kernel(GemmBatch gb) {
-  __shared__ __attribute__((aligned(16))) float As[2 * TILE_F];
-  __shared__ __attribute__((aligned(16))) float Bs[2 * TILE_F];
   const int z = blockIdx.z;
   const int pi = z / gb.ksplit, ks = z - pi * gb.ksplit;
   const GemmProb p = gb.p[pi];
-  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
-  if (m0 >= p.M || n0 >= p.N) return;  // workgroup-uniform
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int wr = wave >> 1, wc = wave & 1, l31 = lane & 31, hi = lane >> 5;
+  const int m0 = blockIdx.y * BM + wr * 32, n0 = blockIdx.x * BN + wc * 32;  // this wave's 32 x 32 tile
+  if (m0 >= p.M || n0 >= p.N) return;                                        // wave-uniform; no barriers below
   int kper = (p.K + gb.ksplit - 1) / gb.ksplit;
-  kper = (kper + BK - 1) / BK * BK;
+  kper = (kper + KS - 1) / KS * KS;
   const int kb = ks * kper;
   const int ke = p.K < kb + kper ? p.K : kb + kper;
 
-  StageKC a_kc, b_kc;
-  StageRC a_rc, b_rc;
-  if (A_T) a_rc.init(p.A, p.lda, p.gather, m0, p.M, kb, ke, t, FAST);
-  else a_kc.init(p.A, p.lda, p.gather, m0, p.M, t);
-  if (B_T) b_kc.init(p.B, p.ldb, nullptr, n0, p.N, t);
-  else b_rc.init(p.B, p.ldb, nullptr, n0, p.N, kb, ke, t, FAST);
-  auto load_tiles = [&](int k0) {
-    const bool full = FAST && (k0 + BK <= ke);  // workgroup-uniform
-    if (full) {
-      if (A_T) a_rc.load_fast(k0, t); else a_kc.load_fast(k0);
-      if (B_T) b_kc.load_fast(k0); else b_rc.load_fast(k0, t);
+  OperandK ak, bk;
+  OperandR ar, br;
+  if (A_T) ar.init(p.A, p.lda, p.gather, m0 + l31, p.M, ke);
+  else ak.init(p.A, p.lda, p.gather, m0 + l31, p.M, hi);
+  if (B_T) bk.init(p.B, p.ldb, nullptr, n0 + l31, p.N, hi);
+  else br.init(p.B, p.ldb, nullptr, n0 + l31, p.N, ke);
+  auto load_set = [&](float (&a)[16], float (&b)[16], int k0) {
+    if (k0 + KS <= ke) {  // wave-uniform
+      if (A_T) ar.load(a, k0, hi); else ak.load(a, k0);
+      if (B_T) bk.load(b, k0); else br.load(b, k0, hi);
     } else {
-      if (A_T) a_rc.load_slow(k0, t); else a_kc.load_slow(k0, ke, t);
-      if (B_T) b_kc.load_slow(k0, ke, t); else b_rc.load_slow(k0, t);
+      if (A_T) ar.load_tail(a, k0, hi); else ak.load_tail(a, k0, ke, hi);
+      if (B_T) bk.load_tail(b, k0, ke, hi); else br.load_tail(b, k0, hi);
     }
-  };
-  auto store_tiles = [&](int b) {
-    if (A_T) a_rc.store(As + b * TILE_F, t); else a_kc.store(As + b * TILE_F, t);
-    if (B_T) b_kc.store(Bs + b * TILE_F, t); else b_rc.store(Bs + b * TILE_F, t);
   };
 
   f32x16 acc;
   for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-  float colsum = 0.f;  // EPI_STORE with bias_out: column sums of the B tile (= bias gradient), m-tile 0 only
-  const bool do_colsum = (EPI == EPI_STORE) && p.bias_out && blockIdx.y == 0 && t < BN;
+  float colsum = 0.f;  // EPI_STORE with bias_out: sum over k of B(k, n) (= bias gradient); waves of the first row tile only
+  const bool do_colsum = (EPI == EPI_STORE) && p.bias_out && m0 == 0;
 
-  int buf = 0;
-  if (kb < ke) {
-    load_tiles(kb);
-    store_tiles(0);
-  }
-  __syncthreads();
-  for (int k0 = kb; k0 < ke; k0 += BK) {
-    const bool more = k0 + BK < ke;
-    if (more) load_tiles(k0 + BK);
-    const float* Ab = As + buf * TILE_F + wr * 32 + l31 + hi * LDT;
-    const float* Bb = Bs + buf * TILE_F + wc * 32 + l31 + hi * LDT;
-    float av[BK / 2], bv[BK / 2];
+  float a0[16], b0[16], a1[16], b1[16];
+  if (kb < ke) load_set(a0, b0, kb);
+  for (int k0 = kb; k0 < ke; k0 += 2 * KS) {
+    // --- set k0 from (a0,b0) while (a1,b1) load ---
+    const bool more1 = k0 + KS < ke;
+    if (more1) load_set(a1, b1, k0 + KS);
 #pragma unroll
-    for (int i = 0; i < BK / 2; ++i) { av[i] = Ab[2 * i * LDT]; bv[i] = Bb[2 * i * LDT]; }
-    const int nk2 = ((ke - k0 < BK ? ke - k0 : BK) + 1) >> 1;  // MFMAs that carry data (k-rows past ke are zeros)
-    if (nk2 == BK / 2) {
-#pragma unroll
-      for (int i = 0; i < BK / 2; ++i) mfma_f32_32x32x2(av[i], bv[i], acc);
-    } else {
-#pragma unroll
-      for (int i = 0; i < BK / 2; ++i)
-        if (i < nk2) mfma_f32_32x32x2(av[i], bv[i], acc);  // partial last k-tile only
-    }
+    for (int i = 0; i < 16; ++i) mfma_f32_32x32x2(a0[i], b0[i], acc);
     if (do_colsum) {
-      const float* Bc = Bs + buf * TILE_F + t;
-      float cs = 0.f;
 #pragma unroll
-      for (int kk = 0; kk < BK; ++kk) cs += Bc[kk * LDT];  // rows past ke were staged as zeros
-      colsum += cs;
+      for (int i = 0; i < 16; ++i) colsum += b0[i];
     }
-    if (more) store_tiles(buf ^ 1);
-    __syncthreads();
-    buf ^= 1;
+    if (!more1) break;
+    // --- set k0+KS from (a1,b1) while (a0,b0) load ---
+    const bool more0 = k0 + 2 * KS < ke;
+    if (more0) load_set(a0, b0, k0 + 2 * KS);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) mfma_f32_32x32x2(a1[i], b1[i], acc);
+    if (do_colsum) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) colsum += b1[i];
+    }
   }
 
   float* C = p.C + (EPI == EPI_STORE ? (size_t)ks * gb.slab_stride : 0);
-  const int col = n0 + wc * 32 + l31;
+  const int col = n0 + l31;
   if (col < p.N) {
     float bias = 0.f;
     if (EPI == EPI_BIAS_ACT && p.bias) bias = p.bias[col];
     for (int r = 0; r < 16; ++r) {
-      const int row = m0 + wr * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+      const int row = m0 + (r & 3) + 8 * (r >> 2) + 4 * hi;
       if (row < p.M) {
         float v = acc[r];
         if (EPI == EPI_BIAS_ACT) {
@@ -219,24 +189,22 @@ __global__ void __launch_bounds__(GEMM_THREADS) gemm_kernel(GemmBatch gb) {
       }
     }
   }
-  if (do_colsum && n0 + t < p.N) p.bias_out[(size_t)ks * gb.slab_stride + n0 + t] = colsum;
+  if (do_colsum) {
+    colsum += __shfl_xor(colsum, 32);  // the two lane halves hold the two k-halves of every group
+    if (hi == 0 && col < p.N) p.bias_out[(size_t)ks * gb.slab_stride + col] = colsum;
+  }
 }
 
 template <bool A_T, bool B_T, int EPI>
 static int32_t launch_t(const GemmBatch& gb, hipStream_t stream) {
   int maxM = 0, maxN = 0;
-  bool fast = true;  // every problem has 16-byte aligned operands with row strides that are multiples of 4 floats
   for (int i = 0; i < gb.count; ++i) {
     const GemmProb& p = gb.p[i];
     maxM = p.M > maxM ? p.M : maxM;
     maxN = p.N > maxN ? p.N : maxN;
-    const bool al = ((reinterpret_cast<uintptr_t>(p.A) | reinterpret_cast<uintptr_t>(p.B)) & 15) == 0 && (p.lda & 3) == 0 && (p.ldb & 3) == 0 && p.lda >= 4 &&
-                    p.ldb >= 4;
-    fast = fast && al;
   }
   dim3 grid(cdiv(maxN, BN), cdiv(maxM, BM), gb.count * gb.ksplit);
-  if (fast) hipLaunchKernelGGL((gemm_kernel<A_T, B_T, EPI, true>), grid, dim3(GEMM_THREADS), 0, stream, gb);
-  else hipLaunchKernelGGL((gemm_kernel<A_T, B_T, EPI, false>), grid, dim3(GEMM_THREADS), 0, stream, gb);
+  hipLaunchKernelGGL((gemm_kernel<A_T, B_T, EPI>), grid, dim3(GEMM_THREADS), 0, stream, gb);
   MPPO_CHECK_LAUNCH("gemm_kernel");
   return MPPO_OK;
 }

@@ -70,9 +70,10 @@ __global__ void __launch_bounds__(256) head_kernel(HeadArgs a) {
   MPPO_DYN_SMEM(smem_raw);
   float* sm = reinterpret_cast<float*>(smem_raw);
   const int H = a.H, A = a.A, AP = a.AP;
-  float* s_h2a = sm;                  // [RT][H]
-  float* s_h2c = s_h2a + RT * H;      // [RT][H]
-  float* s_w3a = s_h2c + RT * H;      // [H][A]
+  const int HS = H + 4;                // padded row stride: rows r, r+1 start 4 banks apart (unpadded: 16-way conflict)
+  float* s_h2a = sm;                  // [RT][HS]
+  float* s_h2c = s_h2a + RT * HS;     // [RT][HS]
+  float* s_w3a = s_h2c + RT * HS;     // [H][A]
   float* s_w3c = s_w3a + H * A;       // [H]
   float* s_do = s_w3c + H;            // [RT][LR]   d mean (cols < A), d value (col A)
   float* s_red = s_do + RT * LR;      // [RT][LR]   per-row partials for the block reduction
@@ -84,8 +85,8 @@ __global__ void __launch_bounds__(256) head_kernel(HeadArgs a) {
   for (int e = t; e < RT * H / 4; e += 256) {
     const int rr = (e * 4) / H, cc = (e * 4) % H;
     const int gi = row0 + rr < a.n ? row0 + rr : a.n - 1;
-    reinterpret_cast<float4*>(s_h2a)[e] = *reinterpret_cast<const float4*>(a.h2a + (size_t)gi * H + cc);
-    reinterpret_cast<float4*>(s_h2c)[e] = *reinterpret_cast<const float4*>(a.h2c + (size_t)gi * H + cc);
+    *reinterpret_cast<float4*>(s_h2a + rr * HS + cc) = *reinterpret_cast<const float4*>(a.h2a + (size_t)gi * H + cc);
+    *reinterpret_cast<float4*>(s_h2c + rr * HS + cc) = *reinterpret_cast<const float4*>(a.h2c + (size_t)gi * H + cc);
   }
   for (int e = t; e < H * A; e += 256) s_w3a[e] = a.w3a[e];
   for (int e = t; e < H; e += 256) s_w3c[e] = a.w3c[e];
@@ -94,12 +95,12 @@ __global__ void __launch_bounds__(256) head_kernel(HeadArgs a) {
   float out = 0.f;
   if (o < A) {
     float s0 = 0.f, s1 = 0.f;
-    const float* hrow = s_h2a + r * H;
+    const float* hrow = s_h2a + r * HS;
     for (int k = 0; k < H; k += 2) { s0 += hrow[k] * s_w3a[k * A + o]; s1 += hrow[k + 1] * s_w3a[(k + 1) * A + o]; }
     out = s0 + s1 + a.b3a[o];
   } else if (o == A) {
     float s0 = 0.f, s1 = 0.f;
-    const float* hrow = s_h2c + r * H;
+    const float* hrow = s_h2c + r * HS;
     for (int k = 0; k < H; k += 2) { s0 += hrow[k] * s_w3c[k]; s1 += hrow[k + 1] * s_w3c[k + 1]; }
     out = s0 + s1 + a.b3c[0];
   }
@@ -179,7 +180,7 @@ __global__ void __launch_bounds__(256) head_kernel(HeadArgs a) {
 #pragma unroll
     for (int rr = 0; rr < RT; ++rr) {
       if (row0 + rr < a.n) {
-        const float ha = s_h2a[rr * H + n], hc = s_h2c[rr * H + n];
+        const float ha = s_h2a[rr * HS + n], hc = s_h2c[rr * HS + n];
         a.dz2a[(size_t)(row0 + rr) * H + n] = a.use_tanh ? acc[rr] * (1.f - ha * ha) : (ha > 0.f ? acc[rr] : 0.f);
         a.dz2c[(size_t)(row0 + rr) * H + n] = hc > 0.f ? s_do[rr * LR + A] * wc : 0.f;
       }
@@ -187,7 +188,7 @@ __global__ void __launch_bounds__(256) head_kernel(HeadArgs a) {
   }
 }
 
-static size_t head_smem_bytes(int LR, int H, int A) { const int RT = 256 / LR; return sizeof(float) * ((size_t)2 * RT * H + (size_t)H * A + H + 2 * RT * LR); }
+static size_t head_smem_bytes(int LR, int H, int A) { const int RT = 256 / LR; return sizeof(float) * ((size_t)2 * RT * (H + 4) + (size_t)H * A + H + 2 * RT * LR); }
 
 int32_t head_launch(const HeadArgs& a, bool loss, hipStream_t stream) {
   MPPO_REQUIRE(a.A + 1 <= 32 && (a.H % 4) == 0, "head kernel: A = %d must be <= 31 and H %% 4 == 0", a.A);
@@ -221,31 +222,39 @@ __global__ void __launch_bounds__(256) grad_reduce_kernel(size_t P, int ksplit, 
   __shared__ float red[4];
   float sq = 0.f;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < P; i += (size_t)gridDim.x * blockDim.x) {
+    if (i >= (size_t)ls_off && i < (size_t)ls_off + A) continue;  // log_std: from the loss partials, below
     float s = 0.f;
-    if (i >= (size_t)ls_off && i < (size_t)ls_off + A) {
-      const int a = (int)(i - ls_off);
-      for (int k = 0; k < nblk; ++k) s += partial[(size_t)k * (4 + AP) + 4 + a];
-      s -= ent_coef * ent_weight;
-    } else {
-      for (int k = 0; k < ksplit; ++k) s += slabs[(size_t)k * slab_stride + i];
-    }
+    for (int k = 0; k < ksplit; ++k) s += slabs[(size_t)k * slab_stride + i];
     grad[i] = s;
     sq += s * s;
+  }
+  if (blockIdx.x == gridDim.x - 1) {
+    // the small sums over the head kernel's per-workgroup partials: every wave computes them (lanes stride over the
+    // nblk partial rows, fixed reduction tree), wave 0 stores.  Columns: 0 actor loss, 1 value loss, 4+a d log_std[a].
+    const int ln = threadIdx.x & 63, wv = threadIdx.x >> 6, W = 4 + AP;
+    float la = 0.f, lv = 0.f;
+    for (int k = ln; k < nblk; k += 64) { la += partial[(size_t)k * W]; lv += partial[(size_t)k * W + 1]; }
+    la = wave_sum(la); lv = wave_sum(lv);
+    float sl = 0.f;
+    for (int a = 0; a < A; ++a) {
+      float d = 0.f;
+      for (int k = ln; k < nblk; k += 64) d += partial[(size_t)k * W + 4 + a];
+      d = wave_sum(d) - ent_coef * ent_weight;
+      sl += log_std[a];
+      if (wv == 0 && ln == 0) { grad[ls_off + a] = d; sq += d * d; }
+    }
+    if (wv == 0 && ln == 0 && loss4) {
+      const float ent = (0.5f * (float)A * (1.f + kLog2Pi) + sl) * ent_weight;
+      loss4[0] = la + vf_coef * lv - ent_coef * ent;
+      loss4[1] = lv;
+      loss4[2] = la;
+      loss4[3] = ent;
+    }
   }
   sq = wave_sum(sq);
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = sq;
   __syncthreads();
   if (threadIdx.x == 0 && sq_partial) sq_partial[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
-  if (blockIdx.x == 0 && threadIdx.x == 0 && loss4) {
-    float la = 0.f, lv = 0.f, sl = 0.f;
-    for (int k = 0; k < nblk; ++k) { la += partial[(size_t)k * (4 + AP)]; lv += partial[(size_t)k * (4 + AP) + 1]; }
-    for (int a = 0; a < A; ++a) sl += log_std[a];
-    const float ent = (0.5f * (float)A * (1.f + kLog2Pi) + sl) * ent_weight;
-    loss4[0] = la + vf_coef * lv - ent_coef * ent;
-    loss4[1] = lv;
-    loss4[2] = la;
-    loss4[3] = ent;
-  }
 }
 
 // ------------------------------------------------------------------------------------------------
