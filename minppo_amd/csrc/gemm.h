@@ -31,6 +31,7 @@ struct GemmProb {
   int lda, ldb, ldc, ldaux;
   int act;
   float* bias_out;
+  float* a_copy;  // forward only: contiguous copy of the (gathered) A rows, [M, lda]
 };
 
 constexpr int kGemmMaxProb = 6;
@@ -43,5 +44,6 @@ struct GemmBatch {
 
 // variant = a_t*2 + b_t ; epi as above; bf16 = 1 uses bf16-in/f32-acc MFMA (inputs rounded to bf16 when staged)
 int32_t gemm_launch(const GemmBatch& batch, int a_t, int b_t, int epi, int bf16, hipStream_t stream);
+int32_t gemm_launch_lds(const GemmBatch& batch, int a_t, int b_t, int epi, hipStream_t stream);  // k_gemm_lds.hip
 
 }  // namespace mppo

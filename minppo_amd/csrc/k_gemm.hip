@@ -18,6 +18,9 @@
 // tile count / wave occupancy rather than by memory.
 #include <wave_ops.h>
 
+#include <cstdlib>
+#include <cstring>
+
 #include "gemm.h"
 #include "mppo_common.h"
 
@@ -34,7 +37,7 @@ constexpr int BM = 64, BN = 64, KS = 32, GEMM_THREADS = 256;  // workgroup tile,
 // Operands are read straight from L1/L2 into registers (8 B/clk per wave, far below the L1 rate), double-buffered one
 // set ahead, so a wave never touches LDS and never meets a barrier.
 struct OperandK {  // memory contiguous along k:  element (r, k) at base[row(r)*ld + k]   (row = lane's own row, clamped)
-  const float* ptr;
+  const float* ptr;  // row(r)*ld + 4*h ; the k-set offset is added per load (pointer bump + immediates)
   bool ok, vec;
   __device__ __forceinline__ void init(const float* base, int ld, const int* gather, int r, int R, int h) {
     vec = ((ld & 3) == 0) && ((reinterpret_cast<uintptr_t>(base) & 15) == 0);  // problem-uniform: float4 loads are legal
@@ -44,17 +47,18 @@ struct OperandK {  // memory contiguous along k:  element (r, k) at base[row(r)*
     ptr = base + row * (long)ld + 4 * h;
   }
   __device__ __forceinline__ void load(float (&v)[16], int k0) const {  // full set: k0 .. k0+31 all valid
+    const float* q0 = ptr + k0;
     if (vec) {
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
-        const float4 q = *reinterpret_cast<const float4*>(ptr + k0 + 8 * g);
+        const float4 q = *reinterpret_cast<const float4*>(q0 + 8 * g);
         v[4 * g] = q.x; v[4 * g + 1] = q.y; v[4 * g + 2] = q.z; v[4 * g + 3] = q.w;
       }
     } else {  // odd action dimension / unpadded rows: same data with dword loads
 #pragma unroll
       for (int g = 0; g < 4; ++g)
 #pragma unroll
-        for (int c = 0; c < 4; ++c) v[4 * g + c] = ptr[k0 + 8 * g + c];
+        for (int c = 0; c < 4; ++c) v[4 * g + c] = q0[8 * g + c];
     }
   }
   __device__ __forceinline__ void load_tail(float (&v)[16], int k0, int kend, int h) const {
@@ -68,25 +72,22 @@ struct OperandK {  // memory contiguous along k:  element (r, k) at base[row(r)*
   }
 };
 
-struct OperandR {  // memory contiguous along r:  element (r, k) at base[row(k)*ld + r]   (r = lane's own column)
-  const float* base;
-  const int* gather;
-  long ld;
-  int col, kend;
+struct OperandR {  // memory contiguous along r:  element (r, k) at base[k*ld + r]   (r = lane's own column, clamped)
+  const float* base;  // wave-uniform
+  int ld, lane_off, kend;  // lane_off = column + 4*h*ld : the only per-lane part of the address
   bool ok;
-  __device__ __forceinline__ void init(const float* base_, int ld_, const int* gather_, int r, int R, int kend_) {
+  __device__ __forceinline__ void init(const float* base_, int ld_, int r, int R, int kend_, int h) {
     ok = r < R;
-    col = ok ? r : R - 1;
-    base = base_ + col; ld = ld_; gather = gather_; kend = kend_;
+    base = base_; ld = ld_; kend = kend_;
+    lane_off = (ok ? r : R - 1) + 4 * h * ld_;
   }
-  __device__ __forceinline__ void load(float (&v)[16], int k0, int h) const {  // full set
+  __device__ __forceinline__ void load(float (&v)[16], int k0) const {  // full set; uniform base + 32-bit lane offset
 #pragma unroll
     for (int g = 0; g < 4; ++g)
 #pragma unroll
       for (int c = 0; c < 4; ++c) {
-        const int k = k0 + 8 * g + 4 * h + c;
-        const long row = gather ? gather[k] : k;
-        v[4 * g + c] = base[row * ld];
+        const float* up = base + (long)(k0 + 8 * g + c) * ld;  // scalar arithmetic
+        v[4 * g + c] = up[lane_off];
       }
   }
   __device__ __forceinline__ void load_tail(float (&v)[16], int k0, int h) const {
@@ -95,9 +96,7 @@ struct OperandR {  // memory contiguous along r:  element (r, k) at base[row(k)*
 #pragma unroll
       for (int c = 0; c < 4; ++c) {
         const int k = k0 + 8 * g + 4 * h + c;
-        float x = 0.f;
-        if (ok && k < kend) { const long row = gather ? gather[k] : k; x = base[row * ld]; }
-        v[4 * g + c] = x;
+        v[4 * g + c] = (ok && k < kend) ? base[(long)(k0 + 8 * g + c) * ld + lane_off] : 0.f;
       }
   }
 };
@@ -108,66 +107,90 @@ __device__ __forceinline__ float fast_tanh(float x) {
   return 1.f - __fdividef(2.f, e + 1.f);
 }
 
-template <bool A_T, bool B_T, int EPI>
+// Direct variant for the k-contiguous-A products (forward NN, backward NT).
+template <bool B_T, int EPI>
 __global__ void __launch_bounds__(GEMM_THREADS) gemm_kernel(GemmBatch gb) {
   const int z = blockIdx.z;
-  const int pi = z / gb.ksplit, ks = z - pi * gb.ksplit;
-  const GemmProb p = gb.p[pi];
+  const GemmProb p = gb.p[z];
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int wr = wave >> 1, wc = wave & 1, l31 = lane & 31, hi = lane >> 5;
   const int m0 = blockIdx.y * BM + wr * 32, n0 = blockIdx.x * BN + wc * 32;  // this wave's 32 x 32 tile
   if (m0 >= p.M || n0 >= p.N) return;                                        // wave-uniform; no barriers below
-  int kper = (p.K + gb.ksplit - 1) / gb.ksplit;
-  kper = (kper + KS - 1) / KS * KS;
-  const int kb = ks * kper;
-  const int ke = p.K < kb + kper ? p.K : kb + kper;
-
+  const int K = p.K;
   OperandK ak, bk;
-  OperandR ar, br;
-  if (A_T) ar.init(p.A, p.lda, p.gather, m0 + l31, p.M, ke);
-  else ak.init(p.A, p.lda, p.gather, m0 + l31, p.M, hi);
+  OperandR br;
+  ak.init(p.A, p.lda, p.gather, m0 + l31, p.M, hi);
   if (B_T) bk.init(p.B, p.ldb, nullptr, n0 + l31, p.N, hi);
-  else br.init(p.B, p.ldb, nullptr, n0 + l31, p.N, ke);
-  auto load_set = [&](float (&a)[16], float (&b)[16], int k0) {
-    if (k0 + KS <= ke) {  // wave-uniform
-      if (A_T) ar.load(a, k0, hi); else ak.load(a, k0);
-      if (B_T) bk.load(b, k0); else br.load(b, k0, hi);
-    } else {
-      if (A_T) ar.load_tail(a, k0, hi); else ak.load_tail(a, k0, ke, hi);
-      if (B_T) bk.load_tail(b, k0, ke, hi); else br.load_tail(b, k0, hi);
+  else br.init(p.B, p.ldb, n0 + l31, p.N, K, hi);
+  // forward only: the waves of the first column tile also write their (gathered) A rows to a contiguous copy, so that
+  // the weight-gradient product later reads the minibatch without a gather (p.a_copy: [M, lda], same row stride)
+  float* acopy = (EPI == EPI_BIAS_ACT && p.a_copy && n0 == 0 && ak.ok) ? p.a_copy + (size_t)(m0 + l31) * p.lda + 4 * hi : nullptr;
+  auto copy_out = [&](const float (&v)[16], int k0) {
+    if (acopy) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) *reinterpret_cast<float4*>(acopy + k0 + 8 * g) = make_float4(v[4 * g], v[4 * g + 1], v[4 * g + 2], v[4 * g + 3]);
     }
   };
 
   f32x16 acc;
   for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-  float colsum = 0.f;  // EPI_STORE with bias_out: sum over k of B(k, n) (= bias gradient); waves of the first row tile only
-  const bool do_colsum = (EPI == EPI_STORE) && p.bias_out && m0 == 0;
-
+  const int nfull = K / KS, tail = K - nfull * KS;
   float a0[16], b0[16], a1[16], b1[16];
-  if (kb < ke) load_set(a0, b0, kb);
-  for (int k0 = kb; k0 < ke; k0 += 2 * KS) {
-    // --- set k0 from (a0,b0) while (a1,b1) load ---
-    const bool more1 = k0 + KS < ke;
-    if (more1) load_set(a1, b1, k0 + KS);
+  if (nfull > 0) {
+    ak.load(a0, 0);
+    if (B_T) bk.load(b0, 0); else br.load(b0, 0);
+    // steady state, copy-free ping-pong.  Invariant at the loop top: (a0,b0) hold set sidx-1, loaded but not yet consumed.
+    // Each half is one basic block: the loads of the next set are interleaved with the 16 MFMAs of the current one and
+    // have a whole further MFMA block (>= 1024 cycles) before their first use.
+    int sidx = 1;
+    for (; sidx + 1 < nfull; sidx += 2) {
+      ak.load(a1, sidx * KS);
+      if (B_T) bk.load(b1, sidx * KS); else br.load(b1, sidx * KS);
 #pragma unroll
-    for (int i = 0; i < 16; ++i) mfma_f32_32x32x2(a0[i], b0[i], acc);
-    if (do_colsum) {
+      for (int i = 0; i < 16; ++i) mfma_f32_32x32x2(a0[i], b0[i], acc);
+      if (B_T) { MPPO_INTERLEAVE_MFMA16(1, 1) } else { MPPO_INTERLEAVE_MFMA16(2, 2) }
+      copy_out(a0, (sidx - 1) * KS);
+      ak.load(a0, (sidx + 1) * KS);
+      if (B_T) bk.load(b0, (sidx + 1) * KS); else br.load(b0, (sidx + 1) * KS);
 #pragma unroll
-      for (int i = 0; i < 16; ++i) colsum += b0[i];
+      for (int i = 0; i < 16; ++i) mfma_f32_32x32x2(a1[i], b1[i], acc);
+      if (B_T) { MPPO_INTERLEAVE_MFMA16(1, 1) } else { MPPO_INTERLEAVE_MFMA16(2, 2) }
+      copy_out(a1, sidx * KS);
     }
-    if (!more1) break;
-    // --- set k0+KS from (a1,b1) while (a0,b0) load ---
-    const bool more0 = k0 + 2 * KS < ke;
-    if (more0) load_set(a0, b0, k0 + 2 * KS);
+    if (sidx < nfull) {  // one more set to fetch
+      ak.load(a1, sidx * KS);
+      if (B_T) bk.load(b1, sidx * KS); else br.load(b1, sidx * KS);
 #pragma unroll
-    for (int i = 0; i < 16; ++i) mfma_f32_32x32x2(a1[i], b1[i], acc);
-    if (do_colsum) {
+      for (int i = 0; i < 16; ++i) mfma_f32_32x32x2(a0[i], b0[i], acc);
+      if (B_T) { MPPO_INTERLEAVE_MFMA16(1, 1) } else { MPPO_INTERLEAVE_MFMA16(2, 2) }
+      copy_out(a0, (sidx - 1) * KS);
 #pragma unroll
-      for (int i = 0; i < 16; ++i) colsum += b1[i];
+      for (int i = 0; i < 16; ++i) mfma_f32_32x32x2(a1[i], b1[i], acc);
+      copy_out(a1, sidx * KS);
+    } else {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) mfma_f32_32x32x2(a0[i], b0[i], acc);
+      copy_out(a0, (sidx - 1) * KS);
+    }
+  }
+  if (tail > 0) {
+    ak.load_tail(a0, nfull * KS, K, hi);
+    if (B_T) bk.load_tail(b0, nfull * KS, K, hi); else br.load_tail(b0, nfull * KS, hi);
+    const int nm = (tail + 7) / 8 * 4;  // MFMAs that can carry data (groups of 8 k's)
+#pragma unroll
+    for (int i = 0; i < 16; ++i)
+      if (i < nm) mfma_f32_32x32x2(a0[i], b0[i], acc);
+    if (acopy) {  // tail columns (zeros past K keep the copy's padding clean up to the row stride)
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const int k = nfull * KS + 8 * g + 4 * hi + c;
+          if (k < p.lda) acopy[nfull * KS + 8 * g + c] = a0[4 * g + c];
+        }
     }
   }
 
-  float* C = p.C + (EPI == EPI_STORE ? (size_t)ks * gb.slab_stride : 0);
   const int col = n0 + l31;
   if (col < p.N) {
     float bias = 0.f;
@@ -185,14 +208,91 @@ __global__ void __launch_bounds__(GEMM_THREADS) gemm_kernel(GemmBatch gb) {
           if (p.act == ACT_TANH) v *= (1.f - hval * hval);
           else if (p.act == ACT_RELU) v = hval > 0.f ? v : 0.f;
         }
-        C[(size_t)row * p.ldc + col] = v;
+        p.C[(size_t)row * p.ldc + col] = v;
       }
+    }
+  }
+}
+
+// Direct variant of the weight-gradient product C[M,N] = A^T . B with A stored [K,M] and B stored [K,N] (K = samples,
+// no gather: the minibatch rows were laid out contiguously by the forward pass).  Both operands are "r-contiguous":
+// 16 coalesced dword loads per operand and k-set, uniform base + 32-bit lane offset.  Split-K over blockIdx.z.
+__global__ void __launch_bounds__(GEMM_THREADS) gemm_tn_kernel(GemmBatch gb) {
+  const int z = blockIdx.z;
+  const int pi = z / gb.ksplit, ks = z - pi * gb.ksplit;
+  const GemmProb p = gb.p[pi];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int wr = wave >> 1, wc = wave & 1, l31 = lane & 31, hi = lane >> 5;
+  const int m0 = blockIdx.y * BM + wr * 32, n0 = blockIdx.x * BN + wc * 32;
+  if (m0 >= p.M || n0 >= p.N) return;
+  int kper = (p.K + gb.ksplit - 1) / gb.ksplit;
+  kper = (kper + KS - 1) / KS * KS;
+  const int kb = ks * kper;
+  const int ke = p.K < kb + kper ? p.K : kb + kper;
+  OperandR ar, br;
+  ar.init(p.A, p.lda, m0 + l31, p.M, ke, hi);
+  br.init(p.B, p.ldb, n0 + l31, p.N, ke, hi);
+  f32x16 acc;
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  float colsum = 0.f;  // sum over k of B(k, n) = bias gradient; waves of the first row tile only
+  const bool do_colsum = p.bias_out && m0 == 0;
+  const int nfull = ke > kb ? (ke - kb) / KS : 0, tail = ke > kb ? (ke - kb) - nfull * KS : 0;
+  float a0[16], b0[16], a1[16], b1[16];
+  if (nfull > 0) {
+    ar.load(a0, kb); br.load(b0, kb);
+    int sidx = 1;
+    for (; sidx + 1 < nfull; sidx += 2) {
+      ar.load(a1, kb + sidx * KS); br.load(b1, kb + sidx * KS);
+#pragma unroll
+      for (int i = 0; i < 16; ++i) { mfma_f32_32x32x2(a0[i], b0[i], acc); colsum += b0[i]; }
+      MPPO_INTERLEAVE_MFMA16(3, 2)
+      ar.load(a0, kb + (sidx + 1) * KS); br.load(b0, kb + (sidx + 1) * KS);
+#pragma unroll
+      for (int i = 0; i < 16; ++i) { mfma_f32_32x32x2(a1[i], b1[i], acc); colsum += b1[i]; }
+      MPPO_INTERLEAVE_MFMA16(3, 2)
+    }
+    if (sidx < nfull) {
+      ar.load(a1, kb + sidx * KS); br.load(b1, kb + sidx * KS);
+#pragma unroll
+      for (int i = 0; i < 16; ++i) { mfma_f32_32x32x2(a0[i], b0[i], acc); colsum += b0[i]; }
+      MPPO_INTERLEAVE_MFMA16(3, 2)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) { mfma_f32_32x32x2(a1[i], b1[i], acc); colsum += b1[i]; }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) { mfma_f32_32x32x2(a0[i], b0[i], acc); colsum += b0[i]; }
+    }
+  }
+  if (tail > 0) {
+    ar.load_tail(a0, kb + nfull * KS, hi); br.load_tail(b0, kb + nfull * KS, hi);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { mfma_f32_32x32x2(a0[i], b0[i], acc); colsum += b0[i]; }
+  }
+  float* C = p.C + (size_t)ks * gb.slab_stride;
+  const int col = n0 + l31;
+  if (col < p.N) {
+    for (int r = 0; r < 16; ++r) {
+      const int row = m0 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+      if (row < p.M) C[(size_t)row * p.ldc + col] = acc[r];
     }
   }
   if (do_colsum) {
     colsum += __shfl_xor(colsum, 32);  // the two lane halves hold the two k-halves of every group
     if (hi == 0 && col < p.N) p.bias_out[(size_t)ks * gb.slab_stride + col] = colsum;
   }
+}
+
+template <bool B_T, int EPI>
+static int32_t launch_t(const GemmBatch& gb, hipStream_t stream) {
+  int maxM = 0, maxN = 0;
+  for (int i = 0; i < gb.count; ++i) {
+    maxM = gb.p[i].M > maxM ? gb.p[i].M : maxM;
+    maxN = gb.p[i].N > maxN ? gb.p[i].N : maxN;
+  }
+  dim3 grid(cdiv(maxN, BN), cdiv(maxM, BM), gb.count);
+  hipLaunchKernelGGL((gemm_kernel<B_T, EPI>), grid, dim3(GEMM_THREADS), 0, stream, gb);
+  MPPO_CHECK_LAUNCH("gemm_kernel");
+  return MPPO_OK;
 }
 
 template <bool A_T, bool B_T, int EPI>
@@ -220,9 +320,23 @@ int32_t gemm_launch(const GemmBatch& gb, int a_t, int b_t, int epi, int bf16, hi
     MPPO_REQUIRE(!p.bias_out || epi == EPI_STORE, "gemm_launch: bias_out only with EPI_STORE");
   }
   const int v = a_t * 2 + b_t;
-  if (epi == EPI_BIAS_ACT && v == 0) return launch_t<false, false, EPI_BIAS_ACT>(gb, stream);
-  if (epi == EPI_DACT && v == 1) return launch_t<false, true, EPI_DACT>(gb, stream);
-  if (epi == EPI_STORE && v == 2) return launch_t<true, false, EPI_STORE>(gb, stream);
+  // implementation per variant: direct-to-register everywhere (gathered weight-gradient operands fall back to LDS).
+  // MPPO_GEMM_IMPL = "ddd" / "lll" / ... overrides per variant (d = direct, l = LDS) for A/B measurements.
+  static const char* impl = getenv("MPPO_GEMM_IMPL");
+  const char choice = (impl && (int)strlen(impl) > v) ? impl[v] : 'd';
+  if (choice == 'l') return gemm_launch_lds(gb, a_t, b_t, epi, stream);
+  if (epi == EPI_BIAS_ACT && v == 0) return launch_t<false, EPI_BIAS_ACT>(gb, stream);
+  if (epi == EPI_DACT && v == 1) return launch_t<true, EPI_DACT>(gb, stream);
+  if (epi == EPI_STORE && v == 2) {
+    bool gathered = false;
+    for (int i = 0; i < gb.count; ++i) gathered = gathered || gb.p[i].gather;
+    if (gathered) return gemm_launch_lds(gb, a_t, b_t, epi, stream);  // sample rows by index: LDS-staged kernel
+    int maxM = 0, maxN = 0;
+    for (int i = 0; i < gb.count; ++i) { maxM = gb.p[i].M > maxM ? gb.p[i].M : maxM; maxN = gb.p[i].N > maxN ? gb.p[i].N : maxN; }
+    hipLaunchKernelGGL(gemm_tn_kernel, dim3(cdiv(maxN, BN), cdiv(maxM, BM), gb.count * gb.ksplit), dim3(GEMM_THREADS), 0, stream, gb);
+    MPPO_CHECK_LAUNCH("gemm_tn_kernel");
+    return MPPO_OK;
+  }
   return fail(MPPO_EINVAL, "gemm_launch: variant a_t=%d b_t=%d epi=%d is not instantiated", a_t, b_t, epi);
 }
 

@@ -192,7 +192,7 @@ static size_t head_smem_bytes(int LR, int H, int A) { const int RT = 256 / LR; r
 
 int32_t head_launch(const HeadArgs& a, bool loss, hipStream_t stream) {
   MPPO_REQUIRE(a.A + 1 <= 32 && (a.H % 4) == 0, "head kernel: A = %d must be <= 31 and H %% 4 == 0", a.A);
-  const int LR = a.A + 1 <= 16 ? 16 : 32;
+  const int LR = 32;  // 8 rows per workgroup: 160 workgroups at mb = 1280
   const int RT = 256 / LR;
   const size_t smem = head_smem_bytes(LR, a.H, a.A);
   MPPO_REQUIRE(smem <= 64 * 1024, "head kernel: %zu bytes of LDS needed (H = %d too large)", smem, a.H);
@@ -229,25 +229,33 @@ __global__ void __launch_bounds__(256) grad_reduce_kernel(size_t P, int ksplit, 
     sq += s * s;
   }
   if (blockIdx.x == gridDim.x - 1) {
-    // the small sums over the head kernel's per-workgroup partials: every wave computes them (lanes stride over the
-    // nblk partial rows, fixed reduction tree), wave 0 stores.  Columns: 0 actor loss, 1 value loss, 4+a d log_std[a].
-    const int ln = threadIdx.x & 63, wv = threadIdx.x >> 6, W = 4 + AP;
-    float la = 0.f, lv = 0.f;
-    for (int k = ln; k < nblk; k += 64) { la += partial[(size_t)k * W]; lv += partial[(size_t)k * W + 1]; }
-    la = wave_sum(la); lv = wave_sum(lv);
-    float sl = 0.f;
-    for (int a = 0; a < A; ++a) {
-      float d = 0.f;
-      for (int k = ln; k < nblk; k += 64) d += partial[(size_t)k * W + 4 + a];
-      d = wave_sum(d) - ent_coef * ent_weight;
-      sl += log_std[a];
-      if (wv == 0 && ln == 0) { grad[ls_off + a] = d; sq += d * d; }
+    // the small sums over the head kernel's per-workgroup partials [nblk][4+AP]: thread c < 4+AP adds column c (independent
+    // loads, fixed order).  Columns: 0 actor loss, 1 value loss, 4+a d log_std[a].
+    __shared__ float s_col[40];
+    const int W = 4 + AP;
+    if (threadIdx.x < W) {
+      float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+      int k = 0;
+      for (; k + 3 < nblk; k += 4) {
+        s0 += partial[(size_t)k * W + threadIdx.x]; s1 += partial[(size_t)(k + 1) * W + threadIdx.x];
+        s2 += partial[(size_t)(k + 2) * W + threadIdx.x]; s3 += partial[(size_t)(k + 3) * W + threadIdx.x];
+      }
+      for (; k < nblk; ++k) s0 += partial[(size_t)k * W + threadIdx.x];
+      s_col[threadIdx.x] = (s0 + s1) + (s2 + s3);
     }
-    if (wv == 0 && ln == 0 && loss4) {
+    __syncthreads();
+    if (threadIdx.x < A) {
+      const float d = s_col[4 + threadIdx.x] - ent_coef * ent_weight;
+      grad[ls_off + threadIdx.x] = d;
+      sq += d * d;
+    }
+    if (threadIdx.x == 0 && loss4) {
+      float sl = 0.f;
+      for (int a = 0; a < A; ++a) sl += log_std[a];
       const float ent = (0.5f * (float)A * (1.f + kLog2Pi) + sl) * ent_weight;
-      loss4[0] = la + vf_coef * lv - ent_coef * ent;
-      loss4[1] = lv;
-      loss4[2] = la;
+      loss4[0] = s_col[2 - 2] + vf_coef * s_col[1] - ent_coef * ent;
+      loss4[1] = s_col[1];
+      loss4[2] = s_col[0];
       loss4[3] = ent;
     }
   }
@@ -390,13 +398,14 @@ static GemmProb fwd_prob(const float* A, int lda, const int* gather, int M, int 
 
 // hidden layers of actor + critic on n rows of `obs` (optionally gathered): h1, h2 of both networks into the FwdBufs
 int32_t mlp_hidden_forward(const mppo_net_t& net, const float* params, int n, const float* obs, int obs_ld, const int* gather, const FwdBufs& fb,
-                           hipStream_t stream) {
+                           float* xcopy, hipStream_t stream) {
   const ParamLayout L = param_layout(net.O, net.A, net.H);
   const int H = net.H, act_a = net.use_tanh ? ACT_TANH : ACT_RELU;
   GemmBatch gb{};
   gb.count = 2; gb.ksplit = 1;
   gb.p[0] = fwd_prob(obs, obs_ld, gather, n, net.O, params + L.a_w1, H, params + L.a_b1, act_a, fb.h1a, H);
   gb.p[1] = fwd_prob(obs, obs_ld, gather, n, net.O, params + L.c_w1, H, params + L.c_b1, ACT_RELU, fb.h1c, H);
+  gb.p[0].a_copy = xcopy;  // (row stride obs_ld; only the actor problem writes it)
   MPPO_TRY(gemm_launch(gb, 0, 0, EPI_BIAS_ACT, net.bf16, stream));
   gb.p[0] = fwd_prob(fb.h1a, H, nullptr, n, H, params + L.a_w2, H, params + L.a_b2, act_a, fb.h2a, H);
   gb.p[1] = fwd_prob(fb.h1c, H, nullptr, n, H, params + L.c_w2, H, params + L.c_b2, ACT_RELU, fb.h2c, H);
@@ -416,7 +425,7 @@ static HeadArgs head_args(const mppo_net_t& net, const float* params, int n, con
 // full policy step on n rows: hidden layers, heads, sample + log-prob (noise may be null: value only)
 int32_t policy_forward(const mppo_net_t& net, const float* params, int n, const float* obs, int obs_ld, const FwdBufs& fb, const float* noise, float* action,
                        float* log_prob, float* value, float* mean_out, hipStream_t stream) {
-  MPPO_TRY(mlp_hidden_forward(net, params, n, obs, obs_ld, nullptr, fb, stream));
+  MPPO_TRY(mlp_hidden_forward(net, params, n, obs, obs_ld, nullptr, fb, nullptr, stream));
   HeadArgs a = head_args(net, params, n, fb);
   a.noise = noise; a.action = action; a.log_prob = log_prob; a.value = value; a.mean_out = mean_out;
   if (!noise) {  // value-only call (bootstrap, train.py:182): sample outputs go to the scratch `mean` buffer and are ignored
@@ -430,14 +439,14 @@ int32_t minibatch_grad(const mppo_net_t& net, const float* params, const mppo_ba
   const ParamLayout L = param_layout(net.O, net.A, net.H);
   const int H = net.H, A = net.A, AP = gbuf.f.AP, DP = AP + 4, O = net.O;
   const int act_a = net.use_tanh ? ACT_TANH : ACT_RELU;
-  MPPO_TRY(mlp_hidden_forward(net, params, mb, batch.obs, batch.obs_ld, idx, gbuf.f, stream));
+  MPPO_REQUIRE(batch.obs_ld == net.OP, "minibatch_grad: obs_ld (%d) must equal the padded observation width OP (%d)", batch.obs_ld, net.OP);
+  MPPO_TRY(mlp_hidden_forward(net, params, mb, batch.obs, batch.obs_ld, idx, gbuf.f, gbuf.xmb, stream));
   // heads + loss + dZ2 (one launch)
   HeadArgs ha = head_args(net, params, mb, gbuf.f);
   ha.idx = idx; ha.b = batch; ha.adv_stat = adv_stat; ha.inv_count = inv_count; ha.lc = lc;
   ha.dout = gbuf.dout; ha.dz2a = gbuf.dz2a; ha.dz2c = gbuf.dz2c; ha.partial = gbuf.partial;
   MPPO_TRY(head_launch(ha, true, stream));
-  const int LR = A + 1 <= 16 ? 16 : 32;
-  const int nblk = cdiv(mb, 256 / LR);
+  const int nblk = cdiv(mb, 8);  // head kernel: 8 rows per workgroup
   GemmBatch gb{};
   gb.count = 2; gb.ksplit = 1;
   // dZ1 = (dZ2 . W2^T) * act'(h1)
@@ -459,10 +468,10 @@ int32_t minibatch_grad(const mppo_net_t& net, const float* params, const mppo_ba
   };
   gb.p[0] = wprob(gbuf.f.h2a, H, nullptr, H, gbuf.dout, DP, A, L.a_w3, L.a_b3);
   gb.p[1] = wprob(gbuf.f.h1a, H, nullptr, H, gbuf.dz2a, H, H, L.a_w2, L.a_b2);
-  gb.p[2] = wprob(batch.obs, batch.obs_ld, idx, O, gbuf.dz1a, H, H, L.a_w1, L.a_b1);
+  gb.p[2] = wprob(gbuf.xmb, net.OP, nullptr, O, gbuf.dz1a, H, H, L.a_w1, L.a_b1);
   gb.p[3] = wprob(gbuf.f.h2c, H, nullptr, H, gbuf.dout + AP, DP, 1, L.c_w3, L.c_b3);
   gb.p[4] = wprob(gbuf.f.h1c, H, nullptr, H, gbuf.dz2c, H, H, L.c_w2, L.c_b2);
-  gb.p[5] = wprob(batch.obs, batch.obs_ld, idx, O, gbuf.dz1c, H, H, L.c_w1, L.c_b1);
+  gb.p[5] = wprob(gbuf.xmb, net.OP, nullptr, O, gbuf.dz1c, H, H, L.c_w1, L.c_b1);
   MPPO_TRY(gemm_launch(gb, 1, 0, EPI_STORE, net.bf16, stream));
   const float ent_weight = (float)mb * inv_count;
   hipLaunchKernelGGL(grad_reduce_kernel, dim3(kNormBlocks), dim3(256), 0, stream, (size_t)L.total, gbuf.ksplit, gbuf.slab_stride, gbuf.slabs, L.log_std, A, AP, nblk,

@@ -50,6 +50,7 @@ constexpr int kGradKSplit = 3;  // 72 weight-gradient tiles x 3 K-slices = 216 w
 struct GradBufs {
   FwdBufs f;
   float *dout, *dz2a, *dz2c, *dz1a, *dz1c, *partial, *slabs;  // dout [mb, AP+4]: d mean | d value
+  float* xmb;  // [mb, OP]: the minibatch observations, laid out contiguously by the first forward GEMM
   int ksplit;
   size_t slab_stride;
 };
@@ -57,7 +58,7 @@ inline size_t grad_bufs_floats(const mppo_net_t& net, int mb) {
   const size_t AP = pad4((size_t)net.A), nh = pad4((size_t)mb * net.H);
   const size_t P = pad4((size_t)param_layout(net.O, net.A, net.H).total);
   const size_t nblk = (size_t)(mb + 7) / 8;  // head kernel: 8 or 16 rows per workgroup
-  return fwd_bufs_floats(net, mb) + pad4((size_t)mb * (AP + 4)) + 4 * nh + pad4(nblk * (4 + AP)) + (size_t)kGradKSplit * P;
+  return fwd_bufs_floats(net, mb) + pad4((size_t)mb * (AP + 4)) + 4 * nh + pad4(nblk * (4 + AP)) + (size_t)kGradKSplit * P + pad4((size_t)mb * net.OP);
 }
 inline GradBufs carve_grad(const mppo_net_t& net, int mb, float* ws) {
   GradBufs g;
@@ -69,6 +70,7 @@ inline GradBufs carve_grad(const mppo_net_t& net, int mb, float* ws) {
   const size_t nblk = (size_t)(mb + 7) / 8;
   g.partial = ws; ws += pad4(nblk * (4 + AP));
   g.slabs = ws;
+  g.xmb = ws + (size_t)kGradKSplit * pad4((size_t)param_layout(net.O, net.A, net.H).total);
   g.ksplit = kGradKSplit;
   g.slab_stride = pad4((size_t)param_layout(net.O, net.A, net.H).total);
   return g;

@@ -112,3 +112,5 @@ inline float __shfl_xor(float x, int mask) {
   __syncthreads();
   return r;
 }
+
+#define MPPO_INTERLEAVE_MFMA16(NVALU, NVMEM)
