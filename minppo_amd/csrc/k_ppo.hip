@@ -4,6 +4,7 @@
 #include <wave_ops.h>
 
 #include <cmath>
+#include <cstdlib>
 
 #include "gemm.h"
 #include "mppo_common.h"
@@ -211,37 +212,52 @@ int32_t head_launch(const HeadArgs& a, bool loss, hipStream_t stream) {
 // ------------------------------------------------------------------------------------------------
 // grad = sum of split-K slabs (+ log_std gradient from the loss partials); loss4 from the partials.
 // ------------------------------------------------------------------------------------------------
-constexpr int kNormBlocks = 128;
+constexpr int kNormBlocks = 256;
 
-// kNormBlocks workgroups, grid-stride over P; also leaves the per-workgroup sum of squares of the reduced gradient in
-// `sq_partial` (used by the clip when no all-reduce sits between this kernel and Adam).
+// grad = sum of the split-K slabs (one float4 per slab per thread, every load in flight at once), the log_std gradient
+// and loss4 from the head kernel's per-workgroup partials, and the per-workgroup sums of squares of the result in
+// `sq_partial[kNormBlocks]` (consumed by the clip when no all-reduce sits between this kernel and Adam).
+// Launched with exactly kNormBlocks workgroups of 256 threads; requires P <= kNormBlocks * 256 * 4 * kReduceIter.
+constexpr int kReduceIter = 4;
 __global__ void __launch_bounds__(256) grad_reduce_kernel(size_t P, int ksplit, size_t slab_stride, const float* __restrict__ slabs, int ls_off, int A,
                                                           int AP, int nblk, const float* __restrict__ partial, const float* __restrict__ log_std,
                                                           float ent_coef, float vf_coef, float ent_weight, float* __restrict__ grad,
                                                           float* __restrict__ loss4, float* __restrict__ sq_partial) {
   __shared__ float red[4];
+  __shared__ float s_part[16][40];
   float sq = 0.f;
-  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < P; i += (size_t)gridDim.x * blockDim.x) {
-    if (i >= (size_t)ls_off && i < (size_t)ls_off + A) continue;  // log_std: from the loss partials, below
-    float s = 0.f;
-    for (int k = 0; k < ksplit; ++k) s += slabs[(size_t)k * slab_stride + i];
-    grad[i] = s;
-    sq += s * s;
-  }
-  if (blockIdx.x == gridDim.x - 1) {
-    // the small sums over the head kernel's per-workgroup partials [nblk][4+AP]: thread c < 4+AP adds column c (independent
-    // loads, fixed order).  Columns: 0 actor loss, 1 value loss, 4+a d log_std[a].
-    __shared__ float s_col[40];
-    const int W = 4 + AP;
-    if (threadIdx.x < W) {
-      float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-      int k = 0;
-      for (; k + 3 < nblk; k += 4) {
-        s0 += partial[(size_t)k * W + threadIdx.x]; s1 += partial[(size_t)(k + 1) * W + threadIdx.x];
-        s2 += partial[(size_t)(k + 2) * W + threadIdx.x]; s3 += partial[(size_t)(k + 3) * W + threadIdx.x];
+#pragma unroll
+  for (int it = 0; it < kReduceIter; ++it) {
+    const size_t i = ((size_t)(it * kNormBlocks + blockIdx.x) * 256 + threadIdx.x) * 4;
+    if (i >= P) continue;
+    float v[4] = {0.f, 0.f, 0.f, 0.f};
+    if (i + 3 < P) {
+      for (int k = 0; k < ksplit; ++k) {
+        const float4 q = *reinterpret_cast<const float4*>(slabs + (size_t)k * slab_stride + i);
+        v[0] += q.x; v[1] += q.y; v[2] += q.z; v[3] += q.w;
       }
-      for (; k < nblk; ++k) s0 += partial[(size_t)k * W + threadIdx.x];
-      s_col[threadIdx.x] = (s0 + s1) + (s2 + s3);
+    } else {
+      for (int c = 0; c < 4; ++c) if (i + c < P) for (int k = 0; k < ksplit; ++k) v[c] += slabs[(size_t)k * slab_stride + i + c];
+    }
+    for (int c = 0; c < 4; ++c) {
+      const size_t e = i + c;
+      if (e < P && !(e >= (size_t)ls_off && e < (size_t)ls_off + A)) { grad[e] = v[c]; sq += v[c] * v[c]; }  // log_std: below
+    }
+  }
+  if (blockIdx.x == kNormBlocks - 1) {
+    // column sums of partial[nblk][4+AP] in two levels: thread (g = t/16 .. , c = t%16 ..) adds rows g, g+16, ... of column c
+    const int W = 4 + AP;
+    for (int c = threadIdx.x & 15; c < W; c += 16) {
+      float s0 = 0.f;
+      for (int k = threadIdx.x >> 4; k < nblk; k += 16) s0 += partial[(size_t)k * W + c];
+      s_part[threadIdx.x >> 4][c] = s0;
+    }
+    __syncthreads();
+    __shared__ float s_col[40];
+    if (threadIdx.x < W) {
+      float s0 = 0.f;
+      for (int gq = 0; gq < 16; ++gq) s0 += s_part[gq][threadIdx.x];
+      s_col[threadIdx.x] = s0;
     }
     __syncthreads();
     if (threadIdx.x < A) {
@@ -253,7 +269,7 @@ __global__ void __launch_bounds__(256) grad_reduce_kernel(size_t P, int ksplit, 
       float sl = 0.f;
       for (int a = 0; a < A; ++a) sl += log_std[a];
       const float ent = (0.5f * (float)A * (1.f + kLog2Pi) + sl) * ent_weight;
-      loss4[0] = s_col[2 - 2] + vf_coef * s_col[1] - ent_coef * ent;
+      loss4[0] = s_col[0] + vf_coef * s_col[1] - ent_coef * ent;
       loss4[1] = s_col[1];
       loss4[2] = s_col[0];
       loss4[3] = ent;
@@ -314,10 +330,10 @@ __global__ void __launch_bounds__(256) sumsq_kernel(size_t P, const float* __res
 __global__ void __launch_bounds__(256) adam_kernel(size_t P, float* __restrict__ p, float* __restrict__ m, float* __restrict__ v,
                                                    const float* __restrict__ g, const float* __restrict__ partial, const int* __restrict__ count_base,
                                                    int step_offset, mppo_adam_cfg_t c) {
-  // every wave adds the same kNormBlocks (= 128) partials in the same order (two per lane, fixed reduction tree):
+  // every wave adds the same kNormBlocks (= 256) partials in the same order (four per lane, fixed reduction tree):
   // bitwise-identical clip scale everywhere without a second pass
   const int ln = threadIdx.x & 63;
-  const float ss = wave_sum(partial[ln] + partial[ln + 64]);
+  const float ss = wave_sum((partial[ln] + partial[ln + 64]) + (partial[ln + 128] + partial[ln + 192]));
   const float norm = sqrtf(ss);
   const float scale = norm < c.max_grad_norm ? 1.f : c.max_grad_norm / norm;
   const int count = count_base[0] + step_offset;
@@ -440,23 +456,32 @@ int32_t minibatch_grad(const mppo_net_t& net, const float* params, const mppo_ba
   const int H = net.H, A = net.A, AP = gbuf.f.AP, DP = AP + 4, O = net.O;
   const int act_a = net.use_tanh ? ACT_TANH : ACT_RELU;
   MPPO_REQUIRE(batch.obs_ld == net.OP, "minibatch_grad: obs_ld (%d) must equal the padded observation width OP (%d)", batch.obs_ld, net.OP);
-  MPPO_TRY(mlp_hidden_forward(net, params, mb, batch.obs, batch.obs_ld, idx, gbuf.f, gbuf.xmb, stream));
-  // heads + loss + dZ2 (one launch)
-  HeadArgs ha = head_args(net, params, mb, gbuf.f);
-  ha.idx = idx; ha.b = batch; ha.adv_stat = adv_stat; ha.inv_count = inv_count; ha.lc = lc;
-  ha.dout = gbuf.dout; ha.dz2a = gbuf.dz2a; ha.dz2c = gbuf.dz2c; ha.partial = gbuf.partial;
-  MPPO_TRY(head_launch(ha, true, stream));
-  const int nblk = cdiv(mb, 8);  // head kernel: 8 rows per workgroup
+  static const char* nofuse = getenv("MPPO_NO_FUSED");  // A/B switch for measurements
+  const bool fused = fused_supported(net, batch) && !(nofuse && nofuse[0] == '1');
+  int nblk;
   GemmBatch gb{};
-  gb.count = 2; gb.ksplit = 1;
-  // dZ1 = (dZ2 . W2^T) * act'(h1)
-  {
-    GemmProb& a = gb.p[0]; a = GemmProb{};
-    a.A = gbuf.dz2a; a.lda = H; a.M = mb; a.K = H; a.B = params + L.a_w2; a.ldb = H; a.N = H; a.aux = gbuf.f.h1a; a.ldaux = H; a.act = act_a; a.C = gbuf.dz1a; a.ldc = H;
-    GemmProb& c = gb.p[1]; c = GemmProb{};
-    c.A = gbuf.dz2c; c.lda = H; c.M = mb; c.K = H; c.B = params + L.c_w2; c.ldb = H; c.N = H; c.aux = gbuf.f.h1c; c.ldaux = H; c.act = ACT_RELU; c.C = gbuf.dz1c; c.ldc = H;
+  if (fused) {
+    // hidden layers, heads, loss terms, dZ2 and dZ1 in one launch (k_fused.hip)
+    MPPO_TRY(fused_forward_backward(net, params, batch, idx, mb, adv_stat, inv_count, lc, gbuf, stream));
+    nblk = cdiv(mb, 16);
+  } else {
+    MPPO_TRY(mlp_hidden_forward(net, params, mb, batch.obs, batch.obs_ld, idx, gbuf.f, gbuf.xmb, stream));
+    // heads + loss + dZ2 (one launch)
+    HeadArgs ha = head_args(net, params, mb, gbuf.f);
+    ha.idx = idx; ha.b = batch; ha.adv_stat = adv_stat; ha.inv_count = inv_count; ha.lc = lc;
+    ha.dout = gbuf.dout; ha.dz2a = gbuf.dz2a; ha.dz2c = gbuf.dz2c; ha.partial = gbuf.partial;
+    MPPO_TRY(head_launch(ha, true, stream));
+    nblk = cdiv(mb, 8);  // head kernel: 8 rows per workgroup
+    gb.count = 2; gb.ksplit = 1;
+    // dZ1 = (dZ2 . W2^T) * act'(h1)
+    {
+      GemmProb& a = gb.p[0]; a = GemmProb{};
+      a.A = gbuf.dz2a; a.lda = H; a.M = mb; a.K = H; a.B = params + L.a_w2; a.ldb = H; a.N = H; a.aux = gbuf.f.h1a; a.ldaux = H; a.act = act_a; a.C = gbuf.dz1a; a.ldc = H;
+      GemmProb& c = gb.p[1]; c = GemmProb{};
+      c.A = gbuf.dz2c; c.lda = H; c.M = mb; c.K = H; c.B = params + L.c_w2; c.ldb = H; c.N = H; c.aux = gbuf.f.h1c; c.ldaux = H; c.act = ACT_RELU; c.C = gbuf.dz1c; c.ldc = H;
+    }
+    MPPO_TRY(gemm_launch(gb, 0, 1, EPI_DACT, net.bf16, stream));
   }
-  MPPO_TRY(gemm_launch(gb, 0, 1, EPI_DACT, net.bf16, stream));
   // weight gradients dW = H_prev^T . dZ into split-K slabs; the bias gradients (column sums of dZ) ride along.
   // dOut is [mb, DP] with d mean in columns [0,A) and d value in column AP: every operand is 16-byte aligned -> fast path.
   gb.count = 6; gb.ksplit = gbuf.ksplit; gb.slab_stride = gbuf.slab_stride;
@@ -474,6 +499,7 @@ int32_t minibatch_grad(const mppo_net_t& net, const float* params, const mppo_ba
   gb.p[5] = wprob(gbuf.xmb, net.OP, nullptr, O, gbuf.dz1c, H, H, L.c_w1, L.c_b1);
   MPPO_TRY(gemm_launch(gb, 1, 0, EPI_STORE, net.bf16, stream));
   const float ent_weight = (float)mb * inv_count;
+  MPPO_REQUIRE((size_t)L.total <= (size_t)kNormBlocks * 256 * 4 * kReduceIter, "minibatch_grad: %d parameters exceed the reduce kernel's range", L.total);
   hipLaunchKernelGGL(grad_reduce_kernel, dim3(kNormBlocks), dim3(256), 0, stream, (size_t)L.total, gbuf.ksplit, gbuf.slab_stride, gbuf.slabs, L.log_std, A, AP, nblk,
                      gbuf.partial, params + L.log_std, lc.ent_coef, lc.vf_coef, ent_weight, grad, loss4, sq_partial);
   MPPO_CHECK_LAUNCH("grad_reduce_kernel");

@@ -57,7 +57,7 @@ struct GradBufs {
 inline size_t grad_bufs_floats(const mppo_net_t& net, int mb) {
   const size_t AP = pad4((size_t)net.A), nh = pad4((size_t)mb * net.H);
   const size_t P = pad4((size_t)param_layout(net.O, net.A, net.H).total);
-  const size_t nblk = (size_t)(mb + 7) / 8;  // head kernel: 8 or 16 rows per workgroup
+  const size_t nblk = (size_t)(mb + 7) / 8;  // head kernel: 8 rows per workgroup (fused kernel: 16)
   return fwd_bufs_floats(net, mb) + pad4((size_t)mb * (AP + 4)) + 4 * nh + pad4(nblk * (4 + AP)) + (size_t)kGradKSplit * P + pad4((size_t)mb * net.OP);
 }
 inline GradBufs carve_grad(const mppo_net_t& net, int mb, float* ws) {
@@ -86,6 +86,10 @@ int32_t clip_adam(size_t P, float* params, float* m, float* v, const float* grad
                   bool have_sumsq, hipStream_t stream);
 int32_t gae_launch(int T, int N, float gamma, float lam, const float* reward, const float* value, const unsigned char* done, const float* last_val, float* adv,
                    float* target, hipStream_t stream);
+// k_fused.hip: row-local forward + backward of one minibatch in a single launch (falls back to the layer-wise path when unsupported)
+bool fused_supported(const mppo_net_t& net, const mppo_batch_t& b);
+int32_t fused_forward_backward(const mppo_net_t& net, const float* params, const mppo_batch_t& batch, const int* idx, int mb, const float* adv_stat,
+                               float inv_count, const mppo_loss_cfg_t& lc, const GradBufs& g, hipStream_t stream);
 int32_t perm_fill_keys(unsigned long long seed, unsigned long long stream_id, const int* ctr, int B, unsigned* keys, int* vals, hipStream_t stream);
 int32_t normal_fill_ctr(unsigned long long seed, unsigned long long stream_id, const int* ctr, size_t n, float* out, hipStream_t stream);
 int32_t permutation_ctr(unsigned long long seed, unsigned long long stream_id, const int* ctr, int B, int* idx, void* ws, size_t ws_bytes, hipStream_t stream);

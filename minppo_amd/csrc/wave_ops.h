@@ -73,3 +73,9 @@ __device__ __forceinline__ double wave_sum_f64(double x) {
     __builtin_amdgcn_sched_group_barrier(0x002, NVALU, 0);        \
     __builtin_amdgcn_sched_group_barrier(0x020, NVMEM, 0);        \
   }
+
+// D(16x16) += A(16x4) * B(4x16), exact f32 (v_mfma_f32_16x16x4_f32, 32 cycles).
+// lane l supplies A[i = l&15][k = l>>4] and B[k = l>>4][j = l&15]; acc[r] is D[row = 4*(l>>4) + r][col = l&15].
+__device__ __forceinline__ void mfma_f32_16x16x4(float a, float b, f32x4& acc) {
+  acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc, 0, 0, 0);
+}

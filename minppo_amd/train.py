@@ -362,7 +362,7 @@ class Trainer:
                 if W > 1:
                     self._sync()
                     allreduce_sum(reg["grad"])
-                lib.clip_adam(self.P, p["params"], p["adam_m"], p["adam_v"], p["grad"], p["count"], st, C.byref(ac), p["adam_ws"], 512, s)
+                lib.clip_adam(self.P, p["params"], p["adam_m"], p["adam_v"], p["grad"], p["count"], st, C.byref(ac), p["adam_ws"], 1024, s)
         self._sync()
         cnt = self.region("count")
         cnt[0] += E * M

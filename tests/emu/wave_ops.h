@@ -114,3 +114,20 @@ inline float __shfl_xor(float x, int mask) {
 }
 
 #define MPPO_INTERLEAVE_MFMA16(NVALU, NVMEM)
+
+// lane l supplies A[i = l&15][k = l>>4], B[k = l>>4][j = l&15]; acc[r] = D[4*(l>>4) + r][l&15]
+inline void mfma_f32_16x16x4(float a, float b, f32x4& acc) {
+  const int t = emu::tid(), lane = t & 63, wave = t >> 6;
+  float* A = reinterpret_cast<float*>(emu::g_xchg) + wave * 128;
+  float* B = A + 64;
+  A[lane] = a; B[lane] = b;
+  __syncthreads();
+  const int col = lane & 15, q = lane >> 4;
+  for (int r = 0; r < 4; ++r) {
+    const int row = 4 * q + r;
+    float c = acc[r];
+    for (int k = 0; k < 4; ++k) c = fmaf(A[16 * k + row], B[16 * k + col], c);
+    acc[r] = c;
+  }
+  __syncthreads();
+}
