@@ -11,6 +11,8 @@
 // Outputs to HBM/L2: h1, h2, dZ2, dZ1 (operands of the weight-gradient GEMM), dOut, the gathered rows (xmb), loss partials.
 #include <wave_ops.h>
 
+#include <cstdlib>
+
 #include "mppo_common.h"
 #include "ppo_layout.h"
 
@@ -35,45 +37,88 @@ struct FusedArgs {
   mppo_loss_cfg_t lc;
   float *h1[2], *h2[2], *dz2[2], *dz1[2];
   float *dout, *xmb, *partial;
+  int skip;  // timing experiments only (MPPO_FUSED_SKIP bit mask): 1 L1, 2 L2, 4 heads, 8 dZ2, 16 dZ1, 32 activation stores, 64 gather
 };
 
-// one 16-row x 32-col slab of  act(A_tile . W + bias)  (A_tile in LDS, row stride AS; W [K,H] in global memory)
-//   NT = false: W stored [K][H] (forward);  NT = true: W stored [H][K], i.e. B(k,n) = W[n*K + k] (backward dZ1)
+// One 16-row x 32-column slab of A_tile . op(W) on the 16x16x4 f32 MFMA (A_tile in LDS with row stride AS, K a multiple
+// of 32, zero beyond Kvalid).  The wave's 32 columns are two INTERLEAVED 16-column tiles: tile tau holds columns
+// n0 + 2j + tau (j = lane&15), so that one float2 load feeds both tiles.
+//   NT = false: W stored [K][H] (forward):   lane (j, kq) loads W[k][n0+2j .. +1] for its 8 k's of the stage
+//   NT = true : W stored [H][K] (backward):  B(k,n) = W[n*K + k], lane loads float4 W[n][k..k+3] for both of its columns
+// Stage = 32 k = 16 MFMAs; stage S+1's B fragment is fetched while stage S computes (copy-free ping-pong), so with two
+// waves per SIMD a load has about 1000 cycles before its first use.  k inside a stage: 32S + 16g + 4kq + c.
 template <bool NT>
-__device__ __forceinline__ void tile_gemm(const float* At, int AS, int K, int Kvalid, const float* W, int H, int n0, int lane, f32x4& acc0, f32x4& acc1) {
-  const int i = lane & 15, kq = lane >> 4;
-  const float* arow = At + i * AS + 4 * kq;
-  const int ngroups = (K + 15) / 16;
-  float bw0[4], bw1[4], nb0[4], nb1[4];
-  auto loadB = [&](int G, float (&x0)[4], float (&x1)[4]) {
+struct BStage {
+  float x0[8], x1[8];
+  __device__ __forceinline__ void load(const float* W, int H, int K, int S, int n0, int j, int kq, int Kvalid) {
     if (NT) {
-      const float4 q0 = *reinterpret_cast<const float4*>(W + (size_t)(n0 + i) * K + 16 * G + 4 * kq);
-      const float4 q1 = *reinterpret_cast<const float4*>(W + (size_t)(n0 + 16 + i) * K + 16 * G + 4 * kq);
-      x0[0] = q0.x; x0[1] = q0.y; x0[2] = q0.z; x0[3] = q0.w; x1[0] = q1.x; x1[1] = q1.y; x1[2] = q1.z; x1[3] = q1.w;
-    } else {
 #pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        int k = 16 * G + 4 * kq + c;
-        k = k < Kvalid ? k : Kvalid - 1;  // rows past K meet zero activations; clamp keeps the read inside W
-        x0[c] = W[(size_t)k * H + n0 + i];
-        x1[c] = W[(size_t)k * H + n0 + 16 + i];
+      for (int g = 0; g < 2; ++g) {
+        const float4 q0 = *reinterpret_cast<const float4*>(W + (size_t)(n0 + 2 * j) * K + 32 * S + 16 * g + 4 * kq);
+        const float4 q1 = *reinterpret_cast<const float4*>(W + (size_t)(n0 + 2 * j + 1) * K + 32 * S + 16 * g + 4 * kq);
+        x0[4 * g] = q0.x; x0[4 * g + 1] = q0.y; x0[4 * g + 2] = q0.z; x0[4 * g + 3] = q0.w;
+        x1[4 * g] = q1.x; x1[4 * g + 1] = q1.y; x1[4 * g + 2] = q1.z; x1[4 * g + 3] = q1.w;
+      }
+    } else {
+      const int lane_off = 4 * kq * H + n0 + 2 * j;  // the only per-lane part of the address
+      if (32 * S + 32 <= Kvalid) {                   // wave-uniform: every k of the stage exists
+#pragma unroll
+        for (int g = 0; g < 2; ++g)
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            const float* up = W + (size_t)(32 * S + 16 * g + c) * H;  // scalar
+            const float2 q = *reinterpret_cast<const float2*>(up + lane_off);
+            x0[4 * g + c] = q.x; x1[4 * g + c] = q.y;
+          }
+      } else {  // last stage of the first layer: rows past K meet zero activations; the clamp keeps the read inside W
+#pragma unroll
+        for (int g = 0; g < 2; ++g)
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            int k = 32 * S + 16 * g + 4 * kq + c;
+            k = k < Kvalid ? k : Kvalid - 1;
+            const float2 q = *reinterpret_cast<const float2*>(W + (size_t)k * H + n0 + 2 * j);
+            x0[4 * g + c] = q.x; x1[4 * g + c] = q.y;
+          }
       }
     }
-  };
-  loadB(0, bw0, bw1);
-  for (int G = 0; G < ngroups; ++G) {
-    const float4 av = *reinterpret_cast<const float4*>(arow + 16 * G);
-    const bool more = G + 1 < ngroups;
-    if (more) loadB(G + 1, nb0, nb1);
-    mfma_f32_16x16x4(av.x, bw0[0], acc0); mfma_f32_16x16x4(av.x, bw1[0], acc1);
-    mfma_f32_16x16x4(av.y, bw0[1], acc0); mfma_f32_16x16x4(av.y, bw1[1], acc1);
-    mfma_f32_16x16x4(av.z, bw0[2], acc0); mfma_f32_16x16x4(av.z, bw1[2], acc1);
-    mfma_f32_16x16x4(av.w, bw0[3], acc0); mfma_f32_16x16x4(av.w, bw1[3], acc1);
-    if (more) {
-#pragma unroll
-      for (int c = 0; c < 4; ++c) { bw0[c] = nb0[c]; bw1[c] = nb1[c]; }
-    }
   }
+};
+
+__device__ __forceinline__ void stage_mfma(const float* arow, int S, const float (&x0)[8], const float (&x1)[8], f32x4& acc0, f32x4& acc1) {
+  const float4 a0 = *reinterpret_cast<const float4*>(arow + 32 * S);
+  const float4 a1 = *reinterpret_cast<const float4*>(arow + 32 * S + 16);
+  mfma_f32_16x16x4(a0.x, x0[0], acc0); mfma_f32_16x16x4(a0.x, x1[0], acc1);
+  mfma_f32_16x16x4(a0.y, x0[1], acc0); mfma_f32_16x16x4(a0.y, x1[1], acc1);
+  mfma_f32_16x16x4(a0.z, x0[2], acc0); mfma_f32_16x16x4(a0.z, x1[2], acc1);
+  mfma_f32_16x16x4(a0.w, x0[3], acc0); mfma_f32_16x16x4(a0.w, x1[3], acc1);
+  mfma_f32_16x16x4(a1.x, x0[4], acc0); mfma_f32_16x16x4(a1.x, x1[4], acc1);
+  mfma_f32_16x16x4(a1.y, x0[5], acc0); mfma_f32_16x16x4(a1.y, x1[5], acc1);
+  mfma_f32_16x16x4(a1.z, x0[6], acc0); mfma_f32_16x16x4(a1.z, x1[6], acc1);
+  mfma_f32_16x16x4(a1.w, x0[7], acc0); mfma_f32_16x16x4(a1.w, x1[7], acc1);
+}
+
+template <bool NT>
+__device__ __forceinline__ void tile_gemm(const float* At, int AS, int K, int Kvalid, const float* W, int H, int n0, int lane, f32x4& acc0, f32x4& acc1) {
+  const int j = lane & 15, kq = lane >> 4;
+  const float* arow = At + j * AS + 4 * kq;
+  const int nst = K / 32;
+  // three-deep register ring: stage S+2 is fetched while stage S computes, so a weight fragment has two full MFMA blocks
+  // (about 2000 cycles with two waves per SIMD) to arrive from L2.  Invariant at the loop top: b0 = stage S, b1 = stage S+1.
+  BStage<NT> b0, b1, b2;
+  b0.load(W, H, K, 0, n0, j, kq, Kvalid);
+  if (nst > 1) b1.load(W, H, K, 1, n0, j, kq, Kvalid);
+  int S = 0;
+  for (; S + 2 < nst; S += 3) {
+    b2.load(W, H, K, S + 2, n0, j, kq, Kvalid);
+    stage_mfma(arow, S, b0.x0, b0.x1, acc0, acc1);
+    if (S + 3 < nst) b0.load(W, H, K, S + 3, n0, j, kq, Kvalid);
+    stage_mfma(arow, S + 1, b1.x0, b1.x1, acc0, acc1);
+    if (S + 4 < nst) b1.load(W, H, K, S + 4, n0, j, kq, Kvalid);
+    stage_mfma(arow, S + 2, b2.x0, b2.x1, acc0, acc1);
+  }
+  if (S < nst) stage_mfma(arow, S, b0.x0, b0.x1, acc0, acc1);
+  if (S + 1 < nst) stage_mfma(arow, S + 1, b1.x0, b1.x1, acc0, acc1);
 }
 
 template <int LRW>
@@ -88,16 +133,17 @@ __global__ void __launch_bounds__(512) fused_mlp_kernel(FusedArgs a) {
   float* sm = reinterpret_cast<float*>(smem_raw);
   const int H = a.H, O = a.O, OP = a.OP, A = a.A, AP = a.AP;
   const int net = blockIdx.y;  // 0 actor, 1 critic
-  const int KP = (O + 15) & ~15;
+  const int KP = (O + 31) & ~31;  // first-layer K padded to whole 32-k stages (x tile zero-padded)
   const int XS = KP + 4, HS = H + 4;
   const int R0 = FRT * (XS > HS ? XS : HS);
   float* xt = sm;            // [16][XS]  then dZ2 tile [16][HS]
   float* h1t = sm + R0;      // [16][HS]
   float* h2t = h1t + FRT * HS;
   float* w3s = h2t + FRT * HS;          // actor: [H][A], critic: [H]
-  float* s_do = w3s + H * (A > 1 ? A : 1);  // [16][32]  d mean (cols < A) | critic: col 0 = d value
-  float* s_red = s_do + FRT * 32;       // [16][32]
-  float* s_l = s_red + FRT * 32;        // [16]
+  float* s_do = w3s + H * (A > 1 ? A : 1);  // [16][16]  d mean (cols < A, zero beyond) | critic: col 0 = d value
+  float* s_red = s_do + FRT * 16;       // [16][16]  d log_std terms
+  float* s_l = s_red + FRT * 16;        // [16]      per-row loss term
+  float* s_hp = s_l + FRT;              // [H/32 waves][64 lanes][4]  partial head tiles
   const int t = threadIdx.x, nthr = blockDim.x, lane = t & 63, wave = t >> 6;
   const int row0 = blockIdx.x * FRT;
   const bool tanh_act = net == 0 && a.use_tanh;
@@ -113,7 +159,7 @@ __global__ void __launch_bounds__(512) fused_mlp_kernel(FusedArgs a) {
   for (int e = t; e < FRT * (KP / 4); e += nthr) {
     const int r = e / (KP / 4), c4 = (e % (KP / 4)) * 4;
     const int gi = row0 + r < a.mb ? row0 + r : a.mb - 1;
-    const long row = a.idx ? a.idx[gi] : gi;
+    const long row = (a.idx && !(a.skip & 64)) ? a.idx[gi] : gi;
     float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
     if (c4 < OP) q = *reinterpret_cast<const float4*>(a.b.obs + row * a.b.obs_ld + c4);
     *reinterpret_cast<float4*>(xt + r * XS + c4) = q;
@@ -128,80 +174,113 @@ __global__ void __launch_bounds__(512) fused_mlp_kernel(FusedArgs a) {
   for (int layer = 0; layer < 2; ++layer) {
     f32x4 acc0, acc1;
     for (int r = 0; r < 4; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
-    if (layer == 0) tile_gemm<false>(xt, XS, KP, O, W1, H, n0, lane, acc0, acc1);
-    else tile_gemm<false>(h1t, HS, H, H, W2, H, n0, lane, acc0, acc1);
+    if (layer == 0) { if (!(a.skip & 1)) tile_gemm<false>(xt, XS, KP, O, W1, H, n0, lane, acc0, acc1); }
+    else if (!(a.skip & 2)) tile_gemm<false>(h1t, HS, H, H, W2, H, n0, lane, acc0, acc1);
     const float* bias = layer == 0 ? B1 : B2;
     float* ht = layer == 0 ? h1t : h2t;
     float* hg = layer == 0 ? a.h1[net] : a.h2[net];
-    const float bz0 = bias[n0 + cj], bz1 = bias[n0 + 16 + cj];
+    const int c0 = n0 + 2 * cj, c1 = c0 + 1;  // the wave's two interleaved column tiles
+    const float bz0 = bias[c0], bz1 = bias[c1];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int rr = 4 * rq + r;
       float v0 = acc0[r] + bz0, v1 = acc1[r] + bz1;
       if (tanh_act) { v0 = fused_tanh(v0); v1 = fused_tanh(v1); } else { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); }
-      ht[rr * HS + n0 + cj] = v0;
-      ht[rr * HS + n0 + 16 + cj] = v1;
-      if (row0 + rr < a.mb) {
-        hg[(size_t)(row0 + rr) * H + n0 + cj] = v0;
-        hg[(size_t)(row0 + rr) * H + n0 + 16 + cj] = v1;
-      }
+      *reinterpret_cast<float2*>(ht + rr * HS + c0) = make_float2(v0, v1);
+      if (row0 + rr < a.mb && !(a.skip & 32)) *reinterpret_cast<float2*>(hg + (size_t)(row0 + rr) * H + c0) = make_float2(v0, v1);
     }
     __syncthreads();
   }
 
-  // ---- P3: output layer + loss terms of this network; 32 lanes per row ----
-  const int rows_per_pass = nthr / 32;
-  for (int rbase = 0; rbase < FRT; rbase += rows_per_pass) {
-    const int r = rbase + t / 32, o = t & 31;
-    const int i = row0 + r;
-    const bool on = i < a.mb;
-    long row = 0;
-    if (on) row = a.idx ? a.idx[i] : i;
-    const float* hrow = h2t + r * HS;
-    if (net == 0) {
-      float out = 0.f;
-      if (o < A) {
-        float s0 = 0.f, s1 = 0.f;
-        for (int k = 0; k < H; k += 2) { s0 += hrow[k] * w3s[k * A + o]; s1 += hrow[k + 1] * w3s[(k + 1) * A + o]; }
-        out = s0 + s1 + B3[o];
+  // ---- P3: output layer on the matrix cores: one 16x16 tile (rows x outputs), K = H split over the waves ----
+  // wave w multiplies h2[:, 32w .. 32w+32) by W3[32w .. 32w+32, :]; the H/32 partial tiles are summed through LDS.
+  {
+    f32x4 hp;
+    for (int r = 0; r < 4; ++r) hp[r] = 0.f;
+    if (!(a.skip & 4)) {
+      const float* arow = h2t + cj * HS + 4 * rq + 32 * wave;
+#pragma unroll
+      for (int g = 0; g < 2; ++g) {
+        const float4 av = *reinterpret_cast<const float4*>(arow + 16 * g);
+        const int kb = 32 * wave + 16 * g + 4 * rq;
+        const float b0 = cj < nout ? w3s[(kb + 0) * nout + cj] : 0.f, b1 = cj < nout ? w3s[(kb + 1) * nout + cj] : 0.f;
+        const float b2 = cj < nout ? w3s[(kb + 2) * nout + cj] : 0.f, b3 = cj < nout ? w3s[(kb + 3) * nout + cj] : 0.f;
+        mfma_f32_16x16x4(av.x, b0, hp); mfma_f32_16x16x4(av.y, b1, hp); mfma_f32_16x16x4(av.z, b2, hp); mfma_f32_16x16x4(av.w, b3, hp);
       }
+    }
+    *reinterpret_cast<float4*>(s_hp + (wave * 64 + lane) * 4) = make_float4(hp[0], hp[1], hp[2], hp[3]);
+  }
+  __syncthreads();
+  {
+    // every wave adds the partial tiles (same order: identical values everywhere); lane (o = lane&15, q = lane>>4) holds
+    // out[r] = output o of row 4q + r.  A DPP row of 16 lanes therefore spans all outputs of a row: row reductions are
+    // group16 sums, one per accumulator register.  Only wave 0 stores.
+    float out[4] = {0.f, 0.f, 0.f, 0.f};
+    const int nw = nthr >> 6;
+    for (int w = 0; w < nw; ++w) {
+      const float4 q = *reinterpret_cast<const float4*>(s_hp + (w * 64 + lane) * 4);
+      out[0] += q.x; out[1] += q.y; out[2] += q.z; out[3] += q.w;
+    }
+    const int o = cj;
+    const bool st = wave == 0;
+    if (net == 0) {
       const float ls = o < A ? a.params[a.L.log_std + o] : 0.f;
       const float inv_std = __expf(-ls);
-      const float sum_ls = row32_sum<32>(ls);
-      float z = 0.f;
-      if (on && o < A) z = (a.b.action[row * a.b.act_ld + o] - out) * inv_std;
-      const float ss = row32_sum<32>(z * z);
-      float la = 0.f, dlogp = 0.f;
-      if (on) {
-        const float logp = -0.5f * ss - sum_ls - 0.5f * (float)A * kLog2PiF;
-        const float ratio = __expf(logp - a.b.log_prob[row]);
-        const float g = (a.b.adv[row] - a.adv_stat[0]) * a.adv_stat[1];
-        const float la1 = ratio * g;
-        const float la2 = fminf(fmaxf(ratio, 1.f - a.lc.clip_eps), 1.f + a.lc.clip_eps) * g;
-        la = -fminf(la1, la2) * a.inv_count;
-        const bool unclipped = (ratio >= 1.f - a.lc.clip_eps) && (ratio <= 1.f + a.lc.clip_eps);
-        dlogp = (unclipped || la1 < la2) ? -g * ratio * a.inv_count : 0.f;
+      const float sum_ls = group16_sum(ls);
+      const float b3v = o < A ? B3[o] : 0.f;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int rr = 4 * rq + r, i = row0 + rr;
+        const bool on = i < a.mb;
+        long row = 0;
+        if (on) row = a.idx ? a.idx[i] : i;
+        const float mean = out[r] + b3v;
+        float z = 0.f;
+        if (on && o < A) z = (a.b.action[row * a.b.act_ld + o] - mean) * inv_std;
+        const float ss = group16_sum(z * z);
+        float la = 0.f, dlogp = 0.f;
+        if (on) {
+          const float logp = -0.5f * ss - sum_ls - 0.5f * (float)A * kLog2PiF;
+          const float ratio = __expf(logp - a.b.log_prob[row]);
+          const float g = (a.b.adv[row] - a.adv_stat[0]) * a.adv_stat[1];
+          const float la1 = ratio * g;
+          const float la2 = fminf(fmaxf(ratio, 1.f - a.lc.clip_eps), 1.f + a.lc.clip_eps) * g;
+          la = -fminf(la1, la2) * a.inv_count;
+          const bool unclipped = (ratio >= 1.f - a.lc.clip_eps) && (ratio <= 1.f + a.lc.clip_eps);
+          dlogp = (unclipped || la1 < la2) ? -g * ratio * a.inv_count : 0.f;
+        }
+        const float dm = o < A ? dlogp * z * inv_std : 0.f;
+        if (st) {
+          s_do[rr * 16 + o] = dm;
+          s_red[rr * 16 + o] = o < A ? dlogp * (z * z - 1.f) : 0.f;
+          if (o == 0) s_l[rr] = la;
+          if (on && o < AP) a.dout[(size_t)i * a.DP + o] = dm;
+        }
       }
-      const float dm = o < A ? dlogp * z * inv_std : 0.f;
-      s_do[r * 32 + o] = dm;
-      s_red[r * 32 + o] = o < A ? dlogp * (z * z - 1.f) : 0.f;
-      if (o == 0) s_l[r] = la;
-      if (on && o < AP) a.dout[(size_t)i * a.DP + o] = dm;
     } else {
-      float s0 = 0.f;
-      for (int k = o; k < H; k += 32) s0 += hrow[k] * w3s[k];
-      const float vnew = row32_sum<32>(s0) + B3[0];
-      float lv = 0.f, dv = 0.f;
-      if (on) {
-        const float ov = a.b.value[row], tg = a.b.target[row];
-        const float vc = ov + fminf(fmaxf(vnew - ov, -a.lc.clip_eps), a.lc.clip_eps);
-        const float vl1 = (vnew - tg) * (vnew - tg), vl2 = (vc - tg) * (vc - tg);
-        lv = 0.5f * fmaxf(vl1, vl2) * a.inv_count;
-        const bool vin = fabsf(vnew - ov) <= a.lc.clip_eps;
-        dv = (vin || vl1 > vl2) ? (vnew - tg) * a.inv_count * a.lc.vf_coef : 0.f;
+      const float b3v = B3[0];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int rr = 4 * rq + r, i = row0 + rr;
+        const bool on = i < a.mb;
+        long row = 0;
+        if (on) row = a.idx ? a.idx[i] : i;
+        const float vnew = group16_sum(o == 0 ? out[r] : 0.f) + b3v;
+        float lv = 0.f, dv = 0.f;
+        if (on) {
+          const float ov = a.b.value[row], tg = a.b.target[row];
+          const float vc = ov + fminf(fmaxf(vnew - ov, -a.lc.clip_eps), a.lc.clip_eps);
+          const float vl1 = (vnew - tg) * (vnew - tg), vl2 = (vc - tg) * (vc - tg);
+          lv = 0.5f * fmaxf(vl1, vl2) * a.inv_count;
+          const bool vin = fabsf(vnew - ov) <= a.lc.clip_eps;
+          dv = (vin || vl1 > vl2) ? (vnew - tg) * a.inv_count * a.lc.vf_coef : 0.f;
+        }
+        if (st) {
+          s_do[rr * 16 + o] = o == 0 ? dv : 0.f;
+          if (o == 0) s_l[rr] = lv;
+          if (on && o < 4) a.dout[(size_t)i * a.DP + AP + o] = o == 0 ? dv : 0.f;
+        }
       }
-      if (o == 0) { s_do[r * 32] = dv; s_l[r] = lv; }
-      if (on && o < 4) a.dout[(size_t)i * a.DP + AP + o] = o == 0 ? dv : 0.f;
     }
   }
   __syncthreads();
@@ -210,49 +289,64 @@ __global__ void __launch_bounds__(512) fused_mlp_kernel(FusedArgs a) {
     float* prow = a.partial + (size_t)blockIdx.x * (4 + AP);
     if (net == 0) {
       if (t == 0) { float s = 0.f; for (int r = 0; r < FRT; ++r) s += s_l[r]; prow[0] = s; }
-      if (t >= 4 && t < 4 + AP) { float s = 0.f; if (t - 4 < A) for (int r = 0; r < FRT; ++r) s += s_red[r * 32 + (t - 4)]; prow[t] = s; }
+      if (t >= 4 && t < 4 + AP) { float s = 0.f; if (t - 4 < A) for (int r = 0; r < FRT; ++r) s += s_red[r * 16 + (t - 4)]; prow[t] = s; }
     } else if (t == 0) {
       float s = 0.f; for (int r = 0; r < FRT; ++r) s += s_l[r]; prow[1] = s;
     }
   }
-  // ---- P4: dZ2 = (dOut . W3^T) * act'(h2) -> LDS (over the dead x tile) + global ----
+  // ---- P4: dZ2 = (dOut . W3^T) * act'(h2) on the matrix cores (K = outputs padded to 16) -> LDS (over the dead x tile) + global ----
   float* dzt = xt;
-  for (int e = t; e < FRT * H; e += nthr) {
-    const int r = e / H, n = e - r * H;
-    float s = 0.f;
-    if (net == 0) { for (int k = 0; k < A; ++k) s += s_do[r * 32 + k] * w3s[n * A + k]; }
-    else s = s_do[r * 32] * w3s[n];
-    const float hv = h2t[r * HS + n];
-    s = tanh_act ? s * (1.f - hv * hv) : (hv > 0.f ? s : 0.f);
-    dzt[r * HS + n] = s;
-    if (row0 + r < a.mb) a.dz2[net][(size_t)(row0 + r) * H + n] = s;
+  {
+    f32x4 d0, d1;
+    for (int r = 0; r < 4; ++r) { d0[r] = 0.f; d1[r] = 0.f; }
+    const int c0 = n0 + 2 * cj;
+    if (!(a.skip & 8)) {
+#pragma unroll
+      for (int m = 0; m < 4; ++m) {
+        const int ai = 4 * m + rq;  // output index contracted over
+        const float av = s_do[cj * 16 + ai];
+        const float b0 = ai < nout ? w3s[c0 * nout + ai] : 0.f, b1 = ai < nout ? w3s[(c0 + 1) * nout + ai] : 0.f;
+        mfma_f32_16x16x4(av, b0, d0); mfma_f32_16x16x4(av, b1, d1);
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int rr = 4 * rq + r;
+      const float2 hv = *reinterpret_cast<const float2*>(h2t + rr * HS + c0);
+      const float z0 = tanh_act ? d0[r] * (1.f - hv.x * hv.x) : (hv.x > 0.f ? d0[r] : 0.f);
+      const float z1 = tanh_act ? d1[r] * (1.f - hv.y * hv.y) : (hv.y > 0.f ? d1[r] : 0.f);
+      *reinterpret_cast<float2*>(dzt + rr * HS + c0) = make_float2(z0, z1);
+      if (row0 + rr < a.mb && !(a.skip & 32)) *reinterpret_cast<float2*>(a.dz2[net] + (size_t)(row0 + rr) * H + c0) = make_float2(z0, z1);
+    }
   }
   __syncthreads();
   // ---- P5: dZ1 = (dZ2 . W2^T) * act'(h1) ----
   {
     f32x4 acc0, acc1;
     for (int r = 0; r < 4; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
-    tile_gemm<true>(dzt, HS, H, H, W2, H, n0, lane, acc0, acc1);
+    if (!(a.skip & 16)) tile_gemm<true>(dzt, HS, H, H, W2, H, n0, lane, acc0, acc1);
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int rr = 4 * rq + r;
       if (row0 + rr < a.mb) {
-        const float g0 = h1t[rr * HS + n0 + cj], g1 = h1t[rr * HS + n0 + 16 + cj];
-        a.dz1[net][(size_t)(row0 + rr) * H + n0 + cj] = tanh_act ? acc0[r] * (1.f - g0 * g0) : (g0 > 0.f ? acc0[r] : 0.f);
-        a.dz1[net][(size_t)(row0 + rr) * H + n0 + 16 + cj] = tanh_act ? acc1[r] * (1.f - g1 * g1) : (g1 > 0.f ? acc1[r] : 0.f);
+        const int c0 = n0 + 2 * cj;
+        const float2 gq = *reinterpret_cast<const float2*>(h1t + rr * HS + c0);
+        const float d0 = tanh_act ? acc0[r] * (1.f - gq.x * gq.x) : (gq.x > 0.f ? acc0[r] : 0.f);
+        const float d1 = tanh_act ? acc1[r] * (1.f - gq.y * gq.y) : (gq.y > 0.f ? acc1[r] : 0.f);
+        *reinterpret_cast<float2*>(a.dz1[net] + (size_t)(row0 + rr) * H + c0) = make_float2(d0, d1);
       }
     }
   }
 }
 
 size_t fused_smem_bytes(int O, int A, int H) {
-  const int KP = (O + 15) & ~15, XS = KP + 4, HS = H + 4;
+  const int KP = (O + 31) & ~31, XS = KP + 4, HS = H + 4;
   const size_t R0 = (size_t)FRT * (XS > HS ? XS : HS);
-  return sizeof(float) * (R0 + 2 * (size_t)FRT * HS + (size_t)H * (A > 1 ? A : 1) + 2 * FRT * 32 + FRT);
+  return sizeof(float) * (R0 + 2 * (size_t)FRT * HS + (size_t)H * (A > 1 ? A : 1) + 2 * FRT * 16 + FRT + (size_t)(H / 32) * 256);
 }
 
 bool fused_supported(const mppo_net_t& net, const mppo_batch_t& b) {
-  return net.H % 32 == 0 && net.H >= 32 && net.H <= 512 && net.A <= 31 && net.bf16 == 0 && b.obs_ld == net.OP && (net.OP % 4) == 0 &&
+  return net.H % 32 == 0 && net.H >= 32 && net.H <= 512 && net.A <= 16 && net.bf16 == 0 && b.obs_ld == net.OP && (net.OP % 4) == 0 &&
          (reinterpret_cast<uintptr_t>(b.obs) & 15) == 0 && fused_smem_bytes(net.O, net.A, net.H) <= 160 * 1024 &&
          (param_layout(net.O, net.A, net.H).c_w2 % 4) == 0;  // float4 rows of W2 in the backward product
 }
@@ -264,6 +358,8 @@ int32_t fused_forward_backward(const mppo_net_t& net, const float* params, const
   a.params = params; a.L = param_layout(net.O, net.A, net.H); a.b = batch; a.idx = idx; a.adv_stat = adv_stat; a.inv_count = inv_count; a.lc = lc;
   a.h1[0] = g.f.h1a; a.h1[1] = g.f.h1c; a.h2[0] = g.f.h2a; a.h2[1] = g.f.h2c; a.dz2[0] = g.dz2a; a.dz2[1] = g.dz2c; a.dz1[0] = g.dz1a; a.dz1[1] = g.dz1c;
   a.dout = g.dout; a.xmb = g.xmb; a.partial = g.partial;
+  static const int skip = [] { const char* e = getenv("MPPO_FUSED_SKIP"); return e ? atoi(e) : 0; }();
+  a.skip = skip;
   const size_t smem = fused_smem_bytes(net.O, net.A, net.H);
   static thread_local size_t attr_for = 0;
   if (smem > 64 * 1024 && attr_for < smem) {

@@ -4,6 +4,7 @@
 
 #include <cstddef>
 #include <cstdint>
+#include <cstdlib>
 
 #include "../../include/minppo_hip.h"
 
@@ -44,7 +45,11 @@ inline FwdBufs carve_fwd(const mppo_net_t& net, int n, float* ws) {
   return f;
 }
 
-constexpr int kGradKSplit = 3;  // 72 weight-gradient tiles x 3 K-slices = 216 workgroups: one round on 256 CUs
+constexpr int kGradKSplitMax = 8;  // slabs reserved in the workspace
+inline int grad_ksplit() {  // K-slices of the weight-gradient product; MPPO_KSPLIT overrides for measurements
+  static const int v = [] { const char* e = getenv("MPPO_KSPLIT"); int k = e ? atoi(e) : 8; return k < 1 ? 1 : (k > kGradKSplitMax ? kGradKSplitMax : k); }();
+  return v;
+}
 
 // everything one minibatch gradient needs beyond the forward activations
 struct GradBufs {
@@ -58,7 +63,7 @@ inline size_t grad_bufs_floats(const mppo_net_t& net, int mb) {
   const size_t AP = pad4((size_t)net.A), nh = pad4((size_t)mb * net.H);
   const size_t P = pad4((size_t)param_layout(net.O, net.A, net.H).total);
   const size_t nblk = (size_t)(mb + 7) / 8;  // head kernel: 8 rows per workgroup (fused kernel: 16)
-  return fwd_bufs_floats(net, mb) + pad4((size_t)mb * (AP + 4)) + 4 * nh + pad4(nblk * (4 + AP)) + (size_t)kGradKSplit * P + pad4((size_t)mb * net.OP);
+  return fwd_bufs_floats(net, mb) + pad4((size_t)mb * (AP + 4)) + 4 * nh + pad4(nblk * (4 + AP)) + (size_t)kGradKSplitMax * P + pad4((size_t)mb * net.OP);
 }
 inline GradBufs carve_grad(const mppo_net_t& net, int mb, float* ws) {
   GradBufs g;
@@ -70,8 +75,8 @@ inline GradBufs carve_grad(const mppo_net_t& net, int mb, float* ws) {
   const size_t nblk = (size_t)(mb + 7) / 8;
   g.partial = ws; ws += pad4(nblk * (4 + AP));
   g.slabs = ws;
-  g.xmb = ws + (size_t)kGradKSplit * pad4((size_t)param_layout(net.O, net.A, net.H).total);
-  g.ksplit = kGradKSplit;
+  g.xmb = ws + (size_t)kGradKSplitMax * pad4((size_t)param_layout(net.O, net.A, net.H).total);
+  g.ksplit = grad_ksplit();
   g.slab_stride = pad4((size_t)param_layout(net.O, net.A, net.H).total);
   return g;
 }

@@ -86,3 +86,4 @@ struct uint4 { unsigned x, y, z, w; };
 struct uint2 { unsigned x, y; };
 inline float __expf(float x) { return expf(x); }
 inline float __fdividef(float a, float b) { return a / b; }
+inline float2 make_float2(float x, float y) { return {x, y}; }
