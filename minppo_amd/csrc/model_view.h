@@ -70,7 +70,7 @@ __host__ __device__ inline PhysLds make_phys_lds(int nq, int nv, int nu, int nbo
   p.qpos = take(nq); p.qvel = take(nv); p.ctrl = take(nu > 0 ? nu : 1); p.warm = take(nv);
   p.xpos = take(3 * nbody); p.xquat = take(4 * nbody); p.xipos = take(3 * nbody); p.rootcom = take(3 * (nroot > 0 ? nroot : 1));
   p.cinert = take(10 * nbody); p.cdof = take(6 * nv); p.cvel = take(6 * nbody);
-  p.ldm = nv + 1;
+  p.ldm = nv + 1;  // odd row stride: a column read by 16 lanes hits 16 different banks
   p.M = take(nv * p.ldm); p.LL = take(nv * p.ldm);
   p.qfs = take(nv); p.qas = take(nv); p.qact = take(nv); p.qacc = take(nv); p.Ma = take(nv); p.grad = take(nv);
   p.Mgrad = take(nv); p.search = take(nv); p.mv = take(nv); p.qfc = take(nv); p.t0 = take(nv); p.t1 = take(nv);
