@@ -12,9 +12,10 @@ environments PER GPU (weak scaling: configs[2] is 8 x 4096), fp32.  Inputs are s
 HBM (the environment state itself); weights are random-init.  Rank 0 prints ONE JSON line.
 
 The line also carries
-  roofline     : the dominant kernel (the f32-MFMA batched GEMM of the hidden layers) timed live with HIP
-                 events on the engine's stream, algorithmic FLOPs per launch / average duration against the
-                 dense f32 MFMA peak (157.3 TFLOP/s, MI355X_MICROARCH.md)
+  roofline     : the dominant kernel (`fused_mlp_kernel`, the row-local forward + backward of one minibatch on the
+                 f32 matrix cores) timed live with HIP events on a hipGraph replay of 50 launches, algorithmic
+                 FLOPs per launch / average duration against the dense f32 MFMA peak (157.3 TFLOP/s,
+                 MI355X_MICROARCH.md)
   cpu_baseline : the NumPy oracle (oracle/, a "port" of the reference's algorithm; the JAX reference
                  cannot run here) timed on this box's host cores on a bounded sample of the same workload.
 """
@@ -49,35 +50,48 @@ def parse() -> argparse.Namespace:
     return ap.parse_args()
 
 
-def gemm_probe(tr, reps: int = 200):
-    """Average duration of the dominant kernel: the hidden-layer forward GEMM of one minibatch
-    (both networks in one launch: 2 x [mb,256] = [mb,256] . [256,256], bias + activation), HIP events on
-    the engine stream.  Returns (seconds per launch, algorithmic flops per launch, description)."""
+def rowpass_probe(tr, launches: int = 50, replays: int = 4):
+    """Average duration of the dominant kernel, `fused_mlp_kernel` (row-local forward + backward of one minibatch:
+    both hidden layers, heads, loss terms, dZ2, dZ1 of actor and critic), on the engine's own buffers.  `launches`
+    back-to-back launches are captured into a hipGraph on the engine stream and replayed, bracketed by HIP events recorded
+    on that stream, so the host is not in the loop.  Returns (seconds per launch, algorithmic flops per launch, text)."""
     import torch
     from minppo_amd import _native as nat
 
-    mb, H = tr.minibatch_size // tr.world_size, tr.H
-    dev = tr.device
-    a = torch.randn(2, mb, H, device=dev)
-    w = torch.randn(2, H, H, device=dev) * 0.06
-    b = torch.zeros(2, H, device=dev)
-    c = torch.empty(2, mb, H, device=dev)
-    descs = (nat.GemmDesc * 2)()
-    for i in range(2):
-        descs[i] = nat.GemmDesc(a[i].data_ptr(), w[i].data_ptr(), c[i].data_ptr(), b[i].data_ptr(), 0, 0, 0, mb, H, H, H, H, H, 0, 1 if i == 0 else 2)
+    T, N, E, M = tr.T, tr.N, tr.E, tr.M
+    mb = T * N // M
+    reg = {k: tr.region(k) for k in ("params", "obs", "action", "value", "log_prob", "adv", "target", "perm", "adv_stats", "grad_ws")}
+    batch = nat.Batch(reg["obs"].data_ptr(), tr.OP, reg["action"].data_ptr(), tr.A, reg["value"].data_ptr(), reg["log_prob"].data_ptr(),
+                      reg["adv"].data_ptr(), reg["target"].data_ptr())
+    lc = tr.ecfg.loss
+    wsb = tr.lib.grad_ws_bytes(C.byref(tr.net), mb)
     s = tr.stream
+
+    def launch(k):
+        tr.lib.minibatch_rowpass(C.byref(tr.net), reg["params"].data_ptr(), C.byref(batch), reg["perm"].data_ptr() + 4 * (k % M) * mb, mb,
+                                 reg["adv_stats"].data_ptr() + 8 * (k % M), 1.0 / mb, C.byref(lc), reg["grad_ws"].data_ptr(), wsb, s.cuda_stream)
+
+    for k in range(3):
+        launch(k)
+    s.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, stream=s):
+        for k in range(launches):
+            launch(k)
+    g.replay()
+    torch.cuda.synchronize()
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    for _ in range(20):
-        tr.lib.gemm_batch(descs, 2, 0, 1, 0, 0, s.cuda_stream)
-    s.synchronize()
-    ev0.record(s)
-    for _ in range(reps):
-        tr.lib.gemm_batch(descs, 2, 0, 1, 0, 0, s.cuda_stream)
-    ev1.record(s)
-    s.synchronize()
-    sec = ev0.elapsed_time(ev1) * 1e-3 / reps
-    flops = 2.0 * 2 * mb * H * H
-    return sec, flops, f"gemm_kernel<fwd> 2x[{mb},{H}]x[{H},{H}] f32 MFMA"
+    cur = torch.cuda.current_stream()
+    ev0.record(cur)
+    for _ in range(replays):
+        g.replay()
+    ev1.record(cur)
+    torch.cuda.synchronize()
+    sec = ev0.elapsed_time(ev1) * 1e-3 / (launches * replays)
+    O, A, H = tr.O, tr.A, tr.H
+    macs_row = (2 * O * H + 2 * H * H + H * (A + 1)) + (2 * H * H + H * (A + 1))  # forward (both nets) + dZ2, dZ1 (both nets)
+    flops = 2.0 * macs_row * mb
+    return sec, flops, f"fused_mlp_kernel: row pass of one minibatch (mb={mb}, O={O}, H={H}, A={A}, actor+critic; f32 MFMA 16x16x4)"
 
 
 def cpu_baseline(config_name: str, n_envs: int):
@@ -164,7 +178,7 @@ def main() -> None:
 
     out = None
     if rank == 0:
-        sec, flops, desc = gemm_probe(tr)
+        sec, flops, desc = rowpass_probe(tr)
         achieved = flops / sec / 1e12
         out = {
             "metric": "env-steps/sec (whole node), stompy_pro 4096 envs, 1/2/4/8 MI355X",

@@ -175,6 +175,13 @@ int32_t mppo_minibatch_grad(const mppo_net_t* net, const float* params, const mp
                             int32_t mb, const float* adv_stat, float inv_count, const mppo_loss_cfg_t* lc, float* grad,
                             float* loss4, void* ws, size_t ws_bytes, void* stream);
 
+/* The row-local half of mppo_minibatch_grad on its own (forward of both networks, loss terms, d loss / d outputs and the
+ * activation gradients dZ2, dZ1; one fused launch when H % 32 == 0 and A <= 16).  Same arguments; leaves its results in
+ * `ws` for the weight-gradient product.  Exposed so that benchmarks can time exactly this kernel. */
+int32_t mppo_minibatch_rowpass(const mppo_net_t* net, const float* params, const mppo_batch_t* batch, const int32_t* idx,
+                               int32_t mb, const float* adv_stat, float inv_count, const mppo_loss_cfg_t* lc, void* ws,
+                               size_t ws_bytes, void* stream);
+
 /* Per-minibatch advantage statistics for all E*M minibatches of an update in one launch:
  * sums[k] = {sum adv, sum adv^2} (float64) over rows idx[k*mb .. (k+1)*mb); then
  * mppo_adv_stats_finalize turns (possibly all-reduced) sums into {mean, 1/(std+1e-8)}. */

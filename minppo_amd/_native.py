@@ -103,6 +103,7 @@ SIGNATURES = {
     "mppo_grad_ws_bytes": (c_sz, [P(Net), c_i32]),
     "mppo_minibatch_grad": (c_i32, [P(Net), c_vp, P(Batch), c_vp, c_i32, c_vp, c_f, P(LossCfg), c_vp, c_vp, c_vp, c_sz,
                                     c_vp]),
+    "mppo_minibatch_rowpass": (c_i32, [P(Net), c_vp, P(Batch), c_vp, c_i32, c_vp, c_f, P(LossCfg), c_vp, c_sz, c_vp]),
     "mppo_adv_sums": (c_i32, [c_vp, c_vp, c_i32, c_i32, c_vp, c_vp]),
     "mppo_adv_stats_finalize": (c_i32, [c_vp, c_i32, C.c_double, c_vp, c_vp]),
     "mppo_adam_ws_bytes": (c_sz, [c_sz]),

@@ -450,38 +450,46 @@ int32_t policy_forward(const mppo_net_t& net, const float* params, int n, const 
   return head_launch(a, false, stream);
 }
 
-int32_t minibatch_grad(const mppo_net_t& net, const float* params, const mppo_batch_t& batch, const int* idx, int mb, const float* adv_stat,
-                       float inv_count, const mppo_loss_cfg_t& lc, float* grad, float* loss4, float* sq_partial, const GradBufs& gbuf, hipStream_t stream) {
+// Everything of a minibatch step that is local to a row: forward of both networks, loss terms, d(loss)/d(outputs), dZ2, dZ1
+// (one fused launch where supported, k_fused.hip; otherwise layer-wise GEMMs + the head kernel).  Leaves h1, h2, dZ2, dZ1,
+// dOut, xmb and the loss partials in the GradBufs; *nblk_out = number of partial rows written.
+int32_t minibatch_rowpass(const mppo_net_t& net, const float* params, const mppo_batch_t& batch, const int* idx, int mb, const float* adv_stat,
+                          float inv_count, const mppo_loss_cfg_t& lc, const GradBufs& gbuf, int* nblk_out, hipStream_t stream) {
   const ParamLayout L = param_layout(net.O, net.A, net.H);
-  const int H = net.H, A = net.A, AP = gbuf.f.AP, DP = AP + 4, O = net.O;
+  const int H = net.H;
   const int act_a = net.use_tanh ? ACT_TANH : ACT_RELU;
   MPPO_REQUIRE(batch.obs_ld == net.OP, "minibatch_grad: obs_ld (%d) must equal the padded observation width OP (%d)", batch.obs_ld, net.OP);
   static const char* nofuse = getenv("MPPO_NO_FUSED");  // A/B switch for measurements
   const bool fused = fused_supported(net, batch) && !(nofuse && nofuse[0] == '1');
-  int nblk;
-  GemmBatch gb{};
   if (fused) {
-    // hidden layers, heads, loss terms, dZ2 and dZ1 in one launch (k_fused.hip)
     MPPO_TRY(fused_forward_backward(net, params, batch, idx, mb, adv_stat, inv_count, lc, gbuf, stream));
-    nblk = cdiv(mb, 16);
-  } else {
-    MPPO_TRY(mlp_hidden_forward(net, params, mb, batch.obs, batch.obs_ld, idx, gbuf.f, gbuf.xmb, stream));
-    // heads + loss + dZ2 (one launch)
-    HeadArgs ha = head_args(net, params, mb, gbuf.f);
-    ha.idx = idx; ha.b = batch; ha.adv_stat = adv_stat; ha.inv_count = inv_count; ha.lc = lc;
-    ha.dout = gbuf.dout; ha.dz2a = gbuf.dz2a; ha.dz2c = gbuf.dz2c; ha.partial = gbuf.partial;
-    MPPO_TRY(head_launch(ha, true, stream));
-    nblk = cdiv(mb, 8);  // head kernel: 8 rows per workgroup
-    gb.count = 2; gb.ksplit = 1;
-    // dZ1 = (dZ2 . W2^T) * act'(h1)
-    {
-      GemmProb& a = gb.p[0]; a = GemmProb{};
-      a.A = gbuf.dz2a; a.lda = H; a.M = mb; a.K = H; a.B = params + L.a_w2; a.ldb = H; a.N = H; a.aux = gbuf.f.h1a; a.ldaux = H; a.act = act_a; a.C = gbuf.dz1a; a.ldc = H;
-      GemmProb& c = gb.p[1]; c = GemmProb{};
-      c.A = gbuf.dz2c; c.lda = H; c.M = mb; c.K = H; c.B = params + L.c_w2; c.ldb = H; c.N = H; c.aux = gbuf.f.h1c; c.ldaux = H; c.act = ACT_RELU; c.C = gbuf.dz1c; c.ldc = H;
-    }
-    MPPO_TRY(gemm_launch(gb, 0, 1, EPI_DACT, net.bf16, stream));
+    *nblk_out = cdiv(mb, 16);
+    return MPPO_OK;
   }
+  MPPO_TRY(mlp_hidden_forward(net, params, mb, batch.obs, batch.obs_ld, idx, gbuf.f, gbuf.xmb, stream));
+  HeadArgs ha = head_args(net, params, mb, gbuf.f);
+  ha.idx = idx; ha.b = batch; ha.adv_stat = adv_stat; ha.inv_count = inv_count; ha.lc = lc;
+  ha.dout = gbuf.dout; ha.dz2a = gbuf.dz2a; ha.dz2c = gbuf.dz2c; ha.partial = gbuf.partial;
+  MPPO_TRY(head_launch(ha, true, stream));  // heads + loss + dZ2
+  *nblk_out = cdiv(mb, 8);
+  GemmBatch gb{};
+  gb.count = 2; gb.ksplit = 1;
+  {  // dZ1 = (dZ2 . W2^T) * act'(h1)
+    GemmProb& a = gb.p[0]; a = GemmProb{};
+    a.A = gbuf.dz2a; a.lda = H; a.M = mb; a.K = H; a.B = params + L.a_w2; a.ldb = H; a.N = H; a.aux = gbuf.f.h1a; a.ldaux = H; a.act = act_a; a.C = gbuf.dz1a; a.ldc = H;
+    GemmProb& c = gb.p[1]; c = GemmProb{};
+    c.A = gbuf.dz2c; c.lda = H; c.M = mb; c.K = H; c.B = params + L.c_w2; c.ldb = H; c.N = H; c.aux = gbuf.f.h1c; c.ldaux = H; c.act = ACT_RELU; c.C = gbuf.dz1c; c.ldc = H;
+  }
+  return gemm_launch(gb, 0, 1, EPI_DACT, net.bf16, stream);
+}
+
+int32_t minibatch_grad(const mppo_net_t& net, const float* params, const mppo_batch_t& batch, const int* idx, int mb, const float* adv_stat,
+                       float inv_count, const mppo_loss_cfg_t& lc, float* grad, float* loss4, float* sq_partial, const GradBufs& gbuf, hipStream_t stream) {
+  const ParamLayout L = param_layout(net.O, net.A, net.H);
+  const int H = net.H, A = net.A, AP = gbuf.f.AP, DP = AP + 4, O = net.O;
+  int nblk = 0;
+  MPPO_TRY(minibatch_rowpass(net, params, batch, idx, mb, adv_stat, inv_count, lc, gbuf, &nblk, stream));
+  GemmBatch gb{};
   // weight gradients dW = H_prev^T . dZ into split-K slabs; the bias gradients (column sums of dZ) ride along.
   // dOut is [mb, DP] with d mean in columns [0,A) and d value in column AP: every operand is 16-byte aligned -> fast path.
   gb.count = 6; gb.ksplit = gbuf.ksplit; gb.slab_stride = gbuf.slab_stride;
@@ -573,6 +581,16 @@ extern "C" int32_t mppo_minibatch_grad(const mppo_net_t* net, const float* param
   if (ws_bytes < mppo_grad_ws_bytes(net, mb)) return fail(MPPO_ENOMEM, "mppo_minibatch_grad: workspace %zu < %zu bytes", ws_bytes, mppo_grad_ws_bytes(net, mb));
   const GradBufs gb = carve_grad(*net, mb, static_cast<float*>(ws));
   return minibatch_grad(*net, params, *batch, idx, mb, adv_stat, inv_count, *lc, grad, loss4, nullptr, gb, static_cast<hipStream_t>(stream));
+}
+
+extern "C" int32_t mppo_minibatch_rowpass(const mppo_net_t* net, const float* params, const mppo_batch_t* batch, const int32_t* idx, int32_t mb,
+                                          const float* adv_stat, float inv_count, const mppo_loss_cfg_t* lc, void* ws, size_t ws_bytes, void* stream) {
+  MPPO_TRY(check_net(net));
+  MPPO_REQUIRE(params && batch && adv_stat && lc && ws && mb >= 1, "mppo_minibatch_rowpass: null argument or mb < 1");
+  if (ws_bytes < mppo_grad_ws_bytes(net, mb)) return fail(MPPO_ENOMEM, "mppo_minibatch_rowpass: workspace %zu < %zu bytes", ws_bytes, mppo_grad_ws_bytes(net, mb));
+  const GradBufs gb = carve_grad(*net, mb, static_cast<float*>(ws));
+  int nblk = 0;
+  return minibatch_rowpass(*net, params, *batch, idx, mb, adv_stat, inv_count, *lc, gb, &nblk, static_cast<hipStream_t>(stream));
 }
 
 extern "C" int32_t mppo_adv_sums(const float* adv, const int32_t* idx, int32_t nmb, int32_t mb, double* sums, void* stream) {
