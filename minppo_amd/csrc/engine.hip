@@ -19,6 +19,7 @@
 #include "ppo_layout.h"
 #include "platform.h"
 
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -179,7 +180,11 @@ static int32_t do_learn(mppo_engine* e, hipStream_t s) {
       MPPO_TRY(permutation_ctr(c.seed, kStreamPerm + ((unsigned long long)c.rank << 16) + (unsigned long long)ep, e->count + 1, e->B, e->perm + (size_t)ep * e->B,
                                e->perm_ws, e->perm_ws_bytes, s));                                                    // train.py:258
   MPPO_TRY(mppo_adv_sums(e->adv, e->perm, EM, e->mb, e->adv_sums, s));
-  if (c.world_size > 1) MPPO_TRY(comm_allreduce_f64(e->comm, e->adv_sums, (size_t)EM * 2, s));
+  // MPPO_FORCE_COMM=1 runs the collectives also at world size 1 (identity all-reduce): hardware check of the RCCL path
+  const char* fc = getenv("MPPO_FORCE_COMM");
+  const bool force_comm = fc && fc[0] == '1';
+  const bool use_comm = c.world_size > 1 || (force_comm && e->comm);
+  if (use_comm) MPPO_TRY(comm_allreduce_f64(e->comm, e->adv_sums, (size_t)EM * 2, s));
   MPPO_TRY(mppo_adv_stats_finalize(e->adv_sums, EM, (double)e->mb * c.world_size, e->adv_stats, s));
   mppo_batch_t batch;
   batch.obs = e->obs; batch.obs_ld = e->OP; batch.action = e->action; batch.act_ld = e->A; batch.value = e->value; batch.log_prob = e->log_prob;
@@ -192,7 +197,7 @@ static int32_t do_learn(mppo_engine* e, hipStream_t s) {
   for (int ep = 0; ep < e->E; ++ep) {
     for (int k = 0; k < e->M; ++k) {
       const int st = ep * e->M + k;
-      const bool single = c.world_size == 1;  // then the reduce kernel's sums of squares are those of the final gradient
+      const bool single = !use_comm;  // then the reduce kernel's sums of squares are those of the final gradient
       MPPO_TRY(minibatch_grad(c.net, e->params, batch, e->perm + (size_t)ep * e->B + (size_t)k * e->mb, e->mb, e->adv_stats + 2 * st, inv_count, c.loss, e->grad,
                               e->losses + 4 * st, single ? e->adam_ws : nullptr, gb, s));                            // train.py:246-247
       if (!single) MPPO_TRY(comm_allreduce_f32(e->comm, e->grad, (size_t)e->P, s));
@@ -294,7 +299,7 @@ extern "C" int32_t mppo_engine_learn(mppo_engine_t* e, void* stream) {
 extern "C" int32_t mppo_engine_update(mppo_engine_t* e, void* stream) {
   MPPO_TRY(require_ready(e, true));
   hipStream_t s = static_cast<hipStream_t>(stream);
-  const bool want_graph = e->cfg.use_graph && !e->graph_failed && e->cfg.world_size == 1 && s != nullptr;
+  const bool want_graph = e->cfg.use_graph && !e->graph_failed && e->cfg.world_size == 1 && !e->comm && s != nullptr;
   if (want_graph) {
     if (!e->graph) {
       // capture once; every pointer and size in the sequence is fixed by the arena layout

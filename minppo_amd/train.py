@@ -305,6 +305,11 @@ class Trainer:
     def init_comm(self) -> None:
         """Creates the engine's RCCL communicator; the 128-byte id travels through torch.distributed."""
         if self.world_size == 1:
+            if os.environ.get("MPPO_FORCE_COMM") == "1":  # single-rank communicator: exercises the RCCL path on one GPU
+                host = np.zeros(128, np.uint8)
+                self.lib.comm_unique_id(host.ctypes.data)
+                with self.torch.cuda.device(self.device):
+                    self.lib.engine_comm_init(self._engine, host.ctypes.data)
             return
         import torch.distributed as dist
 

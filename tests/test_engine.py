@@ -182,3 +182,28 @@ def test_full_size_properties_on_gpu():
     assert np.isfinite(lo).all()
     np.testing.assert_allclose(lo[..., 0], lo[..., 2] + cfg.rl.vf_coef * lo[..., 1] - cfg.rl.ent_coef * lo[..., 3], rtol=1e-5, atol=1e-5)
     tr.close()
+
+
+@pytest.mark.gpu
+def test_rccl_path_at_world_size_one_is_the_identity(monkeypatch):
+    """Hardware check of the collective path: with MPPO_FORCE_COMM=1 a single-rank RCCL communicator is created and the
+    engine issues its all-reduces (f64 advantage sums per update, f32 gradient per optimizer step) on the compute stream;
+    at world size 1 they are identities.  The only arithmetic difference is where the gradient's sum of squares is
+    taken (inside the reduce kernel without a communicator, in its own pass after the all-reduce with one), i.e. a
+    different f32 summation order of the global norm: parameters agree to rounding, not bitwise."""
+    from backends import get_backend
+
+    be = get_backend("hip")
+    cfg = _cfg("training.num_envs=256", "training.num_minibatches=8", "training.update_epochs=2", "training.total_timesteps=100000000")
+    res = []
+    for force in ("0", "1"):
+        monkeypatch.setenv("MPPO_FORCE_COMM", force)
+        tr = be.trainer(cfg, use_graph=False)
+        tr.init_comm()
+        tr.reset()
+        for _ in range(2):
+            tr.update()
+        res.append(tr.params_flat())
+        tr.close()
+    assert np.isfinite(res[1]).all()
+    np.testing.assert_allclose(res[0], res[1], rtol=1e-4, atol=1e-6)
