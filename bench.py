@@ -129,6 +129,12 @@ def cpu_baseline(config_name: str, n_envs: int):
 
 def main() -> None:
     args = parse()
+    # The contract is ONE JSON line on stdout.  RCCL prints a version banner through C stdio on stdout (flushed at
+    # exit, i.e. AFTER anything Python printed), so fd 1 is pointed at stderr for the life of the process and the JSON
+    # line is written to the saved descriptor.
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     import torch
     import torch.distributed as dist
 
@@ -180,6 +186,14 @@ def main() -> None:
     if rank == 0:
         sec, flops, desc = rowpass_probe(tr)
         achieved = flops / sec / 1e12
+        # HBM-side bytes per launch of the roofline kernel: PMC counters need rocprofv3 around the process, so they are
+        # collected by tools/gpu_traffic.sh (separate FETCH_SIZE / WRITE_SIZE passes, gfx950 x2 fetch correction) and
+        # the committed summary is read here; null when the workload is not the one the summary was taken on.
+        traffic, traffic_src = None, None
+        tf = ROOT / "profiles" / "r01_d_hbm_traffic.json"
+        if tf.exists() and args.config == "stompy_pro" and args.envs_per_gpu == 4096:
+            traffic = json.loads(tf.read_text())["kernels"]["fused_mlp_kernel"]["hbm_bytes_per_launch"]
+            traffic_src = "profiles/r01_d_hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, corrected)"
         out = {
             "metric": "env-steps/sec (whole node), stompy_pro 4096 envs, 1/2/4/8 MI355X",
             "value": steps_total / dt,
@@ -197,7 +211,7 @@ def main() -> None:
                        "global_envs": n_global, "parallelism": f"env-sharded dp{world}, RCCL gradient all-reduce per optimizer step" if world > 1 else "single GPU",
                        "hipgraph": bool(not args.no_graph and world == 1)},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_F32_MFMA_TFLOPS,
-                         "traffic": None, "kernel": desc, "us_per_launch": sec * 1e6,
+                         "traffic": traffic, "traffic_unit": "bytes/launch", "traffic_source": traffic_src, "kernel": desc, "us_per_launch": sec * 1e6,
                          "whole_update_mlp_tflops": (26.0 * (2 * tr.O * tr.H + 2 * tr.H * tr.H + tr.H * (tr.A + 1)) + 0.2 * (tr.O * tr.H + tr.H * tr.H + tr.H)) * steps_total / world / dt / 1e12},
             "sanity": {"mean_reward": stats["mean_reward"], "done_fraction": stats["done_fraction"], "mean_total_loss": float(lossm[0])},
         }
@@ -211,7 +225,7 @@ def main() -> None:
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
-        print(json.dumps(out))
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
 
 
 if __name__ == "__main__":
