@@ -98,28 +98,37 @@ __device__ __forceinline__ void stage_mfma(const float* arow, int S, const float
   mfma_f32_16x16x4(a1.w, x0[7], acc0); mfma_f32_16x16x4(a1.w, x1[7], acc1);
 }
 
+// Three-deep register ring over the K stages: stage S+2 is fetched while stage S computes, so a weight fragment has two
+// full MFMA blocks (about 2000 cycles with two waves per SIMD) to arrive from L2.  The first two stages are requested by
+// prefetch(), which the kernel calls one phase EARLY (weights depend on nothing computed here): the fill latency of each
+// GEMM phase hides under the barrier / epilogue / loss code of the phase before it.
 template <bool NT>
-__device__ __forceinline__ void tile_gemm(const float* At, int AS, int K, int Kvalid, const float* W, int H, int n0, int lane, f32x4& acc0, f32x4& acc1) {
-  const int j = lane & 15, kq = lane >> 4;
-  const float* arow = At + j * AS + 4 * kq;
-  const int nst = K / 32;
-  // three-deep register ring: stage S+2 is fetched while stage S computes, so a weight fragment has two full MFMA blocks
-  // (about 2000 cycles with two waves per SIMD) to arrive from L2.  Invariant at the loop top: b0 = stage S, b1 = stage S+1.
-  BStage<NT> b0, b1, b2;
-  b0.load(W, H, K, 0, n0, j, kq, Kvalid);
-  if (nst > 1) b1.load(W, H, K, 1, n0, j, kq, Kvalid);
-  int S = 0;
-  for (; S + 2 < nst; S += 3) {
-    b2.load(W, H, K, S + 2, n0, j, kq, Kvalid);
-    stage_mfma(arow, S, b0.x0, b0.x1, acc0, acc1);
-    if (S + 3 < nst) b0.load(W, H, K, S + 3, n0, j, kq, Kvalid);
-    stage_mfma(arow, S + 1, b1.x0, b1.x1, acc0, acc1);
-    if (S + 4 < nst) b1.load(W, H, K, S + 4, n0, j, kq, Kvalid);
-    stage_mfma(arow, S + 2, b2.x0, b2.x1, acc0, acc1);
+struct GemmPipe {
+  BStage<NT> b0, b1;
+  __device__ __forceinline__ void prefetch(int K, int Kvalid, const float* W, int H, int n0, int lane) {
+    const int j = lane & 15, kq = lane >> 4;
+    b0.load(W, H, K, 0, n0, j, kq, Kvalid);
+    if (K > 32) b1.load(W, H, K, 1, n0, j, kq, Kvalid);
   }
-  if (S < nst) stage_mfma(arow, S, b0.x0, b0.x1, acc0, acc1);
-  if (S + 1 < nst) stage_mfma(arow, S + 1, b1.x0, b1.x1, acc0, acc1);
-}
+  // invariant at the loop top: b0 = stage S, b1 = stage S+1
+  __device__ __forceinline__ void run(const float* At, int AS, int K, int Kvalid, const float* W, int H, int n0, int lane, f32x4& acc0, f32x4& acc1) {
+    const int j = lane & 15, kq = lane >> 4;
+    const float* arow = At + j * AS + 4 * kq;
+    const int nst = K / 32;
+    BStage<NT> b2;
+    int S = 0;
+    for (; S + 2 < nst; S += 3) {
+      b2.load(W, H, K, S + 2, n0, j, kq, Kvalid);
+      stage_mfma(arow, S, b0.x0, b0.x1, acc0, acc1);
+      if (S + 3 < nst) b0.load(W, H, K, S + 3, n0, j, kq, Kvalid);
+      stage_mfma(arow, S + 1, b1.x0, b1.x1, acc0, acc1);
+      if (S + 4 < nst) b1.load(W, H, K, S + 4, n0, j, kq, Kvalid);
+      stage_mfma(arow, S + 2, b2.x0, b2.x1, acc0, acc1);
+    }
+    if (S < nst) stage_mfma(arow, S, b0.x0, b0.x1, acc0, acc1);
+    if (S + 1 < nst) stage_mfma(arow, S + 1, b1.x0, b1.x1, acc0, acc1);
+  }
+};
 
 template <int LRW>
 __device__ __forceinline__ float row32_sum(float x) {
@@ -155,6 +164,37 @@ __global__ void __launch_bounds__(512) fused_mlp_kernel(FusedArgs a) {
   const float* B3 = a.params + (net ? a.L.c_b3 : a.L.a_b3);
   const int nout = net ? 1 : A;
 
+  const int n0 = 32 * wave;
+  const int cj = lane & 15, rq = lane >> 4;
+  // ---- everything that depends on nothing computed here is requested now and consumed phases later: the first two
+  // weight stages of layer 1, the biases, and the per-row scalars of the loss (index -> action / log_prob / advantage /
+  // value / target: a dependent HBM chain of ~3 us that would otherwise sit between the head GEMM and the loss) ----
+  GemmPipe<false> pipe1;
+  pipe1.prefetch(KP, O, W1, H, n0, lane);
+  const float2 bz1 = *reinterpret_cast<const float2*>(B1 + n0 + 2 * cj), bz2 = *reinterpret_cast<const float2*>(B2 + n0 + 2 * cj);
+  const float adv_mean = a.adv_stat[0], adv_rstd = a.adv_stat[1];
+  const float ls = (net == 0 && cj < A) ? a.params[a.L.log_std + cj] : 0.f;
+  const float b3v = cj < nout ? B3[cj] : 0.f;
+  long prow[4];
+  float pf0[4], pf1[4], pf2[4];  // actor: action[o], old log_prob, advantage | critic: old value, target, -
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int i = row0 + 4 * rq + r;
+    const bool on = i < a.mb;
+    prow[r] = on ? (a.idx ? (long)a.idx[i] : (long)i) : 0;
+    pf0[r] = pf1[r] = pf2[r] = 0.f;
+    if (on) {
+      if (net == 0) {
+        if (cj < A) pf0[r] = a.b.action[prow[r] * a.b.act_ld + cj];
+        pf1[r] = a.b.log_prob[prow[r]];
+        pf2[r] = a.b.adv[prow[r]];
+      } else {
+        pf0[r] = a.b.value[prow[r]];
+        pf1[r] = a.b.target[prow[r]];
+      }
+    }
+  }
+
   // ---- P0: gathered observation rows -> LDS (zero-padded to KP columns); the actor workgroup also writes xmb ----
   for (int e = t; e < FRT * (KP / 4); e += nthr) {
     const int r = e / (KP / 4), c4 = (e % (KP / 4)) * 4;
@@ -168,23 +208,27 @@ __global__ void __launch_bounds__(512) fused_mlp_kernel(FusedArgs a) {
   for (int e = t; e < H * nout; e += nthr) w3s[e] = W3[e];
   __syncthreads();
 
-  const int n0 = 32 * wave;
-  const int cj = lane & 15, rq = lane >> 4;
   // ---- P1 / P2: hidden layers ----
+  GemmPipe<false> pipe2;
+  GemmPipe<true> pipe5;
   for (int layer = 0; layer < 2; ++layer) {
     f32x4 acc0, acc1;
     for (int r = 0; r < 4; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
-    if (layer == 0) { if (!(a.skip & 1)) tile_gemm<false>(xt, XS, KP, O, W1, H, n0, lane, acc0, acc1); }
-    else if (!(a.skip & 2)) tile_gemm<false>(h1t, HS, H, H, W2, H, n0, lane, acc0, acc1);
-    const float* bias = layer == 0 ? B1 : B2;
+    if (layer == 0) {
+      if (!(a.skip & 1)) pipe1.run(xt, XS, KP, O, W1, H, n0, lane, acc0, acc1);
+      pipe2.prefetch(H, H, W2, H, n0, lane);  // arrives during the epilogue + barrier below
+    } else {
+      if (!(a.skip & 2)) pipe2.run(h1t, HS, H, H, W2, H, n0, lane, acc0, acc1);
+      pipe5.prefetch(H, H, W2, H, n0, lane);  // W2^T fragments of the backward product: hidden under heads / loss / dZ2
+    }
     float* ht = layer == 0 ? h1t : h2t;
     float* hg = layer == 0 ? a.h1[net] : a.h2[net];
-    const int c0 = n0 + 2 * cj, c1 = c0 + 1;  // the wave's two interleaved column tiles
-    const float bz0 = bias[c0], bz1 = bias[c1];
+    const int c0 = n0 + 2 * cj;  // the wave's two interleaved column tiles: c0, c0 + 1
+    const float2 bz = layer == 0 ? bz1 : bz2;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int rr = 4 * rq + r;
-      float v0 = acc0[r] + bz0, v1 = acc1[r] + bz1;
+      float v0 = acc0[r] + bz.x, v1 = acc1[r] + bz.y;
       if (tanh_act) { v0 = fused_tanh(v0); v1 = fused_tanh(v1); } else { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); }
       *reinterpret_cast<float2*>(ht + rr * HS + c0) = make_float2(v0, v1);
       if (row0 + rr < a.mb && !(a.skip & 32)) *reinterpret_cast<float2*>(hg + (size_t)(row0 + rr) * H + c0) = make_float2(v0, v1);
@@ -224,25 +268,21 @@ __global__ void __launch_bounds__(512) fused_mlp_kernel(FusedArgs a) {
     const int o = cj;
     const bool st = wave == 0;
     if (net == 0) {
-      const float ls = o < A ? a.params[a.L.log_std + o] : 0.f;
       const float inv_std = __expf(-ls);
       const float sum_ls = group16_sum(ls);
-      const float b3v = o < A ? B3[o] : 0.f;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int rr = 4 * rq + r, i = row0 + rr;
         const bool on = i < a.mb;
-        long row = 0;
-        if (on) row = a.idx ? a.idx[i] : i;
         const float mean = out[r] + b3v;
         float z = 0.f;
-        if (on && o < A) z = (a.b.action[row * a.b.act_ld + o] - mean) * inv_std;
+        if (on && o < A) z = (pf0[r] - mean) * inv_std;
         const float ss = group16_sum(z * z);
         float la = 0.f, dlogp = 0.f;
         if (on) {
           const float logp = -0.5f * ss - sum_ls - 0.5f * (float)A * kLog2PiF;
-          const float ratio = __expf(logp - a.b.log_prob[row]);
-          const float g = (a.b.adv[row] - a.adv_stat[0]) * a.adv_stat[1];
+          const float ratio = __expf(logp - pf1[r]);
+          const float g = (pf2[r] - adv_mean) * adv_rstd;
           const float la1 = ratio * g;
           const float la2 = fminf(fmaxf(ratio, 1.f - a.lc.clip_eps), 1.f + a.lc.clip_eps) * g;
           la = -fminf(la1, la2) * a.inv_count;
@@ -258,17 +298,15 @@ __global__ void __launch_bounds__(512) fused_mlp_kernel(FusedArgs a) {
         }
       }
     } else {
-      const float b3v = B3[0];
+      const float b3c = group16_sum(b3v);  // lane o = 0 holds the critic's single output bias
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int rr = 4 * rq + r, i = row0 + rr;
         const bool on = i < a.mb;
-        long row = 0;
-        if (on) row = a.idx ? a.idx[i] : i;
-        const float vnew = group16_sum(o == 0 ? out[r] : 0.f) + b3v;
+        const float vnew = group16_sum(o == 0 ? out[r] : 0.f) + b3c;
         float lv = 0.f, dv = 0.f;
         if (on) {
-          const float ov = a.b.value[row], tg = a.b.target[row];
+          const float ov = pf0[r], tg = pf1[r];
           const float vc = ov + fminf(fmaxf(vnew - ov, -a.lc.clip_eps), a.lc.clip_eps);
           const float vl1 = (vnew - tg) * (vnew - tg), vl2 = (vc - tg) * (vc - tg);
           lv = 0.5f * fmaxf(vl1, vl2) * a.inv_count;
@@ -324,7 +362,7 @@ __global__ void __launch_bounds__(512) fused_mlp_kernel(FusedArgs a) {
   {
     f32x4 acc0, acc1;
     for (int r = 0; r < 4; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
-    if (!(a.skip & 16)) tile_gemm<true>(dzt, HS, H, H, W2, H, n0, lane, acc0, acc1);
+    if (!(a.skip & 16)) pipe5.run(dzt, HS, H, H, W2, H, n0, lane, acc0, acc1);
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int rr = 4 * rq + r;
