@@ -189,6 +189,7 @@ def main() -> None:
         # HBM-side bytes per launch of the roofline kernel: PMC counters need rocprofv3 around the process, so they are
         # collected by tools/gpu_traffic.sh (separate FETCH_SIZE / WRITE_SIZE passes, gfx950 x2 fetch correction) and
         # the committed summary is read here; null when the workload is not the one the summary was taken on.
+        baseline_cfg = {"stompy_pro": "BASELINE configs[1]; configs[2] at 8 GPUs", "stompy_full": "BASELINE configs[4]"}.get(args.config, "not a BASELINE config")
         traffic, traffic_src = None, None
         tf = ROOT / "profiles" / "r01_d_hbm_traffic.json"
         if tf.exists() and args.config == "stompy_pro" and args.envs_per_gpu == 4096:
@@ -206,8 +207,8 @@ def main() -> None:
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": "f32",
-            "data": "synthetic (stand-in robot synth_stompy_pro, random-init weights, Philox action noise)",
-            "config": {"workload": f"{args.config}: {args.envs_per_gpu} envs/GPU x T={tr.T} rollout + {tr.E}x{tr.M} minibatch PPO update, O={tr.O} A={tr.A} H={tr.H}, fp32 (BASELINE configs[1]; configs[2] at 8 GPUs)",
+            "data": f"synthetic (stand-in robot {cfg.kscale_id}, random-init weights, Philox action noise)",
+            "config": {"workload": f"{args.config}: {args.envs_per_gpu} envs/GPU x T={tr.T} rollout + {tr.E}x{tr.M} minibatch PPO update, O={tr.O} A={tr.A} H={tr.H}, fp32 ({baseline_cfg})",
                        "global_envs": n_global, "parallelism": f"env-sharded dp{world}, RCCL gradient all-reduce per optimizer step" if world > 1 else "single GPU",
                        "hipgraph": bool(not args.no_graph and world == 1)},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_F32_MFMA_TFLOPS,
