@@ -35,6 +35,7 @@ if str(ROOT) not in sys.path:
     sys.path.insert(0, str(ROOT))
 
 PEAK_F32_MFMA_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md: "Peak FP32 (matrix)"
+PEAK_BF16_MFMA_TFLOPS = 2500.0  # same guide: dense bf16 MFMA ~2.5 PFLOP/s (no sparsity)
 
 
 def parse() -> argparse.Namespace:
@@ -44,6 +45,7 @@ def parse() -> argparse.Namespace:
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--envs-per-gpu", type=int, default=4096)
     ap.add_argument("--config", default="stompy_pro")
+    ap.add_argument("--set", action="append", default=[], metavar="KEY=VALUE", help="config override (dot-list), e.g. training.mlp_dtype=bf16")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-envs", type=int, default=4096)
@@ -91,7 +93,7 @@ def rowpass_probe(tr, launches: int = 50, replays: int = 4):
     O, A, H = tr.O, tr.A, tr.H
     macs_row = (2 * O * H + 2 * H * H + H * (A + 1)) + (2 * H * H + H * (A + 1))  # forward (both nets) + dZ2, dZ1 (both nets)
     flops = 2.0 * macs_row * mb
-    return sec, flops, f"fused_mlp_kernel: row pass of one minibatch (mb={mb}, O={O}, H={H}, A={A}, actor+critic; f32 MFMA 16x16x4)"
+    return sec, flops, f"fused_mlp_kernel: row pass of one minibatch (mb={mb}, O={O}, H={H}, A={A}, actor+critic; {'bf16 MFMA 16x16x16, f32 accumulate' if tr.net.bf16 else 'f32 MFMA 16x16x4'})"
 
 
 def cpu_baseline(config_name: str, n_envs: int):
@@ -154,7 +156,7 @@ def main() -> None:
     from minppo_amd.train import Trainer
 
     n_global = args.envs_per_gpu * world
-    cfg = load_config_from_cli([args.config, f"training.num_envs={n_global}"])
+    cfg = load_config_from_cli([args.config, f"training.num_envs={n_global}", *args.set])
     tr = Trainer(cfg, device=f"cuda:{local_rank}", rank=rank, world_size=world, use_graph=not args.no_graph)
     tr.init_comm()
     tr.reset()
@@ -190,9 +192,13 @@ def main() -> None:
         # collected by tools/gpu_traffic.sh (separate FETCH_SIZE / WRITE_SIZE passes, gfx950 x2 fetch correction) and
         # the committed summary is read here; null when the workload is not the one the summary was taken on.
         baseline_cfg = {"stompy_pro": "BASELINE configs[1]; configs[2] at 8 GPUs", "stompy_full": "BASELINE configs[4]"}.get(args.config, "not a BASELINE config")
+        bf16 = cfg.training.mlp_dtype == "bf16"
+        if bf16:
+            baseline_cfg = "BASELINE configs[3]" if args.config == "stompy_pro" else baseline_cfg + ", bf16 MFMA"
+        peak = PEAK_BF16_MFMA_TFLOPS if bf16 else PEAK_F32_MFMA_TFLOPS
         traffic, traffic_src = None, None
         tf = ROOT / "profiles" / "r01_d_hbm_traffic.json"
-        if tf.exists() and args.config == "stompy_pro" and args.envs_per_gpu == 4096:
+        if tf.exists() and args.config == "stompy_pro" and args.envs_per_gpu == 4096 and not bf16:
             traffic = json.loads(tf.read_text())["kernels"]["fused_mlp_kernel"]["hbm_bytes_per_launch"]
             traffic_src = "profiles/r01_d_hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, corrected)"
         out = {
@@ -206,12 +212,12 @@ def main() -> None:
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f32",
-            "data": f"synthetic (stand-in robot {cfg.kscale_id}, random-init weights, Philox action noise)",
-            "config": {"workload": f"{args.config}: {args.envs_per_gpu} envs/GPU x T={tr.T} rollout + {tr.E}x{tr.M} minibatch PPO update, O={tr.O} A={tr.A} H={tr.H}, fp32 ({baseline_cfg})",
+            "dtype": "bf16" if bf16 else "f32",
+            "data": f"synthetic (stand-in robot {tr.cm.name}, random-init weights, Philox action noise)",
+            "config": {"workload": f"{args.config}: {args.envs_per_gpu} envs/GPU x T={tr.T} rollout + {tr.E}x{tr.M} minibatch PPO update, O={tr.O} A={tr.A} H={tr.H}, {'bf16-in/f32-acc MLP products, f32 elsewhere' if bf16 else 'fp32'} ({baseline_cfg})",
                        "global_envs": n_global, "parallelism": f"env-sharded dp{world}, RCCL gradient all-reduce per optimizer step" if world > 1 else "single GPU",
                        "hipgraph": bool(not args.no_graph and world == 1)},
-            "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_F32_MFMA_TFLOPS,
+            "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
                          "traffic": traffic, "traffic_unit": "bytes/launch", "traffic_source": traffic_src, "kernel": desc, "us_per_launch": sec * 1e6,
                          "whole_update_mlp_tflops": (26.0 * (2 * tr.O * tr.H + 2 * tr.H * tr.H + tr.H * (tr.A + 1)) + 0.2 * (tr.O * tr.H + tr.H * tr.H + tr.H)) * steps_total / world / dt / 1e12},
             "sanity": {"mean_reward": stats["mean_reward"], "done_fraction": stats["done_fraction"], "mean_total_loss": float(lossm[0])},

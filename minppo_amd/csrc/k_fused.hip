@@ -85,9 +85,20 @@ struct BStage {
   }
 };
 
+// BF16: a lane's four consecutive k's (the float4 it already holds) are one operand of v_mfma_f32_16x16x16_bf16: the same
+// registers, rounded to bf16, feed 4 MFMAs instead of 16 (f32 accumulate).
+template <bool BF16>
 __device__ __forceinline__ void stage_mfma(const float* arow, int S, const float (&x0)[8], const float (&x1)[8], f32x4& acc0, f32x4& acc1) {
   const float4 a0 = *reinterpret_cast<const float4*>(arow + 32 * S);
   const float4 a1 = *reinterpret_cast<const float4*>(arow + 32 * S + 16);
+  if (BF16) {
+    const bf16x4 A0 = pack_bf16x4(a0.x, a0.y, a0.z, a0.w), A1 = pack_bf16x4(a1.x, a1.y, a1.z, a1.w);
+    mfma_bf16_16x16x16(A0, pack_bf16x4(x0[0], x0[1], x0[2], x0[3]), acc0);
+    mfma_bf16_16x16x16(A0, pack_bf16x4(x1[0], x1[1], x1[2], x1[3]), acc1);
+    mfma_bf16_16x16x16(A1, pack_bf16x4(x0[4], x0[5], x0[6], x0[7]), acc0);
+    mfma_bf16_16x16x16(A1, pack_bf16x4(x1[4], x1[5], x1[6], x1[7]), acc1);
+    return;
+  }
   mfma_f32_16x16x4(a0.x, x0[0], acc0); mfma_f32_16x16x4(a0.x, x1[0], acc1);
   mfma_f32_16x16x4(a0.y, x0[1], acc0); mfma_f32_16x16x4(a0.y, x1[1], acc1);
   mfma_f32_16x16x4(a0.z, x0[2], acc0); mfma_f32_16x16x4(a0.z, x1[2], acc1);
@@ -111,6 +122,7 @@ struct GemmPipe {
     if (K > 32) b1.load(W, H, K, 1, n0, j, kq, Kvalid);
   }
   // invariant at the loop top: b0 = stage S, b1 = stage S+1
+  template <bool BF16>
   __device__ __forceinline__ void run(const float* At, int AS, int K, int Kvalid, const float* W, int H, int n0, int lane, f32x4& acc0, f32x4& acc1) {
     const int j = lane & 15, kq = lane >> 4;
     const float* arow = At + j * AS + 4 * kq;
@@ -119,14 +131,14 @@ struct GemmPipe {
     int S = 0;
     for (; S + 2 < nst; S += 3) {
       b2.load(W, H, K, S + 2, n0, j, kq, Kvalid);
-      stage_mfma(arow, S, b0.x0, b0.x1, acc0, acc1);
+      stage_mfma<BF16>(arow, S, b0.x0, b0.x1, acc0, acc1);
       if (S + 3 < nst) b0.load(W, H, K, S + 3, n0, j, kq, Kvalid);
-      stage_mfma(arow, S + 1, b1.x0, b1.x1, acc0, acc1);
+      stage_mfma<BF16>(arow, S + 1, b1.x0, b1.x1, acc0, acc1);
       if (S + 4 < nst) b1.load(W, H, K, S + 4, n0, j, kq, Kvalid);
-      stage_mfma(arow, S + 2, b2.x0, b2.x1, acc0, acc1);
+      stage_mfma<BF16>(arow, S + 2, b2.x0, b2.x1, acc0, acc1);
     }
-    if (S < nst) stage_mfma(arow, S, b0.x0, b0.x1, acc0, acc1);
-    if (S + 1 < nst) stage_mfma(arow, S + 1, b1.x0, b1.x1, acc0, acc1);
+    if (S < nst) stage_mfma<BF16>(arow, S, b0.x0, b0.x1, acc0, acc1);
+    if (S + 1 < nst) stage_mfma<BF16>(arow, S + 1, b1.x0, b1.x1, acc0, acc1);
   }
 };
 
@@ -137,6 +149,7 @@ __device__ __forceinline__ float row32_sum(float x) {
   return x;
 }
 
+template <bool BF16>
 __global__ void __launch_bounds__(512) fused_mlp_kernel(FusedArgs a) {
   MPPO_DYN_SMEM(smem_raw);
   float* sm = reinterpret_cast<float*>(smem_raw);
@@ -215,10 +228,10 @@ __global__ void __launch_bounds__(512) fused_mlp_kernel(FusedArgs a) {
     f32x4 acc0, acc1;
     for (int r = 0; r < 4; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
     if (layer == 0) {
-      if (!(a.skip & 1)) pipe1.run(xt, XS, KP, O, W1, H, n0, lane, acc0, acc1);
+      if (!(a.skip & 1)) pipe1.template run<BF16>(xt, XS, KP, O, W1, H, n0, lane, acc0, acc1);
       pipe2.prefetch(H, H, W2, H, n0, lane);  // arrives during the epilogue + barrier below
     } else {
-      if (!(a.skip & 2)) pipe2.run(h1t, HS, H, H, W2, H, n0, lane, acc0, acc1);
+      if (!(a.skip & 2)) pipe2.template run<BF16>(h1t, HS, H, H, W2, H, n0, lane, acc0, acc1);
       pipe5.prefetch(H, H, W2, H, n0, lane);  // W2^T fragments of the backward product: hidden under heads / loss / dZ2
     }
     float* ht = layer == 0 ? h1t : h2t;
@@ -362,7 +375,7 @@ __global__ void __launch_bounds__(512) fused_mlp_kernel(FusedArgs a) {
   {
     f32x4 acc0, acc1;
     for (int r = 0; r < 4; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
-    if (!(a.skip & 16)) pipe5.run(dzt, HS, H, H, W2, H, n0, lane, acc0, acc1);
+    if (!(a.skip & 16)) pipe5.template run<BF16>(dzt, HS, H, H, W2, H, n0, lane, acc0, acc1);
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int rr = 4 * rq + r;
@@ -384,7 +397,7 @@ size_t fused_smem_bytes(int O, int A, int H) {
 }
 
 bool fused_supported(const mppo_net_t& net, const mppo_batch_t& b) {
-  return net.H % 32 == 0 && net.H >= 32 && net.H <= 512 && net.A <= 16 && net.bf16 == 0 && b.obs_ld == net.OP && (net.OP % 4) == 0 &&
+  return net.H % 32 == 0 && net.H >= 32 && net.H <= 512 && net.A <= 16 && b.obs_ld == net.OP && (net.OP % 4) == 0 &&
          (reinterpret_cast<uintptr_t>(b.obs) & 15) == 0 && fused_smem_bytes(net.O, net.A, net.H) <= 160 * 1024 &&
          (param_layout(net.O, net.A, net.H).c_w2 % 4) == 0;  // float4 rows of W2 in the backward product
 }
@@ -401,10 +414,12 @@ int32_t fused_forward_backward(const mppo_net_t& net, const float* params, const
   const size_t smem = fused_smem_bytes(net.O, net.A, net.H);
   static thread_local size_t attr_for = 0;
   if (smem > 64 * 1024 && attr_for < smem) {
-    MPPO_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(fused_mlp_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+    MPPO_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(fused_mlp_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+    MPPO_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(fused_mlp_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
     attr_for = smem;
   }
-  hipLaunchKernelGGL(fused_mlp_kernel, dim3(cdiv(mb, FRT), 2), dim3(2 * net.H), smem, stream, a);
+  if (net.bf16) hipLaunchKernelGGL(fused_mlp_kernel<true>, dim3(cdiv(mb, FRT), 2), dim3(2 * net.H), smem, stream, a);
+  else hipLaunchKernelGGL(fused_mlp_kernel<false>, dim3(cdiv(mb, FRT), 2), dim3(2 * net.H), smem, stream, a);
   MPPO_CHECK_LAUNCH("fused_mlp_kernel");
   return MPPO_OK;
 }

@@ -107,8 +107,23 @@ __device__ __forceinline__ float fast_tanh(float x) {
   return 1.f - __fdividef(2.f, e + 1.f);
 }
 
+// One k-set (32 k's) of a wave's 32x32 tile.  f32: 16 x v_mfma_f32_32x32x2_f32.  BF16: the lane's four consecutive k's of a
+// group (k = 8g + 4h + c) are exactly the operand of v_mfma_f32_32x32x8_bf16, so the same registers feed 4 MFMAs after
+// rounding to bf16 (round to nearest even), f32 accumulate.
+template <bool BF16>
+__device__ __forceinline__ void mfma_set(const float (&a)[16], const float (&b)[16], f32x16& acc) {
+  if (BF16) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+      mfma_bf16_32x32x8(pack_bf16x4(a[4 * g], a[4 * g + 1], a[4 * g + 2], a[4 * g + 3]), pack_bf16x4(b[4 * g], b[4 * g + 1], b[4 * g + 2], b[4 * g + 3]), acc);
+  } else {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) mfma_f32_32x32x2(a[i], b[i], acc);
+  }
+}
+
 // Direct variant for the k-contiguous-A products (forward NN, backward NT).
-template <bool B_T, int EPI>
+template <bool B_T, int EPI, bool BF16>
 __global__ void __launch_bounds__(GEMM_THREADS) gemm_kernel(GemmBatch gb) {
   const int z = blockIdx.z;
   const GemmProb p = gb.p[z];
@@ -146,40 +161,39 @@ __global__ void __launch_bounds__(GEMM_THREADS) gemm_kernel(GemmBatch gb) {
     for (; sidx + 1 < nfull; sidx += 2) {
       ak.load(a1, sidx * KS);
       if (B_T) bk.load(b1, sidx * KS); else br.load(b1, sidx * KS);
-#pragma unroll
-      for (int i = 0; i < 16; ++i) mfma_f32_32x32x2(a0[i], b0[i], acc);
-      if (B_T) { MPPO_INTERLEAVE_MFMA16(1, 1) } else { MPPO_INTERLEAVE_MFMA16(2, 2) }
+      mfma_set<BF16>(a0, b0, acc);
+      if (!BF16) { if (B_T) { MPPO_INTERLEAVE_MFMA16(1, 1) } else { MPPO_INTERLEAVE_MFMA16(2, 2) } }
       copy_out(a0, (sidx - 1) * KS);
       ak.load(a0, (sidx + 1) * KS);
       if (B_T) bk.load(b0, (sidx + 1) * KS); else br.load(b0, (sidx + 1) * KS);
-#pragma unroll
-      for (int i = 0; i < 16; ++i) mfma_f32_32x32x2(a1[i], b1[i], acc);
-      if (B_T) { MPPO_INTERLEAVE_MFMA16(1, 1) } else { MPPO_INTERLEAVE_MFMA16(2, 2) }
+      mfma_set<BF16>(a1, b1, acc);
+      if (!BF16) { if (B_T) { MPPO_INTERLEAVE_MFMA16(1, 1) } else { MPPO_INTERLEAVE_MFMA16(2, 2) } }
       copy_out(a1, sidx * KS);
     }
     if (sidx < nfull) {  // one more set to fetch
       ak.load(a1, sidx * KS);
       if (B_T) bk.load(b1, sidx * KS); else br.load(b1, sidx * KS);
-#pragma unroll
-      for (int i = 0; i < 16; ++i) mfma_f32_32x32x2(a0[i], b0[i], acc);
-      if (B_T) { MPPO_INTERLEAVE_MFMA16(1, 1) } else { MPPO_INTERLEAVE_MFMA16(2, 2) }
+      mfma_set<BF16>(a0, b0, acc);
+      if (!BF16) { if (B_T) { MPPO_INTERLEAVE_MFMA16(1, 1) } else { MPPO_INTERLEAVE_MFMA16(2, 2) } }
       copy_out(a0, (sidx - 1) * KS);
-#pragma unroll
-      for (int i = 0; i < 16; ++i) mfma_f32_32x32x2(a1[i], b1[i], acc);
+      mfma_set<BF16>(a1, b1, acc);
       copy_out(a1, sidx * KS);
     } else {
-#pragma unroll
-      for (int i = 0; i < 16; ++i) mfma_f32_32x32x2(a0[i], b0[i], acc);
+      mfma_set<BF16>(a0, b0, acc);
       copy_out(a0, (sidx - 1) * KS);
     }
   }
   if (tail > 0) {
     ak.load_tail(a0, nfull * KS, K, hi);
     if (B_T) bk.load_tail(b0, nfull * KS, K, hi); else br.load_tail(b0, nfull * KS, hi);
-    const int nm = (tail + 7) / 8 * 4;  // MFMAs that can carry data (groups of 8 k's)
+    if (BF16) {
+      mfma_set<true>(a0, b0, acc);  // zeros beyond the tail
+    } else {
+      const int nm = (tail + 7) / 8 * 4;  // MFMAs that can carry data (groups of 8 k's)
 #pragma unroll
-    for (int i = 0; i < 16; ++i)
-      if (i < nm) mfma_f32_32x32x2(a0[i], b0[i], acc);
+      for (int i = 0; i < 16; ++i)
+        if (i < nm) mfma_f32_32x32x2(a0[i], b0[i], acc);
+    }
     if (acopy) {  // tail columns (zeros past K keep the copy's padding clean up to the row stride)
 #pragma unroll
       for (int g = 0; g < 4; ++g)
@@ -217,6 +231,7 @@ __global__ void __launch_bounds__(GEMM_THREADS) gemm_kernel(GemmBatch gb) {
 // Direct variant of the weight-gradient product C[M,N] = A^T . B with A stored [K,M] and B stored [K,N] (K = samples,
 // no gather: the minibatch rows were laid out contiguously by the forward pass).  Both operands are "r-contiguous":
 // 16 coalesced dword loads per operand and k-set, uniform base + 32-bit lane offset.  Split-K over blockIdx.z.
+template <bool BF16>
 __global__ void __launch_bounds__(GEMM_THREADS) gemm_tn_kernel(GemmBatch gb) {
   const int z = blockIdx.z;
   const int pi = z / gb.ksplit, ks = z - pi * gb.ksplit;
@@ -243,30 +258,36 @@ __global__ void __launch_bounds__(GEMM_THREADS) gemm_tn_kernel(GemmBatch gb) {
     int sidx = 1;
     for (; sidx + 1 < nfull; sidx += 2) {
       ar.load(a1, kb + sidx * KS); br.load(b1, kb + sidx * KS);
+      mfma_set<BF16>(a0, b0, acc);
 #pragma unroll
-      for (int i = 0; i < 16; ++i) { mfma_f32_32x32x2(a0[i], b0[i], acc); colsum += b0[i]; }
-      MPPO_INTERLEAVE_MFMA16(3, 2)
+      for (int i = 0; i < 16; ++i) colsum += b0[i];
+      if (!BF16) { MPPO_INTERLEAVE_MFMA16(3, 2) }
       ar.load(a0, kb + (sidx + 1) * KS); br.load(b0, kb + (sidx + 1) * KS);
+      mfma_set<BF16>(a1, b1, acc);
 #pragma unroll
-      for (int i = 0; i < 16; ++i) { mfma_f32_32x32x2(a1[i], b1[i], acc); colsum += b1[i]; }
-      MPPO_INTERLEAVE_MFMA16(3, 2)
+      for (int i = 0; i < 16; ++i) colsum += b1[i];
+      if (!BF16) { MPPO_INTERLEAVE_MFMA16(3, 2) }
     }
     if (sidx < nfull) {
       ar.load(a1, kb + sidx * KS); br.load(b1, kb + sidx * KS);
+      mfma_set<BF16>(a0, b0, acc);
 #pragma unroll
-      for (int i = 0; i < 16; ++i) { mfma_f32_32x32x2(a0[i], b0[i], acc); colsum += b0[i]; }
-      MPPO_INTERLEAVE_MFMA16(3, 2)
+      for (int i = 0; i < 16; ++i) colsum += b0[i];
+      if (!BF16) { MPPO_INTERLEAVE_MFMA16(3, 2) }
+      mfma_set<BF16>(a1, b1, acc);
 #pragma unroll
-      for (int i = 0; i < 16; ++i) { mfma_f32_32x32x2(a1[i], b1[i], acc); colsum += b1[i]; }
+      for (int i = 0; i < 16; ++i) colsum += b1[i];
     } else {
+      mfma_set<BF16>(a0, b0, acc);
 #pragma unroll
-      for (int i = 0; i < 16; ++i) { mfma_f32_32x32x2(a0[i], b0[i], acc); colsum += b0[i]; }
+      for (int i = 0; i < 16; ++i) colsum += b0[i];
     }
   }
   if (tail > 0) {
     ar.load_tail(a0, kb + nfull * KS, hi); br.load_tail(b0, kb + nfull * KS, hi);
+    mfma_set<BF16>(a0, b0, acc);
 #pragma unroll
-    for (int i = 0; i < 16; ++i) { mfma_f32_32x32x2(a0[i], b0[i], acc); colsum += b0[i]; }
+    for (int i = 0; i < 16; ++i) colsum += b0[i];
   }
   float* C = p.C + (size_t)ks * gb.slab_stride;
   const int col = n0 + l31;
@@ -282,7 +303,7 @@ __global__ void __launch_bounds__(GEMM_THREADS) gemm_tn_kernel(GemmBatch gb) {
   }
 }
 
-template <bool B_T, int EPI>
+template <bool B_T, int EPI, bool BF16>
 static int32_t launch_t(const GemmBatch& gb, hipStream_t stream) {
   int maxM = 0, maxN = 0;
   for (int i = 0; i < gb.count; ++i) {
@@ -290,21 +311,7 @@ static int32_t launch_t(const GemmBatch& gb, hipStream_t stream) {
     maxN = gb.p[i].N > maxN ? gb.p[i].N : maxN;
   }
   dim3 grid(cdiv(maxN, BN), cdiv(maxM, BM), gb.count);
-  hipLaunchKernelGGL((gemm_kernel<B_T, EPI>), grid, dim3(GEMM_THREADS), 0, stream, gb);
-  MPPO_CHECK_LAUNCH("gemm_kernel");
-  return MPPO_OK;
-}
-
-template <bool A_T, bool B_T, int EPI>
-static int32_t launch_t(const GemmBatch& gb, hipStream_t stream) {
-  int maxM = 0, maxN = 0;
-  for (int i = 0; i < gb.count; ++i) {
-    const GemmProb& p = gb.p[i];
-    maxM = p.M > maxM ? p.M : maxM;
-    maxN = p.N > maxN ? p.N : maxN;
-  }
-  dim3 grid(cdiv(maxN, BN), cdiv(maxM, BM), gb.count * gb.ksplit);
-  hipLaunchKernelGGL((gemm_kernel<A_T, B_T, EPI>), grid, dim3(GEMM_THREADS), 0, stream, gb);
+  hipLaunchKernelGGL((gemm_kernel<B_T, EPI, BF16>), grid, dim3(GEMM_THREADS), 0, stream, gb);
   MPPO_CHECK_LAUNCH("gemm_kernel");
   return MPPO_OK;
 }
@@ -312,7 +319,6 @@ static int32_t launch_t(const GemmBatch& gb, hipStream_t stream) {
 int32_t gemm_launch(const GemmBatch& gb, int a_t, int b_t, int epi, int bf16, hipStream_t stream) {
   MPPO_REQUIRE(gb.count >= 1 && gb.count <= kGemmMaxProb, "gemm_launch: %d problems", gb.count);
   MPPO_REQUIRE(gb.ksplit >= 1 && (gb.ksplit == 1 || epi == EPI_STORE), "gemm_launch: split-K only with EPI_STORE");
-  MPPO_REQUIRE(bf16 == 0, "gemm_launch: the bf16 MFMA path is not built into this library");
   for (int i = 0; i < gb.count; ++i) {
     const GemmProb& p = gb.p[i];
     MPPO_REQUIRE(p.A && p.B && p.C && p.M >= 1 && p.N >= 1 && p.K >= 1, "gemm_launch: problem %d malformed (M=%d N=%d K=%d)", i, p.M, p.N, p.K);
@@ -324,16 +330,19 @@ int32_t gemm_launch(const GemmBatch& gb, int a_t, int b_t, int epi, int bf16, hi
   // MPPO_GEMM_IMPL = "ddd" / "lll" / ... overrides per variant (d = direct, l = LDS) for A/B measurements.
   static const char* impl = getenv("MPPO_GEMM_IMPL");
   const char choice = (impl && (int)strlen(impl) > v) ? impl[v] : 'd';
-  if (choice == 'l') return gemm_launch_lds(gb, a_t, b_t, epi, stream);
-  if (epi == EPI_BIAS_ACT && v == 0) return launch_t<false, EPI_BIAS_ACT>(gb, stream);
-  if (epi == EPI_DACT && v == 1) return launch_t<true, EPI_DACT>(gb, stream);
+  // bf16-in / f32-accumulate exists for the direct forward and weight-gradient kernels only (the fused row pass covers the rest)
+  if (choice == 'l') { MPPO_REQUIRE(!bf16, "gemm_launch: no bf16 variant of the LDS-staged kernels"); return gemm_launch_lds(gb, a_t, b_t, epi, stream); }
+  if (epi == EPI_BIAS_ACT && v == 0) return bf16 ? launch_t<false, EPI_BIAS_ACT, true>(gb, stream) : launch_t<false, EPI_BIAS_ACT, false>(gb, stream);
+  if (epi == EPI_DACT && v == 1) { MPPO_REQUIRE(!bf16, "gemm_launch: no bf16 variant of the stand-alone backward product"); return launch_t<true, EPI_DACT, false>(gb, stream); }
   if (epi == EPI_STORE && v == 2) {
     bool gathered = false;
     for (int i = 0; i < gb.count; ++i) gathered = gathered || gb.p[i].gather;
-    if (gathered) return gemm_launch_lds(gb, a_t, b_t, epi, stream);  // sample rows by index: LDS-staged kernel
+    if (gathered) { MPPO_REQUIRE(!bf16, "gemm_launch: no bf16 variant of the gathered weight-gradient product"); return gemm_launch_lds(gb, a_t, b_t, epi, stream); }  // rows by index: LDS-staged kernel
     int maxM = 0, maxN = 0;
     for (int i = 0; i < gb.count; ++i) { maxM = gb.p[i].M > maxM ? gb.p[i].M : maxM; maxN = gb.p[i].N > maxN ? gb.p[i].N : maxN; }
-    hipLaunchKernelGGL(gemm_tn_kernel, dim3(cdiv(maxN, BN), cdiv(maxM, BM), gb.count * gb.ksplit), dim3(GEMM_THREADS), 0, stream, gb);
+    const dim3 grid(cdiv(maxN, BN), cdiv(maxM, BM), gb.count * gb.ksplit);
+    if (bf16) hipLaunchKernelGGL(gemm_tn_kernel<true>, grid, dim3(GEMM_THREADS), 0, stream, gb);
+    else hipLaunchKernelGGL(gemm_tn_kernel<false>, grid, dim3(GEMM_THREADS), 0, stream, gb);
     MPPO_CHECK_LAUNCH("gemm_tn_kernel");
     return MPPO_OK;
   }

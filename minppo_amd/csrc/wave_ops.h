@@ -23,6 +23,32 @@ __device__ __forceinline__ void mfma_bf16_32x32x16(bf16x8 a, bf16x8 b, f32x16& a
   acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc, 0, 0, 0);
 }
 
+// ---- bf16-in / f32-accumulate variants (training.mlp_dtype = "bf16", BASELINE configs[3]) ----
+typedef short bf16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x2_native __attribute__((ext_vector_type(2)));
+typedef float f32x2_native __attribute__((ext_vector_type(2)));
+
+// four floats -> four bf16 (round to nearest even; v_cvt_pk_bf16_f32 on gfx950)
+__device__ __forceinline__ bf16x4 pack_bf16x4(float a, float b, float c, float d) {
+  const bf16x2_native lo = __builtin_convertvector(f32x2_native{a, b}, bf16x2_native);
+  const bf16x2_native hi = __builtin_convertvector(f32x2_native{c, d}, bf16x2_native);
+  typedef short short2_native __attribute__((ext_vector_type(2)));
+  const short2_native l = __builtin_bit_cast(short2_native, lo), h = __builtin_bit_cast(short2_native, hi);
+  return bf16x4{l[0], l[1], h[0], h[1]};
+}
+
+// D(16x16) += A(16x16) * B(16x16): lane l supplies A[i = l&15][k = 4*(l>>4) + c] and B[k = 4*(l>>4) + c][j = l&15], c = 0..3;
+// acc[r] is D[row = 4*(l>>4) + r][col = l&15]  (v_mfma_f32_16x16x16_bf16, 8 passes: 4x the k of the f32 16x16x4 per issue slot)
+__device__ __forceinline__ void mfma_bf16_16x16x16(bf16x4 a, bf16x4 b, f32x4& acc) {
+  acc = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a, b, acc, 0, 0, 0);
+}
+
+// D(32x32) += A(32x8) * B(8x32): lane l supplies A[i = l&31][k = 4*(l>>5) + c] and B[k = 4*(l>>5) + c][j = l&31];
+// acc layout as mfma_f32_32x32x2  (v_mfma_f32_32x32x8_bf16)
+__device__ __forceinline__ void mfma_bf16_32x32x8(bf16x4 a, bf16x4 b, f32x16& acc) {
+  acc = __builtin_amdgcn_mfma_f32_32x32x8bf16_1k(a, b, acc, 0, 0, 0);
+}
+
 template <int CTRL>
 __device__ __forceinline__ float dpp_row(float x) {
   return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), CTRL, 0xf, 0xf, false));

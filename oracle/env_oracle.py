@@ -147,14 +147,14 @@ class EnvOracle:
 # ---------------------------------------------------------------------------
 
 
-def rollout(env: EnvOracle, named_params, es: dict, last_obs, noise, use_tanh=True):
+def rollout(env: EnvOracle, named_params, es: dict, last_obs, noise, use_tanh=True, bf16=False):
     """train.py:150-179: T policy/env steps. noise [T,N,A] ~ N(0,1). Returns (es, last_obs, traj)."""
     T = noise.shape[0]
     keys = ("done", "action", "value", "reward", "log_prob", "obs")
     traj = {k: [] for k in keys}
     info = []
     for t in range(T):
-        mean, log_std, value = po.actor_critic_forward(named_params, last_obs, use_tanh)
+        mean, log_std, value = po.actor_critic_forward(named_params, last_obs, use_tanh, bf16=bf16)
         action = po.mvn_sample(mean, log_std, noise[t])
         logp = po.mvn_log_prob(action, mean, log_std)
         es = env.step(es, action)
@@ -171,8 +171,9 @@ def update_step(env: EnvOracle, flat_p, opt: po.OptState, es: dict, last_obs, no
                 num_minibatches, hp: dict, use_tanh=True):
     """One full PPO update. Returns (flat_p, opt, es, last_obs, traj, adv, targets, losses)."""
     named = po.flat_to_named(flat_p, O, A, H)
-    es, last_obs, traj = rollout(env, named, es, last_obs, noise, use_tanh)
-    _, _, last_val = po.actor_critic_forward(named, last_obs, use_tanh)  # train.py:182
+    bf16 = bool(hp.get("mlp_bf16", False))
+    es, last_obs, traj = rollout(env, named, es, last_obs, noise, use_tanh, bf16)
+    _, _, last_val = po.actor_critic_forward(named, last_obs, use_tanh, bf16=bf16)  # train.py:182
     adv, tgt = po.calculate_gae(traj["done"], traj["value"], traj["reward"], last_val, hp["gamma"], hp["gae_lambda"])
     flat_p, opt, losses = po.update_epochs_on_batch(flat_p, opt, traj, adv, tgt, perms, O=O, A=A, H=H,
                                                     num_minibatches=num_minibatches, hp=hp, use_tanh=use_tanh)

@@ -123,16 +123,34 @@ def init_params(seed: int, O: int, A: int, H: int, dtype=np.float64) -> Dict[str
 # ---------------------------------------------------------------------------
 
 
-def actor_critic_forward(p: Dict[str, np.ndarray], x: np.ndarray, use_tanh: bool = True, keep: bool = False):
+def round_bf16(a: np.ndarray) -> np.ndarray:
+    """Round-to-nearest-even to bfloat16 precision (8 significant bits), result in the input's dtype.
+
+    BASELINE configs[3] ("bf16 MLP MFMA path with fp32 GAE/Adam"): the engine feeds its matrix cores bf16 operands and
+    accumulates in f32.  This is the operand rounding, so the oracle can follow the same arithmetic."""
+    a32 = np.ascontiguousarray(a, dtype=np.float32)
+    u = a32.view(np.uint32).astype(np.uint64)
+    u = (u + 0x7FFF + ((u >> 16) & 1)) & 0xFFFF0000
+    return u.astype(np.uint32).view(np.float32).reshape(a32.shape).astype(a.dtype)
+
+
+def _mm(a, b, bf16: bool):
+    """Matrix product of the MLP; with bf16=True both operands are rounded to bf16 first (products and sums stay in the
+    array dtype, like bf16-in / f32-accumulate MFMA)."""
+    return round_bf16(a) @ round_bf16(b) if bf16 else a @ b
+
+
+def actor_critic_forward(p: Dict[str, np.ndarray], x: np.ndarray, use_tanh: bool = True, keep: bool = False, bf16: bool = False):
     """Returns (mean [n,A], log_std [A], value [n]) and, with keep=True, the hidden activations.
 
-    Actor: tanh if use_tanh else relu (train.py:79); critic: always relu (train.py:82, quirk C-4)."""
+    Actor: tanh if use_tanh else relu (train.py:79); critic: always relu (train.py:82, quirk C-4).
+    bf16: operand rounding of the two hidden-layer products (the engine keeps the small output-layer products in f32)."""
     act_a = np.tanh if use_tanh else (lambda z: np.maximum(z, 0))
-    h1a = act_a(x @ p["a_w1"] + p["a_b1"])
-    h2a = act_a(h1a @ p["a_w2"] + p["a_b2"])
+    h1a = act_a(_mm(x, p["a_w1"], bf16) + p["a_b1"])
+    h2a = act_a(_mm(h1a, p["a_w2"], bf16) + p["a_b2"])
     mean = h2a @ p["a_w3"] + p["a_b3"]
-    h1c = np.maximum(x @ p["c_w1"] + p["c_b1"], 0)
-    h2c = np.maximum(h1c @ p["c_w2"] + p["c_b2"], 0)
+    h1c = np.maximum(_mm(x, p["c_w1"], bf16) + p["c_b1"], 0)
+    h2c = np.maximum(_mm(h1c, p["c_w2"], bf16) + p["c_b2"], 0)
     value = (h2c @ p["c_w3"] + p["c_b3"])[..., 0]
     if keep:
         return mean, p["log_std"], value, (h1a, h2a, h1c, h2c)
@@ -192,16 +210,18 @@ class LossOut(NamedTuple):
 
 
 def loss_and_grad(p, obs, action, old_value, old_logp, gae, targets, clip_eps=0.2, vf_coef=0.5, ent_coef=0.0,
-                  use_tanh=True, adv_mean=None, adv_std=None, inv_count=None):
+                  use_tanh=True, adv_mean=None, adv_std=None, inv_count=None, bf16=False):
     """Clipped-PPO loss on one minibatch and d(total)/d(params) as a named dict.
 
     Hand-derived backward (the HIP kernels implement the same formulas); the test-suite
     checks it against torch autograd.  `adv_mean/adv_std/inv_count` override the
     per-minibatch statistics for the sharded (multi-GPU) equivalence test: there the
-    statistics and the 1/mb factor are global over ranks."""
+    statistics and the 1/mb factor are global over ranks.
+    bf16: bf16 operand rounding in the hidden-layer products, the dZ.W2^T back-product and all weight-gradient products
+    (what the engine does with training.mlp_dtype = "bf16"); the output-layer products h2.W3 and dOut.W3^T stay exact."""
     dt = obs.dtype
     n = obs.shape[0]
-    mean, log_std, value, (h1a, h2a, h1c, h2c) = actor_critic_forward(p, obs, use_tanh, keep=True)
+    mean, log_std, value, (h1a, h2a, h1c, h2c) = actor_critic_forward(p, obs, use_tanh, keep=True, bf16=bf16)
     A = action.shape[-1]
     inv_std = np.exp(-log_std)
     z = (action - mean) * inv_std
@@ -241,26 +261,26 @@ def loss_and_grad(p, obs, action, old_value, old_logp, gae, targets, clip_eps=0.
 
     grads = {}
     # actor
-    grads["a_w3"] = h2a.T @ dmean
+    grads["a_w3"] = _mm(h2a.T, dmean, bf16)
     grads["a_b3"] = dmean.sum(0)
     dh2 = dmean @ p["a_w3"].T
     dz2 = dh2 * ((1 - h2a * h2a) if use_tanh else (h2a > 0))
-    grads["a_w2"] = h1a.T @ dz2
+    grads["a_w2"] = _mm(h1a.T, dz2, bf16)
     grads["a_b2"] = dz2.sum(0)
-    dh1 = dz2 @ p["a_w2"].T
+    dh1 = _mm(dz2, p["a_w2"].T, bf16)
     dz1 = dh1 * ((1 - h1a * h1a) if use_tanh else (h1a > 0))
-    grads["a_w1"] = obs.T @ dz1
+    grads["a_w1"] = _mm(obs.T, dz1, bf16)
     grads["a_b1"] = dz1.sum(0)
     grads["log_std"] = dlog_std
     # critic (relu)
     dvo = dv[:, None]
-    grads["c_w3"] = h2c.T @ dvo
+    grads["c_w3"] = _mm(h2c.T, dvo, bf16)
     grads["c_b3"] = dvo.sum(0)
     dz2c = (dvo @ p["c_w3"].T) * (h2c > 0)
-    grads["c_w2"] = h1c.T @ dz2c
+    grads["c_w2"] = _mm(h1c.T, dz2c, bf16)
     grads["c_b2"] = dz2c.sum(0)
-    dz1c = (dz2c @ p["c_w2"].T) * (h1c > 0)
-    grads["c_w1"] = obs.T @ dz1c
+    dz1c = _mm(dz2c, p["c_w2"].T, bf16) * (h1c > 0)
+    grads["c_w1"] = _mm(obs.T, dz1c, bf16)
     grads["c_b1"] = dz1c.sum(0)
     grads = {k: v.astype(dt) for k, v in grads.items()}
     return LossOut(float(total), float(value_loss), float(actor_loss), float(entropy)), grads
@@ -336,7 +356,7 @@ def update_epochs_on_batch(flat_p, opt: OptState, traj: Dict[str, np.ndarray], a
             named = flat_to_named(flat_p, O, A, H)
             lo, grads = loss_and_grad(named, flat["obs"][idx], flat["action"][idx], flat["value"][idx],
                                       flat["log_prob"][idx], adv_f[idx], tgt_f[idx],
-                                      hp["clip_eps"], hp["vf_coef"], hp["ent_coef"], use_tanh)
+                                      hp["clip_eps"], hp["vf_coef"], hp["ent_coef"], use_tanh, bf16=bool(hp.get("mlp_bf16", False)))
             g = named_to_flat(grads, O, A, H)
             flat_p, opt = optimizer_update(flat_p, opt, g, max_grad_norm=hp["max_grad_norm"], anneal_lr=hp["anneal_lr"],
                                            lr_train=hp["lr_train"], lr_opt=hp["lr_opt"], minibatch_size=mb,

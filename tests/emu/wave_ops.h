@@ -46,6 +46,49 @@ inline void mfma_bf16_32x32x16(bf16x8 a, bf16x8 b, f32x16& acc) {
   __syncthreads();
 }
 
+typedef short bf16x4 __attribute__((vector_size(8)));
+inline short emu_f32_to_bf16(float f) {  // round to nearest even
+  unsigned u; memcpy(&u, &f, 4);
+  u += 0x7FFFu + ((u >> 16) & 1u);
+  return (short)(u >> 16);
+}
+inline bf16x4 pack_bf16x4(float a, float b, float c, float d) {
+  bf16x4 r; r[0] = emu_f32_to_bf16(a); r[1] = emu_f32_to_bf16(b); r[2] = emu_f32_to_bf16(c); r[3] = emu_f32_to_bf16(d);
+  return r;
+}
+// lane l supplies A[i = l&15][k = 4*(l>>4) + c], B[k][j = l&15]; acc[r] = D[4*(l>>4) + r][l&15]
+inline void mfma_bf16_16x16x16(bf16x4 a, bf16x4 b, f32x4& acc) {
+  const int t = emu::tid(), lane = t & 63, wave = t >> 6;
+  float* A = reinterpret_cast<float*>(emu::g_xchg) + wave * 512;  // [k][i]
+  float* B = A + 256;                                             // [k][j]
+  const int i = lane & 15, q = lane >> 4;
+  for (int c = 0; c < 4; ++c) { A[(4 * q + c) * 16 + i] = emu_bf16_to_f32(a[c]); B[(4 * q + c) * 16 + i] = emu_bf16_to_f32(b[c]); }
+  __syncthreads();
+  for (int r = 0; r < 4; ++r) {
+    const int row = 4 * q + r;
+    float c = acc[r];
+    for (int k = 0; k < 16; ++k) c = fmaf(A[k * 16 + row], B[k * 16 + i], c);
+    acc[r] = c;
+  }
+  __syncthreads();
+}
+// lane l supplies A[i = l&31][k = 4*(l>>5) + c], B[k][j = l&31]; acc layout as mfma_f32_32x32x2
+inline void mfma_bf16_32x32x8(bf16x4 a, bf16x4 b, f32x16& acc) {
+  const int t = emu::tid(), lane = t & 63, wave = t >> 6;
+  float* A = reinterpret_cast<float*>(emu::g_xchg) + wave * 512;  // [k][i]
+  float* B = A + 256;
+  const int i = lane & 31, h = lane >> 5;
+  for (int c = 0; c < 4; ++c) { A[(4 * h + c) * 32 + i] = emu_bf16_to_f32(a[c]); B[(4 * h + c) * 32 + i] = emu_bf16_to_f32(b[c]); }
+  __syncthreads();
+  for (int r = 0; r < 16; ++r) {
+    const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
+    float c = acc[r];
+    for (int k = 0; k < 8; ++k) c = fmaf(A[k * 32 + row], B[k * 32 + i], c);
+    acc[r] = c;
+  }
+  __syncthreads();
+}
+
 inline float group16_sum(float x) {
   float* s = reinterpret_cast<float*>(emu::g_xchg);
   const int t = emu::tid();

@@ -94,6 +94,53 @@ def test_update_matches_oracle_stage_by_stage(be):
     tr.close()
 
 
+def test_update_bf16_mlp_tracks_the_bf16_oracle(be):
+    """BASELINE configs[3] through the whole engine: training.mlp_dtype = "bf16" (bf16-in / f32-accumulate MFMA in the MLP
+    products; GAE, loss, clip and Adam in f32).  The PPO half of one update against the oracle run with the same operand
+    rounding (hp["mlp_bf16"]), on the engine's own trajectory."""
+    cfg = _cfg(*_small(be), "training.mlp_dtype=bf16")
+    tr = be.trainer(cfg, external_random=True, use_graph=False)
+    tr.reset()
+    N, T, A, H, O, E, M = tr.N, tr.T, tr.A, tr.H, tr.O, tr.E, tr.M
+    rng = np.random.default_rng(0)
+    hp = dict(default_hp(cfg), mlp_bf16=True)
+    p = tr.params_flat().astype(np.float64)
+    opt = po.OptState(np.zeros_like(p), np.zeros_like(p), 0)
+    noise = rng.standard_normal((T, N, A)).astype(np.float32)
+    perms = np.stack([rng.permutation(N * T) for _ in range(E)]).astype(np.int32)
+    be.put(tr.region("noise", (T, N, A)), noise)
+    be.put(tr.region("perm", (E, N * T)), perms)
+    tr.rollout()
+    tr._sync()
+    tj = {k: be.host(v).copy() for k, v in tr.traj().items()}
+    obs = tj["obs"][:, :, :O].astype(np.float64)
+    named = po.flat_to_named(p, O, A, H)
+    for t in range(T):
+        mean, ls, val = po.actor_critic_forward(named, obs[t], bf16=True)
+        mean_x, _, val_x = po.actor_critic_forward(named, obs[t])
+        act = po.mvn_sample(mean, ls, noise[t].astype(np.float64))
+        np.testing.assert_allclose(tj["action"][t], act, atol=2e-3 * np.abs(mean_x).max() + 1e-5)
+        np.testing.assert_allclose(tj["value"][t], val, atol=2e-3 * np.abs(val_x).max() + 1e-5)
+    adv, tgt = po.calculate_gae(tj["done"].astype(bool), tj["value"].astype(np.float64), tj["reward"].astype(np.float64), tj["last_val"].astype(np.float64),
+                                cfg.rl.gamma, cfg.rl.gae_lambda)
+    np.testing.assert_allclose(tj["adv"], adv, rtol=1e-4, atol=1e-4)  # GAE stays f32 on f32 values
+    tr.learn()
+    traj = dict(obs=obs[:T], action=tj["action"].astype(np.float64), value=tj["value"].astype(np.float64), log_prob=tj["log_prob"].astype(np.float64))
+    p_new, opt, losses = po.update_epochs_on_batch(p, opt, traj, adv, tgt, perms, O=O, A=A, H=H, num_minibatches=M, hp=hp)
+    p_exact, _, losses_exact = po.update_epochs_on_batch(p, po.OptState(np.zeros_like(p), np.zeros_like(p), 0), traj, adv, tgt, perms, O=O, A=A, H=H,
+                                                         num_minibatches=M, hp=default_hp(cfg))
+    step = np.abs(p_new - p).max()
+    got = tr.params_flat()
+    err_b, err_x = np.abs(got - p_new).max(), np.abs(got - p_exact).max()
+    # against the same-rounding oracle: a few percent of the update's step (rounding-boundary flips are amplified by Adam's
+    # normalisation where gradients are tiny); the exact oracle is visibly further away, i.e. the rounding is really applied
+    assert err_b < 0.15 * step, (err_b, step)
+    np.testing.assert_allclose(tr.losses()[..., :2], losses[..., :2], rtol=5e-3, atol=5e-4)
+    np.testing.assert_allclose(tr.losses()[..., :2], losses_exact[..., :2], rtol=2e-2, atol=2e-3)  # SURVEY 8c bound
+    assert np.abs(p_new - p_exact).max() > 0 and np.isfinite(got).all()
+    tr.close()
+
+
 def test_internal_rng_update_is_deterministic_and_learns_something(be):
     cfg = _cfg(*_small(be))
     outs = []
