@@ -14,6 +14,8 @@ Tolerances (float32 kernel vs float64 oracle), stated per quantity:
 
 import ctypes as C
 
+from pathlib import Path
+
 import numpy as np
 import pytest
 
@@ -57,7 +59,10 @@ def _walk(cm, N, steps, seed, scale=0.3):
     return ph, d, rng
 
 
-@pytest.mark.parametrize("model,N", [("synth_stompy_pro", 9), ("synth_stompy_full", 5), ("synth_pendulum", 3), ("synth_ball", 2)])
+MJCF_ROBOT = str(Path(__file__).parent / "golden" / "hand_leg.xml")  # goes through minppo_amd/mjcf.py
+
+
+@pytest.mark.parametrize("model,N", [("synth_stompy_pro", 9), ("synth_stompy_full", 5), ("synth_pendulum", 3), ("synth_ball", 2), (MJCF_ROBOT, 4)])
 def test_forward_matches_oracle(be, model, N):
     cm = load_model(model)
     h, dims, _keep = be.model(cm)

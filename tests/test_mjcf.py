@@ -1,0 +1,139 @@
+"""MJCF subset compiler (`minppo_amd/mjcf.py`; stands where reference env.py:27-50 loads the robot file)."""
+import math
+
+import numpy as np
+import pytest
+
+from minppo_amd import mjcf
+from minppo_amd.model import BUILTIN_MODELS, GEOM_CAPSULE, GEOM_SPHERE, JNT_FREE, JNT_HINGE, compile_model, load_model
+
+
+@pytest.mark.parametrize("name", sorted(BUILTIN_MODELS))
+def test_round_trip_through_mjcf_reproduces_the_compiled_tables(name):
+    spec = BUILTIN_MODELS[name]()
+    xml = mjcf.to_mjcf(spec)
+    back = mjcf.parse_mjcf(xml, name=spec.name)
+    a, b = compile_model(spec), compile_model(back)
+    assert a.t.keys() == b.t.keys()
+    for k in a.t:
+        np.testing.assert_allclose(np.asarray(b.t[k], dtype=np.float64), np.asarray(a.t[k], dtype=np.float64), rtol=1e-12, atol=1e-12, err_msg=k)
+    assert a.to_blob() == b.to_blob()
+    assert a.joint_names == b.joint_names and a.body_names == b.body_names
+
+
+HAND = """
+<mujoco model="hand">
+  <compiler angle="degree" eulerseq="xyz"/>
+  <option timestep="0.001" gravity="0 0 -9.81" solver="Newton" iterations="50"/>
+  <default>
+    <joint damping="0.3" armature="0.05" frictionloss="0.1"/>
+    <geom friction="0.8" density="500"/>
+    <position kp="25" ctrlrange="-1 1"/>
+    <default class="knee">
+      <joint range="-90 0" damping="0.7"/>
+    </default>
+  </default>
+  <asset><texture name="t" type="2d" builtin="checker" width="8" height="8"/></asset>
+  <worldbody>
+    <light pos="0 0 3"/>
+    <geom type="plane" size="5 5 0.1" pos="0 0 0" friction="1.2"/>
+    <body name="base" pos="0.1 -0.2 0.75" euler="0 0 90">
+      <freejoint name="root"/>
+      <geom type="sphere" size="0.1"/>
+      <body name="thigh" pos="0 0 -0.1" childclass="knee">
+        <inertial pos="0 0 -0.15" mass="2.0" fullinertia="0.02 0.03 0.01 0.001 0 0"/>
+        <joint name="hip" axis="0 1 0" range="-45 45" class="main"/>
+        <geom type="capsule" size="0.04" fromto="0 0 0 0 0 -0.3"/>
+        <body name="shin" pos="0 0 -0.3">
+          <joint name="knee" axis="0 1 0"/>
+          <geom type="capsule" size="0.03 0.1" pos="0 0 -0.1"/>
+          <geom type="box" size="0.05 0.02 0.01" pos="0.02 0 -0.22" contype="0" conaffinity="0"/>
+        </body>
+      </body>
+    </body>
+  </worldbody>
+  <actuator>
+    <position joint="hip"/>
+    <position joint="knee" kp="40" forcerange="-30 30"/>
+  </actuator>
+</mujoco>
+"""
+
+
+def test_hand_written_mjcf_defaults_units_and_inertia():
+    s = mjcf.parse_mjcf(HAND, "hand")
+    assert s.timestep == 0.001 and s.iterations == 6 and s.ls_iterations == 6   # solver settings are forced (env.py:95-97)
+    assert s.plane_friction[0] == 1.2 and s.plane_z == 0.0 and s.free_root_z == 0.75
+    base, thigh, shin = s.bodies
+    # euler 0 0 90 deg about z
+    np.testing.assert_allclose(base.quat, [math.cos(math.pi / 4), 0, 0, math.sin(math.pi / 4)], atol=1e-12)
+    assert base.joints[0].type == JNT_FREE
+    # sphere r=0.1 at density 500: m = 4/3 pi r^3 rho, I = 2/5 m r^2
+    m = 4 / 3 * math.pi * 1e-3 * 500
+    assert base.mass == pytest.approx(m) and base.inertia == pytest.approx([0.4 * m * 0.01] * 3)
+    assert base.geoms[0].friction[0] == 0.8
+    # thigh: explicit inertial wins over its geom; fullinertia diagonalised (principal moments descending)
+    assert thigh.mass == 2.0
+    w = np.linalg.eigvalsh(np.array([[0.02, 0.001, 0], [0.001, 0.03, 0], [0, 0, 0.01]]))[::-1]
+    np.testing.assert_allclose(thigh.inertia, w, rtol=1e-12)
+    hip = thigh.joints[0]
+    assert hip.type == JNT_HINGE and hip.damping == 0.3 and hip.armature == 0.05           # class="main" beats childclass
+    np.testing.assert_allclose(hip.range, np.radians([-45, 45]))
+    g = thigh.geoms[0]
+    assert g.type == GEOM_CAPSULE and g.size == pytest.approx((0.04, 0.15))
+    np.testing.assert_allclose(g.pos, [0, 0, -0.15], atol=1e-12)
+    np.testing.assert_allclose(np.abs(g.quat), [0, 1, 0, 0], atol=1e-12)                # local z -> -z
+    knee = shin.joints[0]
+    assert knee.damping == 0.7 and knee.armature == 0.05                                # childclass "knee" inherits armature
+    np.testing.assert_allclose(knee.range, np.radians([-90, 0]))
+    # shin inertia from its capsule AND the non-colliding box; only the capsule collides
+    assert len(shin.geoms) == 1 and shin.geoms[0].type == GEOM_CAPSULE
+    r, h = 0.03, 0.2
+    mc = 500 * (math.pi * r * r * h + 4 / 3 * math.pi * r ** 3)
+    mb = 500 * 0.1 * 0.04 * 0.02
+    assert shin.mass == pytest.approx(mc + mb)
+    com_z = (mc * -0.1 + mb * -0.22) / (mc + mb)
+    assert shin.ipos[2] == pytest.approx(com_z) and shin.ipos[0] == pytest.approx(mb * 0.02 / (mc + mb))
+    a0, a1 = s.actuators
+    assert (a0.joint, a0.kp, a0.ctrlrange, a0.forcerange) == ("hip", 25.0, (-1.0, 1.0), None)
+    assert (a1.joint, a1.kp, a1.ctrlrange, a1.forcerange) == ("knee", 40.0, (-1.0, 1.0), (-30.0, 30.0))
+    cm = compile_model(s)
+    assert (cm.nq, cm.nv, cm.nu) == (9, 8, 2)
+
+
+def test_frictionloss_is_stripped_only_where_the_reference_strips_it():
+    mjcf.parse_mjcf(HAND)  # <default><joint frictionloss> is deleted (reference env.py:41-45): no error
+    bad = HAND.replace('<joint name="knee" axis="0 1 0"/>', '<joint name="knee" axis="0 1 0" frictionloss="0.2"/>')
+    with pytest.raises(ValueError, match="frictionloss"):
+        mjcf.parse_mjcf(bad)
+
+
+@pytest.mark.parametrize("old,new,msg", [
+    ('<actuator>', '<equality/><actuator>', "equality"),
+    ('type="sphere" size="0.1"', 'type="box" size="0.1 0.1 0.1"', "only sphere and capsule geoms can collide"),
+    ('<joint name="knee" axis="0 1 0"/>', '<joint name="knee" type="ball"/>', "joint type"),
+    ('<position joint="hip"/>', '<position tendon="t"/>', "joint transmissions"),
+    ('<position joint="hip"/>', '<position joint="nope"/>', "unknown joint"),
+    ('<option timestep="0.001"', '<option cone="elliptic" timestep="0.001"', "elliptic"),
+    ('<body name="shin" pos="0 0 -0.3">', '<body name="shin" pos="0 0 -0.3" mocap="true">', "mocap"),
+])
+def test_outside_the_subset_is_an_error_not_a_silent_drop(old, new, msg):
+    assert old in HAND
+    with pytest.raises(ValueError, match=msg):
+        mjcf.parse_mjcf(HAND.replace(old, new))
+
+
+def test_load_model_accepts_an_xml_path_and_the_oracle_can_step_it(tmp_path):
+    from oracle.physics_oracle import Physics
+
+    p = tmp_path / "hand.xml"
+    p.write_text(HAND)
+    cm = load_model(str(p))
+    assert cm.name == "hand" and cm.nu == 2
+    ph = Physics(cm.t, np.float64)
+    q0 = np.tile(np.asarray(cm.t["qpos0"], np.float64), (3, 1))
+    d = ph.pipeline_init(q0, np.zeros((3, cm.nv)))
+    for _ in range(5):
+        d = ph.pipeline_step(d, np.zeros((3, cm.nu)))
+    assert np.isfinite(d["qpos"]).all() and np.isfinite(d["qvel"]).all()
+    assert (d["qpos"][:, 2] < 0.75).all()  # it falls
