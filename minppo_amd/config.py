@@ -121,6 +121,12 @@ class TrainingConfig:
     # Extension: MLP GEMM arithmetic. "f32" = exact f32 MFMA; "bf16" = bf16-in /
     # f32-accumulate MFMA (BASELINE config 4).  GAE and Adam are always f32.
     mlp_dtype: str = field(default="f32")
+    # Extension (absent upstream): full-state checkpoints.  `checkpoint_path` is written every
+    # `checkpoint_every` updates (0 = only at the end, "" = never); `resume_from` restores parameters, Adam moments,
+    # step counters (LR schedule + RNG stream position), environment states and episode metrics before training.
+    checkpoint_path: str = field(default="")
+    checkpoint_every: int = field(default=0)
+    resume_from: str = field(default="")
 
 
 @dataclass

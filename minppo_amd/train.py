@@ -23,6 +23,7 @@ import logging
 import math
 import os
 import pickle
+from pathlib import Path
 import sys
 import time
 from typing import Any, Callable, Dict, NamedTuple, Optional, Sequence
@@ -297,6 +298,56 @@ class Trainer:
         self._sync()
         return self._to_host(self.region("params")).copy()
 
+    # -- full-state checkpoint (the reference only pickles the final parameters, train.py:86-89,314) ------
+    # Everything that is carried from one update to the next lives in these arena regions: parameters, Adam moments,
+    # the device counters (optimizer step = LR-schedule position, update index = RNG stream position), per-env physics
+    # records, episode bookkeeping, and RunnerState.last_obs (slot 0 of `obs`).  Restoring them reproduces the
+    # uninterrupted run bit for bit (tests/test_train_surface.py).
+    _CKPT_REGIONS = ("params", "adam_m", "adam_v", "count", "state", "episode_returns", "episode_lengths", "returned_episode_returns",
+                     "returned_episode_lengths", "timestep", "returned_episode")
+    _CKPT_VERSION = 1
+
+    def _ckpt_meta(self) -> Dict[str, Any]:
+        return dict(version=self._CKPT_VERSION, model=self.cm.name, num_envs=self.N, num_steps=self.T, obs_dim=self.O, act_dim=self.A, hidden=self.H,
+                    params=self.P, rec_dim=int(self.dims.rec_dim), seed=int(self.seed), rank=self.rank, world_size=self.world_size)
+
+    def save_checkpoint(self, path: str) -> None:
+        self._sync()
+        arrays = {name: self._to_host(self.region(name)).copy() for name in self._CKPT_REGIONS}
+        arrays["last_obs"] = self._to_host(self.region("obs", (self.T + 1, self.N, self.OP))[0]).copy()
+        meta = dict(self._ckpt_meta(), updates_done=int(self.updates_done))
+        p = Path(path)
+        if p.parent != Path(""):
+            p.parent.mkdir(parents=True, exist_ok=True)
+        tmp = p.with_name(p.name + ".tmp")
+        with open(tmp, "wb") as f:
+            np.savez(f, __meta__=np.frombuffer(pickle.dumps(meta), np.uint8), **arrays)
+        os.replace(tmp, p)  # a crash never leaves a truncated checkpoint under the final name
+
+    def load_checkpoint(self, path: str) -> None:
+        with np.load(path) as z:
+            meta = pickle.loads(z["__meta__"].tobytes())
+            want = self._ckpt_meta()
+            # the seed keys the engine's Philox streams: only the same seed continues the same noise / permutation sequence
+            for k in ("version", "model", "num_envs", "num_steps", "obs_dim", "act_dim", "hidden", "params", "rec_dim", "world_size", "rank", "seed"):
+                if meta.get(k) != want[k]:
+                    raise ValueError(f"checkpoint {path}: {k} = {meta.get(k)!r} does not match this run ({want[k]!r})")
+            self.reset()  # (re)builds the constant reset record; everything else is overwritten below
+            self._sync()
+            for name in self._CKPT_REGIONS:
+                self._write_region(self.region(name), z[name])
+            self._write_region(self.region("obs", (self.T + 1, self.N, self.OP))[0], z["last_obs"])
+        self.updates_done = int(meta["updates_done"])
+
+    def _write_region(self, dst, src: np.ndarray) -> None:
+        if tuple(dst.shape) != tuple(src.shape):
+            raise ValueError(f"checkpoint region shape {src.shape} does not match {tuple(dst.shape)}")
+        if self.xp == "torch":
+            dst.copy_(self.torch.from_numpy(np.ascontiguousarray(src)))
+            self.torch.cuda.synchronize(self.device)
+        else:
+            dst[...] = src
+
     @property
     def params(self) -> dict:
         return flat_to_tree(self.params_flat(), self.O, self.A, self.H)
@@ -428,21 +479,32 @@ def make_train(config: Config, **trainer_kwargs: Any) -> Callable[[Any], TrainOu
     def train(rng: Any, max_updates: Optional[int] = None, log_every: int = 0) -> TrainOutput:
         tr = Trainer(config, seed=_seed_from_rng(rng), **trainer_kwargs)
         tr.init_comm()
-        tr.reset()
-        n = num_updates if max_updates is None else min(num_updates, max_updates)
+        tc = config.training
+        ckpt = (tc.checkpoint_path + (f".rank{tr.rank}" if tr.world_size > 1 else "")) if tc.checkpoint_path else ""
+        if tc.resume_from:
+            tr.load_checkpoint(tc.resume_from + (f".rank{tr.rank}" if tr.world_size > 1 else ""))
+            logger.info("resumed from %s at update %d", tc.resume_from, tr.updates_done)
+        else:
+            tr.reset()
+        first = tr.updates_done
+        n = num_updates if max_updates is None else min(num_updates, first + max_updates)
         metrics = {"mean_reward": [], "done_fraction": [], "total_loss": [], "value_loss": [], "actor_loss": [], "entropy": []}
         t0 = time.time()
-        for u in range(n):
+        for u in range(first, n):
             tr.update()
+            if ckpt and tc.checkpoint_every > 0 and (u + 1) % tc.checkpoint_every == 0 and u + 1 < n:
+                tr.save_checkpoint(ckpt)
             if log_every and ((u + 1) % log_every == 0 or u + 1 == n):
                 st, lo = tr.rollout_stats(), tr.losses().reshape(-1, 4).mean(0)
                 for k, v in st.items():
                     metrics[k].append(v)
                 for k, v in zip(("total_loss", "value_loss", "actor_loss", "entropy"), lo):
                     metrics[k].append(float(v))
-                sps = (u + 1) * tr.T * tr.N * tr.world_size / (time.time() - t0)
+                sps = (u + 1 - first) * tr.T * tr.N * tr.world_size / (time.time() - t0)
                 logger.info("update %d/%d  reward %.3f  done %.4f  loss %.4f  %.0f env-steps/s", u + 1, n, st["mean_reward"], st["done_fraction"],
                             lo[0], sps)
+        if ckpt:
+            tr.save_checkpoint(ckpt)
         params = tr.params
         count = int(tr._to_host(tr.region("count"))[0]) if n else 0
         state = TrainState(step=count, params=params, opt_state={"mu": flat_to_tree(tr._to_host(tr.region("adam_m")), tr.O, tr.A, tr.H),

@@ -49,3 +49,59 @@ def test_make_train_runs_and_saves(tmp_path):
     assert T._seed_from_rng(np.array([0, 1337], np.uint32)) != T._seed_from_rng(np.array([0, 1338], np.uint32))
     with pytest.raises(ValueError, match="batch_size"):
         T.make_train(make_config(BASE, ["training.num_envs=6", "training.num_minibatches=4", "training.num_steps=1"]))
+
+
+def _resume_case(be, tmp_path, trainer_kw):
+    """4 updates in one go == 2 updates, checkpoint, NEW trainer, resume, 2 updates - bit for bit (parameters, Adam moments,
+    counters, environment states, episode metrics); the engine's own RNG streams are positioned by the restored counters."""
+    over = ["training.num_envs=8", "training.num_steps=4", "rl.num_env_steps=4", "training.num_minibatches=2", "training.update_epochs=2",
+            "model.hidden_size=32", "training.total_timesteps=100000"] if be.name == "emu" else \
+           ["training.num_envs=256", "training.num_minibatches=8", "training.update_epochs=2", "training.total_timesteps=100000000"]
+    cfg = make_config(BASE, over)
+    ck = str(tmp_path / "ck" / "state.npz")
+    a = be.trainer(cfg, **trainer_kw)
+    a.reset()
+    for _ in range(2):
+        a.update()
+    a.save_checkpoint(ck)
+    for _ in range(2):
+        a.update()
+    names = T.Trainer._CKPT_REGIONS
+    want = {n: a._to_host(a.region(n)).copy() for n in names}
+    a._sync()
+    a.close()
+    b = be.trainer(cfg, **trainer_kw)
+    b.load_checkpoint(ck)
+    assert b.updates_done == 2
+    for _ in range(2):
+        b.update()
+    b._sync()
+    for n in names:
+        np.testing.assert_array_equal(b._to_host(b.region(n)), want[n], err_msg=n)
+    assert int(b._to_host(b.region("count"))[1]) == 4
+    b.close()
+    # a checkpoint of another shape / seed is refused
+    c = be.trainer(make_config(BASE, over + ["training.seed=7"]), **trainer_kw)
+    with pytest.raises(ValueError, match="seed"):
+        c.load_checkpoint(ck)
+    c.close()
+
+
+def test_checkpoint_resume_is_bit_exact(tmp_path):
+    _resume_case(get_backend("emu"), tmp_path, dict(use_graph=False))
+
+
+@pytest.mark.gpu
+def test_checkpoint_resume_is_bit_exact_on_gpu_with_hipgraph(tmp_path):
+    _resume_case(get_backend("hip"), tmp_path, dict(use_graph=True))
+
+
+def test_make_train_checkpoints_and_resumes(tmp_path):
+    be = get_backend("emu")
+    ck = tmp_path / "run.npz"
+    common = SMALL[:-1] + ["training.total_timesteps=64", f"training.model_save_path={tmp_path / 'm.pkl'}", f"training.checkpoint_path={ck}"]
+    full = T.make_train(make_config(BASE, common), lib=be.lib, xp="numpy", use_graph=False)(1337)          # 4 updates
+    T.make_train(make_config(BASE, common), lib=be.lib, xp="numpy", use_graph=False)(1337, max_updates=2)  # stops after 2, leaves a checkpoint
+    rest = T.make_train(make_config(BASE, common + [f"training.resume_from={ck}"]), lib=be.lib, xp="numpy", use_graph=False)(1337)
+    assert rest.runner_state.train_state.step == full.runner_state.train_state.step
+    np.testing.assert_array_equal(T.tree_to_flat(rest.runner_state.train_state.params, 225, 10, 16), T.tree_to_flat(full.runner_state.train_state.params, 225, 10, 16))
