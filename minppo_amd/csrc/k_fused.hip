@@ -47,7 +47,10 @@ struct FusedArgs {
 //   NT = true : W stored [H][K] (backward):  B(k,n) = W[n*K + k], lane loads float4 W[n][k..k+3] for both of its columns
 // Stage = 32 k = 16 MFMAs; stage S+1's B fragment is fetched while stage S computes (copy-free ping-pong), so with two
 // waves per SIMD a load has about 1000 cycles before its first use.  k inside a stage: 32S + 16g + 4kq + c.
-template <bool NT>
+// Loads are BRANCH-FREE on purpose: a conditional around a prefetch splits the loop body into basic blocks, and the
+// compiler's s_waitcnt insertion then has to assume the shorter of the two histories at the join - it waited for vmcnt(0)
+// before a stage whose operands had been requested two stages earlier, i.e. the ring degenerated to depth one.
+template <bool NT, bool CLAMP>
 struct BStage {
   float x0[8], x1[8];
   __device__ __forceinline__ void load(const float* W, int H, int K, int S, int n0, int j, int kq, int Kvalid) {
@@ -59,28 +62,27 @@ struct BStage {
         x0[4 * g] = q0.x; x0[4 * g + 1] = q0.y; x0[4 * g + 2] = q0.z; x0[4 * g + 3] = q0.w;
         x1[4 * g] = q1.x; x1[4 * g + 1] = q1.y; x1[4 * g + 2] = q1.z; x1[4 * g + 3] = q1.w;
       }
-    } else {
+    } else if (!CLAMP) {  // every k of every stage exists (K == Kvalid)
       const int lane_off = 4 * kq * H + n0 + 2 * j;  // the only per-lane part of the address
-      if (32 * S + 32 <= Kvalid) {                   // wave-uniform: every k of the stage exists
 #pragma unroll
-        for (int g = 0; g < 2; ++g)
+      for (int g = 0; g < 2; ++g)
 #pragma unroll
-          for (int c = 0; c < 4; ++c) {
-            const float* up = W + (size_t)(32 * S + 16 * g + c) * H;  // scalar
-            const float2 q = *reinterpret_cast<const float2*>(up + lane_off);
-            x0[4 * g + c] = q.x; x1[4 * g + c] = q.y;
-          }
-      } else {  // last stage of the first layer: rows past K meet zero activations; the clamp keeps the read inside W
+        for (int c = 0; c < 4; ++c) {
+          const float* up = W + (size_t)(32 * S + 16 * g + c) * H;  // scalar
+          const float2 q = *reinterpret_cast<const float2*>(up + lane_off);
+          x0[4 * g + c] = q.x; x1[4 * g + c] = q.y;
+        }
+    } else {  // first layer: K is padded to whole stages; rows past Kvalid meet zero activations, the clamp keeps the read inside W
+      const int col = n0 + 2 * j;
 #pragma unroll
-        for (int g = 0; g < 2; ++g)
+      for (int g = 0; g < 2; ++g)
 #pragma unroll
-          for (int c = 0; c < 4; ++c) {
-            int k = 32 * S + 16 * g + 4 * kq + c;
-            k = k < Kvalid ? k : Kvalid - 1;
-            const float2 q = *reinterpret_cast<const float2*>(W + (size_t)k * H + n0 + 2 * j);
-            x0[4 * g + c] = q.x; x1[4 * g + c] = q.y;
-          }
-      }
+        for (int c = 0; c < 4; ++c) {
+          int k = 32 * S + 16 * g + 4 * kq + c;
+          k = k < Kvalid ? k : Kvalid - 1;
+          const float2 q = *reinterpret_cast<const float2*>(W + k * H + col);
+          x0[4 * g + c] = q.x; x1[4 * g + c] = q.y;
+        }
     }
   }
 };
@@ -113,29 +115,39 @@ __device__ __forceinline__ void stage_mfma(const float* arow, int S, const float
 // full MFMA blocks (about 2000 cycles with two waves per SIMD) to arrive from L2.  The first two stages are requested by
 // prefetch(), which the kernel calls one phase EARLY (weights depend on nothing computed here): the fill latency of each
 // GEMM phase hides under the barrier / epilogue / loss code of the phase before it.
-template <bool NT>
+template <bool NT, bool CLAMP>
 struct GemmPipe {
-  BStage<NT> b0, b1;
+  BStage<NT, CLAMP> b0, b1;
   __device__ __forceinline__ void prefetch(int K, int Kvalid, const float* W, int H, int n0, int lane) {
     const int j = lane & 15, kq = lane >> 4;
+    const int last = K / 32 - 1;
     b0.load(W, H, K, 0, n0, j, kq, Kvalid);
-    if (K > 32) b1.load(W, H, K, 1, n0, j, kq, Kvalid);
+    b1.load(W, H, K, last < 1 ? last : 1, n0, j, kq, Kvalid);
   }
-  // invariant at the loop top: b0 = stage S, b1 = stage S+1
+  // invariant at the loop top: b0 = stage S, b1 = stage S+1.  Stage indices past the end are clamped to the last stage
+  // (a redundant, harmless load) instead of being skipped: straight-line code, exact vmcnt bookkeeping.
   template <bool BF16>
   __device__ __forceinline__ void run(const float* At, int AS, int K, int Kvalid, const float* W, int H, int n0, int lane, f32x4& acc0, f32x4& acc1) {
     const int j = lane & 15, kq = lane >> 4;
     const float* arow = At + j * AS + 4 * kq;
-    const int nst = K / 32;
-    BStage<NT> b2;
+    const int nst = K / 32, last = nst - 1;
+    BStage<NT, CLAMP> b2;
     int S = 0;
+    // MPPO_SCHED_FENCE: the machine scheduler otherwise sinks a stage's loads down to their first use (it minimises
+    // register pressure), which is exactly the latency exposure the ring exists to avoid
     for (; S + 2 < nst; S += 3) {
       b2.load(W, H, K, S + 2, n0, j, kq, Kvalid);
+      MPPO_SCHED_FENCE();
       stage_mfma<BF16>(arow, S, b0.x0, b0.x1, acc0, acc1);
-      if (S + 3 < nst) b0.load(W, H, K, S + 3, n0, j, kq, Kvalid);
+      MPPO_SCHED_FENCE();
+      b0.load(W, H, K, S + 3 < last ? S + 3 : last, n0, j, kq, Kvalid);
+      MPPO_SCHED_FENCE();
       stage_mfma<BF16>(arow, S + 1, b1.x0, b1.x1, acc0, acc1);
-      if (S + 4 < nst) b1.load(W, H, K, S + 4, n0, j, kq, Kvalid);
+      MPPO_SCHED_FENCE();
+      b1.load(W, H, K, S + 4 < last ? S + 4 : last, n0, j, kq, Kvalid);
+      MPPO_SCHED_FENCE();
       stage_mfma<BF16>(arow, S + 2, b2.x0, b2.x1, acc0, acc1);
+      MPPO_SCHED_FENCE();
     }
     if (S < nst) stage_mfma<BF16>(arow, S, b0.x0, b0.x1, acc0, acc1);
     if (S + 1 < nst) stage_mfma<BF16>(arow, S + 1, b1.x0, b1.x1, acc0, acc1);
@@ -182,7 +194,7 @@ __global__ void __launch_bounds__(512) fused_mlp_kernel(FusedArgs a) {
   // ---- everything that depends on nothing computed here is requested now and consumed phases later: the first two
   // weight stages of layer 1, the biases, and the per-row scalars of the loss (index -> action / log_prob / advantage /
   // value / target: a dependent HBM chain of ~3 us that would otherwise sit between the head GEMM and the loss) ----
-  GemmPipe<false> pipe1;
+  GemmPipe<false, true> pipe1;
   pipe1.prefetch(KP, O, W1, H, n0, lane);
   const float2 bz1 = *reinterpret_cast<const float2*>(B1 + n0 + 2 * cj), bz2 = *reinterpret_cast<const float2*>(B2 + n0 + 2 * cj);
   const float adv_mean = a.adv_stat[0], adv_rstd = a.adv_stat[1];
@@ -222,8 +234,8 @@ __global__ void __launch_bounds__(512) fused_mlp_kernel(FusedArgs a) {
   __syncthreads();
 
   // ---- P1 / P2: hidden layers ----
-  GemmPipe<false> pipe2;
-  GemmPipe<true> pipe5;
+  GemmPipe<false, false> pipe2;
+  GemmPipe<true, false> pipe5;
   for (int layer = 0; layer < 2; ++layer) {
     f32x4 acc0, acc1;
     for (int r = 0; r < 4; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }

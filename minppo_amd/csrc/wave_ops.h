@@ -93,6 +93,9 @@ __device__ __forceinline__ double wave_sum_f64(double x) {
 // MFMA place NVALU vector-ALU and NVMEM vector-memory-read instructions.  The dependent f32 MFMA chain leaves a 64-cycle
 // gap after each issue; in-order issue would otherwise run the ~100 address / load instructions of the next k-set
 // strictly before the whole chain.  (LLVM sched_group_barrier masks: 0x8 MFMA, 0x2 VALU, 0x20 VMEM read.)
+// nothing is scheduled across this point (compiler-only; no instruction is emitted)
+#define MPPO_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
+
 #define MPPO_INTERLEAVE_MFMA16(NVALU, NVMEM)                      \
   _Pragma("unroll") for (int _i = 0; _i < 16; ++_i) {             \
     __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);            \

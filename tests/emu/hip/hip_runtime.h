@@ -53,6 +53,7 @@ namespace emu {
 extern dim3 g_threadIdx, g_blockIdx, g_blockDim, g_gridDim;
 extern unsigned char* g_dyn_smem;
 extern double g_xchg[4096];
+extern const void* g_kernel_ptr;
 void launch(dim3 grid, dim3 block, size_t shmem, const std::function<void()>& body);
 void barrier();
 inline int tid() { return (int)(g_threadIdx.x + g_blockDim.x * (g_threadIdx.y + g_blockDim.y * g_threadIdx.z)); }
@@ -67,6 +68,7 @@ inline void __syncthreads() { emu::barrier(); }
 
 template <typename K, typename... Args>
 inline void hipLaunchKernelGGL(K kernel, dim3 grid, dim3 block, size_t shmem, hipStream_t, Args... args) {
+  emu::g_kernel_ptr = reinterpret_cast<const void*>(kernel);  // for diagnostics (dladdr)
   emu::launch(grid, block, shmem, [=]() { kernel(args...); });
 }
 

@@ -156,6 +156,7 @@ inline float __shfl_xor(float x, int mask) {
   return r;
 }
 
+#define MPPO_SCHED_FENCE()
 #define MPPO_INTERLEAVE_MFMA16(NVALU, NVMEM)
 
 // lane l supplies A[i = l&15][k = l>>4], B[k = l>>4][j = l&15]; acc[r] = D[4*(l>>4) + r][l&15]

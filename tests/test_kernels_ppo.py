@@ -219,7 +219,8 @@ def test_clip_adam_and_schedule(be):
     p, m, v, g = be.zeros((4,)), be.zeros((4,)), be.zeros((4,)), be.arr(g1)
     cnt = be.zeros((4,), np.int32)
     cfg = nat.AdamCfg(1e-3, 0.5, 0.9, 0.999, 1e-5, 0, 1, 1)
-    be.lib.clip_adam(4, be.ptr(p), be.ptr(m), be.ptr(v), be.ptr(g), be.ptr(cnt), 0, C.byref(cfg), be.ptr(be.zeros((256,))), 1024, be.stream)
+    ws = be.zeros((256,))  # (kept alive across the call: a temporary here would be freed before the kernels write to it)
+    be.lib.clip_adam(4, be.ptr(p), be.ptr(m), be.ptr(v), be.ptr(g), be.ptr(cnt), 0, C.byref(cfg), be.ptr(ws), 1024, be.stream)
     gc = g1 / 2
     np.testing.assert_allclose(be.host(p)[:2], -1e-3 * gc[:2] / (np.abs(gc[:2]) + 1e-5), rtol=1e-5)
     assert (be.host(p)[2:] == 0).all()
@@ -249,7 +250,8 @@ def test_philox_normal_and_permutation(be):
     # golden prefix: the Philox stream is part of the engine's contract (same on emulator and GPU)
     idx = be.zeros((16,), np.int32)
     wsb = be.lib.permutation_ws_bytes(16)
-    be.lib.permutation(1337, 3, 16, be.ptr(idx), be.ptr(be.zeros((wsb // 4 + 4,), np.int32)), wsb, be.stream)
+    pws = be.zeros((wsb // 4 + 4,), np.int32)  # kept alive across the (asynchronous, on the GPU) call
+    be.lib.permutation(1337, 3, 16, be.ptr(idx), be.ptr(pws), wsb, be.stream)
     golden = np.load(str(__import__("pathlib").Path(__file__).parent / "golden" / "philox.npz"))
     np.testing.assert_array_equal(be.host(idx), golden["perm16"])
     np.testing.assert_allclose(zh[:8], golden["normal8"], rtol=2e-6, atol=1e-6)
