@@ -20,6 +20,9 @@ namespace mppo {
 
 constexpr float kLog2PiF = 1.8378770664093453f;
 constexpr int FRT = 16;  // rows per workgroup
+#ifndef MPPO_ROLLOUT_WAVES
+#define MPPO_ROLLOUT_WAVES 4
+#endif
 
 __device__ __forceinline__ float fused_tanh(float x) {
   const float e = __expf(2.f * x);
@@ -37,6 +40,10 @@ struct FusedArgs {
   mppo_loss_cfg_t lc;
   float *h1[2], *h2[2], *dz2[2], *dz1[2];
   float *dout, *xmb, *partial;
+  // rollout mode (ROLLOUT = true): forward + pi.sample + pi.log_prob (train.py:157-160); rows are not gathered
+  const float* noise;
+  float *action, *log_prob, *value, *mean_out;
+  int net0;  // first network of the launch: 0 = actor + critic, 1 = critic only (bootstrap value, train.py:182)
   int skip;  // timing experiments only (MPPO_FUSED_SKIP bit mask): 1 L1, 2 L2, 4 heads, 8 dZ2, 16 dZ1, 32 activation stores, 64 gather
 };
 
@@ -50,10 +57,11 @@ struct FusedArgs {
 // Loads are BRANCH-FREE on purpose: a conditional around a prefetch splits the loop body into basic blocks, and the
 // compiler's s_waitcnt insertion then has to assume the shorter of the two histories at the join - it waited for vmcnt(0)
 // before a stage whose operands had been requested two stages earlier, i.e. the ring degenerated to depth one.
-template <bool NT, bool CLAMP>
+template <bool NT>
 struct BStage {
   float x0[8], x1[8];
-  __device__ __forceinline__ void load(const float* W, int H, int K, int S, int n0, int j, int kq, int Kvalid) {
+  // NT = false: `wb` is a range-checked view of W[0 .. Kvalid) x H: rows of the zero-padded K tail read as 0
+  __device__ __forceinline__ void load(const float* W, const BufView& wb, int H, int K, int S, int n0, int j, int kq) {
     if (NT) {
 #pragma unroll
       for (int g = 0; g < 2; ++g) {
@@ -62,25 +70,13 @@ struct BStage {
         x0[4 * g] = q0.x; x0[4 * g + 1] = q0.y; x0[4 * g + 2] = q0.z; x0[4 * g + 3] = q0.w;
         x1[4 * g] = q1.x; x1[4 * g + 1] = q1.y; x1[4 * g + 2] = q1.z; x1[4 * g + 3] = q1.w;
       }
-    } else if (!CLAMP) {  // every k of every stage exists (K == Kvalid)
-      const int lane_off = 4 * kq * H + n0 + 2 * j;  // the only per-lane part of the address
+    } else {
+      const int lane_off = (4 * kq * H + n0 + 2 * j) * 4;  // bytes; the only per-lane part of the address
 #pragma unroll
       for (int g = 0; g < 2; ++g)
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
-          const float* up = W + (size_t)(32 * S + 16 * g + c) * H;  // scalar
-          const float2 q = *reinterpret_cast<const float2*>(up + lane_off);
-          x0[4 * g + c] = q.x; x1[4 * g + c] = q.y;
-        }
-    } else {  // first layer: K is padded to whole stages; rows past Kvalid meet zero activations, the clamp keeps the read inside W
-      const int col = n0 + 2 * j;
-#pragma unroll
-      for (int g = 0; g < 2; ++g)
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-          int k = 32 * S + 16 * g + 4 * kq + c;
-          k = k < Kvalid ? k : Kvalid - 1;
-          const float2 q = *reinterpret_cast<const float2*>(W + k * H + col);
+          const float2 q = buf_load_f2(wb, lane_off, (32 * S + 16 * g + c) * H * 4);
           x0[4 * g + c] = q.x; x1[4 * g + c] = q.y;
         }
     }
@@ -115,36 +111,38 @@ __device__ __forceinline__ void stage_mfma(const float* arow, int S, const float
 // full MFMA blocks (about 2000 cycles with two waves per SIMD) to arrive from L2.  The first two stages are requested by
 // prefetch(), which the kernel calls one phase EARLY (weights depend on nothing computed here): the fill latency of each
 // GEMM phase hides under the barrier / epilogue / loss code of the phase before it.
-template <bool NT, bool CLAMP>
+template <bool NT>
 struct GemmPipe {
-  BStage<NT, CLAMP> b0, b1;
+  BStage<NT> b0, b1;
+  BufView wb;
   __device__ __forceinline__ void prefetch(int K, int Kvalid, const float* W, int H, int n0, int lane) {
     const int j = lane & 15, kq = lane >> 4;
     const int last = K / 32 - 1;
-    b0.load(W, H, K, 0, n0, j, kq, Kvalid);
-    b1.load(W, H, K, last < 1 ? last : 1, n0, j, kq, Kvalid);
+    wb = make_buf(W, (unsigned)Kvalid * (unsigned)H * 4u);
+    b0.load(W, wb, H, K, 0, n0, j, kq);
+    b1.load(W, wb, H, K, last < 1 ? last : 1, n0, j, kq);
   }
   // invariant at the loop top: b0 = stage S, b1 = stage S+1.  Stage indices past the end are clamped to the last stage
   // (a redundant, harmless load) instead of being skipped: straight-line code, exact vmcnt bookkeeping.
   template <bool BF16>
-  __device__ __forceinline__ void run(const float* At, int AS, int K, int Kvalid, const float* W, int H, int n0, int lane, f32x4& acc0, f32x4& acc1) {
+  __device__ __forceinline__ void run(const float* At, int AS, int K, const float* W, int H, int n0, int lane, f32x4& acc0, f32x4& acc1) {
     const int j = lane & 15, kq = lane >> 4;
     const float* arow = At + j * AS + 4 * kq;
     const int nst = K / 32, last = nst - 1;
-    BStage<NT, CLAMP> b2;
+    BStage<NT> b2;
     int S = 0;
     // MPPO_SCHED_FENCE: the machine scheduler otherwise sinks a stage's loads down to their first use (it minimises
     // register pressure), which is exactly the latency exposure the ring exists to avoid
     for (; S + 2 < nst; S += 3) {
-      b2.load(W, H, K, S + 2, n0, j, kq, Kvalid);
+      b2.load(W, wb, H, K, S + 2, n0, j, kq);
       MPPO_SCHED_FENCE();
       stage_mfma<BF16>(arow, S, b0.x0, b0.x1, acc0, acc1);
       MPPO_SCHED_FENCE();
-      b0.load(W, H, K, S + 3 < last ? S + 3 : last, n0, j, kq, Kvalid);
+      b0.load(W, wb, H, K, S + 3 < last ? S + 3 : last, n0, j, kq);
       MPPO_SCHED_FENCE();
       stage_mfma<BF16>(arow, S + 1, b1.x0, b1.x1, acc0, acc1);
       MPPO_SCHED_FENCE();
-      b1.load(W, H, K, S + 4 < last ? S + 4 : last, n0, j, kq, Kvalid);
+      b1.load(W, wb, H, K, S + 4 < last ? S + 4 : last, n0, j, kq);
       MPPO_SCHED_FENCE();
       stage_mfma<BF16>(arow, S + 2, b2.x0, b2.x1, acc0, acc1);
       MPPO_SCHED_FENCE();
@@ -161,12 +159,14 @@ __device__ __forceinline__ float row32_sum(float x) {
   return x;
 }
 
-template <bool BF16>
-__global__ void __launch_bounds__(512) fused_mlp_kernel(FusedArgs a) {
+// rollout launches have 2 x N/16 workgroups (512 at N = 4096): two per CU must be co-resident = 4 waves per SIMD (the second
+// __launch_bounds__ argument is HIP's minimum waves per execution unit), i.e. at most 128 VGPRs
+template <bool BF16, bool ROLLOUT>
+__global__ void __launch_bounds__(512, ROLLOUT ? MPPO_ROLLOUT_WAVES : 2) fused_mlp_kernel(FusedArgs a) {
   MPPO_DYN_SMEM(smem_raw);
   float* sm = reinterpret_cast<float*>(smem_raw);
   const int H = a.H, O = a.O, OP = a.OP, A = a.A, AP = a.AP;
-  const int net = blockIdx.y;  // 0 actor, 1 critic
+  const int net = blockIdx.y + (ROLLOUT ? a.net0 : 0);  // 0 actor, 1 critic
   const int KP = (O + 31) & ~31;  // first-layer K padded to whole 32-k stages (x tile zero-padded)
   const int XS = KP + 4, HS = H + 4;
   const int R0 = FRT * (XS > HS ? XS : HS);
@@ -194,21 +194,23 @@ __global__ void __launch_bounds__(512) fused_mlp_kernel(FusedArgs a) {
   // ---- everything that depends on nothing computed here is requested now and consumed phases later: the first two
   // weight stages of layer 1, the biases, and the per-row scalars of the loss (index -> action / log_prob / advantage /
   // value / target: a dependent HBM chain of ~3 us that would otherwise sit between the head GEMM and the loss) ----
-  GemmPipe<false, true> pipe1;
+  GemmPipe<false> pipe1;
   pipe1.prefetch(KP, O, W1, H, n0, lane);
   const float2 bz1 = *reinterpret_cast<const float2*>(B1 + n0 + 2 * cj), bz2 = *reinterpret_cast<const float2*>(B2 + n0 + 2 * cj);
-  const float adv_mean = a.adv_stat[0], adv_rstd = a.adv_stat[1];
+  const float adv_mean = ROLLOUT ? 0.f : a.adv_stat[0], adv_rstd = ROLLOUT ? 1.f : a.adv_stat[1];
   const float ls = (net == 0 && cj < A) ? a.params[a.L.log_std + cj] : 0.f;
   const float b3v = cj < nout ? B3[cj] : 0.f;
   long prow[4];
-  float pf0[4], pf1[4], pf2[4];  // actor: action[o], old log_prob, advantage | critic: old value, target, -
+  float pf0[4], pf1[4], pf2[4];  // actor: action[o], old log_prob, advantage | critic: old value, target, -  (rollout: noise[o])
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     const int i = row0 + 4 * rq + r;
     const bool on = i < a.mb;
-    prow[r] = on ? (a.idx ? (long)a.idx[i] : (long)i) : 0;
+    prow[r] = on ? ((a.idx && !ROLLOUT) ? (long)a.idx[i] : (long)i) : 0;
     pf0[r] = pf1[r] = pf2[r] = 0.f;
-    if (on) {
+    if (ROLLOUT) {
+      if (on && net == 0 && cj < A && a.noise) pf0[r] = a.noise[(size_t)i * A + cj];
+    } else if (on) {
       if (net == 0) {
         if (cj < A) pf0[r] = a.b.action[prow[r] * a.b.act_ld + cj];
         pf1[r] = a.b.log_prob[prow[r]];
@@ -224,27 +226,29 @@ __global__ void __launch_bounds__(512) fused_mlp_kernel(FusedArgs a) {
   for (int e = t; e < FRT * (KP / 4); e += nthr) {
     const int r = e / (KP / 4), c4 = (e % (KP / 4)) * 4;
     const int gi = row0 + r < a.mb ? row0 + r : a.mb - 1;
-    const long row = (a.idx && !(a.skip & 64)) ? a.idx[gi] : gi;
+    const long row = (!ROLLOUT && a.idx && !(a.skip & 64)) ? a.idx[gi] : gi;
     float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
     if (c4 < OP) q = *reinterpret_cast<const float4*>(a.b.obs + row * a.b.obs_ld + c4);
     *reinterpret_cast<float4*>(xt + r * XS + c4) = q;
-    if (net == 0 && c4 < OP && row0 + r < a.mb) *reinterpret_cast<float4*>(a.xmb + (size_t)(row0 + r) * OP + c4) = q;
+    if (!ROLLOUT && net == 0 && c4 < OP && row0 + r < a.mb) *reinterpret_cast<float4*>(a.xmb + (size_t)(row0 + r) * OP + c4) = q;
   }
   for (int e = t; e < H * nout; e += nthr) w3s[e] = W3[e];
   __syncthreads();
 
   // ---- P1 / P2: hidden layers ----
-  GemmPipe<false, false> pipe2;
-  GemmPipe<true, false> pipe5;
+  GemmPipe<false> pipe2;
+  GemmPipe<true> pipe5;
   for (int layer = 0; layer < 2; ++layer) {
     f32x4 acc0, acc1;
     for (int r = 0; r < 4; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
     if (layer == 0) {
-      if (!(a.skip & 1)) pipe1.template run<BF16>(xt, XS, KP, O, W1, H, n0, lane, acc0, acc1);
-      pipe2.prefetch(H, H, W2, H, n0, lane);  // arrives during the epilogue + barrier below
+      if (!(a.skip & 1)) pipe1.template run<BF16>(xt, XS, KP, W1, H, n0, lane, acc0, acc1);
+      if (!ROLLOUT) pipe2.prefetch(H, H, W2, H, n0, lane);  // arrives during the epilogue + barrier below
     } else {
-      if (!(a.skip & 2)) pipe2.template run<BF16>(h1t, HS, H, H, W2, H, n0, lane, acc0, acc1);
-      pipe5.prefetch(H, H, W2, H, n0, lane);  // W2^T fragments of the backward product: hidden under heads / loss / dZ2
+      // rollout: 4 waves per SIMD hide the fill latency, and the 128-VGPR budget has no room for a cross-phase prefetch
+      if (ROLLOUT) pipe2.prefetch(H, H, W2, H, n0, lane);
+      if (!(a.skip & 2)) pipe2.template run<BF16>(h1t, HS, H, W2, H, n0, lane, acc0, acc1);
+      if (!ROLLOUT) pipe5.prefetch(H, H, W2, H, n0, lane);  // W2^T fragments of the backward product: hidden under heads / loss / dZ2
     }
     float* ht = layer == 0 ? h1t : h2t;
     float* hg = layer == 0 ? a.h1[net] : a.h2[net];
@@ -256,7 +260,7 @@ __global__ void __launch_bounds__(512) fused_mlp_kernel(FusedArgs a) {
       float v0 = acc0[r] + bz.x, v1 = acc1[r] + bz.y;
       if (tanh_act) { v0 = fused_tanh(v0); v1 = fused_tanh(v1); } else { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); }
       *reinterpret_cast<float2*>(ht + rr * HS + c0) = make_float2(v0, v1);
-      if (row0 + rr < a.mb && !(a.skip & 32)) *reinterpret_cast<float2*>(hg + (size_t)(row0 + rr) * H + c0) = make_float2(v0, v1);
+      if (!ROLLOUT && row0 + rr < a.mb && !(a.skip & 32)) *reinterpret_cast<float2*>(hg + (size_t)(row0 + rr) * H + c0) = make_float2(v0, v1);
     }
     __syncthreads();
   }
@@ -292,6 +296,40 @@ __global__ void __launch_bounds__(512) fused_mlp_kernel(FusedArgs a) {
     }
     const int o = cj;
     const bool st = wave == 0;
+    if (ROLLOUT) {
+      // pi.sample + pi.log_prob (train.py:158-160) / value (train.py:157,182); same arithmetic as head_kernel<.,false>
+      if (net == 0) {
+        const float inv_std = __expf(-ls), stdv = __expf(ls);
+        const float sum_ls = group16_sum(ls);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int i = row0 + 4 * rq + r;
+          const bool on = i < a.mb;
+          const float mean = out[r] + b3v;
+          float z2 = 0.f;
+          if (on && o < A) {
+            const float act = mean + stdv * pf0[r];
+            const float z = (act - mean) * inv_std;
+            z2 = z * z;
+            if (st) {
+              a.action[(size_t)i * A + o] = act;
+              if (a.mean_out) a.mean_out[(size_t)i * AP + o] = mean;
+            }
+          }
+          const float ss = group16_sum(z2);
+          if (st && on && o == 0) a.log_prob[i] = -0.5f * ss - sum_ls - 0.5f * (float)A * kLog2PiF;
+        }
+      } else {
+        const float b3c = group16_sum(b3v);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int i = row0 + 4 * rq + r;
+          const float v = group16_sum(o == 0 ? out[r] : 0.f) + b3c;
+          if (st && i < a.mb && o == 0) a.value[i] = v;
+        }
+      }
+      return;
+    }
     if (net == 0) {
       const float inv_std = __expf(-ls);
       const float sum_ls = group16_sum(ls);
@@ -387,7 +425,7 @@ __global__ void __launch_bounds__(512) fused_mlp_kernel(FusedArgs a) {
   {
     f32x4 acc0, acc1;
     for (int r = 0; r < 4; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
-    if (!(a.skip & 16)) pipe5.template run<BF16>(dzt, HS, H, H, W2, H, n0, lane, acc0, acc1);
+    if (!(a.skip & 16)) pipe5.template run<BF16>(dzt, HS, H, W2, H, n0, lane, acc0, acc1);
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int rr = 4 * rq + r;
@@ -414,6 +452,19 @@ bool fused_supported(const mppo_net_t& net, const mppo_batch_t& b) {
          (param_layout(net.O, net.A, net.H).c_w2 % 4) == 0;  // float4 rows of W2 in the backward product
 }
 
+bool fused_rollout_supported(const mppo_net_t& net, const float* obs, int obs_ld) {
+  return net.H % 32 == 0 && net.H >= 32 && net.H <= 512 && net.A <= 16 && obs_ld == net.OP && (net.OP % 4) == 0 && (reinterpret_cast<uintptr_t>(obs) & 15) == 0 &&
+         fused_smem_bytes(net.O, net.A, net.H) <= 160 * 1024;
+}
+
+static int32_t fused_set_smem(size_t smem) {
+  MPPO_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(fused_mlp_kernel<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+  MPPO_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(fused_mlp_kernel<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+  MPPO_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(fused_mlp_kernel<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+  MPPO_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(fused_mlp_kernel<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+  return MPPO_OK;
+}
+
 int32_t fused_forward_backward(const mppo_net_t& net, const float* params, const mppo_batch_t& batch, const int* idx, int mb, const float* adv_stat,
                                float inv_count, const mppo_loss_cfg_t& lc, const GradBufs& g, hipStream_t stream) {
   FusedArgs a{};
@@ -426,13 +477,35 @@ int32_t fused_forward_backward(const mppo_net_t& net, const float* params, const
   const size_t smem = fused_smem_bytes(net.O, net.A, net.H);
   static thread_local size_t attr_for = 0;
   if (smem > 64 * 1024 && attr_for < smem) {
-    MPPO_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(fused_mlp_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-    MPPO_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(fused_mlp_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+    MPPO_TRY(fused_set_smem(smem));
     attr_for = smem;
   }
-  if (net.bf16) hipLaunchKernelGGL(fused_mlp_kernel<true>, dim3(cdiv(mb, FRT), 2), dim3(2 * net.H), smem, stream, a);
-  else hipLaunchKernelGGL(fused_mlp_kernel<false>, dim3(cdiv(mb, FRT), 2), dim3(2 * net.H), smem, stream, a);
+  if (net.bf16) hipLaunchKernelGGL((fused_mlp_kernel<true, false>), dim3(cdiv(mb, FRT), 2), dim3(2 * net.H), smem, stream, a);
+  else hipLaunchKernelGGL((fused_mlp_kernel<false, false>), dim3(cdiv(mb, FRT), 2), dim3(2 * net.H), smem, stream, a);
   MPPO_CHECK_LAUNCH("fused_mlp_kernel");
+  return MPPO_OK;
+}
+
+// Rollout policy step on n rows in ONE launch: both hidden layers, the heads, sample + log-prob, value (train.py:157-160);
+// noise == nullptr: critic only (bootstrap value, train.py:182).  Replaces two layer GEMM launches + the head kernel.
+int32_t fused_policy_forward(const mppo_net_t& net, const float* params, int n, const float* obs, int obs_ld, const float* noise, float* action, float* log_prob,
+                             float* value, float* mean_out, int AP, hipStream_t stream) {
+  FusedArgs a{};
+  a.mb = n; a.O = net.O; a.OP = net.OP; a.A = net.A; a.AP = AP; a.DP = AP + 4; a.H = net.H; a.use_tanh = net.use_tanh;
+  a.params = params; a.L = param_layout(net.O, net.A, net.H);
+  a.b.obs = obs; a.b.obs_ld = obs_ld;
+  a.noise = noise; a.action = action; a.log_prob = log_prob; a.value = value; a.mean_out = mean_out;
+  a.net0 = noise ? 0 : 1;
+  const size_t smem = fused_smem_bytes(net.O, net.A, net.H);
+  static thread_local size_t attr_for = 0;
+  if (smem > 64 * 1024 && attr_for < smem) {
+    MPPO_TRY(fused_set_smem(smem));
+    attr_for = smem;
+  }
+  const dim3 grid(cdiv(n, FRT), noise ? 2 : 1);
+  if (net.bf16) hipLaunchKernelGGL((fused_mlp_kernel<true, true>), grid, dim3(2 * net.H), smem, stream, a);
+  else hipLaunchKernelGGL((fused_mlp_kernel<false, true>), grid, dim3(2 * net.H), smem, stream, a);
+  MPPO_CHECK_LAUNCH("fused_mlp_kernel<rollout>");
   return MPPO_OK;
 }
 

@@ -441,6 +441,9 @@ static HeadArgs head_args(const mppo_net_t& net, const float* params, int n, con
 // full policy step on n rows: hidden layers, heads, sample + log-prob (noise may be null: value only)
 int32_t policy_forward(const mppo_net_t& net, const float* params, int n, const float* obs, int obs_ld, const FwdBufs& fb, const float* noise, float* action,
                        float* log_prob, float* value, float* mean_out, hipStream_t stream) {
+  static const char* nofuse = getenv("MPPO_NO_FUSED");  // A/B switch for measurements
+  if (fused_rollout_supported(net, obs, obs_ld) && !(nofuse && nofuse[0] == '1'))
+    return fused_policy_forward(net, params, n, obs, obs_ld, noise, action, log_prob, value, noise ? mean_out : nullptr, fb.AP, stream);  // one launch
   MPPO_TRY(mlp_hidden_forward(net, params, n, obs, obs_ld, nullptr, fb, nullptr, stream));
   HeadArgs a = head_args(net, params, n, fb);
   a.noise = noise; a.action = action; a.log_prob = log_prob; a.value = value; a.mean_out = mean_out;

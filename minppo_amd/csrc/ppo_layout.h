@@ -93,6 +93,9 @@ int32_t gae_launch(int T, int N, float gamma, float lam, const float* reward, co
                    float* target, hipStream_t stream);
 // k_fused.hip: row-local forward + backward of one minibatch in a single launch (falls back to the layer-wise path when unsupported)
 bool fused_supported(const mppo_net_t& net, const mppo_batch_t& b);
+bool fused_rollout_supported(const mppo_net_t& net, const float* obs, int obs_ld);
+int32_t fused_policy_forward(const mppo_net_t& net, const float* params, int n, const float* obs, int obs_ld, const float* noise, float* action, float* log_prob,
+                             float* value, float* mean_out, int AP, hipStream_t stream);
 int32_t fused_forward_backward(const mppo_net_t& net, const float* params, const mppo_batch_t& batch, const int* idx, int mb, const float* adv_stat,
                                float inv_count, const mppo_loss_cfg_t& lc, const GradBufs& g, hipStream_t stream);
 int32_t perm_fill_keys(unsigned long long seed, unsigned long long stream_id, const int* ctr, int B, unsigned* keys, int* vals, hipStream_t stream);

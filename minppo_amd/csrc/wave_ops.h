@@ -93,6 +93,31 @@ __device__ __forceinline__ double wave_sum_f64(double x) {
 // MFMA place NVALU vector-ALU and NVMEM vector-memory-read instructions.  The dependent f32 MFMA chain leaves a 64-cycle
 // gap after each issue; in-order issue would otherwise run the ~100 address / load instructions of the next k-set
 // strictly before the whole chain.  (LLVM sched_group_barrier masks: 0x8 MFMA, 0x2 VALU, 0x20 VMEM read.)
+// ---- raw buffer loads: 32-bit lane offset + scalar offset against a range-checked descriptor; a read past `bytes` returns 0
+// (the hardware's bounds check does the K-tail of the first layer: no clamp arithmetic, no 64-bit lane addresses).
+// The intrinsic is bound by name: clang's __builtin_amdgcn_raw_buffer_load_b64 / _b128 of this ROCm release are lowered to a
+// single buffer_load_dword (upper lanes of the result undefined) - measured, see DESIGN.md. ----
+typedef int i32x4_rsrc __attribute__((ext_vector_type(4)));
+typedef float f32x2_native __attribute__((ext_vector_type(2)));
+__device__ f32x2_native mppo_raw_buffer_load_f32x2(i32x4_rsrc rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.load.v2f32");
+
+struct BufView {
+  i32x4_rsrc r;
+};
+__device__ __forceinline__ BufView make_buf(const float* base, unsigned bytes) {
+  union { i32x4_rsrc v; struct { const float* p; unsigned n; unsigned f; } s; } u;
+  u.s.p = base;        // words 0-1: 48-bit base, stride 0 (raw buffer)
+  u.s.n = bytes;       // word 2: num_records in bytes
+  u.s.f = 0x00020000;  // word 3: 32-bit data format (gfx9 family)
+  BufView b;
+  b.r = u.v;
+  return b;
+}
+__device__ __forceinline__ float2 buf_load_f2(const BufView& b, int lane_off_bytes, int uniform_off_bytes) {
+  const f32x2_native q = mppo_raw_buffer_load_f32x2(b.r, lane_off_bytes, uniform_off_bytes, 0);
+  return make_float2(q.x, q.y);
+}
+
 // nothing is scheduled across this point (compiler-only; no instruction is emitted)
 #define MPPO_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
 

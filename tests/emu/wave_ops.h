@@ -157,6 +157,15 @@ inline float __shfl_xor(float x, int mask) {
 }
 
 #define MPPO_SCHED_FENCE()
+struct BufView { const char* base; unsigned bytes; };
+inline BufView make_buf(const float* base, unsigned bytes) { return BufView{reinterpret_cast<const char*>(base), bytes}; }
+inline float2 buf_load_f2(const BufView& b, int lane_off_bytes, int uniform_off_bytes) {  // per-dword range check, 0 outside (as the hardware)
+  const unsigned off = (unsigned)lane_off_bytes + (unsigned)uniform_off_bytes;
+  float2 q = make_float2(0.f, 0.f);
+  if (off + 4 <= b.bytes) memcpy(&q.x, b.base + off, 4);
+  if (off + 8 <= b.bytes) memcpy(&q.y, b.base + off + 4, 4);
+  return q;
+}
 #define MPPO_INTERLEAVE_MFMA16(NVALU, NVMEM)
 
 // lane l supplies A[i = l&15][k = l>>4], B[k = l>>4][j = l&15]; acc[r] = D[4*(l>>4) + r][l&15]

@@ -67,8 +67,8 @@ def _resume_case(be, tmp_path, trainer_kw):
     for _ in range(2):
         a.update()
     names = T.Trainer._CKPT_REGIONS
+    a._sync()  # the engine runs on its own stream: wait before reading the arena
     want = {n: a._to_host(a.region(n)).copy() for n in names}
-    a._sync()
     a.close()
     b = be.trainer(cfg, **trainer_kw)
     b.load_checkpoint(ck)
