@@ -418,7 +418,7 @@ class Trainer:
                 if W > 1:
                     self._sync()
                     allreduce_sum(reg["grad"])
-                lib.clip_adam(self.P, p["params"], p["adam_m"], p["adam_v"], p["grad"], p["count"], st, C.byref(ac), p["adam_ws"], 1024, s)
+                lib.clip_adam(self.P, p["params"], p["adam_m"], p["adam_v"], p["grad"], p["count"], st, C.byref(ac), p["adam_ws"], self.lib.adam_ws_bytes(self.P), s)
         self._sync()
         cnt = self.region("count")
         cnt[0] += E * M

@@ -68,7 +68,8 @@ def test_kernels_reproduce_ppo_golden(be):
     p, m, v, grad, loss4 = be.arr(g["params0"].astype(f32)), be.zeros((P,)), be.zeros((P,)), be.zeros((P,)), be.zeros((E * M, 4))
     cnt = be.zeros((4,), np.int32)
     wsb = be.lib.grad_ws_bytes(C.byref(net), mb)
-    ws, aws = be.zeros((wsb // 4 + 4,)), be.zeros((256,))
+    awsb = be.lib.adam_ws_bytes(P)
+    ws, aws = be.zeros((wsb // 4 + 4,)), be.zeros((awsb // 4,))
     cfg = nat.AdamCfg(3e-4, 0.5, 0.9, 0.999, 1e-5, 1, mb * E, 1000)
     l4h = be.host(loss4)
     for e in range(E):
@@ -79,7 +80,7 @@ def test_kernels_reproduce_ppo_golden(be):
                                   be.ptr(grad), be.ptr(loss4) + 16 * st, be.ptr(ws), wsb, be.stream)
             if st == 0:
                 np.testing.assert_allclose(be.host(grad), g["grad0"], rtol=0, atol=2e-5 * np.abs(g["grad0"]).max())
-            be.lib.clip_adam(P, be.ptr(p), be.ptr(m), be.ptr(v), be.ptr(grad), be.ptr(cnt), st, C.byref(cfg), be.ptr(aws), 1024, be.stream)
+            be.lib.clip_adam(P, be.ptr(p), be.ptr(m), be.ptr(v), be.ptr(grad), be.ptr(cnt), st, C.byref(cfg), be.ptr(aws), awsb, be.stream)
     np.testing.assert_allclose(be.host(loss4), g["losses"].reshape(-1, 4), rtol=2e-4, atol=1e-5)
     step = np.abs(g["params1"] - g["params0"]).max()
     assert np.abs(be.host(p) - g["params1"]).max() < 1e-3 * step  # params after E*M = 8 Adam steps

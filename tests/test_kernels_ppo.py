@@ -205,10 +205,11 @@ def test_clip_adam_and_schedule(be):
         p, m, v, g = be.arr(p0), be.zeros((P,)), be.zeros((P,)), be.arr(grad)
         cnt = be.arr(np.array([count0, 0, 0, 0], np.int32))
         cfg = nat.AdamCfg(3e-4, 0.5, 0.9, 0.999, 1e-5, anneal, 5120, 24414)
-        ws = be.zeros((256,))
+        wsb = be.lib.adam_ws_bytes(P)
+        ws = be.zeros((wsb // 4,))
         p64, opt = p0.astype(np.float64), po.OptState(np.zeros(P), np.zeros(P), count0)
         for s in range(3):
-            be.lib.clip_adam(P, be.ptr(p), be.ptr(m), be.ptr(v), be.ptr(g), be.ptr(cnt), s, C.byref(cfg), be.ptr(ws), 1024, be.stream)
+            be.lib.clip_adam(P, be.ptr(p), be.ptr(m), be.ptr(v), be.ptr(g), be.ptr(cnt), s, C.byref(cfg), be.ptr(ws), wsb, be.stream)
             p64, opt = po.optimizer_update(p64, opt, grad.astype(np.float64), max_grad_norm=0.5, anneal_lr=bool(anneal), lr_train=3e-4, lr_opt=3e-4,
                                            minibatch_size=1280, update_epochs=4, num_updates=24414)
         np.testing.assert_allclose(be.host(p), p64, atol=1e-6)
@@ -219,8 +220,11 @@ def test_clip_adam_and_schedule(be):
     p, m, v, g = be.zeros((4,)), be.zeros((4,)), be.zeros((4,)), be.arr(g1)
     cnt = be.zeros((4,), np.int32)
     cfg = nat.AdamCfg(1e-3, 0.5, 0.9, 0.999, 1e-5, 0, 1, 1)
-    ws = be.zeros((256,))  # (kept alive across the call: a temporary here would be freed before the kernels write to it)
-    be.lib.clip_adam(4, be.ptr(p), be.ptr(m), be.ptr(v), be.ptr(g), be.ptr(cnt), 0, C.byref(cfg), be.ptr(ws), 1024, be.stream)
+    wsb = be.lib.adam_ws_bytes(4)
+    ws = be.zeros((wsb // 4,))  # (kept alive across the call: a temporary here would be freed before the kernels write to it)
+    be.lib.clip_adam(4, be.ptr(p), be.ptr(m), be.ptr(v), be.ptr(g), be.ptr(cnt), 0, C.byref(cfg), be.ptr(ws), wsb, be.stream)
+    with pytest.raises(nat.NativeError, match="workspace"):
+        be.lib.clip_adam(4, be.ptr(p), be.ptr(m), be.ptr(v), be.ptr(g), be.ptr(cnt), 0, C.byref(cfg), be.ptr(ws), wsb - 4, be.stream)
     gc = g1 / 2
     np.testing.assert_allclose(be.host(p)[:2], -1e-3 * gc[:2] / (np.abs(gc[:2]) + 1e-5), rtol=1e-5)
     assert (be.host(p)[2:] == 0).all()
