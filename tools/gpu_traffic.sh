@@ -14,7 +14,7 @@ import csv, glob, collections, json
 agg=collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob('gpurun_out/traffic/*/*/*counter_collection.csv'):
     for r in csv.DictReader(open(f)):
-        k=r['Kernel_Name'].split('(')[0].split('<')[0][:60]
+        k=r['Kernel_Name'].split('(')[0][:80]
         agg[k][r['Counter_Name']].append(float(r['Counter_Value']))
 out={}
 for k,d in agg.items():
