@@ -40,7 +40,13 @@ struct EnvArgs {
   mppo_forward_probe_t probe;
 };
 
+// wave-level synchronisation point: an environment's LDS arrays are touched by ONE wavefront only, whose LDS instructions
+// execute in program order - all that is needed is that the compiler keeps that order (the emulator yields here instead)
+#ifdef MPPO_EMU
 #define SYNC() __syncthreads()
+#else
+#define SYNC() __builtin_amdgcn_wave_barrier()
+#endif
 #define FOR_G(i, n) for (int i = g; i < (n); i += kGroupLanes)
 // model tables in LDS (see the staging copy at the top of the kernel)
 #define TI(name) (tabI + mv.o[BI_##name])
@@ -188,7 +194,8 @@ __global__ void __launch_bounds__(kEnvBlock) env_kernel(ModelView mv, EnvArgs a,
   MPPO_DYN_SMEM(smem_raw);
   const int tid = threadIdx.x;
   const int g = tid & (kGroupLanes - 1);
-  const int el = tid / kGroupLanes;
+  const int row = (tid & 63) / kGroupLanes;                 // DPP row inside the wave
+  const int el = (tid >> 6) * kEnvsPerWave + row;          // environment inside the workgroup
   int env = blockIdx.x * kEnvsPerBlock + el;
   const bool valid = env < a.N;
   if (!valid) env = a.N - 1;  // surplus groups shadow the last environment and never store
@@ -200,7 +207,8 @@ __global__ void __launch_bounds__(kEnvBlock) env_kernel(ModelView mv, EnvArgs a,
     float4* dst = reinterpret_cast<float4*>(smem_raw);
     for (int i = tid; i < mv.blob_words / 4; i += kEnvBlock) dst[i] = src[i];
   }
-  SYNC();
+  __syncthreads();  // the only workgroup-wide barrier: model tables are shared by the waves of the block
+  if (row >= kEnvsPerWave) return;  // rows without an environment
   float* S = reinterpret_cast<float*>(smem_raw) + mv.blob_words + (size_t)el * P.total;
 
   const int nq = mv.nq, nv = NV ? NV : mv.nv, nu = mv.nu, nb = mv.nbody, njnt = mv.njnt, ncon = mv.ncon, nlim = mv.nlimit, nefc = NV ? NEFC : mv.nefc;

@@ -89,8 +89,23 @@ __host__ __device__ inline PhysLds make_phys_lds(int nq, int nv, int nu, int nbo
   return p;
 }
 
+// Geometry of the environment kernel.  An environment is private to ONE wavefront (16 lanes = one DPP row), so everything
+// after the staging of the model tables synchronises at wave level only (program order; no s_barrier).  A wave carries
+// kEnvsPerWave environments on its first rows (the other rows retire after the staging); kWavesPerBlock waves share one LDS
+// copy of the model tables.  Measured on MI355X, 4096 envs, synth_stompy_pro (tools/env_iters_probe.py), envs/wave x waves/block:
+//   4 x 1: 158 us (default)   2 x 8: 183 us   2 x 4 and 2 x 2: 300 us (LDS lets only one block per CU run)   1 x 4: 600 us
+// i.e. the kernel is bound by the instruction stream each WAVE issues (the same ~27 k VALU instructions whether 16 or 64 lanes
+// are active), not by latency: two half-filled waves per SIMD run 1.7x faster per wave, but there are twice as many.
+#ifndef MPPO_ENVS_PER_WAVE
+#define MPPO_ENVS_PER_WAVE 4
+#endif
+#ifndef MPPO_WAVES_PER_BLOCK
+#define MPPO_WAVES_PER_BLOCK 1
+#endif
 constexpr int kGroupLanes = 16;                      // lanes that cooperate on one environment
-constexpr int kEnvBlock = 64;                        // one wavefront per workgroup
-constexpr int kEnvsPerBlock = kEnvBlock / kGroupLanes;
+constexpr int kEnvsPerWave = MPPO_ENVS_PER_WAVE;     // 1, 2 or 4
+constexpr int kWavesPerBlock = MPPO_WAVES_PER_BLOCK;
+constexpr int kEnvBlock = 64 * kWavesPerBlock;       // threads per workgroup
+constexpr int kEnvsPerBlock = kEnvsPerWave * kWavesPerBlock;
 
 }  // namespace mppo
