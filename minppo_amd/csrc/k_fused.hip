@@ -447,13 +447,13 @@ size_t fused_smem_bytes(int O, int A, int H) {
 }
 
 bool fused_supported(const mppo_net_t& net, const mppo_batch_t& b) {
-  return net.H % 32 == 0 && net.H >= 32 && net.H <= 512 && net.A <= 16 && b.obs_ld == net.OP && (net.OP % 4) == 0 &&
+  return net.H % 32 == 0 && net.H >= 32 && net.H <= 256 && net.A <= 16 && b.obs_ld == net.OP && (net.OP % 4) == 0 &&
          (reinterpret_cast<uintptr_t>(b.obs) & 15) == 0 && fused_smem_bytes(net.O, net.A, net.H) <= 160 * 1024 &&
          (param_layout(net.O, net.A, net.H).c_w2 % 4) == 0;  // float4 rows of W2 in the backward product
 }
 
 bool fused_rollout_supported(const mppo_net_t& net, const float* obs, int obs_ld) {
-  return net.H % 32 == 0 && net.H >= 32 && net.H <= 512 && net.A <= 16 && obs_ld == net.OP && (net.OP % 4) == 0 && (reinterpret_cast<uintptr_t>(obs) & 15) == 0 &&
+  return net.H % 32 == 0 && net.H >= 32 && net.H <= 256 && net.A <= 16 && obs_ld == net.OP && (net.OP % 4) == 0 && (reinterpret_cast<uintptr_t>(obs) & 15) == 0 &&
          fused_smem_bytes(net.O, net.A, net.H) <= 160 * 1024;
 }
 

@@ -44,7 +44,7 @@ def test_gae(be, T, N):
         be.lib.gae(0, N, 0.99, 0.95, 0, 0, 0, 0, 0, 0, be.stream)
 
 
-@pytest.mark.parametrize("O,A,H,n,tanh", [(225, 10, 256, 150, 1), (37, 3, 64, 70, 0), (415, 20, 256, 33, 1)])
+@pytest.mark.parametrize("O,A,H,n,tanh", [(225, 10, 256, 150, 1), (37, 3, 64, 70, 0), (415, 20, 256, 33, 1), (40, 4, 512, 20, 1), (24, 2, 48, 19, 0)])
 def test_policy_forward_sample_logprob(be, O, A, H, n, tanh):
     rng = np.random.default_rng(1)
     net = _net(O, A, H, tanh)
@@ -73,7 +73,8 @@ def test_policy_forward_sample_logprob(be, O, A, H, n, tanh):
         be.lib.policy_forward(C.byref(net), be.ptr(d_flat), n, be.ptr(d_obs), OP, 0, 0, 0, be.ptr(value2), 0, be.ptr(ws), 16, be.stream)
 
 
-@pytest.mark.parametrize("O,A,H,B,mb,tanh,ent", [(225, 10, 256, 400, 200, 1, 0.01), (37, 3, 64, 129, 129, 0, 0.0), (225, 10, 256, 1280, 1280, 1, 0.0)])
+@pytest.mark.parametrize("O,A,H,B,mb,tanh,ent", [(225, 10, 256, 400, 200, 1, 0.01), (37, 3, 64, 129, 129, 0, 0.0), (225, 10, 256, 1280, 1280, 1, 0.0),
+                                                  (40, 4, 512, 80, 48, 1, 0.0)])  # last: H > 256 takes the layer-wise path
 def test_minibatch_grad_matches_oracle(be, O, A, H, B, mb, tanh, ent):
     if be.name == "emu" and mb > 400:
         pytest.skip("full-size minibatch only on the GPU")
