@@ -161,8 +161,10 @@ __device__ __forceinline__ float row32_sum(float x) {
 
 // rollout launches have 2 x N/16 workgroups (512 at N = 4096): two per CU must be co-resident = 4 waves per SIMD (the second
 // __launch_bounds__ argument is HIP's minimum waves per execution unit), i.e. at most 128 VGPRs
-template <bool BF16, bool ROLLOUT>
+// OT = 16-wide output tiles of the head GEMM: 1 for A <= 16, 2 for A <= 32 (BASELINE configs[4]: 20 actuators)
+template <bool BF16, bool ROLLOUT, int OT>
 __global__ void __launch_bounds__(512, ROLLOUT ? MPPO_ROLLOUT_WAVES : 2) fused_mlp_kernel(FusedArgs a) {
+  constexpr int SD = 16 * OT;  // row stride of the per-row output-space tiles
   MPPO_DYN_SMEM(smem_raw);
   float* sm = reinterpret_cast<float*>(smem_raw);
   const int H = a.H, O = a.O, OP = a.OP, A = a.A, AP = a.AP;
@@ -174,10 +176,10 @@ __global__ void __launch_bounds__(512, ROLLOUT ? MPPO_ROLLOUT_WAVES : 2) fused_m
   float* h1t = sm + R0;      // [16][HS]
   float* h2t = h1t + FRT * HS;
   float* w3s = h2t + FRT * HS;          // actor: [H][A], critic: [H]
-  float* s_do = w3s + H * (A > 1 ? A : 1);  // [16][16]  d mean (cols < A, zero beyond) | critic: col 0 = d value
-  float* s_red = s_do + FRT * 16;       // [16][16]  d log_std terms
-  float* s_l = s_red + FRT * 16;        // [16]      per-row loss term
-  float* s_hp = s_l + FRT;              // [H/32 waves][64 lanes][4]  partial head tiles
+  float* s_do = w3s + H * (A > 1 ? A : 1);  // [16][SD]  d mean (cols < A, zero beyond) | critic: col 0 = d value
+  float* s_red = s_do + FRT * SD;       // [16][SD]  d log_std terms
+  float* s_l = s_red + FRT * SD;        // [16]      per-row loss term
+  float* s_hp = s_l + FRT;              // [H/32 waves][OT][64 lanes][4]  partial head tiles
   const int t = threadIdx.x, nthr = blockDim.x, lane = t & 63, wave = t >> 6;
   const int row0 = blockIdx.x * FRT;
   const bool tanh_act = net == 0 && a.use_tanh;
@@ -198,25 +200,36 @@ __global__ void __launch_bounds__(512, ROLLOUT ? MPPO_ROLLOUT_WAVES : 2) fused_m
   pipe1.prefetch(KP, O, W1, H, n0, lane);
   const float2 bz1 = *reinterpret_cast<const float2*>(B1 + n0 + 2 * cj), bz2 = *reinterpret_cast<const float2*>(B2 + n0 + 2 * cj);
   const float adv_mean = ROLLOUT ? 0.f : a.adv_stat[0], adv_rstd = ROLLOUT ? 1.f : a.adv_stat[1];
-  const float ls = (net == 0 && cj < A) ? a.params[a.L.log_std + cj] : 0.f;
-  const float b3v = cj < nout ? B3[cj] : 0.f;
+  float ls[OT], b3v[OT];  // output o = cj + 16*ot of this lane
+#pragma unroll
+  for (int ot = 0; ot < OT; ++ot) {
+    const int o = cj + 16 * ot;
+    ls[ot] = (net == 0 && o < A) ? a.params[a.L.log_std + o] : 0.f;
+    b3v[ot] = o < nout ? B3[o] : 0.f;
+  }
   long prow[4];
-  float pf0[4], pf1[4], pf2[4];  // actor: action[o], old log_prob, advantage | critic: old value, target, -  (rollout: noise[o])
+  float pf0[OT][4], pf1[4], pf2[4];  // actor: action[o], old log_prob, advantage | critic: old value, target, -  (rollout: noise[o])
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     const int i = row0 + 4 * rq + r;
     const bool on = i < a.mb;
     prow[r] = on ? ((a.idx && !ROLLOUT) ? (long)a.idx[i] : (long)i) : 0;
-    pf0[r] = pf1[r] = pf2[r] = 0.f;
+    pf1[r] = pf2[r] = 0.f;
+#pragma unroll
+    for (int ot = 0; ot < OT; ++ot) pf0[ot][r] = 0.f;
     if (ROLLOUT) {
-      if (on && net == 0 && cj < A && a.noise) pf0[r] = a.noise[(size_t)i * A + cj];
+#pragma unroll
+      for (int ot = 0; ot < OT; ++ot)
+        if (on && net == 0 && cj + 16 * ot < A && a.noise) pf0[ot][r] = a.noise[(size_t)i * A + cj + 16 * ot];
     } else if (on) {
       if (net == 0) {
-        if (cj < A) pf0[r] = a.b.action[prow[r] * a.b.act_ld + cj];
+#pragma unroll
+        for (int ot = 0; ot < OT; ++ot)
+          if (cj + 16 * ot < A) pf0[ot][r] = a.b.action[prow[r] * a.b.act_ld + cj + 16 * ot];
         pf1[r] = a.b.log_prob[prow[r]];
         pf2[r] = a.b.adv[prow[r]];
       } else {
-        pf0[r] = a.b.value[prow[r]];
+        pf0[0][r] = a.b.value[prow[r]];
         pf1[r] = a.b.target[prow[r]];
       }
     }
@@ -265,82 +278,102 @@ __global__ void __launch_bounds__(512, ROLLOUT ? MPPO_ROLLOUT_WAVES : 2) fused_m
     __syncthreads();
   }
 
-  // ---- P3: output layer on the matrix cores: one 16x16 tile (rows x outputs), K = H split over the waves ----
+  // ---- P3: output layer on the matrix cores: OT 16x16 tiles (rows x outputs), K = H split over the waves ----
   // wave w multiplies h2[:, 32w .. 32w+32) by W3[32w .. 32w+32, :]; the H/32 partial tiles are summed through LDS.
   {
-    f32x4 hp;
-    for (int r = 0; r < 4; ++r) hp[r] = 0.f;
+    f32x4 hp[OT];
+#pragma unroll
+    for (int ot = 0; ot < OT; ++ot)
+      for (int r = 0; r < 4; ++r) hp[ot][r] = 0.f;
     if (!(a.skip & 4)) {
       const float* arow = h2t + cj * HS + 4 * rq + 32 * wave;
 #pragma unroll
       for (int g = 0; g < 2; ++g) {
         const float4 av = *reinterpret_cast<const float4*>(arow + 16 * g);
         const int kb = 32 * wave + 16 * g + 4 * rq;
-        const float b0 = cj < nout ? w3s[(kb + 0) * nout + cj] : 0.f, b1 = cj < nout ? w3s[(kb + 1) * nout + cj] : 0.f;
-        const float b2 = cj < nout ? w3s[(kb + 2) * nout + cj] : 0.f, b3 = cj < nout ? w3s[(kb + 3) * nout + cj] : 0.f;
-        mfma_f32_16x16x4(av.x, b0, hp); mfma_f32_16x16x4(av.y, b1, hp); mfma_f32_16x16x4(av.z, b2, hp); mfma_f32_16x16x4(av.w, b3, hp);
+#pragma unroll
+        for (int ot = 0; ot < OT; ++ot) {
+          const int o = cj + 16 * ot;
+          const float b0 = o < nout ? w3s[(kb + 0) * nout + o] : 0.f, b1 = o < nout ? w3s[(kb + 1) * nout + o] : 0.f;
+          const float b2 = o < nout ? w3s[(kb + 2) * nout + o] : 0.f, b3 = o < nout ? w3s[(kb + 3) * nout + o] : 0.f;
+          mfma_f32_16x16x4(av.x, b0, hp[ot]); mfma_f32_16x16x4(av.y, b1, hp[ot]); mfma_f32_16x16x4(av.z, b2, hp[ot]); mfma_f32_16x16x4(av.w, b3, hp[ot]);
+        }
       }
     }
-    *reinterpret_cast<float4*>(s_hp + (wave * 64 + lane) * 4) = make_float4(hp[0], hp[1], hp[2], hp[3]);
+#pragma unroll
+    for (int ot = 0; ot < OT; ++ot)
+      *reinterpret_cast<float4*>(s_hp + ((wave * OT + ot) * 64 + lane) * 4) = make_float4(hp[ot][0], hp[ot][1], hp[ot][2], hp[ot][3]);
   }
   __syncthreads();
   {
-    // every wave adds the partial tiles (same order: identical values everywhere); lane (o = lane&15, q = lane>>4) holds
-    // out[r] = output o of row 4q + r.  A DPP row of 16 lanes therefore spans all outputs of a row: row reductions are
-    // group16 sums, one per accumulator register.  Only wave 0 stores.
-    float out[4] = {0.f, 0.f, 0.f, 0.f};
+    // every wave adds the partial tiles (same order: identical values everywhere); lane (cj = lane&15, q = lane>>4) holds
+    // out[ot][r] = output cj + 16*ot of row 4q + r.  A DPP row of 16 lanes therefore spans all outputs of a row: row
+    // reductions are group16 sums (of the per-lane sum over ot), one per accumulator register.  Only wave 0 stores.
+    float out[OT][4];
     const int nw = nthr >> 6;
-    for (int w = 0; w < nw; ++w) {
-      const float4 q = *reinterpret_cast<const float4*>(s_hp + (w * 64 + lane) * 4);
-      out[0] += q.x; out[1] += q.y; out[2] += q.z; out[3] += q.w;
+#pragma unroll
+    for (int ot = 0; ot < OT; ++ot) {
+      out[ot][0] = out[ot][1] = out[ot][2] = out[ot][3] = 0.f;
+      for (int w = 0; w < nw; ++w) {
+        const float4 q = *reinterpret_cast<const float4*>(s_hp + ((w * OT + ot) * 64 + lane) * 4);
+        out[ot][0] += q.x; out[ot][1] += q.y; out[ot][2] += q.z; out[ot][3] += q.w;
+      }
     }
-    const int o = cj;
     const bool st = wave == 0;
+    float sum_ls_l = 0.f, b3_l = 0.f;
+#pragma unroll
+    for (int ot = 0; ot < OT; ++ot) { sum_ls_l += ls[ot]; b3_l += b3v[ot]; }
     if (ROLLOUT) {
       // pi.sample + pi.log_prob (train.py:158-160) / value (train.py:157,182); same arithmetic as head_kernel<.,false>
       if (net == 0) {
-        const float inv_std = __expf(-ls), stdv = __expf(ls);
-        const float sum_ls = group16_sum(ls);
+        const float sum_ls = group16_sum(sum_ls_l);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int i = row0 + 4 * rq + r;
           const bool on = i < a.mb;
-          const float mean = out[r] + b3v;
           float z2 = 0.f;
-          if (on && o < A) {
-            const float act = mean + stdv * pf0[r];
-            const float z = (act - mean) * inv_std;
-            z2 = z * z;
-            if (st) {
-              a.action[(size_t)i * A + o] = act;
-              if (a.mean_out) a.mean_out[(size_t)i * AP + o] = mean;
+#pragma unroll
+          for (int ot = 0; ot < OT; ++ot) {
+            const int o = cj + 16 * ot;
+            if (on && o < A) {
+              const float mean = out[ot][r] + b3v[ot];
+              const float act = mean + __expf(ls[ot]) * pf0[ot][r];
+              const float z = (act - mean) * __expf(-ls[ot]);
+              z2 += z * z;
+              if (st) {
+                a.action[(size_t)i * A + o] = act;
+                if (a.mean_out) a.mean_out[(size_t)i * AP + o] = mean;
+              }
             }
           }
           const float ss = group16_sum(z2);
-          if (st && on && o == 0) a.log_prob[i] = -0.5f * ss - sum_ls - 0.5f * (float)A * kLog2PiF;
+          if (st && on && cj == 0) a.log_prob[i] = -0.5f * ss - sum_ls - 0.5f * (float)A * kLog2PiF;
         }
       } else {
-        const float b3c = group16_sum(b3v);
+        const float b3c = group16_sum(b3v[0]);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int i = row0 + 4 * rq + r;
-          const float v = group16_sum(o == 0 ? out[r] : 0.f) + b3c;
-          if (st && i < a.mb && o == 0) a.value[i] = v;
+          const float v = group16_sum(cj == 0 ? out[0][r] : 0.f) + b3c;
+          if (st && i < a.mb && cj == 0) a.value[i] = v;
         }
       }
       return;
     }
     if (net == 0) {
-      const float inv_std = __expf(-ls);
-      const float sum_ls = group16_sum(ls);
+      const float sum_ls = group16_sum(sum_ls_l);
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int rr = 4 * rq + r, i = row0 + rr;
         const bool on = i < a.mb;
-        const float mean = out[r] + b3v;
-        float z = 0.f;
-        if (on && o < A) z = (pf0[r] - mean) * inv_std;
-        const float ss = group16_sum(z * z);
+        float z[OT], zz = 0.f;
+#pragma unroll
+        for (int ot = 0; ot < OT; ++ot) {
+          z[ot] = 0.f;
+          if (on && cj + 16 * ot < A) z[ot] = (pf0[ot][r] - (out[ot][r] + b3v[ot])) * __expf(-ls[ot]);
+          zz += z[ot] * z[ot];
+        }
+        const float ss = group16_sum(zz);
         float la = 0.f, dlogp = 0.f;
         if (on) {
           const float logp = -0.5f * ss - sum_ls - 0.5f * (float)A * kLog2PiF;
@@ -352,24 +385,28 @@ __global__ void __launch_bounds__(512, ROLLOUT ? MPPO_ROLLOUT_WAVES : 2) fused_m
           const bool unclipped = (ratio >= 1.f - a.lc.clip_eps) && (ratio <= 1.f + a.lc.clip_eps);
           dlogp = (unclipped || la1 < la2) ? -g * ratio * a.inv_count : 0.f;
         }
-        const float dm = o < A ? dlogp * z * inv_std : 0.f;
         if (st) {
-          s_do[rr * 16 + o] = dm;
-          s_red[rr * 16 + o] = o < A ? dlogp * (z * z - 1.f) : 0.f;
-          if (o == 0) s_l[rr] = la;
-          if (on && o < AP) a.dout[(size_t)i * a.DP + o] = dm;
+#pragma unroll
+          for (int ot = 0; ot < OT; ++ot) {
+            const int o = cj + 16 * ot;
+            const float dm = o < A ? dlogp * z[ot] * __expf(-ls[ot]) : 0.f;
+            s_do[rr * SD + o] = dm;
+            s_red[rr * SD + o] = o < A ? dlogp * (z[ot] * z[ot] - 1.f) : 0.f;
+            if (on && o < AP) a.dout[(size_t)i * a.DP + o] = dm;
+          }
+          if (cj == 0) s_l[rr] = la;
         }
       }
     } else {
-      const float b3c = group16_sum(b3v);  // lane o = 0 holds the critic's single output bias
+      const float b3c = group16_sum(b3v[0]);  // lane cj = 0 holds the critic's single output bias
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int rr = 4 * rq + r, i = row0 + rr;
         const bool on = i < a.mb;
-        const float vnew = group16_sum(o == 0 ? out[r] : 0.f) + b3c;
+        const float vnew = group16_sum(cj == 0 ? out[0][r] : 0.f) + b3c;
         float lv = 0.f, dv = 0.f;
         if (on) {
-          const float ov = pf0[r], tg = pf1[r];
+          const float ov = pf0[0][r], tg = pf1[r];
           const float vc = ov + fminf(fmaxf(vnew - ov, -a.lc.clip_eps), a.lc.clip_eps);
           const float vl1 = (vnew - tg) * (vnew - tg), vl2 = (vc - tg) * (vc - tg);
           lv = 0.5f * fmaxf(vl1, vl2) * a.inv_count;
@@ -377,9 +414,10 @@ __global__ void __launch_bounds__(512, ROLLOUT ? MPPO_ROLLOUT_WAVES : 2) fused_m
           dv = (vin || vl1 > vl2) ? (vnew - tg) * a.inv_count * a.lc.vf_coef : 0.f;
         }
         if (st) {
-          s_do[rr * 16 + o] = o == 0 ? dv : 0.f;
-          if (o == 0) s_l[rr] = lv;
-          if (on && o < 4) a.dout[(size_t)i * a.DP + AP + o] = o == 0 ? dv : 0.f;
+#pragma unroll
+          for (int ot = 0; ot < OT; ++ot) s_do[rr * SD + cj + 16 * ot] = (cj == 0 && ot == 0) ? dv : 0.f;
+          if (cj == 0) s_l[rr] = lv;
+          if (on && cj < 4) a.dout[(size_t)i * a.DP + AP + cj] = cj == 0 ? dv : 0.f;
         }
       }
     }
@@ -387,15 +425,15 @@ __global__ void __launch_bounds__(512, ROLLOUT ? MPPO_ROLLOUT_WAVES : 2) fused_m
   __syncthreads();
   // per-workgroup partial sums: partial[blockIdx.x][4+AP]: col 0 actor loss, col 1 value loss, 4+a d log_std[a]
   {
-    float* prow = a.partial + (size_t)blockIdx.x * (4 + AP);
+    float* prow_out = a.partial + (size_t)blockIdx.x * (4 + AP);
     if (net == 0) {
-      if (t == 0) { float s = 0.f; for (int r = 0; r < FRT; ++r) s += s_l[r]; prow[0] = s; }
-      if (t >= 4 && t < 4 + AP) { float s = 0.f; if (t - 4 < A) for (int r = 0; r < FRT; ++r) s += s_red[r * 16 + (t - 4)]; prow[t] = s; }
+      if (t == 0) { float s = 0.f; for (int r = 0; r < FRT; ++r) s += s_l[r]; prow_out[0] = s; }
+      if (t >= 4 && t < 4 + AP) { float s = 0.f; if (t - 4 < A) for (int r = 0; r < FRT; ++r) s += s_red[r * SD + (t - 4)]; prow_out[t] = s; }
     } else if (t == 0) {
-      float s = 0.f; for (int r = 0; r < FRT; ++r) s += s_l[r]; prow[1] = s;
+      float s = 0.f; for (int r = 0; r < FRT; ++r) s += s_l[r]; prow_out[1] = s;
     }
   }
-  // ---- P4: dZ2 = (dOut . W3^T) * act'(h2) on the matrix cores (K = outputs padded to 16) -> LDS (over the dead x tile) + global ----
+  // ---- P4: dZ2 = (dOut . W3^T) * act'(h2) on the matrix cores (K = outputs padded to 16*OT) -> LDS (over the dead x tile) + global ----
   float* dzt = xt;
   {
     f32x4 d0, d1;
@@ -403,9 +441,9 @@ __global__ void __launch_bounds__(512, ROLLOUT ? MPPO_ROLLOUT_WAVES : 2) fused_m
     const int c0 = n0 + 2 * cj;
     if (!(a.skip & 8)) {
 #pragma unroll
-      for (int m = 0; m < 4; ++m) {
+      for (int m = 0; m < 4 * OT; ++m) {
         const int ai = 4 * m + rq;  // output index contracted over
-        const float av = s_do[cj * 16 + ai];
+        const float av = s_do[cj * SD + ai];
         const float b0 = ai < nout ? w3s[c0 * nout + ai] : 0.f, b1 = ai < nout ? w3s[(c0 + 1) * nout + ai] : 0.f;
         mfma_f32_16x16x4(av, b0, d0); mfma_f32_16x16x4(av, b1, d1);
       }
@@ -441,27 +479,28 @@ __global__ void __launch_bounds__(512, ROLLOUT ? MPPO_ROLLOUT_WAVES : 2) fused_m
 }
 
 size_t fused_smem_bytes(int O, int A, int H) {
-  const int KP = (O + 31) & ~31, XS = KP + 4, HS = H + 4;
+  const int KP = (O + 31) & ~31, XS = KP + 4, HS = H + 4, OT = A > 16 ? 2 : 1;
   const size_t R0 = (size_t)FRT * (XS > HS ? XS : HS);
-  return sizeof(float) * (R0 + 2 * (size_t)FRT * HS + (size_t)H * (A > 1 ? A : 1) + 2 * FRT * 16 + FRT + (size_t)(H / 32) * 256);
+  return sizeof(float) * (R0 + 2 * (size_t)FRT * HS + (size_t)H * (A > 1 ? A : 1) + 2 * FRT * 16 * OT + FRT + (size_t)(H / 32) * 256 * OT);
 }
 
 bool fused_supported(const mppo_net_t& net, const mppo_batch_t& b) {
-  return net.H % 32 == 0 && net.H >= 32 && net.H <= 256 && net.A <= 16 && b.obs_ld == net.OP && (net.OP % 4) == 0 &&
+  return net.H % 32 == 0 && net.H >= 32 && net.H <= 256 && net.A <= 32 && b.obs_ld == net.OP && (net.OP % 4) == 0 &&
          (reinterpret_cast<uintptr_t>(b.obs) & 15) == 0 && fused_smem_bytes(net.O, net.A, net.H) <= 160 * 1024 &&
          (param_layout(net.O, net.A, net.H).c_w2 % 4) == 0;  // float4 rows of W2 in the backward product
 }
 
 bool fused_rollout_supported(const mppo_net_t& net, const float* obs, int obs_ld) {
-  return net.H % 32 == 0 && net.H >= 32 && net.H <= 256 && net.A <= 16 && obs_ld == net.OP && (net.OP % 4) == 0 && (reinterpret_cast<uintptr_t>(obs) & 15) == 0 &&
+  return net.H % 32 == 0 && net.H >= 32 && net.H <= 256 && net.A <= 32 && obs_ld == net.OP && (net.OP % 4) == 0 && (reinterpret_cast<uintptr_t>(obs) & 15) == 0 &&
          fused_smem_bytes(net.O, net.A, net.H) <= 160 * 1024;
 }
 
 static int32_t fused_set_smem(size_t smem) {
-  MPPO_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(fused_mlp_kernel<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-  MPPO_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(fused_mlp_kernel<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-  MPPO_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(fused_mlp_kernel<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-  MPPO_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(fused_mlp_kernel<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+#define MPPO_FUSED_ATTR(B, R, T) \
+  MPPO_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(fused_mlp_kernel<B, R, T>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem))
+  MPPO_FUSED_ATTR(false, false, 1); MPPO_FUSED_ATTR(true, false, 1); MPPO_FUSED_ATTR(false, true, 1); MPPO_FUSED_ATTR(true, true, 1);
+  MPPO_FUSED_ATTR(false, false, 2); MPPO_FUSED_ATTR(true, false, 2); MPPO_FUSED_ATTR(false, true, 2); MPPO_FUSED_ATTR(true, true, 2);
+#undef MPPO_FUSED_ATTR
   return MPPO_OK;
 }
 
@@ -480,8 +519,14 @@ int32_t fused_forward_backward(const mppo_net_t& net, const float* params, const
     MPPO_TRY(fused_set_smem(smem));
     attr_for = smem;
   }
-  if (net.bf16) hipLaunchKernelGGL((fused_mlp_kernel<true, false>), dim3(cdiv(mb, FRT), 2), dim3(2 * net.H), smem, stream, a);
-  else hipLaunchKernelGGL((fused_mlp_kernel<false, false>), dim3(cdiv(mb, FRT), 2), dim3(2 * net.H), smem, stream, a);
+  const dim3 grid(cdiv(mb, FRT), 2), block(2 * net.H);
+  if (net.A > 16) {
+    if (net.bf16) hipLaunchKernelGGL((fused_mlp_kernel<true, false, 2>), grid, block, smem, stream, a);
+    else hipLaunchKernelGGL((fused_mlp_kernel<false, false, 2>), grid, block, smem, stream, a);
+  } else {
+    if (net.bf16) hipLaunchKernelGGL((fused_mlp_kernel<true, false, 1>), grid, block, smem, stream, a);
+    else hipLaunchKernelGGL((fused_mlp_kernel<false, false, 1>), grid, block, smem, stream, a);
+  }
   MPPO_CHECK_LAUNCH("fused_mlp_kernel");
   return MPPO_OK;
 }
@@ -503,8 +548,14 @@ int32_t fused_policy_forward(const mppo_net_t& net, const float* params, int n, 
     attr_for = smem;
   }
   const dim3 grid(cdiv(n, FRT), noise ? 2 : 1);
-  if (net.bf16) hipLaunchKernelGGL((fused_mlp_kernel<true, true>), grid, dim3(2 * net.H), smem, stream, a);
-  else hipLaunchKernelGGL((fused_mlp_kernel<false, true>), grid, dim3(2 * net.H), smem, stream, a);
+  const dim3 block(2 * net.H);
+  if (net.A > 16) {
+    if (net.bf16) hipLaunchKernelGGL((fused_mlp_kernel<true, true, 2>), grid, block, smem, stream, a);
+    else hipLaunchKernelGGL((fused_mlp_kernel<false, true, 2>), grid, block, smem, stream, a);
+  } else {
+    if (net.bf16) hipLaunchKernelGGL((fused_mlp_kernel<true, true, 1>), grid, block, smem, stream, a);
+    else hipLaunchKernelGGL((fused_mlp_kernel<false, true, 1>), grid, block, smem, stream, a);
+  }
   MPPO_CHECK_LAUNCH("fused_mlp_kernel<rollout>");
   return MPPO_OK;
 }

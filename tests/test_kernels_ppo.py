@@ -44,7 +44,7 @@ def test_gae(be, T, N):
         be.lib.gae(0, N, 0.99, 0.95, 0, 0, 0, 0, 0, 0, be.stream)
 
 
-@pytest.mark.parametrize("O,A,H,n,tanh", [(225, 10, 256, 150, 1), (37, 3, 64, 70, 0), (415, 20, 256, 33, 1), (40, 4, 512, 20, 1), (24, 2, 48, 19, 0)])
+@pytest.mark.parametrize("O,A,H,n,tanh", [(225, 10, 256, 150, 1), (37, 3, 64, 70, 0), (415, 20, 256, 33, 1), (40, 4, 512, 20, 1), (24, 2, 48, 19, 0), (50, 32, 64, 21, 0)])
 def test_policy_forward_sample_logprob(be, O, A, H, n, tanh):
     rng = np.random.default_rng(1)
     net = _net(O, A, H, tanh)
@@ -74,7 +74,9 @@ def test_policy_forward_sample_logprob(be, O, A, H, n, tanh):
 
 
 @pytest.mark.parametrize("O,A,H,B,mb,tanh,ent", [(225, 10, 256, 400, 200, 1, 0.01), (37, 3, 64, 129, 129, 0, 0.0), (225, 10, 256, 1280, 1280, 1, 0.0),
-                                                  (40, 4, 512, 80, 48, 1, 0.0)])  # last: H > 256 takes the layer-wise path
+                                                  (40, 4, 512, 80, 48, 1, 0.0),       # H > 256 takes the layer-wise path
+                                                  (415, 20, 256, 120, 72, 1, 0.01),   # stompy_full: 20 outputs = two head tiles
+                                                  (50, 32, 64, 64, 40, 0, 0.0)])      # the widest head the fused kernel covers
 def test_minibatch_grad_matches_oracle(be, O, A, H, B, mb, tanh, ent):
     if be.name == "emu" and mb > 400:
         pytest.skip("full-size minibatch only on the GPU")
@@ -122,7 +124,7 @@ def test_minibatch_grad_matches_oracle(be, O, A, H, B, mb, tanh, ent):
     np.testing.assert_array_equal(be.host(g1), be.host(g2))
 
 
-@pytest.mark.parametrize("O,A,H,B,mb,tanh", [(225, 10, 256, 400, 200, 1), (37, 3, 64, 129, 129, 0), (225, 10, 256, 1280, 1280, 1)])
+@pytest.mark.parametrize("O,A,H,B,mb,tanh", [(225, 10, 256, 400, 200, 1), (37, 3, 64, 129, 129, 0), (225, 10, 256, 1280, 1280, 1), (415, 20, 256, 120, 72, 1)])
 def test_bf16_mfma_path(be, O, A, H, B, mb, tanh):
     """BASELINE configs[3]: bf16-in / f32-accumulate MFMA in the MLP products, everything else f32.
 
@@ -191,7 +193,10 @@ def test_bf16_mfma_path(be, O, A, H, B, mb, tanh):
     np.testing.assert_allclose(be.host(loss4)[2], lo_x[2], rtol=0, atol=2e-2 * np.abs(gn).mean())
     cos = lambda a, b: float(a @ b / (np.linalg.norm(a) * np.linalg.norm(b)))
     assert cos(got, gb) > 0.99999, cos(got, gb)
-    assert cos(got, gx) > 0.999, cos(got, gx)
+    # SURVEY 8c proposes cosine >= 0.999 against exact arithmetic; what bf16 operands themselves cost depends on the shape (0.9987 for
+    # K = 415 on 72 rows, oracle vs oracle), so the kernel is required to be as close to exact as the bf16 oracle is
+    assert cos(got, gx) > min(0.999, cos(gb, gx) - 1e-4), (cos(got, gx), cos(gb, gx))
+    assert cos(gb, gx) > 0.998
     for k, (o, s) in po.param_slices(O, A, H).items():
         sz = int(np.prod(s))
         np.testing.assert_allclose(got[o:o + sz], gb[o:o + sz], rtol=0, atol=5e-3 * np.abs(gb[o:o + sz]).max() + 1e-7, err_msg=k)
