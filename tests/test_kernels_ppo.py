@@ -44,6 +44,57 @@ def test_gae(be, T, N):
         be.lib.gae(0, N, 0.99, 0.95, 0, 0, 0, 0, 0, 0, be.stream)
 
 
+def _gae(be, T, N, rew, val, done, lv, gamma=0.99, lam=0.95):
+    d = [be.arr(np.ascontiguousarray(x)) for x in (rew.astype(f32), val.astype(f32), done.astype(np.uint8), lv.astype(f32))]
+    adv, tgt = be.zeros((T, N)), be.zeros((T, N))
+    be.lib.gae(T, N, gamma, lam, *[be.ptr(x) for x in d], be.ptr(adv), be.ptr(tgt), be.stream)
+    return be.host(adv).copy(), be.host(tgt).copy()
+
+
+def test_gae_properties_at_full_size(be):
+    """Size-independent properties at the BASELINE trajectory size (T = 10, N = 4096; reference train.py:185-205):
+    the scan is linear in (reward, value, last_val) for a fixed done pattern; done everywhere => adv = r - v;
+    lambda = 0 => adv = delta; gamma = 0 => adv = r - v; targets = adv + value."""
+    T, N = 10, 4096
+    rng = np.random.default_rng(4)
+    done = rng.random((T, N)) < 0.05
+    r1, v1, l1 = rng.standard_normal((T, N)), rng.standard_normal((T, N)), rng.standard_normal(N)
+    r2, v2, l2 = rng.standard_normal((T, N)), rng.standard_normal((T, N)), rng.standard_normal(N)
+    a1, t1 = _gae(be, T, N, r1, v1, done, l1)
+    a2, _ = _gae(be, T, N, r2, v2, done, l2)
+    a12, _ = _gae(be, T, N, 2 * r1 - r2, 2 * v1 - v2, done, 2 * l1 - l2)
+    np.testing.assert_allclose(a12, 2 * a1 - a2, rtol=1e-4, atol=2e-5)
+    np.testing.assert_allclose(t1, a1 + v1.astype(f32), rtol=1e-6, atol=1e-6)
+    a_done, _ = _gae(be, T, N, r1, v1, np.ones((T, N), bool), l1)
+    np.testing.assert_allclose(a_done, (r1 - v1).astype(f32), rtol=1e-6, atol=1e-6)
+    a_g0, _ = _gae(be, T, N, r1, v1, done, l1, gamma=0.0)
+    np.testing.assert_allclose(a_g0, (r1 - v1).astype(f32), rtol=1e-6, atol=1e-6)
+    a_l0, _ = _gae(be, T, N, r1, v1, done, l1, lam=0.0)
+    vnext = np.concatenate([v1[1:], l1[None]], 0)
+    np.testing.assert_allclose(a_l0, (r1 + 0.99 * vnext * (1 - done) - v1).astype(f32), rtol=1e-5, atol=1e-5)
+
+
+def test_gae_random_shapes_match_oracle():
+    """Property test on the emulator build: random T, N, gamma, lambda and done densities (incl. ragged N)."""
+    from hypothesis import given, settings, strategies as st
+    from backends import get_backend
+
+    be = get_backend("emu")
+
+    @settings(max_examples=25, deadline=None)
+    @given(T=st.integers(1, 12), N=st.integers(1, 70), gamma=st.floats(0.0, 1.0), lam=st.floats(0.0, 1.0), p=st.floats(0.0, 1.0), seed=st.integers(0, 2**31 - 1))
+    def check(T, N, gamma, lam, p, seed):
+        rng = np.random.default_rng(seed)
+        rew, val, lv = rng.standard_normal((T, N)), rng.standard_normal((T, N)), rng.standard_normal(N)
+        done = rng.random((T, N)) < p
+        adv, tgt = _gae(be, T, N, rew, val, done, lv, gamma, lam)
+        a64, t64 = po.calculate_gae(done, val.astype(f32).astype(np.float64), rew.astype(f32).astype(np.float64), lv.astype(f32).astype(np.float64), gamma, lam)
+        np.testing.assert_allclose(adv, a64, rtol=1e-4, atol=1e-4)
+        np.testing.assert_allclose(tgt, t64, rtol=1e-4, atol=1e-4)
+
+    check()
+
+
 @pytest.mark.parametrize("O,A,H,n,tanh", [(225, 10, 256, 150, 1), (37, 3, 64, 70, 0), (415, 20, 256, 33, 1), (40, 4, 512, 20, 1), (24, 2, 48, 19, 0), (50, 32, 64, 21, 0)])
 def test_policy_forward_sample_logprob(be, O, A, H, n, tanh):
     rng = np.random.default_rng(1)
