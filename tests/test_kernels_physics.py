@@ -186,6 +186,77 @@ def test_env_step_matches_env_oracle(be, n_frames):
     be.lib.model_close(h)
 
 
+@pytest.mark.gpu
+def test_env_step_properties_at_full_size():
+    """BASELINE configs[1] size (4096 envs) through the C ABI: size-independent properties of `HumanoidEnv.step`
+    (reference env.py:148-196).  (i) Environments are independent and the kernel is a pure function of (state, action):
+    permuting the environments permutes every output, bit for bit - whatever lane group / wave / workgroup an environment
+    lands in.  (ii) Identical states + identical actions give identical results in all 4096 slots.  (iii) An environment
+    driven into termination comes back as the reset record (env.py:179-180) while its neighbours are untouched."""
+    from backends import get_backend
+
+    be = get_backend("hip")
+    cm = load_model("synth_stompy_pro")
+    h, dims, _keep = be.model(cm)
+    N, OP, R, nu, nv, nq = 4096, dims.obs_pad, dims.rec_dim, cm.nu, cm.nv, cm.nq
+    met_np = dict(episode_returns=f32, episode_lengths=np.int32, returned_episode_returns=f32, returned_episode_lengths=np.int32, timestep=np.int32,
+                  returned_episode=np.uint8)
+    rc = nat.RewardCfg(-0.2, 2.0, 2.0, 0.2, 0.5, 0.1, 4.0, 1.0, 1.25)
+
+    def run(actions_per_step, order):
+        """reset, then one step per action array with the environments laid out in `order`; returns per-step outputs in env order"""
+        state, reset_rec, obs = be.zeros((N, R)), be.zeros((R,)), be.zeros((N, OP))
+        rew, done = be.zeros((N,)), be.zeros((N,), np.uint8)
+        met = {k: be.zeros((N,), dt) for k, dt in met_np.items()}
+        M = nat.EnvMetrics(**{k: be.ptr(v) for k, v in met.items()})
+        be.lib.env_reset(h, N, be.ptr(state), be.ptr(reset_rec), be.ptr(obs), OP, be.ptr(rew), be.ptr(done), C.byref(M), be.stream)
+        inv = np.argsort(order)
+        outs = []
+        for a in actions_per_step:
+            da = be.arr(np.ascontiguousarray(a[order]))
+            be.lib.env_step(h, N, 1, C.byref(rc), be.ptr(state), be.ptr(reset_rec), be.ptr(da), nu, be.ptr(obs), OP, be.ptr(rew), be.ptr(done), C.byref(M),
+                            be.stream)
+            outs.append(dict(obs=be.host(obs)[inv].copy(), rew=be.host(rew)[inv].copy(), done=be.host(done)[inv].copy(), state=be.host(state)[inv].copy(),
+                             ret=be.host(met["episode_returns"])[inv].copy()))
+        return outs, be.host(reset_rec).copy()
+
+    rng = np.random.default_rng(11)
+    acts = [(0.5 * rng.standard_normal((N, nu))).astype(f32) for _ in range(4)]
+    acts[1][:64] = acts[1][0]  # (ii) a block of environments with identical histories from here on ...
+    acts[0][:64], acts[2][:64], acts[3][:64] = acts[0][0], acts[2][0], acts[3][0]
+    ident = np.arange(N)
+    perm = rng.permutation(N)
+    a_out, reset_rec = run(acts, ident)
+    b_out, _ = run(acts, perm)
+    for t, (x, y) in enumerate(zip(a_out, b_out)):
+        for k in x:
+            np.testing.assert_array_equal(x[k], y[k], err_msg=f"step {t}: {k} depends on where the environment sits")  # (i)
+    last = a_out[-1]
+    for k in ("obs", "rew", "state"):
+        assert (last[k][:64] == last[k][0]).all(), k  # (ii)
+    assert np.isfinite(last["obs"]).all() and np.isfinite(last["rew"]).all() and not last["done"].any()
+    assert np.unique(last["state"][:, :nq], axis=0).shape[0] > N - 64  # different actions really give different states
+    # (iii) slam every 97th environment through the floor: it terminates (height) and is reset; the others continue
+    state, reset_buf, obs = be.zeros((N, R)), be.zeros((R,)), be.zeros((N, OP))
+    rew, done = be.zeros((N,)), be.zeros((N,), np.uint8)
+    met = {k: be.zeros((N,), dt) for k, dt in met_np.items()}
+    M = nat.EnvMetrics(**{k: be.ptr(v) for k, v in met.items()})
+    be.lib.env_reset(h, N, be.ptr(state), be.ptr(reset_buf), be.ptr(obs), OP, be.ptr(rew), be.ptr(done), C.byref(M), be.stream)
+    st = be.host(state).copy()
+    victims = np.arange(0, N, 97)
+    st[victims, 2] = -5.0  # qpos z far below height_min_z
+    be.put(state, st)
+    da = be.arr(acts[0])
+    be.lib.env_step(h, N, 1, C.byref(rc), be.ptr(state), be.ptr(reset_buf), be.ptr(da), nu, be.ptr(obs), OP, be.ptr(rew), be.ptr(done), C.byref(M), be.stream)
+    d = be.host(done).astype(bool)
+    assert d[victims].all() and d.sum() == victims.size
+    np.testing.assert_array_equal(be.host(state)[victims], np.tile(reset_rec, (victims.size, 1)))
+    others = np.setdiff1d(np.arange(N), victims)
+    np.testing.assert_array_equal(be.host(state)[others], a_out[0]["state"][others])
+    assert (be.host(met["returned_episode"])[victims] == 1).all() and (be.host(met["episode_lengths"])[victims] == 0).all()
+    be.lib.model_close(h)
+
+
 def test_model_blob_validation(be):
     cm = load_model("synth_stompy_pro")
     blob = np.frombuffer(cm.to_blob(), np.uint8).copy()
