@@ -253,6 +253,47 @@ def test_bf16_mfma_path(be, O, A, H, B, mb, tanh):
         np.testing.assert_allclose(got[o:o + sz], gb[o:o + sz], rtol=0, atol=5e-3 * np.abs(gb[o:o + sz]).max() + 1e-7, err_msg=k)
 
 
+def test_minibatch_grad_is_exactly_linear_in_the_row_weight(be):
+    """Property at the BASELINE minibatch size on the GPU (a small one on the emulator): every row enters the loss with the weight
+    `inv_count` (1/mb, or 1/(mb*world_size) on a sharded run), and nothing else normalises by the batch size - so doubling it
+    must double every gradient entry and every loss sum BIT FOR BIT (power-of-two scaling is exact in binary floating point).
+    Also: the entropy coefficient moves only the log_std gradient and the total loss (train.py:240-243)."""
+    O, A, H = 225, 10, 256
+    B = mb = 1280 if be.name == "hip" else 96
+    rng = np.random.default_rng(8)
+    net = _net(O, A, H, 1)
+    OP = net.OP
+    flat, n64 = _params(rng, O, A, H)
+    bobs = np.zeros((B, OP), f32); bobs[:, :O] = rng.standard_normal((B, O))
+    bact = rng.standard_normal((B, A)).astype(f32)
+    m_, ls_, v_ = po.actor_critic_forward(n64, bobs[:, :O].astype(np.float64), True)
+    bval = (v_ + 0.3 * rng.standard_normal(B)).astype(f32)
+    blp = (po.mvn_log_prob(bact.astype(np.float64), m_, ls_) + 0.3 * rng.standard_normal(B)).astype(f32)
+    badv, btgt = rng.standard_normal(B).astype(f32), rng.standard_normal(B).astype(f32)
+    d = {k: be.arr(v) for k, v in dict(flat=flat, obs=bobs, act=bact, val=bval, lp=blp, adv=badv, tgt=btgt).items()}
+    stats = be.arr(np.array([badv.mean(), 1 / (badv.std() + 1e-8)], f32))
+    batch = nat.Batch(be.ptr(d["obs"]), OP, be.ptr(d["act"]), A, be.ptr(d["val"]), be.ptr(d["lp"]), be.ptr(d["adv"]), be.ptr(d["tgt"]))
+    wsb = be.lib.grad_ws_bytes(C.byref(net), mb)
+    ws = be.full((wsb // 4 + 4,), np.nan)
+
+    def grad(inv_count, ent):
+        lc = nat.LossCfg(0.2, 0.5, ent)
+        g, l4 = be.full((flat.size,), np.nan), be.zeros((4,))
+        be.lib.minibatch_grad(C.byref(net), be.ptr(d["flat"]), C.byref(batch), 0, mb, be.ptr(stats), inv_count, C.byref(lc), be.ptr(g), be.ptr(l4), be.ptr(ws), wsb, be.stream)
+        return be.host(g).copy(), be.host(l4).copy()
+
+    g1, l1 = grad(1.0 / mb, 0.0)
+    g2, l2 = grad(2.0 / mb, 0.0)
+    np.testing.assert_array_equal(g2, 2 * g1)
+    np.testing.assert_array_equal(l2[:3], 2 * l1[:3])
+    g3, l3 = grad(1.0 / mb, 0.25)
+    ls_off, _ = po.param_slices(O, A, H)["log_std"]
+    mask = np.ones(flat.size, bool); mask[ls_off:ls_off + A] = False
+    np.testing.assert_array_equal(g3[mask], g1[mask])
+    np.testing.assert_allclose(g3[~mask], g1[~mask] - 0.25, rtol=1e-6, atol=1e-7)  # d(-ent_coef * entropy)/d log_std = -ent_coef
+    np.testing.assert_allclose(l3[0], l1[0] - 0.25 * l3[3], rtol=1e-6)
+
+
 def test_clip_adam_and_schedule(be):
     rng = np.random.default_rng(3)
     P = 5003
