@@ -175,11 +175,10 @@ __global__ void __launch_bounds__(512, ROLLOUT ? MPPO_ROLLOUT_WAVES : 2) fused_m
   float* xt = sm;            // [16][XS]  then dZ2 tile [16][HS]
   float* h1t = sm + R0;      // [16][HS]
   float* h2t = h1t + FRT * HS;
-  float* w3s = h2t + FRT * HS;          // actor: [H][A], critic: [H]
-  float* s_do = w3s + H * (A > 1 ? A : 1);  // [16][SD]  d mean (cols < A, zero beyond) | critic: col 0 = d value
+  float* s_do = h2t + FRT * HS;         // [16][SD]  d mean (cols < A, zero beyond) | critic: col 0 = d value
   float* s_red = s_do + FRT * SD;       // [16][SD]  d log_std terms
   float* s_l = s_red + FRT * SD;        // [16]      per-row loss term
-  float* s_hp = s_l + FRT;              // [H/32 waves][OT][64 lanes][4]  partial head tiles
+  float* s_hp = xt;                     // [H/32 waves][OT][64 lanes][4]  partial head tiles: over the x tile, dead between layer 1 and dZ2
   const int t = threadIdx.x, nthr = blockDim.x, lane = t & 63, wave = t >> 6;
   const int row0 = blockIdx.x * FRT;
   const bool tanh_act = net == 0 && a.use_tanh;
@@ -206,6 +205,25 @@ __global__ void __launch_bounds__(512, ROLLOUT ? MPPO_ROLLOUT_WAVES : 2) fused_m
     const int o = cj + 16 * ot;
     ls[ot] = (net == 0 && o < A) ? a.params[a.L.log_std + o] : 0.f;
     b3v[ot] = o < nout ? B3[o] : 0.f;
+  }
+  // output-layer weights of this lane, straight into registers (they used to be staged in LDS: 20 KB at A = 20, which kept a
+  // second workgroup off the CU): w3p = B operands of the head GEMM (k = 32*wave + 16g + 4rq + c, output o), w3q = B operands
+  // of dZ2 = dOut . W3^T (hidden columns c0, c0 + 1, output ai = 4m + rq)
+  float w3p[OT][8], w3q[4 * OT][2];
+#pragma unroll
+  for (int ot = 0; ot < OT; ++ot)
+#pragma unroll
+    for (int gc = 0; gc < 8; ++gc) {
+      const int o = cj + 16 * ot, k = 32 * wave + 16 * (gc >> 2) + 4 * rq + (gc & 3);
+      w3p[ot][gc] = o < nout ? W3[k * nout + o] : 0.f;
+    }
+  if (!ROLLOUT) {
+#pragma unroll
+    for (int m = 0; m < 4 * OT; ++m) {
+      const int ai = 4 * m + rq, c0 = n0 + 2 * cj;
+      w3q[m][0] = ai < nout ? W3[c0 * nout + ai] : 0.f;
+      w3q[m][1] = ai < nout ? W3[(c0 + 1) * nout + ai] : 0.f;
+    }
   }
   long prow[4];
   float pf0[OT][4], pf1[4], pf2[4];  // actor: action[o], old log_prob, advantage | critic: old value, target, -  (rollout: noise[o])
@@ -245,7 +263,6 @@ __global__ void __launch_bounds__(512, ROLLOUT ? MPPO_ROLLOUT_WAVES : 2) fused_m
     *reinterpret_cast<float4*>(xt + r * XS + c4) = q;
     if (!ROLLOUT && net == 0 && c4 < OP && row0 + r < a.mb) *reinterpret_cast<float4*>(a.xmb + (size_t)(row0 + r) * OP + c4) = q;
   }
-  for (int e = t; e < H * nout; e += nthr) w3s[e] = W3[e];
   __syncthreads();
 
   // ---- P1 / P2: hidden layers ----
@@ -290,13 +307,10 @@ __global__ void __launch_bounds__(512, ROLLOUT ? MPPO_ROLLOUT_WAVES : 2) fused_m
 #pragma unroll
       for (int g = 0; g < 2; ++g) {
         const float4 av = *reinterpret_cast<const float4*>(arow + 16 * g);
-        const int kb = 32 * wave + 16 * g + 4 * rq;
 #pragma unroll
         for (int ot = 0; ot < OT; ++ot) {
-          const int o = cj + 16 * ot;
-          const float b0 = o < nout ? w3s[(kb + 0) * nout + o] : 0.f, b1 = o < nout ? w3s[(kb + 1) * nout + o] : 0.f;
-          const float b2 = o < nout ? w3s[(kb + 2) * nout + o] : 0.f, b3 = o < nout ? w3s[(kb + 3) * nout + o] : 0.f;
-          mfma_f32_16x16x4(av.x, b0, hp[ot]); mfma_f32_16x16x4(av.y, b1, hp[ot]); mfma_f32_16x16x4(av.z, b2, hp[ot]); mfma_f32_16x16x4(av.w, b3, hp[ot]);
+          mfma_f32_16x16x4(av.x, w3p[ot][4 * g + 0], hp[ot]); mfma_f32_16x16x4(av.y, w3p[ot][4 * g + 1], hp[ot]);
+          mfma_f32_16x16x4(av.z, w3p[ot][4 * g + 2], hp[ot]); mfma_f32_16x16x4(av.w, w3p[ot][4 * g + 3], hp[ot]);
         }
       }
     }
@@ -444,8 +458,7 @@ __global__ void __launch_bounds__(512, ROLLOUT ? MPPO_ROLLOUT_WAVES : 2) fused_m
       for (int m = 0; m < 4 * OT; ++m) {
         const int ai = 4 * m + rq;  // output index contracted over
         const float av = s_do[cj * SD + ai];
-        const float b0 = ai < nout ? w3s[c0 * nout + ai] : 0.f, b1 = ai < nout ? w3s[(c0 + 1) * nout + ai] : 0.f;
-        mfma_f32_16x16x4(av, b0, d0); mfma_f32_16x16x4(av, b1, d1);
+        mfma_f32_16x16x4(av, w3q[m][0], d0); mfma_f32_16x16x4(av, w3q[m][1], d1);
       }
     }
 #pragma unroll
@@ -481,7 +494,8 @@ __global__ void __launch_bounds__(512, ROLLOUT ? MPPO_ROLLOUT_WAVES : 2) fused_m
 size_t fused_smem_bytes(int O, int A, int H) {
   const int KP = (O + 31) & ~31, XS = KP + 4, HS = H + 4, OT = A > 16 ? 2 : 1;
   const size_t R0 = (size_t)FRT * (XS > HS ? XS : HS);
-  return sizeof(float) * (R0 + 2 * (size_t)FRT * HS + (size_t)H * (A > 1 ? A : 1) + 2 * FRT * 16 * OT + FRT + (size_t)(H / 32) * 256 * OT);
+  // x tile (later: partial head tiles, then the dZ2 tile) | h1 | h2 | dOut, d log_std terms | per-row loss
+  return sizeof(float) * (R0 + 2 * (size_t)FRT * HS + 2 * FRT * 16 * OT + FRT);
 }
 
 bool fused_supported(const mppo_net_t& net, const mppo_batch_t& b) {
