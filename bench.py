@@ -199,7 +199,7 @@ def main() -> None:
         traffic, traffic_src = None, None
         tf = ROOT / "profiles" / "r01_f_hbm_traffic.json"
         if tf.exists() and args.config == "stompy_pro" and args.envs_per_gpu == 4096 and not bf16:
-            traffic = json.loads(tf.read_text())["kernels"]["fused_mlp_kernel<false, false>"]["hbm_bytes_per_launch"]
+            traffic = json.loads(tf.read_text())["kernels"]["fused_mlp_kernel<false, false, 1>"]["hbm_bytes_per_launch"]
             traffic_src = "profiles/r01_f_hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, corrected)"
         out = {
             "metric": "env-steps/sec (whole node), stompy_pro 4096 envs, 1/2/4/8 MI355X",
