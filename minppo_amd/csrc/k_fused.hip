@@ -9,6 +9,10 @@
 // chains interleave on the matrix pipe.  Replaces four launches (two GEMMs, the head/loss kernel, one backward GEMM) and
 // their ~4 us fixed cost each; what needs a reduction over rows (weight gradients) stays in the split-K GEMM that follows.
 // Outputs to HBM/L2: h1, h2, dZ2, dZ1 (operands of the weight-gradient GEMM), dOut, the gathered rows (xmb), loss partials.
+// Template arguments: BF16 (bf16-in / f32-accumulate MFMA, BASELINE configs[3]); ROLLOUT (forward + pi.sample + log_prob + value
+// on N rows, reference train.py:157-160,182: stops after the heads, writes no activations); OT (16-wide output tiles: A <= 16 / 32).
+// Weight stream: range-checked buffer loads through a branch-free three-deep register ring (see BStage / GemmPipe); the
+// output-layer weights live in registers.  LDS per workgroup at O = 225, H = 256: 52 KB.
 #include <wave_ops.h>
 
 #include <cstdlib>
