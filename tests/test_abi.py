@@ -47,3 +47,23 @@ def test_product_package_never_imports_the_oracle():
         src = f.read_text()
         assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M), f"{f} imports the oracle"
         assert "libminppo_emu" not in src, f"{f} references the emulator build"
+
+
+def test_header_is_plain_c_and_cxx(tmp_path):
+    """The boundary is a C ABI: the header must compile as C99 and as C++17 with nothing but the standard headers."""
+    import shutil
+    import subprocess
+
+    hdr = str(Path(__file__).resolve().parents[1] / "include" / "minppo_hip.h")
+    for cc, args in (("gcc", ["-std=c99", "-x", "c"]), ("g++", ["-std=c++17", "-x", "c++"])):
+        if shutil.which(cc) is None:
+            pytest.skip(f"{cc} not installed")
+        r = subprocess.run([cc, "-fsyntax-only", "-Wall", "-Werror", *args, hdr], capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
+    # and a C translation unit that calls through it links against the library's symbol names (no C++ mangling)
+    src = tmp_path / "use.c"
+    src.write_text('#include "minppo_hip.h"\nint main(void) { mppo_net_t n = {225, 228, 10, 256, 1, 0}; return mppo_param_count(&n) == 250133 ? 0 : 1; }\n')
+    r = subprocess.run(["gcc", "-std=c99", "-c", "-I", str(Path(hdr).parent), str(src), "-o", str(tmp_path / "use.o")], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    nm = subprocess.run(["nm", "-u", str(tmp_path / "use.o")], capture_output=True, text=True).stdout
+    assert "mppo_param_count" in nm and "_Z" not in nm
