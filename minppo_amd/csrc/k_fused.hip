@@ -265,7 +265,7 @@ __global__ void __launch_bounds__(512, ROLLOUT ? MPPO_ROLLOUT_WAVES : 2) fused_m
     float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
     if (c4 < OP) q = *reinterpret_cast<const float4*>(a.b.obs + row * a.b.obs_ld + c4);
     *reinterpret_cast<float4*>(xt + r * XS + c4) = q;
-    if (!ROLLOUT && net == 0 && c4 < OP && row0 + r < a.mb) *reinterpret_cast<float4*>(a.xmb + (size_t)(row0 + r) * OP + c4) = q;
+    if (!ROLLOUT && net == 0 && c4 < OP && row0 + r < a.mb) stream_store(a.xmb + (size_t)(row0 + r) * OP + c4, q);
   }
   __syncthreads();
 
@@ -294,7 +294,7 @@ __global__ void __launch_bounds__(512, ROLLOUT ? MPPO_ROLLOUT_WAVES : 2) fused_m
       float v0 = acc0[r] + bz.x, v1 = acc1[r] + bz.y;
       if (tanh_act) { v0 = fused_tanh(v0); v1 = fused_tanh(v1); } else { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); }
       *reinterpret_cast<float2*>(ht + rr * HS + c0) = make_float2(v0, v1);
-      if (!ROLLOUT && row0 + rr < a.mb && !(a.skip & 32)) *reinterpret_cast<float2*>(hg + (size_t)(row0 + rr) * H + c0) = make_float2(v0, v1);
+      if (!ROLLOUT && row0 + rr < a.mb && !(a.skip & 32)) stream_store(hg + (size_t)(row0 + rr) * H + c0, make_float2(v0, v1));
     }
     __syncthreads();
   }
@@ -472,7 +472,7 @@ __global__ void __launch_bounds__(512, ROLLOUT ? MPPO_ROLLOUT_WAVES : 2) fused_m
       const float z0 = tanh_act ? d0[r] * (1.f - hv.x * hv.x) : (hv.x > 0.f ? d0[r] : 0.f);
       const float z1 = tanh_act ? d1[r] * (1.f - hv.y * hv.y) : (hv.y > 0.f ? d1[r] : 0.f);
       *reinterpret_cast<float2*>(dzt + rr * HS + c0) = make_float2(z0, z1);
-      if (row0 + rr < a.mb && !(a.skip & 32)) *reinterpret_cast<float2*>(a.dz2[net] + (size_t)(row0 + rr) * H + c0) = make_float2(z0, z1);
+      if (row0 + rr < a.mb && !(a.skip & 32)) stream_store(a.dz2[net] + (size_t)(row0 + rr) * H + c0, make_float2(z0, z1));
     }
   }
   __syncthreads();
@@ -489,7 +489,7 @@ __global__ void __launch_bounds__(512, ROLLOUT ? MPPO_ROLLOUT_WAVES : 2) fused_m
         const float2 gq = *reinterpret_cast<const float2*>(h1t + rr * HS + c0);
         const float d0 = tanh_act ? acc0[r] * (1.f - gq.x * gq.x) : (gq.x > 0.f ? acc0[r] : 0.f);
         const float d1 = tanh_act ? acc1[r] * (1.f - gq.y * gq.y) : (gq.y > 0.f ? acc1[r] : 0.f);
-        *reinterpret_cast<float2*>(a.dz1[net] + (size_t)(row0 + rr) * H + c0) = make_float2(d0, d1);
+        stream_store(a.dz1[net] + (size_t)(row0 + rr) * H + c0, make_float2(d0, d1));
       }
     }
   }

@@ -118,6 +118,35 @@ __device__ __forceinline__ float2 buf_load_f2(const BufView& b, int lane_off_byt
   return make_float2(q.x, q.y);
 }
 
+// streaming stores: data written once for ANOTHER kernel (possibly on another XCD) goes to memory without staying dirty in this
+// XCD's L2 - the end-of-kernel write-back has less to flush (MPPO_NT_STORES=0 at compile time restores plain stores)
+#ifndef MPPO_NT_STORES
+#define MPPO_NT_STORES 1
+#endif
+__device__ __forceinline__ void stream_store(float* p, float2 v) {
+#if MPPO_NT_STORES
+  typedef float f32x2_st __attribute__((ext_vector_type(2)));
+  __builtin_nontemporal_store(f32x2_st{v.x, v.y}, reinterpret_cast<f32x2_st*>(p));
+#else
+  *reinterpret_cast<float2*>(p) = v;
+#endif
+}
+__device__ __forceinline__ void stream_store(float* p, float v) {
+#if MPPO_NT_STORES
+  __builtin_nontemporal_store(v, p);
+#else
+  *p = v;
+#endif
+}
+__device__ __forceinline__ void stream_store(float* p, float4 v) {
+#if MPPO_NT_STORES
+  typedef float f32x4_st __attribute__((ext_vector_type(4)));
+  __builtin_nontemporal_store(f32x4_st{v.x, v.y, v.z, v.w}, reinterpret_cast<f32x4_st*>(p));
+#else
+  *reinterpret_cast<float4*>(p) = v;
+#endif
+}
+
 // nothing is scheduled across this point (compiler-only; no instruction is emitted)
 #define MPPO_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
 
