@@ -346,8 +346,8 @@ __global__ void __launch_bounds__(256) adam_kernel(size_t P, float* __restrict__
   const float gi = g[i] * scale;
   const float mi = c.b1 * m[i] + (1.f - c.b1) * gi;
   const float vi = c.b2 * v[i] + (1.f - c.b2) * gi * gi;
-  m[i] = mi;
-  v[i] = vi;
+  stream_store(m + i, mi);  // the moments are next read by the next step's Adam, three kernels and ~60 MB of traffic later
+  stream_store(v + i, vi);
   p[i] = p[i] - lr * (mi / bc1) / (sqrtf(vi / bc2) + c.eps);
 }
 
