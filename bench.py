@@ -129,8 +129,76 @@ def cpu_baseline(config_name: str, n_envs: int):
             "sample": f"1 update of the NumPy float32 oracle: {N} envs x {T} steps + {E}x{M} minibatches ({dt:.1f} s); BLAS threads = cores, element-wise NumPy is single-threaded"}
 
 
+def spawn_ranks(args: argparse.Namespace) -> int:
+    """`python bench.py --gpus N` with N > 1 and no launcher around it: this process becomes a supervisor that starts
+    one fresh child per GPU (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in the environment, exactly what
+    torch.distributed.run would set) and forwards rank 0's JSON line.  It never touches the GPU itself
+    (`torch.cuda.device_count()` does not initialise HIP on this image), so nothing that has initialised a GPU is
+    ever re-executed.  If the ranks fail or exceed the time limit with the RCCL calls captured inside the hipGraph
+    (the default), the exact child PIDs are killed and the run is repeated once with eager launches
+    (MPPO_GRAPH_COMM=0)."""
+    import socket
+    import subprocess
+
+    import torch
+
+    have = torch.cuda.device_count()
+    if have < args.gpus:
+        sys.stderr.write(f"bench.py: --gpus {args.gpus} but this machine exposes {have} GPU(s); nothing was run\n")
+        return 2
+
+    def free_port() -> int:
+        s = socket.socket()
+        s.bind(("127.0.0.1", 0))
+        p = s.getsockname()[1]
+        s.close()
+        return p
+
+    def attempt(extra_env: dict, limit_s: float):
+        port = free_port()
+        procs = []
+        for r in range(args.gpus):
+            env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), LOCAL_WORLD_SIZE=str(args.gpus),
+                       MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"), **extra_env)
+            procs.append(subprocess.Popen([sys.executable, str(Path(__file__).resolve()), *sys.argv[1:]], env=env,
+                                          stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, stderr=None))
+        deadline = time.monotonic() + limit_s
+        line, ok = b"", True
+        try:
+            out0, _ = procs[0].communicate(timeout=limit_s)
+            line = out0
+            for p in procs[1:]:
+                p.wait(timeout=max(1.0, deadline - time.monotonic()))
+        except subprocess.TimeoutExpired:
+            ok = False
+        for p in procs:  # exactly the PIDs started above, never a pattern
+            if p.poll() is None:
+                p.kill()
+                p.wait()
+        ok = ok and all(p.returncode == 0 for p in procs)
+        return ok, line
+
+    limit = float(os.environ.get("MPPO_BENCH_RANK_TIMEOUT", "900"))
+    ok, line = attempt({}, limit)
+    if not ok and os.environ.get("MPPO_GRAPH_COMM", "1") != "0":
+        sys.stderr.write("bench.py: ranks failed with RCCL inside the hipGraph; repeating with eager launches (MPPO_GRAPH_COMM=0)\n")
+        ok, line = attempt({"MPPO_GRAPH_COMM": "0"}, limit)
+    if not ok:
+        sys.stderr.write("bench.py: a rank failed or timed out\n")
+        return 1
+    js = [l for l in line.decode(errors="replace").splitlines() if l.startswith("{")]
+    if not js:
+        sys.stderr.write("bench.py: rank 0 printed no JSON line\n")
+        return 1
+    sys.stdout.write(js[-1] + "\n")
+    sys.stdout.flush()
+    return 0
+
+
 def main() -> None:
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(spawn_ranks(args))  # before anything in this process touches a GPU
     # The contract is ONE JSON line on stdout.  RCCL prints a version banner through C stdio on stdout (flushed at
     # exit, i.e. AFTER anything Python printed), so fd 1 is pointed at stderr for the life of the process and the JSON
     # line is written to the saved descriptor.
@@ -144,9 +212,9 @@ def main() -> None:
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch multi-GPU runs with torch.distributed.run (one process per GPU); see the docstring")
         raise SystemExit(f"--gpus {args.gpus} does not match WORLD_SIZE {world}")
+    if torch.cuda.device_count() <= local_rank:
+        raise SystemExit(f"rank {rank}: LOCAL_RANK {local_rank} but only {torch.cuda.device_count()} GPU(s) are visible")
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")

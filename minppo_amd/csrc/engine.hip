@@ -4,7 +4,7 @@
 // kernel launches enqueued from C++ on the caller's stream (about 1.3k launches per update at the
 // default 4 epochs x 32 minibatches), optionally captured once into a hipGraph and replayed, so
 // that Python is out of the loop.  All buffers live in one caller-owned HBM arena whose layout is
-// fixed at creation time (so the captured graph stays valid); dynamic quantities the graph must
+// fixed at creation time (so the captured graph stays valid; with several ranks the RCCL calls are captured too); dynamic quantities the graph must
 // not bake in (Adam step index, RNG stream position) live in the arena's `count` words and are
 // advanced by a kernel at the end of every update.
 //
@@ -31,20 +31,40 @@ __global__ void advance_counters_kernel(int* count, int opt_steps) {
   if (threadIdx.x == 0 && blockIdx.x == 0) { count[0] += opt_steps; count[1] += 1; }
 }
 
-// per-update rollout statistics (device-side reduction of what the reference returns as the
-// full [T,N] metrics history, train.py:283): {sum reward, #done, sum returned_episode_returns
-// over done steps, sum returned_episode_lengths over done steps}
-__global__ void __launch_bounds__(256) rollout_stats_kernel(int n, const float* __restrict__ reward, const unsigned char* __restrict__ done,
-                                                            float* __restrict__ out) {
-  __shared__ float red[4][2];
-  float sr = 0.f, sd = 0.f;
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) { sr += reward[i]; sd += done[i] ? 1.f : 0.f; }
-  sr = wave_sum(sr); sd = wave_sum(sd);
-  if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6][0] = sr; red[threadIdx.x >> 6][1] = sd; }
+// Per-update rollout statistics: the device-side reduction of what the reference returns as the full [T,N] history of
+// `EnvMetrics` (env.py:183-194 -> Memory.info, train.py:170,283).  One workgroup of 1024 threads; thread n walks its
+// environments through the T steps, replaying the episode bookkeeping of env.py:183-190 from the rollout's own reward /
+// done arrays (carry-in = the environments' episode_returns / episode_lengths as they stood BEFORE the rollout, copied
+// by the engine), and the block reduces in a fixed order in float64: bit-reproducible, no atomics.
+//   out[0] sum of rewards            out[1] number of done steps (= returned episodes)
+//   out[2] sum over done steps of returned_episode_returns      out[3] ... of returned_episode_lengths
+//   out[4] = out[2]/out[1], out[5] = out[3]/out[1] (0 when no episode ended)    out[6], out[7] = 0
+constexpr int kStatsThreads = 1024;
+__global__ void __launch_bounds__(kStatsThreads) rollout_stats_kernel(int T, int N, const float* __restrict__ reward, const unsigned char* __restrict__ done,
+                                                                      const float* __restrict__ ret_in, const int* __restrict__ len_in, float* __restrict__ out) {
+  __shared__ double red[kStatsThreads / 64][4];
+  double sr = 0.0, sd = 0.0, sret = 0.0, slen = 0.0;
+  for (int n = threadIdx.x; n < N; n += kStatsThreads) {
+    float ret = ret_in[n];
+    int len = len_in[n];
+    for (int t = 0; t < T; ++t) {
+      const float r = reward[(size_t)t * N + n];
+      const bool d = done[(size_t)t * N + n] != 0;
+      ret += r; len += 1;                       // new_episode_return / new_episode_length (env.py:183-184)
+      sr += (double)r;
+      if (d) { sd += 1.0; sret += (double)ret; slen += (double)len; ret = 0.f; len = 0; }  // env.py:187-190
+    }
+  }
+  sr = wave_sum_f64(sr); sd = wave_sum_f64(sd); sret = wave_sum_f64(sret); slen = wave_sum_f64(slen);
+  if ((threadIdx.x & 63) == 0) { double* q = red[threadIdx.x >> 6]; q[0] = sr; q[1] = sd; q[2] = sret; q[3] = slen; }
   __syncthreads();
   if (threadIdx.x == 0) {
-    atomicAdd(out + 0, red[0][0] + red[1][0] + red[2][0] + red[3][0]);
-    atomicAdd(out + 1, red[0][1] + red[1][1] + red[2][1] + red[3][1]);
+    double a[4] = {0.0, 0.0, 0.0, 0.0};
+    for (int w = 0; w < kStatsThreads / 64; ++w) for (int k = 0; k < 4; ++k) a[k] += red[w][k];
+    for (int k = 0; k < 4; ++k) out[k] = (float)a[k];
+    out[4] = a[1] > 0.0 ? (float)(a[2] / a[1]) : 0.f;
+    out[5] = a[1] > 0.0 ? (float)(a[3] / a[1]) : 0.f;
+    out[6] = 0.f; out[7] = 0.f;
   }
 }
 
@@ -67,6 +87,8 @@ struct mppo_engine {
   double* adv_sums;
   mppo_env_metrics_t met;
   float *fwd_ws, *grad_ws, *adam_ws;
+  float* stat_ret_in;
+  int* stat_len_in;
   void* perm_ws;
   size_t perm_ws_bytes;
   mppo::Comm* comm;
@@ -109,7 +131,9 @@ static size_t layout(mppo_engine* e, bool assign) {
   e->adv_sums = (double*)take("adv_sums", EM * 2 * 8);
   e->adv_stats = (float*)take("adv_stats", EM * 2 * 4);
   e->losses = (float*)take("losses", EM * 4 * 4);
-  e->stats = (float*)take("rollout_stats", 4 * 4);
+  e->stats = (float*)take("rollout_stats", 8 * 4);
+  e->stat_ret_in = (float*)take("stats_carry_returns", N * 4);
+  e->stat_len_in = (int*)take("stats_carry_lengths", N * 4);
   e->met.episode_returns = (float*)take("episode_returns", N * 4);
   e->met.episode_lengths = (int32_t*)take("episode_lengths", N * 4);
   e->met.returned_episode_returns = (float*)take("returned_episode_returns", N * 4);
@@ -154,6 +178,9 @@ constexpr unsigned long long kStreamPerm = 0x5045524Dull << 24;     // "PERM"
 static int32_t do_rollout(mppo_engine* e, hipStream_t s) {
   const mppo_engine_cfg_t& c = e->cfg;
   const size_t N = e->N, OP = e->OP, A = e->A;
+  // episode bookkeeping as it stands before the rollout: carry-in of the statistics kernel at the end
+  MPPO_CHECK_HIP(hipMemcpyAsync(e->stat_ret_in, e->met.episode_returns, N * 4, hipMemcpyDeviceToDevice, s));
+  MPPO_CHECK_HIP(hipMemcpyAsync(e->stat_len_in, e->met.episode_lengths, N * 4, hipMemcpyDeviceToDevice, s));
   if (!c.external_random)
     MPPO_TRY(normal_fill_ctr(c.seed, kStreamNoise + ((unsigned long long)c.rank << 16), e->count + 1, (size_t)e->T * N * A, e->noise, s));
   FwdBufs fb = carve_fwd(c.net, e->N, e->fwd_ws);
@@ -166,8 +193,7 @@ static int32_t do_rollout(mppo_engine* e, hipStream_t s) {
   }
   MPPO_TRY(policy_forward(c.net, e->params, e->N, e->obs + (size_t)e->T * N * OP, e->OP, fb, nullptr, nullptr, nullptr, e->last_val, nullptr, s));  // train.py:182
   MPPO_TRY(gae_launch(e->T, e->N, c.gamma, c.gae_lambda, e->reward, e->value, e->done, e->last_val, e->adv, e->target, s));
-  MPPO_CHECK_HIP(hipMemsetAsync(e->stats, 0, 16, s));
-  hipLaunchKernelGGL(rollout_stats_kernel, dim3(64), dim3(256), 0, s, e->B, e->reward, e->done, e->stats);
+  hipLaunchKernelGGL(rollout_stats_kernel, dim3(1), dim3(kStatsThreads), 0, s, e->T, e->N, e->reward, e->done, e->stat_ret_in, e->stat_len_in, e->stats);
   MPPO_CHECK_LAUNCH("rollout_stats_kernel");
   return MPPO_OK;
 }
@@ -264,7 +290,15 @@ extern "C" int32_t mppo_comm_unique_id(void* id128) {
 extern "C" int32_t mppo_engine_comm_init(mppo_engine_t* e, const void* id128) {
   MPPO_REQUIRE(e && id128, "mppo_engine_comm_init: null argument");
   MPPO_REQUIRE(!e->comm, "mppo_engine_comm_init: communicator already initialised");
-  return comm_create(id128, e->cfg.rank, e->cfg.world_size, &e->comm);
+  MPPO_TRY(comm_create(id128, e->cfg.rank, e->cfg.world_size, &e->comm));
+  // one eager all-reduce of each kind now (scratch regions of the arena, overwritten before they are read): RCCL sets up
+  // its channels and buffers on the first call, which must not happen inside a stream capture
+  MPPO_CHECK_HIP(hipMemsetAsync(e->grad, 0, (size_t)e->P * 4, nullptr));
+  MPPO_CHECK_HIP(hipMemsetAsync(e->adv_sums, 0, (size_t)e->E * e->M * 2 * 8, nullptr));
+  MPPO_TRY(comm_allreduce_f32(e->comm, e->grad, (size_t)e->P, nullptr));
+  MPPO_TRY(comm_allreduce_f64(e->comm, e->adv_sums, (size_t)e->E * e->M * 2, nullptr));
+  MPPO_CHECK_HIP(hipStreamSynchronize(nullptr));
+  return MPPO_OK;
 }
 
 extern "C" int32_t mppo_engine_reset(mppo_engine_t* e, void* stream) {
@@ -299,11 +333,16 @@ extern "C" int32_t mppo_engine_learn(mppo_engine_t* e, void* stream) {
 extern "C" int32_t mppo_engine_update(mppo_engine_t* e, void* stream) {
   MPPO_TRY(require_ready(e, true));
   hipStream_t s = static_cast<hipStream_t>(stream);
-  const bool want_graph = e->cfg.use_graph && !e->graph_failed && e->cfg.world_size == 1 && !e->comm && s != nullptr;
+  // The RCCL all-reduces are captured into the graph together with the kernels (MPPO_GRAPH_COMM=0: multi-rank updates
+  // run as eager launches instead).  Every rank takes the same decision: the setting is an environment variable of the
+  // job and a capture failure is a property of the installation, not of the rank.
+  static const bool graph_comm = [] { const char* v = getenv("MPPO_GRAPH_COMM"); return !(v && v[0] == '0'); }();
+  const bool with_comm = e->cfg.world_size > 1 || e->comm;
+  const bool want_graph = e->cfg.use_graph && !e->graph_failed && s != nullptr && (!with_comm || graph_comm);
   if (want_graph) {
     if (!e->graph) {
       // capture once; every pointer and size in the sequence is fixed by the arena layout
-      if (graph_begin(s) == MPPO_OK) {
+      if (graph_begin(s, with_comm) == MPPO_OK) {
         int32_t r = do_rollout(e, s);
         if (r == MPPO_OK) r = do_learn(e, s);
         const int32_t r2 = graph_end(s, &e->graph);

@@ -16,7 +16,7 @@ int32_t comm_allreduce_f32(Comm* c, float* buf, size_t n, hipStream_t s);   // i
 int32_t comm_allreduce_f64(Comm* c, double* buf, size_t n, hipStream_t s);  // in-place sum
 
 struct GraphExec;
-int32_t graph_begin(hipStream_t s);
+int32_t graph_begin(hipStream_t s, bool with_collectives);  // with_collectives: relaxed capture mode (RCCL calls runtime APIs while enqueueing)
 int32_t graph_end(hipStream_t s, GraphExec** out);
 int32_t graph_launch(GraphExec* g, hipStream_t s);
 void graph_destroy(GraphExec* g);

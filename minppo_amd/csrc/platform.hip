@@ -56,8 +56,8 @@ int32_t comm_allreduce_f64(Comm* c, double* buf, size_t n, hipStream_t s) {
   return MPPO_OK;
 }
 
-int32_t graph_begin(hipStream_t s) {
-  MPPO_CHECK_HIP(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+int32_t graph_begin(hipStream_t s, bool with_collectives) {
+  MPPO_CHECK_HIP(hipStreamBeginCapture(s, with_collectives ? hipStreamCaptureModeRelaxed : hipStreamCaptureModeThreadLocal));
   return MPPO_OK;
 }
 

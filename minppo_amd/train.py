@@ -362,17 +362,22 @@ class Trainer:
                 with self.torch.cuda.device(self.device):
                     self.lib.engine_comm_init(self._engine, host.ctypes.data)
             return
+        import torch
         import torch.distributed as dist
 
-        idbuf = self.torch.zeros(128, dtype=self.torch.uint8)
+        host = np.zeros(128, np.uint8)
         if self.rank == 0:
-            host = np.zeros(128, np.uint8)
             self.lib.comm_unique_id(host.ctypes.data)
-            idbuf = self.torch.from_numpy(host)
-        idbuf = idbuf.to(self.device)
+        idbuf = torch.from_numpy(host)
+        on_gpu = self.xp == "torch" and dist.get_backend() == "nccl"
+        if on_gpu:
+            idbuf = idbuf.to(self.device)
         dist.broadcast(idbuf, src=0)
         host = idbuf.cpu().numpy().copy()
-        with self.torch.cuda.device(self.device):
+        if self.xp == "torch":
+            with self.torch.cuda.device(self.device):
+                self.lib.engine_comm_init(self._engine, host.ctypes.data)
+        else:  # emulator build: the "communicator" is a shared-memory segment between the rank processes (tests/emu)
             self.lib.engine_comm_init(self._engine, host.ctypes.data)
 
     # -- stepping ----------------------------------------------------------------
@@ -430,15 +435,40 @@ class Trainer:
             obs[0] = obs[self.T]
         self.updates_done += 1
 
-    def rollout_stats(self) -> Dict[str, float]:
+    def rollout_stats(self, reduce: bool = False) -> Dict[str, float]:
+        """Device-side reduction of the last rollout's `EnvMetrics` history (`env.py:183-194`, `train.py:170,283`):
+        mean reward per env-step, fraction of done steps, number of episodes that ended, and the mean return / length
+        of those episodes (`returned_episode_returns / _lengths` at the steps where `returned_episode` is set).
+        `reduce=True` sums over the ranks first (a collective)."""
         self._sync()
-        s = self._to_host(self.region("rollout_stats"))
+        s = self._to_host(self.region("rollout_stats")).astype(np.float64)[:4]
         n = float(self.T * self.N)
-        return {"mean_reward": float(s[0]) / n, "done_fraction": float(s[1]) / n}
+        if reduce and self.world_size > 1:
+            s = self._allreduce_host(s)
+            n *= self.world_size
+        ep = float(s[1])
+        return {"mean_reward": float(s[0]) / n, "done_fraction": ep / n, "episodes": ep,
+                "mean_episode_return": float(s[2]) / ep if ep > 0 else 0.0, "mean_episode_length": float(s[3]) / ep if ep > 0 else 0.0}
 
-    def losses(self) -> np.ndarray:
+    def losses(self, reduce: bool = False) -> np.ndarray:
+        """[E, M, 4] = (total, value, actor, entropy) of every minibatch of the last update.  With more than one rank
+        the engine weights rows 1/(mb*world), so each rank holds its partial sums; `reduce=True` adds them over the
+        ranks (a collective: every rank must call it) and returns the losses of the global minibatches."""
         self._sync()
-        return self._to_host(self.region("losses", (self.E, self.M, 4))).copy()
+        out = self._to_host(self.region("losses", (self.E, self.M, 4))).copy()
+        if reduce and self.world_size > 1:
+            out = self._allreduce_host(out)
+        return out
+
+    def _allreduce_host(self, a: np.ndarray) -> np.ndarray:
+        import torch
+        import torch.distributed as dist
+
+        t = torch.from_numpy(np.ascontiguousarray(a))
+        if dist.get_backend() == "nccl":
+            t = t.to(self.device)
+        dist.all_reduce(t)
+        return t.cpu().numpy()
 
     def close(self) -> None:
         if getattr(self, "_engine", None) is not None and self._engine:
@@ -488,21 +518,22 @@ def make_train(config: Config, **trainer_kwargs: Any) -> Callable[[Any], TrainOu
             tr.reset()
         first = tr.updates_done
         n = num_updates if max_updates is None else min(num_updates, first + max_updates)
-        metrics = {"mean_reward": [], "done_fraction": [], "total_loss": [], "value_loss": [], "actor_loss": [], "entropy": []}
+        metrics = {"mean_reward": [], "done_fraction": [], "episodes": [], "mean_episode_return": [], "mean_episode_length": [], "total_loss": [], "value_loss": [],
+                   "actor_loss": [], "entropy": []}
         t0 = time.time()
         for u in range(first, n):
             tr.update()
             if ckpt and tc.checkpoint_every > 0 and (u + 1) % tc.checkpoint_every == 0 and u + 1 < n:
                 tr.save_checkpoint(ckpt)
             if log_every and ((u + 1) % log_every == 0 or u + 1 == n):
-                st, lo = tr.rollout_stats(), tr.losses().reshape(-1, 4).mean(0)
+                st, lo = tr.rollout_stats(reduce=True), tr.losses(reduce=True).reshape(-1, 4).mean(0)
                 for k, v in st.items():
                     metrics[k].append(v)
                 for k, v in zip(("total_loss", "value_loss", "actor_loss", "entropy"), lo):
                     metrics[k].append(float(v))
                 sps = (u + 1 - first) * tr.T * tr.N * tr.world_size / (time.time() - t0)
-                logger.info("update %d/%d  reward %.3f  done %.4f  loss %.4f  %.0f env-steps/s", u + 1, n, st["mean_reward"], st["done_fraction"],
-                            lo[0], sps)
+                logger.info("update %d/%d  reward %.3f  done %.4f  episode return %.2f length %.1f  loss %.4f  %.0f env-steps/s", u + 1, n, st["mean_reward"],
+                            st["done_fraction"], st["mean_episode_return"], st["mean_episode_length"], lo[0], sps)
         if ckpt:
             tr.save_checkpoint(ckpt)
         params = tr.params
@@ -518,22 +549,50 @@ def make_train(config: Config, **trainer_kwargs: Any) -> Callable[[Any], TrainOu
     return train
 
 
+def _dist_env() -> tuple[int, int, int]:
+    """(rank, world_size, local_rank) as torch.distributed.run / bench.py export them; (0, 1, 0) for a plain run."""
+    return int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("LOCAL_RANK", "0"))
+
+
 def main(args: Sequence[str] | None = None) -> None:
+    """`minppo train <config> [overrides]` (`minppo/train.py:294-315`).  Under `python -m torch.distributed.run
+    --nproc-per-node G -m minppo_amd.train ...` every process is one rank of the env-sharded run:
+    rank r drives GPU LOCAL_RANK with num_envs / G environments, the engine all-reduces gradients over RCCL, and
+    only rank 0 writes the model file."""
     logging.basicConfig(level=logging.INFO, format="%(asctime)s - %(levelname)s - %(message)s")
     if args is None:
         args = sys.argv[1:]
     config = load_config_from_cli(args)
     logger.info("Configuration loaded")
+    rank, world, local_rank = _dist_env()
+    kwargs: Dict[str, Any] = {}
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+
+        torch.cuda.set_device(local_rank)
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if not dist.is_initialized():
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        kwargs = dict(rank=rank, world_size=world, device=f"cuda:{local_rank}")
+        logger.info("rank %d of %d on cuda:%d (%d environments per rank)", rank, world, local_rank, config.training.num_envs // world)
     rng = config.training.seed
     logger.info(f"Random seed set to {config.training.seed}")
-    train = make_train(config)
+    train = make_train(config, **kwargs)
     logger.info("Training function bound to the MI355X engine")
     logger.info("Starting training...")
-    out = train(rng, log_every=max(1, (config.training.total_timesteps // config.training.num_steps // config.training.num_envs) // 100))
+    log_every = max(1, (config.training.total_timesteps // config.training.num_steps // config.training.num_envs) // 100)
+    out = train(rng, log_every=log_every if rank == 0 or world > 1 else 0)
     logger.info("Training completed")
-    logger.info(f"Saving model to {config.training.model_save_path}")
-    save_model(out.runner_state.train_state.params, config.training.model_save_path)
-    logger.info("Model saved successfully")
+    if rank == 0:
+        logger.info(f"Saving model to {config.training.model_save_path}")
+        save_model(out.runner_state.train_state.params, config.training.model_save_path)
+        logger.info("Model saved successfully")
+    if world > 1:
+        import torch.distributed as dist
+
+        dist.barrier()
+        dist.destroy_process_group()
 
 
 if __name__ == "__main__":

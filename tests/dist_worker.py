@@ -1,4 +1,5 @@
-"""Worker for tests/test_distributed.py: one rank of an env-sharded run on the CPU (emulator kernels, gloo collectives)."""
+"""Worker for tests/test_distributed.py: one rank of an env-sharded run on the CPU (emulator kernels; the engine's
+collectives go through the emulator build's shared-memory communicator, the rendezvous through gloo)."""
 import os
 import sys
 
@@ -42,6 +43,9 @@ def run_rank(rank, world, port, overrides, updates, out_path):
     be = get_backend("emu")
     cfg = make_config({"kscale_id": "5eb3cb7f23232298", "visualization": {"camera_name": "track"}}, overrides)
     tr = be.trainer(cfg, rank=rank, world_size=world, external_random=True, use_graph=False)
+    host_driven = os.environ.get("MPPO_TEST_HOST_DRIVEN") == "1"
+    if not host_driven:
+        tr.init_comm()  # the engine's own communicator (emulator build: shared memory between the rank processes)
     tr.reset()
     N, Nl, T, A, E, M = cfg.training.num_envs, tr.N, tr.T, tr.A, tr.E, tr.M
 
@@ -54,7 +58,10 @@ def run_rank(rank, world, port, overrides, updates, out_path):
         tr.region("noise", (T, Nl, A))[:] = noise[:, rank * Nl:(rank + 1) * Nl]
         tr.region("perm", (E, T * Nl))[:] = local[rank]
         tr.rollout()
-        tr.learn_host_driven(allreduce_sum)
+        if host_driven:
+            tr.learn_host_driven(allreduce_sum)  # the stage calls driven from Python with gloo collectives
+        else:
+            tr.learn()  # mppo_engine_learn: csrc/engine.hip do_learn with its communicator branch
     np.savez(out_path, params=tr.params_flat(), losses=tr.losses(), reward=np.array(tr.region("reward", (T, Nl))))
     tr.close()
     dist.barrier()

@@ -1,8 +1,17 @@
 // TEST INFRASTRUCTURE — CPU stand-ins for the pieces of the engine that call vendor device
-// libraries (rocPRIM sort, RCCL): same ABI, same results (the radix sort is stable, as is this one).
+// libraries (rocPRIM sort, RCCL): same ABI, same results (the radix sort is stable, as is this one; the
+// all-reduce is a sum over rank processes through POSIX shared memory).
 #include <hip/hip_runtime.h>
 
+#include <fcntl.h>
+#include <sched.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
 #include <algorithm>
+#include <atomic>
+#include <ctime>
 #include <numeric>
 #include <vector>
 
@@ -26,15 +35,115 @@ int32_t permutation_ctr(unsigned long long seed, unsigned long long stream_id, c
   return MPPO_OK;
 }
 
-// no RCCL and no hipGraph on the CPU: world_size must be 1, updates run eagerly
-struct Comm {};
+// RCCL's place is taken by an all-reduce through POSIX shared memory between the rank PROCESSES of a CPU test
+// (tests/test_distributed.py): same call sites in engine.hip, same semantics (in-place sum, every rank gets the
+// identical result: slots are added in rank order).  The 128-byte "unique id" carries the segment name.
+struct ShmHdr {
+  std::atomic<int> ready, arrive, gen;
+  int world;
+  size_t cap;
+};
+struct Comm {
+  int rank, world;
+  ShmHdr* hdr;
+  unsigned char* slots;
+  size_t map_bytes;
+  char name[96];
+};
+constexpr size_t kSlotBytes = 4u << 20;  // per rank: gradients of up to 1 M parameters
+
+int32_t comm_unique_id(void* id128) {
+  static std::atomic<unsigned> serial{0};
+  memset(id128, 0, 128);
+  snprintf(static_cast<char*>(id128), 96, "/mppo_emu_%d_%lld_%u", (int)getpid(), (long long)time(nullptr), serial.fetch_add(1));
+  return MPPO_OK;
+}
+
+static int32_t shm_barrier(Comm* c) {
+  ShmHdr* h = c->hdr;
+  const int g = h->gen.load();
+  if (h->arrive.fetch_add(1) + 1 == c->world) {
+    h->arrive.store(0);
+    h->gen.fetch_add(1);
+    return MPPO_OK;
+  }
+  const time_t t0 = time(nullptr);
+  while (h->gen.load() == g) {
+    sched_yield();
+    if (time(nullptr) - t0 > 300) return fail(MPPO_ENCCL, "emulator all-reduce: a peer rank did not arrive within 300 s");
+  }
+  return MPPO_OK;
+}
+
+int32_t comm_create(const void* id128, int rank, int world, Comm** out) {
+  MPPO_REQUIRE(world >= 1 && world <= 64 && rank >= 0 && rank < world, "emulator communicator: bad rank %d / world %d", rank, world);
+  Comm* c = new Comm();
+  c->rank = rank; c->world = world;
+  memcpy(c->name, id128, 96);
+  c->name[95] = 0;
+  c->map_bytes = 4096 + (size_t)world * kSlotBytes;
+  int fd = -1;
+  if (rank == 0) {
+    fd = shm_open(c->name, O_CREAT | O_EXCL | O_RDWR, 0600);
+    if (fd < 0 || ftruncate(fd, (off_t)c->map_bytes) != 0) { delete c; return fail(MPPO_ENCCL, "emulator communicator: cannot create %s", (const char*)id128); }
+  } else {
+    const time_t t0 = time(nullptr);
+    for (;;) {
+      fd = shm_open(c->name, O_RDWR, 0600);
+      struct stat st;
+      if (fd >= 0 && fstat(fd, &st) == 0 && (size_t)st.st_size >= c->map_bytes) break;
+      if (fd >= 0) close(fd);
+      if (time(nullptr) - t0 > 120) { delete c; return fail(MPPO_ENCCL, "emulator communicator: %s never appeared", (const char*)id128); }
+      usleep(2000);
+    }
+  }
+  void* m = mmap(nullptr, c->map_bytes, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+  close(fd);
+  if (m == MAP_FAILED) { delete c; return fail(MPPO_ENCCL, "emulator communicator: mmap failed"); }
+  c->hdr = static_cast<ShmHdr*>(m);
+  c->slots = static_cast<unsigned char*>(m) + 4096;
+  if (rank == 0) {
+    c->hdr->arrive.store(0); c->hdr->gen.store(0); c->hdr->world = world; c->hdr->cap = kSlotBytes;
+    c->hdr->ready.store(1);
+  } else {
+    const time_t t0 = time(nullptr);
+    while (c->hdr->ready.load() != 1) {
+      usleep(1000);
+      if (time(nullptr) - t0 > 120) { munmap(m, c->map_bytes); delete c; return fail(MPPO_ENCCL, "emulator communicator: rank 0 never initialised the segment"); }
+    }
+  }
+  const int32_t r = shm_barrier(c);  // everyone has the segment mapped: rank 0 may unlink the name
+  if (rank == 0) shm_unlink(c->name);
+  if (r != MPPO_OK) { munmap(m, c->map_bytes); delete c; return r; }
+  *out = c;
+  return MPPO_OK;
+}
+
+void comm_destroy(Comm* c) {
+  if (!c) return;
+  munmap(c->hdr, c->map_bytes);
+  delete c;
+}
+
+template <typename T>
+static int32_t shm_allreduce(Comm* c, T* buf, size_t n) {
+  MPPO_REQUIRE(c, "all-reduce without a communicator");
+  MPPO_REQUIRE(n * sizeof(T) <= kSlotBytes, "emulator all-reduce: %zu bytes exceed the slot size", n * sizeof(T));
+  memcpy(c->slots + (size_t)c->rank * kSlotBytes, buf, n * sizeof(T));
+  MPPO_TRY(shm_barrier(c));
+  for (size_t i = 0; i < n; ++i) {
+    T s = reinterpret_cast<const T*>(c->slots)[i];
+    for (int r = 1; r < c->world; ++r) s += reinterpret_cast<const T*>(c->slots + (size_t)r * kSlotBytes)[i];
+    buf[i] = s;
+  }
+  return shm_barrier(c);  // nobody overwrites a slot that a peer is still reading
+}
+int32_t comm_allreduce_f32(Comm* c, float* buf, size_t n, hipStream_t) { return shm_allreduce(c, buf, n); }
+int32_t comm_allreduce_f64(Comm* c, double* buf, size_t n, hipStream_t) { return shm_allreduce(c, buf, n); }
+
+// no hipGraph on the CPU: updates run eagerly
 struct GraphExec {};
-int32_t comm_unique_id(void*) { return fail(MPPO_ENCCL, "RCCL is not available in the emulator build"); }
-int32_t comm_create(const void*, int, int, Comm**) { return fail(MPPO_ENCCL, "RCCL is not available in the emulator build"); }
-void comm_destroy(Comm*) {}
-int32_t comm_allreduce_f32(Comm*, float*, size_t, hipStream_t) { return fail(MPPO_ENCCL, "RCCL is not available in the emulator build"); }
-int32_t comm_allreduce_f64(Comm*, double*, size_t, hipStream_t) { return fail(MPPO_ENCCL, "RCCL is not available in the emulator build"); }
-int32_t graph_begin(hipStream_t) { return fail(MPPO_EHIP, "hipGraph is not available in the emulator build"); }
+int32_t graph_begin(hipStream_t, bool) { return fail(MPPO_EHIP, "hipGraph is not available in the emulator build"); }
 int32_t graph_end(hipStream_t, GraphExec**) { return fail(MPPO_EHIP, "hipGraph is not available in the emulator build"); }
 int32_t graph_launch(GraphExec*, hipStream_t) { return fail(MPPO_EHIP, "hipGraph is not available in the emulator build"); }
 void graph_destroy(GraphExec*) {}

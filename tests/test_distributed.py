@@ -27,16 +27,26 @@ def _free_port():
     return p
 
 
-def test_two_ranks_equal_one_process_on_the_union(tmp_path):
-    updates, world = 2, 2
+import os
+
+import pytest
+
+
+@pytest.mark.parametrize("world,host_driven", [(2, False), (4, False), (2, True)])
+def test_ranks_equal_one_process_on_the_union(tmp_path, world, host_driven):
+    """world ranks through `mppo_engine_learn` (engine.hip do_learn, communicator branch) == one process on the union;
+    `host_driven`: the same stages driven from Python (`Trainer.learn_host_driven`) with gloo all-reduces."""
+    updates = 2
     port = _free_port()
+    env = dict(os.environ, MPPO_TEST_HOST_DRIVEN="1" if host_driven else "0")
     procs = [subprocess.Popen([sys.executable, str(HERE / "dist_worker.py"), str(r), str(world), str(port), str(updates), str(tmp_path / f"r{r}.npz"), *OVR],
-                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(world)]
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, env=env) for r in range(world)]
     outs = [p.communicate(timeout=900)[0] for p in procs]
     assert all(p.returncode == 0 for p in procs), "\n".join(outs)
     ranks = [np.load(tmp_path / f"r{r}.npz") for r in range(world)]
     # replicas stay bit-identical (same reduced gradient, same Adam arithmetic)
-    np.testing.assert_array_equal(ranks[0]["params"], ranks[1]["params"])
+    for r in range(1, world):
+        np.testing.assert_array_equal(ranks[0]["params"], ranks[r]["params"])
 
     be = get_backend("emu")
     cfg = make_config({"kscale_id": "5eb3cb7f23232298", "visualization": {"camera_name": "track"}}, OVR)
@@ -54,9 +64,9 @@ def test_two_ranks_equal_one_process_on_the_union(tmp_path):
     assert step > 1e-4
     assert np.abs(ranks[0]["params"] - single).max() < 1e-3 * step + 1e-7, (np.abs(ranks[0]["params"] - single).max(), step)
     # per-rank loss partial sums add up to the single-process losses
-    np.testing.assert_allclose(ranks[0]["losses"] + ranks[1]["losses"], tr.losses(), rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(sum(r["losses"] for r in ranks), tr.losses(), rtol=1e-4, atol=1e-5)
     # environments are independent: each shard's rewards are the corresponding slice of the union run (last update:
     # the parameters differ by summation order after the first one, so equality is to rounding, not bitwise)
     rew = np.array(tr.region("reward", (T, N)))
-    np.testing.assert_allclose(np.concatenate([ranks[0]["reward"], ranks[1]["reward"]], 1), rew, atol=5e-3)
+    np.testing.assert_allclose(np.concatenate([r["reward"] for r in ranks], 1), rew, atol=5e-3)
     tr.close()

@@ -90,7 +90,53 @@ def test_update_matches_oracle_stage_by_stage(be):
         p = got.astype(np.float64)  # continue from the engine's parameters (identical inputs for the next update)
         opt = po.OptState(be.host(tr.region("adam_m")).astype(np.float64), be.host(tr.region("adam_v")).astype(np.float64), opt.count)
     st = tr.rollout_stats()
-    assert np.isfinite(st["mean_reward"]) and st["done_fraction"] == 0.0
+    assert np.isfinite(st["mean_reward"]) and st["done_fraction"] == 0.0 and st["episodes"] == 0 and st["mean_episode_return"] == 0.0
+    np.testing.assert_allclose(st["mean_reward"], tj["reward"].astype(np.float64).mean(), rtol=1e-6)
+    tr.close()
+
+
+def test_rollout_statistics_match_the_env_metrics_history(be):
+    """the per-update reduction of `EnvMetrics` (reference env.py:183-194, stacked into `Memory.info` at
+    train.py:170 and returned at :283).  The height window is set so tightly (the standing robot bobs by ~1 mm) that episodes end inside the rollouts; the reduced
+    sums must equal the same sums over the [T, N] history the env oracle's bookkeeping produces from the engine's own
+    reward / done arrays, across two consecutive rollouts (episodes spanning an update boundary carry over), and the
+    per-environment metrics the kernel keeps must agree with that history at the end."""
+    cfg = _cfg(*_small(be), "reward.height_max_z=1.0101")
+    tr = be.trainer(cfg, external_random=True, use_graph=False)
+    tr.reset()
+    N, T, A, E = tr.N, tr.T, tr.A, tr.E
+    rng = np.random.default_rng(3)
+    ep_ret, ep_len = np.zeros(N, np.float32), np.zeros(N, np.int64)
+    total_done = 0
+    for u in range(3):
+        be.put(tr.region("noise", (T, N, A)), (3.0 * rng.standard_normal((T, N, A))).astype(np.float32))
+        be.put(tr.region("perm", (E, N * T)), np.stack([rng.permutation(N * T) for _ in range(E)]).astype(np.int32))
+        tr.rollout()
+        tr._sync()
+        rew, done = be.host(tr.region("reward", (T, N))).copy(), be.host(tr.region("done", (T, N))).astype(bool)
+        s_ret = s_len = 0.0
+        for t in range(T):  # env.py:183-194 on the engine's reward / done history
+            ep_ret = ep_ret + rew[t]
+            ep_len = ep_len + 1
+            s_ret += float(ep_ret[done[t]].astype(np.float64).sum())
+            s_len += float(ep_len[done[t]].sum())
+            ep_ret = np.where(done[t], np.float32(0), ep_ret).astype(np.float32)
+            ep_len = np.where(done[t], 0, ep_len)
+        st = tr.rollout_stats()
+        nd = int(done.sum())
+        total_done += nd
+        assert st["episodes"] == nd
+        np.testing.assert_allclose(st["mean_reward"], rew.astype(np.float64).mean(), rtol=1e-6)
+        if nd:
+            np.testing.assert_allclose(st["mean_episode_return"], s_ret / nd, rtol=1e-5, atol=1e-5)
+            np.testing.assert_allclose(st["mean_episode_length"], s_len / nd, rtol=1e-6)
+        np.testing.assert_array_equal(be.host(tr.region("episode_lengths")), ep_len)
+        np.testing.assert_allclose(be.host(tr.region("episode_returns")), ep_ret, rtol=1e-6, atol=1e-6)
+        raw = be.host(tr.region("rollout_stats"))
+        st2 = tr.rollout_stats()
+        assert st == st2 and raw[6] == 0 and raw[7] == 0
+        tr.learn()
+    assert total_done >= 2, "the test must see episodes end (raise the noise or the height threshold)"
     tr.close()
 
 
