@@ -240,7 +240,8 @@ typedef struct mppo_engine_cfg {
  * every buffer out inside it.  mppo_engine_arena_bytes gives the size; named regions can be
  * located with mppo_engine_region (offset in bytes, size in bytes) to view them as tensors:
  * "params" "adam_m" "adam_v" "grad" "count" "state" "reset_rec" "obs" "action" "value" "reward"
- * "log_prob" "done" "last_val" "adv" "target" "noise" "perm" "adv_stats" "losses" "metrics_sum" ... */
+ * "log_prob" "done" "last_val" "adv" "target" "noise" "perm" "adv_stats" "losses" "rollout_stats"
+ * (8 floats: sum reward, episodes ended, sum of their returns, sum of their lengths, the two means, 0, 0) ... */
 int32_t mppo_engine_arena_bytes(const mppo_model_t* m, const mppo_engine_cfg_t* cfg, size_t* out);
 int32_t mppo_engine_create(const mppo_model_t* m, const mppo_engine_cfg_t* cfg, void* arena, size_t arena_bytes,
                            mppo_engine_t** out);
@@ -255,6 +256,9 @@ int32_t mppo_engine_comm_init(mppo_engine_t* e, const void* id128);
 int32_t mppo_engine_reset(mppo_engine_t* e, void* stream);
 /* one full update: T rollout steps, bootstrap value, GAE, E epochs x M minibatches */
 int32_t mppo_engine_update(mppo_engine_t* e, void* stream);
+/* *out = 1 once mppo_engine_update replays a captured hipGraph (with several ranks: RCCL calls included), 0 while it
+ * launches eagerly (use_graph = 0, null stream, MPPO_GRAPH_COMM=0 with a communicator, or a failed capture) */
+int32_t mppo_engine_graph_active(const mppo_engine_t* e, int32_t* out);
 /* pieces of the update, for stage-wise parity tests */
 int32_t mppo_engine_rollout(mppo_engine_t* e, void* stream);
 int32_t mppo_engine_learn(mppo_engine_t* e, void* stream);

@@ -119,6 +119,7 @@ SIGNATURES = {
     "mppo_engine_comm_init": (c_i32, [c_vp, c_vp]),
     "mppo_engine_reset": (c_i32, [c_vp, c_vp]),
     "mppo_engine_update": (c_i32, [c_vp, c_vp]),
+    "mppo_engine_graph_active": (c_i32, [c_vp, P(c_i32)]),
     "mppo_engine_rollout": (c_i32, [c_vp, c_vp]),
     "mppo_engine_learn": (c_i32, [c_vp, c_vp]),
 }

@@ -330,6 +330,12 @@ extern "C" int32_t mppo_engine_learn(mppo_engine_t* e, void* stream) {
   return do_learn(e, static_cast<hipStream_t>(stream));
 }
 
+extern "C" int32_t mppo_engine_graph_active(const mppo_engine_t* e, int32_t* out) {
+  MPPO_REQUIRE(e && out, "mppo_engine_graph_active: null argument");
+  *out = e->graph ? 1 : 0;
+  return MPPO_OK;
+}
+
 extern "C" int32_t mppo_engine_update(mppo_engine_t* e, void* stream) {
   MPPO_TRY(require_ready(e, true));
   hipStream_t s = static_cast<hipStream_t>(stream);

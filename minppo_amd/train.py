@@ -19,6 +19,7 @@ Deviations from the reference, all deliberate and documented in DESIGN.md:
 from __future__ import annotations
 
 import ctypes as C
+import json
 import logging
 import math
 import os
@@ -321,12 +322,15 @@ class Trainer:
             p.parent.mkdir(parents=True, exist_ok=True)
         tmp = p.with_name(p.name + ".tmp")
         with open(tmp, "wb") as f:
-            np.savez(f, __meta__=np.frombuffer(pickle.dumps(meta), np.uint8), **arrays)
+            np.savez(f, __meta__=np.frombuffer(json.dumps(meta).encode("utf-8"), np.uint8), **arrays)  # JSON, not pickle: loading never executes code
         os.replace(tmp, p)  # a crash never leaves a truncated checkpoint under the final name
 
     def load_checkpoint(self, path: str) -> None:
         with np.load(path) as z:
-            meta = pickle.loads(z["__meta__"].tobytes())
+            try:
+                meta = json.loads(z["__meta__"].tobytes().decode("utf-8"))
+            except (UnicodeDecodeError, ValueError) as exc:
+                raise ValueError(f"checkpoint {path}: metadata is not JSON (written by an older version?)") from exc
             want = self._ckpt_meta()
             # the seed keys the engine's Philox streams: only the same seed continues the same noise / permutation sequence
             for k in ("version", "model", "num_envs", "num_steps", "obs_dim", "act_dim", "hidden", "params", "rec_dim", "world_size", "rank", "seed"):
@@ -387,6 +391,12 @@ class Trainer:
     def update(self) -> None:
         self.lib.engine_update(self._engine, self._stream_ptr)
         self.updates_done += 1
+
+    def graph_active(self) -> bool:
+        """True once `update()` replays a captured hipGraph (false: eager launches)."""
+        out = C.c_int32(0)
+        self.lib.engine_graph_active(self._engine, C.byref(out))
+        return bool(out.value)
 
     def rollout(self) -> None:
         self.lib.engine_rollout(self._engine, self._stream_ptr)

@@ -5,11 +5,16 @@ Runs on the CPU emulator build of the kernel source (default) and on the MI355X 
 Tolerances (float32 kernel vs float64 oracle), stated per quantity:
   * everything before the constraint solver (kinematics, inertia, bias, Jacobian, reference
     acceleration) ............................................ 1e-5 .. 5e-4 of the field's scale
-  * the solver: the reference's 6-iteration CG is not converged, so `qacc` itself is only loosely
-    reproducible between ANY two float32 evaluations (tests/test_oracle_physics.py shows this for
-    the oracle alone); what is asserted is the COST reached (rtol 5e-2, never worse than the
-    unconstrained start) and identical iteration counts in the common case
-  * env wrapper: done flags exact; observation 1e-4; reward 1e-2 (it contains d(com)/dt = dx / 0.002)
+  * the solver (`qacc`): the reference's 6-iteration CG with its bracketing line search is not converged, and a row
+    whose `Jaref` sits near zero flips between active and inactive under float32 rounding.  Measured envelope of ANY
+    float32 evaluation against float64 (the oracle run in float32 shows the same numbers as the kernel,
+    tests/test_oracle_physics.py): per-environment max |dqacc| / max |qacc| has median 6e-4 .. 2e-3 and maximum
+    0.02 .. 0.25 on walking states.  Asserted: median <= 5e-3, max <= 0.3, the COST reached within 5e-2 and never above
+    the unconstrained start, iteration counts <= 6.  Where the active set is stable the solver is reproducible and the
+    bound is tight for the bulk: resting contacts median <= 1e-3, joint limits only median <= 1e-4 and 75th percentile
+    <= 3e-3  (test_solver_is_tight_where_the_active_set_is_stable, which also explains the remaining outliers)
+  * env wrapper (kernel re-seeded from the oracle state before every step): done flags exact; observation 1e-4;
+    reward 1e-2 (it contains d(com)/dt = dx / 0.002); qpos 2e-3; qvel 0.15 per frame (= h x the solver envelope above)
 """
 
 import ctypes as C
@@ -50,6 +55,16 @@ def _cost(ref, qacc):
     return 0.5 * np.sum(ref.efc_D * jar * jar * (jar < 0), -1) + 0.5 * np.sum((Ma - ref.qfrc_smooth) * (qacc - ref.qacc_smooth), -1)
 
 
+def _euler_acc(cm, ref):
+    """the acceleration the integrator applies (MJX euler with implicit joint damping):
+    (M + h diag(damping))^-1 (qfrc_smooth + qfrc_constraint), or qacc itself for an undamped model"""
+    damp = np.asarray(cm.t["dof_damping"], np.float64)
+    if not np.any(damp > 0):
+        return ref.qacc
+    dh = ref.qM + float(cm.t["timestep"]) * np.eye(cm.nv)[None] * damp[None, :, None]
+    return np.linalg.solve(dh, (ref.qfrc_smooth + ref.qfrc_constraint)[..., None])[..., 0]
+
+
 def _walk(cm, N, steps, seed, scale=0.3):
     ph = Physics(cm.t)
     rng = np.random.default_rng(seed)
@@ -88,8 +103,76 @@ def test_forward_matches_oracle(be, model, N):
         np.testing.assert_allclose(c_got, c_ref, rtol=5e-2, atol=1e-3)
         assert np.all(c_got <= c_smooth * (1 + 1e-5) + 1e-6)
         assert np.all(got["niter"] <= 6)
+        # qacc itself, at the measured float32 envelope of the unconverged solver (module docstring)
+        rel = np.abs(got["qacc"] - ref.qacc).max(1) / (np.abs(ref.qacc).max(1) + 1e-9)
+        assert np.median(rel) <= 5e-3 and rel.max() <= 0.3, (np.median(rel), rel.max())
+        # and what the integrator does with it: qvel' = qvel + h (M + h D)^-1 (qfrc_smooth + qfrc_constraint)
+        # (qfrc_constraint = J^T efc_force enters here: the oracle's value is the float64 one)
+        ref_e = _euler_acc(cm, ref)
+        rel_e = np.abs(got["qacc_euler"] - ref_e).max(1) / (np.abs(ref_e).max(1) + 1e-9)
+        assert np.median(rel_e) <= 5e-3 and rel_e.max() <= 0.3, (np.median(rel_e), rel_e.max())
     else:
         np.testing.assert_allclose(got["qacc"], ref.qacc, rtol=1e-4, atol=1e-4)
+    be.lib.model_close(h)
+
+
+def _rest_state(cm, ph, N, rng):
+    """standing on the ground after 40 quiet steps: every foot contact is active and stays active"""
+    d = ph.pipeline_init(np.tile(cm.t["qpos0"], (N, 1)), np.zeros((N, cm.nv)))
+    for _ in range(40):
+        d = ph.pipeline_step(d, 0.02 * rng.standard_normal((N, cm.nu)))
+    return d.qpos, d.qvel, 0.02 * rng.standard_normal((N, cm.nu)), d.qacc_warmstart
+
+
+def _limit_state(cm, ph, N, rng):
+    """every limited joint pushed 0.01..0.03 rad past one of its limits (slowly moving), the robot lifted off the ground:
+    limit rows only, none of them close to releasing"""
+    t = cm.t
+    qpos = np.tile(t["qpos0"], (N, 1)).astype(np.float64)
+    for j in np.asarray(t["lim_jntid"]):
+        qa = int(t["jnt_qposadr"][j])
+        lo, hi = t["jnt_range"][j]
+        side = rng.integers(0, 2, N)
+        pen = 0.01 + 0.02 * rng.random(N)
+        qpos[:, qa] = np.where(side == 1, hi + pen, lo - pen)
+    if int(t["jnt_type"][0]) == 0:
+        qpos[:, 2] += 1.0
+    return qpos, 0.1 * rng.standard_normal((N, cm.nv)), 0.5 * rng.standard_normal((N, cm.nu)), np.zeros((N, cm.nv))
+
+
+@pytest.mark.parametrize("model,state,med,q75", [("synth_stompy_pro", "rest", 1e-3, 3e-3), ("synth_stompy_full", "rest", 1e-3, 3e-3),
+                                                  ("synth_stompy_pro", "limits", 1e-4, 3e-3), ("synth_stompy_full", "limits", 1e-4, 3e-3),
+                                                  (MJCF_ROBOT, "limits", 1e-4, 3e-3)])
+def test_solver_is_tight_where_the_active_set_is_stable(be, model, state, med, q75):
+    """The CG solver (reference env.py:95-97: CG, 6 iterations, 6 line-search iterations) compared on `qacc` directly, on
+    states whose active constraint set does not flip under float32 rounding: resting foot contacts, and joint limits
+    only.  There the float32 kernel reproduces the float64 oracle to 1e-3 of the acceleration scale for the bulk of the
+    environments (median and 75th percentile over 32 environments of max_dof |dqacc| / max_dof |qacc|, per case in the
+    parametrisation).  A few environments still land further away: six Polak-Ribiere iterations on the stiff quadratic do
+    not converge, and float32 loses conjugacy at a different iteration than float64 does — the float32 ORACLE shows the
+    same outliers in other environments (measured: up to 0.12) — hence the global 0.3 bound on the maximum."""
+    cm = load_model(model)
+    h, dims, _keep = be.model(cm)
+    ph = Physics(cm.t)
+    rng = np.random.default_rng(1)
+    N = 32
+    qpos, qvel, ctrl, warm = (_rest_state if state == "rest" else _limit_state)(cm, ph, N, rng)
+    q32 = [x.astype(f32) for x in (qpos, qvel, ctrl, warm)]
+    ref = PhysState(qpos=q32[0].astype(np.float64), qvel=q32[1].astype(np.float64), ctrl=q32[2].astype(np.float64),
+                    qacc_warmstart=q32[3].astype(np.float64), time=np.zeros(N))
+    ph.forward(ref)
+    nact = (ref.efc_D > 0).sum(1)
+    assert nact.min() >= (2 if state == "limits" else 4), nact  # the case really has active rows
+    got = _probe(be, h, cm, *q32)
+    rel = np.abs(got["qacc"] - ref.qacc).max(1) / (np.abs(ref.qacc).max(1) + 1e-9)
+    assert np.median(rel) <= med and np.quantile(rel, 0.75) <= q75 and rel.max() <= 0.3, (np.median(rel), np.quantile(rel, 0.75), rel.max())
+    ref_e = _euler_acc(cm, ref)
+    # at rest the net acceleration is the small difference of gravity and contact forces: its scale is that of qacc_smooth
+    rel_e = np.abs(got["qacc_euler"] - ref_e).max(1) / np.maximum(np.abs(ref_e).max(1), np.abs(ref.qacc_smooth).max(1))
+    # (no bound on the maximum here: qfrc_constraint = J^T D (aref - J qacc) multiplies a solver outlier by the constraint
+    # stiffness D, so the few non-converged environments are amplified; bulk statistics only)
+    assert np.median(rel_e) <= med and np.quantile(rel_e, 0.75) <= 2 * q75, (np.median(rel_e), np.quantile(rel_e, 0.75), rel_e.max())
+    np.testing.assert_allclose(_cost(ref, got["qacc"]), _cost(ref, ref.qacc), rtol=5e-2, atol=1e-3)
     be.lib.model_close(h)
 
 
@@ -126,11 +209,11 @@ def _pack(env, s, dims, nv):
     return rec
 
 
-@pytest.mark.parametrize("n_frames", [1, 2])
-def test_env_step_matches_env_oracle(be, n_frames):
+@pytest.mark.parametrize("model,n_frames", [("synth_stompy_pro", 1), ("synth_stompy_pro", 2), ("synth_stompy_full", 1)])
+def test_env_step_matches_env_oracle(be, model, n_frames):
     """reset + 24 steps, the kernel re-seeded from the oracle state before every step (identical inputs):
-    observation lag, reward, height / NaN termination, auto-reset, metrics."""
-    cm = load_model("synth_stompy_pro")
+    observation lag, reward, height / NaN termination, auto-reset, metrics.  Both BASELINE robots (configs[1] / configs[4])."""
+    cm = load_model(model)
     h, dims, _keep = be.model(cm)
     N, O, OP, R, nv, nu = 7, dims.obs_dim, dims.obs_pad, dims.rec_dim, cm.nv, cm.nu
     rcfg = RewardCfg(height_min_z=0.95)
@@ -174,7 +257,7 @@ def test_env_step_matches_env_oracle(be, n_frames):
         np.testing.assert_allclose(be.host(rew)[fin], es["reward"][fin], atol=1e-2)
         st = be.host(state)
         np.testing.assert_allclose(st[:, :cm.nq], s.qpos, atol=2e-3 * n_frames)
-        np.testing.assert_allclose(st[:, cm.nq:cm.nq + nv], s.qvel, atol=1.5 * n_frames)  # solver looseness (|dqacc| up to a few 100) x h
+        np.testing.assert_allclose(st[:, cm.nq:cm.nq + nv], s.qvel, atol=0.15 * n_frames)  # h x the solver's float32 envelope (module docstring)
         np.testing.assert_allclose(st[:, OP + nv + 1], s.time, atol=1e-6)
         for k in met:
             g, w = be.host(met[k]), es["metrics"][k]
