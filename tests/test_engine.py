@@ -67,14 +67,15 @@ def test_update_matches_oracle_stage_by_stage(be, robot):
                 # FREELY (float32 kernel, float64 oracle, same actions) and separate at the rate the unconverged solver
                 # allows (test_kernels_physics.py).  Measured for float32 vs float64 of the oracle itself, 256 envs,
                 # unit-variance actions: max |dqvel| 0.13 at t = 0 growing to 0.7 .. 1.0 at t = 9, median over envs of the
-                # per-env max 1e-3 -> 1.6e-2, |dqpos| <= 4.4e-3 at t = 9, |dreward| <= 1.6e-2.  Bounds = that envelope x ~1.5:
+                # per-env max 1e-3 -> 1.6e-2 (the MI355X kernel, with its fast reciprocal square roots: 3e-2), |dqpos| <= 4.4e-3 at t = 9,
+                # |dreward| <= 1.6e-2.  Bounds = that envelope x 1.5 .. 2:
                 if t == 0:
                     np.testing.assert_allclose(obs[1], es["obs"], atol=1e-4)
                 else:
                     nq, nv = tr.cm.nq, tr.cm.nv
                     np.testing.assert_allclose(obs[t + 1][:, :nq], es["obs"][:, :nq], atol=1e-3 * t)
                     dv = np.abs(obs[t + 1][:, nq:nq + nv] - es["obs"][:, nq:nq + nv]).max(1)
-                    assert dv.max() <= 0.15 * (t + 1) and np.median(dv) <= 0.03, (t, dv.max(), np.median(dv))
+                    assert dv.max() <= 0.15 * (t + 1) and np.median(dv) <= 0.06, (t, dv.max(), np.median(dv))
                 np.testing.assert_allclose(tj["reward"][t], es["reward"], atol=0.05)
         # GAE on the engine's trajectory
         adv, tgt = po.calculate_gae(tj["done"].astype(bool), tj["value"].astype(np.float64), tj["reward"].astype(np.float64), tj["last_val"].astype(np.float64),

@@ -1,0 +1,39 @@
+"""env_kernel time per launch (HIP events, 30 launches after warm-up) for a given build of the library (argv[1], default: the product).
+States are walking states: the policy's unit-variance actions drive the robot for 10 steps first."""
+import ctypes as C, sys
+from pathlib import Path
+import numpy as np, torch
+sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
+from minppo_amd import _native as nat
+if len(sys.argv) > 1:
+    nat.HIP_LIB_PATH = Path(sys.argv[1]).resolve()
+from minppo_amd.model import load_model
+lib = nat.load()
+print("library:", lib.path)
+for model, N in (("synth_stompy_pro", 4096), ("synth_stompy_full", 8192)):
+    cm = load_model(model)
+    blob = np.frombuffer(cm.to_blob(), np.uint8)
+    dblob = torch.from_numpy(blob.copy()).cuda()
+    h = C.c_void_p()
+    lib.model_open(blob.ctypes.data, blob.size, dblob.data_ptr(), C.byref(h))
+    dims = nat.ModelDims(); lib.model_get_dims(h, C.byref(dims))
+    state = torch.zeros(N, dims.rec_dim, device="cuda"); reset = torch.zeros(dims.rec_dim, device="cuda")
+    obs = torch.zeros(N, dims.obs_pad, device="cuda")
+    s = torch.cuda.current_stream().cuda_stream
+    met = nat.EnvMetrics(*[t.data_ptr() for t in (torch.zeros(N, device="cuda"), torch.zeros(N, dtype=torch.int32, device="cuda"), torch.zeros(N, device="cuda"),
+                                                   torch.zeros(N, dtype=torch.int32, device="cuda"), torch.zeros(N, dtype=torch.int32, device="cuda"), torch.zeros(N, dtype=torch.uint8, device="cuda"))])
+    lib.env_reset(h, N, state.data_ptr(), reset.data_ptr(), obs.data_ptr(), dims.obs_pad, 0, 0, C.byref(met), s)
+    g = torch.Generator(device="cuda"); g.manual_seed(0)
+    acts = [torch.randn(N, dims.nu, device="cuda", generator=g) for _ in range(10)]
+    rew = torch.zeros(N, device="cuda"); done = torch.zeros(N, dtype=torch.uint8, device="cuda")
+    rc = nat.RewardCfg(-0.2, 2.0, 2.0, 0.2, 0.5, 0.1, 4.0, 1.0, 1.25)
+    def step(k):
+        lib.env_step(h, N, 1, C.byref(rc), state.data_ptr(), reset.data_ptr(), acts[k % 10].data_ptr(), dims.nu, obs.data_ptr(), dims.obs_pad, rew.data_ptr(), done.data_ptr(), C.byref(met), s)
+    for k in range(10): step(k)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for k in range(30): step(k)
+    e1.record(); torch.cuda.synchronize()
+    print(f"{model} N={N}: {e0.elapsed_time(e1) / 30 * 1e3:.1f} us per env_step launch; state checksum {float(state.double().sum()):.6f} done {int(done.sum())}")
+    lib.model_close(h)
