@@ -9,6 +9,7 @@
 #include "gemm.h"
 #include "mppo_common.h"
 #include "ppo_layout.h"
+#include "wgrad.h"
 
 namespace mppo {
 
@@ -457,13 +458,14 @@ int32_t policy_forward(const mppo_net_t& net, const float* params, int n, const 
 // (one fused launch where supported, k_fused.hip; otherwise layer-wise GEMMs + the head kernel).  Leaves h1, h2, dZ2, dZ1,
 // dOut, xmb and the loss partials in the GradBufs; *nblk_out = number of partial rows written.
 int32_t minibatch_rowpass(const mppo_net_t& net, const float* params, const mppo_batch_t& batch, const int* idx, int mb, const float* adv_stat,
-                          float inv_count, const mppo_loss_cfg_t& lc, const GradBufs& gbuf, int* nblk_out, hipStream_t stream) {
+                          float inv_count, const mppo_loss_cfg_t& lc, const GradBufs& gbuf, int* nblk_out, bool* fused_out, hipStream_t stream) {
   const ParamLayout L = param_layout(net.O, net.A, net.H);
   const int H = net.H;
   const int act_a = net.use_tanh ? ACT_TANH : ACT_RELU;
   MPPO_REQUIRE(batch.obs_ld == net.OP, "minibatch_grad: obs_ld (%d) must equal the padded observation width OP (%d)", batch.obs_ld, net.OP);
   static const char* nofuse = getenv("MPPO_NO_FUSED");  // A/B switch for measurements
   const bool fused = fused_supported(net, batch) && !(nofuse && nofuse[0] == '1');
+  if (fused_out) *fused_out = fused;
   if (fused) {
     MPPO_TRY(fused_forward_backward(net, params, batch, idx, mb, adv_stat, inv_count, lc, gbuf, stream));
     *nblk_out = cdiv(mb, 16);
@@ -491,7 +493,33 @@ int32_t minibatch_grad(const mppo_net_t& net, const float* params, const mppo_ba
   const ParamLayout L = param_layout(net.O, net.A, net.H);
   const int H = net.H, A = net.A, AP = gbuf.f.AP, DP = AP + 4, O = net.O;
   int nblk = 0;
-  MPPO_TRY(minibatch_rowpass(net, params, batch, idx, mb, adv_stat, inv_count, lc, gbuf, &nblk, stream));
+  bool fused = false;
+  MPPO_TRY(minibatch_rowpass(net, params, batch, idx, mb, adv_stat, inv_count, lc, gbuf, &nblk, &fused, stream));
+  const float ent_weight = (float)mb * inv_count;
+  static const char* old_wgrad = getenv("MPPO_OLD_WGRAD");  // A/B switch for measurements: round 1's direct-to-register kernel
+  bool done = false;
+  if (fused && !(old_wgrad && old_wgrad[0] == '1')) {
+    // six weight gradients + six bias gradients as K-chunk partial sums, LDS-staged (k_wgrad.hip)
+    WgradArgs w{};
+    auto wp = [&](const float* Aprev, int lda, int Min, const float* dZ, int ldz, int bcols, int N, int off_w, int off_b) {
+      WgradProb p{};
+      p.A = Aprev; p.lda = lda; p.acols = lda; p.M = Min; p.B = dZ; p.ldb = ldz; p.bcols = bcols; p.N = N; p.off_w = off_w; p.off_b = off_b;
+      return p;
+    };
+    w.count = 6; w.ksplit = gbuf.ksplit; w.slab_stride = gbuf.slab_stride; w.slabs = gbuf.slabs;
+    w.p[0] = wp(gbuf.f.h1a, H, H, gbuf.dz2a, H, H, H, L.a_w2, L.a_b2);
+    w.p[1] = wp(gbuf.xmb, net.OP, O, gbuf.dz1a, H, H, H, L.a_w1, L.a_b1);
+    w.p[2] = wp(gbuf.f.h1c, H, H, gbuf.dz2c, H, H, H, L.c_w2, L.c_b2);
+    w.p[3] = wp(gbuf.xmb, net.OP, O, gbuf.dz1c, H, H, H, L.c_w1, L.c_b1);
+    w.p[4] = wp(gbuf.f.h2a, H, H, gbuf.dout, DP, AP, A, L.a_w3, L.a_b3);
+    w.p[5] = wp(gbuf.f.h2c, H, H, gbuf.dout + AP, DP, 4, 1, L.c_w3, L.c_b3);
+    MPPO_TRY(wgrad_plan(w, mb));
+    if (wgrad_supported(w)) {
+      MPPO_TRY(wgrad_launch(w, net.bf16 != 0, stream));
+      done = true;
+    }
+  }
+  if (!done) {
   GemmBatch gb{};
   // weight gradients dW = H_prev^T . dZ into split-K slabs; the bias gradients (column sums of dZ) ride along.
   // dOut is [mb, DP] with d mean in columns [0,A) and d value in column AP: every operand is 16-byte aligned -> fast path.
@@ -509,7 +537,7 @@ int32_t minibatch_grad(const mppo_net_t& net, const float* params, const mppo_ba
   gb.p[4] = wprob(gbuf.f.h1c, H, nullptr, H, gbuf.dz2c, H, H, L.c_w2, L.c_b2);
   gb.p[5] = wprob(gbuf.xmb, net.OP, nullptr, O, gbuf.dz1c, H, H, L.c_w1, L.c_b1);
   MPPO_TRY(gemm_launch(gb, 1, 0, EPI_STORE, net.bf16, stream));
-  const float ent_weight = (float)mb * inv_count;
+  }
   MPPO_REQUIRE((size_t)L.total <= (size_t)kNormBlocks * 256 * 4 * kReduceIter, "minibatch_grad: %d parameters exceed the reduce kernel's range", L.total);
   hipLaunchKernelGGL(grad_reduce_kernel, dim3(kNormBlocks), dim3(256), 0, stream, (size_t)L.total, gbuf.ksplit, gbuf.slab_stride, gbuf.slabs, L.log_std, A, AP, nblk,
                      gbuf.partial, params + L.log_std, lc.ent_coef, lc.vf_coef, ent_weight, grad, loss4, sq_partial);
@@ -593,7 +621,7 @@ extern "C" int32_t mppo_minibatch_rowpass(const mppo_net_t* net, const float* pa
   if (ws_bytes < mppo_grad_ws_bytes(net, mb)) return fail(MPPO_ENOMEM, "mppo_minibatch_rowpass: workspace %zu < %zu bytes", ws_bytes, mppo_grad_ws_bytes(net, mb));
   const GradBufs gb = carve_grad(*net, mb, static_cast<float*>(ws));
   int nblk = 0;
-  return minibatch_rowpass(*net, params, *batch, idx, mb, adv_stat, inv_count, *lc, gb, &nblk, static_cast<hipStream_t>(stream));
+  return minibatch_rowpass(*net, params, *batch, idx, mb, adv_stat, inv_count, *lc, gb, &nblk, nullptr, static_cast<hipStream_t>(stream));
 }
 
 extern "C" int32_t mppo_adv_sums(const float* adv, const int32_t* idx, int32_t nmb, int32_t mb, double* sums, void* stream) {

@@ -113,6 +113,12 @@ __device__ __forceinline__ BufView make_buf(const float* base, unsigned bytes) {
   b.r = u.v;
   return b;
 }
+typedef float f32x4_native __attribute__((ext_vector_type(4)));
+__device__ f32x4_native mppo_raw_buffer_load_f32x4(i32x4_rsrc rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.load.v4f32");
+__device__ __forceinline__ float4 buf_load_f4(const BufView& b, int lane_off_bytes, int uniform_off_bytes) {
+  const f32x4_native q = mppo_raw_buffer_load_f32x4(b.r, lane_off_bytes, uniform_off_bytes, 0);
+  return make_float4(q.x, q.y, q.z, q.w);
+}
 __device__ __forceinline__ float2 buf_load_f2(const BufView& b, int lane_off_bytes, int uniform_off_bytes) {
   const f32x2_native q = mppo_raw_buffer_load_f32x2(b.r, lane_off_bytes, uniform_off_bytes, 0);
   return make_float2(q.x, q.y);
@@ -146,6 +152,19 @@ __device__ __forceinline__ void stream_store(float* p, float4 v) {
   *reinterpret_cast<float4*>(p) = v;
 #endif
 }
+
+// ---- agent-scope accesses for data exchanged between workgroups INSIDE one kernel (k_wgrad.hip).  The eight XCDs have private
+// L2s: relaxed atomics at agent scope are write-through stores / cache-bypassing loads (sc1 on gfx950), which is what makes a
+// partial result written on one XCD readable on another before the kernel ends.
+__device__ __forceinline__ void agent_store(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ float agent_load(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ float2 agent_load2(const float* p) {  // p 8-byte aligned
+  const unsigned long long u = __hip_atomic_load(reinterpret_cast<const unsigned long long*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  return make_float2(__builtin_bit_cast(float, (unsigned)u), __builtin_bit_cast(float, (unsigned)(u >> 32)));
+}
+__device__ __forceinline__ int agent_fetch_add(int* p, int v) { return __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void wg_release_fence() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); }  // own stores acknowledged
+__device__ __forceinline__ void agent_acquire_fence() { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); }   // drop stale cache lines
 
 // nothing is scheduled across this point (compiler-only; no instruction is emitted)
 #define MPPO_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)

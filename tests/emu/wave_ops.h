@@ -169,6 +169,12 @@ inline float2 buf_load_f2(const BufView& b, int lane_off_bytes, int uniform_off_
   if (off + 8 <= b.bytes) memcpy(&q.y, b.base + off + 4, 4);
   return q;
 }
+inline float4 buf_load_f4(const BufView& b, int lane_off_bytes, int uniform_off_bytes) {
+  const unsigned long long off = (unsigned long long)(unsigned)lane_off_bytes + (unsigned)uniform_off_bytes;
+  float v[4] = {0.f, 0.f, 0.f, 0.f};
+  for (int c = 0; c < 4; ++c) if (off + 4 * c + 4 <= b.bytes) memcpy(&v[c], b.base + off + 4 * c, 4);
+  return make_float4(v[0], v[1], v[2], v[3]);
+}
 #define MPPO_INTERLEAVE_MFMA16(NVALU, NVMEM)
 
 // lane l supplies A[i = l&15][k = l>>4], B[k = l>>4][j = l&15]; acc[r] = D[4*(l>>4) + r][l&15]
@@ -187,3 +193,11 @@ inline void mfma_f32_16x16x4(float a, float b, f32x4& acc) {
   }
   __syncthreads();
 }
+
+// agent-scope exchange between workgroups: the emulator runs workgroups one after another in one thread
+inline void agent_store(float* p, float v) { *p = v; }
+inline float agent_load(const float* p) { return *p; }
+inline float2 agent_load2(const float* p) { return make_float2(p[0], p[1]); }
+inline int agent_fetch_add(int* p, int v) { const int o = *p; *p = o + v; return o; }
+inline void wg_release_fence() {}
+inline void agent_acquire_fence() {}
