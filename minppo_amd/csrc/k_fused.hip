@@ -8,7 +8,9 @@
 // weights stream from L2.  At mb = 1280 that is 160 workgroups of 8 waves: two waves per SIMD, whose dependent MFMA
 // chains interleave on the matrix pipe.  Replaces four launches (two GEMMs, the head/loss kernel, one backward GEMM) and
 // their ~4 us fixed cost each; what needs a reduction over rows (weight gradients) stays in the split-K GEMM that follows.
-// Outputs to HBM/L2: h1, h2, dZ2, dZ1 (operands of the weight-gradient GEMM), dOut, the gathered rows (xmb), loss partials.
+// Outputs to HBM/L2: h1, h2, dZ2, dZ1, dOut and the gathered rows (xmb) - the operands of the weight-gradient kernel - in
+// K-QUAD layout [rows/4][cols][4] (ppo_layout.h: the four consecutive minibatch rows of a column are one float4, which is both
+// what a lane of this kernel holds in its accumulators and what a lane of k_wgrad.hip feeds to four MFMAs); loss partials.
 // Template arguments: BF16 (bf16-in / f32-accumulate MFMA, BASELINE configs[3]); ROLLOUT (forward + pi.sample + log_prob + value
 // on N rows, reference train.py:157-160,182: stops after the heads, writes no activations); OT (16-wide output tiles: A <= 16 / 32).
 // Weight stream: range-checked buffer loads through a branch-free three-deep register ring (see BStage / GemmPipe); the
@@ -265,9 +267,18 @@ __global__ void __launch_bounds__(512, ROLLOUT ? MPPO_ROLLOUT_WAVES : 2) fused_m
     float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
     if (c4 < OP) q = *reinterpret_cast<const float4*>(a.b.obs + row * a.b.obs_ld + c4);
     *reinterpret_cast<float4*>(xt + r * XS + c4) = q;
-    if (!ROLLOUT && net == 0 && c4 < OP && row0 + r < a.mb) stream_store(a.xmb + (size_t)(row0 + r) * OP + c4, q);
   }
   __syncthreads();
+  if (!ROLLOUT && net == 0) {
+    // the gathered rows, k-quad layout [mb/4][OP][4], for the first layer's weight gradient (the actor workgroup writes them)
+    for (int e = t; e < 4 * OP; e += nthr) {
+      const int qd = e / OP, c = e - qd * OP;
+      float v[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) v[j] = row0 + 4 * qd + j < a.mb ? xt[(4 * qd + j) * XS + c] : 0.f;
+      stream_store(a.xmb + quad_index(row0 + 4 * qd, c, OP), make_float4(v[0], v[1], v[2], v[3]));
+    }
+  }
 
   // ---- P1 / P2: hidden layers ----
   GemmPipe<false> pipe2;
@@ -288,13 +299,20 @@ __global__ void __launch_bounds__(512, ROLLOUT ? MPPO_ROLLOUT_WAVES : 2) fused_m
     float* hg = layer == 0 ? a.h1[net] : a.h2[net];
     const int c0 = n0 + 2 * cj;  // the wave's two interleaved column tiles: c0, c0 + 1
     const float2 bz = layer == 0 ? bz1 : bz2;
+    float q0[4], q1[4];  // the lane's 4 rows x 2 columns: one k-quad of column c0 and one of column c0 + 1
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int rr = 4 * rq + r;
       float v0 = acc0[r] + bz.x, v1 = acc1[r] + bz.y;
       if (tanh_act) { v0 = fused_tanh(v0); v1 = fused_tanh(v1); } else { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); }
       *reinterpret_cast<float2*>(ht + rr * HS + c0) = make_float2(v0, v1);
-      if (!ROLLOUT && row0 + rr < a.mb && !(a.skip & 32)) stream_store(hg + (size_t)(row0 + rr) * H + c0, make_float2(v0, v1));
+      const bool on = row0 + rr < a.mb;  // rows past the minibatch are zero in the quad buffers (they are contracted over)
+      q0[r] = on ? v0 : 0.f; q1[r] = on ? v1 : 0.f;
+    }
+    if (!ROLLOUT && !(a.skip & 32)) {
+      float* dst = hg + quad_index(row0 + 4 * rq, c0, H);  // two consecutive float4: 32 bytes per lane
+      stream_store(dst, make_float4(q0[0], q0[1], q0[2], q0[3]));
+      stream_store(dst + 4, make_float4(q1[0], q1[1], q1[2], q1[3]));
     }
     __syncthreads();
   }
@@ -380,6 +398,7 @@ __global__ void __launch_bounds__(512, ROLLOUT ? MPPO_ROLLOUT_WAVES : 2) fused_m
     }
     if (net == 0) {
       const float sum_ls = group16_sum(sum_ls_l);
+      float dmq[OT][4];
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int rr = 4 * rq + r, i = row0 + rr;
@@ -403,20 +422,28 @@ __global__ void __launch_bounds__(512, ROLLOUT ? MPPO_ROLLOUT_WAVES : 2) fused_m
           const bool unclipped = (ratio >= 1.f - a.lc.clip_eps) && (ratio <= 1.f + a.lc.clip_eps);
           dlogp = (unclipped || la1 < la2) ? -g * ratio * a.inv_count : 0.f;
         }
+#pragma unroll
+        for (int ot = 0; ot < OT; ++ot) dmq[ot][r] = (on && cj + 16 * ot < A) ? dlogp * z[ot] * __expf(-ls[ot]) : 0.f;
         if (st) {
 #pragma unroll
           for (int ot = 0; ot < OT; ++ot) {
             const int o = cj + 16 * ot;
-            const float dm = o < A ? dlogp * z[ot] * __expf(-ls[ot]) : 0.f;
-            s_do[rr * SD + o] = dm;
+            s_do[rr * SD + o] = dmq[ot][r];
             s_red[rr * SD + o] = o < A ? dlogp * (z[ot] * z[ot] - 1.f) : 0.f;
-            if (on && o < AP) a.dout[(size_t)i * a.DP + o] = dm;
           }
           if (cj == 0) s_l[rr] = la;
         }
       }
+      if (st) {  // d mean, k-quad layout [mb/4][DP][4]: the lane's four rows of output o are one float4 (columns A .. AP-1: zeros)
+#pragma unroll
+        for (int ot = 0; ot < OT; ++ot) {
+          const int o = cj + 16 * ot;
+          if (o < AP) *reinterpret_cast<float4*>(a.dout + quad_index(row0 + 4 * rq, o, a.DP)) = make_float4(dmq[ot][0], dmq[ot][1], dmq[ot][2], dmq[ot][3]);
+        }
+      }
     } else {
       const float b3c = group16_sum(b3v[0]);  // lane cj = 0 holds the critic's single output bias
+      float dvq[4];
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int rr = 4 * rq + r, i = row0 + rr;
@@ -431,13 +458,15 @@ __global__ void __launch_bounds__(512, ROLLOUT ? MPPO_ROLLOUT_WAVES : 2) fused_m
           const bool vin = fabsf(vnew - ov) <= a.lc.clip_eps;
           dv = (vin || vl1 > vl2) ? (vnew - tg) * a.inv_count * a.lc.vf_coef : 0.f;
         }
+        dvq[r] = dv;
         if (st) {
 #pragma unroll
           for (int ot = 0; ot < OT; ++ot) s_do[rr * SD + cj + 16 * ot] = (cj == 0 && ot == 0) ? dv : 0.f;
           if (cj == 0) s_l[rr] = lv;
-          if (on && cj < 4) a.dout[(size_t)i * a.DP + AP + cj] = cj == 0 ? dv : 0.f;
         }
       }
+      // d value in column AP of dOut (k-quad layout), columns AP+1 .. AP+3 zero
+      if (st && cj < 4) *reinterpret_cast<float4*>(a.dout + quad_index(row0 + 4 * rq, AP + cj, a.DP)) = cj == 0 ? make_float4(dvq[0], dvq[1], dvq[2], dvq[3]) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
   }
   __syncthreads();
@@ -465,6 +494,7 @@ __global__ void __launch_bounds__(512, ROLLOUT ? MPPO_ROLLOUT_WAVES : 2) fused_m
         mfma_f32_16x16x4(av, w3q[m][0], d0); mfma_f32_16x16x4(av, w3q[m][1], d1);
       }
     }
+    float q0[4], q1[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int rr = 4 * rq + r;
@@ -472,7 +502,13 @@ __global__ void __launch_bounds__(512, ROLLOUT ? MPPO_ROLLOUT_WAVES : 2) fused_m
       const float z0 = tanh_act ? d0[r] * (1.f - hv.x * hv.x) : (hv.x > 0.f ? d0[r] : 0.f);
       const float z1 = tanh_act ? d1[r] * (1.f - hv.y * hv.y) : (hv.y > 0.f ? d1[r] : 0.f);
       *reinterpret_cast<float2*>(dzt + rr * HS + c0) = make_float2(z0, z1);
-      if (row0 + rr < a.mb && !(a.skip & 32)) stream_store(a.dz2[net] + (size_t)(row0 + rr) * H + c0, make_float2(z0, z1));
+      const bool on = row0 + rr < a.mb;
+      q0[r] = on ? z0 : 0.f; q1[r] = on ? z1 : 0.f;
+    }
+    if (!(a.skip & 32)) {
+      float* dst = a.dz2[net] + quad_index(row0 + 4 * rq, c0, H);
+      stream_store(dst, make_float4(q0[0], q0[1], q0[2], q0[3]));
+      stream_store(dst + 4, make_float4(q1[0], q1[1], q1[2], q1[3]));
     }
   }
   __syncthreads();
@@ -481,17 +517,20 @@ __global__ void __launch_bounds__(512, ROLLOUT ? MPPO_ROLLOUT_WAVES : 2) fused_m
     f32x4 acc0, acc1;
     for (int r = 0; r < 4; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
     if (!(a.skip & 16)) pipe5.template run<BF16>(dzt, HS, H, W2, H, n0, lane, acc0, acc1);
+    const int c0 = n0 + 2 * cj;
+    float q0[4], q1[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int rr = 4 * rq + r;
-      if (row0 + rr < a.mb) {
-        const int c0 = n0 + 2 * cj;
-        const float2 gq = *reinterpret_cast<const float2*>(h1t + rr * HS + c0);
-        const float d0 = tanh_act ? acc0[r] * (1.f - gq.x * gq.x) : (gq.x > 0.f ? acc0[r] : 0.f);
-        const float d1 = tanh_act ? acc1[r] * (1.f - gq.y * gq.y) : (gq.y > 0.f ? acc1[r] : 0.f);
-        stream_store(a.dz1[net] + (size_t)(row0 + rr) * H + c0, make_float2(d0, d1));
-      }
+      const bool on = row0 + rr < a.mb;
+      const float2 gq = *reinterpret_cast<const float2*>(h1t + rr * HS + c0);
+      const float d0 = tanh_act ? acc0[r] * (1.f - gq.x * gq.x) : (gq.x > 0.f ? acc0[r] : 0.f);
+      const float d1 = tanh_act ? acc1[r] * (1.f - gq.y * gq.y) : (gq.y > 0.f ? acc1[r] : 0.f);
+      q0[r] = on ? d0 : 0.f; q1[r] = on ? d1 : 0.f;
     }
+    float* dst = a.dz1[net] + quad_index(row0 + 4 * rq, c0, H);
+    stream_store(dst, make_float4(q0[0], q0[1], q0[2], q0[3]));
+    stream_store(dst + 4, make_float4(q1[0], q1[1], q1[2], q1[3]));
   }
 }
 

@@ -214,6 +214,7 @@ int32_t head_launch(const HeadArgs& a, bool loss, hipStream_t stream) {
 // grad = sum of split-K slabs (+ log_std gradient from the loss partials); loss4 from the partials.
 // ------------------------------------------------------------------------------------------------
 constexpr int kNormBlocks = 256;
+static_assert(kSqSlots == 2 * kNormBlocks, "adam_kernel adds kSqSlots partials; the reduce / sumsq kernels fill the first half");
 
 // grad = sum of the split-K slabs (one float4 per slab per thread, every load in flight at once), the log_std gradient
 // and loss4 from the head kernel's per-workgroup partials, and the per-workgroup sums of squares of the result in
@@ -280,6 +281,7 @@ __global__ void __launch_bounds__(256) grad_reduce_kernel(size_t P, int ksplit, 
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = sq;
   __syncthreads();
   if (threadIdx.x == 0 && sq_partial) sq_partial[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+  if (blockIdx.x == 0 && sq_partial) sq_partial[kNormBlocks + threadIdx.x] = 0.f;  // the clip adds kSqSlots = 2 x kNormBlocks partials
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -326,15 +328,17 @@ __global__ void __launch_bounds__(256) sumsq_kernel(size_t P, const float* __res
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
   __syncthreads();
   if (threadIdx.x == 0) partial[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+  if (blockIdx.x == 0) partial[kNormBlocks + threadIdx.x] = 0.f;  // the clip adds kSqSlots = 2 x kNormBlocks partials
 }
 
 __global__ void __launch_bounds__(256) adam_kernel(size_t P, float* __restrict__ p, float* __restrict__ m, float* __restrict__ v,
                                                    const float* __restrict__ g, const float* __restrict__ partial, const int* __restrict__ count_base,
                                                    int step_offset, mppo_adam_cfg_t c) {
-  // every wave adds the same kNormBlocks (= 256) partials in the same order (four per lane, fixed reduction tree):
+  // every wave adds the same kSqSlots (= 512) partials in the same order (eight per lane, fixed reduction tree):
   // bitwise-identical clip scale everywhere without a second pass
   const int ln = threadIdx.x & 63;
-  const float ss = wave_sum((partial[ln] + partial[ln + 64]) + (partial[ln + 128] + partial[ln + 192]));
+  const float ss = wave_sum(((partial[ln] + partial[ln + 64]) + (partial[ln + 128] + partial[ln + 192])) +
+                            ((partial[ln + 256] + partial[ln + 320]) + (partial[ln + 384] + partial[ln + 448])));
   const float norm = sqrtf(ss);
   const float scale = norm < c.max_grad_norm ? 1.f : c.max_grad_norm / norm;
   const int count = count_base[0] + step_offset;
@@ -496,30 +500,31 @@ int32_t minibatch_grad(const mppo_net_t& net, const float* params, const mppo_ba
   bool fused = false;
   MPPO_TRY(minibatch_rowpass(net, params, batch, idx, mb, adv_stat, inv_count, lc, gbuf, &nblk, &fused, stream));
   const float ent_weight = (float)mb * inv_count;
-  static const char* old_wgrad = getenv("MPPO_OLD_WGRAD");  // A/B switch for measurements: round 1's direct-to-register kernel
-  bool done = false;
-  if (fused && !(old_wgrad && old_wgrad[0] == '1')) {
-    // six weight gradients + six bias gradients as K-chunk partial sums, LDS-staged (k_wgrad.hip)
+  static const char* old_wgrad = getenv("MPPO_OLD_WGRAD");  // (no longer selectable with the fused row pass: its outputs are k-quad operands)
+  (void)old_wgrad;
+  if (fused) {
+    // the row pass left its outputs in k-quad layout: one launch produces the complete gradient (k_wgrad.hip)
     WgradArgs w{};
-    auto wp = [&](const float* Aprev, int lda, int Min, const float* dZ, int ldz, int bcols, int N, int off_w, int off_b) {
+    auto wp = [&](const float* Aq, int lda, int Min, const float* Bq, int ldb, int bcols, int N, int off_w, int off_b) {
       WgradProb p{};
-      p.A = Aprev; p.lda = lda; p.acols = lda; p.M = Min; p.B = dZ; p.ldb = ldz; p.bcols = bcols; p.N = N; p.off_w = off_w; p.off_b = off_b;
+      p.A = Aq; p.lda = lda; p.acols = lda; p.M = Min; p.B = Bq; p.ldb = ldb; p.bcols = bcols; p.N = N; p.off_w = off_w; p.off_b = off_b;
       return p;
     };
-    w.count = 6; w.ksplit = gbuf.ksplit; w.slab_stride = gbuf.slab_stride; w.slabs = gbuf.slabs;
+    w.count = 6; w.grad = grad; w.sq_partial = sq_partial;
     w.p[0] = wp(gbuf.f.h1a, H, H, gbuf.dz2a, H, H, H, L.a_w2, L.a_b2);
     w.p[1] = wp(gbuf.xmb, net.OP, O, gbuf.dz1a, H, H, H, L.a_w1, L.a_b1);
     w.p[2] = wp(gbuf.f.h1c, H, H, gbuf.dz2c, H, H, H, L.c_w2, L.c_b2);
     w.p[3] = wp(gbuf.xmb, net.OP, O, gbuf.dz1c, H, H, H, L.c_w1, L.c_b1);
     w.p[4] = wp(gbuf.f.h2a, H, H, gbuf.dout, DP, AP, A, L.a_w3, L.a_b3);
-    w.p[5] = wp(gbuf.f.h2c, H, H, gbuf.dout + AP, DP, 4, 1, L.c_w3, L.c_b3);
+    w.p[5] = wp(gbuf.f.h2c, H, H, gbuf.dout + 4 * AP, DP, 4, 1, L.c_w3, L.c_b3);  // column AP of the quad rows
+    w.ls_off = L.log_std; w.A = A; w.AP = AP; w.nblk = nblk; w.partial = gbuf.partial; w.log_std = params + L.log_std;
+    w.ent_coef = lc.ent_coef; w.vf_coef = lc.vf_coef; w.ent_weight = ent_weight; w.loss4 = loss4;
+    { static const char* e8 = getenv("MPPO_WGRAD_DBG"); if (e8 && (atoi(e8) & 8)) w.count = 4; }  // timing experiment: big problems only
     MPPO_TRY(wgrad_plan(w, mb));
-    if (wgrad_supported(w)) {
-      MPPO_TRY(wgrad_launch(w, net.bf16 != 0, stream));
-      done = true;
-    }
+    MPPO_REQUIRE(wgrad_supported(w), "minibatch_grad: weight-gradient launch not applicable (%d tiles)", w.ntiles);
+    return wgrad_launch(w, net.bf16 != 0, stream);
   }
-  if (!done) {
+  {
   GemmBatch gb{};
   // weight gradients dW = H_prev^T . dZ into split-K slabs; the bias gradients (column sums of dZ) ride along.
   // dOut is [mb, DP] with d mean in columns [0,A) and d value in column AP: every operand is 16-byte aligned -> fast path.
@@ -638,7 +643,7 @@ extern "C" int32_t mppo_adv_stats_finalize(const double* sums, int32_t nmb, doub
   return MPPO_OK;
 }
 
-extern "C" size_t mppo_adam_ws_bytes(size_t) { return kNormBlocks * sizeof(float); }
+extern "C" size_t mppo_adam_ws_bytes(size_t) { return kSqSlots * sizeof(float); }
 
 extern "C" int32_t mppo_clip_adam(size_t P, float* params, float* m, float* v, const float* grad, const int32_t* count_base, int32_t step_offset,
                                   const mppo_adam_cfg_t* cfg, void* ws, size_t ws_bytes, void* stream) {

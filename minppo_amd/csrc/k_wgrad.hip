@@ -1,29 +1,31 @@
-// k_wgrad.hip — all weight and bias gradients of one minibatch as split-K partial sums, one launch.
+// k_wgrad.hip — all weight and bias gradients of one minibatch, COMPLETE, in one launch.
 //
 // What `jax.value_and_grad(_loss_fn)` (reference minppo/train.py:246-247) derives for the six Dense layers:
 //   dW = H_prev^T . dZ   (contraction over the minibatch rows, K = mb)      db = column sums of dZ
-// for actor and critic.  The K chunks are summed by grad_reduce_kernel (k_ppo.hip), which follows.
+// for actor and critic, plus the `log_std` gradient, the four loss scalars (train.py:240-243) and the per-workgroup sums of
+// squares that `clip_by_global_norm` needs (train.py:117).  Replaces two launches of round 1 (split-K GEMM into 8 slabs, then
+// a slab-sum kernel: 17.2 + 5.0 us) - there are no slabs any more:
 //
-// Shape regime: six problems C[M,N] = A^T.B with A stored [K, M] (h1 / h2 / the gathered observations), B stored [K, N]
-// (dZ1 / dZ2 / dOut), M, N <= 256, K = 1280 .. 2560.  Too little work per output tile to fill 256 CUs without splitting K,
-// so a workgroup = one 64x64 output tile x one K chunk (K / ksplit rows):
-//   * operands are staged through LDS in their natural [k][m] layout, one 32-row k-set per stage, with range-checked
-//     buffer_load_dwordx4 (4 per thread and stage; round 1's direct-to-register kernel issued 32 dword loads per stage and
-//     fetched every operand element twice per workgroup).  The first five stages (= the whole K chunk at mb = 1280) are
-//     requested before anything else: the activations were written with streaming stores by the row pass, so the first
-//     touch comes from memory, and there is ONE such latency per workgroup instead of one per stage;
-//   * 4 waves, each a 32x32 accumulator on v_mfma_f32_32x32x2_f32 (bf16: 32x32x8), operands read from LDS rows
-//     (lanes = consecutive columns: conflict-free, ds_read2st64_b32);
-//   * K chunk <-> XCD: workgroup ids that are equal modulo 8 run on the same XCD (round-robin dispatch), and with ksplit = 8
-//     chunk c of EVERY tile is given to XCD c, so each operand row is fetched from memory by exactly one L2 and the other
-//     tiles' re-reads hit that L2 (a performance mapping only; nothing depends on it for correctness).
-// Measured and rejected in round 2: summing the chunks of a tile inside this launch by the tile's last workgroup
-// to arrive (agent-scope write-through partials + arrival counter).  Correct (600-launch bitwise stress test), but the one
-// workgroup per tile that pulls 8 x 16 KB back through the memory side needs 7.4 us - more than the launch of the separate
-// reduce kernel (5.0 us), whose 256 workgroups share that work.
+//   * a workgroup owns ONE 32x32 output tile over the WHOLE K range: 8 waves, wave g contracts rows [g K/8, (g+1) K/8) on
+//     v_mfma_f32_32x32x2_f32 (bf16: 32x32x8) and the eight accumulators are summed through LDS in wave order (a fixed
+//     order: the gradient is bit-reproducible).
+//   * exactly one workgroup per CU at the headline shape (O = 225, H = 256): 240 full tiles + 16 head-layer tiles = 256.
+//     One workgroup too many costs 5 us (a CU with two workgroups needs twice as long; measured 21.8 against 16.8 us), so
+//     the row band of the first layer that holds a single observation row (225 = 7 x 32 + 1) is not given 32x32 tiles of its
+//     own: such a THIN band (<= 4 rows) is contracted on the vector ALU by the workgroups of the problem's FIRST row band,
+//     which already hold the B operand it needs in registers (the same workgroups that sum B's columns for the bias).
+//   * no operand staging: the row pass (k_fused.hip) writes the activations in K-QUAD layout [K/4][cols][4], so a lane's
+//     operand for four MFMAs is ONE 16-byte load, coalesced over the 32 columns of the tile (512 bytes per half wave);
+//     range-checked buffer loads return 0 past the last quad and for columns outside the operand.
+//   * 328 KB of operands per workgroup come from L2 (84 MB per launch against 7.5 MB of distinct bytes): the price of
+//     not exchanging partial sums between workgroups, paid at L2 bandwidth instead of with a kernel boundary.
+// Measured and rejected on the way: an LDS-staged 64x64 split-K kernel (16.7 us + the reduce kernel), and the
+// same with the K chunks of a tile summed inside the launch by the tile's last workgroup to arrive (agent-scope partials +
+// arrival counter: correct in a 600-launch bitwise stress test, 24 us).
 #include <wave_ops.h>
 
 #include <cstdlib>
+#include <vector>
 
 #include "mppo_common.h"
 #include "ppo_layout.h"
@@ -31,169 +33,256 @@
 
 namespace mppo {
 
-constexpr int WT = 64;        // output tile edge
-constexpr int WKS = 32;       // k rows per stage
-constexpr int WTHREADS = 256;
-
-constexpr int WRING = 5;  // stages in flight (registers); the K chunk is a whole number of rings (wgrad_plan)
+constexpr int WTILE = 32;
+constexpr int WWAVES = 8;
+constexpr int WTHREADS = 64 * WWAVES;
+constexpr int WSTAGE = 8;  // quads per stage = 32 k
+constexpr float kLog2PiW = 1.8378770664093453f;
+constexpr int kThinQuads = 1280;  // LDS quads for a thin band: Kq x rows (20 KB)
 
 template <bool BF16>
 __global__ void __launch_bounds__(WTHREADS) wgrad_kernel(WgradArgs a) {
-  __shared__ __attribute__((aligned(16))) float smem[2][2][WKS][WT];  // [operand][buffer][k][column]: 32 KB
-  float (*sA)[WKS][WT] = smem[0];
-  float (*sB)[WKS][WT] = smem[1];
-  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-  // workgroup -> (tile, K chunk): chunk = id % ksplit; with ksplit = 8 that is the XCD the workgroup runs on
-  const int wg = blockIdx.x;
-  const int tile = wg / a.ksplit, split = wg % a.ksplit;
-  if (tile >= a.ntiles) return;
+  __shared__ float red[WWAVES][WTILE * (WTILE + 1)];
+  __shared__ float cred[WWAVES][WTILE];
+  __shared__ float s_red[WWAVES];
+  const int t = threadIdx.x, lane = t & 63, g = wave_uniform(t >> 6), i = lane & 31, h = lane >> 5;
+  const int tile = a.order[blockIdx.x];
   int pi = 0;
   while (pi + 1 < a.count && tile >= a.p[pi + 1].tile0) ++pi;
   const WgradProb p = a.p[pi];
   const int lt = tile - p.tile0, mt = lt / p.tiles_n, nt = lt - mt * p.tiles_n;
-  const int m0 = mt * WT, n0 = nt * WT;
-  const int kb = split * a.kchunk, ke = a.K < kb + a.kchunk ? a.K : kb + a.kchunk;
-  const int nst = a.kchunk / WKS;  // a multiple of WRING; stages past `ke` read zeros (range-checked buffer loads)
-
-  // staging: thread t moves float4 (rows t/16 and t/16 + 16 of the stage, columns 4*(t%16) ..) of both operands.
-  // Range-checked buffer loads: rows at or past `ke` return 0 without a branch; a column overhang (tile wider than the
-  // operand's readable row) gets a lane offset past the buffer's extent, which reads as 0 too.  WRING stages are in flight at any time:
-  // the activations were written with streaming stores by the row pass, so the first touch comes from memory (~2 us).
-  const int lr = t >> 4, lc = (t & 15) * 4;
-  const int ext = ke > kb ? ke - kb : 0;
-  const BufView bufA = make_buf(p.A + (size_t)kb * p.lda, (unsigned)ext * (unsigned)p.lda * 4u);
-  const BufView bufB = make_buf(p.B + (size_t)kb * p.ldb, (unsigned)ext * (unsigned)p.ldb * 4u);
-  const int ca = m0 + lc, cb = n0 + lc;
-  constexpr int kOutOfRange = 0x40000000;  // lane offset past any buffer extent: the range check returns 0, no mask arithmetic
-  const int offa = ca < p.acols ? (lr * p.lda + ca) * 4 : kOutOfRange, offb = cb < p.bcols ? (lr * p.ldb + cb) * 4 : kOutOfRange;
-  const int last = nst - 1;
-  float4 ra[WRING][2], rb[WRING][2];
-  if (a.dbg & 8) for (int i = 0; i < WRING; ++i) for (int h = 0; h < 2; ++h) { ra[i][h] = make_float4(0.f, 0.f, 0.f, 0.f); rb[i][h] = ra[i][h]; }
-#define WG_LOAD(SLOT, STAGE)                                                          \
-  do {                                                                                \
-    const int _st = (STAGE) < last ? (STAGE) : last;                                  \
-    _Pragma("unroll") for (int h = 0; h < 2; ++h) {                                   \
-      if (!(a.dbg & 8)) {                                                           \
-      ra[SLOT][h] = buf_load_f4(bufA, offa, (_st * WKS + 16 * h) * p.lda * 4);        \
-      rb[SLOT][h] = buf_load_f4(bufB, offb, (_st * WKS + 16 * h) * p.ldb * 4); }      \
-    }                                                                                 \
-  } while (0)
-#define WG_LSTORE(SLOT, BUF)                                                                                                      \
-  do {                                                                                                                            \
-    _Pragma("unroll") for (int h = 0; h < 2; ++h) {                                                                               \
-      *reinterpret_cast<float4*>(&sA[BUF][lr + 16 * h][lc]) = ra[SLOT][h];                                                        \
-      *reinterpret_cast<float4*>(&sB[BUF][lr + 16 * h][lc]) = rb[SLOT][h];                                                        \
-    }                                                                                                                             \
-  } while (0)
-  const int wr = wave >> 1, wc = wave & 1, i31 = lane & 31, hi = lane >> 5;
+  const int m0 = mt * WTILE, n0 = nt * WTILE;
+  const int q0 = g * a.qwave;                        // first quad of this wave
+  const int nst = a.qwave / WSTAGE;
+  // operand views: all quads of the minibatch; a lane offset past the extent (column outside the operand) reads 0
+  const BufView bufA = make_buf(p.A, (unsigned)a.Kq * (unsigned)p.lda * 16u);
+  const BufView bufB = make_buf(p.B, (unsigned)a.Kq * (unsigned)p.ldb * 16u);
+  constexpr int kOutOfRange = 0x40000000;
+  const int offa = m0 + i < p.acols ? (h * p.lda + m0 + i) * 16 : kOutOfRange;
+  const int offb = n0 + i < p.bcols ? (h * p.ldb + n0 + i) * 16 : kOutOfRange;
+  // tile 0 also owns the log_std gradient and the loss scalars: first level of the column sums of the row pass's partials
+  // [nblk][4+AP], requested NOW so that their latency hides under the K loop (at the end they were the launch's long pole)
+  __shared__ float s_part[16][40];
+  __shared__ float s_col[40];
+  if (tile == 0 && t < 256) {
+    const int W = 4 + a.AP;
+    for (int c = t & 15; c < W; c += 16) {
+      float s0 = 0.f;
+      for (int k = t >> 4; k < a.nblk; k += 16) s0 += a.partial[(size_t)k * W + c];
+      s_part[t >> 4][c] = s0;
+    }
+  }
+  float sum_log_std = 0.f;
+  if (tile == 0 && t == 0) for (int k = 0; k < a.A; ++k) sum_log_std += a.log_std[k];
   f32x16 acc;
   for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-  float colsum = 0.f;  // bias gradient: sum over k of B(k, n); waves of the first row band of the first row tile only
-  const bool do_colsum = p.off_b >= 0 && mt == 0 && wr == 0;
-  // a wave whose 32x32 block lies entirely outside the problem (the head layers' second column block, the observation
-  // layer's last row block) leaves the matrix pipe to the other waves of the SIMD; it still stages operands
-#ifdef MPPO_EMU
-  const bool live = true;  // the emulator's MFMA shim synchronises the whole workgroup
-#else
-  const bool live = m0 + wr * 32 < p.M && n0 + wc * 32 < p.N;
-#endif
-  auto compute = [&](int buf) {
-    if ((a.dbg & 1) || !live) return;
-    const float* pa = &sA[buf][0][wr * 32 + i31];
-    const float* pb = &sB[buf][0][wc * 32 + i31];
-    if (BF16) {
-      // v_mfma_f32_32x32x8_bf16: lane (i, h) supplies k = 8g + 4h + c, c = 0..3
+  float colsum = 0.f;  // bias gradient: sum over k of B(k, n); tiles of the first row band only
+  const bool do_colsum = p.off_b >= 0 && mt == 0;
+  constexpr int RING = 5;  // stages in flight per wave = the whole K range at mb = 1280 (40 quads): ONE memory latency (measured: a ring of 4 costs 3 us)
+  float4 ra[RING][4], rb[RING][4];
+  // a thin band's own operand (its <= 4 rows of A over all K) is tiny: staged in LDS once, read as broadcasts
+  __shared__ float4 sx[kThinQuads];
+  const bool do_thin = mt == 0 && p.thin_rows > 0;  // uniform
+  float tacc[4] = {0.f, 0.f, 0.f, 0.f};
+  constexpr int kThinPerThread = (kThinQuads + WTHREADS - 1) / WTHREADS;
+  float4 sxr[kThinPerThread];
+  if (do_thin) {  // requested first, stored to LDS after the prologue's loads have been requested too (one latency, not two)
 #pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        float av[4], bv[4];
+    for (int j = 0; j < kThinPerThread; ++j) {
+      const int e = t + WTHREADS * j, rr = e / a.Kq, qd = e - rr * a.Kq;
+      sxr[j] = buf_load_f4(bufA, e < a.Kq * p.thin_rows ? (qd * p.lda + p.thin_row0 + rr) * 16 : kOutOfRange, 0);  // (per-lane offsets: the scalar one must be wave-uniform)
+    }
+  }
+  auto load = [&](int slot, int s) {  // stage s: quads q0 + 8 s + 2 c + h, c = 0..3
 #pragma unroll
-        for (int c = 0; c < 4; ++c) { av[c] = pa[(8 * g + 4 * hi + c) * WT]; bv[c] = pb[(8 * g + 4 * hi + c) * WT]; }
-        mfma_bf16_32x32x8(pack_bf16x4(av[0], av[1], av[2], av[3]), pack_bf16x4(bv[0], bv[1], bv[2], bv[3]), acc);
-        colsum += (bv[0] + bv[1]) + (bv[2] + bv[3]);
-      }
-    } else {
-      // v_mfma_f32_32x32x2_f32: lane (i, h) supplies k = 2j + h of MFMA j
-      float av[16], bv[16];
-#pragma unroll
-      for (int j = 0; j < 16; ++j) { av[j] = pa[(2 * j + hi) * WT]; bv[j] = pb[(2 * j + hi) * WT]; }
-#pragma unroll
-      for (int j = 0; j < 16; ++j) mfma_f32_32x32x2(av[j], bv[j], acc);
-#pragma unroll
-      for (int j = 0; j < 16; ++j) colsum += bv[j];
+    for (int c = 0; c < 4; ++c) {
+      const int qu = q0 + WSTAGE * s + 2 * c;  // uniform
+      ra[slot][c] = buf_load_f4(bufA, offa, qu * p.lda * 16);
+      rb[slot][c] = buf_load_f4(bufB, offb, qu * p.ldb * 16);
     }
   };
-  // prologue: the whole first ring is requested at once
-  WG_LOAD(0, 0); WG_LOAD(1, 1); WG_LOAD(2, 2); WG_LOAD(3, 3); WG_LOAD(4, 4);
-  WG_LSTORE(0, 0);
-  if (nst > WRING) WG_LOAD(0, 5);
-  __syncthreads();
-  int par = 0;  // LDS buffer of the ring's first stage (a ring has an odd number of stages: the parity flips every round)
-  for (int s = 0; s < nst; s += WRING) {
-    const bool more = s + 2 * WRING <= nst;  // stage s + u + 6 exists: a further ring follows (uniform; stage u + 1's slot is free once staged)
-    compute(par);     WG_LSTORE(1, par ^ 1); if (more) WG_LOAD(1, s + 6);  __syncthreads();
-    compute(par ^ 1); WG_LSTORE(2, par);     if (more) WG_LOAD(2, s + 7);  __syncthreads();
-    compute(par);     WG_LSTORE(3, par ^ 1); if (more) WG_LOAD(3, s + 8);  __syncthreads();
-    compute(par ^ 1); WG_LSTORE(4, par);     if (more) WG_LOAD(4, s + 9);  __syncthreads();
-    compute(par);     WG_LSTORE(0, par ^ 1); if (s + 2 * WRING < nst) WG_LOAD(0, s + 10); __syncthreads();
-    par ^= 1;
-  }
-#undef WG_LOAD
-#undef WG_LSTORE
-
-  if (a.dbg & 2) return;
-  // ---- partial tile -> slab `split` through LDS (the operand buffers are dead): the MFMA accumulator layout holds a
-  // column per lane, i.e. 128-byte row fragments; staged as a [64][68] tile, every store instruction of a wave writes four
-  // complete 256-byte rows.  The bias gradient's partial rides along. ----
-  float* slab = a.slabs + (size_t)split * a.slab_stride;
-  float* ct = &smem[0][0][0][0];  // 64 x 68 floats = 17 KB of the 32 KB
-  constexpr int CTS = WT + 4;
-  static_assert(sizeof(smem) >= WT * CTS * sizeof(float), "the output tile is staged over the operand buffers");
+  auto mm = [&](int slot, int s) {
 #pragma unroll
-  for (int r = 0; r < 16; ++r) ct[(wr * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi) * CTS + wc * 32 + i31] = acc[r];
-  colsum += __shfl_xor(colsum, 32);  // the two lane halves hold the odd / even k's
-  const int col = n0 + wc * 32 + i31;
-  if (do_colsum && hi == 0 && col < p.N) slab[p.off_b + col] = colsum;
-  __syncthreads();
-  const int tc = n0 + lc;
-  const bool vec = (p.N & 3) == 0 && (p.off_w & 3) == 0;  // rows of this gradient tensor are 16-byte aligned
+    for (int c = 0; c < 4; ++c) {
+      const float4 x = ra[slot][c], y = rb[slot][c];
+      colsum += (y.x + y.y) + (y.z + y.w);
+      if (do_thin) {
+        const int qd = q0 + WSTAGE * s + 2 * c + h;  // this lane's quad (past the last quad: y is 0, the index is clamped)
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const int rl = lr + 16 * j, row = m0 + rl;
-    if (row < p.M && tc < p.N) {
-      const float4 v = *reinterpret_cast<const float4*>(ct + rl * CTS + lc);
-      float* dst = slab + p.off_w + (size_t)row * p.N + tc;
-      if (vec) {
-        *reinterpret_cast<float4*>(dst) = v;
-      } else {  // the head layers (N = A, N = 1)
-        dst[0] = v.x;
-        if (tc + 1 < p.N) dst[1] = v.y;
-        if (tc + 2 < p.N) dst[2] = v.z;
-        if (tc + 3 < p.N) dst[3] = v.w;
+        for (int rr = 0; rr < 4; ++rr)
+          if (rr < p.thin_rows) { const float4 z = sx[rr * a.Kq + (qd < a.Kq ? qd : a.Kq - 1)]; tacc[rr] += (z.x * y.x + z.y * y.y) + (z.z * y.z + z.w * y.w); }
+      }
+      if (BF16) {
+        // v_mfma_f32_32x32x8_bf16: lane (i, h) supplies k = 4h + c: exactly its quad
+        mfma_bf16_32x32x8(pack_bf16x4(x.x, x.y, x.z, x.w), pack_bf16x4(y.x, y.y, y.z, y.w), acc);
+      } else {
+        // v_mfma_f32_32x32x2_f32: lane (i, h) supplies one k per MFMA: the four k's of its quad, one after the other
+        mfma_f32_32x32x2(x.x, y.x, acc); mfma_f32_32x32x2(x.y, y.y, acc);
+        mfma_f32_32x32x2(x.z, y.z, acc); mfma_f32_32x32x2(x.w, y.w, acc);
       }
     }
+  };
+  // stages past the end are clamped to the last one (a redundant load, never multiplied): straight-line prologue
+#pragma unroll
+  for (int d = 0; d < RING; ++d) load(d, d < nst ? d : nst - 1);
+  if (do_thin) {  // uniform per workgroup
+#pragma unroll
+    for (int j = 0; j < kThinPerThread; ++j)
+      if (t + WTHREADS * j < kThinQuads) sx[t + WTHREADS * j] = sxr[j];
+    __syncthreads();
+  }
+  for (int s = 0; s < nst; s += RING) {
+#pragma unroll
+    for (int u = 0; u < RING; ++u) {
+      if (s + u < nst) mm(u, s + u);
+      if (s + u + RING < nst) load(u, s + u + RING);
+    }
+  }
+  __shared__ float tred[WWAVES][4][WTILE];
+  if (do_thin) {
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) {
+      tacc[rr] += __shfl_xor(tacc[rr], 32);
+      if (h == 0) tred[g][rr][i] = tacc[rr];
+    }
+  }
+  // ---- sum the eight K ranges in wave order ----
+#pragma unroll
+  for (int r = 0; r < 16; ++r) red[g][((r & 3) + 8 * (r >> 2) + 4 * h) * (WTILE + 1) + i] = acc[r];
+  colsum += __shfl_xor(colsum, 32);  // the two lane halves hold different quads
+  if (h == 0) cred[g][i] = colsum;
+  __syncthreads();
+  float sq = 0.f;
+#pragma unroll
+  for (int e = 0; e < 2; ++e) {
+    const int idx = t + WTHREADS * e, row = idx >> 5, col = idx & 31;
+    float v = 0.f;
+#pragma unroll
+    for (int k = 0; k < WWAVES; ++k) v += red[k][row * (WTILE + 1) + col];
+    if (m0 + row < p.M && n0 + col < p.N) {
+      a.grad[p.off_w + (size_t)(m0 + row) * p.N + n0 + col] = v;
+      sq += v * v;
+    }
+  }
+  if (do_thin && t < 4 * WTILE) {
+    const int rr = t >> 5, col = n0 + (t & 31);
+    if (rr < p.thin_rows && col < p.N) {
+      float v = 0.f;
+#pragma unroll
+      for (int k = 0; k < WWAVES; ++k) v += tred[k][rr][t & 31];
+      a.grad[p.off_w + (size_t)(p.thin_row0 + rr) * p.N + col] = v;
+      sq += v * v;
+    }
+  }
+  if (do_colsum && t < WTILE && n0 + t < p.N) {
+    float v = 0.f;
+#pragma unroll
+    for (int k = 0; k < WWAVES; ++k) v += cred[k][t];
+    a.grad[p.off_b + n0 + t] = v;
+    sq += v * v;
+  }
+  // ---- tile 0: second level of the partial sums (s_part was written before the K loop; the barrier above orders it) ----
+  if (tile == 0) {
+    const int W = 4 + a.AP;
+    if (t < W) {
+      float s0 = 0.f;
+      for (int gq = 0; gq < 16; ++gq) s0 += s_part[gq][t];
+      s_col[t] = s0;
+    }
+    __syncthreads();
+    if (t < a.A) {
+      const float d = s_col[4 + t] - a.ent_coef * a.ent_weight;
+      a.grad[a.ls_off + t] = d;
+      sq += d * d;
+    }
+    if (t == 0 && a.loss4) {
+      const float ent = (0.5f * (float)a.A * (1.f + kLog2PiW) + sum_log_std) * a.ent_weight;
+      a.loss4[0] = s_col[0] + a.vf_coef * s_col[1] - a.ent_coef * ent;
+      a.loss4[1] = s_col[1];
+      a.loss4[2] = s_col[0];
+      a.loss4[3] = ent;
+    }
+    if (a.sq_partial)  // slots of workgroups that do not exist
+      for (int e = a.ntiles + t; e < kSqSlots; e += WTHREADS) a.sq_partial[e] = 0.f;  // (slots are indexed by workgroup id)
+  }
+  // ---- the tile's sum of squares (input of clip_by_global_norm, train.py:117) ----
+  sq = wave_sum(sq);
+  if (lane == 0) s_red[g] = sq;
+  __syncthreads();
+  if (t == 0 && a.sq_partial) {
+    float s = 0.f;
+    for (int k = 0; k < WWAVES; ++k) s += s_red[k];
+    a.sq_partial[blockIdx.x] = s;
   }
 }
 
 bool wgrad_supported(const WgradArgs& a) {
-  if (a.count < 1 || a.count > kWgradMaxProb) return false;
-  for (int i = 0; i < a.count; ++i) {
-    const WgradProb& p = a.p[i];
-    if ((p.lda & 3) || (p.ldb & 3) || (p.acols & 3) || (p.bcols & 3) || p.acols < p.M || p.bcols < p.N || p.acols > p.lda || p.bcols > p.ldb || (reinterpret_cast<uintptr_t>(p.A) & 15) || (reinterpret_cast<uintptr_t>(p.B) & 15)) return false;
+  if (a.count < 1 || a.count > kWgradMaxProb || a.ntiles < 1 || a.ntiles > kSqSlots || a.AP + 4 > 40) return false;
+  for (int k = 0; k < a.count; ++k) {
+    const WgradProb& p = a.p[k];
+    if ((reinterpret_cast<uintptr_t>(p.A) & 15) || (reinterpret_cast<uintptr_t>(p.B) & 15) || p.acols < p.M || p.bcols < p.N || p.acols > p.lda || p.bcols > p.ldb)
+      return false;
   }
   return true;
 }
 
-int32_t wgrad_plan(WgradArgs& a, int K) {
+int32_t wgrad_plan(WgradArgs& a, int mb) {
   int tiles = 0;
-  for (int i = 0; i < a.count; ++i) {
-    WgradProb& p = a.p[i];
-    p.tiles_m = cdiv(p.M, WT); p.tiles_n = cdiv(p.N, WT); p.tile0 = tiles;
+  for (int k = 0; k < a.count; ++k) {
+    WgradProb& p = a.p[k];
+    p.tiles_m = cdiv(p.M, WTILE); p.tiles_n = cdiv(p.N, WTILE); p.tile0 = tiles;
+    p.thin_row0 = 0; p.thin_rows = 0;
+    const int rem = p.M - (p.tiles_m - 1) * WTILE;
+    if (p.tiles_m > 1 && rem <= 4 && (int)(pad16((size_t)mb) / 4) * rem <= kThinQuads) {  // a last row band of at most 4 rows is THIN: contracted by the first band's workgroups
+      p.tiles_m -= 1;
+      p.thin_row0 = p.tiles_m * WTILE; p.thin_rows = rem;
+    }
     tiles += p.tiles_m * p.tiles_n;
   }
   a.ntiles = tiles;
-  a.K = K;
-  const int ring = WKS * WRING;  // the kernel streams whole rings of stages
-  a.kchunk = cdiv(cdiv(K, a.ksplit), ring) * ring;
+  if (tiles > kSqSlots) return MPPO_OK;  // wgrad_supported says no
+  // Workgroup -> tile.  Workgroup ids that are equal modulo 8 run on the same XCD (round-robin dispatch) and share its L2.
+  // A tile reads a 32-column band of A and one of B over all K rows; every band a XCD touches comes from memory once.
+  // Big problems (>= 16 tiles) are split by row bands over consecutive XCD pairs, so that a XCD holds tm/2 bands of A and
+  // all bands of B of ONE problem (12 bands = 2 MB at H = 256) instead of bands of every problem; small ones go round.
+  {
+    std::vector<std::vector<int>> queue(8);
+    std::vector<int> bigidx(a.count, -1);
+    int big = 0, small = 0;
+    for (int k = 0; k < a.count; ++k)
+      if (a.p[k].tiles_m * a.p[k].tiles_n >= 16) bigidx[k] = big++;
+    for (int pass = 0; pass < 2; ++pass) {  // big problems first; the small ones' tiles then level the XCDs' queues
+      for (int k = 0; k < a.count; ++k) {
+        const WgradProb& p = a.p[k];
+        const int n = p.tiles_m * p.tiles_n;
+        if ((bigidx[k] >= 0) != (pass == 0)) continue;
+        for (int t = 0; t < n; ++t) {
+          int x;
+          if (pass == 0) {
+            x = (2 * bigidx[k] + ((t / p.tiles_n) * 2 >= p.tiles_m ? 1 : 0)) & 7;
+          } else {
+            x = 0;
+            for (int y = 1; y < 8; ++y) if (queue[y].size() < queue[x].size()) x = y;
+          }
+          queue[x].push_back(p.tile0 + t);
+        }
+      }
+    }
+    (void)small;
+    std::vector<int> assigned(tiles, -1), free_wg;
+    std::vector<size_t> pos(8, 0);
+    for (int w = 0; w < tiles; ++w) {
+      const int x = w & 7;
+      if (pos[x] < queue[x].size()) assigned[w] = queue[x][pos[x]++];
+      else free_wg.push_back(w);
+    }
+    size_t f = 0;
+    for (int x = 0; x < 8; ++x)
+      while (pos[x] < queue[x].size()) assigned[free_wg[f++]] = queue[x][pos[x]++];
+    for (int w = 0; w < tiles; ++w) a.order[w] = (unsigned short)assigned[w];
+  }
+  a.Kq = (int)(pad16((size_t)mb) / 4);                      // the row pass writes whole 16-row tiles (zeros past mb)
+  a.qwave = cdiv(cdiv(a.Kq, WWAVES), WSTAGE) * WSTAGE;      // quads per wave, whole stages
   return MPPO_OK;
 }
 
@@ -201,11 +290,13 @@ int32_t wgrad_launch(const WgradArgs& a_in, bool bf16, hipStream_t stream) {
   WgradArgs a = a_in;
   static const int dbg = [] { const char* e = getenv("MPPO_WGRAD_DBG"); return e ? atoi(e) : 0; }();
   a.dbg = dbg;
-  MPPO_REQUIRE(wgrad_supported(a), "wgrad_launch: operands must be 16-byte aligned with leading dimensions that are multiples of 4");
-  MPPO_REQUIRE(a.ksplit >= 1 && a.ksplit <= kGradKSplitMax && a.kchunk % (WKS * WRING) == 0, "wgrad_launch: ksplit %d / kchunk %d", a.ksplit, a.kchunk);
-  const dim3 grid(a.ntiles * a.ksplit);
-  if (bf16) hipLaunchKernelGGL(wgrad_kernel<true>, grid, dim3(WTHREADS), 0, stream, a);
-  else hipLaunchKernelGGL(wgrad_kernel<false>, grid, dim3(WTHREADS), 0, stream, a);
+  MPPO_REQUIRE(wgrad_supported(a), "wgrad_launch: operands must be 16-byte aligned k-quad buffers, at most %d tiles", kSqSlots);
+  if (bf16) hipLaunchKernelGGL(wgrad_kernel<true>, dim3(a.ntiles), dim3(WTHREADS), 0, stream, a);
+  else hipLaunchKernelGGL(wgrad_kernel<false>, dim3(a.ntiles), dim3(WTHREADS), 0, stream, a);
+  if (dbg & 4) {  // timing experiment: the same launch again, operands now warm in the L2s
+    if (bf16) hipLaunchKernelGGL(wgrad_kernel<true>, dim3(a.ntiles), dim3(WTHREADS), 0, stream, a);
+    else hipLaunchKernelGGL(wgrad_kernel<false>, dim3(a.ntiles), dim3(WTHREADS), 0, stream, a);
+  }
   MPPO_CHECK_LAUNCH("wgrad_kernel");
   return MPPO_OK;
 }

@@ -26,6 +26,12 @@ inline ParamLayout param_layout(int O, int A, int H) {
 
 inline size_t pad4(size_t n) { return (n + 3) & ~(size_t)3; }
 
+// K-QUAD layout of a [rows][cols] operand of the weight-gradient product (contraction over rows): [rows/4][cols][4], i.e. the
+// four consecutive rows of a column are one float4.  The fused row pass (k_fused.hip) writes h1, h2, dZ1, dZ2, dOut and the
+// gathered observations this way and k_wgrad.hip reads them; rows are padded to the row pass's 16-row tiles with zeros.
+__host__ __device__ inline size_t quad_index(size_t row, size_t col, size_t cols) { return ((row >> 2) * cols + col) * 4 + (row & 3); }
+inline size_t pad16(size_t n) { return (n + 15) & ~(size_t)15; }
+
 // activations of one forward pass over n rows
 struct FwdBufs {
   float *h1a, *h2a, *h1c, *h2c, *mean, *value;
@@ -60,17 +66,19 @@ struct GradBufs {
   size_t slab_stride;
 };
 inline size_t grad_bufs_floats(const mppo_net_t& net, int mb) {
-  const size_t AP = pad4((size_t)net.A), nh = pad4((size_t)mb * net.H);
+  const size_t mbp = pad16((size_t)mb);  // the quad-layout operands are written in whole 16-row tiles
+  const size_t AP = pad4((size_t)net.A), nh = pad4(mbp * net.H);
   const size_t P = pad4((size_t)param_layout(net.O, net.A, net.H).total);
   const size_t nblk = (size_t)(mb + 7) / 8;  // head kernel: 8 rows per workgroup (fused kernel: 16)
-  return fwd_bufs_floats(net, mb) + pad4((size_t)mb * (AP + 4)) + 4 * nh + pad4(nblk * (4 + AP)) + (size_t)kGradKSplitMax * P + pad4((size_t)mb * net.OP);
+  return fwd_bufs_floats(net, (int)mbp) + pad4(mbp * (AP + 4)) + 4 * nh + pad4(nblk * (4 + AP)) + (size_t)kGradKSplitMax * P + pad4(mbp * net.OP);
 }
 inline GradBufs carve_grad(const mppo_net_t& net, int mb, float* ws) {
   GradBufs g;
-  g.f = carve_fwd(net, mb, ws);
-  ws += fwd_bufs_floats(net, mb);
-  const size_t AP = (size_t)g.f.AP, nh = pad4((size_t)mb * net.H);
-  g.dout = ws; ws += pad4((size_t)mb * (AP + 4));
+  const size_t mbp = pad16((size_t)mb);
+  g.f = carve_fwd(net, (int)mbp, ws);
+  ws += fwd_bufs_floats(net, (int)mbp);
+  const size_t AP = (size_t)g.f.AP, nh = pad4(mbp * net.H);
+  g.dout = ws; ws += pad4(mbp * (AP + 4));
   g.dz2a = ws; ws += nh; g.dz2c = ws; ws += nh; g.dz1a = ws; ws += nh; g.dz1c = ws; ws += nh;
   const size_t nblk = (size_t)(mb + 7) / 8;
   g.partial = ws; ws += pad4(nblk * (4 + AP));

@@ -166,6 +166,11 @@ __device__ __forceinline__ int agent_fetch_add(int* p, int v) { return __hip_ato
 __device__ __forceinline__ void wg_release_fence() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); }  // own stores acknowledged
 __device__ __forceinline__ void agent_acquire_fence() { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); }   // drop stale cache lines
 
+// a value the program knows to be the same in every lane of the wave (e.g. threadIdx.x >> 6), moved to a scalar register: the
+// compiler cannot prove that by itself and would otherwise wrap every buffer load whose scalar offset depends on it in a
+// waterfall loop (measured on k_wgrad.hip: 21 us -> 14 us)
+__device__ __forceinline__ int wave_uniform(int x) { return __builtin_amdgcn_readfirstlane(x); }
+
 // nothing is scheduled across this point (compiler-only; no instruction is emitted)
 #define MPPO_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
 

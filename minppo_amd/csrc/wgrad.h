@@ -1,4 +1,4 @@
-// wgrad.h — descriptor of the split-K weight-gradient launch (k_wgrad.hip).
+// wgrad.h — descriptor of the weight-gradient launch (k_wgrad.hip).
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -8,27 +8,37 @@
 namespace mppo {
 
 constexpr int kWgradMaxProb = 6;
+constexpr int kSqSlots = 512;  // per-workgroup sums of squares consumed by the clip (adam_kernel adds exactly this many)
 
-// C[M,N] = A^T . B, A stored [K, lda] (columns [0,M) used), B stored [K, ldb] (columns [0,N) used); the result goes to
-// offset off_w of K-chunk slab `c` (row-major [M][N], the Flax kernel layout [in][out]) and the column sums of B to off_b.
+// C[M,N] = A^T . B over K minibatch rows.  A and B are K-QUAD operands (ppo_layout.h): element (k, c) at
+// ((k/4) * cols + c) * 4 + k%4, with `acols` / `bcols` columns per quad row (>= M / N) as seen from the given base pointers.
+// The result goes to the flat gradient at off_w (row-major [M][N]: the Flax kernel layout [in][out]) and the column sums of
+// B (the bias gradient) to off_b.
 struct WgradProb {
   const float* A;
   const float* B;
-  int M, N, lda, ldb;
-  int acols, bcols;            // readable columns of a row of A / B from the given base pointers (multiples of 4, >= M / N)
-  int off_w, off_b;            // offsets (floats) inside the flat gradient / slab; off_b < 0: no bias gradient
+  int M, N, acols, bcols, lda, ldb;  // lda / ldb: columns of the whole quad row (the stride between quads, in float4 units)
+  int off_w, off_b;
   int tiles_m, tiles_n, tile0;  // filled by wgrad_plan
+  int thin_row0, thin_rows;     // a last row band of <= 4 rows gets no tiles: the first row band's workgroups contract it (wgrad_plan)
 };
 
 struct WgradArgs {
   WgradProb p[kWgradMaxProb];
-  int count, K, ksplit, kchunk, ntiles;
-  size_t slab_stride;   // floats between K-chunk slabs
-  float* slabs;         // [ksplit][slab_stride] partial gradients
-  int dbg;  // timing experiments only (MPPO_WGRAD_DBG bit mask): 1 no MFMAs, 2 no stores, 8 no global loads
+  int count, Kq, qwave, ntiles;  // Kq quads in all, qwave quads per wave (a multiple of 8 = one stage)
+  float* grad;                   // [P] gradient of the minibatch
+  float* sq_partial;             // [kSqSlots] per-workgroup sums of squares of `grad` (optional)
+  // log_std gradient + loss scalars (train.py:240-243) from the row pass's per-workgroup partials [nblk][4 + AP]
+  int ls_off, A, AP, nblk;
+  const float* partial;
+  const float* log_std;
+  float ent_coef, vf_coef, ent_weight;
+  float* loss4;
+  unsigned short order[kSqSlots];  // workgroup id -> tile (wgrad_plan): tiles that share operand bands sit on the same XCD
+  int dbg;  // timing experiments only (MPPO_WGRAD_DBG bit mask): 4 launch twice (warm operands), 8 big problems only
 };
 
-int32_t wgrad_plan(WgradArgs& a, int K);  // tile table + K chunking (a.count, a.p[].{M,N}, a.ksplit set by the caller)
+int32_t wgrad_plan(WgradArgs& a, int mb);  // tile table + K ranges (a.count, a.p[].{M,N} set by the caller)
 bool wgrad_supported(const WgradArgs& a);
 int32_t wgrad_launch(const WgradArgs& a, bool bf16, hipStream_t stream);
 

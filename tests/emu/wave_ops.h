@@ -199,5 +199,6 @@ inline void agent_store(float* p, float v) { *p = v; }
 inline float agent_load(const float* p) { return *p; }
 inline float2 agent_load2(const float* p) { return make_float2(p[0], p[1]); }
 inline int agent_fetch_add(int* p, int v) { const int o = *p; *p = o + v; return o; }
+inline int wave_uniform(int x) { return x; }
 inline void wg_release_fence() {}
 inline void agent_acquire_fence() {}

@@ -127,7 +127,8 @@ def test_policy_forward_sample_logprob(be, O, A, H, n, tanh):
 @pytest.mark.parametrize("O,A,H,B,mb,tanh,ent", [(225, 10, 256, 400, 200, 1, 0.01), (37, 3, 64, 129, 129, 0, 0.0), (225, 10, 256, 1280, 1280, 1, 0.0),
                                                   (40, 4, 512, 80, 48, 1, 0.0),       # H > 256 takes the layer-wise path
                                                   (415, 20, 256, 120, 72, 1, 0.01),   # stompy_full: 20 outputs = two head tiles
-                                                  (50, 32, 64, 64, 40, 0, 0.0)])      # the widest head the fused kernel covers
+                                                  (50, 32, 64, 64, 40, 0, 0.0),       # the widest head the fused kernel covers
+                                                  (35, 3, 64, 90, 70, 1, 0.0)])       # 35 = 32 + 3 observation rows: a "thin" last row band of the first layer's gradient
 def test_minibatch_grad_matches_oracle(be, O, A, H, B, mb, tanh, ent):
     if be.name == "emu" and mb > 400:
         pytest.skip("full-size minibatch only on the GPU")
