@@ -17,7 +17,9 @@ The line also carries
                  FLOPs per launch / average duration against the dense f32 MFMA peak (157.3 TFLOP/s,
                  MI355X_MICROARCH.md)
   cpu_baseline : the NumPy oracle (oracle/, a "port" of the reference's algorithm; the JAX reference
-                 cannot run here) timed on this box's host cores on a bounded sample of the same workload.
+                 cannot run here) timed on this box's host cores on a bounded sample of the same workload: the
+                 rollout's environments sharded over one worker process per core, the PPO update with BLAS
+                 threads; `cores` = the worker processes actually used.
 """
 
 from __future__ import annotations
@@ -96,37 +98,105 @@ def rowpass_probe(tr, launches: int = 50, replays: int = 4):
     return sec, flops, f"fused_mlp_kernel: row pass of one minibatch (mb={mb}, O={O}, H={H}, A={A}, actor+critic; {'bf16 MFMA 16x16x16, f32 accumulate' if tr.net.bf16 else 'f32 MFMA 16x16x4'})"
 
 
-def cpu_baseline(config_name: str, n_envs: int):
-    """Times one update of the NumPy oracle (oracle/env_oracle.update_step) on the host."""
+def _cpu_rollout_shard(job):
+    """One worker process of the CPU baseline: the policy + environment rollout of a shard of the environments (they are
+    independent, reference train.py:136,140), NumPy float32 oracle, BLAS pinned to one thread (the parallelism is the
+    process pool).  Returns (seconds, number of env-steps, checksum)."""
+    config_name, overrides, n_local, seed = job
+    os.environ["OMP_NUM_THREADS"] = os.environ["OPENBLAS_NUM_THREADS"] = os.environ["MKL_NUM_THREADS"] = "1"
+    import numpy as np
+    try:
+        from threadpoolctl import threadpool_limits
+        threadpool_limits(1)
+    except Exception:
+        pass
+    from minppo_amd.config import load_config_from_cli
+    from minppo_amd.model import load_model
+    from oracle import ppo_oracle as po
+    from oracle.env_oracle import EnvOracle, rollout
+
+    cfg = load_config_from_cli([config_name, *overrides])
+    cm = load_model(cfg.environment.model or cfg.kscale_id)
+    env = EnvOracle(cm.t, dtype=np.float32)
+    T, A, H, O = cfg.training.num_steps, cm.nu, cfg.model.hidden_size, env.observation_size
+    named = po.init_params(cfg.training.seed, O, A, H, np.float32)
+    es = env.reset(n_local)
+    noise = np.random.default_rng(seed).standard_normal((T, n_local, A)).astype(np.float32)
+    t0 = time.perf_counter()
+    es, last_obs, traj = rollout(env, named, es, es["obs"], noise, bool(cfg.model.use_tanh))
+    dt = time.perf_counter() - t0
+    return dt, T * n_local, float(np.asarray(traj["reward"], np.float64).sum())
+
+
+def cpu_baseline(config_name: str, overrides, n_envs: int):
+    """The CPU restatement of the same update on this box's host cores (the JAX reference itself cannot run here:
+    BASELINE.md).  Rollout: the environments are sharded over one worker process per core (`os.cpu_count()`), each running
+    the NumPy float32 oracle on its shard; PPO update (GAE + E x M minibatches): one process, BLAS threads = cores (the
+    minibatch GEMMs are what parallelises there).  A bounded sample: `n_envs` environments, one update."""
+    import subprocess
+
     import numpy as np
     from minppo_amd.config import load_config_from_cli
     from minppo_amd.model import load_model
     from oracle import ppo_oracle as po
-    from oracle.env_oracle import EnvOracle, default_hp, update_step
+    from oracle.env_oracle import EnvOracle, default_hp
 
-    cfg = load_config_from_cli([config_name, f"training.num_envs={n_envs}"])
+    cores = os.cpu_count() or 1
+    workers = max(1, min(cores, n_envs // 16))
+    shard = n_envs // workers
+    n_used = shard * workers
+    # one fresh interpreter per worker (plain child processes: nothing of the GPU process is inherited, nothing is respawned)
+    code = ("import sys, json; sys.path.insert(0, %r); import bench; "
+            "print(json.dumps(bench._cpu_rollout_shard((sys.argv[1], json.loads(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4])))))" % str(ROOT))
+    env = dict(os.environ, OMP_NUM_THREADS="1", OPENBLAS_NUM_THREADS="1", MKL_NUM_THREADS="1", HIP_VISIBLE_DEVICES="", ROCR_VISIBLE_DEVICES="")
+    t0 = time.perf_counter()
+    procs = [subprocess.Popen([sys.executable, "-c", code, config_name, json.dumps(list(overrides)), str(shard), str(1000 + w)], env=env,
+                              stdout=subprocess.PIPE, stderr=subprocess.DEVNULL) for w in range(workers)]
+    res = []
+    try:
+        for pr in procs:
+            out, _ = pr.communicate(timeout=600)
+            if pr.returncode != 0:
+                raise RuntimeError("a CPU-baseline worker failed")
+            res.append(json.loads(out.decode().strip().splitlines()[-1]))
+    finally:
+        for pr in procs:  # exactly the PIDs started above
+            if pr.poll() is None:
+                pr.kill()
+                pr.wait()
+    wall_rollout = time.perf_counter() - t0          # includes interpreter start-up: reported, not used
+    t_rollout = max(r[0] for r in res)               # the slowest shard = the parallel rollout's duration
+    # PPO update on a synthetic trajectory of the same size (values of the right shapes; the arithmetic does not depend on them)
+    cfg = load_config_from_cli([config_name, f"training.num_envs={n_used}", *overrides])
     cm = load_model(cfg.environment.model or cfg.kscale_id)
     env = EnvOracle(cm.t, dtype=np.float32)
-    N, T, A, H, M, E = n_envs, cfg.training.num_steps, cm.nu, cfg.model.hidden_size, cfg.training.num_minibatches, cfg.training.update_epochs
+    N, T, A, H, M, E = n_used, cfg.training.num_steps, cm.nu, cfg.model.hidden_size, cfg.training.num_minibatches, cfg.training.update_epochs
     O = env.observation_size
     rng = np.random.default_rng(0)
     p = po.named_to_flat(po.init_params(cfg.training.seed, O, A, H, np.float32), O, A, H)
     opt = po.OptState(np.zeros_like(p), np.zeros_like(p), 0)
-    es = env.reset(N)
-    hp = default_hp(cfg)
-    noise = rng.standard_normal((T, N, A)).astype(np.float32)
+    traj = dict(obs=rng.standard_normal((T, N, O)).astype(np.float32), action=rng.standard_normal((T, N, A)).astype(np.float32),
+                value=rng.standard_normal((T, N)).astype(np.float32), log_prob=(-14.0 + rng.standard_normal((T, N))).astype(np.float32),
+                reward=rng.standard_normal((T, N)).astype(np.float32), done=rng.random((T, N)) < 0.02)
+    last_val = rng.standard_normal(N).astype(np.float32)
     perms = np.stack([rng.permutation(N * T) for _ in range(E)])
+    hp = default_hp(cfg)
     t0 = time.perf_counter()
-    update_step(env, p, opt, es, es["obs"], noise, perms, O=O, A=A, H=H, num_minibatches=M, hp=hp)
-    dt = time.perf_counter() - t0
+    adv, tgt = po.calculate_gae(traj["done"], traj["value"], traj["reward"], last_val, hp["gamma"], hp["gae_lambda"])
+    po.update_epochs_on_batch(p, opt, traj, adv, tgt, perms, O=O, A=A, H=H, num_minibatches=M, hp=hp)
+    t_update = time.perf_counter() - t0
     try:
         from threadpoolctl import threadpool_info
 
-        threads = max([i.get("num_threads", 1) for i in threadpool_info()] or [1])
+        blas_threads = max([i.get("num_threads", 1) for i in threadpool_info()] or [1])
     except Exception:
-        threads = os.cpu_count() or 1
-    return {"value": N * T / dt, "unit": "env-steps/s", "cores": int(threads), "kind": "port",
-            "sample": f"1 update of the NumPy float32 oracle: {N} envs x {T} steps + {E}x{M} minibatches ({dt:.1f} s); BLAS threads = cores, element-wise NumPy is single-threaded"}
+        blas_threads = cores
+    dt = t_rollout + t_update
+    return {"value": N * T / dt, "unit": "env-steps/s", "cores": int(workers), "kind": "port",
+            "sample": f"1 update of the NumPy float32 oracle (oracle/, a port: the JAX reference cannot run on this box) at {N} envs x {T} steps: "
+                      f"rollout sharded over {workers} worker processes ({shard} envs each, slowest shard {t_rollout:.1f} s; {wall_rollout:.1f} s wall with "
+                      f"interpreter start-up), then GAE + {E}x{M} minibatch steps in one process with {blas_threads} BLAS threads ({t_update:.1f} s)",
+            "host_cores": int(cores)}
 
 
 def spawn_ranks(args: argparse.Namespace) -> int:
@@ -270,7 +340,8 @@ def main() -> None:
             traffic = json.loads(tf.read_text())["kernels"]["fused_mlp_kernel<false, false, 1>"]["hbm_bytes_per_launch"]
             traffic_src = "profiles/r01_f_hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, corrected)"
         out = {
-            "metric": "env-steps/sec (whole node), stompy_pro 4096 envs, 1/2/4/8 MI355X",
+            "metric": ("env-steps/sec (whole node), stompy_pro 4096 envs, 1/2/4/8 MI355X" if args.config == "stompy_pro" and args.envs_per_gpu == 4096
+                       else f"env-steps/sec (whole node), {args.config} {args.envs_per_gpu} envs per GPU, {world} MI355X"),
             "value": steps_total / dt,
             "unit": "env-steps/s",
             "n_gpus": world,
@@ -291,8 +362,8 @@ def main() -> None:
             "sanity": {"mean_reward": stats["mean_reward"], "done_fraction": stats["done_fraction"], "mean_total_loss": float(lossm[0])},
         }
         if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(args.config, args.cpu_baseline_envs)
-            out["cpu_baseline"]["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]
+            out["cpu_baseline"] = cpu_baseline(args.config, args.set, args.cpu_baseline_envs)
+            out["cpu_baseline"]["engine_over_oracle"] = out["value"] / out["cpu_baseline"]["value"]  # oracle port vs engine: not a statement about kernel quality
         else:
             out["cpu_baseline"] = None
     tr.close()
