@@ -16,11 +16,13 @@
  *     stream behind the caller's back, unless stated.  Device pointers are owned by the caller
  *     (torch tensors) and must outlive the enqueued work.
  *   - all device arrays are float32 unless stated; matrices are row-major.
- *   - flat parameter vector layout (P = 2(O*H + H + H*H + H) + H*A + 2A + H + 1 floats):
+ *   - flat parameter vector layout (P = 2(O*H + H + H*H + H) + H*A + 2A + H + 1 parameters):
  *       actor : W1[O,H] b1[H] W2[H,H] b2[H] W3[H,A] b3[A]  log_std[A]
  *       critic: W1[O,H] b1[H] W2[H,H] b2[H] W3[H,1] b3[1]
  *     (`kernel [in,out]`, `bias [out]`: the Flax layout of train.py:63,68; two hidden layers,
- *     config.py:53.)
+ *     config.py:53.)  Every tensor starts at the next multiple of 4 floats (16 bytes), whatever
+ *     A is; the alignment words in between hold zeros in the parameter, gradient and moment
+ *     vectors.  mppo_param_count() is the length including them.
  *   - trajectories are time-major [T,N,...]; flat sample index = t*N + n (train.py:260).
  *   - observation rows are padded to OP = round_up(O, 4) floats (pad = 0) so that every row
  *     starts 16-byte aligned.
@@ -126,6 +128,8 @@ typedef struct mppo_net {
   int32_t bf16;      /* 0: exact f32 MFMA; 1: bf16-in/f32-accumulate MFMA for the hidden GEMMs */
 } mppo_net_t;
 
+/* Length (floats) of the flat parameter / gradient / Adam-moment vectors: the model's parameters with every tensor starting on
+ * a 16-byte boundary (250 140 for O = 225, A = 10, H = 256: 250 133 parameters + 7 alignment words, which hold zeros). */
 size_t mppo_param_count(const mppo_net_t* net);
 
 /* `ActorCritic.__call__` + sample + log_prob on n rows (train.py:157-160, 79-83):
@@ -170,6 +174,9 @@ typedef struct mppo_batch {
   const float* target;                       /* [B]           */
 } mppo_batch_t;
 typedef struct mppo_loss_cfg { float clip_eps, vf_coef, ent_coef; } mppo_loss_cfg_t;
+/* *fused = 1 if mppo_minibatch_grad takes the fused row pass + single-launch weight gradients for this geometry
+ * (H a multiple of 32 up to 256, A <= 32, 16-byte aligned observation rows), 0 if it runs the layer-wise kernels. */
+int32_t mppo_minibatch_path(const mppo_net_t* net, const mppo_batch_t* batch, int32_t* fused);
 size_t mppo_grad_ws_bytes(const mppo_net_t* net, int32_t mb);
 int32_t mppo_minibatch_grad(const mppo_net_t* net, const float* params, const mppo_batch_t* batch, const int32_t* idx,
                             int32_t mb, const float* adv_stat, float inv_count, const mppo_loss_cfg_t* lc, float* grad,

@@ -766,7 +766,7 @@ __global__ void __launch_bounds__(kEnvBlock) env_kernel(ModelView mv, EnvArgs a,
   float* recw = a.state + (size_t)env * mv.rec_dim;
   if (a.mode == 0) {
     // reset: record = [qpos0, 0, cinert[1:], cvel[1:], qfrc_actuator | pad | qacc_warmstart = qacc | com_x | time = 0]
-    const int o_ci = nq + nv, o_cv = o_ci + 10 * (nb - 1), o_qa = o_cv + 6 * (nb - 1);
+    const int o_ci = nq + nv, o_cv = o_ci + (mv.include_c ? 10 * (nb - 1) : 0), o_qa = o_cv + (mv.include_c ? 6 * (nb - 1) : 0);
     FOR_G(i, mv.rec_dim) {
       float v = 0.f;
       if (i < nq) v = qpos[i];
@@ -813,7 +813,7 @@ __global__ void __launch_bounds__(kEnvBlock) env_kernel(ModelView mv, EnvArgs a,
   FOR_G(i, 6 * nb) bad = bad || isnan(cvel[i]);
   bad = bad || isnan(new_comx);
   const bool done = !((rc.height_min_z < z) && (z < rc.height_max_z)) || group16_any(bad);
-  const int o_ci = nq + nv, o_cv = o_ci + 10 * (nb - 1), o_qa = o_cv + 6 * (nb - 1);
+  const int o_ci = nq + nv, o_cv = o_ci + (mv.include_c ? 10 * (nb - 1) : 0), o_qa = o_cv + (mv.include_c ? 6 * (nb - 1) : 0);
   FOR_G(i, mv.rec_dim) {
     // observation = the PRE-step record (env.py:163, quirk C-5), or the reset observation when done (env.py:180)
     const float old = recw[i];
@@ -882,7 +882,7 @@ extern "C" int32_t mppo_model_open(const void* host_blob, size_t nbytes, const v
   mppo_model* m = new mppo_model();
   ModelView& v = m->mv;
   v.nq = wi[3]; v.nv = wi[4]; v.nu = wi[5]; v.nbody = wi[6]; v.njnt = wi[7]; v.ncon = wi[8]; v.nlimit = wi[9];
-  v.iterations = wi[10]; v.ls_iterations = wi[11]; v.nlevel = wi[12]; v.nroot = wi[13];
+  v.iterations = wi[10]; v.ls_iterations = wi[11]; v.nlevel = wi[12]; v.nroot = wi[13]; v.include_c = wi[14] ? 1 : 0;
   v.nefc = v.nlimit + 4 * v.ncon;
   v.timestep = wf[16]; v.tolerance = wf[17]; v.ls_tolerance = wf[18]; v.impratio = wf[19]; v.plane_z = wf[20]; v.meaninertia = wf[21];
   auto bad = [&](const char* what) { delete m; return fail(MPPO_EMODEL, "model blob: %s", what); };
@@ -945,7 +945,7 @@ extern "C" int32_t mppo_model_open(const void* host_blob, size_t nbytes, const v
   v.blob_words = (int)((total + 3) & ~(size_t)3);
   if ((size_t)v.blob_words != total) return bad("blob length must be a multiple of 4 words");
   for (int k = 0; k < BLOB_ARRAY_COUNT; ++k) v.o[k] = dir[2 * k];
-  v.obs_dim = v.nq + 2 * v.nv + 16 * (v.nbody - 1);
+  v.obs_dim = v.nq + 2 * v.nv + (v.include_c ? 16 * (v.nbody - 1) : 0);  // env.py:246-259
   v.obs_pad = (v.obs_dim + 3) & ~3;
   v.rec_dim = v.obs_pad + ((v.nv + 2 + 3) & ~3);
   m->lds = make_phys_lds(v.nq, v.nv, v.nu, v.nbody, v.njnt, v.ncon, v.nefc, v.nroot);

@@ -221,10 +221,16 @@ static_assert(kSqSlots == 2 * kNormBlocks, "adam_kernel adds kSqSlots partials; 
 // `sq_partial[kNormBlocks]` (consumed by the clip when no all-reduce sits between this kernel and Adam).
 // Launched with exactly kNormBlocks workgroups of 256 threads; requires P <= kNormBlocks * 256 * 4 * kReduceIter.
 constexpr int kReduceIter = 4;
+struct PadList { int n, off[13], cnt[13]; };  // alignment words of the flat layout: no GEMM writes them into the slabs
+__device__ __forceinline__ bool is_pad(const PadList& pl, size_t e) {
+  bool r = false;
+  for (int k = 0; k < pl.n; ++k) r = r || (e >= (size_t)pl.off[k] && e < (size_t)(pl.off[k] + pl.cnt[k]));
+  return r;
+}
 __global__ void __launch_bounds__(256) grad_reduce_kernel(size_t P, int ksplit, size_t slab_stride, const float* __restrict__ slabs, int ls_off, int A,
                                                           int AP, int nblk, const float* __restrict__ partial, const float* __restrict__ log_std,
                                                           float ent_coef, float vf_coef, float ent_weight, float* __restrict__ grad,
-                                                          float* __restrict__ loss4, float* __restrict__ sq_partial) {
+                                                          float* __restrict__ loss4, float* __restrict__ sq_partial, PadList pl) {
   __shared__ float red[4];
   __shared__ float s_part[16][40];
   float sq = 0.f;
@@ -243,7 +249,10 @@ __global__ void __launch_bounds__(256) grad_reduce_kernel(size_t P, int ksplit, 
     }
     for (int c = 0; c < 4; ++c) {
       const size_t e = i + c;
-      if (e < P && !(e >= (size_t)ls_off && e < (size_t)ls_off + A)) { grad[e] = v[c]; sq += v[c] * v[c]; }  // log_std: below
+      if (e < P && !(e >= (size_t)ls_off && e < (size_t)ls_off + A)) {  // log_std: below
+        const float g = is_pad(pl, e) ? 0.f : v[c];
+        grad[e] = g; sq += g * g;
+      }
     }
   }
   if (blockIdx.x == kNormBlocks - 1) {
@@ -519,6 +528,8 @@ int32_t minibatch_grad(const mppo_net_t& net, const float* params, const mppo_ba
     w.p[5] = wp(gbuf.f.h2c, H, H, gbuf.dout + 4 * AP, DP, 4, 1, L.c_w3, L.c_b3);  // column AP of the quad rows
     w.ls_off = L.log_std; w.A = A; w.AP = AP; w.nblk = nblk; w.partial = gbuf.partial; w.log_std = params + L.log_std;
     w.ent_coef = lc.ent_coef; w.vf_coef = lc.vf_coef; w.ent_weight = ent_weight; w.loss4 = loss4;
+    w.npad = L.npad;
+    for (int k = 0; k < L.npad; ++k) { w.pad_off[k] = L.pad_off[k]; w.pad_cnt[k] = L.pad_cnt[k]; }
     { static const char* e8 = getenv("MPPO_WGRAD_DBG"); if (e8 && (atoi(e8) & 8)) w.count = 4; }  // timing experiment: big problems only
     MPPO_TRY(wgrad_plan(w, mb));
     MPPO_REQUIRE(wgrad_supported(w), "minibatch_grad: weight-gradient launch not applicable (%d tiles)", w.ntiles);
@@ -544,8 +555,11 @@ int32_t minibatch_grad(const mppo_net_t& net, const float* params, const mppo_ba
   MPPO_TRY(gemm_launch(gb, 1, 0, EPI_STORE, net.bf16, stream));
   }
   MPPO_REQUIRE((size_t)L.total <= (size_t)kNormBlocks * 256 * 4 * kReduceIter, "minibatch_grad: %d parameters exceed the reduce kernel's range", L.total);
+  PadList pl{};
+  pl.n = L.npad;
+  for (int k = 0; k < L.npad; ++k) { pl.off[k] = L.pad_off[k]; pl.cnt[k] = L.pad_cnt[k]; }
   hipLaunchKernelGGL(grad_reduce_kernel, dim3(kNormBlocks), dim3(256), 0, stream, (size_t)L.total, gbuf.ksplit, gbuf.slab_stride, gbuf.slabs, L.log_std, A, AP, nblk,
-                     gbuf.partial, params + L.log_std, lc.ent_coef, lc.vf_coef, ent_weight, grad, loss4, sq_partial);
+                     gbuf.partial, params + L.log_std, lc.ent_coef, lc.vf_coef, ent_weight, grad, loss4, sq_partial, pl);
   MPPO_CHECK_LAUNCH("grad_reduce_kernel");
   return MPPO_OK;
 }
@@ -603,6 +617,14 @@ extern "C" int32_t mppo_gae(int32_t T, int32_t N, float gamma, float lam, const 
                             const float* last_val, float* adv, float* target, void* stream) {
   MPPO_REQUIRE(T >= 1 && N >= 1 && reward && value && done && last_val && adv && target, "mppo_gae: bad argument");
   return gae_launch(T, N, gamma, lam, reward, value, done, last_val, adv, target, static_cast<hipStream_t>(stream));
+}
+
+extern "C" int32_t mppo_minibatch_path(const mppo_net_t* net, const mppo_batch_t* batch, int32_t* fused) {
+  MPPO_TRY(check_net(net));
+  MPPO_REQUIRE(batch && fused, "mppo_minibatch_path: null argument");
+  static const char* nofuse = getenv("MPPO_NO_FUSED");
+  *fused = (fused_supported(*net, *batch) && !(nofuse && nofuse[0] == '1')) ? 1 : 0;
+  return MPPO_OK;
 }
 
 extern "C" size_t mppo_grad_ws_bytes(const mppo_net_t* net, int32_t mb) { return net ? grad_bufs_floats(*net, mb) * sizeof(float) : 0; }

@@ -202,6 +202,7 @@ __global__ void __launch_bounds__(WTHREADS) wgrad_kernel(WgradArgs a) {
       a.loss4[2] = s_col[0];
       a.loss4[3] = ent;
     }
+    if (t < a.npad) for (int k = 0; k < a.pad_cnt[t]; ++k) a.grad[a.pad_off[t] + k] = 0.f;  // alignment words of the flat layout
     if (a.sq_partial)  // slots of workgroups that do not exist
       for (int e = a.ntiles + t; e < kSqSlots; e += WTHREADS) a.sq_partial[e] = 0.f;  // (slots are indexed by workgroup id)
   }

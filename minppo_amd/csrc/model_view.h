@@ -29,7 +29,7 @@ enum BlobF32 {
 };
 
 constexpr uint32_t kBlobMagic = 0x4D50504F;
-constexpr uint32_t kBlobVersion = 1;
+constexpr uint32_t kBlobVersion = 2;
 constexpr int kBlobHeaderWords = 64;
 constexpr int JNT_FREE = 0, JNT_HINGE = 2, JNT_SLIDE = 3;
 constexpr float MJ_MINVAL = 1e-15f, MJ_MINIMP = 0.0001f, MJ_MAXIMP = 0.9999f;
@@ -41,6 +41,7 @@ typedef unsigned long long u64;
 struct ModelView {
   int nq, nv, nu, nbody, njnt, ncon, nlimit, nefc, iterations, ls_iterations, nlevel, nroot;
   int obs_dim, obs_pad, rec_dim;
+  int include_c;  // observation = qpos, qvel, cinert[1:], cvel[1:], qfrc_actuator (1) or qpos, qvel, qfrc_actuator (0): env.py:246-259
   float timestep, tolerance, ls_tolerance, impratio, plane_z, meaninertia;
   const int* blob;   // device copy of the whole blob (16-byte aligned)
   int blob_words;    // multiple of 4

@@ -10,16 +10,27 @@
 
 namespace mppo {
 
-// Offsets (floats) inside the flat parameter / gradient / Adam-moment vectors (include/minppo_hip.h).
+// Offsets (floats) inside the flat parameter / gradient / Adam-moment vectors (include/minppo_hip.h).  Every tensor starts on
+// a 16-byte boundary whatever the action dimension is (float4 rows in the fused row pass and the weight-gradient kernel, bf16
+// for odd A); the up to three padding words after a tensor hold zeros in all four vectors and stay zero (zero gradient -> zero
+// Adam update).  `total` counts the padding; the model has total - npad_words parameters (P of SURVEY 8).
 struct ParamLayout {
   int a_w1, a_b1, a_w2, a_b2, a_w3, a_b3, log_std, c_w1, c_b1, c_w2, c_b2, c_w3, c_b3, total;
+  int pad_off[13], pad_cnt[13], npad, npad_words;  // the padding runs (offset, length <= 3)
 };
 inline ParamLayout param_layout(int O, int A, int H) {
-  ParamLayout L;
+  ParamLayout L{};
   int o = 0;
-  L.a_w1 = o; o += O * H; L.a_b1 = o; o += H; L.a_w2 = o; o += H * H; L.a_b2 = o; o += H; L.a_w3 = o; o += H * A; L.a_b3 = o; o += A;
-  L.log_std = o; o += A;
-  L.c_w1 = o; o += O * H; L.c_b1 = o; o += H; L.c_w2 = o; o += H * H; L.c_b2 = o; o += H; L.c_w3 = o; o += H; L.c_b3 = o; o += 1;
+  auto take = [&](int n) {
+    const int at = o;
+    o += n;
+    const int pad = (4 - (o & 3)) & 3;
+    if (pad) { L.pad_off[L.npad] = o; L.pad_cnt[L.npad] = pad; ++L.npad; L.npad_words += pad; o += pad; }
+    return at;
+  };
+  L.a_w1 = take(O * H); L.a_b1 = take(H); L.a_w2 = take(H * H); L.a_b2 = take(H); L.a_w3 = take(H * A); L.a_b3 = take(A);
+  L.log_std = take(A);
+  L.c_w1 = take(O * H); L.c_b1 = take(H); L.c_w2 = take(H * H); L.c_b2 = take(H); L.c_w3 = take(H); L.c_b3 = take(1);
   L.total = o;
   return L;
 }

@@ -34,6 +34,7 @@ struct WgradArgs {
   const float* log_std;
   float ent_coef, vf_coef, ent_weight;
   float* loss4;
+  int npad, pad_off[13], pad_cnt[13];  // alignment words of the flat layout (ppo_layout.h): written as zeros
   unsigned short order[kSqSlots];  // workgroup id -> tile (wgrad_plan): tiles that share operand bands sit on the same XCD
   int dbg;  // timing experiments only (MPPO_WGRAD_DBG bit mask): 4 launch twice (warm operands), 8 big problems only
 };

@@ -62,12 +62,10 @@ class HumanoidEnv:
         self.lib = lib if lib is not None else nat.load()
         self.device = torch.device(device)
         self._include_c_vals = config.environment.include_c_vals
-        if not self._include_c_vals:
-            raise ValueError("environment.include_c_vals=false is not supported by the fused observation record")
         self._kscale_id = config.kscale_id
         self.cm = resolve_model(config)
         self._n_frames = config.environment.n_frames
-        self._blob_host = np.frombuffer(self.cm.to_blob(), np.uint8).copy()
+        self._blob_host = np.frombuffer(self.cm.to_blob(self._include_c_vals), np.uint8).copy()
         self._blob_dev = torch.from_numpy(self._blob_host.copy()).to(self.device)
         self._model = C.c_void_p()
         self.lib.model_open(self._blob_host.ctypes.data, self._blob_host.size, self._blob_dev.data_ptr(), C.byref(self._model))

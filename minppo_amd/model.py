@@ -37,7 +37,7 @@ GEOM_SPHERE, GEOM_CAPSULE = 2, 3
 MJ_MINVAL = 1e-15
 
 BLOB_MAGIC = 0x4D50504F  # "MPPO"
-BLOB_VERSION = 1
+BLOB_VERSION = 2  # 2: header word include_c_vals
 
 
 # ---------------------------------------------------------------------------
@@ -207,8 +207,10 @@ class CompiledModel:
     def dt(self) -> float:
         return float(self.t["timestep"])  # x n_frames at the env level
 
-    def to_blob(self) -> bytes:
-        return _to_blob(self)
+    def to_blob(self, include_c_vals: bool = True) -> bytes:
+        """The model as the engine reads it.  `include_c_vals` (reference `environment.include_c_vals`, `env.py:246-259`) selects
+        what an observation is: qpos, qvel, cinert[1:], cvel[1:], qfrc_actuator - or qpos, qvel, qfrc_actuator only."""
+        return _to_blob(self, include_c_vals)
 
 
 def compile_model(spec: ModelSpec) -> CompiledModel:
@@ -631,12 +633,12 @@ _BLOB_F32 = [
     "con_lpos", "con_radius", "con_friction",
     "contact_solref", "contact_solimp", "limit_solref", "limit_solimp",
 ]
-_HDR_INT = ["nq", "nv", "nu", "nbody", "njnt", "ncon", "nlimit", "iterations", "ls_iterations", "nlevel", "nroot"]
+_HDR_INT = ["nq", "nv", "nu", "nbody", "njnt", "ncon", "nlimit", "iterations", "ls_iterations", "nlevel", "nroot", "include_c_vals"]
 _HDR_F32 = ["timestep", "tolerance", "ls_tolerance", "impratio", "plane_z", "meaninertia"]
 BLOB_HEADER_WORDS = 64  # fixed-size header; array directory follows
 
 
-def _to_blob(cm: CompiledModel) -> bytes:
+def _to_blob(cm: CompiledModel, include_c_vals: bool = True) -> bytes:
     """Packs the model into one little-endian blob of 4-byte words.
 
     word 0: magic, 1: version, 2: total words, 3..: header ints (see _HDR_INT),
@@ -669,7 +671,7 @@ def _to_blob(cm: CompiledModel) -> bytes:
     hdr = bytearray(4 * BLOB_HEADER_WORDS)
     struct.pack_into("<3I", hdr, 0, BLOB_MAGIC, BLOB_VERSION, total)
     for i, k in enumerate(_HDR_INT):
-        struct.pack_into("<i", hdr, 4 * (3 + i), int(t[k]))
+        struct.pack_into("<i", hdr, 4 * (3 + i), int(include_c_vals) if k == "include_c_vals" else int(t[k]))
     for i, k in enumerate(_HDR_F32):
         struct.pack_into("<f", hdr, 4 * (16 + i), float(t[k]))
     struct.pack_into("<i", hdr, 4 * 32, ndir)

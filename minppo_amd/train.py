@@ -91,13 +91,15 @@ def save_model(params: dict, filename: str) -> None:
 
 
 def param_slices(O: int, A: int, H: int):
-    """name -> (offset, shape) of the flat parameter vector (include/minppo_hip.h)."""
+    """name -> (offset, shape) of the flat parameter vector (include/minppo_hip.h): every tensor starts on a 16-byte boundary;
+    the alignment words in between hold zeros.  Returns (slices, total length incl. alignment words)."""
     out, off = {}, 0
     for name, shape in (("a_w1", (O, H)), ("a_b1", (H,)), ("a_w2", (H, H)), ("a_b2", (H,)), ("a_w3", (H, A)), ("a_b3", (A,)),
                         ("log_std", (A,)), ("c_w1", (O, H)), ("c_b1", (H,)), ("c_w2", (H, H)), ("c_b2", (H,)), ("c_w3", (H, 1)),
                         ("c_b3", (1,))):
         out[name] = (off, shape)
         off += int(np.prod(shape))
+        off = (off + 3) & ~3
     return out, off
 
 
@@ -194,8 +196,6 @@ class Trainer:
             raise ValueError(f"rl.num_env_steps ({rl.num_env_steps}) must equal training.num_steps ({tr.num_steps})")
         if config.model.num_layers != 2:
             raise ValueError("the MI355X engine lays out exactly two hidden layers (reference default, config.py:53)")
-        if not config.environment.include_c_vals:
-            raise ValueError("environment.include_c_vals=false is not supported by the fused observation record")
         if tr.num_envs % world_size != 0:
             raise ValueError(f"training.num_envs ({tr.num_envs}) must be divisible by the number of ranks ({world_size})")
         self.num_envs_global = tr.num_envs
@@ -209,7 +209,7 @@ class Trainer:
         self.seed = tr.seed if seed is None else int(seed)
 
         self.cm = resolve_model(config)
-        blob = np.frombuffer(self.cm.to_blob(), np.uint8)
+        blob = np.frombuffer(self.cm.to_blob(config.environment.include_c_vals), np.uint8)
         self._blob_host = blob.copy()
         if xp == "torch":
             import torch
@@ -306,7 +306,7 @@ class Trainer:
     # uninterrupted run bit for bit (tests/test_train_surface.py).
     _CKPT_REGIONS = ("params", "adam_m", "adam_v", "count", "state", "episode_returns", "episode_lengths", "returned_episode_returns",
                      "returned_episode_lengths", "timestep", "returned_episode")
-    _CKPT_VERSION = 1
+    _CKPT_VERSION = 2  # 2: 16-byte-aligned flat parameter layout
 
     def _ckpt_meta(self) -> Dict[str, Any]:
         return dict(version=self._CKPT_VERSION, model=self.cm.name, num_envs=self.N, num_steps=self.T, obs_dim=self.O, act_dim=self.A, hidden=self.H,

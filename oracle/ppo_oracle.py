@@ -38,25 +38,29 @@ LOG_2PI = math.log(2.0 * math.pi)
 
 
 def param_count(O: int, A: int, H: int) -> int:
+    """Number of parameters of the model (P = 512 O + 258 A + 132 353 at H = 256)."""
     return 2 * (O * H + H + H * H + H) + H * A + A + A + H + 1
+
+
+def _slices(O: int, A: int, H: int):
+    out = {}
+    off = 0
+    for name, shape in (("a_w1", (O, H)), ("a_b1", (H,)), ("a_w2", (H, H)), ("a_b2", (H,)), ("a_w3", (H, A)), ("a_b3", (A,)), ("log_std", (A,)),
+                        ("c_w1", (O, H)), ("c_b1", (H,)), ("c_w2", (H, H)), ("c_b2", (H,)), ("c_w3", (H, 1)), ("c_b3", (1,))):
+        out[name] = (off, shape)
+        off = (off + int(np.prod(shape)) + 3) & ~3
+    return out, off
+
+
+def flat_size(O: int, A: int, H: int) -> int:
+    """Length of the FLAT vector the engine and this oracle exchange (include/minppo_hip.h): the parameters with every
+    tensor starting on a 16-byte boundary; the alignment words hold zeros (zero gradient, zero update)."""
+    return _slices(O, A, H)[1]
 
 
 def param_slices(O: int, A: int, H: int) -> Dict[str, Tuple[int, Tuple[int, ...]]]:
     """name -> (offset, shape) in the flat vector."""
-    out = {}
-    off = 0
-
-    def add(name, shape):
-        nonlocal off
-        out[name] = (off, shape)
-        off += int(np.prod(shape))
-
-    add("a_w1", (O, H)); add("a_b1", (H,)); add("a_w2", (H, H)); add("a_b2", (H,))
-    add("a_w3", (H, A)); add("a_b3", (A,)); add("log_std", (A,))
-    add("c_w1", (O, H)); add("c_b1", (H,)); add("c_w2", (H, H)); add("c_b2", (H,))
-    add("c_w3", (H, 1)); add("c_b3", (1,))
-    assert off == param_count(O, A, H)
-    return out
+    return _slices(O, A, H)[0]
 
 
 def flat_to_named(flat: np.ndarray, O: int, A: int, H: int) -> Dict[str, np.ndarray]:
@@ -65,7 +69,7 @@ def flat_to_named(flat: np.ndarray, O: int, A: int, H: int) -> Dict[str, np.ndar
 
 def named_to_flat(named: Dict[str, np.ndarray], O: int, A: int, H: int) -> np.ndarray:
     dt = named["a_w1"].dtype
-    flat = np.zeros(param_count(O, A, H), dt)
+    flat = np.zeros(flat_size(O, A, H), dt)
     for k, (o, s) in param_slices(O, A, H).items():
         flat[o:o + int(np.prod(s))] = np.asarray(named[k], dt).reshape(-1)
     return flat

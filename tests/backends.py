@@ -34,9 +34,9 @@ def _emu_stale() -> bool:
 class Backend:
     name = "?"
 
-    def model(self, cm):
+    def model(self, cm, include_c_vals=True):
         """Opens a compiled robot model; returns (handle, dims, keepalive)."""
-        blob = np.frombuffer(cm.to_blob(), np.uint8).copy()
+        blob = np.frombuffer(cm.to_blob(include_c_vals), np.uint8).copy()
         dev = self.arr(blob)
         h = C.c_void_p()
         self.lib.model_open(blob.ctypes.data, blob.size, self.ptr(dev), C.byref(h))

@@ -62,7 +62,7 @@ def test_header_is_plain_c_and_cxx(tmp_path):
         assert r.returncode == 0, r.stderr
     # and a C translation unit that calls through it links against the library's symbol names (no C++ mangling)
     src = tmp_path / "use.c"
-    src.write_text('#include "minppo_hip.h"\nint main(void) { mppo_net_t n = {225, 228, 10, 256, 1, 0}; return mppo_param_count(&n) == 250133 ? 0 : 1; }\n')
+    src.write_text('#include "minppo_hip.h"\nint main(void) { mppo_net_t n = {225, 228, 10, 256, 1, 0}; return mppo_param_count(&n) == 250140 ? 0 : 1; /* 250133 parameters + 7 alignment words */ }\n')
     r = subprocess.run(["gcc", "-std=c99", "-c", "-I", str(Path(hdr).parent), str(src), "-o", str(tmp_path / "use.o")], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
     nm = subprocess.run(["nm", "-u", str(tmp_path / "use.o")], capture_output=True, text=True).stdout

@@ -25,15 +25,18 @@ def _small(be):
     return ["training.num_envs=256", "training.num_minibatches=8", "training.update_epochs=2", "training.total_timesteps=100000000"]
 
 
-@pytest.mark.parametrize("robot", ["stompy_pro", "stompy_full"])
+@pytest.mark.parametrize("robot", ["stompy_pro", "stompy_full", "stompy_pro_no_c_vals"])
 def test_update_matches_oracle_stage_by_stage(be, robot):
-    """Both BASELINE robots: configs[1] (synth_stompy_pro, O = 225, A = 10) and configs[4] (synth_stompy_full, O = 415, A = 20)."""
-    cfg = _cfg(*_small(be), *(["environment.model=synth_stompy_full"] if robot == "stompy_full" else []))
+    """Both BASELINE robots: configs[1] (synth_stompy_pro, O = 225, A = 10) and configs[4] (synth_stompy_full, O = 415, A = 20);
+    and the short observation of `environment.include_c_vals=false` (qpos, qvel, qfrc_actuator: O = 49; reference env.py:254-259)."""
+    cfg = _cfg(*_small(be), *(["environment.model=synth_stompy_full"] if robot == "stompy_full" else []),
+               *(["environment.include_c_vals=false"] if robot == "stompy_pro_no_c_vals" else []))
     tr = be.trainer(cfg, external_random=True, use_graph=False)
     tr.reset()
     N, T, A, H, O, OP, E, M = tr.N, tr.T, tr.A, tr.H, tr.O, tr.OP, tr.E, tr.M
     rng = np.random.default_rng(0)
-    env = EnvOracle(tr.cm.t, RewardCfg())
+    env = EnvOracle(tr.cm.t, RewardCfg(), include_c_vals=cfg.environment.include_c_vals)
+    assert O == env.observation_size
     hp = default_hp(cfg)
     p = tr.params_flat().astype(np.float64)
     opt = po.OptState(np.zeros_like(p), np.zeros_like(p), 0)

@@ -219,15 +219,17 @@ def _pack(env, s, dims, nv):
     return rec
 
 
-@pytest.mark.parametrize("model,n_frames", [("synth_stompy_pro", 1), ("synth_stompy_pro", 2), ("synth_stompy_full", 1)])
-def test_env_step_matches_env_oracle(be, model, n_frames):
+@pytest.mark.parametrize("model,n_frames,c_vals", [("synth_stompy_pro", 1, True), ("synth_stompy_pro", 2, True), ("synth_stompy_full", 1, True),
+                                                    ("synth_stompy_pro", 1, False)])  # environment.include_c_vals = false (env.py:254-259)
+def test_env_step_matches_env_oracle(be, model, n_frames, c_vals):
     """reset + 24 steps, the kernel re-seeded from the oracle state before every step (identical inputs):
     observation lag, reward, height / NaN termination, auto-reset, metrics.  Both BASELINE robots (configs[1] / configs[4])."""
     cm = load_model(model)
-    h, dims, _keep = be.model(cm)
+    h, dims, _keep = be.model(cm, c_vals)
     N, O, OP, R, nv, nu = 7, dims.obs_dim, dims.obs_pad, dims.rec_dim, cm.nv, cm.nu
+    assert O == cm.obs_size(c_vals)
     rcfg = RewardCfg(height_min_z=0.95)
-    env = EnvOracle(cm.t, rcfg, n_frames=n_frames)
+    env = EnvOracle(cm.t, rcfg, include_c_vals=c_vals, n_frames=n_frames)
     state, reset_rec, obs = be.zeros((N, R)), be.zeros((R,)), be.full((N, OP), np.nan)
     rew, done = be.zeros((N,)), be.zeros((N,), np.uint8)
     met_np = dict(episode_returns=f32, episode_lengths=np.int32, returned_episode_returns=f32, returned_episode_lengths=np.int32, timestep=np.int32,

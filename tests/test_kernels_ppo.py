@@ -128,7 +128,8 @@ def test_policy_forward_sample_logprob(be, O, A, H, n, tanh):
                                                   (40, 4, 512, 80, 48, 1, 0.0),       # H > 256 takes the layer-wise path
                                                   (415, 20, 256, 120, 72, 1, 0.01),   # stompy_full: 20 outputs = two head tiles
                                                   (50, 32, 64, 64, 40, 0, 0.0),       # the widest head the fused kernel covers
-                                                  (35, 3, 64, 90, 70, 1, 0.0)])       # 35 = 32 + 3 observation rows: a "thin" last row band of the first layer's gradient
+                                                  (35, 3, 64, 90, 70, 1, 0.0),        # 35 = 32 + 3 observation rows: a "thin" last row band of the first layer's gradient
+                                                  (60, 7, 64, 100, 80, 1, 0.0), (33, 11, 96, 90, 64, 0, 0.01)])  # odd action dimensions (fused path, see below)
 def test_minibatch_grad_matches_oracle(be, O, A, H, B, mb, tanh, ent):
     if be.name == "emu" and mb > 400:
         pytest.skip("full-size minibatch only on the GPU")
@@ -155,6 +156,9 @@ def test_minibatch_grad_matches_oracle(be, O, A, H, B, mb, tanh, ent):
     grad, loss4 = be.full((flat.size,), np.nan), be.zeros((4,))
     wsb = be.lib.grad_ws_bytes(C.byref(net), mb)
     ws = be.full((wsb // 4 + 4,), np.nan)
+    fused = C.c_int32(-1)
+    be.lib.minibatch_path(C.byref(net), C.byref(batch), C.byref(fused))
+    assert fused.value == (1 if H % 32 == 0 and H <= 256 else 0)  # which kernels run: the fused row pass + k_wgrad.hip, or the layer-wise fallback
     be.lib.minibatch_grad(C.byref(net), be.ptr(d["flat"]), C.byref(batch), be.ptr(d["idx"]), mb, be.ptr(stats), 1.0 / mb, C.byref(lc), be.ptr(grad),
                           be.ptr(loss4), be.ptr(ws), wsb, be.stream)
     lo, gr = po.loss_and_grad(n64, bobs[idx][:, :O].astype(np.float64), bact[idx].astype(np.float64), bval[idx].astype(np.float64),
@@ -176,7 +180,8 @@ def test_minibatch_grad_matches_oracle(be, O, A, H, B, mb, tanh, ent):
     np.testing.assert_array_equal(be.host(g1), be.host(g2))
 
 
-@pytest.mark.parametrize("O,A,H,B,mb,tanh", [(225, 10, 256, 400, 200, 1), (37, 3, 64, 129, 129, 0), (225, 10, 256, 1280, 1280, 1), (415, 20, 256, 120, 72, 1)])
+@pytest.mark.parametrize("O,A,H,B,mb,tanh", [(225, 10, 256, 400, 200, 1), (37, 3, 64, 129, 129, 0), (225, 10, 256, 1280, 1280, 1), (415, 20, 256, 120, 72, 1),
+                                             (60, 7, 64, 100, 80, 1), (33, 11, 96, 90, 64, 1)])  # odd action dimensions
 def test_bf16_mfma_path(be, O, A, H, B, mb, tanh):
     """BASELINE configs[3]: bf16-in / f32-accumulate MFMA in the MLP products, everything else f32.
 
@@ -225,12 +230,10 @@ def test_bf16_mfma_path(be, O, A, H, B, mb, tanh):
     ws = be.full((wsb // 4 + 4,), np.nan)
     call = lambda: be.lib.minibatch_grad(C.byref(net), be.ptr(d["flat"]), C.byref(batch), be.ptr(d["idx"]), mb, be.ptr(stats), 1.0 / mb, C.byref(lc),
                                          be.ptr(grad), be.ptr(loss4), be.ptr(ws), wsb, be.stream)
-    if po.param_slices(O, A, H)["c_w2"][0] % 4:
-        # odd action dimension: the critic's W2 is not 16-byte aligned, the fused row pass does not apply and the layer-wise
-        # fallback has no bf16 backward product: the request is refused, not silently computed in f32
-        with pytest.raises(nat.NativeError, match="no bf16 variant"):
-            call()
-        return
+    # (odd action dimensions take the fused row pass as well: every tensor of the flat layout starts 16-byte aligned)
+    fused = C.c_int32(-1)
+    be.lib.minibatch_path(C.byref(net), C.byref(batch), C.byref(fused))
+    assert fused.value == 1
     call()
     args64 = (bobs[idx][:, :O].astype(np.float64), bact[idx].astype(np.float64), bval[idx].astype(np.float64), blp[idx].astype(np.float64), g,
               btgt[idx].astype(np.float64), 0.2, 0.5, 0.0, bool(tanh))
@@ -248,7 +251,7 @@ def test_bf16_mfma_path(be, O, A, H, B, mb, tanh):
     # SURVEY 8c proposes cosine >= 0.999 against exact arithmetic; what bf16 operands themselves cost depends on the shape (0.9987 for
     # K = 415 on 72 rows, oracle vs oracle), so the kernel is required to be as close to exact as the bf16 oracle is
     assert cos(got, gx) > min(0.999, cos(gb, gx) - 1e-4), (cos(got, gx), cos(gb, gx))
-    assert cos(gb, gx) > 0.998
+    assert cos(gb, gx) > 0.997  # (oracle vs oracle: what bf16 operands cost at this shape)
     for k, (o, s) in po.param_slices(O, A, H).items():
         sz = int(np.prod(s))
         np.testing.assert_allclose(got[o:o + sz], gb[o:o + sz], rtol=0, atol=5e-3 * np.abs(gb[o:o + sz]).max() + 1e-7, err_msg=k)

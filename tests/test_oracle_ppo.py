@@ -129,7 +129,10 @@ def test_clip_adam_schedule_known_answers():
 def test_param_packing_roundtrip_and_tree():
     named = po.init_params(5, O, A, H)
     flat = po.named_to_flat(named, O, A, H)
-    assert flat.size == po.param_count(O, A, H) == 512 // 256 * 0 + 2 * (O * H + H + H * H + H) + H * A + 2 * A + H + 1
+    assert po.param_count(O, A, H) == 2 * (O * H + H + H * H + H) + H * A + 2 * A + H + 1
+    assert flat.size == po.flat_size(O, A, H) >= po.param_count(O, A, H) and flat.size % 4 == 0
+    assert all(o % 4 == 0 for o, _ in po.param_slices(O, A, H).values())  # every tensor starts on a 16-byte boundary
+    assert np.count_nonzero(flat) <= po.param_count(O, A, H)  # the alignment words are zero
     back = po.flat_to_named(flat, O, A, H)
     for k in named:
         np.testing.assert_array_equal(named[k], back[k])
@@ -145,6 +148,7 @@ def test_param_packing_roundtrip_and_tree():
     # SURVEY: P = 512*O + 258*A + 132353 at H=256
     assert po.param_count(225, 10, 256) == 250133
     assert po.param_count(415, 20, 256) == 349993
+    assert po.flat_size(225, 10, 256) == 250140 and po.flat_size(415, 20, 256) == 349996  # + alignment words
 
 
 def test_epoch_driver_matches_manual_steps():

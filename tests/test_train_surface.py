@@ -15,7 +15,7 @@ SMALL = ["training.num_envs=8", "training.num_steps=2", "rl.num_env_steps=2", "t
 
 def test_param_tree_layout_and_init():
     flat = T.init_flat_params(1337, 225, 10, 256)
-    assert flat.size == 250133  # P = 512*O + 258*A + 132353
+    assert flat.size == 250140  # P = 512*O + 258*A + 132353 = 250133 parameters + 7 alignment words of the flat layout
     tree = T.flat_to_tree(flat, 225, 10, 256)
     p = tree["params"]
     assert set(p) == {"MLP_0", "MLP_1", "log_std"} and set(p["MLP_0"]) == {"Dense_0", "Dense_1", "Dense_2"}
