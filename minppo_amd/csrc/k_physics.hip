@@ -48,6 +48,14 @@ struct EnvArgs {
 #define SYNC() __builtin_amdgcn_wave_barrier()
 #endif
 #define FOR_G(i, n) for (int i = g; i < (n); i += kGroupLanes)
+// Phase timers (profiling builds only, -DMPPO_PHYS_TIMERS: tools/env_phases.py): wave 0 of workgroup 0 stamps s_memtime at the phase
+// boundaries of its first frame into a device array that mppo_debug_phys_timers() copies out.
+#ifdef MPPO_PHYS_TIMERS
+__device__ unsigned long long g_phys_t[40];
+#define PT(k) do { if (blockIdx.x == 0 && tid == 0) g_phys_t[k] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define PT(k) do { } while (0)
+#endif
 // model tables in LDS (see the staging copy at the top of the kernel)
 #define TI(name) (tabI + mv.o[BI_##name])
 #define TF(name) (tabF + mv.o[BF_##name])
@@ -120,24 +128,25 @@ __device__ __forceinline__ void cross_force(const float* vel, const float* f, fl
 template <bool EUL, int NV>
 __device__ __forceinline__ void solve_linv(const float* LL, int ldm, int nv_rt, const float* b, float* tmp, float* x, int g) {
   const int nv = NV ? NV : nv_rt;
+  // Both triangular products run over the FULL row with the entries outside the triangle masked to 0 (LL packs two inverse
+  // factors in one square): a lane-independent trip count lets the compiler request eight LDS operands at a time and wait once,
+  // where the triangular loop waited for every single one (one wave per SIMD: nothing else hides an LDS round trip).
   FOR_G(i, nv) {
     float s = 0.f;
-    if (NV && !EUL) {  // row i of the lower factor: full-length masked product (unrolls, float4 LDS reads)
-#pragma unroll
-      for (int k = 0; k < nv; ++k) s += (k <= i ? LL[i * ldm + k] : 0.f) * b[k];
-    } else {
-      for (int k = 0; k <= i; ++k) s += (EUL ? LL[k * ldm + i + 1] : LL[i * ldm + k]) * b[k];
+#pragma unroll 8
+    for (int k = 0; k < nv; ++k) {
+      const float l = EUL ? LL[k * ldm + i + 1] : LL[i * ldm + k];
+      s += (k <= i ? l : 0.f) * b[k];
     }
     tmp[i] = s;
   }
   SYNC();
   FOR_G(i, nv) {
     float s = 0.f;
-    if (NV && EUL) {
-#pragma unroll
-      for (int k = 0; k < nv; ++k) s += (k >= i ? LL[i * ldm + k + 1] : 0.f) * tmp[k];
-    } else {
-      for (int k = i; k < nv; ++k) s += (EUL ? LL[i * ldm + k + 1] : LL[k * ldm + i]) * tmp[k];
+#pragma unroll 8
+    for (int k = 0; k < nv; ++k) {
+      const float l = EUL ? LL[i * ldm + k + 1] : LL[k * ldm + i];
+      s += (k >= i ? l : 0.f) * tmp[k];
     }
     x[i] = s;
   }
@@ -229,6 +238,7 @@ __global__ void __launch_bounds__(kEnvBlock) env_kernel(ModelView mv, EnvArgs a,
 
   const float* rec = a.state ? a.state + (size_t)env * mv.rec_dim : nullptr;
 
+  PT(0);
   // ---- P0: load the state ------------------------------------------------------------------
   if (a.mode == 1) {
     FOR_G(i, nq) qpos[i] = rec[i];
@@ -260,6 +270,7 @@ __global__ void __launch_bounds__(kEnvBlock) env_kernel(ModelView mv, EnvArgs a,
   int niter_out = 0;
   const int frames = a.mode == 1 ? a.n_frames : 1;
   for (int frame = 0; frame < frames; ++frame) {
+    PT(1);
     // ================= fwd_position: kinematics (level-synchronous over the tree) =================
     for (int lv = 0; lv < mv.nlevel; ++lv) {
       const int adr = TI(level_adr)[lv], cnt = TI(level_adr)[lv + 1] - adr;
@@ -300,6 +311,7 @@ __global__ void __launch_bounds__(kEnvBlock) env_kernel(ModelView mv, EnvArgs a,
       }
       SYNC();
     }
+    PT(2);
     // ---- com_pos: centre of mass of every kinematic tree; contact candidates --------------------
     for (int r = 0; r < mv.nroot; ++r) {
       const u64 mask = TU(body_subtree_mask)[TI(root_body)[r]];
@@ -324,6 +336,7 @@ __global__ void __launch_bounds__(kEnvBlock) env_kernel(ModelView mv, EnvArgs a,
       st3(conpos + 3 * c, {centre.x, centre.y, centre.z - (rad + 0.5f * dist)});
     }
     SYNC();
+    PT(3);
     // ---- cinert (per body), cdof (per joint) -------------------------------------------------------
     FOR_G(b, nb) {
       float* ci = cinert + 10 * b;
@@ -373,6 +386,7 @@ __global__ void __launch_bounds__(kEnvBlock) env_kernel(ModelView mv, EnvArgs a,
     }
     FOR_G(i, nv) for (int k = 0; k < nv; ++k) M[i * ldm + k] = 0.f;
     SYNC();
+    PT(4);
     // ---- crb: composite inertia over the subtree mask, dense M ------------------------------------
     FOR_G(i, nv) {
       const int bi = TI(dof_bodyid)[i];
@@ -397,6 +411,7 @@ __global__ void __launch_bounds__(kEnvBlock) env_kernel(ModelView mv, EnvArgs a,
       }
     }
     SYNC();
+    PT(5);
     // work copies for the two factorisations (region A2; the kinematics temporaries are dead)
     FOR_G(i, nv) {
       for (int k = 0; k < nv; ++k) {
@@ -415,6 +430,7 @@ __global__ void __launch_bounds__(kEnvBlock) env_kernel(ModelView mv, EnvArgs a,
       FOR_G(i, nv) {
         if (i > k) {
           const float l1 = C1[i * ldm + k], l2 = C2[i * ldm + k];
+#pragma unroll 4
           for (int j = k + 1; j <= i; ++j) {
             C1[i * ldm + j] -= l1 * C1[j * ldm + k];
             C2[i * ldm + j] -= l2 * C2[j * ldm + k];
@@ -423,18 +439,21 @@ __global__ void __launch_bounds__(kEnvBlock) env_kernel(ModelView mv, EnvArgs a,
       }
     }
     SYNC();
+    PT(6);
     // ---- triangular inverses, one column per lane (no cross-lane dependency inside a column) -------
     FOR_G(j, nv) {
       LL[j * ldm + j] = rsqrtf(fmaxf(C1[j * ldm + j], MJ_MINVAL));      // Li[j][j]
       LL[j * ldm + j + 1] = rsqrtf(fmaxf(C2[j * ldm + j], MJ_MINVAL));  // Le[j][j] (transposed slot)
       for (int i = j + 1; i < nv; ++i) {
         float s1 = 0.f, s2 = 0.f;
+#pragma unroll 4
         for (int k = j; k < i; ++k) { s1 += C1[i * ldm + k] * LL[k * ldm + j]; s2 += C2[i * ldm + k] * LL[j * ldm + k + 1]; }
         LL[i * ldm + j] = -s1 * rsqrtf(fmaxf(C1[i * ldm + i], MJ_MINVAL));      // Li[i][j]
         LL[j * ldm + i + 1] = -s2 * rsqrtf(fmaxf(C2[i * ldm + i], MJ_MINVAL));  // Le[i][j]
       }
     }
     SYNC();
+    PT(7);
     // ================= fwd_velocity: com_vel, passive, rne (closed forms over ancestor masks) =======
     FOR_G(b, nb) {
       float v[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -486,6 +505,7 @@ __global__ void __launch_bounds__(kEnvBlock) env_kernel(ModelView mv, EnvArgs a,
       }
     }
     SYNC();
+    PT(8);
     // ---- qfrc_bias, passive, actuation -> qfrc_smooth -------------------------------------------------
     FOR_G(d, nv) {
       float f[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -523,7 +543,9 @@ __global__ void __launch_bounds__(kEnvBlock) env_kernel(ModelView mv, EnvArgs a,
       }
     }
     SYNC();  // cfrc / cdofdot (region A3) are dead from here: the Jacobian (A4) may overwrite them
+    PT(9);
     solve_linv<false, NV>(LL, ldm, nv, qfs, t0, qas, g);  // fwd_acceleration: qacc_smooth = M^-1 qfrc_smooth
+    PT(10);
     // ================= make_constraint ===================================================================
     FOR_G(r, nefc) for (int k = 0; k < nv; ++k) J[r * ldj + k] = 0.f;
     SYNC();
@@ -574,12 +596,13 @@ __global__ void __launch_bounds__(kEnvBlock) env_kernel(ModelView mv, EnvArgs a,
       if (r < nlim) kbi(TF(limit_solref), TF(limit_solimp), h, pos, k, b, imp);
       else kbi(TF(contact_solref), TF(contact_solimp), h, pos, k, b, imp);
       float s = 0.f;
-      _Pragma("unroll") for (int d = 0; d < nv; ++d) s += J[r * ldj + d] * qvel[d];
+      _Pragma("unroll 8") for (int d = 0; d < nv; ++d) s += J[r * ldj + d] * qvel[d];
       const float R = fmaxf(iw * (1.f - imp) / imp, MJ_MINVAL);
       eD[r] = act ? 1.f / R : 0.f;
       earef[r] = act ? -b * s - k * imp * pos : 0.f;
     }
     SYNC();
+    PT(11);
     // ================= solve: CG (Polak-Ribiere, M^-1 preconditioner) =====================================
     const float scale = mv.meaninertia * (float)(nv > 1 ? nv : 1);
     float cost = 0.f, prev_cost = 0.f, gauss = 0.f;
@@ -593,8 +616,8 @@ __global__ void __launch_bounds__(kEnvBlock) env_kernel(ModelView mv, EnvArgs a,
         if (take) FOR_G(i, nv) qacc[i] = src[i];
         SYNC();
         if (take) {
-          FOR_G(i, nv) { float s = 0.f; _Pragma("unroll") for (int k = 0; k < nv; ++k) s += M[i * ldm + k] * qacc[k]; Ma[i] = s; }
-          FOR_G(r, nefc) { float s = 0.f; _Pragma("unroll") for (int k = 0; k < nv; ++k) s += J[r * ldj + k] * qacc[k]; jaref[r] = s - earef[r]; }
+          FOR_G(i, nv) { float s = 0.f; _Pragma("unroll 8") for (int k = 0; k < nv; ++k) s += M[i * ldm + k] * qacc[k]; Ma[i] = s; }
+          FOR_G(r, nefc) { float s = 0.f; _Pragma("unroll 8") for (int k = 0; k < nv; ++k) s += J[r * ldj + k] * qacc[k]; jaref[r] = s - earef[r]; }
         }
         SYNC();
         float gs = 0.f, cs = 0.f;
@@ -615,11 +638,12 @@ __global__ void __launch_bounds__(kEnvBlock) env_kernel(ModelView mv, EnvArgs a,
       // update_constraint + update_gradient at the starting point
       FOR_G(r, nefc) { const float x = jaref[r]; force[r] = x < 0.f ? -eD[r] * x : 0.f; }
       SYNC();
-      FOR_G(i, nv) { float s = 0.f; _Pragma("unroll") for (int r = 0; r < nefc; ++r) s += J[r * ldj + i] * force[r]; qfc[i] = s; grad[i] = Ma[i] - qfs[i] - s; }
+      FOR_G(i, nv) { float s = 0.f; _Pragma("unroll 8") for (int r = 0; r < nefc; ++r) s += J[r * ldj + i] * force[r]; qfc[i] = s; grad[i] = Ma[i] - qfs[i] - s; }
       SYNC();
       solve_linv<false, NV>(LL, ldm, nv, grad, t0, Mgrad, g);
       FOR_G(i, nv) search[i] = -Mgrad[i];
       SYNC();
+      PT(12);
       for (int it = 0; it < mv.iterations; ++it) {
         float gn = 0.f;
         FOR_G(i, nv) gn += grad[i] * grad[i];
@@ -627,12 +651,14 @@ __global__ void __launch_bounds__(kEnvBlock) env_kernel(ModelView mv, EnvArgs a,
         const float improvement = (prev_cost - cost) / scale;
         const bool run = !((niter >= mv.iterations) || (improvement < mv.tolerance) || (gn < mv.tolerance));
         if (!wave_any(run)) break;
+        PT(13 + (it < 6 ? it : 6));
         // ---------------- line search ----------------
         float sn = 0.f, sMa = 0.f, sq = 0.f;
-        FOR_G(i, nv) { float s = 0.f; _Pragma("unroll") for (int k = 0; k < nv; ++k) s += M[i * ldm + k] * search[k]; mvv[i] = s; }
-        FOR_G(r, nefc) { float s = 0.f; _Pragma("unroll") for (int k = 0; k < nv; ++k) s += J[r * ldj + k] * search[k]; jv[r] = s; }
+        FOR_G(i, nv) { float s = 0.f; _Pragma("unroll 8") for (int k = 0; k < nv; ++k) s += M[i * ldm + k] * search[k]; mvv[i] = s; }
+        FOR_G(r, nefc) { float s = 0.f; _Pragma("unroll 8") for (int k = 0; k < nv; ++k) s += J[r * ldj + k] * search[k]; jv[r] = s; }
         FOR_G(i, nv) { sn += search[i] * search[i]; sMa += search[i] * Ma[i]; sq += search[i] * qfs[i]; }
         SYNC();
+        if (it == 0) PT(24);
         float smv = 0.f;
         FOR_G(i, nv) smv += search[i] * mvv[i];
         sn = group16_sum(sn); sMa = group16_sum(sMa); sq = group16_sum(sq); smv = group16_sum(smv);
@@ -653,6 +679,7 @@ __global__ void __launch_bounds__(kEnvBlock) env_kernel(ModelView mv, EnvArgs a,
           o1 = ls_make(a1, q[3] + qg0, q[4] + qg1, q[5] + qg2);
           o2 = ls_make(a2, q[6] + qg0, q[7] + qg1, q[8] + qg2);
         };
+        if (it == 0) PT(25);
         LsPoint p0, lo, hi, tmpa, tmpb;
         eval3(0.f, 0.f, 0.f, p0, tmpa, tmpb);
         eval3(p0.alpha - p0.d0 / p0.d1, 0.f, 0.f, lo, tmpa, tmpb);
@@ -661,6 +688,7 @@ __global__ void __launch_bounds__(kEnvBlock) env_kernel(ModelView mv, EnvArgs a,
           const LsPoint nlo = ls_sel(lesser, lo, p0), nhi = ls_sel(lesser, p0, lo);
           lo = nlo; hi = nhi;
         }
+        if (it == 0) PT(26);
         bool swap = true;
         int ls_iter = 0;
         for (int li = 0; li < mv.ls_iterations; ++li) {
@@ -678,6 +706,7 @@ __global__ void __launch_bounds__(kEnvBlock) env_kernel(ModelView mv, EnvArgs a,
           const bool s6 = in_bracket(nhi, lo_next); nhi = ls_sel(s6, lo_next, nhi);
           if (go) { lo = nlo; hi = nhi; swap = s1 || s2 || s3 || s4 || s5 || s6; ls_iter += 1; }
         }
+        if (it == 0) PT(27);
         const bool improved = (lo.cost < p0.cost) || (hi.cost < p0.cost);
         const float alpha = (lo.cost < hi.cost) ? lo.alpha : hi.alpha;
         if (improved && run) {
@@ -685,6 +714,7 @@ __global__ void __launch_bounds__(kEnvBlock) env_kernel(ModelView mv, EnvArgs a,
           FOR_G(r, nefc) jaref[r] += alpha * jv[r];
         }
         SYNC();
+        if (it == 0) PT(28);
         // ---------------- update_constraint, update_gradient, Polak-Ribiere ----------------
         FOR_G(i, nv) { t1[i] = Mgrad[i]; }  // previous Mgrad (previous grad is re-read below before being overwritten)
         FOR_G(r, nefc) { const float x = jaref[r]; force[r] = x < 0.f ? -eD[r] * x : 0.f; }
@@ -699,14 +729,16 @@ __global__ void __launch_bounds__(kEnvBlock) env_kernel(ModelView mv, EnvArgs a,
         if (run) { prev_cost = cost; cost = cs; gauss = gs; }
         FOR_G(i, nv) {
           float s = 0.f;
-          _Pragma("unroll") for (int r = 0; r < nefc; ++r) s += J[r * ldj + i] * force[r];
+          _Pragma("unroll 8") for (int r = 0; r < nefc; ++r) s += J[r * ldj + i] * force[r];
           if (run) { qfc[i] = s; grad[i] = Ma[i] - qfs[i] - s; }
         }
         SYNC();
+        if (it == 0) PT(29);
         solve_linv<false, NV>(LL, ldm, nv, grad, t0, mvv, g);  // candidate Mgrad (mvv is free again)
         float num = 0.f;
         FOR_G(i, nv) num += grad[i] * (mvv[i] - t1[i]);
         num = group16_sum(num);
+        if (it == 0) PT(30);
         const float beta = fmaxf(0.f, num / fmaxf(MJ_MINVAL, pgm));
         if (run) {
           FOR_G(i, nv) { Mgrad[i] = mvv[i]; search[i] = -mvv[i] + beta * search[i]; }
@@ -715,6 +747,7 @@ __global__ void __launch_bounds__(kEnvBlock) env_kernel(ModelView mv, EnvArgs a,
         SYNC();
       }
     }
+    PT(20);
     niter_out = niter;
     // ---- probe outputs (parity tests) ---------------------------------------------------------------------
     if (a.mode == 2 && valid) {
@@ -733,6 +766,7 @@ __global__ void __launch_bounds__(kEnvBlock) env_kernel(ModelView mv, EnvArgs a,
       if (pr.solver_niter && g == 0) pr.solver_niter[env] = niter;
     }
     if (a.mode == 0) break;  // pipeline_init = forward only
+    PT(21);
     // ================= euler: implicit damping, semi-implicit integration ====================================
     FOR_G(i, nv) t1[i] = qfs[i] + qfc[i];
     SYNC();
@@ -760,6 +794,7 @@ __global__ void __launch_bounds__(kEnvBlock) env_kernel(ModelView mv, EnvArgs a,
 
   if (a.mode == 2) return;
 
+  PT(22);
   // ================= epilogue: observation, reward, done, auto-reset, metrics, new record ====================
   // The new record's derived fields (cinert, cvel, qfrc_actuator, subtree_com) are those of the LAST forward
   // pass, i.e. they belong to the pre-integration pose: exactly what the MJX data carries.
@@ -849,6 +884,7 @@ __global__ void __launch_bounds__(kEnvBlock) env_kernel(ModelView mv, EnvArgs a,
       a.met.returned_episode[env] = done ? 1 : 0;
     }
   }
+  PT(23);
 }
 
 }  // namespace mppo
@@ -954,6 +990,13 @@ extern "C" int32_t mppo_model_open(const void* host_blob, size_t nbytes, const v
   *out = m;
   return MPPO_OK;
 }
+
+#ifdef MPPO_PHYS_TIMERS
+extern "C" int32_t mppo_debug_phys_timers(unsigned long long* out40) {
+  MPPO_CHECK_HIP(hipMemcpyFromSymbol(out40, HIP_SYMBOL(mppo::g_phys_t), sizeof(unsigned long long) * 40));
+  return MPPO_OK;
+}
+#endif
 
 extern "C" int32_t mppo_model_close(mppo_model_t* m) {
   delete m;
