@@ -24,6 +24,15 @@
 
 namespace mppo {
 
+// Phase timers (profiling builds only, -DMPPO_FUSED_TIMERS: tools/fused_phases.py): wave 0 of the first training workgroup stamps
+// s_memtime at the phase boundaries into a device array that mppo_debug_fused_timers() copies out.
+#ifdef MPPO_FUSED_TIMERS
+__device__ unsigned long long g_fused_t[24 + 64];
+#define FT(k) do { if (!ROLLOUT && blockIdx.x == 40 && blockIdx.y == 0 && threadIdx.x == 0) g_fused_t[k] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define FT(k) do { } while (0)
+#endif
+
 constexpr float kLog2PiF = 1.8378770664093453f;
 constexpr int FRT = 16;  // rows per workgroup
 #ifndef MPPO_ROLLOUT_WAVES
@@ -171,6 +180,7 @@ __device__ __forceinline__ float row32_sum(float x) {
 template <bool BF16, bool ROLLOUT, int OT>
 __global__ void __launch_bounds__(512, ROLLOUT ? MPPO_ROLLOUT_WAVES : 2) fused_mlp_kernel(FusedArgs a) {
   constexpr int SD = 16 * OT;  // row stride of the per-row output-space tiles
+  FT(0);
   MPPO_DYN_SMEM(smem_raw);
   float* sm = reinterpret_cast<float*>(smem_raw);
   const int H = a.H, O = a.O, OP = a.OP, A = a.A, AP = a.AP;
@@ -231,39 +241,69 @@ __global__ void __launch_bounds__(512, ROLLOUT ? MPPO_ROLLOUT_WAVES : 2) fused_m
       w3q[m][1] = ai < nout ? W3[(c0 + 1) * nout + ai] : 0.f;
     }
   }
-  long prow[4];
-  float pf0[OT][4], pf1[4], pf2[4];  // actor: action[o], old log_prob, advantage | critic: old value, target, -  (rollout: noise[o])
+  FT(1);
+  // ---- the index -> row chain.  Everything gathered by permutation index costs two dependent trips to memory (the index,
+  // then what it points at).  All indices this thread needs - its four loss rows and the two rows whose observation chunks
+  // it stages - are requested FIRST and together, then everything that depends on them in one batch; every load is
+  // unconditional on a clamped address and masked afterwards (straight-line code: the compiler cannot hoist a load over a
+  // branch, and round 1's per-row `if (on)` blocks serialised into eight consecutive memory latencies before the first MFMA).
+  const int nx = FRT * (KP / 4);                 // float4 chunks of the x tile
+  const int e0 = t, e1 = t + nthr;                // this thread's chunks (nthr >= nx / 2 for every supported H: checked on the host)
+  const int xr0 = e0 / (KP / 4), xc0 = (e0 % (KP / 4)) * 4, xr1 = (e1 < nx ? e1 : e0) / (KP / 4), xc1 = ((e1 < nx ? e1 : e0) % (KP / 4)) * 4;
+  const int gi0 = row0 + xr0 < a.mb ? row0 + xr0 : a.mb - 1, gi1 = row0 + xr1 < a.mb ? row0 + xr1 : a.mb - 1;
+  const bool gather = !ROLLOUT && a.idx && !(a.skip & 64);
+  long prow[4], xrow0 = gi0, xrow1 = gi1;
+  bool pon[4];
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     const int i = row0 + 4 * rq + r;
-    const bool on = i < a.mb;
-    prow[r] = on ? ((a.idx && !ROLLOUT) ? (long)a.idx[i] : (long)i) : 0;
+    pon[r] = i < a.mb;
+    const int ic = pon[r] ? i : a.mb - 1;
+    prow[r] = gather ? (long)a.idx[ic] : (long)ic;
+  }
+  if (gather) { xrow0 = a.idx[gi0]; xrow1 = a.idx[gi1]; }
+  // dependent batch: the observation chunks (needed first), then the per-row scalars of the loss (needed four phases later)
+  float4 xq0 = make_float4(0.f, 0.f, 0.f, 0.f), xq1 = xq0;
+  if (e0 < nx && xc0 < OP) xq0 = *reinterpret_cast<const float4*>(a.b.obs + xrow0 * a.b.obs_ld + xc0);
+  if (e1 < nx && xc1 < OP) xq1 = *reinterpret_cast<const float4*>(a.b.obs + xrow1 * a.b.obs_ld + xc1);
+  float pf0[OT][4], pf1[4], pf2[4];  // actor: action[o], old log_prob, advantage | critic: old value, target, -  (rollout: noise[o])
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
     pf1[r] = pf2[r] = 0.f;
 #pragma unroll
     for (int ot = 0; ot < OT; ++ot) pf0[ot][r] = 0.f;
     if (ROLLOUT) {
+      if (net == 0 && a.noise) {
 #pragma unroll
-      for (int ot = 0; ot < OT; ++ot)
-        if (on && net == 0 && cj + 16 * ot < A && a.noise) pf0[ot][r] = a.noise[(size_t)i * A + cj + 16 * ot];
-    } else if (on) {
-      if (net == 0) {
-#pragma unroll
-        for (int ot = 0; ot < OT; ++ot)
-          if (cj + 16 * ot < A) pf0[ot][r] = a.b.action[prow[r] * a.b.act_ld + cj + 16 * ot];
-        pf1[r] = a.b.log_prob[prow[r]];
-        pf2[r] = a.b.adv[prow[r]];
-      } else {
-        pf0[0][r] = a.b.value[prow[r]];
-        pf1[r] = a.b.target[prow[r]];
+        for (int ot = 0; ot < OT; ++ot) {
+          const int o = cj + 16 * ot;
+          const float v = a.noise[(size_t)prow[r] * A + (o < A ? o : A - 1)];
+          pf0[ot][r] = (pon[r] && o < A) ? v : 0.f;
+        }
       }
+    } else if (net == 0) {
+#pragma unroll
+      for (int ot = 0; ot < OT; ++ot) {
+        const int o = cj + 16 * ot;
+        const float v = a.b.action[prow[r] * a.b.act_ld + (o < A ? o : A - 1)];
+        pf0[ot][r] = (pon[r] && o < A) ? v : 0.f;
+      }
+      const float lp = a.b.log_prob[prow[r]], ad = a.b.adv[prow[r]];
+      pf1[r] = pon[r] ? lp : 0.f; pf2[r] = pon[r] ? ad : 0.f;
+    } else {
+      const float ov = a.b.value[prow[r]], tg = a.b.target[prow[r]];
+      pf0[0][r] = pon[r] ? ov : 0.f; pf1[r] = pon[r] ? tg : 0.f;
     }
   }
 
-  // ---- P0: gathered observation rows -> LDS (zero-padded to KP columns); the actor workgroup also writes xmb ----
-  for (int e = t; e < FRT * (KP / 4); e += nthr) {
+  FT(2);
+  // ---- P0: gathered observation rows -> LDS (zero-padded to KP columns) ----
+  if (e0 < nx) *reinterpret_cast<float4*>(xt + xr0 * XS + xc0) = xq0;
+  if (e1 < nx) *reinterpret_cast<float4*>(xt + xr1 * XS + xc1) = xq1;
+  for (int e = t + 2 * nthr; e < nx; e += nthr) {  // (only for widths with more than two chunks per thread)
     const int r = e / (KP / 4), c4 = (e % (KP / 4)) * 4;
     const int gi = row0 + r < a.mb ? row0 + r : a.mb - 1;
-    const long row = (!ROLLOUT && a.idx && !(a.skip & 64)) ? a.idx[gi] : gi;
+    const long row = gather ? a.idx[gi] : gi;
     float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
     if (c4 < OP) q = *reinterpret_cast<const float4*>(a.b.obs + row * a.b.obs_ld + c4);
     *reinterpret_cast<float4*>(xt + r * XS + c4) = q;
@@ -280,12 +320,16 @@ __global__ void __launch_bounds__(512, ROLLOUT ? MPPO_ROLLOUT_WAVES : 2) fused_m
     }
   }
 
+  FT(3);
   // ---- P1 / P2: hidden layers ----
   GemmPipe<false> pipe2;
   GemmPipe<true> pipe5;
   for (int layer = 0; layer < 2; ++layer) {
     f32x4 acc0, acc1;
     for (int r = 0; r < 4; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
+#ifdef MPPO_FUSED_TIMERS
+    if (!ROLLOUT && blockIdx.x == 40 && blockIdx.y == 0 && lane == 0) g_fused_t[24 + 16 * layer + wave] = __builtin_amdgcn_s_memtime();
+#endif
     if (layer == 0) {
       if (!(a.skip & 1)) pipe1.template run<BF16>(xt, XS, KP, W1, H, n0, lane, acc0, acc1);
       if (!ROLLOUT) pipe2.prefetch(H, H, W2, H, n0, lane);  // arrives during the epilogue + barrier below
@@ -295,6 +339,10 @@ __global__ void __launch_bounds__(512, ROLLOUT ? MPPO_ROLLOUT_WAVES : 2) fused_m
       if (!(a.skip & 2)) pipe2.template run<BF16>(h1t, HS, H, W2, H, n0, lane, acc0, acc1);
       if (!ROLLOUT) pipe5.prefetch(H, H, W2, H, n0, lane);  // W2^T fragments of the backward product: hidden under heads / loss / dZ2
     }
+    FT(4 + 2 * layer);
+#ifdef MPPO_FUSED_TIMERS
+    if (!ROLLOUT && blockIdx.x == 40 && blockIdx.y == 0 && lane == 0) g_fused_t[24 + 16 * layer + 8 + wave] = __builtin_amdgcn_s_memtime();
+#endif
     float* ht = layer == 0 ? h1t : h2t;
     float* hg = layer == 0 ? a.h1[net] : a.h2[net];
     const int c0 = n0 + 2 * cj;  // the wave's two interleaved column tiles: c0, c0 + 1
@@ -315,8 +363,10 @@ __global__ void __launch_bounds__(512, ROLLOUT ? MPPO_ROLLOUT_WAVES : 2) fused_m
       stream_store(dst + 4, make_float4(q1[0], q1[1], q1[2], q1[3]));
     }
     __syncthreads();
+    FT(5 + 2 * layer);
   }
 
+  FT(8);
   // ---- P3: output layer on the matrix cores: OT 16x16 tiles (rows x outputs), K = H split over the waves ----
   // wave w multiplies h2[:, 32w .. 32w+32) by W3[32w .. 32w+32, :]; the H/32 partial tiles are summed through LDS.
   {
@@ -341,6 +391,7 @@ __global__ void __launch_bounds__(512, ROLLOUT ? MPPO_ROLLOUT_WAVES : 2) fused_m
       *reinterpret_cast<float4*>(s_hp + ((wave * OT + ot) * 64 + lane) * 4) = make_float4(hp[ot][0], hp[ot][1], hp[ot][2], hp[ot][3]);
   }
   __syncthreads();
+  FT(9);
   {
     // every wave adds the partial tiles (same order: identical values everywhere); lane (cj = lane&15, q = lane>>4) holds
     // out[ot][r] = output cj + 16*ot of row 4q + r.  A DPP row of 16 lanes therefore spans all outputs of a row: row
@@ -470,6 +521,7 @@ __global__ void __launch_bounds__(512, ROLLOUT ? MPPO_ROLLOUT_WAVES : 2) fused_m
     }
   }
   __syncthreads();
+  FT(10);
   // per-workgroup partial sums: partial[blockIdx.x][4+AP]: col 0 actor loss, col 1 value loss, 4+a d log_std[a]
   {
     float* prow_out = a.partial + (size_t)blockIdx.x * (4 + AP);
@@ -480,6 +532,7 @@ __global__ void __launch_bounds__(512, ROLLOUT ? MPPO_ROLLOUT_WAVES : 2) fused_m
       float s = 0.f; for (int r = 0; r < FRT; ++r) s += s_l[r]; prow_out[1] = s;
     }
   }
+  FT(11);
   // ---- P4: dZ2 = (dOut . W3^T) * act'(h2) on the matrix cores (K = outputs padded to 16*OT) -> LDS (over the dead x tile) + global ----
   float* dzt = xt;
   {
@@ -512,11 +565,13 @@ __global__ void __launch_bounds__(512, ROLLOUT ? MPPO_ROLLOUT_WAVES : 2) fused_m
     }
   }
   __syncthreads();
+  FT(12);
   // ---- P5: dZ1 = (dZ2 . W2^T) * act'(h1) ----
   {
     f32x4 acc0, acc1;
     for (int r = 0; r < 4; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
     if (!(a.skip & 16)) pipe5.template run<BF16>(dzt, HS, H, W2, H, n0, lane, acc0, acc1);
+    FT(13);
     const int c0 = n0 + 2 * cj;
     float q0[4], q1[4];
 #pragma unroll
@@ -532,7 +587,17 @@ __global__ void __launch_bounds__(512, ROLLOUT ? MPPO_ROLLOUT_WAVES : 2) fused_m
     stream_store(dst, make_float4(q0[0], q0[1], q0[2], q0[3]));
     stream_store(dst + 4, make_float4(q1[0], q1[1], q1[2], q1[3]));
   }
+  FT(14);
 }
+
+#ifdef MPPO_FUSED_TIMERS
+}  // namespace mppo
+extern "C" int32_t mppo_debug_fused_timers(unsigned long long* out24) {
+  MPPO_CHECK_HIP(hipMemcpyFromSymbol(out24, HIP_SYMBOL(mppo::g_fused_t), sizeof(unsigned long long) * (24 + 64)));
+  return MPPO_OK;
+}
+namespace mppo {
+#endif
 
 size_t fused_smem_bytes(int O, int A, int H) {
   const int KP = (O + 31) & ~31, XS = KP + 4, HS = H + 4, OT = A > 16 ? 2 : 1;

@@ -2,7 +2,7 @@
 # where does wgrad_kernel's time go: rocprofv3 average per launch for a set of MPPO_WGRAD_DBG / MPPO_KSPLIT settings
 cd "$GRAFT_REPO_ROOT" || exit 1
 export TMPDIR=/tmp
-for cfg in "0 8" "8 8"; do
+for cfg in "0 8"; do
   set -- $cfg
   rm -rf /tmp/wg_prof; cd /tmp
   MPPO_WGRAD_DBG=$1 MPPO_KSPLIT=$2 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/wg_prof -- python3 $GRAFT_REPO_ROOT/tools/kernel_probe.py learn 1 > /dev/null 2>&1
