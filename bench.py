@@ -335,10 +335,13 @@ def main() -> None:
             baseline_cfg = "BASELINE configs[3]" if args.config == "stompy_pro" else baseline_cfg + ", bf16 MFMA"
         peak = PEAK_BF16_MFMA_TFLOPS if bf16 else PEAK_F32_MFMA_TFLOPS
         traffic, traffic_src = None, None
-        tf = ROOT / "profiles" / "r01_f_hbm_traffic.json"
-        if tf.exists() and args.config == "stompy_pro" and args.envs_per_gpu == 4096 and not bf16:
-            traffic = json.loads(tf.read_text())["kernels"]["fused_mlp_kernel<false, false, 1>"]["hbm_bytes_per_launch"]
-            traffic_src = "profiles/r01_f_hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, corrected)"
+        tfs = sorted((ROOT / "profiles").glob("r*_hbm_traffic.json"))  # the newest committed counter summary
+        if tfs and args.config == "stompy_pro" and args.envs_per_gpu == 4096 and not bf16:
+            k = json.loads(tfs[-1].read_text())["kernels"]
+            key = next((n for n in k if n.endswith("fused_mlp_kernel<false, false, 1>")), None)
+            if key:
+                traffic = k[key]["hbm_bytes_per_launch"]
+                traffic_src = f"profiles/{tfs[-1].name} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, gfx950 corrections)"
         out = {
             "metric": ("env-steps/sec (whole node), stompy_pro 4096 envs, 1/2/4/8 MI355X" if args.config == "stompy_pro" and args.envs_per_gpu == 4096
                        else f"env-steps/sec (whole node), {args.config} {args.envs_per_gpu} envs per GPU, {world} MI355X"),

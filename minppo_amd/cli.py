@@ -19,9 +19,8 @@ def main() -> None:
 
         env_main(other_args)
     elif args.command == "infer":
-        from minppo_amd.infer import main as infer_main
-
-        infer_main(other_args)
+        # the reference's `minppo infer` is a stub as well (`minppo/infer.py:22-27` raises NotImplementedError)
+        raise NotImplementedError("Inference is not implemented yet (as in the reference)")
     else:
         raise ValueError(f"Invalid command: {args.command}")
 

@@ -18,9 +18,9 @@ Subset
   <worldbody>: one <geom type="plane"> (the ground), <body name pos quat|euler|axisangle|xyaxes|zaxis childclass>
       <inertial pos quat|euler mass diaginertia|fullinertia>
       <freejoint/> | <joint type="free|hinge|slide" name pos axis range limited ref damping armature stiffness>
-      <geom type="sphere|capsule" size pos quat|euler fromto friction mass density contype conaffinity>
-            (type="box|cylinder|ellipsoid|mesh" geoms are accepted ONLY with contype="0" conaffinity="0", i.e. visual or
-             inertia-only; box / cylinder / ellipsoid then still contribute to inertiafromgeom)
+      <geom type="sphere|capsule|box" size pos quat|euler fromto friction mass density contype conaffinity>
+            (a box collides with the ground through its eight corners; type="cylinder|ellipsoid|mesh" geoms are accepted ONLY with
+             contype="0" conaffinity="0", i.e. visual or inertia-only; cylinder / ellipsoid then still contribute to inertiafromgeom)
   <actuator>: <position joint kp kv gear ctrlrange forcerange>, <motor joint gear ctrlrange forcerange>
 Contacts: geom-vs-ground-plane only (what the stand-in robots need); robot self-collision pairs are not generated, a
 warning says so when the MJCF's contype / conaffinity masks would enable them.
@@ -36,7 +36,7 @@ from typing import Dict, List, Optional, Sequence, Tuple
 
 import numpy as np
 
-from minppo_amd.model import (GEOM_CAPSULE, GEOM_SPHERE, JNT_FREE, JNT_HINGE, JNT_SLIDE, ActuatorSpec, BodySpec, GeomSpec, JointSpec, ModelSpec, _normalize, _qmat,
+from minppo_amd.model import (GEOM_BOX, GEOM_CAPSULE, GEOM_SPHERE, JNT_FREE, JNT_HINGE, JNT_SLIDE, ActuatorSpec, BodySpec, GeomSpec, JointSpec, ModelSpec, _normalize, _qmat,
                               _qmul)
 
 logger = logging.getLogger(__name__)
@@ -336,8 +336,8 @@ def parse_mjcf(xml: str, name: str = "mjcf") -> ModelSpec:
         part = (m, diag, pos, quat)
         if not collides:
             return "inert", None, part
-        if gtype not in ("sphere", "capsule"):
-            raise ValueError(f"{what}: only sphere and capsule geoms can collide (a colliding {gtype} needs contype='0' conaffinity='0' or a capsule approximation)")
+        if gtype not in ("sphere", "capsule", "box"):
+            raise ValueError(f"{what}: only sphere, capsule and box geoms can collide (a colliding {gtype} needs contype='0' conaffinity='0' or a capsule approximation)")
         for k in ("solref", "solimp"):
             if k in a:
                 solrefs["contact"].add((k, tuple(_floats(a[k]))))
@@ -347,7 +347,7 @@ def parse_mjcf(xml: str, name: str = "mjcf") -> ModelSpec:
             raise ValueError(f"{what}: condim {a['condim']} (only 3: pyramidal sliding friction)")
         self_collision_masks.append((contype, conaff))
         fr = tuple((_floats(a["friction"]) + [0.005, 0.0001])[:3]) if "friction" in a else (1.0, 0.005, 0.0001)
-        gs = GeomSpec(GEOM_SPHERE if gtype == "sphere" else GEOM_CAPSULE, tuple(size[:need]), pos=tuple(pos), quat=tuple(quat), friction=fr)
+        gs = GeomSpec({"sphere": GEOM_SPHERE, "capsule": GEOM_CAPSULE, "box": GEOM_BOX}[gtype], tuple(size[:need]), pos=tuple(pos), quat=tuple(quat), friction=fr)
         return "collide", gs, part
 
     def walk(el: ET.Element, parent: str, childclass: Optional[str]) -> None:
@@ -574,7 +574,7 @@ def to_mjcf(spec: ModelSpec) -> str:
                 a["range"] = _fmt(j.range)
             ET.SubElement(e, "joint", **a)
         for g in b.geoms:
-            ET.SubElement(e, "geom", type="sphere" if g.type == GEOM_SPHERE else "capsule", size=_fmt(g.size), pos=_fmt(g.pos), quat=_fmt(g.quat), friction=_fmt(g.friction))
+            ET.SubElement(e, "geom", type={GEOM_SPHERE: "sphere", GEOM_CAPSULE: "capsule", GEOM_BOX: "box"}[g.type], size=_fmt(g.size), pos=_fmt(g.pos), quat=_fmt(g.quat), friction=_fmt(g.friction))
     act = ET.SubElement(root, "actuator")
     for a in spec.actuators:
         kw = dict(joint=a.joint, gear=repr(float(a.gear)))

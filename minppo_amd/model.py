@@ -32,7 +32,7 @@ from typing import Dict, List, Optional, Sequence, Tuple
 import numpy as np
 
 JNT_FREE, JNT_HINGE, JNT_SLIDE = 0, 2, 3  # (ball=1 unsupported)
-GEOM_SPHERE, GEOM_CAPSULE = 2, 3
+GEOM_SPHERE, GEOM_CAPSULE, GEOM_BOX = 2, 3, 6  # MuJoCo's mjtGeom numbering
 
 MJ_MINVAL = 1e-15
 
@@ -391,7 +391,7 @@ def compile_model(spec: ModelSpec) -> CompiledModel:
             act_forcerange[ai] = a.forcerange
             act_forcelimited[ai] = 1
 
-    # collision candidates: every sphere / capsule end against the ground plane
+    # collision candidates: every sphere / capsule end / box corner against the ground plane
     con_bodyid, con_lpos, con_radius, con_friction = [], [], [], []
     for (gt, bi, gpos, gquat, gsize, gfri) in geoms:
         fri = np.maximum(np.asarray(gfri), np.asarray(spec.plane_friction))
@@ -400,12 +400,17 @@ def compile_model(spec: ModelSpec) -> CompiledModel:
         elif gt == GEOM_CAPSULE:
             axis = _qrot(gquat, [0, 0, 1.0]) * gsize[1]
             ends = [np.asarray(gpos) + axis, np.asarray(gpos) - axis]
+        elif gt == GEOM_BOX:
+            # a box against the ground plane touches with its corners: eight point contacts (radius 0).  MuJoCo's plane-box
+            # routine reports at most four of them per step - the same set whenever no more than four corners penetrate,
+            # which is every pose of a box that is not sunk to its middle.
+            ends = [np.asarray(gpos) + _qrot(gquat, [sx * gsize[0], sy * gsize[1], sz * gsize[2]]) for sx in (-1.0, 1.0) for sy in (-1.0, 1.0) for sz in (-1.0, 1.0)]
         else:
             raise ValueError(f"unsupported geom type {gt}")
         for e in ends:
             con_bodyid.append(bi)
             con_lpos.append(list(e))
-            con_radius.append(gsize[0])
+            con_radius.append(0.0 if gt == GEOM_BOX else gsize[0])
             con_friction.append(list(fri))
     ncon = len(con_bodyid)
 
@@ -783,6 +788,15 @@ def synth_ball() -> ModelSpec:
     return ModelSpec(name="synth_ball", bodies=bodies, actuators=[], free_root_z=0.5)
 
 
+def synth_brick() -> ModelSpec:
+    """A free box above the plane, tilted: the box collider's corner contacts (landing on one corner, then an edge, then a face)."""
+    bodies = [
+        BodySpec("brick", "world", quat=(0.9659258, 0.1830127, 0.1830127, 0.0), mass=1.2, inertia=(0.0013, 0.0044, 0.0055),
+                 joints=[JointSpec("root", JNT_FREE)], geoms=[GeomSpec(GEOM_BOX, (0.10, 0.05, 0.02))]),
+    ]
+    return ModelSpec(name="synth_brick", bodies=bodies, actuators=[], free_root_z=0.12)
+
+
 KSCALE_ID_TABLE = {
     "5eb3cb7f23232298": "synth_stompy_pro",  # reference configs/stompy_pro.yaml:1
 }
@@ -792,6 +806,7 @@ BUILTIN_MODELS = {
     "synth_stompy_full": synth_stompy_full,
     "synth_pendulum": synth_pendulum,
     "synth_ball": synth_ball,
+    "synth_brick": synth_brick,
 }
 
 _CACHE: Dict[str, CompiledModel] = {}

@@ -10,15 +10,10 @@ from minppo_amd.config import make_config
 BASE = {"kscale_id": "5eb3cb7f23232298", "visualization": {"camera_name": "track"}}
 
 
-def test_infer_and_cli_follow_the_reference(tmp_path, monkeypatch):
-    from minppo_amd import cli, infer
+def test_cli_follows_the_reference(tmp_path, monkeypatch):
+    """`minppo {train,env,infer}` (reference cli.py:12-26); `infer` is a stub upstream too (infer.py:22-27)."""
+    from minppo_amd import cli
 
-    p = tmp_path / "m.pkl"
-    with open(p, "wb") as f:
-        pickle.dump({"params": {"log_std": np.zeros(3)}}, f)
-    assert set(infer.load_model(str(p))) == {"params"}
-    with pytest.raises(NotImplementedError):
-        infer.main([])
     monkeypatch.setattr(sys, "argv", ["minppo", "infer", "stompy_pro"])
     with pytest.raises(NotImplementedError):
         cli.main()

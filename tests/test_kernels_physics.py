@@ -81,7 +81,8 @@ def _walk(cm, N, steps, seed, scale=0.3):
 MJCF_ROBOT = str(Path(__file__).parent / "golden" / "hand_leg.xml")  # goes through minppo_amd/mjcf.py
 
 
-@pytest.mark.parametrize("model,N", [("synth_stompy_pro", 33), ("synth_stompy_full", 17), ("synth_pendulum", 3), ("synth_ball", 2), (MJCF_ROBOT, 4)])
+@pytest.mark.parametrize("model,N", [("synth_stompy_pro", 33), ("synth_stompy_full", 17), ("synth_pendulum", 3), ("synth_ball", 2), (MJCF_ROBOT, 4),
+                                     ("synth_brick", 6)])  # a free box: eight corner contacts against the ground (box geoms)
 def test_forward_matches_oracle(be, model, N):
     cm = load_model(model)
     h, dims, _keep = be.model(cm)
@@ -183,6 +184,38 @@ def test_solver_is_tight_where_the_active_set_is_stable(be, model, state, med, q
     c_got, c_ref = _cost(ref, got["qacc"]), _cost(ref, ref.qacc)
     assert np.all(c_got <= 2.0 * c_ref + 1e-3), (c_got / (c_ref + 1e-9)).max()
     assert np.median(np.abs(c_got - c_ref) / (c_ref + 1e-3)) <= 1e-4
+    be.lib.model_close(h)
+
+
+@pytest.mark.parametrize("steps,min_rows,med", [(60, 4, 5e-3), (300, 16, 1e-3)])
+def test_box_collider_corner_contacts(be, steps, min_rows, med):
+    """SURVEY 8(f1) box geoms: a free brick dropped tilted.  After 60 steps it stands on one corner (one contact = four pyramid
+    rows), after 300 it rests on a face (four corners = sixteen rows).  From the oracle's state at that moment the kernel's
+    constraint rows, reference accelerations and solver result are compared as in test_forward_matches_oracle; the resting
+    case is a stable active set (tight bound)."""
+    cm = load_model("synth_brick")
+    assert cm.ncon == 8 and cm.nefc == 32  # eight corners x four pyramid rows
+    h, dims, _keep = be.model(cm)
+    N = 5
+    ph = Physics(cm.t)
+    rng = np.random.default_rng(3)
+    q0 = np.tile(cm.t["qpos0"], (N, 1))
+    q0[:, :2] += 0.01 * rng.standard_normal((N, 2))
+    d = ph.pipeline_init(q0, 0.05 * rng.standard_normal((N, cm.nv)))
+    for _ in range(steps):
+        d = ph.pipeline_step(d, np.zeros((N, 0)))
+    q32 = [x.astype(f32) for x in (d.qpos, d.qvel, np.zeros((N, 1)), d.qacc_warmstart)]
+    ref = PhysState(qpos=q32[0].astype(np.float64), qvel=q32[1].astype(np.float64), ctrl=np.zeros((N, 0)), qacc_warmstart=q32[3].astype(np.float64), time=np.zeros(N))
+    ph.forward(ref)
+    assert ((ref.efc_D > 0).sum(1) >= min_rows).all(), (ref.efc_D > 0).sum(1)
+    got = _probe(be, h, cm, *q32)
+    for k, t in dict(qM=1e-5, efc_J=1e-5, efc_D=5e-4, efc_aref=5e-4, xpos=1e-5).items():
+        r = ref[k]
+        assert np.abs(got[k].reshape(r.shape) - r).max() <= t * (np.abs(r).max() + 1e-6), k
+    rel = np.abs(got["qacc"] - ref.qacc).max(1) / (np.abs(ref.qacc).max(1) + np.abs(ref.qacc_smooth).max(1))
+    assert np.median(rel) <= med and rel.max() <= 0.3, (np.median(rel), rel.max())
+    c_got, c_ref = _cost(ref, got["qacc"]), _cost(ref, ref.qacc)
+    np.testing.assert_allclose(c_got, c_ref, rtol=5e-2, atol=1e-3)
     be.lib.model_close(h)
 
 

@@ -110,7 +110,7 @@ def test_frictionloss_is_stripped_only_where_the_reference_strips_it():
 
 @pytest.mark.parametrize("old,new,msg", [
     ('<actuator>', '<equality/><actuator>', "equality"),
-    ('type="sphere" size="0.1"', 'type="box" size="0.1 0.1 0.1"', "only sphere and capsule geoms can collide"),
+    ('type="sphere" size="0.1"', 'type="cylinder" size="0.1 0.1"', "only sphere, capsule and box geoms can collide"),
     ('<joint name="knee" axis="0 1 0"/>', '<joint name="knee" type="ball"/>', "joint type"),
     ('<position joint="hip"/>', '<position tendon="t"/>', "joint transmissions"),
     ('<position joint="hip"/>', '<position joint="nope"/>', "unknown joint"),
@@ -137,3 +137,28 @@ def test_load_model_accepts_an_xml_path_and_the_oracle_can_step_it(tmp_path):
         d = ph.pipeline_step(d, np.zeros((3, cm.nu)))
     assert np.isfinite(d["qpos"]).all() and np.isfinite(d["qvel"]).all()
     assert (d["qpos"][:, 2] < 0.75).all()  # it falls
+
+
+def test_box_geom_collides_through_its_eight_corners(tmp_path):
+    """box geoms.  A colliding <geom type="box"> becomes eight point contacts (its corners, in the body frame,
+    geom pose applied) against the ground plane; it survives the writer / parser round trip."""
+    import numpy as np
+
+    from minppo_amd import mjcf
+    from minppo_amd.model import compile_model
+
+    xml = """<mujoco model="brick"><option timestep="0.002"/><worldbody><geom type="plane" size="0 0 1"/>
+      <body name="brick" pos="0 0 0.3"><freejoint name="root"/><inertial pos="0 0 0" mass="1.2" diaginertia="0.0013 0.0044 0.0055"/>
+        <geom type="box" size="0.10 0.05 0.02" pos="0.01 0 0" friction="0.8 0.005 0.0001"/></body></worldbody></mujoco>"""
+    p = tmp_path / "brick.xml"
+    p.write_text(xml)
+    spec = mjcf.load_mjcf(str(p))
+    cm = compile_model(spec)
+    assert cm.ncon == 8 and cm.nefc == 32 and (np.asarray(cm.t["con_radius"]) == 0).all()
+    corners = np.asarray(cm.t["con_lpos"]).reshape(8, 3)
+    want = {(0.01 + sx * 0.10, sy * 0.05, sz * 0.02) for sx in (-1, 1) for sy in (-1, 1) for sz in (-1, 1)}
+    assert {tuple(np.round(c, 9)) for c in corners} == {tuple(np.round(w, 9)) for w in want}
+    p2 = tmp_path / "brick2.xml"
+    p2.write_text(mjcf.to_mjcf(spec))
+    cm2 = compile_model(mjcf.load_mjcf(str(p2)))
+    assert cm2.to_blob() == cm.to_blob()
