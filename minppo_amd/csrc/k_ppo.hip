@@ -355,14 +355,33 @@ __global__ void __launch_bounds__(256) adam_kernel(size_t P, float* __restrict__
   if (c.anneal) lr = c.lr * (1.f - (float)(count / c.sched_div) / (float)c.num_updates);
   const float t = (float)(count + 1);
   const float bc1 = 1.f - powf(c.b1, t), bc2 = 1.f - powf(c.b2, t);
-  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= P) return;
-  const float gi = g[i] * scale;
-  const float mi = c.b1 * m[i] + (1.f - c.b1) * gi;
-  const float vi = c.b2 * v[i] + (1.f - c.b2) * gi * gi;
-  stream_store(m + i, mi);  // the moments are next read by the next step's Adam, three kernels and ~60 MB of traffic later
-  stream_store(v + i, vi);
-  p[i] = p[i] - lr * (mi / bc1) / (sqrtf(vi / bc2) + c.eps);
+  // four parameters per thread (the flat layout is a whole number of float4: ppo_layout.h): a quarter of the workgroups to dispatch
+  const size_t i4 = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (4 * i4 >= P) return;
+  if (4 * i4 + 3 < P) {
+    const float4 gq = reinterpret_cast<const float4*>(g)[i4], mq = reinterpret_cast<const float4*>(m)[i4], vq = reinterpret_cast<const float4*>(v)[i4];
+    float4 pq = reinterpret_cast<float4*>(p)[i4];
+    const float gs[4] = {gq.x * scale, gq.y * scale, gq.z * scale, gq.w * scale};
+    const float mo[4] = {mq.x, mq.y, mq.z, mq.w}, vo[4] = {vq.x, vq.y, vq.z, vq.w};
+    float pn[4] = {pq.x, pq.y, pq.z, pq.w}, mn[4], vn[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      mn[k] = c.b1 * mo[k] + (1.f - c.b1) * gs[k];
+      vn[k] = c.b2 * vo[k] + (1.f - c.b2) * gs[k] * gs[k];
+      pn[k] = pn[k] - lr * (mn[k] / bc1) / (sqrtf(vn[k] / bc2) + c.eps);
+    }
+    stream_store(m + 4 * i4, make_float4(mn[0], mn[1], mn[2], mn[3]));  // the moments are next read by the next step's Adam, two kernels and ~40 MB of traffic later
+    stream_store(v + 4 * i4, make_float4(vn[0], vn[1], vn[2], vn[3]));
+    reinterpret_cast<float4*>(p)[i4] = make_float4(pn[0], pn[1], pn[2], pn[3]);
+  } else {
+    for (size_t i = 4 * i4; i < P; ++i) {
+      const float gi = g[i] * scale;
+      const float mi = c.b1 * m[i] + (1.f - c.b1) * gi;
+      const float vi = c.b2 * v[i] + (1.f - c.b2) * gi * gi;
+      m[i] = mi; v[i] = vi;
+      p[i] = p[i] - lr * (mi / bc1) / (sqrtf(vi / bc2) + c.eps);
+    }
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -570,7 +589,9 @@ int32_t clip_adam(size_t P, float* params, float* m, float* v, const float* grad
     hipLaunchKernelGGL(sumsq_kernel, dim3(kNormBlocks), dim3(256), 0, stream, P, grad, ws);
     MPPO_CHECK_LAUNCH("sumsq_kernel");
   }
-  hipLaunchKernelGGL(adam_kernel, dim3(cdiv((long)P, 256)), dim3(256), 0, stream, P, params, m, v, grad, ws, count_base, step_offset, cfg);
+  MPPO_REQUIRE((reinterpret_cast<uintptr_t>(params) & 15) == 0 && (reinterpret_cast<uintptr_t>(m) & 15) == 0 && (reinterpret_cast<uintptr_t>(v) & 15) == 0 &&
+                   (reinterpret_cast<uintptr_t>(grad) & 15) == 0, "clip_adam: params / m / v / grad must be 16-byte aligned");
+  hipLaunchKernelGGL(adam_kernel, dim3(cdiv((long)((P + 3) / 4), 256)), dim3(256), 0, stream, P, params, m, v, grad, ws, count_base, step_offset, cfg);
   MPPO_CHECK_LAUNCH("adam_kernel");
   return MPPO_OK;
 }
