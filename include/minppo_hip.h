@@ -218,6 +218,16 @@ int32_t mppo_normal_fill(uint64_t seed, uint64_t stream_id, size_t n, float* out
 size_t mppo_permutation_ws_bytes(int32_t B);
 int32_t mppo_permutation(uint64_t seed, uint64_t stream_id, int32_t B, int32_t* idx, void* ws, size_t ws_bytes,
                          void* stream);
+/* jax.random-compatible streams (threefry2x32, conventions of jax 0.4.3x; host restatement: minppo_amd/jaxrng.py).
+ * key2 / rng2 / *_keys are DEVICE pointers to uint32 pairs.
+ *   mppo_threefry_normal      jax.random.normal(key, (n,))  (what `pi.sample(seed=key)` draws, train.py:158-159)
+ *   mppo_threefry_bits        jax.random.bits(key, (n,))
+ *   mppo_threefry_update_keys the split tree of one _update_step: rng2 (in/out), act_keys [T][2], sort_keys [E][rounds][2]
+ *   mppo_threefry_permutation jax.random.permutation(key, B) given its `rounds` sort keys (ws as for mppo_permutation) */
+int32_t mppo_threefry_normal(const uint32_t* key2, size_t n, float* out, void* stream);
+int32_t mppo_threefry_bits(const uint32_t* key2, size_t n, uint32_t* out, void* stream);
+int32_t mppo_threefry_update_keys(uint32_t* rng2, int32_t T, int32_t E, int32_t rounds, uint32_t* act_keys, uint32_t* sort_keys, void* stream);
+int32_t mppo_threefry_permutation(const uint32_t* sort_keys, int32_t rounds, int32_t B, int32_t* idx, void* ws, size_t ws_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Engine: the whole `_update_step` (train.py:146-283) as one call, launches enqueued from
@@ -241,6 +251,9 @@ typedef struct mppo_engine_cfg {
   uint64_t seed;
   int32_t use_graph;         /* capture the update in a hipGraph and replay it      */
   int32_t external_random;   /* 1: noise / permutations are written by the caller into the arena (parity tests) */
+  int32_t rng_impl;          /* 0: the engine's Philox streams; 1: jax.random-compatible threefry2x32 streams following the
+                              * reference's split tree (train.py:158,163,252,258); the carried key is arena region "jax_rng" */
+  int32_t reserved0;
 } mppo_engine_cfg_t;
 
 /* Arena: ONE device allocation owned by the caller (a torch uint8 tensor); the engine lays

@@ -79,7 +79,7 @@ class EngineCfg(C.Structure):
     _fields_ = [("num_envs", c_i32), ("num_steps", c_i32), ("num_minibatches", c_i32), ("update_epochs", c_i32),
                 ("n_frames", c_i32), ("num_updates", c_i32), ("world_size", c_i32), ("rank", c_i32), ("gamma", c_f),
                 ("gae_lambda", c_f), ("loss", LossCfg), ("adam", AdamCfg), ("reward", RewardCfg), ("net", Net),
-                ("seed", c_u64), ("use_graph", c_i32), ("external_random", c_i32)]
+                ("seed", c_u64), ("use_graph", c_i32), ("external_random", c_i32), ("rng_impl", c_i32), ("reserved0", c_i32)]
 
 
 P = C.POINTER
@@ -112,6 +112,10 @@ SIGNATURES = {
     "mppo_normal_fill": (c_i32, [c_u64, c_u64, c_sz, c_vp, c_vp]),
     "mppo_permutation_ws_bytes": (c_sz, [c_i32]),
     "mppo_permutation": (c_i32, [c_u64, c_u64, c_i32, c_vp, c_vp, c_sz, c_vp]),
+    "mppo_threefry_normal": (c_i32, [c_vp, c_sz, c_vp, c_vp]),
+    "mppo_threefry_bits": (c_i32, [c_vp, c_sz, c_vp, c_vp]),
+    "mppo_threefry_update_keys": (c_i32, [c_vp, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp]),
+    "mppo_threefry_permutation": (c_i32, [c_vp, c_i32, c_i32, c_vp, c_vp, c_sz, c_vp]),
     "mppo_engine_arena_bytes": (c_i32, [c_vp, P(EngineCfg), P(c_sz)]),
     "mppo_engine_create": (c_i32, [c_vp, P(EngineCfg), c_vp, c_sz, P(c_vp)]),
     "mppo_engine_destroy": (c_i32, [c_vp]),

@@ -121,6 +121,7 @@ class TrainingConfig:
     # Extension: MLP GEMM arithmetic. "f32" = exact f32 MFMA; "bf16" = bf16-in /
     # f32-accumulate MFMA (BASELINE config 4).  GAE and Adam are always f32.
     mlp_dtype: str = field(default="f32")
+    rng_impl: str = field(default="philox")  # "philox": the engine's own streams; "threefry": jax.random-compatible streams following the reference's key plumbing (minppo_amd/jaxrng.py)
     # Extension (absent upstream): full-state checkpoints.  `checkpoint_path` is written every
     # `checkpoint_every` updates (0 = only at the end, "" = never); `resume_from` restores parameters, Adam moments,
     # step counters (LR schedule + RNG stream position), environment states and episode metrics before training.

@@ -89,6 +89,8 @@ struct mppo_engine {
   float *fwd_ws, *grad_ws, *adam_ws;
   float* stat_ret_in;
   int* stat_len_in;
+  unsigned* jax_rng;  // [2] carried key | [T][2] action keys | [E][rounds][2] sort keys (rng_impl = 1)
+  int jax_rounds;
   void* perm_ws;
   size_t perm_ws_bytes;
   mppo::Comm* comm;
@@ -143,6 +145,8 @@ static size_t layout(mppo_engine* e, bool assign) {
   e->fwd_ws = (float*)take("fwd_ws", fwd_bufs_floats(net, (int)N) * 4);
   e->grad_ws = (float*)take("grad_ws", grad_bufs_floats(net, e->mb) * 4);
   e->adam_ws = (float*)take("adam_ws", mppo_adam_ws_bytes(P));
+  e->jax_rounds = threefry_rounds((int)B);
+  e->jax_rng = (unsigned*)take("jax_rng", (2 + 2 * T + 2 * (size_t)e->E * e->jax_rounds) * 4);
   e->perm_ws_bytes = mppo_permutation_ws_bytes((int)B);
   e->perm_ws = take("perm_ws", e->perm_ws_bytes);
   return align_up(off, 256);
@@ -162,6 +166,8 @@ static int32_t validate_cfg(const mppo_model* m, const mppo_engine_cfg_t* c) {
   MPPO_REQUIRE(c->net.A == mv.nu, "engine: net A = %d but the model has %d actuators", c->net.A, mv.nu);
   MPPO_REQUIRE(c->net.A >= 1 && c->net.A <= 32 && c->net.H >= 4 && c->net.H % 4 == 0, "engine: unsupported A / H");
   MPPO_REQUIRE(c->num_updates >= 1, "engine: num_updates must be >= 1 (total_timesteps too small)");
+  MPPO_REQUIRE(c->rng_impl == 0 || c->rng_impl == 1, "engine: rng_impl %d (0 philox, 1 threefry)", c->rng_impl);
+  MPPO_REQUIRE(c->rng_impl == 0 || c->world_size == 1, "engine: the threefry streams follow the reference's single-device key plumbing (world_size must be 1)");
   return MPPO_OK;
 }
 
@@ -181,8 +187,16 @@ static int32_t do_rollout(mppo_engine* e, hipStream_t s) {
   // episode bookkeeping as it stands before the rollout: carry-in of the statistics kernel at the end
   MPPO_CHECK_HIP(hipMemcpyAsync(e->stat_ret_in, e->met.episode_returns, N * 4, hipMemcpyDeviceToDevice, s));
   MPPO_CHECK_HIP(hipMemcpyAsync(e->stat_len_in, e->met.episode_lengths, N * 4, hipMemcpyDeviceToDevice, s));
-  if (!c.external_random)
-    MPPO_TRY(normal_fill_ctr(c.seed, kStreamNoise + ((unsigned long long)c.rank << 16), e->count + 1, (size_t)e->T * N * A, e->noise, s));
+  if (!c.external_random) {
+    if (c.rng_impl == 1) {
+      // the reference's key plumbing (train.py:158,163,252): this update's action keys and sort keys from the carried key,
+      // then one jax.random.normal(action_rng, (N, A)) per env step (what `pi.sample(seed=action_rng)` draws)
+      MPPO_TRY(threefry_chain(e->jax_rng, e->T, e->E, e->jax_rounds, e->jax_rng + 2, e->jax_rng + 2 + 2 * e->T, s));
+      for (int t = 0; t < e->T; ++t) MPPO_TRY(threefry_normal(e->jax_rng + 2 + 2 * t, N * A, e->noise + (size_t)t * N * A, s));
+    } else {
+      MPPO_TRY(normal_fill_ctr(c.seed, kStreamNoise + ((unsigned long long)c.rank << 16), e->count + 1, (size_t)e->T * N * A, e->noise, s));
+    }
+  }
   FwdBufs fb = carve_fwd(c.net, e->N, e->fwd_ws);
   for (int t = 0; t < e->T; ++t) {
     const float* obs_t = e->obs + (size_t)t * N * OP;
@@ -202,9 +216,14 @@ static int32_t do_learn(mppo_engine* e, hipStream_t s) {
   const mppo_engine_cfg_t& c = e->cfg;
   const int EM = e->E * e->M;
   if (!c.external_random)
-    for (int ep = 0; ep < e->E; ++ep)
-      MPPO_TRY(permutation_ctr(c.seed, kStreamPerm + ((unsigned long long)c.rank << 16) + (unsigned long long)ep, e->count + 1, e->B, e->perm + (size_t)ep * e->B,
-                               e->perm_ws, e->perm_ws_bytes, s));                                                    // train.py:258
+    for (int ep = 0; ep < e->E; ++ep) {
+      if (c.rng_impl == 1)
+        MPPO_TRY(threefry_permutation(e->jax_rng + 2 + 2 * e->T + 2 * ep * e->jax_rounds, e->jax_rounds, e->B, e->perm + (size_t)ep * e->B, e->perm_ws,
+                                      e->perm_ws_bytes, s));                                                          // train.py:258 with JAX's keys
+      else
+        MPPO_TRY(permutation_ctr(c.seed, kStreamPerm + ((unsigned long long)c.rank << 16) + (unsigned long long)ep, e->count + 1, e->B, e->perm + (size_t)ep * e->B,
+                                 e->perm_ws, e->perm_ws_bytes, s));                                                  // train.py:258
+    }
   MPPO_TRY(mppo_adv_sums(e->adv, e->perm, EM, e->mb, e->adv_sums, s));
   // MPPO_FORCE_COMM=1 runs the collectives also at world size 1 (identity all-reduce): hardware check of the RCCL path
   const char* fc = getenv("MPPO_FORCE_COMM");

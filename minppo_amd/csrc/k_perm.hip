@@ -39,7 +39,31 @@ int32_t permutation_ctr(unsigned long long seed, unsigned long long stream_id, c
   MPPO_CHECK_HIP(rocprim::radix_sort_pairs(temp, temp_bytes, keys_in, keys_out, vals_in, idx, (size_t)B, 0, 32, s));
   return MPPO_OK;
 }
+// jax.random.permutation (`_shuffle`): round r sorts the current order stably by random_bits(sort_keys[r]); the buffers alternate
+// so that the last round lands in `idx`
+int32_t threefry_permutation(const unsigned* sort_keys, int rounds, int B, int* idx, void* ws, size_t ws_bytes, hipStream_t s) {
+  MPPO_REQUIRE(B >= 1 && idx && ws && sort_keys && rounds >= 1, "threefry_permutation: bad argument");
+  if (ws_bytes < mppo_permutation_ws_bytes(B)) return fail(MPPO_ENOMEM, "threefry_permutation: workspace %zu < %zu bytes", ws_bytes, mppo_permutation_ws_bytes(B));
+  const size_t chunk = align_up((size_t)B * 4, 256);
+  unsigned char* w = static_cast<unsigned char*>(ws);
+  unsigned* keys_in = reinterpret_cast<unsigned*>(w);
+  unsigned* keys_out = reinterpret_cast<unsigned*>(w + chunk);
+  int* tmp = reinterpret_cast<int*>(w + 2 * chunk);
+  void* temp = w + 3 * chunk;
+  size_t temp_bytes = ws_bytes - 3 * chunk;
+  for (int r = 0; r < rounds; ++r) {
+    int* out = ((rounds - 1 - r) % 2 == 0) ? idx : tmp;
+    int* in = out == idx ? tmp : idx;
+    MPPO_TRY(threefry_bits(sort_keys + 2 * r, (size_t)B, keys_in, r == 0 ? in : nullptr, s));
+    MPPO_CHECK_HIP(rocprim::radix_sort_pairs(temp, temp_bytes, keys_in, keys_out, in, out, (size_t)B, 0, 32, s));
+  }
+  return MPPO_OK;
+}
 }  // namespace mppo
+
+extern "C" int32_t mppo_threefry_permutation(const uint32_t* sort_keys, int32_t rounds, int32_t B, int32_t* idx, void* ws, size_t ws_bytes, void* stream) {
+  return mppo::threefry_permutation(sort_keys, rounds, B, idx, ws, ws_bytes, static_cast<hipStream_t>(stream));
+}
 
 extern "C" int32_t mppo_permutation(uint64_t seed, uint64_t stream_id, int32_t B, int32_t* idx, void* ws, size_t ws_bytes, void* stream) {
   return mppo::permutation_ctr(seed, stream_id, nullptr, B, idx, ws, ws_bytes, static_cast<hipStream_t>(stream));

@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <cmath>
 #include <cstddef>
 #include <cstdint>
 #include <cstdlib>
@@ -120,5 +121,12 @@ int32_t fused_forward_backward(const mppo_net_t& net, const float* params, const
 int32_t perm_fill_keys(unsigned long long seed, unsigned long long stream_id, const int* ctr, int B, unsigned* keys, int* vals, hipStream_t stream);
 int32_t normal_fill_ctr(unsigned long long seed, unsigned long long stream_id, const int* ctr, size_t n, float* out, hipStream_t stream);
 int32_t permutation_ctr(unsigned long long seed, unsigned long long stream_id, const int* ctr, int B, int* idx, void* ws, size_t ws_bytes, hipStream_t stream);
+// k_rng.hip / k_perm.hip: jax.random-compatible streams (threefry2x32)
+int32_t threefry_normal(const unsigned* key2, size_t n, float* out, hipStream_t s);
+int32_t threefry_bits(const unsigned* key2, size_t n, unsigned* out, int* iota, hipStream_t s);
+int32_t threefry_chain(unsigned* rng2, int T, int E, int rounds, unsigned* act_keys, unsigned* sort_keys, hipStream_t s);
+// jax.random.permutation(key, B): `rounds` stable sorts by fresh random bits, sort_keys = [rounds][2] device words
+int32_t threefry_permutation(const unsigned* sort_keys, int rounds, int B, int* idx, void* ws, size_t ws_bytes, hipStream_t stream);
+inline int threefry_rounds(int B) { return B <= 1 ? 1 : (int)ceil(3.0 * log((double)B) / log(4294967295.0)); }
 
 }  // namespace mppo

@@ -164,7 +164,7 @@ def tree_to_flat(tree: dict, O: int, A: int, H: int) -> np.ndarray:
 
 _REGION_DTYPES = {
     "count": "int32", "done": "uint8", "perm": "int32", "adv_sums": "float64", "episode_lengths": "int32",
-    "returned_episode_lengths": "int32", "timestep": "int32", "returned_episode": "uint8",
+    "returned_episode_lengths": "int32", "timestep": "int32", "returned_episode": "uint8", "jax_rng": "int32",
 }
 
 
@@ -239,7 +239,8 @@ class Trainer:
             num_updates=max(self.num_updates, 1), world_size=world_size, rank=rank, gamma=rl.gamma, gae_lambda=rl.gae_lambda,
             loss=nat.LossCfg(rl.clip_eps, rl.vf_coef, rl.ent_coef),
             adam=nat.AdamCfg(lr, config.opt.max_grad_norm, 0.9, 0.999, 1e-5, int(tr.anneal_lr), 0, 0),
-            reward=reward_cfg(config), net=self.net, seed=self.seed, use_graph=int(use_graph), external_random=int(external_random))
+            reward=reward_cfg(config), net=self.net, seed=self.seed, use_graph=int(use_graph), external_random=int(external_random),
+            rng_impl=self._rng_impl(tr.rng_impl), reserved0=0)
         nbytes = C.c_size_t()
         self.lib.engine_arena_bytes(self._model, C.byref(self.ecfg), C.byref(nbytes))
         self.arena_bytes = nbytes.value
@@ -256,6 +257,26 @@ class Trainer:
         self.P = int(self.lib.param_count(C.byref(self.net)))
         self.updates_done = 0
         self.set_params_flat(init_flat_params(self.seed, self.O, self.A, self.H))
+
+    @staticmethod
+    def _rng_impl(name: str) -> int:
+        if name not in ("philox", "threefry"):
+            raise ValueError(f"training.rng_impl must be 'philox' or 'threefry', got {name!r}")
+        return 1 if name == "threefry" else 0
+
+    def _seed_jax_rng(self) -> None:
+        """The runner's carried key as the reference derives it from PRNGKey(seed) (train.py:110,142,285): three splits, the
+        first two consumed by parameter init and env reset, the second key of the third is the scan's rng."""
+        from minppo_amd import jaxrng
+
+        rng = jaxrng.prng_key(self.seed)
+        rng = jaxrng.split(rng)[0]   # rng, _rng = split(rng)        network.init
+        rng = jaxrng.split(rng)[0]   # rng, reset_rng = split(rng)   reset_fn
+        runner = jaxrng.split(rng)[1]  # rng, _rng = split(rng); RunnerState(..., _rng)
+        reg = self.region("jax_rng")
+        vals = np.zeros(reg.shape[0], np.int32)
+        vals[:2] = runner.view(np.int32)
+        self._write_region(reg, vals)
 
     # -- arena views ----------------------------------------------------------
     def region(self, name: str, shape: Optional[Sequence[int]] = None):
@@ -305,7 +326,7 @@ class Trainer:
     # records, episode bookkeeping, and RunnerState.last_obs (slot 0 of `obs`).  Restoring them reproduces the
     # uninterrupted run bit for bit (tests/test_train_surface.py).
     _CKPT_REGIONS = ("params", "adam_m", "adam_v", "count", "state", "episode_returns", "episode_lengths", "returned_episode_returns",
-                     "returned_episode_lengths", "timestep", "returned_episode")
+                     "returned_episode_lengths", "timestep", "returned_episode", "jax_rng")
     _CKPT_VERSION = 2  # 2: 16-byte-aligned flat parameter layout
 
     def _ckpt_meta(self) -> Dict[str, Any]:
@@ -387,6 +408,9 @@ class Trainer:
     # -- stepping ----------------------------------------------------------------
     def reset(self) -> None:
         self.lib.engine_reset(self._engine, self._stream_ptr)
+        if self.ecfg.rng_impl == 1:
+            self._sync()
+            self._seed_jax_rng()
 
     def update(self) -> None:
         self.lib.engine_update(self._engine, self._stream_ptr)

@@ -35,6 +35,23 @@ int32_t permutation_ctr(unsigned long long seed, unsigned long long stream_id, c
   return MPPO_OK;
 }
 
+int32_t threefry_permutation(const unsigned* sort_keys, int rounds, int B, int* idx, void* ws, size_t ws_bytes, hipStream_t stream) {
+  MPPO_REQUIRE(B >= 1 && idx && ws && sort_keys && rounds >= 1, "threefry_permutation: bad argument");
+  if (ws_bytes < mppo_permutation_ws_bytes(B)) return fail(MPPO_ENOMEM, "threefry_permutation: workspace too small");
+  unsigned* keys = static_cast<unsigned*>(ws);
+  std::vector<int> cur(B), order(B), next(B);
+  std::iota(cur.begin(), cur.end(), 0);
+  for (int r = 0; r < rounds; ++r) {
+    MPPO_TRY(threefry_bits(sort_keys + 2 * r, (size_t)B, keys, nullptr, stream));
+    std::iota(order.begin(), order.end(), 0);
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return keys[a] < keys[b]; });
+    for (int i = 0; i < B; ++i) next[i] = cur[order[i]];
+    cur.swap(next);
+  }
+  for (int i = 0; i < B; ++i) idx[i] = cur[i];
+  return MPPO_OK;
+}
+
 // RCCL's place is taken by an all-reduce through POSIX shared memory between the rank PROCESSES of a CPU test
 // (tests/test_distributed.py): same call sites in engine.hip, same semantics (in-place sum, every rank gets the
 // identical result: slots are added in rank order).  The 128-byte "unique id" carries the segment name.
@@ -148,6 +165,10 @@ int32_t graph_end(hipStream_t, GraphExec**) { return fail(MPPO_EHIP, "hipGraph i
 int32_t graph_launch(GraphExec*, hipStream_t) { return fail(MPPO_EHIP, "hipGraph is not available in the emulator build"); }
 void graph_destroy(GraphExec*) {}
 }  // namespace mppo
+
+extern "C" int32_t mppo_threefry_permutation(const uint32_t* sort_keys, int32_t rounds, int32_t B, int32_t* idx, void* ws, size_t ws_bytes, void* stream) {
+  return mppo::threefry_permutation(sort_keys, rounds, B, idx, ws, ws_bytes, static_cast<hipStream_t>(stream));
+}
 
 extern "C" int32_t mppo_permutation(uint64_t seed, uint64_t stream_id, int32_t B, int32_t* idx, void* ws, size_t ws_bytes, void* stream) {
   return mppo::permutation_ctr(seed, stream_id, nullptr, B, idx, ws, ws_bytes, static_cast<hipStream_t>(stream));
