@@ -309,17 +309,6 @@ __global__ void __launch_bounds__(512, ROLLOUT ? MPPO_ROLLOUT_WAVES : 2) fused_m
     *reinterpret_cast<float4*>(xt + r * XS + c4) = q;
   }
   __syncthreads();
-  if (!ROLLOUT && net == 0) {
-    // the gathered rows, k-quad layout [mb/4][OP][4], for the first layer's weight gradient (the actor workgroup writes them)
-    for (int e = t; e < 4 * OP; e += nthr) {
-      const int qd = e / OP, c = e - qd * OP;
-      float v[4];
-#pragma unroll
-      for (int j = 0; j < 4; ++j) v[j] = row0 + 4 * qd + j < a.mb ? xt[(4 * qd + j) * XS + c] : 0.f;
-      stream_store(a.xmb + quad_index(row0 + 4 * qd, c, OP), make_float4(v[0], v[1], v[2], v[3]));
-    }
-  }
-
   FT(3);
   // ---- P1 / P2: hidden layers ----
   GemmPipe<false> pipe2;
@@ -343,6 +332,18 @@ __global__ void __launch_bounds__(512, ROLLOUT ? MPPO_ROLLOUT_WAVES : 2) fused_m
 #ifdef MPPO_FUSED_TIMERS
     if (!ROLLOUT && blockIdx.x == 40 && blockIdx.y == 0 && lane == 0) g_fused_t[24 + 16 * layer + 8 + wave] = __builtin_amdgcn_s_memtime();
 #endif
+    if (layer == 0 && !ROLLOUT && net == 0) {
+      // the gathered rows, k-quad layout [mb/4][OP][4], for the first layer's weight gradient (the actor workgroup writes them).
+      // Here, after this wave's share of the first GEMM and before the barrier, the copy costs the early waves nothing: they
+      // would wait for the SIMD's second wave anyway (the x tile stays intact until the head partials overwrite it in P3).
+      for (int e = t; e < 4 * OP; e += nthr) {
+        const int qd = e / OP, c = e - qd * OP;
+        float v[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = row0 + 4 * qd + j < a.mb ? xt[(4 * qd + j) * XS + c] : 0.f;
+        stream_store(a.xmb + quad_index(row0 + 4 * qd, c, OP), make_float4(v[0], v[1], v[2], v[3]));
+      }
+    }
     float* ht = layer == 0 ? h1t : h2t;
     float* hg = layer == 0 ? a.h1[net] : a.h2[net];
     const int c0 = n0 + 2 * cj;  // the wave's two interleaved column tiles: c0, c0 + 1
