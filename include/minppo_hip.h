@@ -70,6 +70,10 @@ typedef struct mppo_model_dims {
 int32_t mppo_model_open(const void* host_blob, size_t nbytes, const void* dev_blob, mppo_model_t** out);
 int32_t mppo_model_close(mppo_model_t* m);
 int32_t mppo_model_get_dims(const mppo_model_t* m, mppo_model_dims_t* out);
+/* *out = 1 when this model's dimensions match one of the environment-kernel instantiations compiled for fixed dimensions
+ * (csrc/spec_dims.inc, written by `python -m minppo_amd.build`; MPPO_SPECIALIZE=robot.xml[,...] adds models), 0 when it runs the
+ * run-time-sized kernel.  Same results either way; the fixed-size kernel is faster (env_kernel). */
+int32_t mppo_model_is_specialized(const mppo_model_t* m, int32_t* out);
 
 /* Reward / termination constants read by compute_reward and is_done (env.py:199-242,
  * config.py:36-48). */

@@ -91,6 +91,7 @@ SIGNATURES = {
     "mppo_model_open": (c_i32, [c_vp, c_sz, c_vp, P(c_vp)]),
     "mppo_model_close": (c_i32, [c_vp]),
     "mppo_model_get_dims": (c_i32, [c_vp, P(ModelDims)]),
+    "mppo_model_is_specialized": (c_i32, [c_vp, P(c_i32)]),
     "mppo_env_reset": (c_i32, [c_vp, c_i32, c_vp, c_vp, c_vp, c_i32, c_vp, c_vp, P(EnvMetrics), c_vp]),
     "mppo_env_step": (c_i32, [c_vp, c_i32, c_i32, P(RewardCfg), c_vp, c_vp, c_vp, c_i32, c_vp, c_i32, c_vp, c_vp,
                               P(EnvMetrics), c_vp]),

@@ -57,9 +57,10 @@ __device__ unsigned long long g_phys_t[40];
 #define PT(k) do { } while (0)
 #endif
 // model tables in LDS (see the staging copy at the top of the kernel)
-#define TI(name) (tabI + mv.o[BI_##name])
-#define TF(name) (tabF + mv.o[BF_##name])
-#define TU(name) (reinterpret_cast<const u64*>(tabI + mv.o[BI_##name]))
+#define TI(name) (tabI + MVO(BI_##name))
+#define TF(name) (tabF + MVO(BF_##name))
+#define TU(name) (reinterpret_cast<const u64*>(tabI + MVO(BI_##name)))
+#define MVO(k) (SD::kStatic ? kSO.o[k] : mv.o[k])  // word offset of table k inside the blob: a constant in a model-specialised kernel
 
 // ---- small vector helpers (registers) -------------------------------------------------------
 struct V3 { float x, y, z; };
@@ -93,6 +94,43 @@ __device__ __forceinline__ V3 qrot(Q4 q, V3 v) {
   float m[9];
   qmat(q, m);
   return {m[0] * v.x + m[1] * v.y + m[2] * v.z, m[3] * v.x + m[4] * v.y + m[5] * v.z, m[6] * v.x + m[7] * v.y + m[8] * v.z};
+}
+// MJX math.normalize_with_norm
+__device__ __forceinline__ V3 normalize_norm(V3 v, float& n) {
+  n = sqrtf(dot3(v, v));
+  return mul3(v, 1.f / (n + (n == 0.f ? 1e-6f : 0.f)));
+}
+// MJX math.closest_segment_point
+__device__ __forceinline__ V3 closest_segment_point(V3 a, V3 b, V3 pt) {
+  const V3 ab = sub3(b, a);
+  const float t = dot3(sub3(pt, a), ab) / (dot3(ab, ab) + 1e-6f);
+  return add3(a, mul3(ab, fminf(fmaxf(t, 0.f), 1.f)));
+}
+// MJX math.closest_segment_to_segment_points (sphere_capsule / capsule_capsule; a sphere is a segment of length 0)
+__device__ __forceinline__ void closest_segment_points(V3 a0, V3 a1, V3 b0, V3 b1, V3& best_a, V3& best_b) {
+  float len_a, len_b;
+  const V3 dir_a = normalize_norm(sub3(a1, a0), len_a), dir_b = normalize_norm(sub3(b1, b0), len_b);
+  const float half_a = 0.5f * len_a, half_b = 0.5f * len_b;
+  const V3 a_mid = add3(a0, mul3(dir_a, half_a)), b_mid = add3(b0, mul3(dir_b, half_b));
+  const V3 trans = sub3(a_mid, b_mid);
+  const float dab = dot3(dir_a, dir_b), dat = dot3(dir_a, trans), dbt = dot3(dir_b, trans);
+  const float denom = 1.f - dab * dab;
+  float ta = (-dat + dab * dbt) / (denom + 1e-6f);
+  float tb = dbt + ta * dab;
+  ta = fminf(fmaxf(ta, -half_a), half_a);
+  tb = fminf(fmaxf(tb, -half_b), half_b);
+  best_a = add3(a_mid, mul3(dir_a, ta));
+  best_b = add3(b_mid, mul3(dir_b, tb));
+  const V3 new_a = closest_segment_point(a0, a1, best_b), new_b = closest_segment_point(b0, b1, best_a);
+  const V3 e1 = sub3(new_a, best_b), e2 = sub3(new_b, best_a);
+  if (dot3(e1, e1) < dot3(e2, e2)) best_a = new_a; else best_b = new_b;
+}
+// second row of MJX math.make_frame(n) for a unit n: y (or z when |n.y| >= 0.5) with its n component removed, normalised
+__device__ __forceinline__ V3 frame_tangent(V3 n) {
+  V3 b = (n.y > -0.5f && n.y < 0.5f) ? V3{0.f, 1.f, 0.f} : V3{0.f, 0.f, 1.f};
+  b = sub3(b, mul3(n, dot3(n, b)));
+  const float l = sqrtf(dot3(b, b));
+  return mul3(b, l > 0.f ? 1.f / l : 1.f);
 }
 __device__ __forceinline__ Q4 axis_angle(V3 axis, float angle) {
   float s, c;
@@ -196,10 +234,31 @@ __device__ __forceinline__ void kbi(const float* solref, const float* solimp, fl
   if (x > 1.f) imp = dmax;
 }
 
-// NV / NEFC > 0: the kernel is instantiated for exactly this model size (compile-time loop bounds: the inner products
-// over dofs unroll completely and read LDS rows as float4); 0: sizes are read from the model at run time.
-template <int NV, int NEFC>
-__global__ void __launch_bounds__(kEnvBlock) env_kernel(ModelView mv, EnvArgs a, PhysLds P) {
+// What the kernel knows at compile time.  RuntimeModel: nothing - dims, table offsets and the LDS layout arrive as kernel
+// arguments (about 200 scalar values; the kernel has ~100 SGPRs, so most of them are spilled to VGPR lanes and read back with
+// v_readlane at every use).  StaticModel<dims...>: the dims, the blob's table offsets and the LDS layout are compile-time
+// constants (the latter two are pure functions of the dims, model_view.h), which frees those registers and drops the code of
+// absent features: 180 -> 148 us (offsets only) -> 131 us (dims too) per step on synth_stompy_pro, 1306 -> 1012 us on
+// synth_stompy_full at 8192 envs; results are bit-identical to the run-time-sized kernel (tests/test_kernels_physics.py).
+// Instantiations are listed in spec_dims.inc (generated by minppo_amd/build.py); other models run the RuntimeModel kernel.
+struct RuntimeModel {
+  static constexpr bool kStatic = false;
+  static constexpr BlobDims dims() { return BlobDims{}; }
+};
+template <int NQ, int NV, int NU, int NBODY, int NJNT, int NCON, int NLIMIT, int NPAIR, int NLEVEL, int NROOT>
+struct StaticModel {
+  static constexpr bool kStatic = true;
+  static constexpr BlobDims dims() { return BlobDims{NQ, NV, NU, NBODY, NJNT, NCON, NLIMIT, NPAIR, NLEVEL, NROOT}; }
+};
+// MODE (EnvArgs::mode) is a template parameter too: the step kernel carries neither the probe's 17 output pointers nor its stores.
+template <class SD, int MODE>
+__global__ void __launch_bounds__(kEnvBlock) env_kernel(ModelView mv, EnvArgs a, PhysLds Prt) {
+  constexpr BlobDims kSD = SD::dims();
+  constexpr BlobOffsets kSO = blob_offsets(kSD);
+  constexpr PhysLds kSP = make_phys_lds(kSD.nq, kSD.nv, kSD.nu, kSD.nbody, kSD.njnt, kSD.ncon, kSD.nlimit + 4 * kSD.ncon, kSD.nroot);
+  const PhysLds P = SD::kStatic ? kSP : Prt;
+  constexpr bool kDims = SD::kStatic;
+  constexpr int NV = kDims ? kSD.nv : 0;
   MPPO_DYN_SMEM(smem_raw);
   const int tid = threadIdx.x;
   const int g = tid & (kGroupLanes - 1);
@@ -220,7 +279,9 @@ __global__ void __launch_bounds__(kEnvBlock) env_kernel(ModelView mv, EnvArgs a,
   if (row >= kEnvsPerWave) return;  // rows without an environment
   float* S = reinterpret_cast<float*>(smem_raw) + mv.blob_words + (size_t)el * P.total;
 
-  const int nq = mv.nq, nv = NV ? NV : mv.nv, nu = mv.nu, nb = mv.nbody, njnt = mv.njnt, ncon = mv.ncon, nlim = mv.nlimit, nefc = NV ? NEFC : mv.nefc;
+  const int nq = kDims ? kSD.nq : mv.nq, nv = kDims ? kSD.nv : mv.nv, nu = kDims ? kSD.nu : mv.nu, nb = kDims ? kSD.nbody : mv.nbody, njnt = kDims ? kSD.njnt : mv.njnt,
+            ncon = kDims ? kSD.ncon : mv.ncon, nlim = kDims ? kSD.nlimit : mv.nlimit, nefc = kDims ? kSD.nlimit + 4 * kSD.ncon : mv.nefc;
+  const int nlevel = kDims ? kSD.nlevel : mv.nlevel, nroot = kDims ? kSD.nroot : mv.nroot;
   const int ldm = P.ldm, ldj = P.ldj;
   const float h = mv.timestep;
   const int O = mv.obs_dim, OP = mv.obs_pad;
@@ -232,7 +293,8 @@ __global__ void __launch_bounds__(kEnvBlock) env_kernel(ModelView mv, EnvArgs a,
   float* grad = (float*)__builtin_assume_aligned(S + P.grad, 16); float* Mgrad = (float*)__builtin_assume_aligned(S + P.Mgrad, 16); float* search = (float*)__builtin_assume_aligned(S + P.search, 16); float* mvv = (float*)__builtin_assume_aligned(S + P.mv, 16); float* qfc = (float*)__builtin_assume_aligned(S + P.qfc, 16);
   float* t0 = (float*)__builtin_assume_aligned(S + P.t0, 16); float* t1 = (float*)__builtin_assume_aligned(S + P.t1, 16);
   float* eD = S + P.D; float* earef = S + P.aref; float* jaref = S + P.jaref; float* jv = S + P.jv; float* force = S + P.force;
-  float* conpos = S + P.conpos; float* condist = S + P.condist;
+  float* conpos = S + P.conpos; float* condist = S + P.condist; float* confr = S + P.confr;
+  const int npair = kDims ? kSD.npair : mv.npair, nplane = ncon - npair;
   float* ximat = S + P.ximat; float* xmat = S + P.xmat; float* xanchor = S + P.xanchor; float* xaxis = S + P.xaxis;
   float* C1 = S + P.C1; float* C2 = S + P.C2; float* cdofdot = S + P.cdofdot; float* cfrc = S + P.cfrc; float* J = (float*)__builtin_assume_aligned(S + P.J, 16);
 
@@ -240,11 +302,11 @@ __global__ void __launch_bounds__(kEnvBlock) env_kernel(ModelView mv, EnvArgs a,
 
   PT(0);
   // ---- P0: load the state ------------------------------------------------------------------
-  if (a.mode == 1) {
+  if (MODE == 1) {
     FOR_G(i, nq) qpos[i] = rec[i];
     FOR_G(i, nv) { qvel[i] = rec[nq + i]; warm[i] = rec[OP + i]; }
     FOR_G(i, nu) ctrl[i] = a.action[(size_t)env * a.act_ld + i];
-  } else if (a.mode == 0) {
+  } else if (MODE == 0) {
     FOR_G(i, nq) qpos[i] = TF(qpos0)[i];
     FOR_G(i, nv) { qvel[i] = 0.f; warm[i] = 0.f; }
     FOR_G(i, nu) ctrl[i] = 0.f;
@@ -255,7 +317,7 @@ __global__ void __launch_bounds__(kEnvBlock) env_kernel(ModelView mv, EnvArgs a,
   }
   // pre-step quantities the reward needs (env.py:212-217, 222)
   float pre_p0 = 0.f, pre_z = 0.f, pre_comx = 0.f, time_in = 0.f;
-  if (a.mode == 1) {
+  if (MODE == 1) {
     float s = 0.f;
     FOR_G(i, nq) { const float d = TF(qpos0)[i] - rec[i]; s += d * d; }
     pre_p0 = sqrtf(group16_sum(s));
@@ -268,11 +330,11 @@ __global__ void __launch_bounds__(kEnvBlock) env_kernel(ModelView mv, EnvArgs a,
 
   float new_comx = 0.f;
   int niter_out = 0;
-  const int frames = a.mode == 1 ? a.n_frames : 1;
+  const int frames = MODE == 1 ? a.n_frames : 1;
   for (int frame = 0; frame < frames; ++frame) {
     PT(1);
     // ================= fwd_position: kinematics (level-synchronous over the tree) =================
-    for (int lv = 0; lv < mv.nlevel; ++lv) {
+    for (int lv = 0; lv < nlevel; ++lv) {
       const int adr = TI(level_adr)[lv], cnt = TI(level_adr)[lv + 1] - adr;
       FOR_G(ii, cnt) {
         const int b = TI(level_body)[adr + ii];
@@ -313,7 +375,7 @@ __global__ void __launch_bounds__(kEnvBlock) env_kernel(ModelView mv, EnvArgs a,
     }
     PT(2);
     // ---- com_pos: centre of mass of every kinematic tree; contact candidates --------------------
-    for (int r = 0; r < mv.nroot; ++r) {
+    for (int r = 0; r < nroot; ++r) {
       const u64 mask = TU(body_subtree_mask)[TI(root_body)[r]];
       float sx = 0.f, sy = 0.f, sz = 0.f, sm = 0.f;
       FOR_G(b, nb) {
@@ -327,13 +389,38 @@ __global__ void __launch_bounds__(kEnvBlock) env_kernel(ModelView mv, EnvArgs a,
       if (g == 0) st3(rootcom + 3 * r, {sx * inv, sy * inv, sz * inv});
       if (r == 0) new_comx = sx * inv;  // subtree_com[1].x: body 1 is the first root (env.py:222-223)
     }
-    FOR_G(c, ncon) {
+    FOR_G(c, nplane) {  // ground contacts (MJX plane_sphere / plane_capsule; a box corner is a sphere of radius 0)
       const int b = TI(con_bodyid)[c];
-      const V3 centre = add3(ld3(xpos + 3 * b), qrot(ld4(xquat + 4 * b), ld3(TF(con_lpos) + 3 * c)));
+      const Q4 q = ld4(xquat + 4 * b);
+      const V3 centre = add3(ld3(xpos + 3 * b), qrot(q, ld3(TF(con_lpos) + 3 * c)));
       const float rad = TF(con_radius)[c];
       const float dist = centre.z - mv.plane_z - rad;
       condist[c] = dist;
       st3(conpos + 3 * c, {centre.x, centre.y, centre.z - (rad + 0.5f * dist)});
+      // frame: normal +z; the first tangent follows the capsule axis projected on the plane unless that projection is shorter
+      // than 0.5 (spheres and corners carry a zero axis) - then make_frame's +y
+      const V3 ax = qrot(q, ld3(TF(con_axis) + 3 * c));
+      const float bn = sqrtf(ax.x * ax.x + ax.y * ax.y);
+      st3(confr + 6 * c, {0.f, 0.f, 1.f});
+      st3(confr + 6 * c + 3, bn < 0.5f ? V3{0.f, 1.f, 0.f} : V3{ax.x / bn, ax.y / bn, 0.f});
+    }
+    FOR_G(k, npair) {  // geom-geom pairs (MJX sphere_sphere / sphere_capsule / capsule_capsule): one contact each
+      const int c = nplane + k;
+      const int b1 = TI(pair_body)[2 * k], b2 = TI(pair_body)[2 * k + 1];
+      const float* gp = TF(pair_geom) + 16 * k;
+      const Q4 q1 = ld4(xquat + 4 * b1), q2 = ld4(xquat + 4 * b2);
+      const V3 c1 = add3(ld3(xpos + 3 * b1), qrot(q1, ld3(gp))), h1 = qrot(q1, ld3(gp + 3));
+      const V3 c2 = add3(ld3(xpos + 3 * b2), qrot(q2, ld3(gp + 8))), h2 = qrot(q2, ld3(gp + 11));
+      V3 p1, p2;
+      closest_segment_points(sub3(c1, h1), add3(c1, h1), sub3(c2, h2), add3(c2, h2), p1, p2);
+      float dist;
+      V3 n = normalize_norm(sub3(p2, p1), dist);
+      if (dist == 0.f) n = {1.f, 0.f, 0.f};
+      dist -= gp[6] + gp[14];
+      condist[c] = dist;
+      st3(conpos + 3 * c, add3(p1, mul3(n, gp[6] + 0.5f * dist)));
+      st3(confr + 6 * c, n);
+      st3(confr + 6 * c + 3, frame_tangent(n));
     }
     SYNC();
     PT(3);
@@ -344,7 +431,7 @@ __global__ void __launch_bounds__(kEnvBlock) env_kernel(ModelView mv, EnvArgs a,
         for (int k = 0; k < 10; ++k) ci[k] = 0.f;
       } else {
         int ri = 0;
-        for (int r = 0; r < mv.nroot; ++r) if (TI(root_body)[r] == TI(body_rootid)[b]) ri = r;
+        for (int r = 0; r < nroot; ++r) if (TI(root_body)[r] == TI(body_rootid)[b]) ri = r;
         const V3 off = sub3(ld3(xipos + 3 * b), ld3(rootcom + 3 * ri));
         const float m = TF(body_mass)[b];
         const float* R = ximat + 9 * b;
@@ -362,7 +449,7 @@ __global__ void __launch_bounds__(kEnvBlock) env_kernel(ModelView mv, EnvArgs a,
     FOR_G(j, njnt) {
       const int b = TI(jnt_bodyid)[j], da = TI(jnt_dofadr)[j], jt = TI(jnt_type)[j];
       int ri = 0;
-      for (int r = 0; r < mv.nroot; ++r) if (TI(root_body)[r] == TI(body_rootid)[b]) ri = r;
+      for (int r = 0; r < nroot; ++r) if (TI(root_body)[r] == TI(body_rootid)[b]) ri = r;
       const V3 off = sub3(ld3(rootcom + 3 * ri), ld3(xanchor + 3 * j));
       if (jt == JNT_FREE) {
         const float* R = xmat + 9 * b;
@@ -537,7 +624,7 @@ __global__ void __launch_bounds__(kEnvBlock) env_kernel(ModelView mv, EnvArgs a,
       }
       qact[d] = act;
       qfs[d] = passive - bias + act;
-      if (a.mode == 2) {
+      if (MODE == 2) {
         if (valid && a.probe.qfrc_bias) a.probe.qfrc_bias[(size_t)env * nv + d] = bias;
         if (valid && a.probe.qfrc_passive) a.probe.qfrc_passive[(size_t)env * nv + d] = passive;
       }
@@ -561,27 +648,39 @@ __global__ void __launch_bounds__(kEnvBlock) env_kernel(ModelView mv, EnvArgs a,
     }
     for (int item = g; item < ncon * nv; item += kGroupLanes) {  // contacts: 4 pyramid rows, (contact, dof) per item
       const int c = item / nv, d = item - c * nv;
-      const int b = TI(con_bodyid)[c];
-      const bool act = condist[c] < 0.f;
-      if (act && ((TU(body_ancdof_mask)[b] >> d) & 1ull)) {
-        int ri = 0;
-        for (int r = 0; r < mv.nroot; ++r) if (TI(root_body)[r] == TI(body_rootid)[b]) ri = r;
-        const V3 off = sub3(ld3(conpos + 3 * c), ld3(rootcom + 3 * ri));
-        const V3 jp = add3(ld3(cdof + 6 * d + 3), cross3(ld3(cdof + 6 * d), off));
-        // contact frame of the +z ground plane (make_frame): normal z, t1 = +y, t2 = -x
-        const float jn = jp.z, jt1 = jp.y, jt2 = -jp.x;
-        const float mu = TF(con_friction)[3 * c];
-        const int r0 = nlim + 4 * c;
-        J[(r0 + 0) * ldj + d] = jn + mu * jt1;
-        J[(r0 + 1) * ldj + d] = jn - mu * jt1;
-        J[(r0 + 2) * ldj + d] = jn + mu * jt2;
-        J[(r0 + 3) * ldj + d] = jn - mu * jt2;
+      if (condist[c] < 0.f) {
+        // translational Jacobian of the contact point: body 2 minus body 1 (body 1 = world for a ground contact)
+        V3 jp = {0.f, 0.f, 0.f};
+        bool any = false;
+        for (int side = 0; side < 2; ++side) {
+          if (side == 1 && c < nplane) break;
+          const int b = side == 0 ? TI(con_bodyid)[c] : TI(pair_body)[2 * (c - nplane)];
+          if ((TU(body_ancdof_mask)[b] >> d) & 1ull) {
+            int ri = 0;
+            for (int r = 0; r < nroot; ++r) if (TI(root_body)[r] == TI(body_rootid)[b]) ri = r;
+            const V3 off = sub3(ld3(conpos + 3 * c), ld3(rootcom + 3 * ri));
+            const V3 jb = add3(ld3(cdof + 6 * d + 3), cross3(ld3(cdof + 6 * d), off));
+            jp = side == 0 ? add3(jp, jb) : sub3(jp, jb);
+            any = true;
+          }
+        }
+        if (any) {
+          const V3 n = ld3(confr + 6 * c), t1 = ld3(confr + 6 * c + 3), t2 = cross3(n, t1);
+          const float jn = dot3(n, jp), jt1 = dot3(t1, jp), jt2 = dot3(t2, jp);
+          const float mu = TF(con_friction)[3 * c];
+          const int r0 = nlim + 4 * c;
+          J[(r0 + 0) * ldj + d] = jn + mu * jt1;
+          J[(r0 + 1) * ldj + d] = jn - mu * jt1;
+          J[(r0 + 2) * ldj + d] = jn + mu * jt2;
+          J[(r0 + 3) * ldj + d] = jn - mu * jt2;
+        }
       }
     }
     FOR_G(c, ncon) {
       const bool act = condist[c] < 0.f;
       const float mu = TF(con_friction)[3 * c];
-      const float tw = TF(body_invweight0)[2 * TI(con_bodyid)[c]];
+      float tw = TF(body_invweight0)[2 * TI(con_bodyid)[c]];
+      if (c >= nplane) tw += TF(body_invweight0)[2 * TI(pair_body)[2 * (c - nplane)]];
       const float iw = (tw + mu * mu * tw) * 2.f * mu * mu / mv.impratio;
       for (int k = 0; k < 4; ++k) {
         jv[nlim + 4 * c + k] = act ? condist[c] : 0.f;
@@ -750,7 +849,7 @@ __global__ void __launch_bounds__(kEnvBlock) env_kernel(ModelView mv, EnvArgs a,
     PT(20);
     niter_out = niter;
     // ---- probe outputs (parity tests) ---------------------------------------------------------------------
-    if (a.mode == 2 && valid) {
+    if (MODE == 2 && valid) {
       const mppo_forward_probe_t& pr = a.probe;
       if (pr.qM) FOR_G(i, nv) for (int k = 0; k < nv; ++k) pr.qM[((size_t)env * nv + i) * nv + k] = M[i * ldm + k];
       if (pr.qfrc_actuator) FOR_G(i, nv) pr.qfrc_actuator[(size_t)env * nv + i] = qact[i];
@@ -765,13 +864,13 @@ __global__ void __launch_bounds__(kEnvBlock) env_kernel(ModelView mv, EnvArgs a,
       if (pr.subtree_com1 && g == 0) pr.subtree_com1[env] = new_comx;
       if (pr.solver_niter && g == 0) pr.solver_niter[env] = niter;
     }
-    if (a.mode == 0) break;  // pipeline_init = forward only
+    if (MODE == 0) break;  // pipeline_init = forward only
     PT(21);
     // ================= euler: implicit damping, semi-implicit integration ====================================
     FOR_G(i, nv) t1[i] = qfs[i] + qfc[i];
     SYNC();
     solve_linv<true, NV>(LL, ldm, nv, t1, t0, mvv, g);  // mvv = (M + h D)^-1 (qfrc_smooth + qfrc_constraint)
-    if (a.mode == 2) {
+    if (MODE == 2) {
       if (valid && a.probe.qacc_euler) FOR_G(i, nv) a.probe.qacc_euler[(size_t)env * nv + i] = mvv[i];
       break;
     }
@@ -792,14 +891,14 @@ __global__ void __launch_bounds__(kEnvBlock) env_kernel(ModelView mv, EnvArgs a,
     SYNC();
   }
 
-  if (a.mode == 2) return;
+  if (MODE == 2) return;
 
   PT(22);
   // ================= epilogue: observation, reward, done, auto-reset, metrics, new record ====================
   // The new record's derived fields (cinert, cvel, qfrc_actuator, subtree_com) are those of the LAST forward
   // pass, i.e. they belong to the pre-integration pose: exactly what the MJX data carries.
   float* recw = a.state + (size_t)env * mv.rec_dim;
-  if (a.mode == 0) {
+  if (MODE == 0) {
     // reset: record = [qpos0, 0, cinert[1:], cvel[1:], qfrc_actuator | pad | qacc_warmstart = qacc | com_x | time = 0]
     const int o_ci = nq + nv, o_cv = o_ci + (mv.include_c ? 10 * (nb - 1) : 0), o_qa = o_cv + (mv.include_c ? 6 * (nb - 1) : 0);
     FOR_G(i, mv.rec_dim) {
@@ -892,10 +991,49 @@ __global__ void __launch_bounds__(kEnvBlock) env_kernel(ModelView mv, EnvArgs a,
 // =================================================================================================
 // host side: model handle + launch wrappers (C ABI)
 // =================================================================================================
+namespace mppo {
+template <class SD>
+static int32_t launch_env_t(const ModelView& mv, const EnvArgs& a, const PhysLds& lds, int lds_bytes, int blocks, hipStream_t stream) {
+  void (*kern)(ModelView, EnvArgs, PhysLds) = a.mode == 0 ? &env_kernel<SD, 0> : a.mode == 1 ? &env_kernel<SD, 1> : &env_kernel<SD, 2>;
+  static thread_local bool attr_set[3] = {false, false, false};
+  if (!attr_set[a.mode] && lds_bytes > 64 * 1024) {
+    MPPO_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
+    attr_set[a.mode] = true;
+  }
+  hipLaunchKernelGGL(kern, dim3(blocks), dim3(kEnvBlock), lds_bytes, stream, mv, a, lds);
+  MPPO_CHECK_LAUNCH("env_kernel");
+  return MPPO_OK;
+}
+
+struct SpecEntry {
+  BlobDims d;
+  int32_t (*launch)(const ModelView&, const EnvArgs&, const PhysLds&, int, int, hipStream_t);
+};
+#define MPPO_SPEC(...) {BlobDims{__VA_ARGS__}, &launch_env_t<StaticModel<__VA_ARGS__>>},
+static const SpecEntry kSpecs[] = {
+#include "spec_dims.inc"
+    {BlobDims{}, nullptr}};
+#undef MPPO_SPEC
+
+// MPPO_ENV_GENERIC=1 forces the run-time-sized kernel (A/B tests of the two instantiations)
+static int find_spec(const BlobDims& d) {
+  const char* e = getenv("MPPO_ENV_GENERIC");
+  if (e && e[0] == '1') return -1;
+  for (int i = 0; kSpecs[i].launch; ++i) {
+    const BlobDims& s = kSpecs[i].d;
+    if (s.nq == d.nq && s.nv == d.nv && s.nu == d.nu && s.nbody == d.nbody && s.njnt == d.njnt && s.ncon == d.ncon && s.nlimit == d.nlimit &&
+        s.npair == d.npair && s.nlevel == d.nlevel && s.nroot == d.nroot)
+      return i;
+  }
+  return -1;
+}
+}  // namespace mppo
+
 struct mppo_model {
   mppo::ModelView mv;
   mppo::PhysLds lds;
   int lds_bytes;
+  int spec;  // index into the table of model-specialised kernels (spec_dims.inc), -1: the run-time-sized kernel
 };
 
 namespace mppo {
@@ -918,35 +1056,24 @@ extern "C" int32_t mppo_model_open(const void* host_blob, size_t nbytes, const v
   mppo_model* m = new mppo_model();
   ModelView& v = m->mv;
   v.nq = wi[3]; v.nv = wi[4]; v.nu = wi[5]; v.nbody = wi[6]; v.njnt = wi[7]; v.ncon = wi[8]; v.nlimit = wi[9];
-  v.iterations = wi[10]; v.ls_iterations = wi[11]; v.nlevel = wi[12]; v.nroot = wi[13]; v.include_c = wi[14] ? 1 : 0;
+  v.iterations = wi[10]; v.ls_iterations = wi[11]; v.nlevel = wi[12]; v.nroot = wi[13]; v.include_c = wi[14] ? 1 : 0; v.npair = wi[15];
   v.nefc = v.nlimit + 4 * v.ncon;
   v.timestep = wf[16]; v.tolerance = wf[17]; v.ls_tolerance = wf[18]; v.impratio = wf[19]; v.plane_z = wf[20]; v.meaninertia = wf[21];
   auto bad = [&](const char* what) { delete m; return fail(MPPO_EMODEL, "model blob: %s", what); };
   if (v.nq < 1 || v.nv < 1 || v.nbody < 2 || v.nbody > 64 || v.nv > 64 || v.nq > 128 || v.nu < 0 || v.nu > v.nv || v.njnt < 1 ||
-      v.ncon < 0 || v.nlimit < 0 || v.nroot < 1 || v.nlevel < 1 || v.iterations < 0 || v.ls_iterations < 0)
+      v.ncon < 0 || v.npair < 0 || v.npair > v.ncon || v.nlimit < 0 || v.nroot < 1 || v.nlevel < 1 || v.iterations < 0 || v.ls_iterations < 0)
     return bad("dimension out of the supported range (nbody<=64, nv<=64)");
   if (!(v.timestep > 0.f) || !(v.meaninertia > 0.f) || !(v.impratio > 0.f)) return bad("non-positive timestep / meaninertia / impratio");
   const int32_t* dir = wi + kBlobHeaderWords;
-  const size_t expect[BLOB_ARRAY_COUNT] = {
-      (size_t)v.nbody, (size_t)v.nbody, (size_t)v.nbody, (size_t)v.nbody, (size_t)v.nbody, (size_t)v.nbody, (size_t)v.nbody,
-      (size_t)v.njnt, (size_t)v.njnt, (size_t)v.njnt, (size_t)v.njnt, (size_t)v.njnt,
-      (size_t)v.nv, (size_t)v.nv, (size_t)v.nv,
-      (size_t)v.nu, (size_t)v.nu, (size_t)v.nu, (size_t)v.nu,
-      (size_t)v.ncon, (size_t)v.nlimit,
-      (size_t)v.nlevel + 1, (size_t)v.nbody - 1, (size_t)v.nroot, 2 * (size_t)v.nbody, 2 * (size_t)v.nbody, 2 * (size_t)v.nv, (size_t)v.nv,
-      3, 3 * (size_t)v.nbody, 4 * (size_t)v.nbody, 3 * (size_t)v.nbody, 4 * (size_t)v.nbody, (size_t)v.nbody, 3 * (size_t)v.nbody,
-      3 * (size_t)v.njnt, 3 * (size_t)v.njnt, 2 * (size_t)v.njnt, (size_t)v.njnt,
-      (size_t)v.nv, (size_t)v.nv, (size_t)v.nv, 2 * (size_t)v.nbody,
-      (size_t)v.nq, (size_t)v.nq,
-      (size_t)v.nu, (size_t)v.nu, 3 * (size_t)v.nu, 2 * (size_t)v.nu, 2 * (size_t)v.nu,
-      3 * (size_t)v.ncon, (size_t)v.ncon, 3 * (size_t)v.ncon,
-      2, 5, 2, 5};
+  const BlobDims bd{v.nq, v.nv, v.nu, v.nbody, v.njnt, v.ncon, v.nlimit, v.npair, v.nlevel, v.nroot};
+  const BlobOffsets canon = blob_offsets(bd);
   const size_t dir_end = kBlobHeaderWords + 2 * (size_t)BLOB_ARRAY_COUNT;
   if (dir_end > total) return bad("directory past the end");
   for (int k = 0; k < BLOB_ARRAY_COUNT; ++k) {
     const long off = dir[2 * k], cnt = dir[2 * k + 1];
     if (off < (long)dir_end || cnt < 0 || (size_t)(off + cnt) > total || (off & 3)) return bad("array directory entry out of range");
-    if ((size_t)cnt != expect[k]) { delete m; return fail(MPPO_EMODEL, "model blob: array %d has %ld entries, expected %zu", k, cnt, expect[k]); }
+    if (cnt != blob_array_len(bd, k)) { delete m; return fail(MPPO_EMODEL, "model blob: array %d has %ld entries, expected %d", k, cnt, blob_array_len(bd, k)); }
+    if (off != canon.o[k]) { delete m; return fail(MPPO_EMODEL, "model blob: array %d sits at word %ld, canonical placement is %d", k, off, canon.o[k]); }
   }
   auto HI = [&](int k) { return wi + dir[2 * k]; };
   // index tables are validated here so that the kernel never dereferences out of range
@@ -958,7 +1085,7 @@ extern "C" int32_t mppo_model_open(const void* host_blob, size_t nbytes, const v
   if (!in_range(BI_body_parent, 0, v.nbody) || !in_range(BI_body_rootid, 0, v.nbody) || !in_range(BI_jnt_bodyid, 1, v.nbody) ||
       !in_range(BI_jnt_qposadr, 0, v.nq) || !in_range(BI_jnt_dofadr, 0, v.nv) || !in_range(BI_dof_bodyid, 1, v.nbody) ||
       !in_range(BI_dof_jntid, 0, v.njnt) || !in_range(BI_dof_parentid, -1, v.nv) || !in_range(BI_dof_qposadr, -1, v.nq) ||
-      !in_range(BI_act_dofid, 0, v.nv) || !in_range(BI_act_qposadr, 0, v.nq) || !in_range(BI_con_bodyid, 1, v.nbody) ||
+      !in_range(BI_act_dofid, 0, v.nv) || !in_range(BI_act_qposadr, 0, v.nq) || !in_range(BI_con_bodyid, 1, v.nbody) || !in_range(BI_pair_body, 1, v.nbody) ||
       !in_range(BI_lim_jntid, 0, v.njnt) || !in_range(BI_level_adr, 0, v.nbody) || !in_range(BI_level_body, 1, v.nbody) ||
       !in_range(BI_root_body, 1, v.nbody) || !in_range(BI_body_jntnum, 0, v.njnt + 1) || !in_range(BI_body_jntadr, -1, v.njnt))
     return bad("index table entry out of range");
@@ -985,6 +1112,7 @@ extern "C" int32_t mppo_model_open(const void* host_blob, size_t nbytes, const v
   v.obs_pad = (v.obs_dim + 3) & ~3;
   v.rec_dim = v.obs_pad + ((v.nv + 2 + 3) & ~3);
   m->lds = make_phys_lds(v.nq, v.nv, v.nu, v.nbody, v.njnt, v.ncon, v.nefc, v.nroot);
+  m->spec = find_spec(bd);
   m->lds_bytes = (v.blob_words + m->lds.total * kEnvsPerBlock) * 4;
   if (m->lds_bytes > 160 * 1024) { delete m; return fail(MPPO_EMODEL, "model needs %d bytes of LDS per workgroup (limit 163840)", m->lds_bytes); }
   *out = m;
@@ -1012,26 +1140,17 @@ extern "C" int32_t mppo_model_get_dims(const mppo_model_t* m, mppo_model_dims_t*
 }
 
 namespace mppo {
-template <int NV, int NEFC>
-static int32_t launch_env_t(const mppo_model_t* m, const EnvArgs& a, hipStream_t stream) {
-  static thread_local bool attr_set = false;
-  if (!attr_set && m->lds_bytes > 64 * 1024) {
-    MPPO_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(env_kernel<NV, NEFC>), hipFuncAttributeMaxDynamicSharedMemorySize, m->lds_bytes));
-    attr_set = true;
-  }
-  const int blocks = cdiv(a.N, kEnvsPerBlock);
-  hipLaunchKernelGGL((env_kernel<NV, NEFC>), dim3(blocks), dim3(kEnvBlock), m->lds_bytes, stream, m->mv, a, m->lds);
-  MPPO_CHECK_LAUNCH("env_kernel");
-  return MPPO_OK;
-}
-
 static int32_t launch_env(const mppo_model_t* m, const EnvArgs& a, hipStream_t stream) {
-  // Run-time-sized kernel.  (A <16,38> instantiation with fully unrolled inner products was measured in round 1: 287 us
-  // against 176 us — the unrolled solver no longer fits the instruction cache and no wide LDS reads were formed; the
-  // solver needs to be restructured around register-resident rows instead.  DESIGN.md section 8.)
-  return launch_env_t<0, 0>(m, a, stream);
+  const int blocks = cdiv(a.N, kEnvsPerBlock);
+  return (m->spec >= 0 ? kSpecs[m->spec].launch : &launch_env_t<RuntimeModel>)(m->mv, a, m->lds, m->lds_bytes, blocks, stream);
 }
 }  // namespace mppo
+
+extern "C" int32_t mppo_model_is_specialized(const mppo_model_t* m, int32_t* out) {
+  if (!m || !out) return mppo::fail(MPPO_EINVAL, "mppo_model_is_specialized: null argument");
+  *out = m->spec >= 0 ? 1 : 0;
+  return MPPO_OK;
+}
 
 extern "C" int32_t mppo_env_reset(const mppo_model_t* m, int32_t N, float* state, float* reset_rec, float* obs, int32_t obs_ld,
                                   float* reward, uint8_t* done, const mppo_env_metrics_t* metrics, void* stream) {

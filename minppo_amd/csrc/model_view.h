@@ -13,7 +13,7 @@ enum BlobInt {
   BI_jnt_type, BI_jnt_qposadr, BI_jnt_dofadr, BI_jnt_bodyid, BI_jnt_limited,
   BI_dof_bodyid, BI_dof_jntid, BI_dof_parentid,
   BI_act_dofid, BI_act_qposadr, BI_act_ctrllimited, BI_act_forcelimited,
-  BI_con_bodyid, BI_lim_jntid,
+  BI_con_bodyid, BI_lim_jntid, BI_pair_body,
   BI_level_adr, BI_level_body, BI_root_body, BI_body_subtree_mask, BI_body_ancdof_mask, BI_dof_velmask, BI_dof_qposadr,
   BI_COUNT
 };
@@ -23,13 +23,13 @@ enum BlobF32 {
   BF_dof_armature, BF_dof_damping, BF_dof_invweight0, BF_body_invweight0,
   BF_qpos0, BF_qpos_spring,
   BF_act_gear, BF_act_gain, BF_act_bias, BF_act_ctrlrange, BF_act_forcerange,
-  BF_con_lpos, BF_con_radius, BF_con_friction,
+  BF_con_lpos, BF_con_radius, BF_con_friction, BF_con_axis, BF_pair_geom,
   BF_contact_solref, BF_contact_solimp, BF_limit_solref, BF_limit_solimp,
   BLOB_ARRAY_COUNT
 };
 
 constexpr uint32_t kBlobMagic = 0x4D50504F;
-constexpr uint32_t kBlobVersion = 2;
+constexpr uint32_t kBlobVersion = 3;
 constexpr int kBlobHeaderWords = 64;
 constexpr int JNT_FREE = 0, JNT_HINGE = 2, JNT_SLIDE = 3;
 constexpr float MJ_MINVAL = 1e-15f, MJ_MINIMP = 0.0001f, MJ_MAXIMP = 0.9999f;
@@ -40,6 +40,7 @@ typedef unsigned long long u64;
 // from there: o[k] is the word offset of array k (BlobInt / BlobF32 index) inside the blob.
 struct ModelView {
   int nq, nv, nu, nbody, njnt, ncon, nlimit, nefc, iterations, ls_iterations, nlevel, nroot;
+  int npair;  // the last npair of the ncon contact slots are geom-geom pairs (pair_body / pair_geom); the others are ground contacts
   int obs_dim, obs_pad, rec_dim;
   int include_c;  // observation = qpos, qvel, cinert[1:], cvel[1:], qfrc_actuator (1) or qpos, qvel, qfrc_actuator (0): env.py:246-259
   float timestep, tolerance, ls_tolerance, impratio, plane_z, meaninertia;
@@ -47,6 +48,52 @@ struct ModelView {
   int blob_words;    // multiple of 4
   int o[BLOB_ARRAY_COUNT];
 };
+
+// The dims every array length follows from, and the canonical placement of the arrays (model.py _to_blob: directory order, each
+// array padded to 4 words, first array right after the directory).  mppo_model_open refuses a blob laid out differently, so a
+// kernel compiled for fixed dims may take the offsets as constants.
+struct BlobDims { int nq, nv, nu, nbody, njnt, ncon, nlimit, npair, nlevel, nroot; };
+struct BlobOffsets { int o[BLOB_ARRAY_COUNT]; int words; };
+__host__ __device__ constexpr inline int blob_array_len(const BlobDims& d, int k) {
+  switch (k) {
+    case BI_body_parent: case BI_body_rootid: case BI_body_depth: case BI_body_jntadr: case BI_body_jntnum: case BI_body_dofadr: case BI_body_dofnum:
+    case BF_body_mass: return d.nbody;
+    case BI_jnt_type: case BI_jnt_qposadr: case BI_jnt_dofadr: case BI_jnt_bodyid: case BI_jnt_limited: case BF_jnt_stiffness: return d.njnt;
+    case BI_dof_bodyid: case BI_dof_jntid: case BI_dof_parentid: case BI_dof_qposadr: case BF_dof_armature: case BF_dof_damping: case BF_dof_invweight0: return d.nv;
+    case BI_act_dofid: case BI_act_qposadr: case BI_act_ctrllimited: case BI_act_forcelimited: case BF_act_gear: case BF_act_gain: return d.nu;
+    case BI_con_bodyid: case BF_con_radius: return d.ncon;
+    case BI_lim_jntid: return d.nlimit;
+    case BI_pair_body: return 2 * d.npair;
+    case BI_level_adr: return d.nlevel + 1;
+    case BI_level_body: return d.nbody - 1;
+    case BI_root_body: return d.nroot;
+    case BI_body_subtree_mask: case BI_body_ancdof_mask: case BF_body_invweight0: return 2 * d.nbody;
+    case BI_dof_velmask: return 2 * d.nv;
+    case BF_gravity: return 3;
+    case BF_body_pos: case BF_body_ipos: case BF_body_inertia: return 3 * d.nbody;
+    case BF_body_quat: case BF_body_iquat: return 4 * d.nbody;
+    case BF_jnt_pos: case BF_jnt_axis: return 3 * d.njnt;
+    case BF_jnt_range: return 2 * d.njnt;
+    case BF_qpos0: case BF_qpos_spring: return d.nq;
+    case BF_act_bias: return 3 * d.nu;
+    case BF_act_ctrlrange: case BF_act_forcerange: return 2 * d.nu;
+    case BF_con_lpos: case BF_con_friction: case BF_con_axis: return 3 * d.ncon;
+    case BF_pair_geom: return 16 * d.npair;
+    case BF_contact_solref: case BF_limit_solref: return 2;
+    case BF_contact_solimp: case BF_limit_solimp: return 5;
+    default: return -1;
+  }
+}
+__host__ __device__ constexpr inline BlobOffsets blob_offsets(const BlobDims& d) {
+  BlobOffsets b{};
+  int cur = (64 + 2 * (int)BLOB_ARRAY_COUNT + 3) & ~3;  // kBlobHeaderWords + directory
+  for (int k = 0; k < BLOB_ARRAY_COUNT; ++k) {
+    b.o[k] = cur;
+    cur += (blob_array_len(d, k) + 3) & ~3;
+  }
+  b.words = cur;
+  return b;
+}
 
 // Per-environment LDS layout (offsets in floats).  Region "A" is time-shared: kinematics
 // temporaries and the RNE scratch live there until the constraint Jacobian is built.
@@ -57,15 +104,15 @@ struct PhysLds {
   int M, LL, ldm;  // LL packs L^-1 of M (lower part, [i][k<=i]) and of M + h*D (stored transposed at [k][i+1])
   int qfs, qas, qact, qacc, Ma, grad, Mgrad, search, mv, qfc, t0, t1;
   int D, aref, jaref, jv, force;
-  int conpos, condist;
+  int conpos, condist, confr;  // per contact slot: point, distance, frame rows (normal, first tangent)
   int A, ximat, xmat, xanchor, xaxis, C1, C2, cdofdot, cfrc, J, ldj;
   int total;
 };
 
-__host__ __device__ inline int imax_(int a, int b) { return a > b ? a : b; }
+__host__ __device__ constexpr inline int imax_(int a, int b) { return a > b ? a : b; }
 
-__host__ __device__ inline PhysLds make_phys_lds(int nq, int nv, int nu, int nbody, int njnt, int ncon, int nefc, int nroot) {
-  PhysLds p;
+__host__ __device__ constexpr inline PhysLds make_phys_lds(int nq, int nv, int nu, int nbody, int njnt, int ncon, int nefc, int nroot) {
+  PhysLds p{};
   int o = 0;
   auto take = [&](int n) { int r = o; o += (n + 3) & ~3; return r; };
   p.qpos = take(nq); p.qvel = take(nv); p.ctrl = take(nu > 0 ? nu : 1); p.warm = take(nv);
@@ -77,7 +124,7 @@ __host__ __device__ inline PhysLds make_phys_lds(int nq, int nv, int nu, int nbo
   p.Mgrad = take(nv); p.search = take(nv); p.mv = take(nv); p.qfc = take(nv); p.t0 = take(nv); p.t1 = take(nv);
   const int ne = nefc > 0 ? nefc : 1;
   p.D = take(ne); p.aref = take(ne); p.jaref = take(ne); p.jv = take(ne); p.force = take(ne);
-  p.conpos = take(3 * (ncon > 0 ? ncon : 1)); p.condist = take(ncon > 0 ? ncon : 1);
+  p.conpos = take(3 * (ncon > 0 ? ncon : 1)); p.condist = take(ncon > 0 ? ncon : 1); p.confr = take(6 * (ncon > 0 ? ncon : 1));
   // region A, four lifetimes (separated by workgroup barriers in the kernel):
   //   A1 kinematics temporaries | A2 Cholesky work copies | A3 velocity/RNE scratch | A4 constraint Jacobian
   p.A = o;

@@ -22,8 +22,8 @@ Subset
             (a box collides with the ground through its eight corners; type="cylinder|ellipsoid|mesh" geoms are accepted ONLY with
              contype="0" conaffinity="0", i.e. visual or inertia-only; cylinder / ellipsoid then still contribute to inertiafromgeom)
   <actuator>: <position joint kp kv gear ctrlrange forcerange>, <motor joint gear ctrlrange forcerange>
-Contacts: geom-vs-ground-plane only (what the stand-in robots need); robot self-collision pairs are not generated, a
-warning says so when the MJCF's contype / conaffinity masks would enable them.
+Contacts: geom-vs-ground-plane, and sphere / capsule geom pairs between bodies that MuJoCo would test (contype / conaffinity
+masks, same-body and parent-child pairs filtered); a box that the masks pair with another geom is an error (`compile_model`).
 """
 
 from __future__ import annotations
@@ -299,7 +299,6 @@ def parse_mjcf(xml: str, name: str = "mjcf") -> ModelSpec:
     bodies: List[BodySpec] = []
     plane: Optional[Dict[str, object]] = None
     solrefs = {"limit": set(), "contact": set()}
-    self_collision_masks: List[Tuple[int, int]] = []
     free_z: List[float] = []
 
     def geom_spec(a: Dict[str, str], what: str):
@@ -311,7 +310,7 @@ def parse_mjcf(xml: str, name: str = "mjcf") -> ModelSpec:
         pos = np.array(_floats(a.get("pos", "0 0 0"), 3, what))
         size = _floats(a["size"]) if "size" in a else []
         if gtype == "plane":
-            return "plane", dict(z=float(pos[2]), friction=tuple((_floats(a.get("friction", "1 0.005 0.0001")) + [0.005, 0.0001])[:3]) if "friction" in a else (1.0, 0.005, 0.0001),
+            return "plane", dict(contype=contype, conaffinity=conaff, z=float(pos[2]), friction=tuple((_floats(a.get("friction", "1 0.005 0.0001")) + [0.005, 0.0001])[:3]) if "friction" in a else (1.0, 0.005, 0.0001),
                                  quat=quat, a=a), None
         if "fromto" in a:
             if gtype not in ("capsule", "cylinder", "box", "ellipsoid"):
@@ -345,9 +344,9 @@ def parse_mjcf(xml: str, name: str = "mjcf") -> ModelSpec:
             raise ValueError(f"{what}: contact margin / gap are not supported")
         if int(a.get("condim", "3")) != 3:
             raise ValueError(f"{what}: condim {a['condim']} (only 3: pyramidal sliding friction)")
-        self_collision_masks.append((contype, conaff))
         fr = tuple((_floats(a["friction"]) + [0.005, 0.0001])[:3]) if "friction" in a else (1.0, 0.005, 0.0001)
-        gs = GeomSpec({"sphere": GEOM_SPHERE, "capsule": GEOM_CAPSULE, "box": GEOM_BOX}[gtype], tuple(size[:need]), pos=tuple(pos), quat=tuple(quat), friction=fr)
+        gs = GeomSpec({"sphere": GEOM_SPHERE, "capsule": GEOM_CAPSULE, "box": GEOM_BOX}[gtype], tuple(size[:need]), pos=tuple(pos), quat=tuple(quat), friction=fr,
+                      contype=contype, conaffinity=conaff)
         return "collide", gs, part
 
     def walk(el: ET.Element, parent: str, childclass: Optional[str]) -> None:
@@ -443,8 +442,9 @@ def parse_mjcf(xml: str, name: str = "mjcf") -> ModelSpec:
         elif inertial is None:
             raise ValueError(f"body {bname}: no <inertial> (inertiafromgeom='false')")
         if any(j.type == JNT_FREE for j in joints):
-            free_z.append(pos[2])  # ModelSpec keeps the height of a free root separately (qpos0[2] = free_root_z)
-            pos = (pos[0], pos[1], 0.0)
+            free_z.append(pos[2])
+            if len(free_z) == 1:  # ModelSpec keeps the height of the first free root separately (qpos0[2] = free_root_z)
+                pos = (pos[0], pos[1], 0.0)
         bodies.append(BodySpec(bname, parent, pos=pos, quat=tuple(quat), mass=inertial[0], inertia=inertial[3], ipos=inertial[1], iquat=inertial[2],
                                joints=joints, geoms=geoms))
         for ch in el.findall("body"):
@@ -471,8 +471,6 @@ def parse_mjcf(xml: str, name: str = "mjcf") -> ModelSpec:
     if not bodies:
         raise ValueError("MJCF has no bodies")
 
-    if len(free_z) > 1:
-        raise ValueError("more than one free-floating body: the engine models one robot per environment")
     free_root_z = float(free_z[0]) if free_z else 1.0
 
     joint_names = {j.name for b in bodies for j in b.joints}
@@ -520,15 +518,13 @@ def parse_mjcf(xml: str, name: str = "mjcf") -> ModelSpec:
     if plane is not None:
         spec_kw["plane_z"] = plane["z"]
         spec_kw["plane_friction"] = plane["friction"]
+        spec_kw["plane_contype"], spec_kw["plane_conaffinity"] = plane["contype"], plane["conaffinity"]
         for k in ("solref", "solimp"):
             if k in plane["a"] and (k, tuple(_floats(plane["a"][k]))) not in solrefs["contact"]:
                 logger.warning("ground plane %s is ignored: contact parameters are taken from the robot's geoms (MuJoCo mixes both by solmix)", k)
     else:
-        logger.warning("MJCF has no ground plane: no contacts will be generated")
-    ncoll = len(self_collision_masks)
-    if ncoll > 1 and any((self_collision_masks[i][0] & self_collision_masks[j][1]) or (self_collision_masks[j][0] & self_collision_masks[i][1])
-                         for i in range(ncoll) for j in range(i + 1, ncoll)):
-        logger.warning("contype / conaffinity of this MJCF enable robot self-collisions; the engine generates geom-vs-ground contacts only")
+        spec_kw["has_plane"] = False
+        logger.warning("MJCF has no ground plane: only geom-geom contacts will be generated")
     return ModelSpec(name=name, bodies=bodies, actuators=acts, free_root_z=free_root_z, **spec_kw)
 
 
@@ -555,12 +551,16 @@ def to_mjcf(spec: ModelSpec) -> str:
     del d
     ET.SubElement(root.find("default"), "geom", solref=_fmt(spec.contact_solref), solimp=_fmt(spec.contact_solimp), condim="3")
     world = ET.SubElement(root, "worldbody")
-    ET.SubElement(world, "geom", name="floor", type="plane", size="0 0 1", pos=f"0 0 {float(spec.plane_z)!r}", friction=_fmt(spec.plane_friction))
+    if spec.has_plane:
+        ET.SubElement(world, "geom", name="floor", type="plane", size="0 0 1", pos=f"0 0 {float(spec.plane_z)!r}", friction=_fmt(spec.plane_friction),
+                      contype=str(spec.plane_contype), conaffinity=str(spec.plane_conaffinity))
     els = {"world": world}
+    first_free = True
     for b in spec.bodies:
         pos = list(b.pos)
-        if any(j.type == JNT_FREE for j in b.joints):
+        if any(j.type == JNT_FREE for j in b.joints) and first_free:
             pos[2] = spec.free_root_z
+            first_free = False
         e = ET.SubElement(els[b.parent], "body", name=b.name, pos=_fmt(pos), quat=_fmt(b.quat))
         els[b.name] = e
         ET.SubElement(e, "inertial", pos=_fmt(b.ipos), quat=_fmt(b.iquat), mass=repr(float(b.mass)), diaginertia=_fmt(b.inertia))
@@ -574,7 +574,8 @@ def to_mjcf(spec: ModelSpec) -> str:
                 a["range"] = _fmt(j.range)
             ET.SubElement(e, "joint", **a)
         for g in b.geoms:
-            ET.SubElement(e, "geom", type={GEOM_SPHERE: "sphere", GEOM_CAPSULE: "capsule", GEOM_BOX: "box"}[g.type], size=_fmt(g.size), pos=_fmt(g.pos), quat=_fmt(g.quat), friction=_fmt(g.friction))
+            ET.SubElement(e, "geom", type={GEOM_SPHERE: "sphere", GEOM_CAPSULE: "capsule", GEOM_BOX: "box"}[g.type], size=_fmt(g.size), pos=_fmt(g.pos), quat=_fmt(g.quat), friction=_fmt(g.friction),
+                          contype=str(g.contype), conaffinity=str(g.conaffinity))
     act = ET.SubElement(root, "actuator")
     for a in spec.actuators:
         kw = dict(joint=a.joint, gear=repr(float(a.gear)))

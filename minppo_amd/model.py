@@ -37,7 +37,7 @@ GEOM_SPHERE, GEOM_CAPSULE, GEOM_BOX = 2, 3, 6  # MuJoCo's mjtGeom numbering
 MJ_MINVAL = 1e-15
 
 BLOB_MAGIC = 0x4D50504F  # "MPPO"
-BLOB_VERSION = 2  # 2: header word include_c_vals
+BLOB_VERSION = 3  # 2: header word include_c_vals; 3: geom-geom pairs (npair, pair_body, pair_geom) and con_axis
 
 
 # ---------------------------------------------------------------------------
@@ -65,6 +65,11 @@ class GeomSpec:
     pos: Sequence[float] = (0.0, 0.0, 0.0)
     quat: Sequence[float] = (1.0, 0.0, 0.0, 0.0)
     friction: Sequence[float] = (1.0, 0.005, 0.0001)
+    # MuJoCo's collision masks: two geoms are candidates iff (contype1 & conaffinity2) | (contype2 & conaffinity1).  The defaults
+    # here (0 / 1, against the plane's 1 / 1) make a geom collide with the ground only; the MJCF loader passes the file's values
+    # (MuJoCo's own default is 1 / 1: every pair that is not parent-child).
+    contype: int = 0
+    conaffinity: int = 1
 
 
 @dataclass
@@ -110,7 +115,10 @@ class ModelSpec:
     limit_solimp: Sequence[float] = (0.9, 0.95, 0.001, 0.5, 2.0)
     plane_friction: Sequence[float] = (1.0, 0.005, 0.0001)
     plane_z: float = 0.0
-    free_root_z: float = 1.0  # qpos0[2] of the free joint
+    plane_contype: int = 1
+    plane_conaffinity: int = 1
+    has_plane: bool = True
+    free_root_z: float = 1.0  # qpos0[2] of the (first) free joint
 
 
 # ---------------------------------------------------------------------------
@@ -190,6 +198,11 @@ class CompiledModel:
         return int(self.t["ncon"])
 
     @property
+    def npair(self) -> int:
+        """geom-geom candidates: the last `npair` of the `ncon` contact slots (the first ncon - npair are ground contacts)."""
+        return int(self.t["npair"])
+
+    @property
     def nlimit(self) -> int:
         return int(self.t["nlimit"])
 
@@ -237,9 +250,10 @@ def compile_model(spec: ModelSpec) -> CompiledModel:
     joint_names: List[str] = []
     dof_bodyid, dof_jntid, dof_armature, dof_damping = [], [], [], []
     qpos0: List[float] = []
-    geoms = []  # (type, bodyid, pos, quat, size, friction)
+    geoms = []  # (type, bodyid, pos, quat, size, friction, contype, conaffinity)
 
     nq = nv = 0
+    seen_free = False
     for bi, b in enumerate(spec.bodies, start=1):
         if b.parent not in names[:bi]:
             raise ValueError(f"body {b.name}: parent {b.parent!r} must be defined earlier")
@@ -271,7 +285,9 @@ def compile_model(spec: ModelSpec) -> CompiledModel:
             if j.type == JNT_FREE:
                 if body_parent[bi] != 0 or len(b.joints) != 1:
                     raise ValueError("free joint only on a top-level body, alone")
-                qpos0 += [b.pos[0], b.pos[1], spec.free_root_z, *body_quat[bi]]
+                # the first free body stands at free_root_z (the robot's root); further free bodies keep their own height
+                qpos0 += [b.pos[0], b.pos[1], spec.free_root_z if not seen_free else b.pos[2], *body_quat[bi]]
+                seen_free = True
                 nq += 7
                 for _ in range(6):
                     dof_bodyid.append(bi)
@@ -292,7 +308,7 @@ def compile_model(spec: ModelSpec) -> CompiledModel:
         body_dofnum[bi] = nv - (body_dofadr[bi] if body_dofadr[bi] >= 0 else nv)
         for g in b.geoms:
             size = list(g.size) + [0.0] * (3 - len(g.size))
-            geoms.append((g.type, bi, list(g.pos), list(_normalize(g.quat)), size, list(g.friction)))
+            geoms.append((g.type, bi, list(g.pos), list(_normalize(g.quat)), size, list(g.friction), int(g.contype), int(g.conaffinity)))
 
     njnt = len(jnt_type)
     # dof_parentid: previous dof in the same body, else last dof of the nearest ancestor with dofs
@@ -391,27 +407,73 @@ def compile_model(spec: ModelSpec) -> CompiledModel:
             act_forcerange[ai] = a.forcerange
             act_forcelimited[ai] = 1
 
-    # collision candidates: every sphere / capsule end / box corner against the ground plane
-    con_bodyid, con_lpos, con_radius, con_friction = [], [], [], []
-    for (gt, bi, gpos, gquat, gsize, gfri) in geoms:
+    # collision candidates, MJX-style static slots.  First every sphere / capsule end / box corner against the ground plane ...
+    def _masks_match(ct1, ca1, ct2, ca2):
+        return bool((ct1 & ca2) | (ct2 & ca1))
+
+    con_bodyid, con_lpos, con_radius, con_friction, con_axis = [], [], [], [], []
+    for (gt, bi, gpos, gquat, gsize, gfri, gct, gca) in geoms:
+        if gt not in (GEOM_SPHERE, GEOM_CAPSULE, GEOM_BOX):
+            raise ValueError(f"unsupported geom type {gt}")
+        if not spec.has_plane or not _masks_match(spec.plane_contype, spec.plane_conaffinity, gct, gca):
+            continue
         fri = np.maximum(np.asarray(gfri), np.asarray(spec.plane_friction))
+        axis_l = np.zeros(3)
         if gt == GEOM_SPHERE:
             ends = [np.asarray(gpos, dtype=np.float64)]
         elif gt == GEOM_CAPSULE:
-            axis = _qrot(gquat, [0, 0, 1.0]) * gsize[1]
+            axis_l = _qrot(gquat, [0, 0, 1.0])  # the two end contacts share a frame whose first tangent follows this axis
+            axis = axis_l * gsize[1]
             ends = [np.asarray(gpos) + axis, np.asarray(gpos) - axis]
-        elif gt == GEOM_BOX:
+        else:
             # a box against the ground plane touches with its corners: eight point contacts (radius 0).  MuJoCo's plane-box
             # routine reports at most four of them per step - the same set whenever no more than four corners penetrate,
             # which is every pose of a box that is not sunk to its middle.
             ends = [np.asarray(gpos) + _qrot(gquat, [sx * gsize[0], sy * gsize[1], sz * gsize[2]]) for sx in (-1.0, 1.0) for sy in (-1.0, 1.0) for sz in (-1.0, 1.0)]
-        else:
-            raise ValueError(f"unsupported geom type {gt}")
         for e in ends:
             con_bodyid.append(bi)
             con_lpos.append(list(e))
             con_radius.append(0.0 if gt == GEOM_BOX else gsize[0])
             con_friction.append(list(fri))
+            con_axis.append(list(axis_l))
+    nplane = len(con_bodyid)
+    # ... then geom-geom pairs between different bodies (sphere / capsule only), filtered as MuJoCo filters them: same weld
+    # group and parent-child weld groups are skipped (mj_filterBodyPair), then the contype / conaffinity masks.  geom1 is the
+    # one with the smaller type id (sphere before capsule); groups are ordered (sphere, sphere), (sphere, capsule),
+    # (capsule, capsule) like MJX's collision-function table.
+    weld = np.arange(nbody)
+    for b in range(1, nbody):
+        if body_jntnum[b] == 0:
+            weld[b] = weld[body_parent[b]]
+    pair_rows = []
+    for i in range(len(geoms)):
+        for j in range(i + 1, len(geoms)):
+            gi, gj = geoms[i], geoms[j]
+            if gi[0] > gj[0]:
+                gi, gj = gj, gi
+            w1, w2 = weld[gi[1]], weld[gj[1]]
+            if w1 == w2:
+                continue
+            if w1 != 0 and w2 != 0 and (w1 == weld[body_parent[w2]] or w2 == weld[body_parent[w1]]):
+                continue
+            if not _masks_match(gi[6], gi[7], gj[6], gj[7]):
+                continue
+            if GEOM_BOX in (gi[0], gj[0]):
+                raise ValueError("a box geom can only collide with the ground plane: exclude it from geom-geom pairs with contype / conaffinity")
+            pair_rows.append(((gi[0], gj[0]), gi, gj))
+    pair_rows.sort(key=lambda r: r[0])  # stable: geom order inside a group
+    pair_body, pair_geom = [], []
+    for _, gi, gj in pair_rows:
+        pair_body += [gi[1], gj[1]]
+        for g_ in (gi, gj):
+            half = _qrot(g_[3], [0, 0, 1.0]) * g_[4][1] if g_[0] == GEOM_CAPSULE else np.zeros(3)
+            pair_geom += [*g_[2], *half, g_[4][0], 0.0]
+        con_bodyid.append(gj[1])
+        con_lpos.append([0.0, 0.0, 0.0])
+        con_radius.append(0.0)
+        con_friction.append(list(np.maximum(np.asarray(gi[5]), np.asarray(gj[5]))))
+        con_axis.append([0.0, 0.0, 0.0])
+    npair = len(pair_rows)
     ncon = len(con_bodyid)
 
     lim_jnt = [j for j in range(njnt) if jnt_limited[j] and jnt_type[j] != JNT_FREE]
@@ -422,7 +484,7 @@ def compile_model(spec: ModelSpec) -> CompiledModel:
     def put(k, v, dt=np.float64):
         t[k] = np.asarray(v, dtype=dt)
 
-    for k, v in dict(nq=nq, nv=nv, nu=nu, nbody=nbody, njnt=njnt, ncon=ncon, nlimit=nlimit,
+    for k, v in dict(nq=nq, nv=nv, nu=nu, nbody=nbody, njnt=njnt, ncon=ncon, nlimit=nlimit, npair=npair,
                      iterations=spec.iterations, ls_iterations=spec.ls_iterations).items():
         put(k, v, np.int32)
     for k, v in dict(timestep=spec.timestep, tolerance=spec.tolerance, ls_tolerance=spec.ls_tolerance,
@@ -480,6 +542,9 @@ def compile_model(spec: ModelSpec) -> CompiledModel:
     put("con_lpos", np.reshape(con_lpos, (ncon, 3)))
     put("con_radius", con_radius)
     put("con_friction", np.reshape(con_friction, (ncon, 3)))
+    put("con_axis", np.reshape(con_axis, (ncon, 3)))
+    put("pair_body", np.reshape(pair_body, (npair, 2)), np.int32)
+    put("pair_geom", np.reshape(pair_geom, (npair, 16)))
     put("lim_jntid", lim_jnt, np.int32)
     put("contact_solref", spec.contact_solref)
     put("contact_solimp", spec.contact_solimp)
@@ -626,7 +691,7 @@ _BLOB_INT = [
     "jnt_type", "jnt_qposadr", "jnt_dofadr", "jnt_bodyid", "jnt_limited",
     "dof_bodyid", "dof_jntid", "dof_parentid",
     "act_dofid", "act_qposadr", "act_ctrllimited", "act_forcelimited",
-    "con_bodyid", "lim_jntid",
+    "con_bodyid", "lim_jntid", "pair_body",
     "level_adr", "level_body", "root_body", "body_subtree_mask", "body_ancdof_mask", "dof_velmask", "dof_qposadr",
 ]
 _BLOB_F32 = [
@@ -635,10 +700,10 @@ _BLOB_F32 = [
     "dof_armature", "dof_damping", "dof_invweight0", "body_invweight0",
     "qpos0", "qpos_spring",
     "act_gear", "act_gain", "act_bias", "act_ctrlrange", "act_forcerange",
-    "con_lpos", "con_radius", "con_friction",
+    "con_lpos", "con_radius", "con_friction", "con_axis", "pair_geom",
     "contact_solref", "contact_solimp", "limit_solref", "limit_solimp",
 ]
-_HDR_INT = ["nq", "nv", "nu", "nbody", "njnt", "ncon", "nlimit", "iterations", "ls_iterations", "nlevel", "nroot", "include_c_vals"]
+_HDR_INT = ["nq", "nv", "nu", "nbody", "njnt", "ncon", "nlimit", "iterations", "ls_iterations", "nlevel", "nroot", "include_c_vals", "npair"]
 _HDR_F32 = ["timestep", "tolerance", "ls_tolerance", "impratio", "plane_z", "meaninertia"]
 BLOB_HEADER_WORDS = 64  # fixed-size header; array directory follows
 
@@ -735,7 +800,7 @@ def _arm(side: str, y: float) -> List[BodySpec]:
     ]
 
 
-def _humanoid(name: str, arms: bool) -> ModelSpec:
+def _humanoid(name: str, arms: bool, self_collide: bool = False) -> ModelSpec:
     torso = BodySpec(
         "torso", "world", pos=(0.0, 0.0, 0.0), mass=10.0 if not arms else 9.0, inertia=(0.12, 0.10, 0.06),
         ipos=(0.0, 0.0, 0.12),
@@ -755,6 +820,10 @@ def _humanoid(name: str, arms: bool) -> ModelSpec:
                                  forcerange=(-60.0, 60.0) if leg else (-20.0, 20.0)))
     # standing height: hip chain 0.10+0.05+0.05, thigh 0.38, shin 0.36, foot capsule centre 0.04 below ankle, r=0.03
     root_z = 0.10 + 0.05 + 0.05 + 0.38 + 0.36 + 0.04 + 0.03 - 0.0005
+    if self_collide:  # MuJoCo's default masks: every geom pair that is not parent-child is a candidate
+        for b in bodies:
+            for g_ in b.geoms:
+                g_.contype = 1
     return ModelSpec(name=name, bodies=bodies, actuators=acts, free_root_z=root_z)
 
 
@@ -766,6 +835,26 @@ def synth_stompy_pro() -> ModelSpec:
 def synth_stompy_full() -> ModelSpec:
     """Stand-in with a larger action dimension (BASELINE config 5): + 2 arms x 5 hinges."""
     return _humanoid("synth_stompy_full", arms=True)
+
+
+def synth_stompy_pro_sc() -> ModelSpec:
+    """synth_stompy_pro with MuJoCo's default collision masks: + 8 geom-geom candidates (torso / shins / feet across the legs)."""
+    return _humanoid("synth_stompy_pro_sc", arms=False, self_collide=True)
+
+
+def synth_tumblers() -> ModelSpec:
+    """Three free bodies (sphere, two capsules) that collide with each other and with the ground: all three pair routines,
+    several kinematic trees."""
+    cap = (0.70710678, 0.0, 0.70710678, 0.0)  # capsule axis along x
+    bodies = [
+        BodySpec("ball", "world", pos=(0.0, 0.0, 0.0), mass=1.0, inertia=(0.004, 0.004, 0.004),
+                 joints=[JointSpec("ball_root", JNT_FREE)], geoms=[GeomSpec(GEOM_SPHERE, (0.1,), contype=1)]),
+        BodySpec("rod_a", "world", pos=(0.25, 0.0, 0.4), mass=0.8, inertia=(0.002, 0.012, 0.012),
+                 joints=[JointSpec("rod_a_root", JNT_FREE)], geoms=[GeomSpec(GEOM_CAPSULE, (0.05, 0.2), quat=cap, contype=1)]),
+        BodySpec("rod_b", "world", pos=(0.0, 0.3, 0.45), mass=0.6, inertia=(0.010, 0.010, 0.001),
+                 joints=[JointSpec("rod_b_root", JNT_FREE)], geoms=[GeomSpec(GEOM_CAPSULE, (0.04, 0.15), contype=1)]),
+    ]
+    return ModelSpec(name="synth_tumblers", bodies=bodies, actuators=[], free_root_z=0.4)
 
 
 def synth_pendulum() -> ModelSpec:
@@ -804,6 +893,8 @@ KSCALE_ID_TABLE = {
 BUILTIN_MODELS = {
     "synth_stompy_pro": synth_stompy_pro,
     "synth_stompy_full": synth_stompy_full,
+    "synth_stompy_pro_sc": synth_stompy_pro_sc,
+    "synth_tumblers": synth_tumblers,
     "synth_pendulum": synth_pendulum,
     "synth_ball": synth_ball,
     "synth_brick": synth_brick,

@@ -131,6 +131,55 @@ def make_frame(a):
     return np.stack([a, b, np.cross(a, b)], -2)
 
 
+def _normalize_with_norm(x):
+    """MJX math.normalize_with_norm: x / (|x| + 1e-6 [|x| == 0]), |x|."""
+    n = np.linalg.norm(x, axis=-1)
+    return x / (n + x.dtype.type(1e-6) * (n == 0).astype(x.dtype))[..., None], n
+
+
+def closest_segment_point(a, b, pt):
+    """MJX math.closest_segment_point: the point of segment a-b nearest to pt."""
+    ab = b - a
+    tt = np.sum((pt - a) * ab, -1) / (np.sum(ab * ab, -1) + 1e-6)
+    return a + np.clip(tt, 0.0, 1.0)[..., None] * ab
+
+
+def closest_segment_to_segment_points(a0, a1, b0, b1):
+    """MJX math.closest_segment_to_segment_points (the routine behind sphere_capsule / capsule_capsule; a sphere is a segment
+    of length 0): minimise over the two infinite lines, clip to the half lengths, then repair the clipping by projecting each
+    clipped point on the other segment and keeping the closer of the two repairs."""
+    dir_a, len_a = _normalize_with_norm(a1 - a0)
+    dir_b, len_b = _normalize_with_norm(b1 - b0)
+    half_a, half_b = 0.5 * len_a, 0.5 * len_b
+    a_mid = a0 + dir_a * half_a[..., None]
+    b_mid = b0 + dir_b * half_b[..., None]
+    trans = a_mid - b_mid
+    dab = np.sum(dir_a * dir_b, -1)
+    dat = np.sum(dir_a * trans, -1)
+    dbt = np.sum(dir_b * trans, -1)
+    denom = 1 - dab * dab
+    ta = (-dat + dab * dbt) / (denom + 1e-6)
+    tb = dbt + ta * dab
+    ta = np.clip(ta, -half_a, half_a)
+    tb = np.clip(tb, -half_b, half_b)
+    best_a = a_mid + dir_a * ta[..., None]
+    best_b = b_mid + dir_b * tb[..., None]
+    new_a = closest_segment_point(a0, a1, best_b)
+    new_b = closest_segment_point(b0, b1, best_a)
+    d1 = np.sum((new_a - best_b) ** 2, -1)
+    d2 = np.sum((new_b - best_a) ** 2, -1)
+    pick = (d1 < d2)[..., None]
+    return np.where(pick, new_a, best_a), np.where(pick, best_b, new_b)
+
+
+def sphere_sphere(pos1, r1, pos2, r2):
+    """MJX collision_primitive._sphere_sphere -> dist, contact point, normal (from geom 1 to geom 2; +x when the centres coincide)."""
+    n, dist = _normalize_with_norm(pos2 - pos1)
+    n = np.where((dist == 0)[..., None], np.array([1.0, 0.0, 0.0], n.dtype), n)
+    dist = dist - (r1 + r2)
+    return dist, pos1 + n * (r1 + 0.5 * dist)[..., None], n
+
+
 # ---------------------------------------------------------------------------
 # data container
 # ---------------------------------------------------------------------------
@@ -158,6 +207,7 @@ class Physics:
         self.nq, self.nv, self.nu = int(t["nq"]), int(t["nv"]), int(t["nu"])
         self.nbody, self.njnt = int(t["nbody"]), int(t["njnt"])
         self.ncon, self.nlimit = int(t["ncon"]), int(t["nlimit"])
+        self.npair = int(t.get("npair", 0))
         self.nefc = self.nlimit + 4 * self.ncon
         self.n_frames = n_frames
         self.timestep = float(t["timestep"])
@@ -291,21 +341,44 @@ class Physics:
         return J
 
     def collision(self, d: PhysState) -> None:
-        """Plane-sphere / plane-capsule-end contacts: every candidate keeps a slot (MJX static shapes)."""
+        """Every candidate keeps a slot (MJX static shapes).  The first ncon - npair slots are ground contacts (MJX
+        collision_primitive.plane_sphere / plane_capsule; a box corner is a sphere of radius 0), the last npair are geom-geom
+        pairs (sphere_sphere / sphere_capsule / capsule_capsule: one contact each)."""
         t = self.t
         N = d.qpos.shape[0]
-        nc = self.ncon
-        dist = np.zeros((N, nc), self.dtype)
-        cpos = np.zeros((N, nc, 3), self.dtype)
-        n = np.array([0.0, 0.0, 1.0], self.dtype)
-        for c in range(nc):
+        nc, npair = self.ncon, self.npair
+        dt = self.dtype
+        dist = np.zeros((N, nc), dt)
+        cpos = np.zeros((N, nc, 3), dt)
+        frame = np.zeros((N, nc, 3, 3), dt)
+        n = np.array([0.0, 0.0, 1.0], dt)
+        for c in range(nc - npair):
             b = t["con_bodyid"][c]
             centre = d.xpos[:, b] + qrot(d.xquat[:, b], t["con_lpos"][c])
             r = t["con_radius"][c]
             dist[:, c] = centre[:, 2] - t["plane_z"] - r
             cpos[:, c] = centre - n * (r + 0.5 * dist[:, c])[:, None]
-        d["con_dist"], d["con_pos"] = dist, cpos
-        d["con_frame"] = np.broadcast_to(make_frame(n[None])[0], (N, nc, 3, 3))
+            # plane_capsule aligns the first tangent with the capsule axis projected on the plane, unless that projection is
+            # shorter than 0.5 (then, and for spheres, make_frame's choice: +y for a z normal)
+            axis = qrot(d.xquat[:, b], np.broadcast_to(t["con_axis"][c], (N, 3)).astype(dt))
+            bvec = axis - n * (axis @ n)[:, None]
+            bn = np.linalg.norm(bvec, axis=-1)
+            t1 = np.where((bn < 0.5)[:, None], np.array([0.0, 1.0, 0.0], dt), bvec / np.maximum(bn, dt.type(1e-30))[:, None])
+            frame[:, c, 0], frame[:, c, 1], frame[:, c, 2] = n, t1, np.cross(np.broadcast_to(n, (N, 3)), t1)
+        for k in range(npair):
+            c = nc - npair + k
+            b1, b2 = t["pair_body"][k]
+            g = t["pair_geom"][k]
+            p1, h1, r1 = g[0:3], g[3:6], g[6]
+            p2, h2, r2 = g[8:11], g[11:14], g[14]
+            c1 = d.xpos[:, b1] + qrot(d.xquat[:, b1], p1)
+            c2 = d.xpos[:, b2] + qrot(d.xquat[:, b2], p2)
+            a1 = qrot(d.xquat[:, b1], np.broadcast_to(h1, (N, 3)).astype(dt))
+            a2 = qrot(d.xquat[:, b2], np.broadcast_to(h2, (N, 3)).astype(dt))
+            q1, q2 = closest_segment_to_segment_points(c1 - a1, c1 + a1, c2 - a2, c2 + a2)
+            dist[:, c], cpos[:, c], nn = sphere_sphere(q1, r1, q2, r2)
+            frame[:, c] = make_frame(nn)
+        d["con_dist"], d["con_pos"], d["con_frame"] = dist, cpos, frame
 
     def _kbi(self, solref, solimp, pos):
         dt = self.dtype
@@ -357,10 +430,14 @@ class Physics:
         for c in range(self.ncon):
             b = t["con_bodyid"][c]
             a = d.con_dist[:, c] < 0
-            jp = self.jacp(d, d.con_pos[:, c], b)  # [N,3,nv]   (body1 = world -> zero)
+            jp = self.jacp(d, d.con_pos[:, c], b)  # [N,3,nv]   (ground contacts: body1 = world -> zero)
+            tw = t["body_invweight0"][b, 0]
+            if c >= self.ncon - self.npair:  # geom-geom: relative motion of body2 against body1, both translational weights
+                b1 = t["pair_body"][c - (self.ncon - self.npair)][0]
+                jp = jp - self.jacp(d, d.con_pos[:, c], b1)
+                tw = tw + t["body_invweight0"][b1, 0]
             jc = np.einsum("nij,njv->niv", d.con_frame[:, c], jp)  # rows: normal, t1, t2
             fri = t["con_friction"][c]
-            tw = t["body_invweight0"][b, 0]
             iw = (tw + fri[0] * fri[0] * tw) * 2 * fri[0] * fri[0] / t["impratio"]
             r = row
             for k in (1, 2):

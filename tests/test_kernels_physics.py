@@ -219,6 +219,177 @@ def test_box_collider_corner_contacts(be, steps, min_rows, med):
     be.lib.model_close(h)
 
 
+def _pair_states(model, cm, N, rng):
+    """states in which geom-geom candidates overlap"""
+    q = np.tile(cm.t["qpos0"], (N, 1)).astype(np.float64)
+    if model == "synth_tumblers":
+        # a cluster high above the ground (last env: just above it, so ground and pair rows mix).  Each rod touches the ball
+        # with 2..20 mm of penetration somewhere along its length; in the odd envs rod_b is instead laid across rod_a
+        # (capsule-capsule), env 1 with parallel axes.
+        def unit(v):
+            return v / np.linalg.norm(v, axis=-1, keepdims=True)
+
+        def arc(a, b):  # shortest-arc quaternion turning unit a into unit b
+            w = 1.0 + np.sum(a * b, -1, keepdims=True)
+            return unit(np.concatenate([w, np.cross(a, b)], -1))
+
+        ball = np.array([0.0, 0.0, 1.5]) + 0.01 * rng.standard_normal((N, 3))
+        ua, ub = unit(rng.standard_normal((N, 3))), unit(rng.standard_normal((N, 3)))
+        ub[1] = ua[1]
+        wa = unit(np.cross(ua, rng.standard_normal((N, 3))))
+        ca = ball + wa * (0.1 + 0.05 - rng.uniform(0.002, 0.02, (N, 1))) + ua * rng.uniform(-0.15, 0.15, (N, 1))
+        wb = unit(np.cross(ub, rng.standard_normal((N, 3))))
+        cb = ball + wb * (0.1 + 0.04 - rng.uniform(0.002, 0.02, (N, 1))) + ub * rng.uniform(-0.1, 0.1, (N, 1))
+        wab = unit(np.cross(ua, ub + 1e-9))
+        wab[1] = wa[1]
+        cb_x = ca + ua * rng.uniform(-0.1, 0.1, (N, 1)) + wab * (0.05 + 0.04 - rng.uniform(0.002, 0.02, (N, 1)))
+        cb[1::2] = cb_x[1::2]
+        q[:, 0:3] = ball
+        q[:, 7:10], q[:, 10:14] = ca, arc(np.broadcast_to([1.0, 0.0, 0.0], (N, 3)), ua)   # rod_a's capsule lies along its body x
+        q[:, 14:17], q[:, 17:21] = cb, arc(np.broadcast_to([0.0, 0.0, 1.0], (N, 3)), ub)  # rod_b's along its body z
+        q[-1, 2::7] -= q[-1, 2::7].min() - 0.12
+    else:
+        # legs closed like scissors: both legs share pitch / knee / ankle angles (plus noise), hip roll inwards by 0.05..0.15 rad
+        # (knees meet from 0.105, feet from 0.08), the feet turned by different yaw angles so that the foot capsules are not parallel
+        names = cm.joint_names[1:]
+        shared = {"hip_pitch": rng.uniform(-0.4, 0.2, N), "knee": rng.uniform(0.0, 0.5, N), "ankle": rng.uniform(-0.3, 0.3, N)}
+        roll = rng.uniform(0.05, 0.15, N)
+        for k, nm in enumerate(names):
+            side, part = nm.split("_", 1)
+            if part in shared:
+                q[:, 7 + k] = shared[part] + 0.03 * rng.standard_normal(N)
+            elif part == "hip_roll":
+                q[:, 7 + k] = -roll if side == "left" else roll
+            elif part == "hip_yaw":
+                q[:, 7 + k] = rng.uniform(0.2, 0.7, N) * (1.0 if side == "left" else -1.0) * rng.choice([-1.0, 1.0], N)
+        q[:, 2] += 0.3
+    return q
+
+
+@pytest.mark.parametrize("model,N", [("synth_tumblers", 12), ("synth_stompy_pro_sc", 48)])
+def test_geom_pair_contacts(be, model, N):
+    """SURVEY 8(f1) body-body pairs: sphere-sphere, sphere-capsule and capsule-capsule candidates between different bodies
+    (several kinematic trees in synth_tumblers, one articulated tree in synth_stompy_pro_sc), filtered like MuJoCo filters
+    them.  Constraint rows, reference accelerations and the solver result against the oracle, from states with active pairs."""
+    cm = load_model(model)
+    assert cm.npair == {"synth_tumblers": 3, "synth_stompy_pro_sc": 8}[model] and cm.nefc == cm.nlimit + 4 * cm.ncon
+    h, dims, _keep = be.model(cm)
+    ph = Physics(cm.t)
+    rng = np.random.default_rng(11)
+    qpos = _pair_states(model, cm, N, rng)
+    qvel = 0.3 * rng.standard_normal((N, cm.nv))
+    ctrl = 0.3 * rng.standard_normal((N, max(cm.nu, 1)))[:, :cm.nu]
+    q32 = [x.astype(f32) for x in (qpos, qvel, ctrl if cm.nu else np.zeros((N, 1)), np.zeros((N, cm.nv)))]
+    ref = PhysState(qpos=q32[0].astype(np.float64), qvel=q32[1].astype(np.float64), ctrl=q32[2].astype(np.float64)[:, :cm.nu],
+                    qacc_warmstart=np.zeros((N, cm.nv)), time=np.zeros(N))
+    ph.forward(ref)
+    first_pair_row = cm.nlimit + 4 * (cm.ncon - cm.npair)
+    pair_active = (ref.efc_D[:, first_pair_row:] > 0).reshape(N, cm.npair, 4)[:, :, 0]
+    assert pair_active.any(0).sum() >= (3 if model == "synth_tumblers" else 2), pair_active.sum(0)  # which candidates fire somewhere in the batch
+    got = _probe(be, h, cm, *q32)
+    # The contact normal is (p2 - p1) / |p2 - p1| between the closest points of the two segments: it is ill-conditioned when
+    # those points nearly coincide (deep overlap), and for parallel capsules the points themselves are (MJX divides rounding
+    # noise by 1e-6 there).  The distance is well-conditioned always.  So: efc_D (a function of the distance) everywhere;
+    # Jacobian rows, reference acceleration and the solver where every active pair keeps its closest points >= 2 cm apart -
+    # there the normal carries (float32 error of the body positions, <= 1e-5) / (that distance), hence 5e-4 for efc_J here
+    # (ground rows are held to 1e-5 in test_forward_matches_oracle).
+    gap = ref.con_dist[:, cm.ncon - cm.npair:] + (cm.t["pair_geom"][:, 6] + cm.t["pair_geom"][:, 14])[None]
+    good = ~(pair_active & (gap < 0.02)).any(1)
+    if model == "synth_tumblers":
+        good[1] = False  # the parallel pair
+    assert good.sum() >= 0.5 * N and pair_active[good].any(0).sum() >= (3 if model == "synth_tumblers" else 2)
+    for k, t in dict(qM=1e-5, efc_J=5e-4, efc_D=5e-4, efc_aref=5e-4, xpos=1e-5).items():
+        r, gk = ref[k], got[k].reshape(ref[k].shape)
+        sel = slice(None) if k in ("efc_D", "qM", "xpos") else good
+        assert np.abs(gk[sel] - r[sel]).max() <= t * (np.abs(r).max() + 1e-6), (k, np.abs(gk[sel] - r[sel]).max())
+    c_got, c_ref, c_smooth = _cost(ref, got["qacc"]), _cost(ref, ref.qacc), _cost(ref, ref.qacc_smooth)
+    np.testing.assert_allclose(c_got[good], c_ref[good], rtol=5e-2, atol=1e-3)
+    assert np.all(c_got[good] <= c_smooth[good] * (1 + 1e-5) + 1e-6)
+    rel = (np.abs(got["qacc"] - ref.qacc).max(1) / (np.abs(ref.qacc).max(1) + 1e-9))[good]
+    assert np.median(rel) <= 5e-3 and rel.max() <= 0.3, (np.median(rel), rel.max())
+    be.lib.model_close(h)
+
+
+def test_colliding_spheres_conserve_momentum(be):
+    """Known answer for a pair contact through the kernel: two free spheres, no gravity, no ground, oblique impact.  The
+    contact acts on both bodies with opposite forces (Jacobian = body 2 minus body 1), so the linear momentum is constant
+    to float32 rounding while the velocities change."""
+    from minppo_amd.model import GEOM_SPHERE, JNT_FREE, BodySpec, GeomSpec, JointSpec, ModelSpec, compile_model
+    spec = ModelSpec(name="two_balls", actuators=[], gravity=(0.0, 0.0, 0.0), has_plane=False, free_root_z=1.0, bodies=[
+        BodySpec("a", "world", pos=(0.0, 0.0, 0.0), mass=1.0, inertia=(0.004, 0.004, 0.004), joints=[JointSpec("ra", JNT_FREE)],
+                 geoms=[GeomSpec(GEOM_SPHERE, (0.1,), contype=1)]),
+        BodySpec("b", "world", pos=(0.3, 0.05, 1.0), mass=2.0, inertia=(0.008, 0.008, 0.008), joints=[JointSpec("rb", JNT_FREE)],
+                 geoms=[GeomSpec(GEOM_SPHERE, (0.1,), contype=1)])])
+    cm = compile_model(spec)
+    assert cm.ncon == 1 and cm.npair == 1
+    h, dims, _keep = be.model(cm)
+    N, OP, R, nq, nv = 2, dims.obs_pad, dims.rec_dim, cm.nq, cm.nv
+    state, reset_rec, obs = be.zeros((N, R)), be.zeros((R,)), be.zeros((N, OP))
+    rew, done = be.zeros((N,)), be.zeros((N,), np.uint8)
+    be.lib.env_reset(h, N, be.ptr(state), be.ptr(reset_rec), be.ptr(obs), OP, be.ptr(rew), be.ptr(done), None, be.stream)
+    st = be.host(state).copy()
+    st[:, nq + 0] = 1.0    # a moves towards b
+    st[:, nq + 6] = -0.5   # b towards a
+    st[1, nq + 1] = 0.2
+    be.put(state, st)
+    mass = np.array([1.0, 2.0])
+    p0 = mass[0] * st[:, nq:nq + 3] + mass[1] * st[:, nq + 6:nq + 9]
+    rc = nat.RewardCfg(-10.0, 10.0, 2.0, 0.2, 0.5, 0.1, 4.0, 1.0, 1.25)
+    act = be.zeros((N, 1))
+    for _ in range(120):
+        be.lib.env_step(h, N, 1, C.byref(rc), be.ptr(state), be.ptr(reset_rec), be.ptr(act), 1, be.ptr(obs), OP, be.ptr(rew), be.ptr(done), None, be.stream)
+    s1 = be.host(state)
+    assert not be.host(done).any()
+    p1 = mass[0] * s1[:, nq:nq + 3] + mass[1] * s1[:, nq + 6:nq + 9]
+    np.testing.assert_allclose(p1, p0, atol=2e-5)
+    assert (s1[:, nq] < 0.5).all() and (s1[:, nq + 6] > -0.25).all()  # they bounced: a slowed down / reversed, b pushed back
+    gap = np.linalg.norm(s1[:, 7:10] - s1[:, 0:3], axis=1)
+    assert (gap > 0.2 - 2e-3).all()  # and no longer overlap (soft contact: ~1 mm of residual penetration allowed)
+    be.lib.model_close(h)
+
+
+def test_specialised_kernel_equals_the_runtime_sized_kernel(be, monkeypatch):
+    """The BASELINE robots run an env_kernel instantiation compiled for their dimensions (csrc/spec_dims.inc); every other
+    model - and these two under MPPO_ENV_GENERIC=1 - runs the run-time-sized instantiation of the same source.  Same
+    arithmetic in the same order: the forward probe and a stretch of env steps agree bit for bit."""
+    for model in ("synth_stompy_pro", "synth_stompy_full"):
+        cm = load_model(model)
+        N = 9
+        ph, d, rng = _walk(cm, N, 5, 8)
+        ctrl = 0.4 * rng.standard_normal((N, cm.nu))
+        q32 = [x.astype(f32) for x in (d.qpos, d.qvel, ctrl, d.qacc_warmstart)]
+        res = []
+        for generic in (False, True):
+            if generic:
+                monkeypatch.setenv("MPPO_ENV_GENERIC", "1")
+            else:
+                monkeypatch.delenv("MPPO_ENV_GENERIC", raising=False)
+            h, dims, _keep = be.model(cm)
+            flag = C.c_int32(-1)
+            be.lib.model_is_specialized(h, C.byref(flag))
+            assert flag.value == (0 if generic else 1)
+            got = _probe(be, h, cm, *q32)
+            OP, R = dims.obs_pad, dims.rec_dim
+            state, reset_rec, obs = be.zeros((N, R)), be.zeros((R,)), be.zeros((N, OP))
+            rew, done = be.zeros((N,)), be.zeros((N,), np.uint8)
+            be.lib.env_reset(h, N, be.ptr(state), be.ptr(reset_rec), be.ptr(obs), OP, be.ptr(rew), be.ptr(done), None, be.stream)
+            rc = nat.RewardCfg(0.95, 2.0, 2.0, 0.2, 0.5, 0.1, 4.0, 1.0, 1.25)
+            r2 = np.random.default_rng(3)
+            for _ in range(6):
+                act = be.arr((0.8 * r2.standard_normal((N, cm.nu))).astype(f32))
+                be.lib.env_step(h, N, 2, C.byref(rc), be.ptr(state), be.ptr(reset_rec), be.ptr(act), cm.nu, be.ptr(obs), OP, be.ptr(rew), be.ptr(done), None, be.stream)
+            got.update(state=be.host(state).copy(), obs=be.host(obs).copy(), rew=be.host(rew).copy(), done=be.host(done).copy())
+            res.append(got)
+            be.lib.model_close(h)
+        for k in res[0]:
+            assert np.array_equal(res[0][k], res[1][k], equal_nan=True), (model, k)
+    h, dims, _keep = be.model(load_model("synth_stompy_pro_sc"))
+    flag = C.c_int32(-1)
+    be.lib.model_is_specialized(h, C.byref(flag))
+    assert flag.value == 0  # not in the list: run-time-sized kernel
+    be.lib.model_close(h)
+
+
 def test_free_fall_is_exact_semi_implicit_euler(be):
     """Known answer through the kernel: a free sphere falls z_k = z0 - g h^2 k(k+1)/2 until it touches."""
     cm = load_model("synth_ball")
@@ -253,7 +424,8 @@ def _pack(env, s, dims, nv):
 
 
 @pytest.mark.parametrize("model,n_frames,c_vals", [("synth_stompy_pro", 1, True), ("synth_stompy_pro", 2, True), ("synth_stompy_full", 1, True),
-                                                    ("synth_stompy_pro", 1, False)])  # environment.include_c_vals = false (env.py:254-259)
+                                                    ("synth_stompy_pro", 1, False),  # environment.include_c_vals = false (env.py:254-259)
+                                                    ("synth_stompy_pro_sc", 1, True)])  # with geom-geom candidates (8 f1)
 def test_env_step_matches_env_oracle(be, model, n_frames, c_vals):
     """reset + 24 steps, the kernel re-seeded from the oracle state before every step (identical inputs):
     observation lag, reward, height / NaN termination, auto-reset, metrics.  Both BASELINE robots (configs[1] / configs[4])."""

@@ -162,3 +162,52 @@ def test_box_geom_collides_through_its_eight_corners(tmp_path):
     p2.write_text(mjcf.to_mjcf(spec))
     cm2 = compile_model(mjcf.load_mjcf(str(p2)))
     assert cm2.to_blob() == cm.to_blob()
+
+
+def test_collision_masks_generate_the_pairs_mujoco_would_test(tmp_path):
+    """SURVEY 8(f1) body-body pairs.  With MuJoCo's default masks (contype = conaffinity = 1) every sphere / capsule pair on
+    different bodies is a candidate except parent-child pairs and bodies welded together; contype / conaffinity remove pairs;
+    geom 1 of a mixed pair is the sphere.  A box that would have to meet another geom is an error."""
+    import numpy as np
+
+    from minppo_amd import mjcf
+    from minppo_amd.model import compile_model
+
+    def xml(extra_a="", extra_d="", dtype="sphere", dsize="0.04"):
+        return f"""<mujoco model="chain"><worldbody><geom type="plane" size="0 0 1"/>
+      <body name="a" pos="0 0 1"><freejoint name="root"/><inertial pos="0 0 0" mass="1" diaginertia="0.01 0.01 0.01"/>
+        <geom name="ga" type="capsule" size="0.05 0.1" {extra_a}/>
+        <body name="b" pos="0.2 0 0"><joint name="j1" type="hinge" axis="0 1 0"/><inertial pos="0 0 0" mass="1" diaginertia="0.01 0.01 0.01"/>
+          <geom name="gb" type="sphere" size="0.05"/>
+          <body name="w" pos="0.1 0 0"><inertial pos="0 0 0" mass="0.1" diaginertia="0.001 0.001 0.001"/>
+            <geom name="gw" type="sphere" size="0.03"/>
+            <body name="c" pos="0.2 0 0"><joint name="j2" type="hinge" axis="0 1 0"/><inertial pos="0 0 0" mass="1" diaginertia="0.01 0.01 0.01"/>
+              <geom name="gc" type="capsule" size="0.04 0.1"/></body></body></body>
+        <body name="d" pos="-0.2 0 0"><joint name="j3" type="hinge" axis="0 1 0"/><inertial pos="0 0 0" mass="1" diaginertia="0.01 0.01 0.01"/>
+          <geom name="gd" type="{dtype}" size="{dsize}" {extra_d}/></body>
+      </body></worldbody></mujoco>"""
+
+    def pairs(text):
+        p = tmp_path / "m.xml"
+        p.write_text(text)
+        cm = compile_model(mjcf.load_mjcf(str(p)))
+        return cm, [tuple(int(v) for v in r) for r in np.asarray(cm.t["pair_body"]).reshape(-1, 2)]
+
+    # bodies: a=1, b=2, w=3 (welded to b: no joint), c=4, d=5.  Parent-child: a-b, a-d, and (w welded to b) b-c / w-c, a-w; same weld: b-w.
+    cm, pb = pairs(xml())
+    assert set(pb) == {(2, 5), (3, 5), (5, 4), (1, 4)}, pb
+    assert cm.npair == 4 and cm.ncon == (2 + 1 + 1 + 2 + 1) + 4
+    # (sphere, sphere) group first, then (sphere, capsule) with the sphere as geom 1, then (capsule, capsule)
+    kinds = [(float(np.linalg.norm(g[3:6])) > 0, float(np.linalg.norm(g[11:14])) > 0) for g in np.asarray(cm.t["pair_geom"]).reshape(-1, 16)]
+    assert kinds == sorted(kinds) and kinds[0] == (False, False) and kinds[-1] == (True, True) and (True, False) not in kinds
+    # masks: d only affine to nothing and typed 2 -> it meets the plane (plane conaffinity 1 & ... no: contype 2 & plane conaffinity 1 = 0,
+    # plane contype 1 & d conaffinity 0 = 0) neither the plane nor anybody
+    cm2, pb2 = pairs(xml(extra_d='contype="2" conaffinity="0"'))
+    assert set(pb2) == {(1, 4)} and cm2.ncon == (2 + 1 + 1 + 2) + 1
+    # a box may stand on the ground, but not be paired with another geom
+    with pytest.raises(ValueError, match="box geom can only collide with the ground"):
+        pairs(xml(dtype="box", dsize="0.04 0.04 0.04"))
+    cm3, pb3 = pairs(xml(dtype="box", dsize="0.04 0.04 0.04", extra_d='contype="0" conaffinity="1"').replace('name="ga" type="capsule"', 'name="ga" contype="0" type="capsule"')
+                     .replace('name="gb" type="sphere"', 'name="gb" contype="0" type="sphere"').replace('name="gw" type="sphere"', 'name="gw" contype="0" type="sphere"')
+                     .replace('name="gc" type="capsule"', 'name="gc" contype="0" type="capsule"'))
+    assert pb3 == [] and cm3.ncon == 2 + 1 + 1 + 2 + 8  # everything still meets the ground (plane contype 1 & conaffinity 1)

@@ -244,3 +244,77 @@ def test_env_done_thresholds_nan_and_metric_rollover():
     s_b = es_b["pipeline_state"]
     assert env.compute_reward(s_b, s_b, np.zeros((1, 10)))[0] == pytest.approx(4 * (np.exp(-2 * 0.0095) - 0.2 * 0.0095) + 1.0, rel=1e-6)
     assert env.is_done(s_b)[0]
+
+
+def test_closest_segment_points_against_brute_force():
+    """The routine behind sphere_capsule / capsule_capsule: never worse than a 401 x 401 grid search over the two segments
+    (spheres = segments of length zero included), in float64 and float32."""
+    from oracle.physics_oracle import closest_segment_to_segment_points as cs
+    rng = np.random.default_rng(0)
+    for dt, tol in ((np.float64, 1e-12), (np.float32, 2e-6)):
+        n = 600
+        a0, a1, b0, b1 = [rng.normal(size=(n, 3)).astype(dt) for _ in range(4)]
+        a1[:60] = a0[:60]
+        b1[30:120] = b0[30:120]
+        qa, qb = cs(a0, a1, b0, b1)
+        assert qa.dtype == dt and qb.dtype == dt
+        d = np.linalg.norm(qa.astype(np.float64) - qb, axis=-1)
+        s = np.linspace(0, 1, 401)
+        pa = a0[:, None, :] + (a1 - a0)[:, None, :] * s[None, :, None]
+        pb = b0[:, None, :] + (b1 - b0)[:, None, :] * s[None, :, None]
+        best = np.array([np.linalg.norm(pa[i, :, None, :] - pb[i, None, :, :], axis=-1).min() for i in range(n)])
+        assert (d <= best + tol).all() and (d >= best - 0.02).all()
+        # and the points lie on their segments
+        for q, p0, p1 in ((qa, a0, a1), (qb, b0, b1)):
+            t = np.sum((q - p0) * (p1 - p0), -1) / np.maximum(np.sum((p1 - p0) ** 2, -1), 1e-30)
+            assert (t > -1e-5).all() and (t < 1 + 1e-5).all()
+
+
+def test_pair_contact_rows_and_capsule_frames():
+    """geom-geom candidates (synth_stompy_pro_sc: 8 pairs after MuJoCo's parent-child filter): the normal-row Jacobian of an
+    active pair times qvel is d(dist)/dt, the frame rows are orthonormal, the weights add up over both bodies; and a ground
+    contact of a capsule end has its first tangent along the capsule axis projected on the ground (plane_capsule)."""
+    m = load_model("synth_stompy_pro_sc"); ph = Physics(m.t)
+    assert ph.npair == 8 and ph.ncon == 15
+    pb = np.asarray(m.t["pair_body"])
+    par = np.asarray(m.t["body_parent"])
+    assert all(par[a] != b and par[b] != a and a != b for a, b in pb)
+    rng = np.random.default_rng(4)
+    N = 64
+    qpos, qvel = _rand_state(m, ph, N, rng, 0.2)
+    names = m.joint_names[1:]
+    for k, nm in enumerate(names):
+        if nm.endswith("hip_roll"):
+            qpos[:, 7 + k] = (-1.0 if nm.startswith("left") else 1.0) * rng.uniform(0.05, 0.2, N)
+        if nm.endswith("hip_yaw"):
+            qpos[:, 7 + k] = rng.uniform(-0.7, 0.7, N)
+    qpos[:, 2] -= 0.03
+    d = ph.pipeline_init(qpos, qvel)
+    first = ph.ncon - ph.npair
+    act = d.con_dist[:, first:] < 0
+    assert act.any(0).sum() >= 2
+    eps = 1e-6
+    def dist(q):
+        k = _kin(ph, q); ph.collision(k); return k.con_dist
+    ddist = (dist(_integrate_q(m, ph, qpos, qvel, eps)) - dist(_integrate_q(m, ph, qpos, qvel, -eps))) / (2 * eps)
+    for c in range(first, ph.ncon):
+        r = ph.nlimit + 4 * c
+        jn = 0.5 * (d.efc_J[:, r] + d.efc_J[:, r + 1])
+        a = act[:, c - first] & (d.con_dist[:, c] + m.t["pair_geom"][c - first][6] + m.t["pair_geom"][c - first][14] > 0.02)
+        # (MJX's closest-point formulas carry +1e-6 regularisers: the points sit ~1e-5 off the true minimisers, hence 3e-3)
+        np.testing.assert_allclose(np.sum(jn * qvel, -1)[a], ddist[a, c], rtol=3e-3, atol=1e-4)
+    fr = d.con_frame
+    np.testing.assert_allclose(np.einsum("ncij,nckj->ncik", fr, fr), np.broadcast_to(np.eye(3), fr.shape), atol=1e-12)
+    # ground contacts of the foot capsules (two ends each): tangent 1 = world capsule axis, flattened and normalised
+    caps = [c for c in range(first) if np.linalg.norm(m.t["con_axis"][c]) > 0]
+    assert len(caps) == 4
+    from oracle.physics_oracle import qrot
+    for c in caps:
+        ax = qrot(d.xquat[:, m.t["con_bodyid"][c]], np.broadcast_to(m.t["con_axis"][c], (N, 3)))
+        flat = ax * np.array([1.0, 1.0, 0.0])
+        ok = np.linalg.norm(flat, axis=-1) >= 0.5
+        assert ok.sum() > N // 2
+        np.testing.assert_allclose(fr[ok, c, 1], flat[ok] / np.linalg.norm(flat[ok], axis=-1, keepdims=True), atol=1e-12)
+        np.testing.assert_allclose(fr[~ok, c, 1], np.broadcast_to([0.0, 1.0, 0.0], (int((~ok).sum()), 3)), atol=0)
+    # solver sanity with pairs in the active set
+    assert np.all(d.efc_force >= 0) and np.all(d.efc_force[~d.efc_active_row] == 0)

@@ -10,7 +10,10 @@ if len(sys.argv) > 1:
 from minppo_amd.model import load_model
 lib = nat.load()
 print("library:", lib.path)
+only = sys.argv[2] if len(sys.argv) > 2 else None  # restrict to one model (needed for single-model experiment builds)
 for model, N in (("synth_stompy_pro", 4096), ("synth_stompy_full", 8192)):
+    if only and model != only:
+        continue
     cm = load_model(model)
     blob = np.frombuffer(cm.to_blob(), np.uint8)
     dblob = torch.from_numpy(blob.copy()).cuda()
