@@ -202,7 +202,8 @@ __device__ __forceinline__ LsPoint ls_make(float alpha, float q0, float q1, floa
   return p;
 }
 __device__ __forceinline__ bool in_bracket(const LsPoint& x, const LsPoint& y) {
-  return ((x.d0 < y.d0) && (y.d0 < 0.f)) || ((x.d0 > y.d0) && (y.d0 > 0.f));
+  // bitwise on purpose: four compares and three mask operations, no short-circuit branches (each would be a save / restore of exec)
+  return (bool)((int)((x.d0 < y.d0) & (y.d0 < 0.f)) | (int)((x.d0 > y.d0) & (y.d0 > 0.f)));
 }
 __device__ __forceinline__ LsPoint ls_sel(bool c, const LsPoint& a, const LsPoint& b) { return c ? a : b; }
 
@@ -748,7 +749,7 @@ __global__ void __launch_bounds__(kEnvBlock) env_kernel(ModelView mv, EnvArgs a,
         FOR_G(i, nv) gn += grad[i] * grad[i];
         gn = sqrtf(group16_sum(gn)) / scale;
         const float improvement = (prev_cost - cost) / scale;
-        const bool run = !((niter >= mv.iterations) || (improvement < mv.tolerance) || (gn < mv.tolerance));
+        const bool run = !(bool)((int)(niter >= mv.iterations) | (int)(improvement < mv.tolerance) | (int)(gn < mv.tolerance));
         if (!wave_any(run)) break;
         PT(13 + (it < 6 ? it : 6));
         // ---------------- line search ----------------
@@ -764,24 +765,62 @@ __global__ void __launch_bounds__(kEnvBlock) env_kernel(ModelView mv, EnvArgs a,
         const float gtol = mv.tolerance * mv.ls_tolerance * sqrtf(sn) * scale;
         const float qg0 = gauss, qg1 = sMa - sq, qg2 = 0.5f * smv;
         // three trial steps at once: sums of the active rows' quadratics
+        // A lane's rows (g, g + 16, ...) do not change during the line search.  With compile-time dims their quadratics live in
+        // registers for the whole search (kRows of them per lane); the run-time-sized kernel re-reads them from LDS per trial.
+        constexpr int kRows = kDims ? (kSD.nlimit + 4 * kSD.ncon + kGroupLanes - 1) / kGroupLanes : 1;
+        float rja[kRows], rv[kRows], rc0[kRows], rc1[kRows], rc2[kRows];
+        if (kDims) {
+          _Pragma("unroll") for (int j = 0; j < kRows; ++j) {
+            const int r = g + kGroupLanes * j;
+            const bool in = r < nefc;
+            const float ja = in ? jaref[in ? r : 0] : 0.f, v = in ? jv[in ? r : 0] : 0.f, d = in ? eD[in ? r : 0] : 0.f;
+            rja[j] = ja; rv[j] = v;
+            rc0[j] = 0.5f * ja * ja * d; rc1[j] = v * ja * d; rc2[j] = 0.5f * v * v * d;  // a row past nefc never tests active: 0 + a 0 < 0 is false
+          }
+        }
         auto eval3 = [&](float a0, float a1, float a2, LsPoint& o0, LsPoint& o1, LsPoint& o2) {
           float q[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-          FOR_G(r, nefc) {
-            const float ja = jaref[r], v = jv[r], d = eD[r];
-            const float c0 = 0.5f * ja * ja * d, c1 = v * ja * d, c2 = 0.5f * v * v * d;
-            if (ja + a0 * v < 0.f) { q[0] += c0; q[1] += c1; q[2] += c2; }
-            if (ja + a1 * v < 0.f) { q[3] += c0; q[4] += c1; q[5] += c2; }
-            if (ja + a2 * v < 0.f) { q[6] += c0; q[7] += c1; q[8] += c2; }
+          if (kDims) {
+            _Pragma("unroll") for (int j = 0; j < kRows; ++j) {
+              const float ja = rja[j], v = rv[j], c0 = rc0[j], c1 = rc1[j], c2 = rc2[j];
+              if (ja + a0 * v < 0.f) { q[0] += c0; q[1] += c1; q[2] += c2; }
+              if (ja + a1 * v < 0.f) { q[3] += c0; q[4] += c1; q[5] += c2; }
+              if (ja + a2 * v < 0.f) { q[6] += c0; q[7] += c1; q[8] += c2; }
+            }
+          } else {
+            FOR_G(r, nefc) {
+              const float ja = jaref[r], v = jv[r], d = eD[r];
+              const float c0 = 0.5f * ja * ja * d, c1 = v * ja * d, c2 = 0.5f * v * v * d;
+              if (ja + a0 * v < 0.f) { q[0] += c0; q[1] += c1; q[2] += c2; }
+              if (ja + a1 * v < 0.f) { q[3] += c0; q[4] += c1; q[5] += c2; }
+              if (ja + a2 * v < 0.f) { q[6] += c0; q[7] += c1; q[8] += c2; }
+            }
           }
           for (int k = 0; k < 9; ++k) q[k] = group16_sum(q[k]);
           o0 = ls_make(a0, q[0] + qg0, q[1] + qg1, q[2] + qg2);
           o1 = ls_make(a1, q[3] + qg0, q[4] + qg1, q[5] + qg2);
           o2 = ls_make(a2, q[6] + qg0, q[7] + qg1, q[8] + qg2);
         };
+        // one trial step: the starting point and the first Newton point (same row order and reduction as eval3)
+        auto eval1 = [&](float a0, LsPoint& o0) {
+          float q0 = 0.f, q1 = 0.f, q2 = 0.f;
+          if (kDims) {
+            _Pragma("unroll") for (int j = 0; j < kRows; ++j) {
+              if (rja[j] + a0 * rv[j] < 0.f) { q0 += rc0[j]; q1 += rc1[j]; q2 += rc2[j]; }
+            }
+          } else {
+            FOR_G(r, nefc) {
+              const float ja = jaref[r], v = jv[r], d = eD[r];
+              if (ja + a0 * v < 0.f) { q0 += 0.5f * ja * ja * d; q1 += v * ja * d; q2 += 0.5f * v * v * d; }
+            }
+          }
+          q0 = group16_sum(q0); q1 = group16_sum(q1); q2 = group16_sum(q2);
+          o0 = ls_make(a0, q0 + qg0, q1 + qg1, q2 + qg2);
+        };
         if (it == 0) PT(25);
-        LsPoint p0, lo, hi, tmpa, tmpb;
-        eval3(0.f, 0.f, 0.f, p0, tmpa, tmpb);
-        eval3(p0.alpha - p0.d0 / p0.d1, 0.f, 0.f, lo, tmpa, tmpb);
+        LsPoint p0, lo, hi;
+        eval1(0.f, p0);
+        eval1(p0.alpha - p0.d0 / p0.d1, lo);
         {
           const bool lesser = lo.d0 < p0.d0;
           const LsPoint nlo = ls_sel(lesser, lo, p0), nhi = ls_sel(lesser, p0, lo);
@@ -791,8 +830,8 @@ __global__ void __launch_bounds__(kEnvBlock) env_kernel(ModelView mv, EnvArgs a,
         bool swap = true;
         int ls_iter = 0;
         for (int li = 0; li < mv.ls_iterations; ++li) {
-          const bool done = (ls_iter >= mv.ls_iterations) || !swap || ((lo.d0 < 0.f) && (lo.d0 > -gtol)) || ((hi.d0 > 0.f) && (hi.d0 < gtol));
-          const bool go = !done && run;
+          const bool done = (bool)((int)(ls_iter >= mv.ls_iterations) | (int)!swap | (int)((lo.d0 < 0.f) & (lo.d0 > -gtol)) | (int)((hi.d0 > 0.f) & (hi.d0 < gtol)));
+          const bool go = (bool)((int)!done & (int)run);
           if (!wave_any(go)) break;
           LsPoint lo_next, hi_next, mid;
           eval3(lo.alpha - lo.d0 / lo.d1, hi.alpha - hi.d0 / hi.d1, 0.5f * (lo.alpha + hi.alpha), lo_next, hi_next, mid);
@@ -803,12 +842,12 @@ __global__ void __launch_bounds__(kEnvBlock) env_kernel(ModelView mv, EnvArgs a,
           const bool s4 = in_bracket(nhi, hi_next); nhi = ls_sel(s4, hi_next, nhi);
           const bool s5 = in_bracket(nhi, mid);     nhi = ls_sel(s5, mid, nhi);
           const bool s6 = in_bracket(nhi, lo_next); nhi = ls_sel(s6, lo_next, nhi);
-          if (go) { lo = nlo; hi = nhi; swap = s1 || s2 || s3 || s4 || s5 || s6; ls_iter += 1; }
+          if (go) { lo = nlo; hi = nhi; swap = (bool)((int)s1 | (int)s2 | (int)s3 | (int)s4 | (int)s5 | (int)s6); ls_iter += 1; }
         }
         if (it == 0) PT(27);
-        const bool improved = (lo.cost < p0.cost) || (hi.cost < p0.cost);
+        const bool improved = (bool)((int)(lo.cost < p0.cost) | (int)(hi.cost < p0.cost));
         const float alpha = (lo.cost < hi.cost) ? lo.alpha : hi.alpha;
-        if (improved && run) {
+        if ((bool)((int)improved & (int)run)) {
           FOR_G(i, nv) { qacc[i] += alpha * search[i]; Ma[i] += alpha * mvv[i]; }
           FOR_G(r, nefc) jaref[r] += alpha * jv[r];
         }
@@ -940,13 +979,15 @@ __global__ void __launch_bounds__(kEnvBlock) env_kernel(ModelView mv, EnvArgs a,
   const float reward = rc.w_ctrl_cost * (-asq) + rc.w_original_pos * pos_r + rc.w_velocity * vel + rc.w_is_healthy * healthy;
   // done: height window on the POST-step state (env.py:171,238-242) or any NaN in the stepped state (env.py:173-176)
   const float z = qpos[2];
-  bool bad = false;
-  FOR_G(i, nq) bad = bad || isnan(qpos[i]);
-  FOR_G(i, nv) bad = bad || isnan(qvel[i]) || isnan(warm[i]) || isnan(qact[i]);
-  FOR_G(i, 10 * nb) bad = bad || isnan(cinert[i]);
-  FOR_G(i, 6 * nb) bad = bad || isnan(cvel[i]);
-  bad = bad || isnan(new_comx);
-  const bool done = !((rc.height_min_z < z) && (z < rc.height_max_z)) || group16_any(bad);
+  // (bitwise accumulation: a short-circuit || would put every load behind its own branch)
+  int badi = 0;
+  FOR_G(i, nq) badi |= (int)isnan(qpos[i]);
+  FOR_G(i, nv) badi |= (int)isnan(qvel[i]) | (int)isnan(warm[i]) | (int)isnan(qact[i]);
+  FOR_G(i, 10 * nb) badi |= (int)isnan(cinert[i]);
+  FOR_G(i, 6 * nb) badi |= (int)isnan(cvel[i]);
+  badi |= (int)isnan(new_comx);
+  const bool bad = badi != 0;
+  const bool done = (bool)((int)!((rc.height_min_z < z) & (z < rc.height_max_z)) | (int)group16_any(bad));
   const int o_ci = nq + nv, o_cv = o_ci + (mv.include_c ? 10 * (nb - 1) : 0), o_qa = o_cv + (mv.include_c ? 6 * (nb - 1) : 0);
   FOR_G(i, mv.rec_dim) {
     // observation = the PRE-step record (env.py:163, quirk C-5), or the reset observation when done (env.py:180)
