@@ -101,6 +101,7 @@ struct PhysLds {
   int qpos, qvel, ctrl, warm;
   int xpos, xquat, xipos, rootcom;
   int cinert, cdof, cvel;
+  int ldc;         // row stride of the factorisation work copies C1 / C2 in a fixed-size kernel: nv rounded up to 4 (rows are read as float4)
   int M, LL, ldm;  // LL packs L^-1 of M (lower part, [i][k<=i]) and of M + h*D (stored transposed at [k][i+1])
   int qfs, qas, qact, qacc, Ma, grad, Mgrad, search, mv, qfc, t0, t1;
   int D, aref, jaref, jv, force;
@@ -130,7 +131,8 @@ __host__ __device__ constexpr inline PhysLds make_phys_lds(int nq, int nv, int n
   p.A = o;
   p.ximat = take(9 * nbody); p.xmat = take(9 * nbody); p.xanchor = take(3 * njnt); p.xaxis = take(3 * njnt);
   int end = o;
-  o = p.A; p.C1 = take(nv * p.ldm); p.C2 = take(nv * p.ldm); end = imax_(end, o);
+  p.ldc = (nv + 3) & ~3;
+  o = p.A; p.C1 = take(nv * imax_(p.ldm, p.ldc)); p.C2 = take(nv * imax_(p.ldm, p.ldc)); end = imax_(end, o);
   o = p.A; p.cdofdot = take(6 * nv); p.cfrc = take(6 * nbody); end = imax_(end, o);
   o = p.A; p.ldj = nv + 1; p.J = take(ne * p.ldj); end = imax_(end, o);
   p.total = (end + 3) & ~3;
