@@ -334,46 +334,71 @@ __global__ void __launch_bounds__(kEnvBlock) env_kernel(ModelView mv, EnvArgs a,
   const int frames = MODE == 1 ? a.n_frames : 1;
   for (int frame = 0; frame < frames; ++frame) {
     PT(1);
-    // ================= fwd_position: kinematics (level-synchronous over the tree) =================
+    // ================= fwd_position: kinematics ================================================================
+    // The tree is deep and narrow (a level holds one or two bodies of a humanoid), so the level-synchronous sweep runs on one
+    // or two lanes.  Only what truly depends on the parent is done there: pose = parent pose o local pose.  Everything else -
+    // the joint rotations (sincos), local anchors / axes, rotation matrices, inertial frames - is done for all bodies at once
+    // before and after the sweep.  (Same transforms as mj_kinematics / mjx.kinematics, regrouped by associativity.)
+    // A: local pose of every body in its parent's frame; local joint anchors / axes
+    FOR_G(b, nb) {
+      if (b > 0) {
+        V3 pl = ld3(TF(body_pos) + 3 * b);
+        Q4 ql = ld4(TF(body_quat) + 4 * b);
+        const int j0 = TI(body_jntadr)[b], j1 = j0 + TI(body_jntnum)[b];
+        for (int j = j0; j < j1; ++j) {
+          const int qa = TI(jnt_qposadr)[j], jt = TI(jnt_type)[j];
+          if (jt == JNT_FREE) {  // only on children of the world: local = world
+            pl = ld3(qpos + qa);
+            ql = qnormalize(ld4(qpos + qa + 3));
+            st3(xanchor + 3 * j, pl);
+            st3(xaxis + 3 * j, qrot(ql, ld3(TF(jnt_axis) + 3 * j)));
+          } else {
+            const V3 anchor = add3(pl, qrot(ql, ld3(TF(jnt_pos) + 3 * j)));
+            const V3 axis = qrot(ql, ld3(TF(jnt_axis) + 3 * j));
+            st3(xanchor + 3 * j, anchor);
+            st3(xaxis + 3 * j, axis);
+            const float disp = qpos[qa] - TF(qpos0)[qa];
+            if (jt == JNT_HINGE) {
+              ql = qmul(ql, axis_angle(ld3(TF(jnt_axis) + 3 * j), disp));
+              pl = sub3(anchor, qrot(ql, ld3(TF(jnt_pos) + 3 * j)));
+            } else {
+              pl = add3(pl, mul3(axis, disp));
+            }
+          }
+        }
+        st3(xpos + 3 * b, pl);
+        st4(xquat + 4 * b, ql);
+      }
+    }
+    SYNC();
+    // B: the sweep, in place (a level reads its parents' finished poses and its own local ones)
     for (int lv = 0; lv < nlevel; ++lv) {
       const int adr = TI(level_adr)[lv], cnt = TI(level_adr)[lv + 1] - adr;
       FOR_G(ii, cnt) {
         const int b = TI(level_body)[adr + ii];
         const int p = TI(body_parent)[b];
         const Q4 pq = ld4(xquat + 4 * p);
-        V3 pos = add3(ld3(xpos + 3 * p), qrot(pq, ld3(TF(body_pos) + 3 * b)));
-        Q4 quat = qmul(pq, ld4(TF(body_quat) + 4 * b));
-        const int j0 = TI(body_jntadr)[b], j1 = j0 + TI(body_jntnum)[b];
-        for (int j = j0; j < j1; ++j) {
-          const int qa = TI(jnt_qposadr)[j], jt = TI(jnt_type)[j];
-          if (jt == JNT_FREE) {
-            pos = ld3(qpos + qa);
-            quat = qnormalize(ld4(qpos + qa + 3));
-            st3(xanchor + 3 * j, pos);
-            st3(xaxis + 3 * j, qrot(quat, ld3(TF(jnt_axis) + 3 * j)));
-          } else {
-            const V3 anchor = add3(pos, qrot(quat, ld3(TF(jnt_pos) + 3 * j)));
-            const V3 axis = qrot(quat, ld3(TF(jnt_axis) + 3 * j));
-            st3(xanchor + 3 * j, anchor);
-            st3(xaxis + 3 * j, axis);
-            const float disp = qpos[qa] - TF(qpos0)[qa];
-            if (jt == JNT_HINGE) {
-              quat = qmul(quat, axis_angle(ld3(TF(jnt_axis) + 3 * j), disp));
-              pos = sub3(anchor, qrot(quat, ld3(TF(jnt_pos) + 3 * j)));
-            } else {
-              pos = add3(pos, mul3(axis, disp));
-            }
-          }
-        }
-        quat = qnormalize(quat);
-        st3(xpos + 3 * b, pos);
-        st4(xquat + 4 * b, quat);
-        qmat(quat, xmat + 9 * b);
-        st3(xipos + 3 * b, add3(pos, qrot(quat, ld3(TF(body_ipos) + 3 * b))));
-        qmat(qmul(quat, ld4(TF(body_iquat) + 4 * b)), ximat + 9 * b);
+        st3(xpos + 3 * b, add3(ld3(xpos + 3 * p), qrot(pq, ld3(xpos + 3 * b))));
+        st4(xquat + 4 * b, qnormalize(qmul(pq, ld4(xquat + 4 * b))));
       }
       SYNC();
     }
+    // C: joint anchors / axes into the world frame (through the parent's pose), rotation matrices, inertial frames
+    FOR_G(j, njnt) {
+      const int p = TI(body_parent)[TI(jnt_bodyid)[j]];
+      const Q4 pq = ld4(xquat + 4 * p);
+      st3(xanchor + 3 * j, add3(ld3(xpos + 3 * p), qrot(pq, ld3(xanchor + 3 * j))));
+      st3(xaxis + 3 * j, qrot(pq, ld3(xaxis + 3 * j)));
+    }
+    FOR_G(b, nb) {
+      if (b > 0) {
+        const Q4 quat = ld4(xquat + 4 * b);
+        qmat(quat, xmat + 9 * b);
+        st3(xipos + 3 * b, add3(ld3(xpos + 3 * b), qrot(quat, ld3(TF(body_ipos) + 3 * b))));
+        qmat(qmul(quat, ld4(TF(body_iquat) + 4 * b)), ximat + 9 * b);
+      }
+    }
+    SYNC();
     PT(2);
     // ---- com_pos: centre of mass of every kinematic tree; contact candidates --------------------
     for (int r = 0; r < nroot; ++r) {
@@ -1048,23 +1073,34 @@ __global__ void __launch_bounds__(kEnvBlock) env_kernel(ModelView mv, EnvArgs a,
   const bool bad = badi != 0;
   const bool done = (bool)((int)!((rc.height_min_z < z) & (z < rc.height_max_z)) | (int)group16_any(bad));
   const int o_ci = nq + nv, o_cv = o_ci + (mv.include_c ? 10 * (nb - 1) : 0), o_qa = o_cv + (mv.include_c ? 6 * (nb - 1) : 0);
-  FOR_G(i, mv.rec_dim) {
-    // observation = the PRE-step record (env.py:163, quirk C-5), or the reset observation when done (env.py:180)
-    const float old = recw[i];
-    const float rst = a.reset_in[i];
-    float v = 0.f;
-    if (i < nq) v = qpos[i];
-    else if (i < o_ci) v = qvel[i - nq];
-    else if (i < o_cv) v = cinert[10 + (i - o_ci)];
-    else if (i < o_qa) v = cvel[6 + (i - o_cv)];
-    else if (i < O) v = qact[i - o_qa];
-    else if (i < OP) v = 0.f;
-    else if (i < OP + nv) v = warm[i - OP];
-    else if (i == OP + nv) v = new_comx;
-    else if (i == OP + nv + 1) v = time_in + dt_env;
-    if (valid) {
-      if (i < OP) a.obs[(size_t)env * a.obs_ld + i] = done ? rst : old;
-      recw[i] = done ? rst : v;
+  // Eight record words per lane at a time: all their global loads are issued before the first store, so a chunk costs one
+  // memory round trip (a plain loop pays one per word: the stores to the record keep the next word's load from moving up).
+  constexpr int kChunk = 8;
+  const int rec_dim = mv.rec_dim;
+  for (int i0 = g; i0 < rec_dim; i0 += kGroupLanes * kChunk) {
+    float old[kChunk], rst[kChunk];
+    _Pragma("unroll") for (int u = 0; u < kChunk; ++u) {
+      const int i = i0 + kGroupLanes * u, ii = i < rec_dim ? i : rec_dim - 1;
+      old[u] = recw[ii];
+      rst[u] = a.reset_in[ii];
+    }
+    _Pragma("unroll") for (int u = 0; u < kChunk; ++u) {
+      const int i = i0 + kGroupLanes * u;
+      // observation = the PRE-step record (env.py:163, quirk C-5), or the reset observation when done (env.py:180)
+      float v = 0.f;
+      if (i < nq) v = qpos[i];
+      else if (i < o_ci) v = qvel[i - nq];
+      else if (i < o_cv) v = cinert[10 + (i - o_ci)];
+      else if (i < o_qa) v = cvel[6 + (i - o_cv)];
+      else if (i < O) v = qact[i - o_qa];
+      else if (i < OP) v = 0.f;
+      else if (i < OP + nv) v = warm[i - OP];
+      else if (i == OP + nv) v = new_comx;
+      else if (i == OP + nv + 1) v = time_in + dt_env;
+      if (valid && i < rec_dim) {
+        if (i < OP) a.obs[(size_t)env * a.obs_ld + i] = done ? rst[u] : old[u];
+        recw[i] = done ? rst[u] : v;
+      }
     }
   }
   if (valid && g == 0) {
