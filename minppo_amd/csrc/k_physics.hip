@@ -207,19 +207,23 @@ __device__ __forceinline__ bool in_bracket(const LsPoint& x, const LsPoint& y) {
 }
 __device__ __forceinline__ LsPoint ls_sel(bool c, const LsPoint& a, const LsPoint& b) { return c ? a : b; }
 
-// impedance / reference (MuJoCo solref + solimp -> k, b, imp), pos = signed distance - margin
-__device__ __forceinline__ void kbi(const float* solref, const float* solimp, float timestep, float pos, float& k, float& b, float& imp) {
+// impedance / reference (MuJoCo solref + solimp -> k, b, imp), pos = signed distance - margin.  k and b depend on the solver
+// parameters only (one pair for joint limits, one for contacts); the impedance depends on the row's violation.
+__device__ __forceinline__ void kb_params(const float* solref, const float* solimp, float timestep, float& k, float& b) {
   const float timeconst = fmaxf(solref[0], 2.f * timestep);  // refsafe
   const float dampratio = solref[1];
+  const float dmax = fminf(fmaxf(solimp[1], MJ_MINIMP), MJ_MAXIMP);
+  k = 1.f / (dmax * dmax * timeconst * timeconst * dampratio * dampratio);
+  b = 2.f / (dmax * timeconst);
+  if (solref[0] <= 0.f) k = -solref[0] / (dmax * dmax);
+  if (solref[1] <= 0.f) b = -solref[1] / dmax;
+}
+__device__ __forceinline__ float impedance(const float* solimp, float pos) {
   const float dmin = fminf(fmaxf(solimp[0], MJ_MINIMP), MJ_MAXIMP);
   const float dmax = fminf(fmaxf(solimp[1], MJ_MINIMP), MJ_MAXIMP);
   const float width = fmaxf(MJ_MINVAL, solimp[2]);
   const float mid = fminf(fmaxf(solimp[3], MJ_MINIMP), MJ_MAXIMP);
   const float power = fmaxf(1.f, solimp[4]);
-  k = 1.f / (dmax * dmax * timeconst * timeconst * dampratio * dampratio);
-  b = 2.f / (dmax * timeconst);
-  if (solref[0] <= 0.f) k = -solref[0] / (dmax * dmax);
-  if (solref[1] <= 0.f) b = -solref[1] / dmax;
   const float x = fabsf(pos) / width;
   float a, c;
   if (power == 2.f) {  // MuJoCo's default solimp power: no transcendental needed
@@ -230,9 +234,10 @@ __device__ __forceinline__ void kbi(const float* solref, const float* solimp, fl
     c = 1.f - (1.f / powf(1.f - mid, power - 1.f)) * powf(fabsf(1.f - x), power);
   }
   const float y = x < mid ? a : c;
-  imp = dmin + y * (dmax - dmin);
+  float imp = dmin + y * (dmax - dmin);
   imp = fminf(fmaxf(imp, dmin), dmax);
   if (x > 1.f) imp = dmax;
+  return imp;
 }
 
 // What the kernel knows at compile time.  RuntimeModel: nothing - dims, table offsets and the LDS layout arrive as kernel
@@ -773,12 +778,15 @@ __global__ void __launch_bounds__(kEnvBlock) env_kernel(ModelView mv, EnvArgs a,
       }
     }
     SYNC();
+    float k_lim, b_lim, k_con, b_con;
+    kb_params(TF(limit_solref), TF(limit_solimp), h, k_lim, b_lim);
+    kb_params(TF(contact_solref), TF(contact_solimp), h, k_con, b_con);
     FOR_G(r, nefc) {
       const float pos = jv[r], iw = force[r];
       const bool act = iw > 0.f;  // inactive rows are inert: J = 0, aref = 0, D = 0
-      float k, b, imp;
-      if (r < nlim) kbi(TF(limit_solref), TF(limit_solimp), h, pos, k, b, imp);
-      else kbi(TF(contact_solref), TF(contact_solimp), h, pos, k, b, imp);
+      const bool lim = r < nlim;
+      const float k = lim ? k_lim : k_con, b = lim ? b_lim : b_con;
+      const float imp = impedance(lim ? TF(limit_solimp) : TF(contact_solimp), pos);
       float s = 0.f;
       _Pragma("unroll 8") for (int d = 0; d < nv; ++d) s += J[r * ldj + d] * qvel[d];
       const float R = fmaxf(iw * (1.f - imp) / imp, MJ_MINVAL);
@@ -1073,10 +1081,23 @@ __global__ void __launch_bounds__(kEnvBlock) env_kernel(ModelView mv, EnvArgs a,
   const bool bad = badi != 0;
   const bool done = (bool)((int)!((rc.height_min_z < z) & (z < rc.height_max_z)) | (int)group16_any(bad));
   const int o_ci = nq + nv, o_cv = o_ci + (mv.include_c ? 10 * (nb - 1) : 0), o_qa = o_cv + (mv.include_c ? 6 * (nb - 1) : 0);
-  // Eight record words per lane at a time: all their global loads are issued before the first store, so a chunk costs one
-  // memory round trip (a plain loop pays one per word: the stores to the record keep the next word's load from moving up).
-  constexpr int kChunk = 8;
+  // The new record is assembled in LDS first (segment copies, region A5: the Jacobian is dead), then written out eight words per
+  // lane at a time: all the global loads of a chunk (old record = the observation to emit, reset record) are issued before its
+  // first store, so a chunk costs one memory round trip (a plain loop pays one per word: the stores to the record keep the next
+  // word's load from moving up).
+  float* recbuf = S + P.recbuf;
   const int rec_dim = mv.rec_dim;
+  FOR_G(i, rec_dim) recbuf[i] = 0.f;
+  SYNC();
+  FOR_G(i, nq) recbuf[i] = qpos[i];
+  FOR_G(i, nv) { recbuf[nq + i] = qvel[i]; recbuf[o_qa + i] = qact[i]; recbuf[OP + i] = warm[i]; }
+  if (mv.include_c) {
+    FOR_G(i, 10 * (nb - 1)) recbuf[o_ci + i] = cinert[10 + i];
+    FOR_G(i, 6 * (nb - 1)) recbuf[o_cv + i] = cvel[6 + i];
+  }
+  if (g == 0) { recbuf[OP + nv] = new_comx; recbuf[OP + nv + 1] = time_in + dt_env; }
+  SYNC();
+  constexpr int kChunk = 8;
   for (int i0 = g; i0 < rec_dim; i0 += kGroupLanes * kChunk) {
     float old[kChunk], rst[kChunk];
     _Pragma("unroll") for (int u = 0; u < kChunk; ++u) {
@@ -1086,20 +1107,10 @@ __global__ void __launch_bounds__(kEnvBlock) env_kernel(ModelView mv, EnvArgs a,
     }
     _Pragma("unroll") for (int u = 0; u < kChunk; ++u) {
       const int i = i0 + kGroupLanes * u;
-      // observation = the PRE-step record (env.py:163, quirk C-5), or the reset observation when done (env.py:180)
-      float v = 0.f;
-      if (i < nq) v = qpos[i];
-      else if (i < o_ci) v = qvel[i - nq];
-      else if (i < o_cv) v = cinert[10 + (i - o_ci)];
-      else if (i < o_qa) v = cvel[6 + (i - o_cv)];
-      else if (i < O) v = qact[i - o_qa];
-      else if (i < OP) v = 0.f;
-      else if (i < OP + nv) v = warm[i - OP];
-      else if (i == OP + nv) v = new_comx;
-      else if (i == OP + nv + 1) v = time_in + dt_env;
       if (valid && i < rec_dim) {
+        // observation = the PRE-step record (env.py:163, quirk C-5), or the reset observation when done (env.py:180)
         if (i < OP) a.obs[(size_t)env * a.obs_ld + i] = done ? rst[u] : old[u];
-        recw[i] = done ? rst[u] : v;
+        recw[i] = done ? rst[u] : recbuf[i];
       }
     }
   }

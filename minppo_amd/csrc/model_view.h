@@ -106,7 +106,7 @@ struct PhysLds {
   int qfs, qas, qact, qacc, Ma, grad, Mgrad, search, mv, qfc, t0, t1;
   int D, aref, jaref, jv, force;
   int conpos, condist, confr;  // per contact slot: point, distance, frame rows (normal, first tangent)
-  int A, ximat, xmat, xanchor, xaxis, C1, C2, cdofdot, cfrc, J, ldj;
+  int A, ximat, xmat, xanchor, xaxis, C1, C2, cdofdot, cfrc, J, ldj, recbuf;
   int total;
 };
 
@@ -127,7 +127,7 @@ __host__ __device__ constexpr inline PhysLds make_phys_lds(int nq, int nv, int n
   p.D = take(ne); p.aref = take(ne); p.jaref = take(ne); p.jv = take(ne); p.force = take(ne);
   p.conpos = take(3 * (ncon > 0 ? ncon : 1)); p.condist = take(ncon > 0 ? ncon : 1); p.confr = take(6 * (ncon > 0 ? ncon : 1));
   // region A, four lifetimes (separated by workgroup barriers in the kernel):
-  //   A1 kinematics temporaries | A2 Cholesky work copies | A3 velocity/RNE scratch | A4 constraint Jacobian
+  //   A1 kinematics temporaries | A2 Cholesky work copies | A3 velocity/RNE scratch | A4 constraint Jacobian | A5 record staging
   p.A = o;
   p.ximat = take(9 * nbody); p.xmat = take(9 * nbody); p.xanchor = take(3 * njnt); p.xaxis = take(3 * njnt);
   int end = o;
@@ -135,6 +135,7 @@ __host__ __device__ constexpr inline PhysLds make_phys_lds(int nq, int nv, int n
   o = p.A; p.C1 = take(nv * imax_(p.ldm, p.ldc)); p.C2 = take(nv * imax_(p.ldm, p.ldc)); end = imax_(end, o);
   o = p.A; p.cdofdot = take(6 * nv); p.cfrc = take(6 * nbody); end = imax_(end, o);
   o = p.A; p.ldj = nv + 1; p.J = take(ne * p.ldj); end = imax_(end, o);
+  o = p.A; p.recbuf = take(nq + 3 * nv + 16 * (nbody - 1) + 12); end = imax_(end, o);  // A5: the new state record, assembled before it is written out
   p.total = (end + 3) & ~3;
   return p;
 }
