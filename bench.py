@@ -248,7 +248,7 @@ def spawn_ranks(args: argparse.Namespace) -> int:
         ok = ok and all(p.returncode == 0 for p in procs)
         return ok, line
 
-    limit = float(os.environ.get("MPPO_BENCH_RANK_TIMEOUT", "900"))
+    limit = float(os.environ.get("MPPO_BENCH_RANK_TIMEOUT", "420"))
     ok, line = attempt({}, limit)
     if not ok and os.environ.get("MPPO_GRAPH_COMM", "1") != "0":
         sys.stderr.write("bench.py: ranks failed with RCCL inside the hipGraph; repeating with eager launches (MPPO_GRAPH_COMM=0)\n")
