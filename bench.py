@@ -71,9 +71,12 @@ def rowpass_probe(tr, launches: int = 50, replays: int = 4):
     wsb = tr.lib.grad_ws_bytes(C.byref(tr.net), mb)
     s = tr.stream
 
+    # exactly what the engine launches: the row pass reading the W2^T shadow copies of the gradient workspace (refreshed here once)
+    tr.lib.shadow_refresh(C.byref(tr.net), reg["params"].data_ptr(), mb, reg["grad_ws"].data_ptr(), wsb, s.cuda_stream)
+
     def launch(k):
-        tr.lib.minibatch_rowpass(C.byref(tr.net), reg["params"].data_ptr(), C.byref(batch), reg["perm"].data_ptr() + 4 * (k % M) * mb, mb,
-                                 reg["adv_stats"].data_ptr() + 8 * (k % M), 1.0 / mb, C.byref(lc), reg["grad_ws"].data_ptr(), wsb, s.cuda_stream)
+        tr.lib.minibatch_rowpass_shadow(C.byref(tr.net), reg["params"].data_ptr(), C.byref(batch), reg["perm"].data_ptr() + 4 * (k % M) * mb, mb,
+                                        reg["adv_stats"].data_ptr() + 8 * (k % M), 1.0 / mb, C.byref(lc), reg["grad_ws"].data_ptr(), wsb, s.cuda_stream)
 
     for k in range(3):
         launch(k)

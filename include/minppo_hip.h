@@ -214,6 +214,24 @@ size_t mppo_adam_ws_bytes(size_t P);
 int32_t mppo_clip_adam(size_t P, float* params, float* m, float* v, const float* grad, const int32_t* count_base,
                        int32_t step_offset, const mppo_adam_cfg_t* cfg, void* ws, size_t ws_bytes, void* stream);
 
+/* Shadow copies.  The gradient workspace also holds W2^T of both networks (2 x H x H floats): with them the backward row pass
+ * streams the second-layer weights like a forward layer (23.9 -> 21.9 us for the headline minibatch).  The workspace carries no
+ * state, so the caller says when the copies match `params`:
+ *   mppo_shadow_refresh          builds them from `params` (one small launch; after an upload, a restore, an external write);
+ *   mppo_clip_adam_shadow        = mppo_clip_adam that also writes the updated W2 entries into the copies of `grad_ws`;
+ *   mppo_minibatch_*_shadow      = mppo_minibatch_rowpass / _grad reading the copies (results identical to the plain forms).
+ * The engine (mppo_engine_update / _learn) refreshes once per update and uses the _shadow forms throughout. */
+int32_t mppo_shadow_refresh(const mppo_net_t* net, const float* params, int32_t mb, void* grad_ws, size_t grad_ws_bytes, void* stream);
+int32_t mppo_minibatch_rowpass_shadow(const mppo_net_t* net, const float* params, const mppo_batch_t* batch, const int32_t* idx,
+                                      int32_t mb, const float* adv_stat, float inv_count, const mppo_loss_cfg_t* lc, void* ws,
+                                      size_t ws_bytes, void* stream);
+int32_t mppo_minibatch_grad_shadow(const mppo_net_t* net, const float* params, const mppo_batch_t* batch, const int32_t* idx,
+                                   int32_t mb, const float* adv_stat, float inv_count, const mppo_loss_cfg_t* lc, float* grad,
+                                   float* loss4, void* ws, size_t ws_bytes, void* stream);
+int32_t mppo_clip_adam_shadow(const mppo_net_t* net, int32_t mb, void* grad_ws, size_t grad_ws_bytes, size_t P, float* params,
+                              float* m, float* v, const float* grad, const int32_t* count_base, int32_t step_offset,
+                              const mppo_adam_cfg_t* cfg, void* ws, size_t ws_bytes, void* stream);
+
 /* Counter-based RNG (Philox4x32-10), the engine's own stream (not JAX threefry).
  * mppo_normal_fill: out[i] ~ N(0,1), i in [0,n), a pure function of (seed, stream_id, i).
  * mppo_permutation: idx = a uniformly random permutation of [0,B) (sort of random keys, as

@@ -234,7 +234,16 @@ static int32_t do_learn(mppo_engine* e, hipStream_t s) {
   mppo_batch_t batch;
   batch.obs = e->obs; batch.obs_ld = e->OP; batch.action = e->action; batch.act_ld = e->A; batch.value = e->value; batch.log_prob = e->log_prob;
   batch.adv = e->adv; batch.target = e->target;
-  const GradBufs gb = carve_grad(c.net, e->mb, e->grad_ws);
+  GradBufs gb = carve_grad(c.net, e->mb, e->grad_ws);
+  // W2^T shadow copies for the backward row pass: rebuilt from the parameters once per update (they may have been written from
+  // outside: upload, checkpoint), then kept current by every Adam step of the update
+  static const bool no_shadow = [] { const char* v = getenv("MPPO_NO_SHADOW"); return v && v[0] == '1'; }();  // A/B switch for measurements
+  const bool use_shadow = fused_supported(c.net, batch) && !no_shadow;
+  ShadowRef shadow{gb.w2t, param_layout(c.net.O, c.net.A, c.net.H).a_w2, param_layout(c.net.O, c.net.A, c.net.H).c_w2, c.net.H, 0};
+  if (use_shadow) {
+    MPPO_TRY(shadow_refresh(c.net, e->params, gb, s));
+    gb.w2t_valid = true;
+  }
   const float inv_count = 1.f / ((float)e->mb * (float)c.world_size);
   mppo_adam_cfg_t ac = c.adam;
   ac.sched_div = e->mb * c.world_size * e->E;  // minibatch_size * update_epochs of the GLOBAL batch (train.py:94,100)
@@ -246,7 +255,7 @@ static int32_t do_learn(mppo_engine* e, hipStream_t s) {
       MPPO_TRY(minibatch_grad(c.net, e->params, batch, e->perm + (size_t)ep * e->B + (size_t)k * e->mb, e->mb, e->adv_stats + 2 * st, inv_count, c.loss, e->grad,
                               e->losses + 4 * st, single ? e->adam_ws : nullptr, gb, s));                            // train.py:246-247
       if (!single) MPPO_TRY(comm_allreduce_f32(e->comm, e->grad, (size_t)e->P, s));
-      MPPO_TRY(clip_adam((size_t)e->P, e->params, e->adam_m, e->adam_v, e->grad, e->count, st, ac, e->adam_ws, single, s));  // train.py:248
+      MPPO_TRY(clip_adam((size_t)e->P, e->params, e->adam_m, e->adam_v, e->grad, e->count, st, ac, e->adam_ws, single, s, use_shadow ? &shadow : nullptr));  // train.py:248
     }
   }
   hipLaunchKernelGGL(advance_counters_kernel, dim3(1), dim3(64), 0, s, e->count, EM);

@@ -55,6 +55,7 @@ struct FusedArgs {
   mppo_loss_cfg_t lc;
   float *h1[2], *h2[2], *dz2[2], *dz1[2];
   float *dout, *xmb, *partial;
+  const float* w2t[2];  // W2^T shadow copies (W2T = true instantiations)
   // rollout mode (ROLLOUT = true): forward + pi.sample + pi.log_prob (train.py:157-160); rows are not gathered
   const float* noise;
   float *action, *log_prob, *value, *mean_out;
@@ -78,10 +79,18 @@ struct BStage {
   // NT = false: `wb` is a range-checked view of W[0 .. Kvalid) x H: rows of the zero-padded K tail read as 0
   __device__ __forceinline__ void load(const float* W, const BufView& wb, int H, int K, int S, int n0, int j, int kq) {
     if (NT) {
+      // buffer loads like the forward pipe: the per-lane part of the address is fixed for the whole GEMM, the stage advances a
+      // scalar offset (flat loads recomputed a 64-bit address per load: VALU work in the MFMA stream)
+      const int lane_off = ((n0 + 2 * j) * K + 4 * kq) * 4;
 #pragma unroll
       for (int g = 0; g < 2; ++g) {
+#ifdef MPPO_FUSED_NT_FLAT
         const float4 q0 = *reinterpret_cast<const float4*>(W + (size_t)(n0 + 2 * j) * K + 32 * S + 16 * g + 4 * kq);
         const float4 q1 = *reinterpret_cast<const float4*>(W + (size_t)(n0 + 2 * j + 1) * K + 32 * S + 16 * g + 4 * kq);
+#else
+        const float4 q0 = buf_load_f4(wb, lane_off, (32 * S + 16 * g) * 4);
+        const float4 q1 = buf_load_f4(wb, lane_off + K * 4, (32 * S + 16 * g) * 4);
+#endif
         x0[4 * g] = q0.x; x0[4 * g + 1] = q0.y; x0[4 * g + 2] = q0.z; x0[4 * g + 3] = q0.w;
         x1[4 * g] = q1.x; x1[4 * g + 1] = q1.y; x1[4 * g + 2] = q1.z; x1[4 * g + 3] = q1.w;
       }
@@ -177,7 +186,8 @@ __device__ __forceinline__ float row32_sum(float x) {
 // rollout launches have 2 x N/16 workgroups (512 at N = 4096): two per CU must be co-resident = 4 waves per SIMD (the second
 // __launch_bounds__ argument is HIP's minimum waves per execution unit), i.e. at most 128 VGPRs
 // OT = 16-wide output tiles of the head GEMM: 1 for A <= 16, 2 for A <= 32 (BASELINE configs[4]: 20 actuators)
-template <bool BF16, bool ROLLOUT, int OT>
+// W2T: the backward product reads the transposed shadow copy of W2 (GradBufs::w2t) through the forward-style pipe: 23.9 -> 21.9 us
+template <bool BF16, bool ROLLOUT, int OT, bool W2T = false>
 __global__ void __launch_bounds__(512, ROLLOUT ? MPPO_ROLLOUT_WAVES : 2) fused_mlp_kernel(FusedArgs a) {
   constexpr int SD = 16 * OT;  // row stride of the per-row output-space tiles
   FT(0);
@@ -312,7 +322,8 @@ __global__ void __launch_bounds__(512, ROLLOUT ? MPPO_ROLLOUT_WAVES : 2) fused_m
   FT(3);
   // ---- P1 / P2: hidden layers ----
   GemmPipe<false> pipe2;
-  GemmPipe<true> pipe5;
+  GemmPipe<!W2T> pipe5;
+  const float* W2back = W2T ? a.w2t[net] : W2;
   for (int layer = 0; layer < 2; ++layer) {
     f32x4 acc0, acc1;
     for (int r = 0; r < 4; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
@@ -326,7 +337,7 @@ __global__ void __launch_bounds__(512, ROLLOUT ? MPPO_ROLLOUT_WAVES : 2) fused_m
       // rollout: 4 waves per SIMD hide the fill latency, and the 128-VGPR budget has no room for a cross-phase prefetch
       if (ROLLOUT) pipe2.prefetch(H, H, W2, H, n0, lane);
       if (!(a.skip & 2)) pipe2.template run<BF16>(h1t, HS, H, W2, H, n0, lane, acc0, acc1);
-      if (!ROLLOUT) pipe5.prefetch(H, H, W2, H, n0, lane);  // W2^T fragments of the backward product: hidden under heads / loss / dZ2
+      if (!ROLLOUT) pipe5.prefetch(H, H, W2back, H, n0, lane);  // W2^T fragments of the backward product: hidden under heads / loss / dZ2
     }
     FT(4 + 2 * layer);
 #ifdef MPPO_FUSED_TIMERS
@@ -571,7 +582,7 @@ __global__ void __launch_bounds__(512, ROLLOUT ? MPPO_ROLLOUT_WAVES : 2) fused_m
   {
     f32x4 acc0, acc1;
     for (int r = 0; r < 4; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
-    if (!(a.skip & 16)) pipe5.template run<BF16>(dzt, HS, H, W2, H, n0, lane, acc0, acc1);
+    if (!(a.skip & 16)) pipe5.template run<BF16>(dzt, HS, H, W2back, H, n0, lane, acc0, acc1);
     FT(13);
     const int c0 = n0 + 2 * cj;
     float q0[4], q1[4];
@@ -624,6 +635,10 @@ static int32_t fused_set_smem(size_t smem) {
   MPPO_FUSED_ATTR(false, false, 1); MPPO_FUSED_ATTR(true, false, 1); MPPO_FUSED_ATTR(false, true, 1); MPPO_FUSED_ATTR(true, true, 1);
   MPPO_FUSED_ATTR(false, false, 2); MPPO_FUSED_ATTR(true, false, 2); MPPO_FUSED_ATTR(false, true, 2); MPPO_FUSED_ATTR(true, true, 2);
 #undef MPPO_FUSED_ATTR
+#define MPPO_FUSED_ATTR(B, T) \
+  MPPO_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(fused_mlp_kernel<B, false, T, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem))
+  MPPO_FUSED_ATTR(false, 1); MPPO_FUSED_ATTR(true, 1); MPPO_FUSED_ATTR(false, 2); MPPO_FUSED_ATTR(true, 2);
+#undef MPPO_FUSED_ATTR
   return MPPO_OK;
 }
 
@@ -634,6 +649,8 @@ int32_t fused_forward_backward(const mppo_net_t& net, const float* params, const
   a.params = params; a.L = param_layout(net.O, net.A, net.H); a.b = batch; a.idx = idx; a.adv_stat = adv_stat; a.inv_count = inv_count; a.lc = lc;
   a.h1[0] = g.f.h1a; a.h1[1] = g.f.h1c; a.h2[0] = g.f.h2a; a.h2[1] = g.f.h2c; a.dz2[0] = g.dz2a; a.dz2[1] = g.dz2c; a.dz1[0] = g.dz1a; a.dz1[1] = g.dz1c;
   a.dout = g.dout; a.xmb = g.xmb; a.partial = g.partial;
+  const bool w2t = g.w2t_valid && g.w2t;
+  a.w2t[0] = g.w2t; a.w2t[1] = g.w2t ? g.w2t + pad4((size_t)net.H * net.H) : nullptr;
   static const int skip = [] { const char* e = getenv("MPPO_FUSED_SKIP"); return e ? atoi(e) : 0; }();
   a.skip = skip;
   const size_t smem = fused_smem_bytes(net.O, net.A, net.H);
@@ -643,13 +660,14 @@ int32_t fused_forward_backward(const mppo_net_t& net, const float* params, const
     attr_for = smem;
   }
   const dim3 grid(cdiv(mb, FRT), 2), block(2 * net.H);
+#define MPPO_FUSED_GO(B, T) do { if (w2t) hipLaunchKernelGGL((fused_mlp_kernel<B, false, T, true>), grid, block, smem, stream, a); \
+                                else hipLaunchKernelGGL((fused_mlp_kernel<B, false, T, false>), grid, block, smem, stream, a); } while (0)
   if (net.A > 16) {
-    if (net.bf16) hipLaunchKernelGGL((fused_mlp_kernel<true, false, 2>), grid, block, smem, stream, a);
-    else hipLaunchKernelGGL((fused_mlp_kernel<false, false, 2>), grid, block, smem, stream, a);
+    if (net.bf16) MPPO_FUSED_GO(true, 2); else MPPO_FUSED_GO(false, 2);
   } else {
-    if (net.bf16) hipLaunchKernelGGL((fused_mlp_kernel<true, false, 1>), grid, block, smem, stream, a);
-    else hipLaunchKernelGGL((fused_mlp_kernel<false, false, 1>), grid, block, smem, stream, a);
+    if (net.bf16) MPPO_FUSED_GO(true, 1); else MPPO_FUSED_GO(false, 1);
   }
+#undef MPPO_FUSED_GO
   MPPO_CHECK_LAUNCH("fused_mlp_kernel");
   return MPPO_OK;
 }

@@ -342,7 +342,7 @@ __global__ void __launch_bounds__(256) sumsq_kernel(size_t P, const float* __res
 
 __global__ void __launch_bounds__(256) adam_kernel(size_t P, float* __restrict__ p, float* __restrict__ m, float* __restrict__ v,
                                                    const float* __restrict__ g, const float* __restrict__ partial, const int* __restrict__ count_base,
-                                                   int step_offset, mppo_adam_cfg_t c) {
+                                                   int step_offset, mppo_adam_cfg_t c, ShadowRef sh) {
   // every wave adds the same kSqSlots (= 512) partials in the same order (eight per lane, fixed reduction tree):
   // bitwise-identical clip scale everywhere without a second pass
   const int ln = threadIdx.x & 63;
@@ -355,8 +355,49 @@ __global__ void __launch_bounds__(256) adam_kernel(size_t P, float* __restrict__
   if (c.anneal) lr = c.lr * (1.f - (float)(count / c.sched_div) / (float)c.num_updates);
   const float t = (float)(count + 1);
   const float bc1 = 1.f - powf(c.b1, t), bc2 = 1.f - powf(c.b2, t);
+  auto step = [&](float gi, float mo, float vo, float po, float& mn, float& vn, float& pn) {
+    const float gs = gi * scale;
+    mn = c.b1 * mo + (1.f - c.b1) * gs;
+    vn = c.b2 * vo + (1.f - c.b2) * gs * gs;
+    pn = po - lr * (mn / bc1) / (sqrtf(vn / bc2) + c.eps);
+  };
+  if (sh.w2t && blockIdx.x >= sh.flat_blocks) {
+    // W2 of the actor / critic, one 32 x 32 tile (k x n) per workgroup: the same update, and the tile goes transposed into the
+    // shadow copy w2t[n][k] through LDS (128-byte row segments both ways; a flat thread would scatter four 4-byte stores)
+    __shared__ float tile[32][33];
+    const int tb = blockIdx.x - sh.flat_blocks, tiles = sh.H / 32, per_net = tiles * tiles;
+    const int netc = tb / per_net, tt = tb - netc * per_net, k0 = 32 * (tt / tiles), n0 = 32 * (tt % tiles);
+    const size_t base = (size_t)(netc ? sh.c_w2 : sh.a_w2);
+    float* T = sh.w2t + (netc ? (((size_t)sh.H * sh.H + 3) & ~(size_t)3) : 0);
+    // thread = (row k = t / 8, four columns n = 4 (t % 8) ..): one float4 per array, exactly like a flat thread
+    const int kr = threadIdx.x >> 3, nq = (threadIdx.x & 7) * 4;
+    const size_t i = base + (size_t)(k0 + kr) * sh.H + n0 + nq;
+    const float4 gq = *reinterpret_cast<const float4*>(g + i), mq = *reinterpret_cast<const float4*>(m + i), vq = *reinterpret_cast<const float4*>(v + i);
+    const float4 pq = *reinterpret_cast<const float4*>(p + i);
+    const float gi[4] = {gq.x, gq.y, gq.z, gq.w}, mo[4] = {mq.x, mq.y, mq.z, mq.w}, vo[4] = {vq.x, vq.y, vq.z, vq.w}, po[4] = {pq.x, pq.y, pq.z, pq.w};
+    float mn[4], vn[4], pn[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      step(gi[q], mo[q], vo[q], po[q], mn[q], vn[q], pn[q]);
+      tile[kr][nq + q] = pn[q];
+    }
+    stream_store(m + i, make_float4(mn[0], mn[1], mn[2], mn[3]));  // like the flat path: next read by the next step's Adam
+    stream_store(v + i, make_float4(vn[0], vn[1], vn[2], vn[3]));
+    *reinterpret_cast<float4*>(p + i) = make_float4(pn[0], pn[1], pn[2], pn[3]);
+    __syncthreads();
+    // w2t[n0 + nr][k0 + 4 kq ..]: four consecutive k of one column, eight threads per 128-byte row segment
+    const int nr = threadIdx.x >> 3, kq = (threadIdx.x & 7) * 4;
+    *reinterpret_cast<float4*>(T + (size_t)(n0 + nr) * sh.H + k0 + kq) = make_float4(tile[kq][nr], tile[kq + 1][nr], tile[kq + 2][nr], tile[kq + 3][nr]);
+    return;
+  }
   // four parameters per thread (the flat layout is a whole number of float4: ppo_layout.h): a quarter of the workgroups to dispatch
-  const size_t i4 = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  size_t i4 = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (sh.w2t) {
+    // the flat workgroups enumerate everything EXCEPT the two W2 ranges (those belong to the tile workgroups above), so the
+    // grid is no larger than without the shadow copies; all boundaries are multiples of four floats (16-byte aligned tensors)
+    const size_t HH4 = (size_t)sh.H * sh.H / 4, a4 = (size_t)sh.a_w2 / 4, c4 = (size_t)sh.c_w2 / 4;
+    i4 = i4 < a4 ? i4 : (i4 + HH4 < c4 ? i4 + HH4 : i4 + 2 * HH4);
+  }
   if (4 * i4 >= P) return;
   if (4 * i4 + 3 < P) {
     const float4 gq = reinterpret_cast<const float4*>(g)[i4], mq = reinterpret_cast<const float4*>(m)[i4], vq = reinterpret_cast<const float4*>(v)[i4];
@@ -583,15 +624,39 @@ int32_t minibatch_grad(const mppo_net_t& net, const float* params, const mppo_ba
   return MPPO_OK;
 }
 
+// w2t[net][n][k] = W2_net[k][n]: 32 x 32 tiles through LDS, both networks in one launch
+__global__ void __launch_bounds__(256) w2_transpose_kernel(const float* __restrict__ params, int a_w2, int c_w2, int H, float* __restrict__ w2t) {
+  __shared__ float tile[32][33];
+  const float* W = params + (blockIdx.z ? c_w2 : a_w2);
+  float* T = w2t + (blockIdx.z ? (((size_t)H * H + 3) & ~(size_t)3) : 0);
+  const int k0 = 32 * blockIdx.y, n0 = 32 * blockIdx.x, tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  for (int r = ty; r < 32; r += 8) tile[r][tx] = (k0 + r < H && n0 + tx < H) ? W[(size_t)(k0 + r) * H + n0 + tx] : 0.f;
+  __syncthreads();
+  for (int r = ty; r < 32; r += 8) if (n0 + r < H && k0 + tx < H) T[(size_t)(n0 + r) * H + k0 + tx] = tile[tx][r];
+}
+
+int32_t shadow_refresh(const mppo_net_t& net, const float* params, const GradBufs& gbuf, hipStream_t stream) {
+  const ParamLayout L = param_layout(net.O, net.A, net.H);
+  hipLaunchKernelGGL(w2_transpose_kernel, dim3(cdiv(net.H, 32), cdiv(net.H, 32), 2), dim3(256), 0, stream, params, L.a_w2, L.c_w2, net.H, gbuf.w2t);
+  MPPO_CHECK_LAUNCH("w2_transpose_kernel");
+  return MPPO_OK;
+}
+
 int32_t clip_adam(size_t P, float* params, float* m, float* v, const float* grad, const int* count_base, int step_offset, const mppo_adam_cfg_t& cfg,
-                  float* ws, bool have_sumsq, hipStream_t stream) {
+                  float* ws, bool have_sumsq, hipStream_t stream, const ShadowRef* shadow) {
   if (!have_sumsq) {
     hipLaunchKernelGGL(sumsq_kernel, dim3(kNormBlocks), dim3(256), 0, stream, P, grad, ws);
     MPPO_CHECK_LAUNCH("sumsq_kernel");
   }
   MPPO_REQUIRE((reinterpret_cast<uintptr_t>(params) & 15) == 0 && (reinterpret_cast<uintptr_t>(m) & 15) == 0 && (reinterpret_cast<uintptr_t>(v) & 15) == 0 &&
                    (reinterpret_cast<uintptr_t>(grad) & 15) == 0, "clip_adam: params / m / v / grad must be 16-byte aligned");
-  hipLaunchKernelGGL(adam_kernel, dim3(cdiv((long)((P + 3) / 4), 256)), dim3(256), 0, stream, P, params, m, v, grad, ws, count_base, step_offset, cfg);
+  ShadowRef sh = shadow ? *shadow : ShadowRef{nullptr, 0, 0, 0, 0};
+  MPPO_REQUIRE(!sh.w2t || sh.H % 32 == 0, "clip_adam: the W2^T shadow copies need H %% 32 == 0 (H = %d)", sh.H);
+  const int tile_blocks = sh.w2t ? 2 * (sh.H / 32) * (sh.H / 32) : 0;
+  const int flat_blocks = cdiv((long)((P + 3) / 4) - (sh.w2t ? (long)sh.H * sh.H / 2 : 0), 256);  // float4 slots outside the two W2 ranges
+  sh.flat_blocks = flat_blocks;
+  hipLaunchKernelGGL(adam_kernel, dim3(flat_blocks + tile_blocks), dim3(256), 0, stream, P, params, m, v, grad, ws, count_base, step_offset, cfg,
+                     sh);
   MPPO_CHECK_LAUNCH("adam_kernel");
   return MPPO_OK;
 }
@@ -694,6 +759,53 @@ extern "C" int32_t mppo_clip_adam(size_t P, float* params, float* m, float* v, c
   MPPO_REQUIRE(!cfg->anneal || (cfg->sched_div >= 1 && cfg->num_updates >= 1), "mppo_clip_adam: anneal needs sched_div, num_updates >= 1");
   if (ws_bytes < mppo_adam_ws_bytes(P)) return fail(MPPO_ENOMEM, "mppo_clip_adam: workspace too small");
   return clip_adam(P, params, m, v, grad, count_base, step_offset, *cfg, static_cast<float*>(ws), false, static_cast<hipStream_t>(stream));
+}
+
+// ---- the same three entry points with the W2^T shadow copies (GradBufs::w2t inside `grad_ws`) in play ----------------------------
+extern "C" int32_t mppo_shadow_refresh(const mppo_net_t* net, const float* params, int32_t mb, void* grad_ws, size_t grad_ws_bytes, void* stream) {
+  MPPO_TRY(check_net(net));
+  MPPO_REQUIRE(params && grad_ws && mb >= 1, "mppo_shadow_refresh: null argument or mb < 1");
+  if (grad_ws_bytes < mppo_grad_ws_bytes(net, mb)) return fail(MPPO_ENOMEM, "mppo_shadow_refresh: workspace %zu < %zu bytes", grad_ws_bytes, mppo_grad_ws_bytes(net, mb));
+  return shadow_refresh(*net, params, carve_grad(*net, mb, static_cast<float*>(grad_ws)), static_cast<hipStream_t>(stream));
+}
+
+extern "C" int32_t mppo_minibatch_rowpass_shadow(const mppo_net_t* net, const float* params, const mppo_batch_t* batch, const int32_t* idx, int32_t mb,
+                                                 const float* adv_stat, float inv_count, const mppo_loss_cfg_t* lc, void* ws, size_t ws_bytes, void* stream) {
+  MPPO_TRY(check_net(net));
+  MPPO_REQUIRE(params && batch && adv_stat && lc && ws && mb >= 1, "mppo_minibatch_rowpass_shadow: null argument or mb < 1");
+  if (ws_bytes < mppo_grad_ws_bytes(net, mb)) return fail(MPPO_ENOMEM, "mppo_minibatch_rowpass_shadow: workspace %zu < %zu bytes", ws_bytes, mppo_grad_ws_bytes(net, mb));
+  GradBufs gb = carve_grad(*net, mb, static_cast<float*>(ws));
+  gb.w2t_valid = true;
+  int nblk = 0;
+  return minibatch_rowpass(*net, params, *batch, idx, mb, adv_stat, inv_count, *lc, gb, &nblk, nullptr, static_cast<hipStream_t>(stream));
+}
+
+extern "C" int32_t mppo_minibatch_grad_shadow(const mppo_net_t* net, const float* params, const mppo_batch_t* batch, const int32_t* idx, int32_t mb,
+                                              const float* adv_stat, float inv_count, const mppo_loss_cfg_t* lc, float* grad, float* loss4, void* ws,
+                                              size_t ws_bytes, void* stream) {
+  MPPO_TRY(check_net(net));
+  MPPO_REQUIRE(params && batch && adv_stat && lc && grad && ws && mb >= 1, "mppo_minibatch_grad_shadow: null argument or mb < 1");
+  MPPO_REQUIRE(batch->obs && batch->action && batch->value && batch->log_prob && batch->adv && batch->target, "mppo_minibatch_grad_shadow: null batch field");
+  MPPO_REQUIRE(batch->obs_ld >= net->O && batch->act_ld >= net->A, "mppo_minibatch_grad_shadow: leading dimensions too small");
+  if (ws_bytes < mppo_grad_ws_bytes(net, mb)) return fail(MPPO_ENOMEM, "mppo_minibatch_grad_shadow: workspace %zu < %zu bytes", ws_bytes, mppo_grad_ws_bytes(net, mb));
+  GradBufs gb = carve_grad(*net, mb, static_cast<float*>(ws));
+  gb.w2t_valid = true;
+  return minibatch_grad(*net, params, *batch, idx, mb, adv_stat, inv_count, *lc, grad, loss4, nullptr, gb, static_cast<hipStream_t>(stream));
+}
+
+extern "C" int32_t mppo_clip_adam_shadow(const mppo_net_t* net, int32_t mb, void* grad_ws, size_t grad_ws_bytes, size_t P, float* params, float* m, float* v,
+                                         const float* grad, const int32_t* count_base, int32_t step_offset, const mppo_adam_cfg_t* cfg, void* ws, size_t ws_bytes,
+                                         void* stream) {
+  MPPO_TRY(check_net(net));
+  MPPO_REQUIRE(P >= 1 && params && m && v && grad && count_base && cfg && ws && grad_ws && mb >= 1, "mppo_clip_adam_shadow: null argument");
+  MPPO_REQUIRE(P == mppo_param_count(net), "mppo_clip_adam_shadow: P = %zu is not this network's parameter count (%zu)", P, mppo_param_count(net));
+  MPPO_REQUIRE(!cfg->anneal || (cfg->sched_div >= 1 && cfg->num_updates >= 1), "mppo_clip_adam_shadow: anneal needs sched_div, num_updates >= 1");
+  if (ws_bytes < mppo_adam_ws_bytes(P)) return fail(MPPO_ENOMEM, "mppo_clip_adam_shadow: workspace too small");
+  if (grad_ws_bytes < mppo_grad_ws_bytes(net, mb)) return fail(MPPO_ENOMEM, "mppo_clip_adam_shadow: gradient workspace too small");
+  const GradBufs gb = carve_grad(*net, mb, static_cast<float*>(grad_ws));
+  const ParamLayout L = param_layout(net->O, net->A, net->H);
+  const ShadowRef sh{gb.w2t, L.a_w2, L.c_w2, net->H, 0};
+  return clip_adam(P, params, m, v, grad, count_base, step_offset, *cfg, static_cast<float*>(ws), false, static_cast<hipStream_t>(stream), &sh);
 }
 
 extern "C" int32_t mppo_normal_fill(uint64_t seed, uint64_t stream_id, size_t n, float* out, void* stream) {

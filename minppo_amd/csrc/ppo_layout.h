@@ -74,6 +74,12 @@ struct GradBufs {
   FwdBufs f;
   float *dout, *dz2a, *dz2c, *dz1a, *dz1c, *partial, *slabs;  // dout [mb, AP+4]: d mean | d value
   float* xmb;  // [mb, OP]: the minibatch observations, laid out contiguously by the first forward GEMM
+  // Shadow copy of the second-layer weights, transposed: w2t[net][n][k] = W2_net[k][n] (net 0 actor, 1 critic).  The backward
+  // product dZ1 = dZ2 . W2^T then streams its B operand exactly like a forward layer (rows of consecutive outputs) instead of
+  // gathering 16-byte pieces of 32 different rows per load.  Written by shadow_refresh() and kept current by clip_adam(); the
+  // CALLER knows whether it matches `params` (w2t_valid): the workspace itself carries no state.
+  float* w2t;
+  bool w2t_valid;
   int ksplit;
   size_t slab_stride;
 };
@@ -82,7 +88,7 @@ inline size_t grad_bufs_floats(const mppo_net_t& net, int mb) {
   const size_t AP = pad4((size_t)net.A), nh = pad4(mbp * net.H);
   const size_t P = pad4((size_t)param_layout(net.O, net.A, net.H).total);
   const size_t nblk = (size_t)(mb + 7) / 8;  // head kernel: 8 rows per workgroup (fused kernel: 16)
-  return fwd_bufs_floats(net, (int)mbp) + pad4(mbp * (AP + 4)) + 4 * nh + pad4(nblk * (4 + AP)) + (size_t)kGradKSplitMax * P + pad4(mbp * net.OP);
+  return fwd_bufs_floats(net, (int)mbp) + pad4(mbp * (AP + 4)) + 4 * nh + pad4(nblk * (4 + AP)) + (size_t)kGradKSplitMax * P + pad4(mbp * net.OP) + 2 * pad4((size_t)net.H * net.H);
 }
 inline GradBufs carve_grad(const mppo_net_t& net, int mb, float* ws) {
   GradBufs g;
@@ -96,6 +102,8 @@ inline GradBufs carve_grad(const mppo_net_t& net, int mb, float* ws) {
   g.partial = ws; ws += pad4(nblk * (4 + AP));
   g.slabs = ws;
   g.xmb = ws + (size_t)kGradKSplitMax * pad4((size_t)param_layout(net.O, net.A, net.H).total);
+  g.w2t = g.xmb + pad4(mbp * net.OP);
+  g.w2t_valid = false;
   g.ksplit = grad_ksplit();
   g.slab_stride = pad4((size_t)param_layout(net.O, net.A, net.H).total);
   return g;
@@ -107,8 +115,11 @@ int32_t policy_forward(const mppo_net_t& net, const float* params, int n, const 
 // sq_partial (optional): per-workgroup sums of squares of the reduced gradient, consumed by clip_adam(have_sumsq = true)
 int32_t minibatch_grad(const mppo_net_t& net, const float* params, const mppo_batch_t& batch, const int* idx, int mb, const float* adv_stat, float inv_count,
                        const mppo_loss_cfg_t& lc, float* grad, float* loss4, float* sq_partial, const GradBufs& gbuf, hipStream_t stream);
+// shadow (optional): the W2^T copies to keep in step with the parameters (GradBufs::w2t of the workspace the row pass reads)
+struct ShadowRef { float* w2t; int a_w2, c_w2, H, flat_blocks; };  // flat_blocks: filled in by clip_adam
 int32_t clip_adam(size_t P, float* params, float* m, float* v, const float* grad, const int* count_base, int step_offset, const mppo_adam_cfg_t& cfg, float* ws,
-                  bool have_sumsq, hipStream_t stream);
+                  bool have_sumsq, hipStream_t stream, const ShadowRef* shadow = nullptr);
+int32_t shadow_refresh(const mppo_net_t& net, const float* params, const GradBufs& gbuf, hipStream_t stream);
 int32_t gae_launch(int T, int N, float gamma, float lam, const float* reward, const float* value, const unsigned char* done, const float* last_val, float* adv,
                    float* target, hipStream_t stream);
 // k_fused.hip: row-local forward + backward of one minibatch in a single launch (falls back to the layer-wise path when unsupported)

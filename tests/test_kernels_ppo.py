@@ -400,3 +400,58 @@ def test_gemm_batch_variants(be):
     X = A[g2][:, :Min].astype(np.float64)
     np.testing.assert_allclose(s[:Min], X.T @ dZ, atol=2e-5)
     np.testing.assert_allclose(s[Min], dZ.sum(0), atol=2e-5)
+
+
+def test_shadow_copies_change_nothing_but_the_layout_of_one_operand(be):
+    """The W2^T shadow copies inside the gradient workspace (include/minppo_hip.h): mppo_minibatch_grad_shadow == mppo_minibatch_grad
+    bit for bit (the backward product issues the same MFMAs on the same values), mppo_clip_adam_shadow == mppo_clip_adam bit
+    for bit on params / m / v, and after it the copies equal a fresh mppo_shadow_refresh of the new parameters."""
+    O, A, H, B, mb = 37, 5, 64, 96, 48
+    OP = (O + 3) // 4 * 4
+    rng = np.random.default_rng(5)
+    net = nat.Net(O, OP, A, H, 1, 0)
+    named = po.init_params(3, O, A, H)
+    flat = po.named_to_flat(named, O, A, H).astype(f32)
+    P = flat.size
+    bobs = np.zeros((B, OP), f32); bobs[:, :O] = rng.standard_normal((B, O))
+    arrs = dict(flat=flat, obs=bobs, act=rng.standard_normal((B, A)).astype(f32), val=rng.standard_normal(B).astype(f32), lp=rng.standard_normal(B).astype(f32),
+                adv=rng.standard_normal(B).astype(f32), tgt=rng.standard_normal(B).astype(f32), idx=rng.permutation(B)[:mb].astype(np.int32))
+    d = {k: be.arr(v) for k, v in arrs.items()}
+    stats = be.arr(np.array([0.1, 0.9], f32))
+    batch = nat.Batch(be.ptr(d["obs"]), OP, be.ptr(d["act"]), A, be.ptr(d["val"]), be.ptr(d["lp"]), be.ptr(d["adv"]), be.ptr(d["tgt"]))
+    lc = nat.LossCfg(0.2, 0.5, 0.01)
+    fused = C.c_int32(-1)
+    be.lib.minibatch_path(C.byref(net), C.byref(batch), C.byref(fused))
+    assert fused.value == 1
+    wsb = be.lib.grad_ws_bytes(C.byref(net), mb)
+    ws = be.full((wsb // 4 + 4,), np.nan)
+    g0, g1, l0, l1 = be.full((P,), np.nan), be.full((P,), np.nan), be.zeros((4,)), be.zeros((4,))
+    common = lambda grad, loss: (C.byref(net), be.ptr(d["flat"]), C.byref(batch), be.ptr(d["idx"]), mb, be.ptr(stats), 1.0 / mb, C.byref(lc), be.ptr(grad),
+                                 be.ptr(loss), be.ptr(ws), wsb, be.stream)
+    be.lib.minibatch_grad(*common(g0, l0))
+    be.lib.shadow_refresh(C.byref(net), be.ptr(d["flat"]), mb, be.ptr(ws), wsb, be.stream)
+    be.lib.minibatch_grad_shadow(*common(g1, l1))
+    assert np.array_equal(be.host(g0), be.host(g1)) and np.array_equal(be.host(l0), be.host(l1)) and not np.isnan(be.host(g1)).any()
+    # Adam: plain on one copy of the state, shadow-maintaining on another
+    cfg = nat.AdamCfg(3e-3, 0.5, 0.9, 0.999, 1e-5, 0, 1, 1)
+    awsb = be.lib.adam_ws_bytes(P)
+    st = [dict(p=be.arr(flat), m=be.zeros((P,)), v=be.zeros((P,)), aws=be.zeros((awsb // 4,))) for _ in range(2)]
+    cnt = be.zeros((1,), np.int32)
+    be.lib.clip_adam(P, be.ptr(st[0]["p"]), be.ptr(st[0]["m"]), be.ptr(st[0]["v"]), be.ptr(g0), be.ptr(cnt), 0, C.byref(cfg), be.ptr(st[0]["aws"]), awsb, be.stream)
+    be.lib.clip_adam_shadow(C.byref(net), mb, be.ptr(ws), wsb, P, be.ptr(st[1]["p"]), be.ptr(st[1]["m"]), be.ptr(st[1]["v"]), be.ptr(g0), be.ptr(cnt), 0,
+                            C.byref(cfg), be.ptr(st[1]["aws"]), awsb, be.stream)
+    for k in ("p", "m", "v"):
+        assert np.array_equal(be.host(st[0][k]), be.host(st[1][k])), k
+    assert not np.array_equal(be.host(st[1]["p"]), flat)
+    after_adam = be.host(ws).copy()
+    be.lib.shadow_refresh(C.byref(net), be.ptr(st[1]["p"]), mb, be.ptr(ws), wsb, be.stream)
+    fresh = be.host(ws)
+    assert np.array_equal(after_adam, fresh, equal_nan=True)
+    # and they are the transposes (the copies are the last 2 H^2 floats of the workspace)
+    sl = po.param_slices(O, A, H)
+    newp = be.host(st[1]["p"])
+    tail = fresh[: wsb // 4][-2 * H * H:]
+    for i, k in enumerate(("a_w2", "c_w2")):
+        o, shp = sl[k]
+        assert shp == (H, H)
+        np.testing.assert_array_equal(tail[i * H * H:(i + 1) * H * H].reshape(H, H), newp[o:o + H * H].reshape(H, H).T)
