@@ -181,6 +181,11 @@ constexpr unsigned long long kStreamNoise = 0x4E4F495345ull << 24;  // "NOISE"
 constexpr unsigned long long kStreamPerm = 0x5045524Dull << 24;     // "PERM"
 
 
+static bool shadow_enabled() {  // MPPO_NO_SHADOW=1: A/B switch for measurements
+  static const bool no_shadow = [] { const char* v = getenv("MPPO_NO_SHADOW"); return v && v[0] == '1'; }();
+  return !no_shadow;
+}
+
 static int32_t do_rollout(mppo_engine* e, hipStream_t s) {
   const mppo_engine_cfg_t& c = e->cfg;
   const size_t N = e->N, OP = e->OP, A = e->A;
@@ -198,6 +203,13 @@ static int32_t do_rollout(mppo_engine* e, hipStream_t s) {
     }
   }
   FwdBufs fb = carve_fwd(c.net, e->N, e->fwd_ws);
+  if (c.net.bf16 && shadow_enabled() && fused_rollout_supported(c.net, e->obs, e->OP)) {
+    // bf16 network: the rollout forwards read the bf16 fragment copies of the gradient workspace too; they are rebuilt here (the
+    // parameters may have been written from outside since the last update) and nothing changes the parameters before the learn phase
+    const GradBufs gb = carve_grad(c.net, e->mb, e->grad_ws);
+    MPPO_TRY(shadow_refresh(c.net, e->params, gb, s));
+    fb.frag = gb.frag; fb.frag_net_stride = gb.frag_net_stride;
+  }
   for (int t = 0; t < e->T; ++t) {
     const float* obs_t = e->obs + (size_t)t * N * OP;
     MPPO_TRY(policy_forward(c.net, e->params, e->N, obs_t, e->OP, fb, e->noise + t * N * A, e->action + t * N * A, e->log_prob + t * N,
@@ -237,9 +249,8 @@ static int32_t do_learn(mppo_engine* e, hipStream_t s) {
   GradBufs gb = carve_grad(c.net, e->mb, e->grad_ws);
   // W2^T shadow copies for the backward row pass: rebuilt from the parameters once per update (they may have been written from
   // outside: upload, checkpoint), then kept current by every Adam step of the update
-  static const bool no_shadow = [] { const char* v = getenv("MPPO_NO_SHADOW"); return v && v[0] == '1'; }();  // A/B switch for measurements
-  const bool use_shadow = fused_supported(c.net, batch) && !no_shadow;
-  ShadowRef shadow{gb.w2t, param_layout(c.net.O, c.net.A, c.net.H).a_w2, param_layout(c.net.O, c.net.A, c.net.H).c_w2, c.net.H, 0};
+  const bool use_shadow = fused_supported(c.net, batch) && shadow_enabled();
+  ShadowRef shadow = make_shadow_ref(c.net, gb);
   if (use_shadow) {
     MPPO_TRY(shadow_refresh(c.net, e->params, gb, s));
     gb.w2t_valid = true;

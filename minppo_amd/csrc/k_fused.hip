@@ -56,6 +56,7 @@ struct FusedArgs {
   float *h1[2], *h2[2], *dz2[2], *dz1[2];
   float *dout, *xmb, *partial;
   const float* w2t[2];  // W2^T shadow copies (W2T = true instantiations)
+  const unsigned short* frag[2];  // bf16 fragment-order copies per network: W1 (KP x H) | W2 | W2^T (BF16 && W2T instantiations)
   // rollout mode (ROLLOUT = true): forward + pi.sample + pi.log_prob (train.py:157-160); rows are not gathered
   const float* noise;
   float *action, *log_prob, *value, *mean_out;
@@ -176,6 +177,68 @@ struct GemmPipe {
   }
 };
 
+// The same ring for a bf16 network with shadow copies: the B operand comes from the fragment-order bf16 copy of the weight
+// (ppo_layout.h frag_index): a lane's sixteen values of a stage are 32 contiguous bytes (two 16-byte buffer loads instead of eight
+// 8-byte ones, half the bytes, and no float -> bf16 conversion of weights in the loop).  `W` = fragment base of the matrix.
+struct FragStage {
+  float4 q0, q1;  // raw bits: q0 = tile 0 (k 0..3 of group 0 | group 1), q1 = tile 1
+  __device__ __forceinline__ void load(const BufView& wb, int S, int nwaves, int wave, int lane) {
+    const int uni = ((S * nwaves + wave) * 64) * 32;  // bytes: (stage, wave slab) block of 2 KB
+    q0 = buf_load_f4(wb, lane * 32, uni);
+    q1 = buf_load_f4(wb, lane * 32 + 16, uni);
+  }
+};
+__device__ __forceinline__ void frag_mfma(const float* arow, int S, const FragStage& b, f32x4& acc0, f32x4& acc1) {
+  const float4 a0 = *reinterpret_cast<const float4*>(arow + 32 * S);
+  const float4 a1 = *reinterpret_cast<const float4*>(arow + 32 * S + 16);
+  const bf16x4 A0 = pack_bf16x4(a0.x, a0.y, a0.z, a0.w), A1 = pack_bf16x4(a1.x, a1.y, a1.z, a1.w);
+  const bf16x4 t0g0 = bf16x4_from_bits(b.q0.x, b.q0.y), t0g1 = bf16x4_from_bits(b.q0.z, b.q0.w);
+  const bf16x4 t1g0 = bf16x4_from_bits(b.q1.x, b.q1.y), t1g1 = bf16x4_from_bits(b.q1.z, b.q1.w);
+  mfma_bf16_16x16x16(A0, t0g0, acc0);
+  mfma_bf16_16x16x16(A0, t1g0, acc1);
+  mfma_bf16_16x16x16(A1, t0g1, acc0);
+  mfma_bf16_16x16x16(A1, t1g1, acc1);
+}
+struct FragPipe {
+  FragStage b0, b1;
+  BufView wb;
+  int nw;
+  // same interface as GemmPipe (K = padded depth, H = columns, n0 = 32 * wave); Kvalid is implicit (the copy is zero-padded)
+  __device__ __forceinline__ void prefetch(int K, int, const float* W, int H, int n0, int lane) {
+    const int last = K / 32 - 1;
+    nw = H / 32;
+    wb = make_buf(W, (unsigned)K * (unsigned)H * 2u);
+    b0.load(wb, 0, nw, n0 >> 5, lane);
+    b1.load(wb, last < 1 ? last : 1, nw, n0 >> 5, lane);
+  }
+  template <bool BF16>
+  __device__ __forceinline__ void run(const float* At, int AS, int K, const float*, int, int n0, int lane, f32x4& acc0, f32x4& acc1) {
+    const int j = lane & 15, kq = lane >> 4, wv = n0 >> 5;
+    const float* arow = At + j * AS + 4 * kq;
+    const int nst = K / 32, last = nst - 1;
+    FragStage b2;
+    int S = 0;
+    for (; S + 2 < nst; S += 3) {
+      b2.load(wb, S + 2, nw, wv, lane);
+      MPPO_SCHED_FENCE();
+      frag_mfma(arow, S, b0, acc0, acc1);
+      MPPO_SCHED_FENCE();
+      b0.load(wb, S + 3 < last ? S + 3 : last, nw, wv, lane);
+      MPPO_SCHED_FENCE();
+      frag_mfma(arow, S + 1, b1, acc0, acc1);
+      MPPO_SCHED_FENCE();
+      b1.load(wb, S + 4 < last ? S + 4 : last, nw, wv, lane);
+      MPPO_SCHED_FENCE();
+      frag_mfma(arow, S + 2, b2, acc0, acc1);
+      MPPO_SCHED_FENCE();
+    }
+    if (S < nst) frag_mfma(arow, S, b0, acc0, acc1);
+    if (S + 1 < nst) frag_mfma(arow, S + 1, b1, acc0, acc1);
+  }
+};
+template <bool FRAG, bool NT> struct PipeSel { typedef GemmPipe<NT> type; };
+template <bool NT> struct PipeSel<true, NT> { typedef FragPipe type; };
+
 template <int LRW>
 __device__ __forceinline__ float row32_sum(float x) {
   x = group16_sum(x);
@@ -221,8 +284,11 @@ __global__ void __launch_bounds__(512, ROLLOUT ? MPPO_ROLLOUT_WAVES : 2) fused_m
   // ---- everything that depends on nothing computed here is requested now and consumed phases later: the first two
   // weight stages of layer 1, the biases, and the per-row scalars of the loss (index -> action / log_prob / advantage /
   // value / target: a dependent HBM chain of ~3 us that would otherwise sit between the head GEMM and the loss) ----
-  GemmPipe<false> pipe1;
-  pipe1.prefetch(KP, O, W1, H, n0, lane);
+  constexpr bool FRAG = BF16 && W2T;  // weights from the bf16 fragment-order shadow copies
+  const float* F1 = FRAG ? reinterpret_cast<const float*>(a.frag[net]) : W1;
+  const float* F2 = FRAG ? reinterpret_cast<const float*>(a.frag[net] + (size_t)KP * H) : W2;
+  typename PipeSel<FRAG, false>::type pipe1;
+  pipe1.prefetch(KP, O, F1, H, n0, lane);
   const float2 bz1 = *reinterpret_cast<const float2*>(B1 + n0 + 2 * cj), bz2 = *reinterpret_cast<const float2*>(B2 + n0 + 2 * cj);
   const float adv_mean = ROLLOUT ? 0.f : a.adv_stat[0], adv_rstd = ROLLOUT ? 1.f : a.adv_stat[1];
   float ls[OT], b3v[OT];  // output o = cj + 16*ot of this lane
@@ -321,9 +387,9 @@ __global__ void __launch_bounds__(512, ROLLOUT ? MPPO_ROLLOUT_WAVES : 2) fused_m
   __syncthreads();
   FT(3);
   // ---- P1 / P2: hidden layers ----
-  GemmPipe<false> pipe2;
-  GemmPipe<!W2T> pipe5;
-  const float* W2back = W2T ? a.w2t[net] : W2;
+  typename PipeSel<FRAG, false>::type pipe2;
+  typename PipeSel<FRAG, !W2T>::type pipe5;
+  const float* W2back = FRAG ? reinterpret_cast<const float*>(a.frag[net] + (size_t)KP * H + (size_t)H * H) : W2T ? a.w2t[net] : W2;
   for (int layer = 0; layer < 2; ++layer) {
     f32x4 acc0, acc1;
     for (int r = 0; r < 4; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
@@ -331,12 +397,12 @@ __global__ void __launch_bounds__(512, ROLLOUT ? MPPO_ROLLOUT_WAVES : 2) fused_m
     if (!ROLLOUT && blockIdx.x == 40 && blockIdx.y == 0 && lane == 0) g_fused_t[24 + 16 * layer + wave] = __builtin_amdgcn_s_memtime();
 #endif
     if (layer == 0) {
-      if (!(a.skip & 1)) pipe1.template run<BF16>(xt, XS, KP, W1, H, n0, lane, acc0, acc1);
-      if (!ROLLOUT) pipe2.prefetch(H, H, W2, H, n0, lane);  // arrives during the epilogue + barrier below
+      if (!(a.skip & 1)) pipe1.template run<BF16>(xt, XS, KP, F1, H, n0, lane, acc0, acc1);
+      if (!ROLLOUT) pipe2.prefetch(H, H, F2, H, n0, lane);  // arrives during the epilogue + barrier below
     } else {
       // rollout: 4 waves per SIMD hide the fill latency, and the 128-VGPR budget has no room for a cross-phase prefetch
-      if (ROLLOUT) pipe2.prefetch(H, H, W2, H, n0, lane);
-      if (!(a.skip & 2)) pipe2.template run<BF16>(h1t, HS, H, W2, H, n0, lane, acc0, acc1);
+      if (ROLLOUT) pipe2.prefetch(H, H, F2, H, n0, lane);
+      if (!(a.skip & 2)) pipe2.template run<BF16>(h1t, HS, H, F2, H, n0, lane, acc0, acc1);
       if (!ROLLOUT) pipe5.prefetch(H, H, W2back, H, n0, lane);  // W2^T fragments of the backward product: hidden under heads / loss / dZ2
     }
     FT(4 + 2 * layer);
@@ -639,6 +705,8 @@ static int32_t fused_set_smem(size_t smem) {
   MPPO_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(fused_mlp_kernel<B, false, T, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem))
   MPPO_FUSED_ATTR(false, 1); MPPO_FUSED_ATTR(true, 1); MPPO_FUSED_ATTR(false, 2); MPPO_FUSED_ATTR(true, 2);
 #undef MPPO_FUSED_ATTR
+  MPPO_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(fused_mlp_kernel<true, true, 1, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+  MPPO_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(fused_mlp_kernel<true, true, 2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
   return MPPO_OK;
 }
 
@@ -651,6 +719,7 @@ int32_t fused_forward_backward(const mppo_net_t& net, const float* params, const
   a.dout = g.dout; a.xmb = g.xmb; a.partial = g.partial;
   const bool w2t = g.w2t_valid && g.w2t;
   a.w2t[0] = g.w2t; a.w2t[1] = g.w2t ? g.w2t + pad4((size_t)net.H * net.H) : nullptr;
+  a.frag[0] = g.frag; a.frag[1] = g.frag ? g.frag + g.frag_net_stride : nullptr;
   static const int skip = [] { const char* e = getenv("MPPO_FUSED_SKIP"); return e ? atoi(e) : 0; }();
   a.skip = skip;
   const size_t smem = fused_smem_bytes(net.O, net.A, net.H);
@@ -675,8 +744,10 @@ int32_t fused_forward_backward(const mppo_net_t& net, const float* params, const
 // Rollout policy step on n rows in ONE launch: both hidden layers, the heads, sample + log-prob, value (train.py:157-160);
 // noise == nullptr: critic only (bootstrap value, train.py:182).  Replaces two layer GEMM launches + the head kernel.
 int32_t fused_policy_forward(const mppo_net_t& net, const float* params, int n, const float* obs, int obs_ld, const float* noise, float* action, float* log_prob,
-                             float* value, float* mean_out, int AP, hipStream_t stream) {
+                             float* value, float* mean_out, int AP, hipStream_t stream, const unsigned short* frag, size_t frag_net_stride) {
   FusedArgs a{};
+  a.frag[0] = frag; a.frag[1] = frag ? frag + frag_net_stride : nullptr;
+  const bool use_frag = net.bf16 && frag;
   a.mb = n; a.O = net.O; a.OP = net.OP; a.A = net.A; a.AP = AP; a.DP = AP + 4; a.H = net.H; a.use_tanh = net.use_tanh;
   a.params = params; a.L = param_layout(net.O, net.A, net.H);
   a.b.obs = obs; a.b.obs_ld = obs_ld;
@@ -691,10 +762,12 @@ int32_t fused_policy_forward(const mppo_net_t& net, const float* params, int n, 
   const dim3 grid(cdiv(n, FRT), noise ? 2 : 1);
   const dim3 block(2 * net.H);
   if (net.A > 16) {
-    if (net.bf16) hipLaunchKernelGGL((fused_mlp_kernel<true, true, 2>), grid, block, smem, stream, a);
+    if (use_frag) hipLaunchKernelGGL((fused_mlp_kernel<true, true, 2, true>), grid, block, smem, stream, a);
+    else if (net.bf16) hipLaunchKernelGGL((fused_mlp_kernel<true, true, 2>), grid, block, smem, stream, a);
     else hipLaunchKernelGGL((fused_mlp_kernel<false, true, 2>), grid, block, smem, stream, a);
   } else {
-    if (net.bf16) hipLaunchKernelGGL((fused_mlp_kernel<true, true, 1>), grid, block, smem, stream, a);
+    if (use_frag) hipLaunchKernelGGL((fused_mlp_kernel<true, true, 1, true>), grid, block, smem, stream, a);
+    else if (net.bf16) hipLaunchKernelGGL((fused_mlp_kernel<true, true, 1>), grid, block, smem, stream, a);
     else hipLaunchKernelGGL((fused_mlp_kernel<false, true, 1>), grid, block, smem, stream, a);
   }
   MPPO_CHECK_LAUNCH("fused_mlp_kernel<rollout>");

@@ -340,6 +340,35 @@ __global__ void __launch_bounds__(256) sumsq_kernel(size_t P, const float* __res
   if (blockIdx.x == 0) partial[kNormBlocks + threadIdx.x] = 0.f;  // the clip adds kSqSlots = 2 x kNormBlocks partials
 }
 
+// One finished 32 x 32 tile (rows k0.., columns n0.. of W1 or W2 of network `netc`, new parameter values in LDS) into the shadow
+// copies; called by all 256 threads of the workgroup after a barrier.
+__device__ __forceinline__ void shadow_write_tile(const ShadowRef& sh, const float (&tile)[32][33], bool is_w1, int netc, int k0, int n0) {
+  const int t = threadIdx.x;
+  if (!is_w1) {
+    // w2t[n0 + nr][k0 + 4 kq ..]: four consecutive k of one column, eight threads per 128-byte row segment
+    float* T = sh.w2t + (netc ? (((size_t)sh.H * sh.H + 3) & ~(size_t)3) : 0);
+    const int nr = t >> 3, kq = (t & 7) * 4;
+    *reinterpret_cast<float4*>(T + (size_t)(n0 + nr) * sh.H + k0 + kq) = make_float4(tile[kq][nr], tile[kq + 1][nr], tile[kq + 2][nr], tile[kq + 3][nr]);
+  }
+  if (sh.frag) {
+    // fragment block (S = k0 / 32, w = n0 / 32): thread = (lane = t / 4, part = t % 4 = 2 tau + g), four values c = 0..3
+    const int lane = t >> 2, part = t & 3, tau = part >> 1, gg = part & 1, kq = lane >> 4, j = lane & 15;
+    const int KP = (sh.O + 31) & ~31, tn = sh.H / 32;
+    unsigned short* F = sh.frag + (size_t)netc * sh.frag_net_stride + (is_w1 ? 0 : (size_t)KP * sh.H);
+    {
+      const bf16x4 v = pack_bf16x4(tile[16 * gg + 4 * kq][2 * j + tau], tile[16 * gg + 4 * kq + 1][2 * j + tau], tile[16 * gg + 4 * kq + 2][2 * j + tau],
+                                   tile[16 * gg + 4 * kq + 3][2 * j + tau]);
+      *reinterpret_cast<bf16x4*>(F + (((size_t)(k0 >> 5) * tn + (n0 >> 5)) * 64 + lane) * 16 + 8 * tau + 4 * gg) = v;
+    }
+    if (!is_w1) {  // the transposed matrix B'(k', n') = W2[n'][k']: block (S = n0 / 32, w = k0 / 32), element from tile[n' - k0][k' - n0]
+      unsigned short* FT_ = F + (size_t)sh.H * sh.H;
+      const bf16x4 v = pack_bf16x4(tile[2 * j + tau][16 * gg + 4 * kq], tile[2 * j + tau][16 * gg + 4 * kq + 1], tile[2 * j + tau][16 * gg + 4 * kq + 2],
+                                   tile[2 * j + tau][16 * gg + 4 * kq + 3]);
+      *reinterpret_cast<bf16x4*>(FT_ + (((size_t)(n0 >> 5) * tn + (k0 >> 5)) * 64 + lane) * 16 + 8 * tau + 4 * gg) = v;
+    }
+  }
+}
+
 __global__ void __launch_bounds__(256) adam_kernel(size_t P, float* __restrict__ p, float* __restrict__ m, float* __restrict__ v,
                                                    const float* __restrict__ g, const float* __restrict__ partial, const int* __restrict__ count_base,
                                                    int step_offset, mppo_adam_cfg_t c, ShadowRef sh) {
@@ -362,16 +391,20 @@ __global__ void __launch_bounds__(256) adam_kernel(size_t P, float* __restrict__
     pn = po - lr * (mn / bc1) / (sqrtf(vn / bc2) + c.eps);
   };
   if (sh.w2t && blockIdx.x >= sh.flat_blocks) {
-    // W2 of the actor / critic, one 32 x 32 tile (k x n) per workgroup: the same update, and the tile goes transposed into the
-    // shadow copy w2t[n][k] through LDS (128-byte row segments both ways; a flat thread would scatter four 4-byte stores)
+    // W2 (and, for a bf16 network, W1) of the actor / critic, one 32 x 32 tile (k x n) per workgroup: the same update, and the
+    // tile goes into the shadow copies through LDS - W2^T as floats (128-byte row segments both ways; a flat thread would
+    // scatter four 4-byte stores), bf16 fragments as one contiguous 2 KB block per copy.
     __shared__ float tile[32][33];
-    const int tb = blockIdx.x - sh.flat_blocks, tiles = sh.H / 32, per_net = tiles * tiles;
-    const int netc = tb / per_net, tt = tb - netc * per_net, k0 = 32 * (tt / tiles), n0 = 32 * (tt % tiles);
-    const size_t base = (size_t)(netc ? sh.c_w2 : sh.a_w2);
-    float* T = sh.w2t + (netc ? (((size_t)sh.H * sh.H + 3) & ~(size_t)3) : 0);
+    const int tb = blockIdx.x - sh.flat_blocks, tn = sh.H / 32, w2_tiles = tn * tn;
+    const bool is_w1 = tb >= 2 * w2_tiles;
+    const int kt1 = (sh.O + 31) / 32, per_net = is_w1 ? kt1 * tn : w2_tiles, tb2 = is_w1 ? tb - 2 * w2_tiles : tb;
+    const int netc = tb2 / per_net, tt = tb2 - netc * per_net, k0 = 32 * (tt / tn), n0 = 32 * (tt % tn);
+    const int krows = is_w1 ? sh.O : sh.H;  // rows of the matrix (W1's last tile is ragged)
+    const size_t base = (size_t)(is_w1 ? (netc ? sh.c_w1 : sh.a_w1) : (netc ? sh.c_w2 : sh.a_w2));
     // thread = (row k = t / 8, four columns n = 4 (t % 8) ..): one float4 per array, exactly like a flat thread
     const int kr = threadIdx.x >> 3, nq = (threadIdx.x & 7) * 4;
-    const size_t i = base + (size_t)(k0 + kr) * sh.H + n0 + nq;
+    const bool row_on = k0 + kr < krows;
+    const size_t i = base + (size_t)(row_on ? k0 + kr : 0) * sh.H + n0 + nq;
     const float4 gq = *reinterpret_cast<const float4*>(g + i), mq = *reinterpret_cast<const float4*>(m + i), vq = *reinterpret_cast<const float4*>(v + i);
     const float4 pq = *reinterpret_cast<const float4*>(p + i);
     const float gi[4] = {gq.x, gq.y, gq.z, gq.w}, mo[4] = {mq.x, mq.y, mq.z, mq.w}, vo[4] = {vq.x, vq.y, vq.z, vq.w}, po[4] = {pq.x, pq.y, pq.z, pq.w};
@@ -379,25 +412,22 @@ __global__ void __launch_bounds__(256) adam_kernel(size_t P, float* __restrict__
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       step(gi[q], mo[q], vo[q], po[q], mn[q], vn[q], pn[q]);
-      tile[kr][nq + q] = pn[q];
+      tile[kr][nq + q] = row_on ? pn[q] : 0.f;  // rows past the matrix are the zero padding of the fragments
     }
-    stream_store(m + i, make_float4(mn[0], mn[1], mn[2], mn[3]));  // like the flat path: next read by the next step's Adam
-    stream_store(v + i, make_float4(vn[0], vn[1], vn[2], vn[3]));
-    *reinterpret_cast<float4*>(p + i) = make_float4(pn[0], pn[1], pn[2], pn[3]);
+    if (row_on) {
+      stream_store(m + i, make_float4(mn[0], mn[1], mn[2], mn[3]));  // like the flat path: next read by the next step's Adam
+      stream_store(v + i, make_float4(vn[0], vn[1], vn[2], vn[3]));
+      *reinterpret_cast<float4*>(p + i) = make_float4(pn[0], pn[1], pn[2], pn[3]);
+    }
     __syncthreads();
-    // w2t[n0 + nr][k0 + 4 kq ..]: four consecutive k of one column, eight threads per 128-byte row segment
-    const int nr = threadIdx.x >> 3, kq = (threadIdx.x & 7) * 4;
-    *reinterpret_cast<float4*>(T + (size_t)(n0 + nr) * sh.H + k0 + kq) = make_float4(tile[kq][nr], tile[kq + 1][nr], tile[kq + 2][nr], tile[kq + 3][nr]);
+    shadow_write_tile(sh, tile, is_w1, netc, k0, n0);
     return;
   }
   // four parameters per thread (the flat layout is a whole number of float4: ppo_layout.h): a quarter of the workgroups to dispatch
   size_t i4 = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (sh.w2t) {
-    // the flat workgroups enumerate everything EXCEPT the two W2 ranges (those belong to the tile workgroups above), so the
-    // grid is no larger than without the shadow copies; all boundaries are multiples of four floats (16-byte aligned tensors)
-    const size_t HH4 = (size_t)sh.H * sh.H / 4, a4 = (size_t)sh.a_w2 / 4, c4 = (size_t)sh.c_w2 / 4;
-    i4 = i4 < a4 ? i4 : (i4 + HH4 < c4 ? i4 + HH4 : i4 + 2 * HH4);
-  }
+  // the flat workgroups enumerate everything EXCEPT the ranges the tile workgroups own, so the grid is no larger than without
+  // the shadow copies; all boundaries are multiples of four floats (16-byte aligned tensors)
+  for (int r = 0; r < sh.nskip; ++r) if (i4 >= sh.skip_start4[r]) i4 += sh.skip_len4[r];
   if (4 * i4 >= P) return;
   if (4 * i4 + 3 < P) {
     const float4 gq = reinterpret_cast<const float4*>(g)[i4], mq = reinterpret_cast<const float4*>(m)[i4], vq = reinterpret_cast<const float4*>(v)[i4];
@@ -517,7 +547,7 @@ int32_t policy_forward(const mppo_net_t& net, const float* params, int n, const 
                        float* log_prob, float* value, float* mean_out, hipStream_t stream) {
   static const char* nofuse = getenv("MPPO_NO_FUSED");  // A/B switch for measurements
   if (fused_rollout_supported(net, obs, obs_ld) && !(nofuse && nofuse[0] == '1'))
-    return fused_policy_forward(net, params, n, obs, obs_ld, noise, action, log_prob, value, noise ? mean_out : nullptr, fb.AP, stream);  // one launch
+    return fused_policy_forward(net, params, n, obs, obs_ld, noise, action, log_prob, value, noise ? mean_out : nullptr, fb.AP, stream, fb.frag, fb.frag_net_stride);  // one launch
   MPPO_TRY(mlp_hidden_forward(net, params, n, obs, obs_ld, nullptr, fb, nullptr, stream));
   HeadArgs a = head_args(net, params, n, fb);
   a.noise = noise; a.action = action; a.log_prob = log_prob; a.value = value; a.mean_out = mean_out;
@@ -624,21 +654,33 @@ int32_t minibatch_grad(const mppo_net_t& net, const float* params, const mppo_ba
   return MPPO_OK;
 }
 
-// w2t[net][n][k] = W2_net[k][n]: 32 x 32 tiles through LDS, both networks in one launch
-__global__ void __launch_bounds__(256) w2_transpose_kernel(const float* __restrict__ params, int a_w2, int c_w2, int H, float* __restrict__ w2t) {
+// Builds every shadow copy from the parameters: one 32 x 32 tile per workgroup, same tile enumeration and same writer as Adam's
+__global__ void __launch_bounds__(256) shadow_refresh_kernel(const float* __restrict__ params, ShadowRef sh) {
   __shared__ float tile[32][33];
-  const float* W = params + (blockIdx.z ? c_w2 : a_w2);
-  float* T = w2t + (blockIdx.z ? (((size_t)H * H + 3) & ~(size_t)3) : 0);
-  const int k0 = 32 * blockIdx.y, n0 = 32 * blockIdx.x, tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
-  for (int r = ty; r < 32; r += 8) tile[r][tx] = (k0 + r < H && n0 + tx < H) ? W[(size_t)(k0 + r) * H + n0 + tx] : 0.f;
+  const int tb = blockIdx.x, tn = sh.H / 32, w2_tiles = tn * tn;
+  const bool is_w1 = tb >= 2 * w2_tiles;
+  const int kt1 = (sh.O + 31) / 32, per_net = is_w1 ? kt1 * tn : w2_tiles, tb2 = is_w1 ? tb - 2 * w2_tiles : tb;
+  const int netc = tb2 / per_net, tt = tb2 - netc * per_net, k0 = 32 * (tt / tn), n0 = 32 * (tt % tn);
+  const int krows = is_w1 ? sh.O : sh.H;
+  const size_t base = (size_t)(is_w1 ? (netc ? sh.c_w1 : sh.a_w1) : (netc ? sh.c_w2 : sh.a_w2));
+  const int kr = threadIdx.x >> 3, nq = (threadIdx.x & 7) * 4;
+  const bool row_on = k0 + kr < krows;
+  const float4 pq = *reinterpret_cast<const float4*>(params + base + (size_t)(row_on ? k0 + kr : 0) * sh.H + n0 + nq);
+  tile[kr][nq] = row_on ? pq.x : 0.f; tile[kr][nq + 1] = row_on ? pq.y : 0.f; tile[kr][nq + 2] = row_on ? pq.z : 0.f; tile[kr][nq + 3] = row_on ? pq.w : 0.f;
   __syncthreads();
-  for (int r = ty; r < 32; r += 8) if (n0 + r < H && k0 + tx < H) T[(size_t)(n0 + r) * H + k0 + tx] = tile[tx][r];
+  shadow_write_tile(sh, tile, is_w1, netc, k0, n0);
+}
+
+static int shadow_tile_blocks(const ShadowRef& sh) {
+  const int tn = sh.H / 32;
+  return 2 * tn * tn + (sh.frag ? 2 * ((sh.O + 31) / 32) * tn : 0);
 }
 
 int32_t shadow_refresh(const mppo_net_t& net, const float* params, const GradBufs& gbuf, hipStream_t stream) {
-  const ParamLayout L = param_layout(net.O, net.A, net.H);
-  hipLaunchKernelGGL(w2_transpose_kernel, dim3(cdiv(net.H, 32), cdiv(net.H, 32), 2), dim3(256), 0, stream, params, L.a_w2, L.c_w2, net.H, gbuf.w2t);
-  MPPO_CHECK_LAUNCH("w2_transpose_kernel");
+  MPPO_REQUIRE(net.H % 32 == 0, "shadow_refresh: the shadow copies need H %% 32 == 0 (H = %d)", net.H);
+  const ShadowRef sh = make_shadow_ref(net, gbuf);
+  hipLaunchKernelGGL(shadow_refresh_kernel, dim3(shadow_tile_blocks(sh)), dim3(256), 0, stream, params, sh);
+  MPPO_CHECK_LAUNCH("shadow_refresh_kernel");
   return MPPO_OK;
 }
 
@@ -650,10 +692,22 @@ int32_t clip_adam(size_t P, float* params, float* m, float* v, const float* grad
   }
   MPPO_REQUIRE((reinterpret_cast<uintptr_t>(params) & 15) == 0 && (reinterpret_cast<uintptr_t>(m) & 15) == 0 && (reinterpret_cast<uintptr_t>(v) & 15) == 0 &&
                    (reinterpret_cast<uintptr_t>(grad) & 15) == 0, "clip_adam: params / m / v / grad must be 16-byte aligned");
-  ShadowRef sh = shadow ? *shadow : ShadowRef{nullptr, 0, 0, 0, 0};
+  ShadowRef sh = shadow ? *shadow : ShadowRef{};
   MPPO_REQUIRE(!sh.w2t || sh.H % 32 == 0, "clip_adam: the W2^T shadow copies need H %% 32 == 0 (H = %d)", sh.H);
-  const int tile_blocks = sh.w2t ? 2 * (sh.H / 32) * (sh.H / 32) : 0;
-  const int flat_blocks = cdiv((long)((P + 3) / 4) - (sh.w2t ? (long)sh.H * sh.H / 2 : 0), 256);  // float4 slots outside the two W2 ranges
+  const int tile_blocks = sh.w2t ? shadow_tile_blocks(sh) : 0;
+  long owned4 = 0;  // float4 slots that tile workgroups update
+  sh.nskip = 0;
+  if (sh.w2t) {
+    struct R { int start, len; } rs[4] = {{sh.a_w2, sh.H * sh.H}, {sh.c_w2, sh.H * sh.H}, {sh.a_w1, sh.frag ? sh.O * sh.H : 0}, {sh.c_w1, sh.frag ? sh.O * sh.H : 0}};
+    for (int a = 0; a < 4; ++a) for (int b = a + 1; b < 4; ++b) if (rs[b].start < rs[a].start) { const R t_ = rs[a]; rs[a] = rs[b]; rs[b] = t_; }
+    for (int a = 0; a < 4; ++a) {
+      if (rs[a].len == 0) continue;
+      MPPO_REQUIRE(rs[a].start % 4 == 0 && rs[a].len % 4 == 0, "clip_adam: a shadowed tensor is not float4-aligned");
+      sh.skip_start4[sh.nskip] = (unsigned)(rs[a].start / 4); sh.skip_len4[sh.nskip] = (unsigned)(rs[a].len / 4); ++sh.nskip;
+      owned4 += rs[a].len / 4;
+    }
+  }
+  const int flat_blocks = cdiv((long)((P + 3) / 4) - owned4, 256);
   sh.flat_blocks = flat_blocks;
   hipLaunchKernelGGL(adam_kernel, dim3(flat_blocks + tile_blocks), dim3(256), 0, stream, P, params, m, v, grad, ws, count_base, step_offset, cfg,
                      sh);
@@ -803,8 +857,7 @@ extern "C" int32_t mppo_clip_adam_shadow(const mppo_net_t* net, int32_t mb, void
   if (ws_bytes < mppo_adam_ws_bytes(P)) return fail(MPPO_ENOMEM, "mppo_clip_adam_shadow: workspace too small");
   if (grad_ws_bytes < mppo_grad_ws_bytes(net, mb)) return fail(MPPO_ENOMEM, "mppo_clip_adam_shadow: gradient workspace too small");
   const GradBufs gb = carve_grad(*net, mb, static_cast<float*>(grad_ws));
-  const ParamLayout L = param_layout(net->O, net->A, net->H);
-  const ShadowRef sh{gb.w2t, L.a_w2, L.c_w2, net->H, 0};
+  const ShadowRef sh = make_shadow_ref(*net, gb);
   return clip_adam(P, params, m, v, grad, count_base, step_offset, *cfg, static_cast<float*>(ws), false, static_cast<hipStream_t>(stream), &sh);
 }
 

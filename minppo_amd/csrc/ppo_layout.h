@@ -48,6 +48,10 @@ inline size_t pad16(size_t n) { return (n + 15) & ~(size_t)15; }
 struct FwdBufs {
   float *h1a, *h2a, *h1c, *h2c, *mean, *value;
   int AP;
+  // optional (engine rollout of a bf16 network): the bf16 fragment-order weight copies of a gradient workspace whose shadow copies
+  // are current (GradBufs::frag); nullptr = convert the float weights in the kernel
+  const unsigned short* frag = nullptr;
+  size_t frag_net_stride = 0;
 };
 inline size_t fwd_bufs_floats(const mppo_net_t& net, int n) {
   const size_t AP = pad4((size_t)net.A);
@@ -80,6 +84,12 @@ struct GradBufs {
   // CALLER knows whether it matches `params` (w2t_valid): the workspace itself carries no state.
   float* w2t;
   bool w2t_valid;
+  // bf16 networks only: the hidden-layer weights once more, rounded to bf16 and stored in the order the MFMA pipe consumes them
+  // (fragment order: [k stage of 32][32-column wave slab][lane][16 values], see frag_index): per network W1 (K padded to 32 with
+  // zeros), W2 and W2^T.  A lane's operands of a stage are 32 contiguous bytes, a wave's 2 KB: half the bytes of the float
+  // weights, no conversion in the GEMM loop.  Same validity as w2t.
+  unsigned short* frag;     // nullptr unless net.bf16
+  size_t frag_net_stride;   // in bf16 elements: KP*H + 2*H*H
   int ksplit;
   size_t slab_stride;
 };
@@ -88,7 +98,8 @@ inline size_t grad_bufs_floats(const mppo_net_t& net, int mb) {
   const size_t AP = pad4((size_t)net.A), nh = pad4(mbp * net.H);
   const size_t P = pad4((size_t)param_layout(net.O, net.A, net.H).total);
   const size_t nblk = (size_t)(mb + 7) / 8;  // head kernel: 8 rows per workgroup (fused kernel: 16)
-  return fwd_bufs_floats(net, (int)mbp) + pad4(mbp * (AP + 4)) + 4 * nh + pad4(nblk * (4 + AP)) + (size_t)kGradKSplitMax * P + pad4(mbp * net.OP) + 2 * pad4((size_t)net.H * net.H);
+  return fwd_bufs_floats(net, (int)mbp) + pad4(mbp * (AP + 4)) + 4 * nh + pad4(nblk * (4 + AP)) + (size_t)kGradKSplitMax * P + pad4(mbp * net.OP) + 2 * pad4((size_t)net.H * net.H) +
+         (net.bf16 ? pad4((size_t)(((net.O + 31) & ~31) + 2 * net.H) * net.H) : 0);  // bf16 fragments: 2 networks x (KP + 2H) x H halves = that many floats
 }
 inline GradBufs carve_grad(const mppo_net_t& net, int mb, float* ws) {
   GradBufs g;
@@ -104,6 +115,8 @@ inline GradBufs carve_grad(const mppo_net_t& net, int mb, float* ws) {
   g.xmb = ws + (size_t)kGradKSplitMax * pad4((size_t)param_layout(net.O, net.A, net.H).total);
   g.w2t = g.xmb + pad4(mbp * net.OP);
   g.w2t_valid = false;
+  g.frag = net.bf16 ? reinterpret_cast<unsigned short*>(g.w2t + 2 * pad4((size_t)net.H * net.H)) : nullptr;
+  g.frag_net_stride = (size_t)(((net.O + 31) & ~31) + 2 * net.H) * net.H;
   g.ksplit = grad_ksplit();
   g.slab_stride = pad4((size_t)param_layout(net.O, net.A, net.H).total);
   return g;
@@ -116,17 +129,36 @@ int32_t policy_forward(const mppo_net_t& net, const float* params, int n, const 
 int32_t minibatch_grad(const mppo_net_t& net, const float* params, const mppo_batch_t& batch, const int* idx, int mb, const float* adv_stat, float inv_count,
                        const mppo_loss_cfg_t& lc, float* grad, float* loss4, float* sq_partial, const GradBufs& gbuf, hipStream_t stream);
 // shadow (optional): the W2^T copies to keep in step with the parameters (GradBufs::w2t of the workspace the row pass reads)
-struct ShadowRef { float* w2t; int a_w2, c_w2, H, flat_blocks; };  // flat_blocks: filled in by clip_adam
+struct ShadowRef {
+  float* w2t; int a_w2, c_w2, H;
+  unsigned short* frag; size_t frag_net_stride; int a_w1, c_w1, O;  // bf16 fragments (nullptr for a float network)
+  // filled in by clip_adam: the flat workgroups skip the ranges that tile workgroups own (sorted, in float4 units)
+  int flat_blocks, nskip; unsigned skip_start4[4], skip_len4[4];
+};
+// Position (in bf16 elements) of B(k, n) of a [K][N] weight inside its fragment-order copy: stage S = k / 32, wave slab w = n / 32,
+// lane = 16 kq + j, element e = 8 tau + 4 g + c with k = 32 S + 16 g + 4 kq + c and n = 32 w + 2 j + tau.
+__host__ __device__ inline size_t frag_index(int k, int n, int N) {
+  const int S = k >> 5, kk = k & 31, g = kk >> 4, kq = (kk >> 2) & 3, c = kk & 3;
+  const int w = n >> 5, nn = n & 31, j = nn >> 1, tau = nn & 1;
+  return (((size_t)S * (N >> 5) + w) * 64 + 16 * kq + j) * 16 + 8 * tau + 4 * g + c;
+}
 int32_t clip_adam(size_t P, float* params, float* m, float* v, const float* grad, const int* count_base, int step_offset, const mppo_adam_cfg_t& cfg, float* ws,
                   bool have_sumsq, hipStream_t stream, const ShadowRef* shadow = nullptr);
 int32_t shadow_refresh(const mppo_net_t& net, const float* params, const GradBufs& gbuf, hipStream_t stream);
+inline ShadowRef make_shadow_ref(const mppo_net_t& net, const GradBufs& g) {
+  const ParamLayout L = param_layout(net.O, net.A, net.H);
+  ShadowRef r{};
+  r.w2t = g.w2t; r.a_w2 = L.a_w2; r.c_w2 = L.c_w2; r.H = net.H;
+  r.frag = g.frag; r.frag_net_stride = g.frag_net_stride; r.a_w1 = L.a_w1; r.c_w1 = L.c_w1; r.O = net.O;
+  return r;
+}
 int32_t gae_launch(int T, int N, float gamma, float lam, const float* reward, const float* value, const unsigned char* done, const float* last_val, float* adv,
                    float* target, hipStream_t stream);
 // k_fused.hip: row-local forward + backward of one minibatch in a single launch (falls back to the layer-wise path when unsupported)
 bool fused_supported(const mppo_net_t& net, const mppo_batch_t& b);
 bool fused_rollout_supported(const mppo_net_t& net, const float* obs, int obs_ld);
 int32_t fused_policy_forward(const mppo_net_t& net, const float* params, int n, const float* obs, int obs_ld, const float* noise, float* action, float* log_prob,
-                             float* value, float* mean_out, int AP, hipStream_t stream);
+                             float* value, float* mean_out, int AP, hipStream_t stream, const unsigned short* frag = nullptr, size_t frag_net_stride = 0);
 int32_t fused_forward_backward(const mppo_net_t& net, const float* params, const mppo_batch_t& batch, const int* idx, int mb, const float* adv_stat,
                                float inv_count, const mppo_loss_cfg_t& lc, const GradBufs& g, hipStream_t stream);
 int32_t perm_fill_keys(unsigned long long seed, unsigned long long stream_id, const int* ctr, int B, unsigned* keys, int* vals, hipStream_t stream);

@@ -39,6 +39,11 @@ __device__ __forceinline__ bf16x4 pack_bf16x4(float a, float b, float c, float d
 
 // D(16x16) += A(16x16) * B(16x16): lane l supplies A[i = l&15][k = 4*(l>>4) + c] and B[k = 4*(l>>4) + c][j = l&15], c = 0..3;
 // acc[r] is D[row = 4*(l>>4) + r][col = l&15]  (v_mfma_f32_16x16x16_bf16, 8 passes: 4x the k of the f32 16x16x4 per issue slot)
+// four bf16 values that arrived as the raw bits of two floats (a 16-byte load of a bf16 array)
+__device__ __forceinline__ bf16x4 bf16x4_from_bits(float lo, float hi) {
+  typedef float f32x2_bits __attribute__((ext_vector_type(2)));
+  return __builtin_bit_cast(bf16x4, f32x2_bits{lo, hi});
+}
 __device__ __forceinline__ void mfma_bf16_16x16x16(bf16x4 a, bf16x4 b, f32x4& acc) {
   acc = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a, b, acc, 0, 0, 0);
 }

@@ -57,6 +57,10 @@ inline bf16x4 pack_bf16x4(float a, float b, float c, float d) {
   return r;
 }
 // lane l supplies A[i = l&15][k = 4*(l>>4) + c], B[k][j = l&15]; acc[r] = D[4*(l>>4) + r][l&15]
+inline bf16x4 bf16x4_from_bits(float lo, float hi) {
+  bf16x4 r; const float t[2] = {lo, hi}; __builtin_memcpy(&r, t, 8);
+  return r;
+}
 inline void mfma_bf16_16x16x16(bf16x4 a, bf16x4 b, f32x4& acc) {
   const int t = emu::tid(), lane = t & 63, wave = t >> 6;
   float* A = reinterpret_cast<float*>(emu::g_xchg) + wave * 512;  // [k][i]

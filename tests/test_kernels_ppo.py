@@ -402,14 +402,17 @@ def test_gemm_batch_variants(be):
     np.testing.assert_allclose(s[Min], dZ.sum(0), atol=2e-5)
 
 
-def test_shadow_copies_change_nothing_but_the_layout_of_one_operand(be):
-    """The W2^T shadow copies inside the gradient workspace (include/minppo_hip.h): mppo_minibatch_grad_shadow == mppo_minibatch_grad
+@pytest.mark.parametrize("bf16", [0, 1])
+def test_shadow_copies_change_nothing_but_the_layout_of_one_operand(be, bf16):
+    """(bf16 = 1: additionally the bf16 fragment-order copies of W1, W2, W2^T that the bf16 row pass then reads instead of
+    converting the float weights in its GEMM loops - same rounding, same values, same MFMAs.)
+    The W2^T shadow copies inside the gradient workspace (include/minppo_hip.h): mppo_minibatch_grad_shadow == mppo_minibatch_grad
     bit for bit (the backward product issues the same MFMAs on the same values), mppo_clip_adam_shadow == mppo_clip_adam bit
     for bit on params / m / v, and after it the copies equal a fresh mppo_shadow_refresh of the new parameters."""
     O, A, H, B, mb = 37, 5, 64, 96, 48
     OP = (O + 3) // 4 * 4
     rng = np.random.default_rng(5)
-    net = nat.Net(O, OP, A, H, 1, 0)
+    net = nat.Net(O, OP, A, H, 1, bf16)
     named = po.init_params(3, O, A, H)
     flat = po.named_to_flat(named, O, A, H).astype(f32)
     P = flat.size
@@ -450,8 +453,35 @@ def test_shadow_copies_change_nothing_but_the_layout_of_one_operand(be):
     # and they are the transposes (the copies are the last 2 H^2 floats of the workspace)
     sl = po.param_slices(O, A, H)
     newp = be.host(st[1]["p"])
-    tail = fresh[: wsb // 4][-2 * H * H:]
+    KP = (O + 31) // 32 * 32
+    nfrag = (KP + 2 * H) * H if bf16 else 0  # floats taken by the bf16 fragments behind the float copies
+    tail = fresh[: wsb // 4][-(2 * H * H + nfrag):][:2 * H * H]
     for i, k in enumerate(("a_w2", "c_w2")):
         o, shp = sl[k]
         assert shp == (H, H)
         np.testing.assert_array_equal(tail[i * H * H:(i + 1) * H * H].reshape(H, H), newp[o:o + H * H].reshape(H, H).T)
+    if bf16:  # spot-check the fragment order against its definition (ppo_layout.h frag_index), W1 of the critic incl. the zero padding
+        frag = fresh[: wsb // 4][-nfrag:].view(np.uint16)
+        per_net = (KP + 2 * H) * H
+
+        def bf16_bits(x):
+            u = np.float32(x).view(np.uint32).astype(np.uint64)
+            return int(((u + 0x7FFF + ((u >> 16) & 1)) >> 16) & 0xFFFF)
+
+        def frag_index(k, n, N):
+            S, kk = k >> 5, k & 31
+            g_, kq, c = kk >> 4, (kk >> 2) & 3, kk & 3
+            w, nn = n >> 5, n & 31
+            j, tau = nn >> 1, nn & 1
+            return ((S * (N >> 5) + w) * 64 + 16 * kq + j) * 16 + 8 * tau + 4 * g_ + c
+
+        o1 = sl["c_w1"][0]
+        W1c = newp[o1:o1 + O * H].reshape(O, H)
+        W2c = newp[sl["c_w2"][0]:sl["c_w2"][0] + H * H].reshape(H, H)
+        r3 = np.random.default_rng(0)
+        for _ in range(200):
+            k, n = int(r3.integers(0, KP)), int(r3.integers(0, H))
+            assert frag[per_net + frag_index(k, n, H)] == (bf16_bits(W1c[k, n]) if k < O else 0), (k, n)
+            k2, n2 = int(r3.integers(0, H)), int(r3.integers(0, H))
+            assert frag[per_net + KP * H + frag_index(k2, n2, H)] == bf16_bits(W2c[k2, n2])
+            assert frag[per_net + KP * H + H * H + frag_index(k2, n2, H)] == bf16_bits(W2c[n2, k2])
