@@ -341,7 +341,9 @@ def main() -> None:
         tfs = sorted((ROOT / "profiles").glob("r*_hbm_traffic.json"))  # the newest committed counter summary
         if tfs and args.config == "stompy_pro" and args.envs_per_gpu == 4096 and not bf16:
             k = json.loads(tfs[-1].read_text())["kernels"]
-            key = next((n for n in k if n.endswith("fused_mlp_kernel<false, false, 1>")), None)
+            # the training row pass of a float network: <BF16 = false, ROLLOUT = false, OT = 1, W2T shadow = true> (the engine's choice)
+            key = next((n for n in k if n.endswith("fused_mlp_kernel<false, false, 1, true>")), None) or \
+                next((n for n in k if n.endswith("fused_mlp_kernel<false, false, 1>")), None)
             if key:
                 traffic = k[key]["hbm_bytes_per_launch"]
                 traffic_src = f"profiles/{tfs[-1].name} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, gfx950 corrections)"
