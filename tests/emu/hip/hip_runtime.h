@@ -88,5 +88,6 @@ struct uint4 { unsigned x, y, z, w; };
 struct uint2 { unsigned x, y; };
 inline float __expf(float x) { return expf(x); }
 inline float __uint_as_float(unsigned u) { float f; memcpy(&f, &u, 4); return f; }
+inline unsigned __float_as_uint(float f) { unsigned u; memcpy(&u, &f, 4); return u; }
 inline float __fdividef(float a, float b) { return a / b; }
 inline float2 make_float2(float x, float y) { return {x, y}; }
