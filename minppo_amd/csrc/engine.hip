@@ -148,6 +148,7 @@ static size_t layout(mppo_engine* e, bool assign) {
   e->jax_rounds = threefry_rounds((int)B);
   e->jax_rng = (unsigned*)take("jax_rng", (2 + 2 * T + 2 * (size_t)e->E * e->jax_rounds) * 4);
   e->perm_ws_bytes = mppo_permutation_ws_bytes((int)B);
+  if (permutation_batch_ws_bytes((int)B, e->E) > e->perm_ws_bytes) e->perm_ws_bytes = permutation_batch_ws_bytes((int)B, e->E);  // all epochs in one sort
   e->perm_ws = take("perm_ws", e->perm_ws_bytes);
   return align_up(off, 256);
 }
@@ -227,15 +228,16 @@ static int32_t do_rollout(mppo_engine* e, hipStream_t s) {
 static int32_t do_learn(mppo_engine* e, hipStream_t s) {
   const mppo_engine_cfg_t& c = e->cfg;
   const int EM = e->E * e->M;
-  if (!c.external_random)
-    for (int ep = 0; ep < e->E; ++ep) {
-      if (c.rng_impl == 1)
+  if (!c.external_random) {
+    if (c.rng_impl == 1) {
+      for (int ep = 0; ep < e->E; ++ep)
         MPPO_TRY(threefry_permutation(e->jax_rng + 2 + 2 * e->T + 2 * ep * e->jax_rounds, e->jax_rounds, e->B, e->perm + (size_t)ep * e->B, e->perm_ws,
                                       e->perm_ws_bytes, s));                                                          // train.py:258 with JAX's keys
-      else
-        MPPO_TRY(permutation_ctr(c.seed, kStreamPerm + ((unsigned long long)c.rank << 16) + (unsigned long long)ep, e->count + 1, e->B, e->perm + (size_t)ep * e->B,
-                                 e->perm_ws, e->perm_ws_bytes, s));                                                  // train.py:258
+    } else {
+      // train.py:258 for all E epochs at once (one sort: k_perm.hip); stream ids kStreamPerm + (rank << 16) + ep as before
+      MPPO_TRY(permutation_batch_ctr(c.seed, kStreamPerm + ((unsigned long long)c.rank << 16), e->count + 1, e->B, e->E, e->perm, e->perm_ws, e->perm_ws_bytes, s));
     }
+  }
   MPPO_TRY(mppo_adv_sums(e->adv, e->perm, EM, e->mb, e->adv_sums, s));
   // MPPO_FORCE_COMM=1 runs the collectives also at world size 1 (identity all-reduce): hardware check of the RCCL path
   const char* fc = getenv("MPPO_FORCE_COMM");

@@ -39,6 +39,36 @@ int32_t permutation_ctr(unsigned long long seed, unsigned long long stream_id, c
   MPPO_CHECK_HIP(rocprim::radix_sort_pairs(temp, temp_bytes, keys_in, keys_out, vals_in, idx, (size_t)B, 0, 32, s));
   return MPPO_OK;
 }
+static int bits_for(int E) { int b = 0; while ((1 << b) < E) ++b; return b; }
+static size_t sort_temp_bytes64(size_t n, int end_bit) {
+  size_t bytes = 0;
+  (void)rocprim::radix_sort_pairs(nullptr, bytes, static_cast<unsigned long long*>(nullptr), static_cast<unsigned long long*>(nullptr), static_cast<int*>(nullptr),
+                                  static_cast<int*>(nullptr), n, 0, end_bit, nullptr);
+  return bytes;
+}
+size_t permutation_batch_ws_bytes(int B, int E) {
+  if (B < 1 || E < 1) return 0;
+  const size_t n = (size_t)B * E;  // keys_in, keys_out (64-bit), vals_in + rocPRIM temporary storage
+  return 2 * align_up(n * 8, 256) + align_up(n * 4, 256) + align_up(sort_temp_bytes64(n, 32 + bits_for(E)), 256);
+}
+// All E epoch permutations of an update with ONE sort (a sort is ~7 launches at the launch floor whatever its size): the pairs
+// (epoch << 32 | key, index) of all epochs are sorted together; the sort is stable and the epoch is the most significant part
+// of the key, so block e of the result is exactly what permutation_ctr(stream_id0 + e) produces.
+int32_t permutation_batch_ctr(unsigned long long seed, unsigned long long stream_id0, const int* ctr, int B, int E, int* idx, void* ws, size_t ws_bytes,
+                              hipStream_t s) {
+  MPPO_REQUIRE(B >= 1 && E >= 1 && idx && ws, "permutation_batch: bad argument");
+  if (ws_bytes < permutation_batch_ws_bytes(B, E)) return fail(MPPO_ENOMEM, "permutation_batch: workspace %zu < %zu bytes", ws_bytes, permutation_batch_ws_bytes(B, E));
+  const size_t n = (size_t)B * E, c8 = align_up(n * 8, 256), c4 = align_up(n * 4, 256);
+  unsigned char* w = static_cast<unsigned char*>(ws);
+  unsigned long long* keys_in = reinterpret_cast<unsigned long long*>(w);
+  unsigned long long* keys_out = reinterpret_cast<unsigned long long*>(w + c8);
+  int* vals_in = reinterpret_cast<int*>(w + 2 * c8);
+  void* temp = w + 2 * c8 + c4;
+  size_t temp_bytes = ws_bytes - (2 * c8 + c4);
+  MPPO_TRY(perm_fill_keys_batch(seed, stream_id0, ctr, B, E, keys_in, vals_in, s));
+  MPPO_CHECK_HIP(rocprim::radix_sort_pairs(temp, temp_bytes, keys_in, keys_out, vals_in, idx, n, 0, 32 + bits_for(E), s));
+  return MPPO_OK;
+}
 // jax.random.permutation (`_shuffle`): round r sorts the current order stably by random_bits(sort_keys[r]); the buffers alternate
 // so that the last round lands in `idx`
 int32_t threefry_permutation(const unsigned* sort_keys, int rounds, int B, int* idx, void* ws, size_t ws_bytes, hipStream_t s) {

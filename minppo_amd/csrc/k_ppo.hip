@@ -495,6 +495,26 @@ __global__ void __launch_bounds__(256) perm_keys_kernel(unsigned long long seed,
   for (int k = 0; k < 4; ++k) if (4 * q + k < B) { keys[4 * q + k] = z[k]; vals[4 * q + k] = 4 * q + k; }
 }
 
+// E permutations' worth of keys in one launch: epoch e draws the stream `stream_id0 + e` exactly as perm_keys_kernel would, and its
+// keys carry e above bit 32, so that ONE stable sort of all E B pairs leaves every epoch's block sorted by its own keys
+__global__ void __launch_bounds__(256) perm_keys_batch_kernel(unsigned long long seed, unsigned long long stream_id0, const int* __restrict__ ctr, int B,
+                                                              unsigned long long* __restrict__ keys, int* __restrict__ vals) {
+  const int q = blockIdx.x * blockDim.x + threadIdx.x, e = blockIdx.y;
+  if (4 * q >= B) return;
+  const unsigned long long stream_id = stream_id0 + (unsigned long long)e;
+  const U4 r = philox4x32((unsigned)q, ctr ? (unsigned)ctr[0] : 0u, (unsigned)stream_id, (unsigned)(stream_id >> 32) ^ 0x5045524Du, (unsigned)seed, (unsigned)(seed >> 32));
+  const unsigned z[4] = {r.x, r.y, r.z, r.w};
+  for (int k = 0; k < 4; ++k)
+    if (4 * q + k < B) { keys[(size_t)e * B + 4 * q + k] = ((unsigned long long)e << 32) | z[k]; vals[(size_t)e * B + 4 * q + k] = 4 * q + k; }
+}
+
+int32_t perm_fill_keys_batch(unsigned long long seed, unsigned long long stream_id0, const int* ctr, int B, int E, unsigned long long* keys, int* vals,
+                             hipStream_t stream) {
+  hipLaunchKernelGGL(perm_keys_batch_kernel, dim3(cdiv(cdiv(B, 4), 256), E), dim3(256), 0, stream, seed, stream_id0, ctr, B, keys, vals);
+  MPPO_CHECK_LAUNCH("perm_keys_batch_kernel");
+  return MPPO_OK;
+}
+
 int32_t perm_fill_keys(unsigned long long seed, unsigned long long stream_id, const int* ctr, int B, unsigned* keys, int* vals, hipStream_t stream) {
   hipLaunchKernelGGL(perm_keys_kernel, dim3(cdiv(cdiv(B, 4), 256)), dim3(256), 0, stream, seed, stream_id, ctr, B, keys, vals);
   MPPO_CHECK_LAUNCH("perm_keys_kernel");

@@ -35,6 +35,22 @@ int32_t permutation_ctr(unsigned long long seed, unsigned long long stream_id, c
   return MPPO_OK;
 }
 
+size_t permutation_batch_ws_bytes(int B, int E) { return (B < 1 || E < 1) ? 0 : (size_t)B * E * 12; }
+int32_t permutation_batch_ctr(unsigned long long seed, unsigned long long stream_id0, const int* ctr, int B, int E, int* idx, void* ws, size_t ws_bytes,
+                              hipStream_t stream) {
+  MPPO_REQUIRE(B >= 1 && E >= 1 && idx && ws, "permutation_batch: bad argument");
+  if (ws_bytes < permutation_batch_ws_bytes(B, E)) return fail(MPPO_ENOMEM, "permutation_batch: workspace too small");
+  const size_t n = (size_t)B * E;
+  unsigned long long* keys = static_cast<unsigned long long*>(ws);
+  int* vals = reinterpret_cast<int*>(keys + n);
+  MPPO_TRY(perm_fill_keys_batch(seed, stream_id0, ctr, B, E, keys, vals, stream));
+  std::vector<size_t> order(n);
+  std::iota(order.begin(), order.end(), (size_t)0);
+  std::stable_sort(order.begin(), order.end(), [&](size_t a, size_t b) { return keys[a] < keys[b]; });
+  for (size_t i = 0; i < n; ++i) idx[i] = vals[order[i]];
+  return MPPO_OK;
+}
+
 int32_t threefry_permutation(const unsigned* sort_keys, int rounds, int B, int* idx, void* ws, size_t ws_bytes, hipStream_t stream) {
   MPPO_REQUIRE(B >= 1 && idx && ws && sort_keys && rounds >= 1, "threefry_permutation: bad argument");
   if (ws_bytes < mppo_permutation_ws_bytes(B)) return fail(MPPO_ENOMEM, "threefry_permutation: workspace too small");

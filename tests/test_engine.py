@@ -211,6 +211,20 @@ def test_internal_rng_update_is_deterministic_and_learns_something(be):
         assert all((np.sort(perm[e]) == np.arange(tr.T * tr.N)).all() for e in range(tr.E))
         noise = be.host(tr.region("noise"))
         assert abs(noise.mean()) < 0.2 and 0.8 < noise.std() < 1.2
+        if rep == 0:
+            # the E epoch permutations of an update come out of ONE sort of (epoch, key) pairs; each must equal the single-permutation
+            # entry point on the same stream (stream id "PERM" << 24 + epoch; these are the second update's: update counter 1 -> not
+            # reproducible through mppo_permutation, whose counter word is 0, so check a FRESH trainer's first update)
+            tr2 = be.trainer(cfg, use_graph=False)
+            tr2.reset(); tr2.update()
+            got = be.host(tr2.region("perm", (tr2.E, tr2.T * tr2.N)))
+            B = tr2.T * tr2.N
+            wsb = be.lib.permutation_ws_bytes(B)
+            pws, one = be.zeros((wsb // 4 + 1,)), be.zeros((B,), np.int32)
+            for e in range(tr2.E):
+                be.lib.permutation(tr2.seed, (0x5045524D << 24) + e, B, be.ptr(one), be.ptr(pws), wsb, be.stream)
+                np.testing.assert_array_equal(got[e], be.host(one), err_msg=f"epoch {e}")
+            tr2.close()
         lo = tr.losses()
         assert np.isfinite(lo).all() and np.allclose(lo[..., 3], 0.5 * tr.A * (1 + np.log(2 * np.pi)), atol=0.5)
         tr.close()
