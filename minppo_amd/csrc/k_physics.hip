@@ -823,9 +823,26 @@ __global__ void __launch_bounds__(kEnvBlock) env_kernel(ModelView mv, EnvArgs a,
       // warm start: keep qacc_warmstart if its cost beats qacc_smooth's (MJX solver.solve)
       float cost_w = 0.f, gauss_w = 0.f;
       ctx_eval(warm, true, gauss_w, cost_w);
+      // fixed-size kernel: the warm-start context (this lane's entries of Ma and Jaref) is parked in registers while the smooth
+      // start is evaluated, and put back if it wins - the run-time-sized kernel evaluates it a second time instead
+      constexpr int kNvR = kDims ? (kSD.nv + kGroupLanes - 1) / kGroupLanes : 1, kEfR = kDims ? (kSD.nlimit + 4 * kSD.ncon + kGroupLanes - 1) / kGroupLanes : 1;
+      float keep_ma[kNvR], keep_ja[kEfR];
+      if (kDims) {
+        _Pragma("unroll") for (int j = 0; j < kNvR; ++j) { const int i = g + kGroupLanes * j; keep_ma[j] = i < nv ? Ma[i] : 0.f; }
+        _Pragma("unroll") for (int j = 0; j < kEfR; ++j) { const int r = g + kGroupLanes * j; keep_ja[j] = r < nefc ? jaref[r] : 0.f; }
+      }
       ctx_eval(qas, true, gauss, cost);
       const bool use_warm = cost_w < cost;
-      if (wave_any(use_warm)) ctx_eval(warm, use_warm, gauss, cost);
+      if (kDims) {
+        if (use_warm) {
+          _Pragma("unroll") for (int j = 0; j < kNvR; ++j) { const int i = g + kGroupLanes * j; if (i < nv) { qacc[i] = warm[i]; Ma[i] = keep_ma[j]; } }
+          _Pragma("unroll") for (int j = 0; j < kEfR; ++j) { const int r = g + kGroupLanes * j; if (r < nefc) jaref[r] = keep_ja[j]; }
+          gauss = gauss_w; cost = cost_w;
+        }
+        SYNC();
+      } else if (wave_any(use_warm)) {
+        ctx_eval(warm, use_warm, gauss, cost);
+      }
       prev_cost = INFINITY;  // MJX Context.create: cost starts at inf, so the first improvement is inf
       // update_constraint + update_gradient at the starting point
       FOR_G(r, nefc) { const float x = jaref[r]; force[r] = x < 0.f ? -eD[r] * x : 0.f; }
