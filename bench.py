@@ -232,7 +232,8 @@ def spawn_ranks(args: argparse.Namespace) -> int:
         procs = []
         for r in range(args.gpus):
             env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), LOCAL_WORLD_SIZE=str(args.gpus),
-                       MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"), **extra_env)
+                       MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"),
+                       MPPO_BENCH_WORKER="1", **extra_env)  # the children measure; this process is already their supervisor
             procs.append(subprocess.Popen([sys.executable, str(Path(__file__).resolve()), *sys.argv[1:]], env=env,
                                           stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, stderr=None))
         deadline = time.monotonic() + limit_s
@@ -268,10 +269,105 @@ def spawn_ranks(args: argparse.Namespace) -> int:
     return 0
 
 
+def supervise_rank(args: argparse.Namespace) -> int:
+    """A rank started by `python -m torch.distributed.run ... bench.py --gpus N` (the driver's spelling).  The rank process
+    itself stays off the GPU and runs the measurement in ONE child (same file, MPPO_BENCH_WORKER=1), so that a failure or
+    a hang of the first attempt - RCCL calls captured inside the hipGraph, the default - can be answered the same way
+    `spawn_ranks` answers it: every rank kills exactly its own child and the run is repeated once with eager launches
+    (MPPO_GRAPH_COMM=0).  The ranks agree through status files in a per-job directory (one node: nnodes = 1); the retry
+    rendezvous on a fresh port picked by rank 0 instead of the launcher's store (which still holds the first attempt's keys)."""
+    import signal
+    import socket
+    import subprocess
+    import tempfile
+
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    # one directory per job: the ranks of a launcher share its pid as their parent (tests name the job themselves)
+    job = "mppo_bench_%s_%s" % (os.environ.get("MASTER_PORT", "0"), os.environ.get("MPPO_BENCH_JOB", str(os.getppid())))
+    d = Path(os.environ.get("MPPO_BENCH_STATUS_DIR", tempfile.gettempdir())) / job
+    d.mkdir(parents=True, exist_ok=True)
+    limit = float(os.environ.get("MPPO_BENCH_RANK_TIMEOUT", "300"))
+    child_argv = [sys.executable, os.environ.get("MPPO_BENCH_WORKER_SCRIPT", str(Path(__file__).resolve())), *sys.argv[1:]]
+    state = {"proc": None}
+
+    def on_term(signum, frame):  # the launcher is tearing the job down: take the child along (its exact PID)
+        p = state["proc"]
+        if p is not None and p.poll() is None:
+            p.kill()
+        os._exit(128 + signum)
+
+    signal.signal(signal.SIGTERM, on_term)
+    signal.signal(signal.SIGINT, on_term)
+
+    def status_file(attempt: int, r: int) -> Path:
+        return d / f"attempt{attempt}.rank{r}"
+
+    def run_attempt(attempt: int, extra_env: dict):
+        env = dict(os.environ, MPPO_BENCH_WORKER="1", HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"), **extra_env)
+        p = subprocess.Popen(child_argv, env=env, stdout=subprocess.PIPE if rank == 0 else subprocess.DEVNULL, stderr=None)
+        state["proc"] = p
+        deadline = time.monotonic() + limit
+        ok, out = True, b""
+        while True:
+            try:
+                o, _ = p.communicate(timeout=1.0)
+                out = o or b""
+                ok = p.returncode == 0
+                break
+            except subprocess.TimeoutExpired:
+                peer_failed = any(status_file(attempt, r).exists() and status_file(attempt, r).read_text().strip() != "ok" for r in range(world))
+                if peer_failed or time.monotonic() > deadline:
+                    p.kill()
+                    o, _ = p.communicate()
+                    ok = False
+                    break
+        state["proc"] = None
+        tmp = status_file(attempt, rank).with_suffix(f".rank{rank}.tmp")
+        tmp.write_text("ok" if ok else "fail")
+        tmp.rename(status_file(attempt, rank))
+        # everybody's verdict (a rank that never reports counts as failed)
+        wait_until = time.monotonic() + limit + 60
+        while time.monotonic() < wait_until and not all(status_file(attempt, r).exists() for r in range(world)):
+            time.sleep(0.2)
+        all_ok = all(status_file(attempt, r).exists() and status_file(attempt, r).read_text().strip() == "ok" for r in range(world))
+        return all_ok, out
+
+    ok, out = run_attempt(0, {})
+    if not ok and os.environ.get("MPPO_GRAPH_COMM", "1") != "0":
+        if rank == 0:
+            sys.stderr.write("bench.py: ranks failed with RCCL inside the hipGraph; repeating with eager launches (MPPO_GRAPH_COMM=0)\n")
+            s = socket.socket()
+            s.bind(("127.0.0.1", 0))
+            port = s.getsockname()[1]
+            s.close()
+            tmp = d / "retry_port.tmp"
+            tmp.write_text(str(port))
+            tmp.rename(d / "retry_port")
+        wait_until = time.monotonic() + 120
+        while time.monotonic() < wait_until and not (d / "retry_port").exists():
+            time.sleep(0.2)
+        if (d / "retry_port").exists():
+            port = (d / "retry_port").read_text().strip()
+            ok, out = run_attempt(1, {"MPPO_GRAPH_COMM": "0", "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": port, "TORCHELASTIC_USE_AGENT_STORE": "False"})
+    if not ok:
+        sys.stderr.write(f"bench.py: rank {rank}: the run failed or timed out\n")
+        return 1
+    if rank == 0:
+        js = [l for l in out.decode(errors="replace").splitlines() if l.startswith("{")]
+        if not js:
+            sys.stderr.write("bench.py: rank 0 printed no JSON line\n")
+            return 1
+        sys.stdout.write(js[-1] + "\n")
+        sys.stdout.flush()
+    return 0
+
+
 def main() -> None:
     args = parse()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         raise SystemExit(spawn_ranks(args))  # before anything in this process touches a GPU
+    if args.gpus > 1 and os.environ.get("MPPO_BENCH_WORKER") != "1" and os.environ.get("MPPO_BENCH_SUPERVISE", "1") != "0":
+        raise SystemExit(supervise_rank(args))  # under a launcher: this process supervises, its child measures
     # The contract is ONE JSON line on stdout.  RCCL prints a version banner through C stdio on stdout (flushed at
     # exit, i.e. AFTER anything Python printed), so fd 1 is pointed at stderr for the life of the process and the JSON
     # line is written to the saved descriptor.

@@ -29,3 +29,68 @@ def test_rank_environment_is_what_torch_distributed_run_would_set():
     for var in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
         assert f"{var}=" in src or f'"{var}"' in src, var
     assert 'MASTER_ADDR="127.0.0.1"' in src
+
+
+_FAKE_WORKER = r'''
+import json, os, sys, time
+rank = int(os.environ["RANK"])
+assert os.environ.get("MPPO_BENCH_WORKER") == "1"
+mode = os.environ["FAKE_MODE"]
+graph_comm = os.environ.get("MPPO_GRAPH_COMM", "1")
+if mode == "rank1_fails_with_graph" and graph_comm != "0":
+    if rank == 1:
+        sys.exit(3)          # this rank dies at once ...
+    time.sleep(600)          # ... the others would hang in a collective: their supervisors must kill them
+if mode == "always_fails":
+    sys.exit(4)
+if rank == 0:
+    print("RCCL banner on stdout")
+    print(json.dumps({"metric": "fake", "graph_comm": graph_comm, "port": os.environ["MASTER_PORT"], "agent_store": os.environ.get("TORCHELASTIC_USE_AGENT_STORE", "")}))
+'''
+
+
+def _run_supervised(tmp_path, mode, world=2, timeout=120):
+    import os
+
+    fake = tmp_path / "fake_worker.py"
+    fake.write_text(_FAKE_WORKER)
+    procs = []
+    for r in range(world):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT="29999", FAKE_MODE=mode,
+                   MPPO_BENCH_WORKER_SCRIPT=str(fake), MPPO_BENCH_STATUS_DIR=str(tmp_path), MPPO_BENCH_JOB=f"test_{mode}", MPPO_BENCH_RANK_TIMEOUT="60")
+        env.pop("MPPO_BENCH_WORKER", None)
+        env.pop("MPPO_GRAPH_COMM", None)
+        procs.append(subprocess.Popen([sys.executable, str(ROOT / "bench.py"), "--gpus", str(world), "--steps", "1", "--warmup", "0"], env=env,
+                                      stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = [p.communicate(timeout=timeout) for p in procs]
+    return [p.returncode for p in procs], outs
+
+
+def test_rank_supervisor_forwards_rank0_json(tmp_path):
+    """Under a launcher (`torch.distributed.run ... bench.py --gpus N`) every rank process supervises ONE child that measures;
+    rank 0 forwards exactly the JSON line."""
+    import json
+
+    rcs, outs = _run_supervised(tmp_path, "ok")
+    assert rcs == [0, 0], (rcs, outs)
+    lines = outs[0][0].strip().splitlines()
+    assert len(lines) == 1 and json.loads(lines[0])["graph_comm"] == "1"
+    assert outs[1][0].strip() == ""
+
+
+def test_rank_supervisor_retries_with_eager_launches_when_a_rank_fails(tmp_path):
+    """One rank dying with the RCCL calls inside the hipGraph: every supervisor kills its own child (the survivors would
+    hang in a collective) and all ranks repeat with MPPO_GRAPH_COMM=0 on a fresh rendezvous port."""
+    import json
+
+    rcs, outs = _run_supervised(tmp_path, "rank1_fails_with_graph")
+    assert rcs == [0, 0], (rcs, outs)
+    d = json.loads(outs[0][0].strip().splitlines()[-1])
+    assert d["graph_comm"] == "0" and d["port"] != "29999" and d["agent_store"] == "False"
+    assert "repeating with eager launches" in outs[0][1]
+
+
+def test_rank_supervisor_reports_failure(tmp_path):
+    rcs, outs = _run_supervised(tmp_path, "always_fails")
+    assert all(rc == 1 for rc in rcs), (rcs, outs)
+    assert outs[0][0].strip() == ""
