@@ -54,7 +54,7 @@ def parse() -> argparse.Namespace:
     return ap.parse_args()
 
 
-def rowpass_probe(tr, launches: int = 50, replays: int = 4):
+def rowpass_probe(tr, launches: int = 64, replays: int = 4):
     """Average duration of the dominant kernel, `fused_mlp_kernel` (row-local forward + backward of one minibatch:
     both hidden layers, heads, loss terms, dZ2, dZ1 of actor and critic), on the engine's own buffers.  `launches`
     back-to-back launches are captured into a hipGraph on the engine stream and replayed, bracketed by HIP events recorded
@@ -71,15 +71,27 @@ def rowpass_probe(tr, launches: int = 50, replays: int = 4):
     wsb = tr.lib.grad_ws_bytes(C.byref(tr.net), mb)
     s = tr.stream
 
-    # exactly what the engine launches: the row pass reading the W2^T shadow copies of the gradient workspace (refreshed here once)
+    # exactly what the engine launches: the row pass reading the W2^T shadow copies of the gradient workspace (refreshed here once),
+    # its observation rows pre-gathered by the previous launch (the first launch's rows by mppo_gather_rows), extra workgroups
+    # gathering the next minibatch's rows
     tr.lib.shadow_refresh(C.byref(tr.net), reg["params"].data_ptr(), mb, reg["grad_ws"].data_ptr(), wsb, s.cuda_stream)
+    pre = os.environ.get("MPPO_NO_PREGATHER", "0") != "1"
+    if pre:
+        tr.lib.gather_rows(C.byref(tr.net), C.byref(batch), reg["perm"].data_ptr(), mb, reg["grad_ws"].data_ptr(), wsb, 0, s.cuda_stream)
 
     def launch(k):
-        tr.lib.minibatch_rowpass_shadow(C.byref(tr.net), reg["params"].data_ptr(), C.byref(batch), reg["perm"].data_ptr() + 4 * (k % M) * mb, mb,
-                                        reg["adv_stats"].data_ptr() + 8 * (k % M), 1.0 / mb, C.byref(lc), reg["grad_ws"].data_ptr(), wsb, s.cuda_stream)
+        idx = reg["perm"].data_ptr() + 4 * (k % M) * mb
+        if pre:
+            tr.lib.minibatch_rowpass_pre(C.byref(tr.net), reg["params"].data_ptr(), C.byref(batch), idx, reg["perm"].data_ptr() + 4 * ((k + 1) % M) * mb, mb,
+                                         reg["adv_stats"].data_ptr() + 8 * (k % M), 1.0 / mb, C.byref(lc), reg["grad_ws"].data_ptr(), wsb, k & 1, s.cuda_stream)
+        else:
+            tr.lib.minibatch_rowpass_shadow(C.byref(tr.net), reg["params"].data_ptr(), C.byref(batch), idx, mb,
+                                            reg["adv_stats"].data_ptr() + 8 * (k % M), 1.0 / mb, C.byref(lc), reg["grad_ws"].data_ptr(), wsb, s.cuda_stream)
 
-    for k in range(3):
+    for k in range(4):  # (an even number: the two row buffers alternate)
         launch(k)
+    if pre:  # buffer 0 holds the rows of minibatch 0 again when the captured sequence starts (and when it restarts: launches % M == 0)
+        tr.lib.gather_rows(C.byref(tr.net), C.byref(batch), reg["perm"].data_ptr(), mb, reg["grad_ws"].data_ptr(), wsb, 0, s.cuda_stream)
     s.synchronize()
     g = torch.cuda.CUDAGraph()
     with torch.cuda.graph(g, stream=s):
@@ -451,7 +463,8 @@ def main() -> None:
         if tfs and args.config == "stompy_pro" and args.envs_per_gpu == 4096 and not bf16:
             k = json.loads(tfs[-1].read_text())["kernels"]
             # the training row pass of a float network: <BF16 = false, ROLLOUT = false, OT = 1, W2T shadow = true> (the engine's choice)
-            key = next((n for n in k if n.endswith("fused_mlp_kernel<false, false, 1, true>")), None) or \
+            key = next((n for n in k if n.endswith("fused_mlp_kernel<false, false, 1, true, true>")), None) or \
+                next((n for n in k if n.endswith("fused_mlp_kernel<false, false, 1, true>")), None) or \
                 next((n for n in k if n.endswith("fused_mlp_kernel<false, false, 1>")), None)
             if key:
                 traffic = k[key]["hbm_bytes_per_launch"]

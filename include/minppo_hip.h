@@ -232,6 +232,24 @@ int32_t mppo_clip_adam_shadow(const mppo_net_t* net, int32_t mb, void* grad_ws, 
                               float* m, float* v, const float* grad, const int32_t* count_base, int32_t step_offset,
                               const mppo_adam_cfg_t* cfg, void* ws, size_t ws_bytes, void* stream);
 
+/* Pre-gathered rows (the engine's minibatch loop).  The observation rows of a minibatch depend on the permutation only, not on
+ * the parameters, so the row pass of optimizer step s gathers the rows of step s + 1 on extra workgroups of its own launch into
+ * the other of two k-quad buffers of the gradient workspace (`parity` 0 / 1 names the buffer that holds the CURRENT step's rows);
+ * step s + 1 then starts from a contiguous tile instead of the index -> row chain (reference train.py:261-265, the gather).
+ *   mppo_gather_rows               rows idx[0 .. mb) -> buffer `parity` (the first step of an update)
+ *   mppo_minibatch_rowpass_pre     = mppo_minibatch_rowpass_shadow reading buffer `parity` and gathering idx_next (may be NULL: the
+ *                                    last step) into the other buffer
+ *   mppo_minibatch_grad_pre        the same, followed by the weight-gradient launch: results identical to mppo_minibatch_grad. */
+int32_t mppo_gather_rows(const mppo_net_t* net, const mppo_batch_t* batch, const int32_t* idx, int32_t mb, void* grad_ws,
+                         size_t grad_ws_bytes, int32_t parity, void* stream);
+int32_t mppo_minibatch_rowpass_pre(const mppo_net_t* net, const float* params, const mppo_batch_t* batch, const int32_t* idx,
+                                   const int32_t* idx_next, int32_t mb, const float* adv_stat, float inv_count,
+                                   const mppo_loss_cfg_t* lc, void* ws, size_t ws_bytes, int32_t parity, void* stream);
+int32_t mppo_minibatch_grad_pre(const mppo_net_t* net, const float* params, const mppo_batch_t* batch, const int32_t* idx,
+                                const int32_t* idx_next, int32_t mb, const float* adv_stat, float inv_count,
+                                const mppo_loss_cfg_t* lc, float* grad, float* loss4, void* ws, size_t ws_bytes, int32_t parity,
+                                void* stream);
+
 /* Counter-based RNG (Philox4x32-10), the engine's own stream (not JAX threefry).
  * mppo_normal_fill: out[i] ~ N(0,1), i in [0,n), a pure function of (seed, stream_id, i).
  * mppo_permutation: idx = a uniformly random permutation of [0,B) (sort of random keys, as

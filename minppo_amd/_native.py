@@ -114,6 +114,9 @@ SIGNATURES = {
     "mppo_minibatch_rowpass_shadow": (c_i32, [P(Net), c_vp, P(Batch), c_vp, c_i32, c_vp, c_f, P(LossCfg), c_vp, c_sz, c_vp]),
     "mppo_minibatch_grad_shadow": (c_i32, [P(Net), c_vp, P(Batch), c_vp, c_i32, c_vp, c_f, P(LossCfg), c_vp, c_vp, c_vp, c_sz, c_vp]),
     "mppo_clip_adam_shadow": (c_i32, [P(Net), c_i32, c_vp, c_sz, c_sz, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, P(AdamCfg), c_vp, c_sz, c_vp]),
+    "mppo_gather_rows": (c_i32, [P(Net), P(Batch), c_vp, c_i32, c_vp, c_sz, c_i32, c_vp]),
+    "mppo_minibatch_rowpass_pre": (c_i32, [P(Net), c_vp, P(Batch), c_vp, c_vp, c_i32, c_vp, c_f, P(LossCfg), c_vp, c_sz, c_i32, c_vp]),
+    "mppo_minibatch_grad_pre": (c_i32, [P(Net), c_vp, P(Batch), c_vp, c_vp, c_i32, c_vp, c_f, P(LossCfg), c_vp, c_vp, c_vp, c_sz, c_i32, c_vp]),
     "mppo_normal_fill": (c_i32, [c_u64, c_u64, c_sz, c_vp, c_vp]),
     "mppo_permutation_ws_bytes": (c_sz, [c_i32]),
     "mppo_permutation": (c_i32, [c_u64, c_u64, c_i32, c_vp, c_vp, c_sz, c_vp]),

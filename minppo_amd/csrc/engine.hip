@@ -187,6 +187,11 @@ static bool shadow_enabled() {  // MPPO_NO_SHADOW=1: A/B switch for measurements
   return !no_shadow;
 }
 
+static bool pregather_enabled() {  // MPPO_NO_PREGATHER=1: A/B switch for measurements
+  static const bool off = [] { const char* v = getenv("MPPO_NO_PREGATHER"); return v && v[0] == '1'; }();
+  return !off;
+}
+
 static int32_t do_rollout(mppo_engine* e, hipStream_t s) {
   const mppo_engine_cfg_t& c = e->cfg;
   const size_t N = e->N, OP = e->OP, A = e->A;
@@ -257,6 +262,10 @@ static int32_t do_learn(mppo_engine* e, hipStream_t s) {
     MPPO_TRY(shadow_refresh(c.net, e->params, gb, s));
     gb.w2t_valid = true;
   }
+  // the row pass of step st gathers the observation rows of step st + 1 beside its own work (k_fused.hip, XPre); the first
+  // step's rows are gathered here
+  const bool use_pre = use_shadow && pregather_enabled();
+  if (use_pre) MPPO_TRY(fused_gather_rows(c.net, batch, e->perm, e->mb, gb.xmb, s));
   const float inv_count = 1.f / ((float)e->mb * (float)c.world_size);
   mppo_adam_cfg_t ac = c.adam;
   ac.sched_div = e->mb * c.world_size * e->E;  // minibatch_size * update_epochs of the GLOBAL batch (train.py:94,100)
@@ -265,8 +274,10 @@ static int32_t do_learn(mppo_engine* e, hipStream_t s) {
     for (int k = 0; k < e->M; ++k) {
       const int st = ep * e->M + k;
       const bool single = !use_comm;  // then the reduce kernel's sums of squares are those of the final gradient
+      XPre pre{(st & 1) ? gb.xmb2 : gb.xmb, (st & 1) ? gb.xmb : gb.xmb2,
+               st + 1 < EM ? e->perm + (size_t)((st + 1) / e->M) * e->B + (size_t)((st + 1) % e->M) * e->mb : nullptr};
       MPPO_TRY(minibatch_grad(c.net, e->params, batch, e->perm + (size_t)ep * e->B + (size_t)k * e->mb, e->mb, e->adv_stats + 2 * st, inv_count, c.loss, e->grad,
-                              e->losses + 4 * st, single ? e->adam_ws : nullptr, gb, s));                            // train.py:246-247
+                              e->losses + 4 * st, single ? e->adam_ws : nullptr, gb, s, use_pre ? &pre : nullptr));  // train.py:246-247
       if (!single) MPPO_TRY(comm_allreduce_f32(e->comm, e->grad, (size_t)e->P, s));
       MPPO_TRY(clip_adam((size_t)e->P, e->params, e->adam_m, e->adam_v, e->grad, e->count, st, ac, e->adam_ws, single, s, use_shadow ? &shadow : nullptr));  // train.py:248
     }

@@ -61,6 +61,14 @@ struct FusedArgs {
   const float* noise;
   float *action, *log_prob, *value, *mean_out;
   int net0;  // first network of the launch: 0 = actor + critic, 1 = critic only (bootstrap value, train.py:182)
+  // engine minibatch loop (PRE = true instantiations, ppo_layout.h XPre): this step's rows, already gathered, in k-quad layout; the
+  // workgroups with blockIdx.y >= gather_y0 gather the NEXT step's rows (idx_next) into xnext while the others compute.  They are
+  // the LAST rows of the grid: workgroups are dispatched in linear order, so the gather fills the CUs the row tiles leave idle
+  // (96 of 256 at the headline shape) and never delays a row tile (it did, by 2 us, as columns of the grid at 8192 environments)
+  const float* xpre;
+  float* xnext;
+  const int* idx_next;
+  int gather_y0;
   int skip;  // timing experiments only (MPPO_FUSED_SKIP bit mask): 1 L1, 2 L2, 4 heads, 8 dZ2, 16 dZ1, 32 activation stores, 64 gather
 };
 
@@ -246,14 +254,43 @@ __device__ __forceinline__ float row32_sum(float x) {
   return x;
 }
 
+// Gather role of a PRE launch: 16 rows of the NEXT minibatch (half = blockIdx.y picks two of the tile's four quads) from the
+// trajectory into the k-quad buffer; rows past the minibatch are written as zeros (the buffer is an operand of the weight-gradient
+// product and of the first layer).  Depends on the permutation only - it runs beside the workgroups that compute this step.
+__device__ __forceinline__ void gather_rows_tile(const FusedArgs& a, int tile, int half) {
+  const int OP = a.OP, row0 = tile * FRT;
+  for (int e = threadIdx.x; e < 2 * OP; e += blockDim.x) {
+    const int qd = 2 * half + e / OP, c = e % OP;
+    long ix[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int r = row0 + 4 * qd + j;
+      ix[j] = a.idx_next[r < a.mb ? r : a.mb - 1];
+    }
+    float v[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float x = a.b.obs[ix[j] * a.b.obs_ld + c];
+      v[j] = row0 + 4 * qd + j < a.mb ? x : 0.f;
+    }
+    stream_store(a.xnext + quad_index(row0 + 4 * qd, c, OP), make_float4(v[0], v[1], v[2], v[3]));
+  }
+}
+
 // rollout launches have 2 x N/16 workgroups (512 at N = 4096): two per CU must be co-resident = 4 waves per SIMD (the second
 // __launch_bounds__ argument is HIP's minimum waves per execution unit), i.e. at most 128 VGPRs
 // OT = 16-wide output tiles of the head GEMM: 1 for A <= 16, 2 for A <= 32 (BASELINE configs[4]: 20 actuators)
 // W2T: the backward product reads the transposed shadow copy of W2 (GradBufs::w2t) through the forward-style pipe: 23.9 -> 21.9 us
-template <bool BF16, bool ROLLOUT, int OT, bool W2T = false>
+// PRE: engine minibatch loop - the x tile comes from the pre-gathered k-quad buffer (one trip to memory instead of index -> row), the
+// gathered rows are not written again, and the grid rows from `gather_y0` on gather the next step's rows
+template <bool BF16, bool ROLLOUT, int OT, bool W2T = false, bool PRE = false>
 __global__ void __launch_bounds__(512, ROLLOUT ? MPPO_ROLLOUT_WAVES : 2) fused_mlp_kernel(FusedArgs a) {
   constexpr int SD = 16 * OT;  // row stride of the per-row output-space tiles
   FT(0);
+  if (PRE && (int)blockIdx.y >= a.gather_y0) {  // uniform per workgroup
+    gather_rows_tile(a, (int)blockIdx.x, (int)blockIdx.y - a.gather_y0);
+    return;
+  }
   MPPO_DYN_SMEM(smem_raw);
   float* sm = reinterpret_cast<float*>(smem_raw);
   const int H = a.H, O = a.O, OP = a.OP, A = a.A, AP = a.AP;
@@ -337,11 +374,18 @@ __global__ void __launch_bounds__(512, ROLLOUT ? MPPO_ROLLOUT_WAVES : 2) fused_m
     const int ic = pon[r] ? i : a.mb - 1;
     prow[r] = gather ? (long)a.idx[ic] : (long)ic;
   }
-  if (gather) { xrow0 = a.idx[gi0]; xrow1 = a.idx[gi1]; }
+  if (gather && !PRE) { xrow0 = a.idx[gi0]; xrow1 = a.idx[gi1]; }
   // dependent batch: the observation chunks (needed first), then the per-row scalars of the loss (needed four phases later)
   float4 xq0 = make_float4(0.f, 0.f, 0.f, 0.f), xq1 = xq0;
-  if (e0 < nx && xc0 < OP) xq0 = *reinterpret_cast<const float4*>(a.b.obs + xrow0 * a.b.obs_ld + xc0);
-  if (e1 < nx && xc1 < OP) xq1 = *reinterpret_cast<const float4*>(a.b.obs + xrow1 * a.b.obs_ld + xc1);
+  const int nxq = 4 * OP;  // PRE: float4 elements of the k-quad tile, element e = (quad e / OP, column e % OP); contiguous in memory
+  const float* xtile = PRE ? a.xpre + (size_t)(row0 >> 2) * OP * 4 : nullptr;
+  if (PRE) {  // depends on nothing but the kernel arguments
+    if (e0 < nxq) xq0 = *reinterpret_cast<const float4*>(xtile + 4 * e0);
+    if (e1 < nxq) xq1 = *reinterpret_cast<const float4*>(xtile + 4 * e1);
+  } else {
+    if (e0 < nx && xc0 < OP) xq0 = *reinterpret_cast<const float4*>(a.b.obs + xrow0 * a.b.obs_ld + xc0);
+    if (e1 < nx && xc1 < OP) xq1 = *reinterpret_cast<const float4*>(a.b.obs + xrow1 * a.b.obs_ld + xc1);
+  }
   float pf0[OT][4], pf1[4], pf2[4];  // actor: action[o], old log_prob, advantage | critic: old value, target, -  (rollout: noise[o])
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
@@ -374,9 +418,22 @@ __global__ void __launch_bounds__(512, ROLLOUT ? MPPO_ROLLOUT_WAVES : 2) fused_m
 
   FT(2);
   // ---- P0: gathered observation rows -> LDS (zero-padded to KP columns) ----
+  if (PRE) {
+    // a k-quad element is one column of four consecutive rows: four LDS words a row stride apart (consecutive lanes hold consecutive columns)
+    auto put = [&](int e, const float4& q) {
+      const int qd = e / OP, c = e - qd * OP;
+      float* d = xt + (4 * qd) * XS + c;
+      d[0] = q.x; d[XS] = q.y; d[2 * XS] = q.z; d[3 * XS] = q.w;
+    };
+    if (e0 < nxq) put(e0, xq0);
+    if (e1 < nxq) put(e1, xq1);
+    for (int e = t + 2 * nthr; e < nxq; e += nthr) put(e, *reinterpret_cast<const float4*>(xtile + 4 * e));
+    for (int e = t; e < FRT * (KP - OP); e += nthr) xt[(e / (KP - OP)) * XS + OP + e % (KP - OP)] = 0.f;  // K padding of the first layer
+  } else {
   if (e0 < nx) *reinterpret_cast<float4*>(xt + xr0 * XS + xc0) = xq0;
   if (e1 < nx) *reinterpret_cast<float4*>(xt + xr1 * XS + xc1) = xq1;
-  for (int e = t + 2 * nthr; e < nx; e += nthr) {  // (only for widths with more than two chunks per thread)
+  }
+  for (int e = t + 2 * nthr; e < nx && !PRE; e += nthr) {  // (only for widths with more than two chunks per thread)
     const int r = e / (KP / 4), c4 = (e % (KP / 4)) * 4;
     const int gi = row0 + r < a.mb ? row0 + r : a.mb - 1;
     const long row = gather ? a.idx[gi] : gi;
@@ -409,7 +466,7 @@ __global__ void __launch_bounds__(512, ROLLOUT ? MPPO_ROLLOUT_WAVES : 2) fused_m
 #ifdef MPPO_FUSED_TIMERS
     if (!ROLLOUT && blockIdx.x == 40 && blockIdx.y == 0 && lane == 0) g_fused_t[24 + 16 * layer + 8 + wave] = __builtin_amdgcn_s_memtime();
 #endif
-    if (layer == 0 && !ROLLOUT && net == 0) {
+    if (layer == 0 && !ROLLOUT && net == 0 && !PRE) {
       // the gathered rows, k-quad layout [mb/4][OP][4], for the first layer's weight gradient (the actor workgroup writes them).
       // Here, after this wave's share of the first GEMM and before the barrier, the copy costs the early waves nothing: they
       // would wait for the SIMD's second wave anyway (the x tile stays intact until the head partials overwrite it in P3).
@@ -705,13 +762,17 @@ static int32_t fused_set_smem(size_t smem) {
   MPPO_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(fused_mlp_kernel<B, false, T, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem))
   MPPO_FUSED_ATTR(false, 1); MPPO_FUSED_ATTR(true, 1); MPPO_FUSED_ATTR(false, 2); MPPO_FUSED_ATTR(true, 2);
 #undef MPPO_FUSED_ATTR
+#define MPPO_FUSED_ATTR(B, T) \
+  MPPO_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(fused_mlp_kernel<B, false, T, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem))
+  MPPO_FUSED_ATTR(false, 1); MPPO_FUSED_ATTR(true, 1); MPPO_FUSED_ATTR(false, 2); MPPO_FUSED_ATTR(true, 2);
+#undef MPPO_FUSED_ATTR
   MPPO_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(fused_mlp_kernel<true, true, 1, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
   MPPO_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(fused_mlp_kernel<true, true, 2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
   return MPPO_OK;
 }
 
 int32_t fused_forward_backward(const mppo_net_t& net, const float* params, const mppo_batch_t& batch, const int* idx, int mb, const float* adv_stat,
-                               float inv_count, const mppo_loss_cfg_t& lc, const GradBufs& g, hipStream_t stream) {
+                               float inv_count, const mppo_loss_cfg_t& lc, const GradBufs& g, hipStream_t stream, const XPre* pre) {
   FusedArgs a{};
   a.mb = mb; a.O = net.O; a.OP = net.OP; a.A = net.A; a.AP = g.f.AP; a.DP = g.f.AP + 4; a.H = net.H; a.use_tanh = net.use_tanh;
   a.params = params; a.L = param_layout(net.O, net.A, net.H); a.b = batch; a.idx = idx; a.adv_stat = adv_stat; a.inv_count = inv_count; a.lc = lc;
@@ -728,8 +789,12 @@ int32_t fused_forward_backward(const mppo_net_t& net, const float* params, const
     MPPO_TRY(fused_set_smem(smem));
     attr_for = smem;
   }
-  const dim3 grid(cdiv(mb, FRT), 2), block(2 * net.H);
-#define MPPO_FUSED_GO(B, T) do { if (w2t) hipLaunchKernelGGL((fused_mlp_kernel<B, false, T, true>), grid, block, smem, stream, a); \
+  MPPO_REQUIRE(!pre || (w2t && idx), "fused_forward_backward: pre-gathered rows need the shadow copies and a permutation");
+  a.gather_y0 = 2;
+  if (pre) { a.xpre = pre->cur; a.xnext = pre->next; a.idx_next = pre->idx_next; }
+  const dim3 grid(cdiv(mb, FRT), pre && pre->idx_next ? 4 : 2), block(2 * net.H);
+#define MPPO_FUSED_GO(B, T) do { if (pre) hipLaunchKernelGGL((fused_mlp_kernel<B, false, T, true, true>), grid, block, smem, stream, a); \
+                                else if (w2t) hipLaunchKernelGGL((fused_mlp_kernel<B, false, T, true>), grid, block, smem, stream, a); \
                                 else hipLaunchKernelGGL((fused_mlp_kernel<B, false, T, false>), grid, block, smem, stream, a); } while (0)
   if (net.A > 16) {
     if (net.bf16) MPPO_FUSED_GO(true, 2); else MPPO_FUSED_GO(false, 2);
@@ -738,6 +803,17 @@ int32_t fused_forward_backward(const mppo_net_t& net, const float* params, const
   }
 #undef MPPO_FUSED_GO
   MPPO_CHECK_LAUNCH("fused_mlp_kernel");
+  return MPPO_OK;
+}
+
+// The first optimizer step of an update has no previous launch to gather its rows: the gather role alone (every workgroup of a PRE
+// launch with gather_y0 = 0).
+int32_t fused_gather_rows(const mppo_net_t& net, const mppo_batch_t& batch, const int* idx, int mb, float* dst, hipStream_t stream) {
+  MPPO_REQUIRE(idx && dst && batch.obs, "fused_gather_rows: null argument");
+  FusedArgs a{};
+  a.mb = mb; a.O = net.O; a.OP = net.OP; a.H = net.H; a.b = batch; a.idx_next = idx; a.xnext = dst; a.gather_y0 = 0;
+  hipLaunchKernelGGL((fused_mlp_kernel<false, false, 1, true, true>), dim3(cdiv(mb, FRT), 2), dim3(256), 0, stream, a);
+  MPPO_CHECK_LAUNCH("fused_mlp_kernel<gather>");
   return MPPO_OK;
 }
 

@@ -581,7 +581,7 @@ int32_t policy_forward(const mppo_net_t& net, const float* params, int n, const 
 // (one fused launch where supported, k_fused.hip; otherwise layer-wise GEMMs + the head kernel).  Leaves h1, h2, dZ2, dZ1,
 // dOut, xmb and the loss partials in the GradBufs; *nblk_out = number of partial rows written.
 int32_t minibatch_rowpass(const mppo_net_t& net, const float* params, const mppo_batch_t& batch, const int* idx, int mb, const float* adv_stat,
-                          float inv_count, const mppo_loss_cfg_t& lc, const GradBufs& gbuf, int* nblk_out, bool* fused_out, hipStream_t stream) {
+                          float inv_count, const mppo_loss_cfg_t& lc, const GradBufs& gbuf, int* nblk_out, bool* fused_out, hipStream_t stream, const XPre* pre = nullptr) {
   const ParamLayout L = param_layout(net.O, net.A, net.H);
   const int H = net.H;
   const int act_a = net.use_tanh ? ACT_TANH : ACT_RELU;
@@ -590,7 +590,7 @@ int32_t minibatch_rowpass(const mppo_net_t& net, const float* params, const mppo
   const bool fused = fused_supported(net, batch) && !(nofuse && nofuse[0] == '1');
   if (fused_out) *fused_out = fused;
   if (fused) {
-    MPPO_TRY(fused_forward_backward(net, params, batch, idx, mb, adv_stat, inv_count, lc, gbuf, stream));
+    MPPO_TRY(fused_forward_backward(net, params, batch, idx, mb, adv_stat, inv_count, lc, gbuf, stream, pre));
     *nblk_out = cdiv(mb, 16);
     return MPPO_OK;
   }
@@ -612,12 +612,13 @@ int32_t minibatch_rowpass(const mppo_net_t& net, const float* params, const mppo
 }
 
 int32_t minibatch_grad(const mppo_net_t& net, const float* params, const mppo_batch_t& batch, const int* idx, int mb, const float* adv_stat,
-                       float inv_count, const mppo_loss_cfg_t& lc, float* grad, float* loss4, float* sq_partial, const GradBufs& gbuf, hipStream_t stream) {
+                       float inv_count, const mppo_loss_cfg_t& lc, float* grad, float* loss4, float* sq_partial, const GradBufs& gbuf, hipStream_t stream, const XPre* pre) {
   const ParamLayout L = param_layout(net.O, net.A, net.H);
   const int H = net.H, A = net.A, AP = gbuf.f.AP, DP = AP + 4, O = net.O;
   int nblk = 0;
   bool fused = false;
-  MPPO_TRY(minibatch_rowpass(net, params, batch, idx, mb, adv_stat, inv_count, lc, gbuf, &nblk, &fused, stream));
+  MPPO_TRY(minibatch_rowpass(net, params, batch, idx, mb, adv_stat, inv_count, lc, gbuf, &nblk, &fused, stream, pre));
+  const float* xq = (pre && fused) ? pre->cur : gbuf.xmb;  // the step's observation rows, k-quad layout (the layer-wise path gathers for itself)
   const float ent_weight = (float)mb * inv_count;
   static const char* old_wgrad = getenv("MPPO_OLD_WGRAD");  // (no longer selectable with the fused row pass: its outputs are k-quad operands)
   (void)old_wgrad;
@@ -631,9 +632,9 @@ int32_t minibatch_grad(const mppo_net_t& net, const float* params, const mppo_ba
     };
     w.count = 6; w.grad = grad; w.sq_partial = sq_partial;
     w.p[0] = wp(gbuf.f.h1a, H, H, gbuf.dz2a, H, H, H, L.a_w2, L.a_b2);
-    w.p[1] = wp(gbuf.xmb, net.OP, O, gbuf.dz1a, H, H, H, L.a_w1, L.a_b1);
+    w.p[1] = wp(xq, net.OP, O, gbuf.dz1a, H, H, H, L.a_w1, L.a_b1);
     w.p[2] = wp(gbuf.f.h1c, H, H, gbuf.dz2c, H, H, H, L.c_w2, L.c_b2);
-    w.p[3] = wp(gbuf.xmb, net.OP, O, gbuf.dz1c, H, H, H, L.c_w1, L.c_b1);
+    w.p[3] = wp(xq, net.OP, O, gbuf.dz1c, H, H, H, L.c_w1, L.c_b1);
     w.p[4] = wp(gbuf.f.h2a, H, H, gbuf.dout, DP, AP, A, L.a_w3, L.a_b3);
     w.p[5] = wp(gbuf.f.h2c, H, H, gbuf.dout + 4 * AP, DP, 4, 1, L.c_w3, L.c_b3);  // column AP of the quad rows
     w.ls_off = L.log_std; w.A = A; w.AP = AP; w.nblk = nblk; w.partial = gbuf.partial; w.log_std = params + L.log_std;
@@ -865,6 +866,46 @@ extern "C" int32_t mppo_minibatch_grad_shadow(const mppo_net_t* net, const float
   GradBufs gb = carve_grad(*net, mb, static_cast<float*>(ws));
   gb.w2t_valid = true;
   return minibatch_grad(*net, params, *batch, idx, mb, adv_stat, inv_count, *lc, grad, loss4, nullptr, gb, static_cast<hipStream_t>(stream));
+}
+
+static int32_t pre_args(const char* who, const mppo_net_t* net, const mppo_batch_t* batch, const int32_t* idx, int32_t mb, void* ws, size_t ws_bytes, int32_t parity,
+                        GradBufs* gb) {
+  MPPO_TRY(check_net(net));
+  MPPO_REQUIRE(batch && batch->obs && idx && ws && mb >= 1 && (parity == 0 || parity == 1), "%s: null argument, mb < 1 or parity not 0 / 1", who);
+  if (ws_bytes < mppo_grad_ws_bytes(net, mb)) return fail(MPPO_ENOMEM, "%s: workspace %zu < %zu bytes", who, ws_bytes, mppo_grad_ws_bytes(net, mb));
+  MPPO_REQUIRE(fused_supported(*net, *batch), "%s: this geometry takes the layer-wise path, which gathers for itself (mppo_minibatch_path)", who);
+  *gb = carve_grad(*net, mb, static_cast<float*>(ws));
+  gb->w2t_valid = true;
+  return MPPO_OK;
+}
+
+extern "C" int32_t mppo_gather_rows(const mppo_net_t* net, const mppo_batch_t* batch, const int32_t* idx, int32_t mb, void* grad_ws, size_t grad_ws_bytes,
+                                    int32_t parity, void* stream) {
+  GradBufs gb;
+  MPPO_TRY(pre_args("mppo_gather_rows", net, batch, idx, mb, grad_ws, grad_ws_bytes, parity, &gb));
+  return fused_gather_rows(*net, *batch, idx, mb, parity ? gb.xmb2 : gb.xmb, static_cast<hipStream_t>(stream));
+}
+
+extern "C" int32_t mppo_minibatch_rowpass_pre(const mppo_net_t* net, const float* params, const mppo_batch_t* batch, const int32_t* idx, const int32_t* idx_next,
+                                              int32_t mb, const float* adv_stat, float inv_count, const mppo_loss_cfg_t* lc, void* ws, size_t ws_bytes,
+                                              int32_t parity, void* stream) {
+  GradBufs gb;
+  MPPO_TRY(pre_args("mppo_minibatch_rowpass_pre", net, batch, idx, mb, ws, ws_bytes, parity, &gb));
+  MPPO_REQUIRE(params && adv_stat && lc, "mppo_minibatch_rowpass_pre: null argument");
+  const XPre pre{parity ? gb.xmb2 : gb.xmb, parity ? gb.xmb : gb.xmb2, idx_next};
+  int nblk = 0;
+  return minibatch_rowpass(*net, params, *batch, idx, mb, adv_stat, inv_count, *lc, gb, &nblk, nullptr, static_cast<hipStream_t>(stream), &pre);
+}
+
+extern "C" int32_t mppo_minibatch_grad_pre(const mppo_net_t* net, const float* params, const mppo_batch_t* batch, const int32_t* idx, const int32_t* idx_next,
+                                           int32_t mb, const float* adv_stat, float inv_count, const mppo_loss_cfg_t* lc, float* grad, float* loss4, void* ws,
+                                           size_t ws_bytes, int32_t parity, void* stream) {
+  GradBufs gb;
+  MPPO_TRY(pre_args("mppo_minibatch_grad_pre", net, batch, idx, mb, ws, ws_bytes, parity, &gb));
+  MPPO_REQUIRE(params && adv_stat && lc && grad, "mppo_minibatch_grad_pre: null argument");
+  MPPO_REQUIRE(batch->action && batch->value && batch->log_prob && batch->adv && batch->target, "mppo_minibatch_grad_pre: null batch field");
+  const XPre pre{parity ? gb.xmb2 : gb.xmb, parity ? gb.xmb : gb.xmb2, idx_next};
+  return minibatch_grad(*net, params, *batch, idx, mb, adv_stat, inv_count, *lc, grad, loss4, nullptr, gb, static_cast<hipStream_t>(stream), &pre);
 }
 
 extern "C" int32_t mppo_clip_adam_shadow(const mppo_net_t* net, int32_t mb, void* grad_ws, size_t grad_ws_bytes, size_t P, float* params, float* m, float* v,

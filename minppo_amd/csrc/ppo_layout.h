@@ -78,6 +78,10 @@ struct GradBufs {
   FwdBufs f;
   float *dout, *dz2a, *dz2c, *dz1a, *dz1c, *partial, *slabs;  // dout [mb, AP+4]: d mean | d value
   float* xmb;  // [mb, OP]: the minibatch observations, laid out contiguously by the first forward GEMM
+  // Second observation buffer (k-quad layout like xmb in the fused path): the engine's row pass of optimizer step s gathers the
+  // rows of step s + 1 on workgroups of its own launch (k_fused.hip, XPre) - they depend on the permutation only, not on the
+  // parameters - so that step s + 1 starts from a contiguous tile instead of the index -> row chain; xmb and xmb2 alternate.
+  float* xmb2;
   // Shadow copy of the second-layer weights, transposed: w2t[net][n][k] = W2_net[k][n] (net 0 actor, 1 critic).  The backward
   // product dZ1 = dZ2 . W2^T then streams its B operand exactly like a forward layer (rows of consecutive outputs) instead of
   // gathering 16-byte pieces of 32 different rows per load.  Written by shadow_refresh() and kept current by clip_adam(); the
@@ -98,7 +102,7 @@ inline size_t grad_bufs_floats(const mppo_net_t& net, int mb) {
   const size_t AP = pad4((size_t)net.A), nh = pad4(mbp * net.H);
   const size_t P = pad4((size_t)param_layout(net.O, net.A, net.H).total);
   const size_t nblk = (size_t)(mb + 7) / 8;  // head kernel: 8 rows per workgroup (fused kernel: 16)
-  return fwd_bufs_floats(net, (int)mbp) + pad4(mbp * (AP + 4)) + 4 * nh + pad4(nblk * (4 + AP)) + (size_t)kGradKSplitMax * P + pad4(mbp * net.OP) + 2 * pad4((size_t)net.H * net.H) +
+  return fwd_bufs_floats(net, (int)mbp) + pad4(mbp * (AP + 4)) + 4 * nh + pad4(nblk * (4 + AP)) + (size_t)kGradKSplitMax * P + 2 * pad4(mbp * net.OP) + 2 * pad4((size_t)net.H * net.H) +  // (xmb, xmb2)
          (net.bf16 ? pad4((size_t)(((net.O + 31) & ~31) + 2 * net.H) * net.H) : 0);  // bf16 fragments: 2 networks x (KP + 2H) x H halves = that many floats
 }
 inline GradBufs carve_grad(const mppo_net_t& net, int mb, float* ws) {
@@ -113,7 +117,8 @@ inline GradBufs carve_grad(const mppo_net_t& net, int mb, float* ws) {
   g.partial = ws; ws += pad4(nblk * (4 + AP));
   g.slabs = ws;
   g.xmb = ws + (size_t)kGradKSplitMax * pad4((size_t)param_layout(net.O, net.A, net.H).total);
-  g.w2t = g.xmb + pad4(mbp * net.OP);
+  g.xmb2 = g.xmb + pad4(mbp * net.OP);
+  g.w2t = g.xmb2 + pad4(mbp * net.OP);  // (the shadow copies stay the LAST region of the workspace)
   g.w2t_valid = false;
   g.frag = net.bf16 ? reinterpret_cast<unsigned short*>(g.w2t + 2 * pad4((size_t)net.H * net.H)) : nullptr;
   g.frag_net_stride = (size_t)(((net.O + 31) & ~31) + 2 * net.H) * net.H;
@@ -122,12 +127,17 @@ inline GradBufs carve_grad(const mppo_net_t& net, int mb, float* ws) {
   return g;
 }
 
+// Pre-gathered observations of the engine's minibatch loop (see GradBufs::xmb2).  cur: the k-quad buffer holding THIS step's rows
+// (written by the previous step's launch or by fused_gather_rows); next / idx_next: where the launch gathers the next step's rows
+// (idx_next == nullptr: the last step, nothing to gather).
+struct XPre { const float* cur; float* next; const int* idx_next; };
+
 // stage launchers (k_ppo.hip)
 int32_t policy_forward(const mppo_net_t& net, const float* params, int n, const float* obs, int obs_ld, const FwdBufs& fb, const float* noise, float* action,
                        float* log_prob, float* value, float* mean_out, hipStream_t stream);
 // sq_partial (optional): per-workgroup sums of squares of the reduced gradient, consumed by clip_adam(have_sumsq = true)
 int32_t minibatch_grad(const mppo_net_t& net, const float* params, const mppo_batch_t& batch, const int* idx, int mb, const float* adv_stat, float inv_count,
-                       const mppo_loss_cfg_t& lc, float* grad, float* loss4, float* sq_partial, const GradBufs& gbuf, hipStream_t stream);
+                       const mppo_loss_cfg_t& lc, float* grad, float* loss4, float* sq_partial, const GradBufs& gbuf, hipStream_t stream, const XPre* pre = nullptr);
 // shadow (optional): the W2^T copies to keep in step with the parameters (GradBufs::w2t of the workspace the row pass reads)
 struct ShadowRef {
   float* w2t; int a_w2, c_w2, H;
@@ -160,7 +170,9 @@ bool fused_rollout_supported(const mppo_net_t& net, const float* obs, int obs_ld
 int32_t fused_policy_forward(const mppo_net_t& net, const float* params, int n, const float* obs, int obs_ld, const float* noise, float* action, float* log_prob,
                              float* value, float* mean_out, int AP, hipStream_t stream, const unsigned short* frag = nullptr, size_t frag_net_stride = 0);
 int32_t fused_forward_backward(const mppo_net_t& net, const float* params, const mppo_batch_t& batch, const int* idx, int mb, const float* adv_stat,
-                               float inv_count, const mppo_loss_cfg_t& lc, const GradBufs& g, hipStream_t stream);
+                               float inv_count, const mppo_loss_cfg_t& lc, const GradBufs& g, hipStream_t stream, const XPre* pre = nullptr);
+// rows idx[0 .. mb) of the observations -> k-quad buffer `dst` (whole 16-row tiles, zeros past mb): the first step of an update
+int32_t fused_gather_rows(const mppo_net_t& net, const mppo_batch_t& batch, const int* idx, int mb, float* dst, hipStream_t stream);
 int32_t perm_fill_keys(unsigned long long seed, unsigned long long stream_id, const int* ctr, int B, unsigned* keys, int* vals, hipStream_t stream);
 int32_t normal_fill_ctr(unsigned long long seed, unsigned long long stream_id, const int* ctr, size_t n, float* out, hipStream_t stream);
 int32_t permutation_ctr(unsigned long long seed, unsigned long long stream_id, const int* ctr, int B, int* idx, void* ws, size_t ws_bytes, hipStream_t stream);

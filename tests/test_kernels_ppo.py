@@ -485,3 +485,47 @@ def test_shadow_copies_change_nothing_but_the_layout_of_one_operand(be, bf16):
             k2, n2 = int(r3.integers(0, H)), int(r3.integers(0, H))
             assert frag[per_net + KP * H + frag_index(k2, n2, H)] == bf16_bits(W2c[k2, n2])
             assert frag[per_net + KP * H + H * H + frag_index(k2, n2, H)] == bf16_bits(W2c[n2, k2])
+
+
+@pytest.mark.parametrize("bf16,mb", [(0, 48), (0, 42), (1, 42)])
+def test_pregathered_rows_change_nothing(be, bf16, mb):
+    """The engine's minibatch loop (include/minppo_hip.h, "Pre-gathered rows"): the row pass of one step gathers the next step's
+    observation rows on extra workgroups of its own launch.  mppo_minibatch_grad_pre == mppo_minibatch_grad bit for bit, for a step
+    whose rows were gathered by mppo_gather_rows and for the following step whose rows were gathered inside the first step's
+    launch; minibatch sizes that are not a multiple of the 16-row tile (zero rows behind the minibatch) included."""
+    O, A, H, B = 37, 5, 64, 96
+    OP = (O + 3) // 4 * 4
+    rng = np.random.default_rng(11)
+    net = nat.Net(O, OP, A, H, 1, bf16)
+    flat = po.named_to_flat(po.init_params(3, O, A, H), O, A, H).astype(f32)
+    P = flat.size
+    bobs = np.zeros((B, OP), f32); bobs[:, :O] = rng.standard_normal((B, O))
+    perm = rng.permutation(B).astype(np.int32)
+    arrs = dict(flat=flat, obs=bobs, act=rng.standard_normal((B, A)).astype(f32), val=rng.standard_normal(B).astype(f32), lp=rng.standard_normal(B).astype(f32),
+                adv=rng.standard_normal(B).astype(f32), tgt=rng.standard_normal(B).astype(f32), idx0=perm[:mb].copy(), idx1=perm[mb:2 * mb].copy())
+    d = {k: be.arr(v) for k, v in arrs.items()}
+    stats = be.arr(np.array([0.1, 0.9], f32))
+    batch = nat.Batch(be.ptr(d["obs"]), OP, be.ptr(d["act"]), A, be.ptr(d["val"]), be.ptr(d["lp"]), be.ptr(d["adv"]), be.ptr(d["tgt"]))
+    lc = nat.LossCfg(0.2, 0.5, 0.01)
+    wsb = be.lib.grad_ws_bytes(C.byref(net), mb)
+    ref, got = {}, {}
+    ws = be.full((wsb // 4 + 4,), np.nan)
+    be.lib.shadow_refresh(C.byref(net), be.ptr(d["flat"]), mb, be.ptr(ws), wsb, be.stream)
+    for k in ("idx0", "idx1"):
+        g, l = be.full((P,), np.nan), be.zeros((4,))
+        be.lib.minibatch_grad_shadow(C.byref(net), be.ptr(d["flat"]), C.byref(batch), be.ptr(d[k]), mb, be.ptr(stats), 1.0 / mb, C.byref(lc), be.ptr(g), be.ptr(l),
+                                     be.ptr(ws), wsb, be.stream)
+        ref[k] = (be.host(g).copy(), be.host(l).copy())
+    ws2 = be.full((wsb // 4 + 4,), np.nan)
+    be.lib.shadow_refresh(C.byref(net), be.ptr(d["flat"]), mb, be.ptr(ws2), wsb, be.stream)
+    be.lib.gather_rows(C.byref(net), C.byref(batch), be.ptr(d["idx0"]), mb, be.ptr(ws2), wsb, 0, be.stream)
+    for parity, (k, nxt) in enumerate((("idx0", be.ptr(d["idx1"])), ("idx1", None))):
+        g, l = be.full((P,), np.nan), be.zeros((4,))
+        be.lib.minibatch_grad_pre(C.byref(net), be.ptr(d["flat"]), C.byref(batch), be.ptr(d[k]), nxt, mb, be.ptr(stats), 1.0 / mb, C.byref(lc), be.ptr(g), be.ptr(l),
+                                  be.ptr(ws2), wsb, parity, be.stream)
+        got[k] = (be.host(g).copy(), be.host(l).copy())
+    for k in ("idx0", "idx1"):
+        assert not np.isnan(got[k][0]).any()
+        assert np.array_equal(ref[k][0], got[k][0]), k
+        assert np.array_equal(ref[k][1], got[k][1]), k
+    assert not np.array_equal(ref["idx0"][0], ref["idx1"][0])
