@@ -412,14 +412,14 @@ def main() -> None:
     # A fresh process stalls ONCE for 70-90 ms some 30-40 ms after its first GPU work (measured per update by
     # tools/ramp_probe.py, graph replay and eager launches alike: profiles/r02_g_ramp.txt); with W = 3 warm-up updates
     # (21 ms) that stall would land in the timed region every few runs.  It is absorbed here, before the W warm-up steps,
-    # by 0.3 s of unrelated device work (plumbing: a torch matmul loop); the W + K steps below are exactly the contract's.
+    # by 0.3 s of unrelated device work (plumbing: torch elementwise passes over 64 MB); the W + K steps below are exactly the contract's.
     pre_warm_s = float(os.environ.get("MPPO_BENCH_PREWARM_S", "0.3"))
     if pre_warm_s > 0:
-        xw = torch.randn(2048, 2048, device=f"cuda:{local_rank}")
+        xw = torch.zeros(16 << 20, device=f"cuda:{local_rank}")  # 64 MB, elementwise passes (no BLAS library is pulled in)
         t_pw = time.perf_counter()
         while time.perf_counter() - t_pw < pre_warm_s:
-            for _ in range(10):
-                xw = torch.tanh(xw @ xw)
+            for _ in range(20):
+                xw.mul_(0.999).add_(1.0)
             torch.cuda.synchronize()
         del xw
     for _ in range(args.warmup):

@@ -130,6 +130,8 @@ typedef struct mppo_net {
   int32_t O, OP, A, H;
   int32_t use_tanh;  /* actor activation; the critic is always ReLU (train.py:82) */
   int32_t bf16;      /* 0: exact f32 MFMA; 1: bf16-in/f32-accumulate MFMA for the hidden GEMMs */
+  int32_t num_layers; /* hidden layers of each MLP (`model.num_layers`, config.py:53, train.py:79,82): 1 .. 4; 0 means 2, the
+                         reference's default.  Two hidden layers take the fused kernels, other depths the layer-wise path. */
 } mppo_net_t;
 
 /* Length (floats) of the flat parameter / gradient / Adam-moment vectors: the model's parameters with every tensor starting on

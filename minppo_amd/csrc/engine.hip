@@ -175,7 +175,7 @@ static int32_t validate_cfg(const mppo_model* m, const mppo_engine_cfg_t* c) {
 static void fill_dims(mppo_engine* e) {
   const mppo_engine_cfg_t& c = e->cfg;
   e->N = c.num_envs; e->T = c.num_steps; e->B = e->N * e->T; e->M = c.num_minibatches; e->E = c.update_epochs; e->mb = e->B / e->M;
-  e->O = c.net.O; e->OP = c.net.OP; e->A = c.net.A; e->H = c.net.H; e->P = param_layout(e->O, e->A, e->H).total;
+  e->O = c.net.O; e->OP = c.net.OP; e->A = c.net.A; e->H = c.net.H; e->P = param_layout(c.net).total;
 }
 
 constexpr unsigned long long kStreamNoise = 0x4E4F495345ull << 24;  // "NOISE"

@@ -742,13 +742,13 @@ size_t fused_smem_bytes(int O, int A, int H) {
 }
 
 bool fused_supported(const mppo_net_t& net, const mppo_batch_t& b) {
-  return net.H % 32 == 0 && net.H >= 32 && net.H <= 256 && net.A <= 32 && b.obs_ld == net.OP && (net.OP % 4) == 0 &&
+  return net_layers(net) == 2 && net.H % 32 == 0 && net.H >= 32 && net.H <= 256 && net.A <= 32 && b.obs_ld == net.OP && (net.OP % 4) == 0 &&
          (reinterpret_cast<uintptr_t>(b.obs) & 15) == 0 && fused_smem_bytes(net.O, net.A, net.H) <= 160 * 1024 &&
-         (param_layout(net.O, net.A, net.H).c_w2 % 4) == 0;  // float4 rows of W2 in the backward product
+         (param_layout(net).c_w2 % 4) == 0;  // float4 rows of W2 in the backward product
 }
 
 bool fused_rollout_supported(const mppo_net_t& net, const float* obs, int obs_ld) {
-  return net.H % 32 == 0 && net.H >= 32 && net.H <= 256 && net.A <= 32 && obs_ld == net.OP && (net.OP % 4) == 0 && (reinterpret_cast<uintptr_t>(obs) & 15) == 0 &&
+  return net_layers(net) == 2 && net.H % 32 == 0 && net.H >= 32 && net.H <= 256 && net.A <= 32 && obs_ld == net.OP && (net.OP % 4) == 0 && (reinterpret_cast<uintptr_t>(obs) & 15) == 0 &&
          fused_smem_bytes(net.O, net.A, net.H) <= 160 * 1024;
 }
 
@@ -775,7 +775,7 @@ int32_t fused_forward_backward(const mppo_net_t& net, const float* params, const
                                float inv_count, const mppo_loss_cfg_t& lc, const GradBufs& g, hipStream_t stream, const XPre* pre) {
   FusedArgs a{};
   a.mb = mb; a.O = net.O; a.OP = net.OP; a.A = net.A; a.AP = g.f.AP; a.DP = g.f.AP + 4; a.H = net.H; a.use_tanh = net.use_tanh;
-  a.params = params; a.L = param_layout(net.O, net.A, net.H); a.b = batch; a.idx = idx; a.adv_stat = adv_stat; a.inv_count = inv_count; a.lc = lc;
+  a.params = params; a.L = param_layout(net); a.b = batch; a.idx = idx; a.adv_stat = adv_stat; a.inv_count = inv_count; a.lc = lc;
   a.h1[0] = g.f.h1a; a.h1[1] = g.f.h1c; a.h2[0] = g.f.h2a; a.h2[1] = g.f.h2c; a.dz2[0] = g.dz2a; a.dz2[1] = g.dz2c; a.dz1[0] = g.dz1a; a.dz1[1] = g.dz1c;
   a.dout = g.dout; a.xmb = g.xmb; a.partial = g.partial;
   const bool w2t = g.w2t_valid && g.w2t;
@@ -825,7 +825,7 @@ int32_t fused_policy_forward(const mppo_net_t& net, const float* params, int n, 
   a.frag[0] = frag; a.frag[1] = frag ? frag + frag_net_stride : nullptr;
   const bool use_frag = net.bf16 && frag;
   a.mb = n; a.O = net.O; a.OP = net.OP; a.A = net.A; a.AP = AP; a.DP = AP + 4; a.H = net.H; a.use_tanh = net.use_tanh;
-  a.params = params; a.L = param_layout(net.O, net.A, net.H);
+  a.params = params; a.L = param_layout(net);
   a.b.obs = obs; a.b.obs_ld = obs_ld;
   a.noise = noise; a.action = action; a.log_prob = log_prob; a.value = value; a.mean_out = mean_out;
   a.net0 = noise ? 0 : 1;

@@ -536,25 +536,27 @@ static GemmProb fwd_prob(const float* A, int lda, const int* gather, int M, int 
   return p;
 }
 
-// hidden layers of actor + critic on n rows of `obs` (optionally gathered): h1, h2 of both networks into the FwdBufs
+// hidden layers of actor + critic on n rows of `obs` (optionally gathered): the activations of every layer of both networks into the FwdBufs
 int32_t mlp_hidden_forward(const mppo_net_t& net, const float* params, int n, const float* obs, int obs_ld, const int* gather, const FwdBufs& fb,
                            float* xcopy, hipStream_t stream) {
-  const ParamLayout L = param_layout(net.O, net.A, net.H);
+  const ParamLayout L = param_layout(net);
   const int H = net.H, act_a = net.use_tanh ? ACT_TANH : ACT_RELU;
   GemmBatch gb{};
   gb.count = 2; gb.ksplit = 1;
-  gb.p[0] = fwd_prob(obs, obs_ld, gather, n, net.O, params + L.a_w1, H, params + L.a_b1, act_a, fb.h1a, H);
-  gb.p[1] = fwd_prob(obs, obs_ld, gather, n, net.O, params + L.c_w1, H, params + L.c_b1, ACT_RELU, fb.h1c, H);
+  gb.p[0] = fwd_prob(obs, obs_ld, gather, n, net.O, params + L.a_w[0], H, params + L.a_b[0], act_a, fb.ha[0], H);
+  gb.p[1] = fwd_prob(obs, obs_ld, gather, n, net.O, params + L.c_w[0], H, params + L.c_b[0], ACT_RELU, fb.hc[0], H);
   gb.p[0].a_copy = xcopy;  // (row stride obs_ld; only the actor problem writes it)
   MPPO_TRY(gemm_launch(gb, 0, 0, EPI_BIAS_ACT, net.bf16, stream));
-  gb.p[0] = fwd_prob(fb.h1a, H, nullptr, n, H, params + L.a_w2, H, params + L.a_b2, act_a, fb.h2a, H);
-  gb.p[1] = fwd_prob(fb.h1c, H, nullptr, n, H, params + L.c_w2, H, params + L.c_b2, ACT_RELU, fb.h2c, H);
-  MPPO_TRY(gemm_launch(gb, 0, 0, EPI_BIAS_ACT, net.bf16, stream));
+  for (int l = 1; l < L.nl; ++l) {  // `for feat in self.features[:-1]` (train.py:62-67)
+    gb.p[0] = fwd_prob(fb.ha[l - 1], H, nullptr, n, H, params + L.a_w[l], H, params + L.a_b[l], act_a, fb.ha[l], H);
+    gb.p[1] = fwd_prob(fb.hc[l - 1], H, nullptr, n, H, params + L.c_w[l], H, params + L.c_b[l], ACT_RELU, fb.hc[l], H);
+    MPPO_TRY(gemm_launch(gb, 0, 0, EPI_BIAS_ACT, net.bf16, stream));
+  }
   return MPPO_OK;
 }
 
 static HeadArgs head_args(const mppo_net_t& net, const float* params, int n, const FwdBufs& fb) {
-  const ParamLayout L = param_layout(net.O, net.A, net.H);
+  const ParamLayout L = param_layout(net);  // (h2 / w3 / b3: the last hidden layer and the output layer, whatever the depth)
   HeadArgs a{};
   a.n = n; a.A = net.A; a.AP = fb.AP; a.DP = fb.AP + 4; a.H = net.H; a.use_tanh = net.use_tanh;
   a.h2a = fb.h2a; a.h2c = fb.h2c; a.w3a = params + L.a_w3; a.b3a = params + L.a_b3; a.w3c = params + L.c_w3; a.b3c = params + L.c_b3;
@@ -582,7 +584,7 @@ int32_t policy_forward(const mppo_net_t& net, const float* params, int n, const 
 // dOut, xmb and the loss partials in the GradBufs; *nblk_out = number of partial rows written.
 int32_t minibatch_rowpass(const mppo_net_t& net, const float* params, const mppo_batch_t& batch, const int* idx, int mb, const float* adv_stat,
                           float inv_count, const mppo_loss_cfg_t& lc, const GradBufs& gbuf, int* nblk_out, bool* fused_out, hipStream_t stream, const XPre* pre = nullptr) {
-  const ParamLayout L = param_layout(net.O, net.A, net.H);
+  const ParamLayout L = param_layout(net);
   const int H = net.H;
   const int act_a = net.use_tanh ? ACT_TANH : ACT_RELU;
   MPPO_REQUIRE(batch.obs_ld == net.OP, "minibatch_grad: obs_ld (%d) must equal the padded observation width OP (%d)", batch.obs_ld, net.OP);
@@ -602,18 +604,19 @@ int32_t minibatch_rowpass(const mppo_net_t& net, const float* params, const mppo
   *nblk_out = cdiv(mb, 8);
   GemmBatch gb{};
   gb.count = 2; gb.ksplit = 1;
-  {  // dZ1 = (dZ2 . W2^T) * act'(h1)
+  for (int l = L.nl - 2; l >= 0; --l) {  // dZ_l = (dZ_{l+1} . W_{l+1}^T) * act'(h_l)
     GemmProb& a = gb.p[0]; a = GemmProb{};
-    a.A = gbuf.dz2a; a.lda = H; a.M = mb; a.K = H; a.B = params + L.a_w2; a.ldb = H; a.N = H; a.aux = gbuf.f.h1a; a.ldaux = H; a.act = act_a; a.C = gbuf.dz1a; a.ldc = H;
+    a.A = gbuf.dza[l + 1]; a.lda = H; a.M = mb; a.K = H; a.B = params + L.a_w[l + 1]; a.ldb = H; a.N = H; a.aux = gbuf.f.ha[l]; a.ldaux = H; a.act = act_a; a.C = gbuf.dza[l]; a.ldc = H;
     GemmProb& c = gb.p[1]; c = GemmProb{};
-    c.A = gbuf.dz2c; c.lda = H; c.M = mb; c.K = H; c.B = params + L.c_w2; c.ldb = H; c.N = H; c.aux = gbuf.f.h1c; c.ldaux = H; c.act = ACT_RELU; c.C = gbuf.dz1c; c.ldc = H;
+    c.A = gbuf.dzc[l + 1]; c.lda = H; c.M = mb; c.K = H; c.B = params + L.c_w[l + 1]; c.ldb = H; c.N = H; c.aux = gbuf.f.hc[l]; c.ldaux = H; c.act = ACT_RELU; c.C = gbuf.dzc[l]; c.ldc = H;
+    MPPO_TRY(gemm_launch(gb, 0, 1, EPI_DACT, net.bf16, stream));
   }
-  return gemm_launch(gb, 0, 1, EPI_DACT, net.bf16, stream);
+  return MPPO_OK;
 }
 
 int32_t minibatch_grad(const mppo_net_t& net, const float* params, const mppo_batch_t& batch, const int* idx, int mb, const float* adv_stat,
                        float inv_count, const mppo_loss_cfg_t& lc, float* grad, float* loss4, float* sq_partial, const GradBufs& gbuf, hipStream_t stream, const XPre* pre) {
-  const ParamLayout L = param_layout(net.O, net.A, net.H);
+  const ParamLayout L = param_layout(net);
   const int H = net.H, A = net.A, AP = gbuf.f.AP, DP = AP + 4, O = net.O;
   int nblk = 0;
   bool fused = false;
@@ -657,13 +660,22 @@ int32_t minibatch_grad(const mppo_net_t& net, const float* params, const mppo_ba
     p.bias_out = gbuf.slabs + off_b;
     return p;
   };
-  gb.p[0] = wprob(gbuf.f.h2a, H, nullptr, H, gbuf.dout, DP, A, L.a_w3, L.a_b3);
-  gb.p[1] = wprob(gbuf.f.h1a, H, nullptr, H, gbuf.dz2a, H, H, L.a_w2, L.a_b2);
-  gb.p[2] = wprob(gbuf.xmb, net.OP, nullptr, O, gbuf.dz1a, H, H, L.a_w1, L.a_b1);
-  gb.p[3] = wprob(gbuf.f.h2c, H, nullptr, H, gbuf.dout + AP, DP, 1, L.c_w3, L.c_b3);
-  gb.p[4] = wprob(gbuf.f.h1c, H, nullptr, H, gbuf.dz2c, H, H, L.c_w2, L.c_b2);
-  gb.p[5] = wprob(gbuf.xmb, net.OP, nullptr, O, gbuf.dz1c, H, H, L.c_w1, L.c_b1);
-  MPPO_TRY(gemm_launch(gb, 1, 0, EPI_STORE, net.bf16, stream));
+  // two problems per layer and network (output layers first), at most kGemmMaxProb per launch
+  GemmProb all[2 * (kMaxHidden + 1)];
+  int np = 0;
+  all[np++] = wprob(gbuf.f.h2a, H, nullptr, H, gbuf.dout, DP, A, L.a_w3, L.a_b3);
+  all[np++] = wprob(gbuf.f.h2c, H, nullptr, H, gbuf.dout + AP, DP, 1, L.c_w3, L.c_b3);
+  for (int l = L.nl - 1; l >= 1; --l) {
+    all[np++] = wprob(gbuf.f.ha[l - 1], H, nullptr, H, gbuf.dza[l], H, H, L.a_w[l], L.a_b[l]);
+    all[np++] = wprob(gbuf.f.hc[l - 1], H, nullptr, H, gbuf.dzc[l], H, H, L.c_w[l], L.c_b[l]);
+  }
+  all[np++] = wprob(gbuf.xmb, net.OP, nullptr, O, gbuf.dza[0], H, H, L.a_w[0], L.a_b[0]);
+  all[np++] = wprob(gbuf.xmb, net.OP, nullptr, O, gbuf.dzc[0], H, H, L.c_w[0], L.c_b[0]);
+  for (int at = 0; at < np; at += kGemmMaxProb) {
+    gb.count = np - at < kGemmMaxProb ? np - at : kGemmMaxProb;
+    for (int k = 0; k < gb.count; ++k) gb.p[k] = all[at + k];
+    MPPO_TRY(gemm_launch(gb, 1, 0, EPI_STORE, net.bf16, stream));
+  }
   }
   MPPO_REQUIRE((size_t)L.total <= (size_t)kNormBlocks * 256 * 4 * kReduceIter, "minibatch_grad: %d parameters exceed the reduce kernel's range", L.total);
   PadList pl{};
@@ -755,10 +767,11 @@ static int32_t check_net(const mppo_net_t* net) {
   MPPO_REQUIRE(net->O >= 1 && net->A >= 1 && net->A <= 32 && net->H >= 4 && (net->H % 4) == 0, "unsupported network geometry O=%d A=%d H=%d (need A<=32, H%%4==0)",
                net->O, net->A, net->H);
   MPPO_REQUIRE(net->OP >= net->O && (net->OP % 4) == 0, "OP=%d must be a multiple of 4 and >= O=%d", net->OP, net->O);
+  MPPO_REQUIRE(net->num_layers >= 0 && net->num_layers <= kMaxHidden, "num_layers=%d: 1 .. %d hidden layers (0 = 2)", net->num_layers, kMaxHidden);
   return MPPO_OK;
 }
 
-extern "C" size_t mppo_param_count(const mppo_net_t* net) { return net ? (size_t)param_layout(net->O, net->A, net->H).total : 0; }
+extern "C" size_t mppo_param_count(const mppo_net_t* net) { return net ? (size_t)param_layout(*net).total : 0; }
 
 extern "C" size_t mppo_policy_ws_bytes(const mppo_net_t* net, int32_t n) { return net ? fwd_bufs_floats(*net, n) * sizeof(float) : 0; }
 

@@ -15,11 +15,18 @@ namespace mppo {
 // a 16-byte boundary whatever the action dimension is (float4 rows in the fused row pass and the weight-gradient kernel, bf16
 // for odd A); the up to three padding words after a tensor hold zeros in all four vectors and stay zero (zero gradient -> zero
 // Adam update).  `total` counts the padding; the model has total - npad_words parameters (P of SURVEY 8).
+// `nl` hidden layers per MLP (`model.num_layers`, reference train.py:79,82): tensors in the order actor W_0, b_0, ..., W_nl, b_nl
+// (W_nl / b_nl: the output layer), log_std, critic W_0 ... b_nl.  The named fields are the two-hidden-layer view the fused kernels
+// use: w1 / b1 = layer 0, w2 / b2 = layer 1 (meaningful for nl >= 2), w3 / b3 = the OUTPUT layer whatever nl is.
+constexpr int kMaxHidden = 4;
+constexpr int kMaxPads = 4 * (kMaxHidden + 1) + 1;
+inline int net_layers(const mppo_net_t& n) { return n.num_layers > 0 ? n.num_layers : 2; }
 struct ParamLayout {
   int a_w1, a_b1, a_w2, a_b2, a_w3, a_b3, log_std, c_w1, c_b1, c_w2, c_b2, c_w3, c_b3, total;
-  int pad_off[13], pad_cnt[13], npad, npad_words;  // the padding runs (offset, length <= 3)
+  int nl, a_w[kMaxHidden + 1], a_b[kMaxHidden + 1], c_w[kMaxHidden + 1], c_b[kMaxHidden + 1];
+  int pad_off[kMaxPads], pad_cnt[kMaxPads], npad, npad_words;  // the padding runs (offset, length <= 3)
 };
-inline ParamLayout param_layout(int O, int A, int H) {
+inline ParamLayout param_layout(int O, int A, int H, int nl = 2) {
   ParamLayout L{};
   int o = 0;
   auto take = [&](int n) {
@@ -29,12 +36,16 @@ inline ParamLayout param_layout(int O, int A, int H) {
     if (pad) { L.pad_off[L.npad] = o; L.pad_cnt[L.npad] = pad; ++L.npad; L.npad_words += pad; o += pad; }
     return at;
   };
-  L.a_w1 = take(O * H); L.a_b1 = take(H); L.a_w2 = take(H * H); L.a_b2 = take(H); L.a_w3 = take(H * A); L.a_b3 = take(A);
+  L.nl = nl;
+  for (int l = 0; l <= nl; ++l) { L.a_w[l] = take((l == 0 ? O : H) * (l == nl ? A : H)); L.a_b[l] = take(l == nl ? A : H); }
   L.log_std = take(A);
-  L.c_w1 = take(O * H); L.c_b1 = take(H); L.c_w2 = take(H * H); L.c_b2 = take(H); L.c_w3 = take(H); L.c_b3 = take(1);
+  for (int l = 0; l <= nl; ++l) { L.c_w[l] = take((l == 0 ? O : H) * (l == nl ? 1 : H)); L.c_b[l] = take(l == nl ? 1 : H); }
   L.total = o;
+  L.a_w1 = L.a_w[0]; L.a_b1 = L.a_b[0]; L.a_w2 = L.a_w[nl >= 2 ? 1 : 0]; L.a_b2 = L.a_b[nl >= 2 ? 1 : 0]; L.a_w3 = L.a_w[nl]; L.a_b3 = L.a_b[nl];
+  L.c_w1 = L.c_w[0]; L.c_b1 = L.c_b[0]; L.c_w2 = L.c_w[nl >= 2 ? 1 : 0]; L.c_b2 = L.c_b[nl >= 2 ? 1 : 0]; L.c_w3 = L.c_w[nl]; L.c_b3 = L.c_b[nl];
   return L;
 }
+inline ParamLayout param_layout(const mppo_net_t& n) { return param_layout(n.O, n.A, n.H, net_layers(n)); }
 
 inline size_t pad4(size_t n) { return (n + 3) & ~(size_t)3; }
 
@@ -46,7 +57,8 @@ inline size_t pad16(size_t n) { return (n + 15) & ~(size_t)15; }
 
 // activations of one forward pass over n rows
 struct FwdBufs {
-  float *h1a, *h2a, *h1c, *h2c, *mean, *value;
+  float *h1a, *h2a, *h1c, *h2c, *mean, *value;  // h1 = hidden layer 0, h2 = the LAST hidden layer (two-hidden-layer view: ha[0], ha[1])
+  float *ha[kMaxHidden], *hc[kMaxHidden];        // hidden activations of actor / critic, layer by layer
   int AP;
   // optional (engine rollout of a bf16 network): the bf16 fragment-order weight copies of a gradient workspace whose shadow copies
   // are current (GradBufs::frag); nullptr = convert the float weights in the kernel
@@ -55,13 +67,17 @@ struct FwdBufs {
 };
 inline size_t fwd_bufs_floats(const mppo_net_t& net, int n) {
   const size_t AP = pad4((size_t)net.A);
-  return 4 * pad4((size_t)n * net.H) + pad4((size_t)n * AP) + pad4((size_t)n);
+  return 2 * (size_t)net_layers(net) * pad4((size_t)n * net.H) + pad4((size_t)n * AP) + pad4((size_t)n);
 }
 inline FwdBufs carve_fwd(const mppo_net_t& net, int n, float* ws) {
   FwdBufs f;
   f.AP = (int)pad4((size_t)net.A);
   const size_t nh = pad4((size_t)n * net.H);
-  f.h1a = ws; ws += nh; f.h2a = ws; ws += nh; f.h1c = ws; ws += nh; f.h2c = ws; ws += nh;
+  const int nl = net_layers(net);
+  for (int l = 0; l < kMaxHidden; ++l) f.ha[l] = f.hc[l] = nullptr;
+  for (int l = 0; l < nl; ++l) { f.ha[l] = ws; ws += nh; }
+  for (int l = 0; l < nl; ++l) { f.hc[l] = ws; ws += nh; }
+  f.h1a = f.ha[0]; f.h2a = f.ha[nl - 1]; f.h1c = f.hc[0]; f.h2c = f.hc[nl - 1];
   f.mean = ws; ws += pad4((size_t)n * f.AP);
   f.value = ws;
   return f;
@@ -76,7 +92,8 @@ inline int grad_ksplit() {  // K-slices of the weight-gradient product; MPPO_KSP
 // everything one minibatch gradient needs beyond the forward activations
 struct GradBufs {
   FwdBufs f;
-  float *dout, *dz2a, *dz2c, *dz1a, *dz1c, *partial, *slabs;  // dout [mb, AP+4]: d mean | d value
+  float *dout, *dz2a, *dz2c, *dz1a, *dz1c, *partial, *slabs;  // dout [mb, AP+4]: d mean | d value; dz1 = layer 0, dz2 = the LAST hidden layer
+  float *dza[kMaxHidden], *dzc[kMaxHidden];                    // d loss / d pre-activation of every hidden layer
   float* xmb;  // [mb, OP]: the minibatch observations, laid out contiguously by the first forward GEMM
   // Second observation buffer (k-quad layout like xmb in the fused path): the engine's row pass of optimizer step s gathers the
   // rows of step s + 1 on workgroups of its own launch (k_fused.hip, XPre) - they depend on the permutation only, not on the
@@ -100,9 +117,9 @@ struct GradBufs {
 inline size_t grad_bufs_floats(const mppo_net_t& net, int mb) {
   const size_t mbp = pad16((size_t)mb);  // the quad-layout operands are written in whole 16-row tiles
   const size_t AP = pad4((size_t)net.A), nh = pad4(mbp * net.H);
-  const size_t P = pad4((size_t)param_layout(net.O, net.A, net.H).total);
+  const size_t P = pad4((size_t)param_layout(net).total);
   const size_t nblk = (size_t)(mb + 7) / 8;  // head kernel: 8 rows per workgroup (fused kernel: 16)
-  return fwd_bufs_floats(net, (int)mbp) + pad4(mbp * (AP + 4)) + 4 * nh + pad4(nblk * (4 + AP)) + (size_t)kGradKSplitMax * P + 2 * pad4(mbp * net.OP) + 2 * pad4((size_t)net.H * net.H) +  // (xmb, xmb2)
+  return fwd_bufs_floats(net, (int)mbp) + pad4(mbp * (AP + 4)) + 2 * (size_t)net_layers(net) * nh + pad4(nblk * (4 + AP)) + (size_t)kGradKSplitMax * P + 2 * pad4(mbp * net.OP) + 2 * pad4((size_t)net.H * net.H) +  // (xmb, xmb2)
          (net.bf16 ? pad4((size_t)(((net.O + 31) & ~31) + 2 * net.H) * net.H) : 0);  // bf16 fragments: 2 networks x (KP + 2H) x H halves = that many floats
 }
 inline GradBufs carve_grad(const mppo_net_t& net, int mb, float* ws) {
@@ -112,18 +129,21 @@ inline GradBufs carve_grad(const mppo_net_t& net, int mb, float* ws) {
   ws += fwd_bufs_floats(net, (int)mbp);
   const size_t AP = (size_t)g.f.AP, nh = pad4(mbp * net.H);
   g.dout = ws; ws += pad4(mbp * (AP + 4));
-  g.dz2a = ws; ws += nh; g.dz2c = ws; ws += nh; g.dz1a = ws; ws += nh; g.dz1c = ws; ws += nh;
+  const int nl = net_layers(net);
+  for (int l = 0; l < kMaxHidden; ++l) g.dza[l] = g.dzc[l] = nullptr;
+  for (int l = nl - 1; l >= 0; --l) { g.dza[l] = ws; ws += nh; g.dzc[l] = ws; ws += nh; }
+  g.dz2a = g.dza[nl - 1]; g.dz2c = g.dzc[nl - 1]; g.dz1a = g.dza[0]; g.dz1c = g.dzc[0];
   const size_t nblk = (size_t)(mb + 7) / 8;
   g.partial = ws; ws += pad4(nblk * (4 + AP));
   g.slabs = ws;
-  g.xmb = ws + (size_t)kGradKSplitMax * pad4((size_t)param_layout(net.O, net.A, net.H).total);
+  g.xmb = ws + (size_t)kGradKSplitMax * pad4((size_t)param_layout(net).total);
   g.xmb2 = g.xmb + pad4(mbp * net.OP);
   g.w2t = g.xmb2 + pad4(mbp * net.OP);  // (the shadow copies stay the LAST region of the workspace)
   g.w2t_valid = false;
   g.frag = net.bf16 ? reinterpret_cast<unsigned short*>(g.w2t + 2 * pad4((size_t)net.H * net.H)) : nullptr;
   g.frag_net_stride = (size_t)(((net.O + 31) & ~31) + 2 * net.H) * net.H;
   g.ksplit = grad_ksplit();
-  g.slab_stride = pad4((size_t)param_layout(net.O, net.A, net.H).total);
+  g.slab_stride = pad4((size_t)param_layout(net).total);
   return g;
 }
 
@@ -156,7 +176,7 @@ int32_t clip_adam(size_t P, float* params, float* m, float* v, const float* grad
                   bool have_sumsq, hipStream_t stream, const ShadowRef* shadow = nullptr);
 int32_t shadow_refresh(const mppo_net_t& net, const float* params, const GradBufs& gbuf, hipStream_t stream);
 inline ShadowRef make_shadow_ref(const mppo_net_t& net, const GradBufs& g) {
-  const ParamLayout L = param_layout(net.O, net.A, net.H);
+  const ParamLayout L = param_layout(net);
   ShadowRef r{};
   r.w2t = g.w2t; r.a_w2 = L.a_w2; r.c_w2 = L.c_w2; r.H = net.H;
   r.frag = g.frag; r.frag_net_stride = g.frag_net_stride; r.a_w1 = L.a_w1; r.c_w1 = L.c_w1; r.O = net.O;
