@@ -45,7 +45,7 @@ extern "C" {
 #define MPPO_ENCCL (-5)    /* an RCCL call failed                                         */
 #define MPPO_ENOMEM (-6)   /* caller-provided workspace too small                         */
 
-#define MPPO_ABI_VERSION 1
+#define MPPO_ABI_VERSION 2
 
 const char* mppo_last_error(void);
 int32_t mppo_abi_version(void);

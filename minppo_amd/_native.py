@@ -54,7 +54,7 @@ class ForwardProbe(C.Structure):
 
 
 class Net(C.Structure):
-    _fields_ = [(n, c_i32) for n in ("O", "OP", "A", "H", "use_tanh", "bf16")]
+    _fields_ = [(n, c_i32) for n in ("O", "OP", "A", "H", "use_tanh", "bf16", "num_layers")]  # num_layers 0 = 2 (the reference default)
 
 
 class Batch(C.Structure):
@@ -200,8 +200,8 @@ def load() -> Lib:
         import torch  # noqa: F401
 
         _LIB = Lib(HIP_LIB_PATH)
-        if _LIB.abi_version() != 1:
-            raise ImportError(f"{HIP_LIB_PATH}: ABI version {_LIB.abi_version()} != 1")
+        if _LIB.abi_version() != 2:
+            raise ImportError(f"{HIP_LIB_PATH}: ABI version {_LIB.abi_version()} != 2")
     return _LIB
 
 

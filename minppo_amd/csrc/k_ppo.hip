@@ -221,7 +221,7 @@ static_assert(kSqSlots == 2 * kNormBlocks, "adam_kernel adds kSqSlots partials; 
 // `sq_partial[kNormBlocks]` (consumed by the clip when no all-reduce sits between this kernel and Adam).
 // Launched with exactly kNormBlocks workgroups of 256 threads; requires P <= kNormBlocks * 256 * 4 * kReduceIter.
 constexpr int kReduceIter = 4;
-struct PadList { int n, off[13], cnt[13]; };  // alignment words of the flat layout: no GEMM writes them into the slabs
+struct PadList { int n, off[kMaxPads], cnt[kMaxPads]; };  // alignment words of the flat layout: no GEMM writes them into the slabs
 __device__ __forceinline__ bool is_pad(const PadList& pl, size_t e) {
   bool r = false;
   for (int k = 0; k < pl.n; ++k) r = r || (e >= (size_t)pl.off[k] && e < (size_t)(pl.off[k] + pl.cnt[k]));

@@ -90,13 +90,22 @@ def save_model(params: dict, filename: str) -> None:
 # ---------------------------------------------------------------------------
 
 
-def param_slices(O: int, A: int, H: int):
+def _tensor_names(O: int, A: int, H: int, L: int = 2):
+    """(name, shape) of every tensor in flat order: `L` hidden layers per MLP (`model.num_layers`, reference train.py:79,82), layer
+    i + 1 of the actor is a_w{i+1} / a_b{i+1}, the output layer a_w{L+1} / a_b{L+1}; then log_std; then the critic alike."""
+    def mlp(pref, last):
+        for i in range(L + 1):
+            n_in, n_out = (O if i == 0 else H), (last if i == L else H)
+            yield f"{pref}_w{i + 1}", (n_in, n_out)
+            yield f"{pref}_b{i + 1}", (n_out,)
+    return [*mlp("a", A), ("log_std", (A,)), *mlp("c", 1)]
+
+
+def param_slices(O: int, A: int, H: int, L: int = 2):
     """name -> (offset, shape) of the flat parameter vector (include/minppo_hip.h): every tensor starts on a 16-byte boundary;
     the alignment words in between hold zeros.  Returns (slices, total length incl. alignment words)."""
     out, off = {}, 0
-    for name, shape in (("a_w1", (O, H)), ("a_b1", (H,)), ("a_w2", (H, H)), ("a_b2", (H,)), ("a_w3", (H, A)), ("a_b3", (A,)),
-                        ("log_std", (A,)), ("c_w1", (O, H)), ("c_b1", (H,)), ("c_w2", (H, H)), ("c_b2", (H,)), ("c_w3", (H, 1)),
-                        ("c_b3", (1,))):
+    for name, shape in _tensor_names(O, A, H, L):
         out[name] = (off, shape)
         off += int(np.prod(shape))
         off = (off + 3) & ~3
@@ -110,36 +119,36 @@ def _orthogonal(rng: np.random.Generator, n_in: int, n_out: int, scale: float) -
     return (scale * (q.T if n_in < n_out else q)).astype(np.float32)
 
 
-def init_flat_params(seed: int, O: int, A: int, H: int) -> np.ndarray:
+def init_flat_params(seed: int, O: int, A: int, H: int, L: int = 2) -> np.ndarray:
     """`ActorCritic.init` (`train.py:63,68,80,112`): orthogonal kernels (gain sqrt 2 hidden, 0.01 heads),
     zero biases, zero log_std.  The generator is NumPy's PCG64 seeded with `seed` (not JAX threefry)."""
     rng = np.random.default_rng(seed)
-    sl, total = param_slices(O, A, H)
+    sl, total = param_slices(O, A, H, L)
     flat = np.zeros(total, np.float32)
     g = math.sqrt(2.0)
-    for pref, last in (("a", A), ("c", 1)):
-        for name, (n_in, n_out, sc) in ((f"{pref}_w1", (O, H, g)), (f"{pref}_w2", (H, H, g)), (f"{pref}_w3", (H, last, 0.01))):
-            off, shape = sl[name]
-            flat[off:off + n_in * n_out] = _orthogonal(rng, n_in, n_out, sc).reshape(-1)
+    for pref in ("a", "c"):
+        for i in range(L + 1):
+            off, (n_in, n_out) = sl[f"{pref}_w{i + 1}"]
+            flat[off:off + n_in * n_out] = _orthogonal(rng, n_in, n_out, 0.01 if i == L else g).reshape(-1)
     return flat
 
 
-def flat_to_tree(flat: np.ndarray, O: int, A: int, H: int) -> dict:
+def flat_to_tree(flat: np.ndarray, O: int, A: int, H: int, L: int = 2) -> dict:
     """The nested dict the reference pickles (`train.py:314`; Flax naming)."""
-    sl, _ = param_slices(O, A, H)
+    sl, _ = param_slices(O, A, H, L)
 
     def get(name):
         off, shape = sl[name]
         return np.array(flat[off:off + int(np.prod(shape))].reshape(shape))
 
     def mlp(p):
-        return {f"Dense_{i}": {"kernel": get(f"{p}_w{i + 1}"), "bias": get(f"{p}_b{i + 1}")} for i in range(3)}
+        return {f"Dense_{i}": {"kernel": get(f"{p}_w{i + 1}"), "bias": get(f"{p}_b{i + 1}")} for i in range(L + 1)}
 
     return {"params": {"MLP_0": mlp("a"), "log_std": get("log_std"), "MLP_1": mlp("c")}}
 
 
-def tree_to_flat(tree: dict, O: int, A: int, H: int) -> np.ndarray:
-    sl, total = param_slices(O, A, H)
+def tree_to_flat(tree: dict, O: int, A: int, H: int, L: int = 2) -> np.ndarray:
+    sl, total = param_slices(O, A, H, L)
     flat = np.zeros(total, np.float32)
     t = tree["params"]
 
@@ -152,7 +161,7 @@ def tree_to_flat(tree: dict, O: int, A: int, H: int) -> np.ndarray:
 
     put("log_std", t["log_std"])
     for p, key in (("a", "MLP_0"), ("c", "MLP_1")):
-        for i in range(3):
+        for i in range(L + 1):
             put(f"{p}_w{i + 1}", t[key][f"Dense_{i}"]["kernel"])
             put(f"{p}_b{i + 1}", t[key][f"Dense_{i}"]["bias"])
     return flat
@@ -194,8 +203,9 @@ class Trainer:
         if rl.num_env_steps != tr.num_steps:
             # the reference would fail at the reshape (`train.py:260`; quirk C-1)
             raise ValueError(f"rl.num_env_steps ({rl.num_env_steps}) must equal training.num_steps ({tr.num_steps})")
-        if config.model.num_layers != 2:
-            raise ValueError("the MI355X engine lays out exactly two hidden layers (reference default, config.py:53)")
+        if not 1 <= config.model.num_layers <= 4:
+            raise ValueError(f"model.num_layers = {config.model.num_layers}: the MI355X engine lays out 1 to 4 hidden layers (reference default 2, config.py:53)")
+        self.L = int(config.model.num_layers)
         if tr.num_envs % world_size != 0:
             raise ValueError(f"training.num_envs ({tr.num_envs}) must be divisible by the number of ranks ({world_size})")
         self.num_envs_global = tr.num_envs
@@ -232,7 +242,7 @@ class Trainer:
         self.dims = nat.ModelDims()
         self.lib.model_get_dims(self._model, C.byref(self.dims))
         self.O, self.OP, self.A, self.H = self.dims.obs_dim, self.dims.obs_pad, self.dims.nu, config.model.hidden_size
-        self.net = nat.Net(self.O, self.OP, self.A, self.H, int(config.model.use_tanh), int(tr.mlp_dtype == "bf16"))
+        self.net = nat.Net(self.O, self.OP, self.A, self.H, int(config.model.use_tanh), int(tr.mlp_dtype == "bf16"), self.L)
         lr = tr.lr if tr.anneal_lr else config.opt.lr  # train.py:101 vs :123 (quirk C-3)
         self.ecfg = nat.EngineCfg(
             num_envs=self.N, num_steps=self.T, num_minibatches=self.M, update_epochs=self.E, n_frames=config.environment.n_frames,
@@ -256,7 +266,7 @@ class Trainer:
         self.lib.engine_create(self._model, C.byref(self.ecfg), nat.ptr(self.arena), self.arena_bytes, C.byref(self._engine))
         self.P = int(self.lib.param_count(C.byref(self.net)))
         self.updates_done = 0
-        self.set_params_flat(init_flat_params(self.seed, self.O, self.A, self.H))
+        self.set_params_flat(init_flat_params(self.seed, self.O, self.A, self.H, self.L))
 
     @staticmethod
     def _rng_impl(name: str) -> int:
@@ -375,7 +385,7 @@ class Trainer:
 
     @property
     def params(self) -> dict:
-        return flat_to_tree(self.params_flat(), self.O, self.A, self.H)
+        return flat_to_tree(self.params_flat(), self.O, self.A, self.H, self.L)
 
     # -- multi-GPU ---------------------------------------------------------------
     def init_comm(self) -> None:
@@ -572,8 +582,8 @@ def make_train(config: Config, **trainer_kwargs: Any) -> Callable[[Any], TrainOu
             tr.save_checkpoint(ckpt)
         params = tr.params
         count = int(tr._to_host(tr.region("count"))[0]) if n else 0
-        state = TrainState(step=count, params=params, opt_state={"mu": flat_to_tree(tr._to_host(tr.region("adam_m")), tr.O, tr.A, tr.H),
-                                                                   "nu": flat_to_tree(tr._to_host(tr.region("adam_v")), tr.O, tr.A, tr.H), "count": count})
+        state = TrainState(step=count, params=params, opt_state={"mu": flat_to_tree(tr._to_host(tr.region("adam_m")), tr.O, tr.A, tr.H, tr.L),
+                                                                   "nu": flat_to_tree(tr._to_host(tr.region("adam_v")), tr.O, tr.A, tr.H, tr.L), "count": count})
         last_obs = tr._to_host(tr.region("obs", (tr.T + 1, tr.N, tr.OP))[0, :, :tr.O])
         rs = RunnerState(train_state=state, env_state=tr._to_host(tr.region("state", (tr.N, tr.dims.rec_dim))), last_obs=last_obs, rng=rng)
         out = TrainOutput(runner_state=rs, metrics={k: np.asarray(v) for k, v in metrics.items()})

@@ -34,50 +34,65 @@ LOG_2PI = math.log(2.0 * math.pi)
 #   critic: W1[O,H] b1[H] W2[H,H] b2[H] W3[H,1] b3[1]
 # Tree layout = what the reference pickles (minppo/train.py:314; Flax naming,
 # SURVEY Appendix A): {"params": {"MLP_0": {"Dense_i": {kernel,bias}}, "log_std", "MLP_1": {...}}}
-# Only num_layers == 2 hidden layers is laid out flat (the reference default, config.py:53).
+# `model.num_layers` hidden layers per MLP (config.py:53, default 2): tensors a_w1 .. a_w{L+1}, the last one the output layer.
 
 
-def param_count(O: int, A: int, H: int) -> int:
-    """Number of parameters of the model (P = 512 O + 258 A + 132 353 at H = 256)."""
-    return 2 * (O * H + H + H * H + H) + H * A + A + A + H + 1
+def param_count(O: int, A: int, H: int, L: int = 2) -> int:
+    """Number of parameters of the model (P = 512 O + 258 A + 132 353 at H = 256, two hidden layers)."""
+    return 2 * (O * H + H + (L - 1) * (H * H + H)) + H * A + A + A + H + 1
 
 
-def _slices(O: int, A: int, H: int):
+def n_hidden(p: Dict[str, np.ndarray]) -> int:
+    """Hidden layers of a named parameter set (`model.num_layers`, train.py:79,82): a_w1 .. a_w{L} hidden, a_w{L+1} the output layer."""
+    return sum(1 for k in p if k.startswith("a_w")) - 1
+
+
+def _slices(O: int, A: int, H: int, L: int = 2):
+    def mlp(pref, last):
+        for i in range(L + 1):
+            n_in, n_out = (O if i == 0 else H), (last if i == L else H)
+            yield f"{pref}_w{i + 1}", (n_in, n_out)
+            yield f"{pref}_b{i + 1}", (n_out,)
     out = {}
     off = 0
-    for name, shape in (("a_w1", (O, H)), ("a_b1", (H,)), ("a_w2", (H, H)), ("a_b2", (H,)), ("a_w3", (H, A)), ("a_b3", (A,)), ("log_std", (A,)),
-                        ("c_w1", (O, H)), ("c_b1", (H,)), ("c_w2", (H, H)), ("c_b2", (H,)), ("c_w3", (H, 1)), ("c_b3", (1,))):
+    for name, shape in (*mlp("a", A), ("log_std", (A,)), *mlp("c", 1)):
         out[name] = (off, shape)
         off = (off + int(np.prod(shape)) + 3) & ~3
     return out, off
 
 
-def flat_size(O: int, A: int, H: int) -> int:
+def flat_size(O: int, A: int, H: int, L: int = 2) -> int:
     """Length of the FLAT vector the engine and this oracle exchange (include/minppo_hip.h): the parameters with every
     tensor starting on a 16-byte boundary; the alignment words hold zeros (zero gradient, zero update)."""
-    return _slices(O, A, H)[1]
+    return _slices(O, A, H, L)[1]
 
 
-def param_slices(O: int, A: int, H: int) -> Dict[str, Tuple[int, Tuple[int, ...]]]:
+def param_slices(O: int, A: int, H: int, L: int = 2) -> Dict[str, Tuple[int, Tuple[int, ...]]]:
     """name -> (offset, shape) in the flat vector."""
-    return _slices(O, A, H)[0]
+    return _slices(O, A, H, L)[0]
 
 
-def flat_to_named(flat: np.ndarray, O: int, A: int, H: int) -> Dict[str, np.ndarray]:
-    return {k: flat[o:o + int(np.prod(s))].reshape(s) for k, (o, s) in param_slices(O, A, H).items()}
+def flat_to_named(flat: np.ndarray, O: int, A: int, H: int, L: int = 0) -> Dict[str, np.ndarray]:
+    """L = 0: the depth whose flat size is len(flat) (1 .. 4 hidden layers)."""
+    if L == 0:
+        L = next(l for l in (2, 1, 3, 4) if flat_size(O, A, H, l) == flat.shape[0])
+    return {k: flat[o:o + int(np.prod(s))].reshape(s) for k, (o, s) in param_slices(O, A, H, L).items()}
 
 
 def named_to_flat(named: Dict[str, np.ndarray], O: int, A: int, H: int) -> np.ndarray:
     dt = named["a_w1"].dtype
-    flat = np.zeros(flat_size(O, A, H), dt)
-    for k, (o, s) in param_slices(O, A, H).items():
+    L = n_hidden(named)
+    flat = np.zeros(flat_size(O, A, H, L), dt)
+    for k, (o, s) in param_slices(O, A, H, L).items():
         flat[o:o + int(np.prod(s))] = np.asarray(named[k], dt).reshape(-1)
     return flat
 
 
 def named_to_tree(p: Dict[str, np.ndarray]) -> dict:
+    L = n_hidden(p)
+
     def mlp(pref):
-        return {f"Dense_{i}": {"kernel": p[f"{pref}_w{i + 1}"], "bias": p[f"{pref}_b{i + 1}"]} for i in range(3)}
+        return {f"Dense_{i}": {"kernel": p[f"{pref}_w{i + 1}"], "bias": p[f"{pref}_b{i + 1}"]} for i in range(L + 1)}
 
     return {"params": {"MLP_0": mlp("a"), "log_std": p["log_std"], "MLP_1": mlp("c")}}
 
@@ -86,7 +101,7 @@ def tree_to_named(tree: dict) -> Dict[str, np.ndarray]:
     t = tree["params"]
     out = {"log_std": np.asarray(t["log_std"])}
     for pref, key in (("a", "MLP_0"), ("c", "MLP_1")):
-        for i in range(3):
+        for i in range(len(t[key])):
             out[f"{pref}_w{i + 1}"] = np.asarray(t[key][f"Dense_{i}"]["kernel"])
             out[f"{pref}_b{i + 1}"] = np.asarray(t[key][f"Dense_{i}"]["bias"])
     return out
@@ -106,18 +121,18 @@ def orthogonal(rng: np.random.Generator, shape: Tuple[int, int], scale: float, d
     return (scale * q).astype(dtype)
 
 
-def init_params(seed: int, O: int, A: int, H: int, dtype=np.float64) -> Dict[str, np.ndarray]:
-    """Weights as `ActorCritic.init` makes them (train.py:63,68,80): hidden gain sqrt(2), heads 0.01, biases 0, log_std 0."""
+def init_params(seed: int, O: int, A: int, H: int, dtype=np.float64, L: int = 2) -> Dict[str, np.ndarray]:
+    """Weights as `ActorCritic.init` makes them (train.py:63,68,80): hidden gain sqrt(2), heads 0.01, biases 0, log_std 0;
+    `L` hidden layers per MLP (`MLP([hidden_size] * num_layers + [out])`, train.py:79,82)."""
     rng = np.random.default_rng(seed)
     g = math.sqrt(2.0)
     p = {}
     for pref, last in (("a", A), ("c", 1)):
-        p[f"{pref}_w1"] = orthogonal(rng, (O, H), g, dtype)
-        p[f"{pref}_b1"] = np.zeros(H, dtype)
-        p[f"{pref}_w2"] = orthogonal(rng, (H, H), g, dtype)
-        p[f"{pref}_b2"] = np.zeros(H, dtype)
-        p[f"{pref}_w3"] = orthogonal(rng, (H, last), 0.01, dtype)
-        p[f"{pref}_b3"] = np.zeros(last, dtype)
+        for i in range(L):
+            p[f"{pref}_w{i + 1}"] = orthogonal(rng, (O if i == 0 else H, H), g, dtype)
+            p[f"{pref}_b{i + 1}"] = np.zeros(H, dtype)
+        p[f"{pref}_w{L + 1}"] = orthogonal(rng, (H, last), 0.01, dtype)
+        p[f"{pref}_b{L + 1}"] = np.zeros(last, dtype)
     p["log_std"] = np.zeros(A, dtype)
     return p
 
@@ -150,14 +165,20 @@ def actor_critic_forward(p: Dict[str, np.ndarray], x: np.ndarray, use_tanh: bool
     Actor: tanh if use_tanh else relu (train.py:79); critic: always relu (train.py:82, quirk C-4).
     bf16: operand rounding of the two hidden-layer products (the engine keeps the small output-layer products in f32)."""
     act_a = np.tanh if use_tanh else (lambda z: np.maximum(z, 0))
-    h1a = act_a(_mm(x, p["a_w1"], bf16) + p["a_b1"])
-    h2a = act_a(_mm(h1a, p["a_w2"], bf16) + p["a_b2"])
-    mean = h2a @ p["a_w3"] + p["a_b3"]
-    h1c = np.maximum(_mm(x, p["c_w1"], bf16) + p["c_b1"], 0)
-    h2c = np.maximum(_mm(h1c, p["c_w2"], bf16) + p["c_b2"], 0)
-    value = (h2c @ p["c_w3"] + p["c_b3"])[..., 0]
+    L = n_hidden(p)
+    ha, hc = [], []  # `for feat in self.features[:-1]` (train.py:62-67), then the linear output layer (train.py:68)
+    h = x
+    for i in range(L):
+        h = act_a(_mm(h, p[f"a_w{i + 1}"], bf16) + p[f"a_b{i + 1}"])
+        ha.append(h)
+    mean = h @ p[f"a_w{L + 1}"] + p[f"a_b{L + 1}"]
+    h = x
+    for i in range(L):
+        h = np.maximum(_mm(h, p[f"c_w{i + 1}"], bf16) + p[f"c_b{i + 1}"], 0)
+        hc.append(h)
+    value = (h @ p[f"c_w{L + 1}"] + p[f"c_b{L + 1}"])[..., 0]
     if keep:
-        return mean, p["log_std"], value, (h1a, h2a, h1c, h2c)
+        return mean, p["log_std"], value, (ha, hc)
     return mean, p["log_std"], value
 
 
@@ -225,7 +246,8 @@ def loss_and_grad(p, obs, action, old_value, old_logp, gae, targets, clip_eps=0.
     (what the engine does with training.mlp_dtype = "bf16"); the output-layer products h2.W3 and dOut.W3^T stay exact."""
     dt = obs.dtype
     n = obs.shape[0]
-    mean, log_std, value, (h1a, h2a, h1c, h2c) = actor_critic_forward(p, obs, use_tanh, keep=True, bf16=bf16)
+    mean, log_std, value, (ha, hc) = actor_critic_forward(p, obs, use_tanh, keep=True, bf16=bf16)
+    L = len(ha)
     A = action.shape[-1]
     inv_std = np.exp(-log_std)
     z = (action - mean) * inv_std
@@ -264,28 +286,18 @@ def loss_and_grad(p, obs, action, old_value, old_logp, gae, targets, clip_eps=0.
     dlog_std = np.sum(dlogp[:, None] * (z * z - 1.0), axis=0) - dt.type(ent_coef)
 
     grads = {}
-    # actor
-    grads["a_w3"] = _mm(h2a.T, dmean, bf16)
-    grads["a_b3"] = dmean.sum(0)
-    dh2 = dmean @ p["a_w3"].T
-    dz2 = dh2 * ((1 - h2a * h2a) if use_tanh else (h2a > 0))
-    grads["a_w2"] = _mm(h1a.T, dz2, bf16)
-    grads["a_b2"] = dz2.sum(0)
-    dh1 = _mm(dz2, p["a_w2"].T, bf16)
-    dz1 = dh1 * ((1 - h1a * h1a) if use_tanh else (h1a > 0))
-    grads["a_w1"] = _mm(obs.T, dz1, bf16)
-    grads["a_b1"] = dz1.sum(0)
+    # output layers: exact products in the engine (module docstring); then dZ_l = (dZ_{l+1} . W_{l+1}^T) * act'(h_l) down the hidden layers
+    for pref, hs, dout, tanh_net in (("a", ha, dmean, use_tanh), ("c", hc, dv[:, None], False)):
+        grads[f"{pref}_w{L + 1}"] = _mm(hs[L - 1].T, dout, bf16)
+        grads[f"{pref}_b{L + 1}"] = dout.sum(0)
+        dz = (dout @ p[f"{pref}_w{L + 1}"].T) * ((1 - hs[L - 1] * hs[L - 1]) if tanh_net else (hs[L - 1] > 0))
+        for i in range(L - 1, -1, -1):  # hidden layer i (0-based): weights {pref}_w{i+1}
+            prev = hs[i - 1] if i > 0 else obs
+            grads[f"{pref}_w{i + 1}"] = _mm(prev.T, dz, bf16)
+            grads[f"{pref}_b{i + 1}"] = dz.sum(0)
+            if i > 0:
+                dz = _mm(dz, p[f"{pref}_w{i + 1}"].T, bf16) * ((1 - hs[i - 1] * hs[i - 1]) if tanh_net else (hs[i - 1] > 0))
     grads["log_std"] = dlog_std
-    # critic (relu)
-    dvo = dv[:, None]
-    grads["c_w3"] = _mm(h2c.T, dvo, bf16)
-    grads["c_b3"] = dvo.sum(0)
-    dz2c = (dvo @ p["c_w3"].T) * (h2c > 0)
-    grads["c_w2"] = _mm(h1c.T, dz2c, bf16)
-    grads["c_b2"] = dz2c.sum(0)
-    dz1c = _mm(dz2c, p["c_w2"].T, bf16) * (h1c > 0)
-    grads["c_w1"] = _mm(obs.T, dz1c, bf16)
-    grads["c_b1"] = dz1c.sum(0)
     grads = {k: v.astype(dt) for k, v in grads.items()}
     return LossOut(float(total), float(value_loss), float(actor_loss), float(entropy)), grads
 

@@ -17,12 +17,12 @@ from oracle import ppo_oracle as po
 f32 = np.float32
 
 
-def _net(O, A, H, tanh=1, bf16=0):
-    return nat.Net(O, (O + 3) // 4 * 4, A, H, tanh, bf16)
+def _net(O, A, H, tanh=1, bf16=0, layers=0):
+    return nat.Net(O, (O + 3) // 4 * 4, A, H, tanh, bf16, layers)
 
 
-def _params(rng, O, A, H, jitter=0.05):
-    named = po.init_params(3, O, A, H)
+def _params(rng, O, A, H, jitter=0.05, layers=2):
+    named = po.init_params(3, O, A, H, L=layers)
     for k in named:
         named[k] = named[k] + jitter * rng.standard_normal(named[k].shape)
     flat = po.named_to_flat(named, O, A, H).astype(f32)
@@ -529,3 +529,61 @@ def test_pregathered_rows_change_nothing(be, bf16, mb):
         assert np.array_equal(ref[k][0], got[k][0]), k
         assert np.array_equal(ref[k][1], got[k][1]), k
     assert not np.array_equal(ref["idx0"][0], ref["idx1"][0])
+
+
+@pytest.mark.parametrize("layers,O,A,H,B,mb,tanh,bf16", [(1, 37, 3, 64, 90, 70, 1, 0), (3, 37, 3, 64, 90, 70, 0, 0), (3, 60, 7, 96, 100, 80, 1, 0), (4, 24, 2, 48, 64, 40, 1, 0)])
+def test_other_depths_match_the_oracle(be, layers, O, A, H, B, mb, tanh, bf16):
+    """`model.num_layers` (reference config.py:53; `MLP([hidden_size] * num_layers + [out])`, train.py:56-68,79,82): depths other than
+    the default two run the layer-wise kernels (mppo_minibatch_path reports 0).  Policy outputs and the minibatch gradient against
+    the float64 oracle, same bounds as the two-layer tests."""
+    rng = np.random.default_rng(4)
+    net = _net(O, A, H, tanh, bf16, layers)
+    OP, AP = net.OP, (A + 3) // 4 * 4
+    flat, n64 = _params(rng, O, A, H, layers=layers)
+    assert po.n_hidden(n64) == layers and be.lib.param_count(C.byref(net)) == flat.size == po.flat_size(O, A, H, layers)
+    bobs = np.zeros((B, OP), f32); bobs[:, :O] = rng.standard_normal((B, O))
+    x64 = bobs[:, :O].astype(np.float64)
+    tol = 30.0 if bf16 else 1.0  # bf16 operand rounding in the hidden products: compared with the oracle's bf16 model at a wider bound
+    # ---- rollout form: sample + log-prob + value
+    noise = rng.standard_normal((B, A)).astype(f32)
+    d_flat, d_obs, d_noise = be.arr(flat), be.arr(bobs), be.arr(noise)
+    act, logp, value, mean = be.zeros((B, A)), be.zeros((B,)), be.zeros((B,)), be.zeros((B, AP))
+    wsb = be.lib.policy_ws_bytes(C.byref(net), B)
+    ws = be.full((wsb // 4 + 4,), np.nan)
+    be.lib.policy_forward(C.byref(net), be.ptr(d_flat), B, be.ptr(d_obs), OP, be.ptr(d_noise), be.ptr(act), be.ptr(logp), be.ptr(value), be.ptr(mean),
+                          be.ptr(ws), wsb, be.stream)
+    m64, ls64, v64 = po.actor_critic_forward(n64, x64, bool(tanh), bf16=bool(bf16))
+    a64 = po.mvn_sample(m64, ls64, noise.astype(np.float64))
+    np.testing.assert_allclose(be.host(mean)[:, :A], m64, atol=2e-5 * tol)
+    np.testing.assert_allclose(be.host(value), v64, atol=2e-5 * tol)
+    np.testing.assert_allclose(be.host(act), a64, atol=2e-5 * tol)
+    np.testing.assert_allclose(be.host(logp), po.mvn_log_prob(a64, m64, ls64), atol=5e-5 * tol)
+    # ---- minibatch gradient
+    bact = rng.standard_normal((B, A)).astype(f32)
+    bval = (v64 + 0.3 * rng.standard_normal(B)).astype(f32)
+    blp = (po.mvn_log_prob(bact.astype(np.float64), m64, ls64) + 0.3 * rng.standard_normal(B)).astype(f32)
+    badv = (rng.standard_normal(B) * 3 + 1).astype(f32)
+    btgt = rng.standard_normal(B).astype(f32)
+    idx = rng.permutation(B)[:mb].astype(np.int32)
+    d = {k: be.arr(v) for k, v in dict(act=bact, val=bval, lp=blp, adv=badv, tgt=btgt, idx=idx).items()}
+    g = badv[idx].astype(np.float64)
+    stats = be.arr(np.array([g.mean(), 1 / (g.std() + 1e-8)], f32))
+    batch = nat.Batch(be.ptr(d_obs), OP, be.ptr(d["act"]), A, be.ptr(d["val"]), be.ptr(d["lp"]), be.ptr(d["adv"]), be.ptr(d["tgt"]))
+    fused = C.c_int32(-1)
+    be.lib.minibatch_path(C.byref(net), C.byref(batch), C.byref(fused))
+    assert fused.value == 0
+    lc = nat.LossCfg(0.2, 0.5, 0.01)
+    grad, loss4 = be.full((flat.size,), np.nan), be.zeros((4,))
+    gwsb = be.lib.grad_ws_bytes(C.byref(net), mb)
+    gws = be.full((gwsb // 4 + 4,), np.nan)
+    be.lib.minibatch_grad(C.byref(net), be.ptr(d_flat), C.byref(batch), be.ptr(d["idx"]), mb, be.ptr(stats), 1.0 / mb, C.byref(lc), be.ptr(grad),
+                          be.ptr(loss4), be.ptr(gws), gwsb, be.stream)
+    lo, gr = po.loss_and_grad(n64, x64[idx], bact[idx].astype(np.float64), bval[idx].astype(np.float64), blp[idx].astype(np.float64), g,
+                              btgt[idx].astype(np.float64), 0.2, 0.5, 0.01, bool(tanh), adv_mean=float(be.host(stats)[0]),
+                              adv_std=1.0 / float(be.host(stats)[1]) - 1e-8, bf16=bool(bf16))
+    np.testing.assert_allclose(be.host(loss4), lo, rtol=1e-5 * tol, atol=1e-6 * tol)
+    got, g64 = be.host(grad), po.named_to_flat(gr, O, A, H)
+    assert not np.isnan(got).any() and got.size == g64.size
+    for k, (o, s) in po.param_slices(O, A, H, layers).items():
+        sz = int(np.prod(s))
+        np.testing.assert_allclose(got[o:o + sz], g64[o:o + sz], rtol=0, atol=1e-4 * tol * np.abs(g64[o:o + sz]).max() + 1e-7, err_msg=k)

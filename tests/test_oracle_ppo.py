@@ -30,12 +30,13 @@ def _torch_loss(named, b, clip_eps, vf_coef, ent_coef, use_tanh):
     tp = {k: torch.tensor(v, dtype=torch.float64, requires_grad=True) for k, v in named.items()}
     x = torch.tensor(b["obs"])
     act = torch.tanh if use_tanh else torch.relu
-    h = act(x @ tp["a_w1"] + tp["a_b1"])
-    h = act(h @ tp["a_w2"] + tp["a_b2"])
-    mean = h @ tp["a_w3"] + tp["a_b3"]
-    c = torch.relu(x @ tp["c_w1"] + tp["c_b1"])
-    c = torch.relu(c @ tp["c_w2"] + tp["c_b2"])
-    value = (c @ tp["c_w3"] + tp["c_b3"])[:, 0]
+    L = po.n_hidden(named)  # `MLP([hidden_size] * num_layers + [out])` (reference train.py:56-68,79,82)
+    h = c = x
+    for i in range(1, L + 1):
+        h = act(h @ tp[f"a_w{i}"] + tp[f"a_b{i}"])
+        c = torch.relu(c @ tp[f"c_w{i}"] + tp[f"c_b{i}"])
+    mean = h @ tp[f"a_w{L + 1}"] + tp[f"a_b{L + 1}"]
+    value = (c @ tp[f"c_w{L + 1}"] + tp[f"c_b{L + 1}"])[:, 0]
     dist = torch.distributions.Independent(torch.distributions.Normal(mean, torch.exp(tp["log_std"])), 1)
     logp = dist.log_prob(torch.tensor(b["action"]))
     ov, tg, g, olp = (torch.tensor(b[k]) for k in ("value", "tgt", "gae", "log_prob"))
@@ -51,10 +52,11 @@ def _torch_loss(named, b, clip_eps, vf_coef, ent_coef, use_tanh):
 
 
 @pytest.mark.parametrize("use_tanh", [True, False])
-@pytest.mark.parametrize("ent_coef", [0.0, 0.01])
-def test_loss_grad_matches_torch_autograd(use_tanh, ent_coef):
+@pytest.mark.parametrize("ent_coef,layers", [(0.0, 2), (0.01, 2), (0.01, 1), (0.0, 3), (0.01, 4)])
+def test_loss_grad_matches_torch_autograd(use_tanh, ent_coef, layers):
     rng = np.random.default_rng(3)
-    named = po.init_params(7, O, A, H)
+    named = po.init_params(7, O, A, H, L=layers)
+    assert po.n_hidden(named) == layers and po.named_to_flat(named, O, A, H).size == po.flat_size(O, A, H, layers) >= po.param_count(O, A, H, layers)
     for k in named:  # move off the init point so every path carries gradient
         named[k] = named[k] + 0.3 * rng.standard_normal(named[k].shape)
     b = _batch(rng, 200)

@@ -105,3 +105,19 @@ def test_make_train_checkpoints_and_resumes(tmp_path):
     rest = T.make_train(make_config(BASE, common + [f"training.resume_from={ck}"]), lib=be.lib, xp="numpy", use_graph=False)(1337)
     assert rest.runner_state.train_state.step == full.runner_state.train_state.step
     np.testing.assert_array_equal(T.tree_to_flat(rest.runner_state.train_state.params, 225, 10, 16), T.tree_to_flat(full.runner_state.train_state.params, 225, 10, 16))
+
+
+def test_param_tree_follows_num_layers():
+    """`MLP([hidden_size] * num_layers + [out])` (reference train.py:79,82): Dense_0 .. Dense_{num_layers} per network."""
+    for L in (1, 3):
+        flat = T.init_flat_params(7, 21, 4, 16, L)
+        tree = T.flat_to_tree(flat, 21, 4, 16, L)
+        assert sorted(tree["params"]["MLP_0"]) == [f"Dense_{i}" for i in range(L + 1)]
+        assert tree["params"]["MLP_0"]["Dense_0"]["kernel"].shape == (21, 16) and tree["params"]["MLP_0"][f"Dense_{L}"]["kernel"].shape == (16, 4)
+        assert tree["params"]["MLP_1"][f"Dense_{L}"]["kernel"].shape == (16, 1)
+        if L > 1:
+            assert tree["params"]["MLP_1"]["Dense_1"]["kernel"].shape == (16, 16)
+        np.testing.assert_array_equal(T.tree_to_flat(tree, 21, 4, 16, L), flat)
+        # same flat layout as the oracle's
+        from oracle import ppo_oracle as po
+        assert {k: v for k, v in T.param_slices(21, 4, 16, L)[0].items()} == po.param_slices(21, 4, 16, L) and flat.size == po.flat_size(21, 4, 16, L)
