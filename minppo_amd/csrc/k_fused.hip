@@ -254,9 +254,30 @@ __device__ __forceinline__ float row32_sum(float x) {
   return x;
 }
 
+// K-quad operands of the weight-gradient kernel.  Float network: one float4 per (quad of rows, column).  bf16 network (BF16 = true):
+// the weight-gradient MFMAs round their operands to bf16 anyway, so the row pass stores them ROUNDED - 8 bytes per quad, the same
+// index (quad_index) in units of bf16: half the bytes written here and read there, no conversion in the consumer, same results.
+template <bool BF16>
+__device__ __forceinline__ void store_quad(float* base, size_t qi, const float (&q)[4]) {
+  if (BF16) stream_store(base + (qi >> 1), bf16x4_bits(pack_bf16x4(q[0], q[1], q[2], q[3])));
+  else stream_store(base + qi, make_float4(q[0], q[1], q[2], q[3]));
+}
+// two adjacent columns (c0 even): 32 bytes as two float4, or 16 bytes of bf16
+template <bool BF16>
+__device__ __forceinline__ void store_quad2(float* base, size_t qi, const float (&q0)[4], const float (&q1)[4]) {
+  if (BF16) {
+    const float2 a = bf16x4_bits(pack_bf16x4(q0[0], q0[1], q0[2], q0[3])), b = bf16x4_bits(pack_bf16x4(q1[0], q1[1], q1[2], q1[3]));
+    stream_store(base + (qi >> 1), make_float4(a.x, a.y, b.x, b.y));
+  } else {
+    stream_store(base + qi, make_float4(q0[0], q0[1], q0[2], q0[3]));
+    stream_store(base + qi + 4, make_float4(q1[0], q1[1], q1[2], q1[3]));
+  }
+}
+
 // Gather role of a PRE launch: 16 rows of the NEXT minibatch (half = blockIdx.y picks two of the tile's four quads) from the
 // trajectory into the k-quad buffer; rows past the minibatch are written as zeros (the buffer is an operand of the weight-gradient
 // product and of the first layer).  Depends on the permutation only - it runs beside the workgroups that compute this step.
+template <bool BF16>
 __device__ __forceinline__ void gather_rows_tile(const FusedArgs& a, int tile, int half) {
   const int OP = a.OP, row0 = tile * FRT;
   for (int e = threadIdx.x; e < 2 * OP; e += blockDim.x) {
@@ -273,7 +294,7 @@ __device__ __forceinline__ void gather_rows_tile(const FusedArgs& a, int tile, i
       const float x = a.b.obs[ix[j] * a.b.obs_ld + c];
       v[j] = row0 + 4 * qd + j < a.mb ? x : 0.f;
     }
-    stream_store(a.xnext + quad_index(row0 + 4 * qd, c, OP), make_float4(v[0], v[1], v[2], v[3]));
+    store_quad<BF16>(a.xnext, quad_index(row0 + 4 * qd, c, OP), v);
   }
 }
 
@@ -288,7 +309,7 @@ __global__ void __launch_bounds__(512, ROLLOUT ? MPPO_ROLLOUT_WAVES : 2) fused_m
   constexpr int SD = 16 * OT;  // row stride of the per-row output-space tiles
   FT(0);
   if (PRE && (int)blockIdx.y >= a.gather_y0) {  // uniform per workgroup
-    gather_rows_tile(a, (int)blockIdx.x, (int)blockIdx.y - a.gather_y0);
+    gather_rows_tile<BF16>(a, (int)blockIdx.x, (int)blockIdx.y - a.gather_y0);
     return;
   }
   MPPO_DYN_SMEM(smem_raw);
@@ -378,10 +399,14 @@ __global__ void __launch_bounds__(512, ROLLOUT ? MPPO_ROLLOUT_WAVES : 2) fused_m
   // dependent batch: the observation chunks (needed first), then the per-row scalars of the loss (needed four phases later)
   float4 xq0 = make_float4(0.f, 0.f, 0.f, 0.f), xq1 = xq0;
   const int nxq = 4 * OP;  // PRE: float4 elements of the k-quad tile, element e = (quad e / OP, column e % OP); contiguous in memory
-  const float* xtile = PRE ? a.xpre + (size_t)(row0 >> 2) * OP * 4 : nullptr;
+  const float* xtile = PRE ? a.xpre + (size_t)(row0 >> 2) * OP * (BF16 ? 2 : 4) : nullptr;  // (bf16 network: 8-byte quads, see store_quad)
+  auto load_xq = [&](int e) {
+    if (BF16) { const float2 b = *reinterpret_cast<const float2*>(xtile + 2 * e); return bf16x4_unpack(b.x, b.y); }
+    return *reinterpret_cast<const float4*>(xtile + 4 * e);
+  };
   if (PRE) {  // depends on nothing but the kernel arguments
-    if (e0 < nxq) xq0 = *reinterpret_cast<const float4*>(xtile + 4 * e0);
-    if (e1 < nxq) xq1 = *reinterpret_cast<const float4*>(xtile + 4 * e1);
+    if (e0 < nxq) xq0 = load_xq(e0);
+    if (e1 < nxq) xq1 = load_xq(e1);
   } else {
     if (e0 < nx && xc0 < OP) xq0 = *reinterpret_cast<const float4*>(a.b.obs + xrow0 * a.b.obs_ld + xc0);
     if (e1 < nx && xc1 < OP) xq1 = *reinterpret_cast<const float4*>(a.b.obs + xrow1 * a.b.obs_ld + xc1);
@@ -427,7 +452,7 @@ __global__ void __launch_bounds__(512, ROLLOUT ? MPPO_ROLLOUT_WAVES : 2) fused_m
     };
     if (e0 < nxq) put(e0, xq0);
     if (e1 < nxq) put(e1, xq1);
-    for (int e = t + 2 * nthr; e < nxq; e += nthr) put(e, *reinterpret_cast<const float4*>(xtile + 4 * e));
+    for (int e = t + 2 * nthr; e < nxq; e += nthr) put(e, load_xq(e));
     for (int e = t; e < FRT * (KP - OP); e += nthr) xt[(e / (KP - OP)) * XS + OP + e % (KP - OP)] = 0.f;  // K padding of the first layer
   } else {
   if (e0 < nx) *reinterpret_cast<float4*>(xt + xr0 * XS + xc0) = xq0;
@@ -475,7 +500,7 @@ __global__ void __launch_bounds__(512, ROLLOUT ? MPPO_ROLLOUT_WAVES : 2) fused_m
         float v[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) v[j] = row0 + 4 * qd + j < a.mb ? xt[(4 * qd + j) * XS + c] : 0.f;
-        stream_store(a.xmb + quad_index(row0 + 4 * qd, c, OP), make_float4(v[0], v[1], v[2], v[3]));
+        store_quad<BF16>(a.xmb, quad_index(row0 + 4 * qd, c, OP), v);
       }
     }
     float* ht = layer == 0 ? h1t : h2t;
@@ -492,11 +517,7 @@ __global__ void __launch_bounds__(512, ROLLOUT ? MPPO_ROLLOUT_WAVES : 2) fused_m
       const bool on = row0 + rr < a.mb;  // rows past the minibatch are zero in the quad buffers (they are contracted over)
       q0[r] = on ? v0 : 0.f; q1[r] = on ? v1 : 0.f;
     }
-    if (!ROLLOUT && !(a.skip & 32)) {
-      float* dst = hg + quad_index(row0 + 4 * rq, c0, H);  // two consecutive float4: 32 bytes per lane
-      stream_store(dst, make_float4(q0[0], q0[1], q0[2], q0[3]));
-      stream_store(dst + 4, make_float4(q1[0], q1[1], q1[2], q1[3]));
-    }
+    if (!ROLLOUT && !(a.skip & 32)) store_quad2<BF16>(hg, quad_index(row0 + 4 * rq, c0, H), q0, q1);  // two adjacent columns: 32 bytes per lane (bf16: 16)
     __syncthreads();
     FT(5 + 2 * layer);
   }
@@ -624,7 +645,7 @@ __global__ void __launch_bounds__(512, ROLLOUT ? MPPO_ROLLOUT_WAVES : 2) fused_m
 #pragma unroll
         for (int ot = 0; ot < OT; ++ot) {
           const int o = cj + 16 * ot;
-          if (o < AP) *reinterpret_cast<float4*>(a.dout + quad_index(row0 + 4 * rq, o, a.DP)) = make_float4(dmq[ot][0], dmq[ot][1], dmq[ot][2], dmq[ot][3]);
+          if (o < AP) store_quad<BF16>(a.dout, quad_index(row0 + 4 * rq, o, a.DP), dmq[ot]);
         }
       }
     } else {
@@ -652,7 +673,10 @@ __global__ void __launch_bounds__(512, ROLLOUT ? MPPO_ROLLOUT_WAVES : 2) fused_m
         }
       }
       // d value in column AP of dOut (k-quad layout), columns AP+1 .. AP+3 zero
-      if (st && cj < 4) *reinterpret_cast<float4*>(a.dout + quad_index(row0 + 4 * rq, AP + cj, a.DP)) = cj == 0 ? make_float4(dvq[0], dvq[1], dvq[2], dvq[3]) : make_float4(0.f, 0.f, 0.f, 0.f);
+      if (st && cj < 4) {
+        const float zq[4] = {cj == 0 ? dvq[0] : 0.f, cj == 0 ? dvq[1] : 0.f, cj == 0 ? dvq[2] : 0.f, cj == 0 ? dvq[3] : 0.f};
+        store_quad<BF16>(a.dout, quad_index(row0 + 4 * rq, AP + cj, a.DP), zq);
+      }
     }
   }
   __syncthreads();
@@ -693,11 +717,7 @@ __global__ void __launch_bounds__(512, ROLLOUT ? MPPO_ROLLOUT_WAVES : 2) fused_m
       const bool on = row0 + rr < a.mb;
       q0[r] = on ? z0 : 0.f; q1[r] = on ? z1 : 0.f;
     }
-    if (!(a.skip & 32)) {
-      float* dst = a.dz2[net] + quad_index(row0 + 4 * rq, c0, H);
-      stream_store(dst, make_float4(q0[0], q0[1], q0[2], q0[3]));
-      stream_store(dst + 4, make_float4(q1[0], q1[1], q1[2], q1[3]));
-    }
+    if (!(a.skip & 32)) store_quad2<BF16>(a.dz2[net], quad_index(row0 + 4 * rq, c0, H), q0, q1);
   }
   __syncthreads();
   FT(12);
@@ -718,9 +738,7 @@ __global__ void __launch_bounds__(512, ROLLOUT ? MPPO_ROLLOUT_WAVES : 2) fused_m
       const float d1 = tanh_act ? acc1[r] * (1.f - gq.y * gq.y) : (gq.y > 0.f ? acc1[r] : 0.f);
       q0[r] = on ? d0 : 0.f; q1[r] = on ? d1 : 0.f;
     }
-    float* dst = a.dz1[net] + quad_index(row0 + 4 * rq, c0, H);
-    stream_store(dst, make_float4(q0[0], q0[1], q0[2], q0[3]));
-    stream_store(dst + 4, make_float4(q1[0], q1[1], q1[2], q1[3]));
+    store_quad2<BF16>(a.dz1[net], quad_index(row0 + 4 * rq, c0, H), q0, q1);
   }
   FT(14);
 }
@@ -812,7 +830,8 @@ int32_t fused_gather_rows(const mppo_net_t& net, const mppo_batch_t& batch, cons
   MPPO_REQUIRE(idx && dst && batch.obs, "fused_gather_rows: null argument");
   FusedArgs a{};
   a.mb = mb; a.O = net.O; a.OP = net.OP; a.H = net.H; a.b = batch; a.idx_next = idx; a.xnext = dst; a.gather_y0 = 0;
-  hipLaunchKernelGGL((fused_mlp_kernel<false, false, 1, true, true>), dim3(cdiv(mb, FRT), 2), dim3(256), 0, stream, a);
+  if (net.bf16) hipLaunchKernelGGL((fused_mlp_kernel<true, false, 1, true, true>), dim3(cdiv(mb, FRT), 2), dim3(256), 0, stream, a);  // (bf16 quads)
+  else hipLaunchKernelGGL((fused_mlp_kernel<false, false, 1, true, true>), dim3(cdiv(mb, FRT), 2), dim3(256), 0, stream, a);
   MPPO_CHECK_LAUNCH("fused_mlp_kernel<gather>");
   return MPPO_OK;
 }

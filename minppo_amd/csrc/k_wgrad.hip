@@ -55,11 +55,18 @@ __global__ void __launch_bounds__(WTHREADS) wgrad_kernel(WgradArgs a) {
   const int q0 = g * a.qwave;                        // first quad of this wave
   const int nst = a.qwave / WSTAGE;
   // operand views: all quads of the minibatch; a lane offset past the extent (column outside the operand) reads 0
-  const BufView bufA = make_buf(p.A, (unsigned)a.Kq * (unsigned)p.lda * 16u);
-  const BufView bufB = make_buf(p.B, (unsigned)a.Kq * (unsigned)p.ldb * 16u);
+  // bytes per k-quad: a float network's operands are float4, a bf16 network's row pass stored them rounded (k_fused.hip store_quad):
+  // 8 bytes that go into the bf16 MFMA as they are
+  constexpr int QB = BF16 ? 8 : 16;
+  const BufView bufA = make_buf(p.A, (unsigned)a.Kq * (unsigned)p.lda * (unsigned)QB);
+  const BufView bufB = make_buf(p.B, (unsigned)a.Kq * (unsigned)p.ldb * (unsigned)QB);
   constexpr int kOutOfRange = 0x40000000;
-  const int offa = m0 + i < p.acols ? (h * p.lda + m0 + i) * 16 : kOutOfRange;
-  const int offb = n0 + i < p.bcols ? (h * p.ldb + n0 + i) * 16 : kOutOfRange;
+  const int offa = m0 + i < p.acols ? (h * p.lda + m0 + i) * QB : kOutOfRange;
+  const int offb = n0 + i < p.bcols ? (h * p.ldb + n0 + i) * QB : kOutOfRange;
+  auto ldq = [&](const BufView& b, int lane_off, int uni_off) {  // one quad; bf16: raw bits in .x, .y
+    if (BF16) { const float2 r = buf_load_f2(b, lane_off, uni_off); return make_float4(r.x, r.y, 0.f, 0.f); }
+    return buf_load_f4(b, lane_off, uni_off);
+  };
   // tile 0 also owns the log_std gradient and the loss scalars: first level of the column sums of the row pass's partials
   // [nblk][4+AP], requested NOW so that their latency hides under the K loop (at the end they were the launch's long pole)
   __shared__ float s_part[16][40];
@@ -90,21 +97,23 @@ __global__ void __launch_bounds__(WTHREADS) wgrad_kernel(WgradArgs a) {
 #pragma unroll
     for (int j = 0; j < kThinPerThread; ++j) {
       const int e = t + WTHREADS * j, rr = e / a.Kq, qd = e - rr * a.Kq;
-      sxr[j] = buf_load_f4(bufA, e < a.Kq * p.thin_rows ? (qd * p.lda + p.thin_row0 + rr) * 16 : kOutOfRange, 0);  // (per-lane offsets: the scalar one must be wave-uniform)
+      sxr[j] = ldq(bufA, e < a.Kq * p.thin_rows ? (qd * p.lda + p.thin_row0 + rr) * QB : kOutOfRange, 0);  // (per-lane offsets: the scalar one must be wave-uniform)
+      if (BF16) sxr[j] = bf16x4_unpack(sxr[j].x, sxr[j].y);
     }
   }
   auto load = [&](int slot, int s) {  // stage s: quads q0 + 8 s + 2 c + h, c = 0..3
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
       const int qu = q0 + WSTAGE * s + 2 * c;  // uniform
-      ra[slot][c] = buf_load_f4(bufA, offa, qu * p.lda * 16);
-      rb[slot][c] = buf_load_f4(bufB, offb, qu * p.ldb * 16);
+      ra[slot][c] = ldq(bufA, offa, qu * p.lda * QB);
+      rb[slot][c] = ldq(bufB, offb, qu * p.ldb * QB);
     }
   };
   auto mm = [&](int slot, int s) {
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
-      const float4 x = ra[slot][c], y = rb[slot][c];
+      const float4 x = ra[slot][c], yraw = rb[slot][c];
+      const float4 y = BF16 ? bf16x4_unpack(yraw.x, yraw.y) : yraw;  // (values: bias sum and thin band; the bf16 MFMA takes the raw bits)
       colsum += (y.x + y.y) + (y.z + y.w);
       if (do_thin) {
         const int qd = q0 + WSTAGE * s + 2 * c + h;  // this lane's quad (past the last quad: y is 0, the index is clamped)
@@ -114,7 +123,7 @@ __global__ void __launch_bounds__(WTHREADS) wgrad_kernel(WgradArgs a) {
       }
       if (BF16) {
         // v_mfma_f32_32x32x8_bf16: lane (i, h) supplies k = 4h + c: exactly its quad
-        mfma_bf16_32x32x8(pack_bf16x4(x.x, x.y, x.z, x.w), pack_bf16x4(y.x, y.y, y.z, y.w), acc);
+        mfma_bf16_32x32x8(bf16x4_from_bits(x.x, x.y), bf16x4_from_bits(yraw.x, yraw.y), acc);
       } else {
         // v_mfma_f32_32x32x2_f32: lane (i, h) supplies one k per MFMA: the four k's of its quad, one after the other
         mfma_f32_32x32x2(x.x, y.x, acc); mfma_f32_32x32x2(x.y, y.y, acc);

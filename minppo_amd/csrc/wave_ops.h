@@ -44,6 +44,16 @@ __device__ __forceinline__ bf16x4 bf16x4_from_bits(float lo, float hi) {
   typedef float f32x2_bits __attribute__((ext_vector_type(2)));
   return __builtin_bit_cast(bf16x4, f32x2_bits{lo, hi});
 }
+// the other way round: four bf16 values as the raw bits of two floats (an 8-byte store into a bf16 array), and their values as floats
+__device__ __forceinline__ float2 bf16x4_bits(bf16x4 v) {
+  typedef float f32x2_bits __attribute__((ext_vector_type(2)));
+  const f32x2_bits b = __builtin_bit_cast(f32x2_bits, v);
+  return make_float2(b[0], b[1]);
+}
+__device__ __forceinline__ float4 bf16x4_unpack(float lo, float hi) {
+  const unsigned a = __float_as_uint(lo), b = __float_as_uint(hi);
+  return make_float4(__uint_as_float(a << 16), __uint_as_float(a & 0xFFFF0000u), __uint_as_float(b << 16), __uint_as_float(b & 0xFFFF0000u));
+}
 __device__ __forceinline__ void mfma_bf16_16x16x16(bf16x4 a, bf16x4 b, f32x4& acc) {
   acc = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a, b, acc, 0, 0, 0);
 }

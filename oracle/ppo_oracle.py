@@ -286,15 +286,18 @@ def loss_and_grad(p, obs, action, old_value, old_logp, gae, targets, clip_eps=0.
     dlog_std = np.sum(dlogp[:, None] * (z * z - 1.0), axis=0) - dt.type(ent_coef)
 
     grads = {}
+    # bf16 model: the engine's row pass hands dZ (and the activations) to the weight-gradient launch ROUNDED to bf16 - they are MFMA
+    # operands there - and the bias gradients are column sums of those same stored values
+    bsum = (lambda d: round_bf16(d).sum(0)) if bf16 else (lambda d: d.sum(0))
     # output layers: exact products in the engine (module docstring); then dZ_l = (dZ_{l+1} . W_{l+1}^T) * act'(h_l) down the hidden layers
     for pref, hs, dout, tanh_net in (("a", ha, dmean, use_tanh), ("c", hc, dv[:, None], False)):
         grads[f"{pref}_w{L + 1}"] = _mm(hs[L - 1].T, dout, bf16)
-        grads[f"{pref}_b{L + 1}"] = dout.sum(0)
+        grads[f"{pref}_b{L + 1}"] = bsum(dout)
         dz = (dout @ p[f"{pref}_w{L + 1}"].T) * ((1 - hs[L - 1] * hs[L - 1]) if tanh_net else (hs[L - 1] > 0))
         for i in range(L - 1, -1, -1):  # hidden layer i (0-based): weights {pref}_w{i+1}
             prev = hs[i - 1] if i > 0 else obs
             grads[f"{pref}_w{i + 1}"] = _mm(prev.T, dz, bf16)
-            grads[f"{pref}_b{i + 1}"] = dz.sum(0)
+            grads[f"{pref}_b{i + 1}"] = bsum(dz)
             if i > 0:
                 dz = _mm(dz, p[f"{pref}_w{i + 1}"].T, bf16) * ((1 - hs[i - 1] * hs[i - 1]) if tanh_net else (hs[i - 1] > 0))
     grads["log_std"] = dlog_std

@@ -61,6 +61,14 @@ inline bf16x4 bf16x4_from_bits(float lo, float hi) {
   bf16x4 r; const float t[2] = {lo, hi}; __builtin_memcpy(&r, t, 8);
   return r;
 }
+inline float2 bf16x4_bits(bf16x4 v) {
+  float t[2]; __builtin_memcpy(t, &v, 8);
+  return make_float2(t[0], t[1]);
+}
+inline float4 bf16x4_unpack(float lo, float hi) {
+  const bf16x4 v = bf16x4_from_bits(lo, hi);
+  return make_float4(emu_bf16_to_f32(v[0]), emu_bf16_to_f32(v[1]), emu_bf16_to_f32(v[2]), emu_bf16_to_f32(v[3]));
+}
 inline void mfma_bf16_16x16x16(bf16x4 a, bf16x4 b, f32x4& acc) {
   const int t = emu::tid(), lane = t & 63, wave = t >> 6;
   float* A = reinterpret_cast<float*>(emu::g_xchg) + wave * 512;  // [k][i]
