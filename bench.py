@@ -361,6 +361,12 @@ def supervise_rank(args: argparse.Namespace) -> int:
         if (d / "retry_port").exists():
             port = (d / "retry_port").read_text().strip()
             ok, out = run_attempt(1, {"MPPO_GRAPH_COMM": "0", "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": port, "TORCHELASTIC_USE_AGENT_STORE": "False"})
+    # leave nothing behind: every rank has read every verdict by now (run_attempt returns after all status files exist or the wait
+    # expired); rank 0 removes the directory a moment later, whatever is still in it
+    if rank == 0:
+        import shutil
+        time.sleep(1.0)
+        shutil.rmtree(d, ignore_errors=True)
     if not ok:
         sys.stderr.write(f"bench.py: rank {rank}: the run failed or timed out\n")
         return 1
