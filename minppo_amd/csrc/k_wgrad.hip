@@ -46,11 +46,10 @@ __global__ void __launch_bounds__(WTHREADS) wgrad_kernel(WgradArgs a) {
   __shared__ float cred[WWAVES][WTILE];
   __shared__ float s_red[WWAVES];
   const int t = threadIdx.x, lane = t & 63, g = wave_uniform(t >> 6), i = lane & 31, h = lane >> 5;
-  const int tile = a.order[blockIdx.x];
-  int pi = 0;
-  while (pi + 1 < a.count && tile >= a.p[pi + 1].tile0) ++pi;
+  const unsigned desc = a.order[blockIdx.x];
+  const int pi = desc & 15, mt = (desc >> 4) & 255, nt = (desc >> 12) & 255;
+  const int tile = (desc >> 20) & 1 ? 0 : 1;  // only "is this tile 0" matters below (it owns the log_std gradient and the loss scalars)
   const WgradProb p = a.p[pi];
-  const int lt = tile - p.tile0, mt = lt / p.tiles_n, nt = lt - mt * p.tiles_n;
   const int m0 = mt * WTILE, n0 = nt * WTILE;
   const int q0 = g * a.qwave;                        // first quad of this wave
   const int nst = a.qwave / WSTAGE;
@@ -230,6 +229,7 @@ bool wgrad_supported(const WgradArgs& a) {
   if (a.count < 1 || a.count > kWgradMaxProb || a.ntiles < 1 || a.ntiles > kSqSlots || a.AP + 4 > 40) return false;
   for (int k = 0; k < a.count; ++k) {
     const WgradProb& p = a.p[k];
+    if (p.tiles_m > 256 || p.tiles_n > 256) return false;  // (8 bits each in WgradArgs::order)
     if ((reinterpret_cast<uintptr_t>(p.A) & 15) || (reinterpret_cast<uintptr_t>(p.B) & 15) || p.acols < p.M || p.bcols < p.N || p.acols > p.lda || p.bcols > p.ldb)
       return false;
   }
@@ -289,7 +289,13 @@ int32_t wgrad_plan(WgradArgs& a, int mb) {
     size_t f = 0;
     for (int x = 0; x < 8; ++x)
       while (pos[x] < queue[x].size()) assigned[free_wg[f++]] = queue[x][pos[x]++];
-    for (int w = 0; w < tiles; ++w) a.order[w] = (unsigned short)assigned[w];
+    for (int w = 0; w < tiles; ++w) {
+      const int tile = assigned[w];
+      int pi = 0;
+      while (pi + 1 < a.count && tile >= a.p[pi + 1].tile0) ++pi;
+      const int lt = tile - a.p[pi].tile0, mt = lt / a.p[pi].tiles_n, nt = lt - mt * a.p[pi].tiles_n;
+      a.order[w] = (unsigned)pi | ((unsigned)mt << 4) | ((unsigned)nt << 12) | (tile == 0 ? 1u << 20 : 0u);
+    }
   }
   a.Kq = (int)(pad16((size_t)mb) / 4);                      // the row pass writes whole 16-row tiles (zeros past mb)
   a.qwave = cdiv(cdiv(a.Kq, WWAVES), WSTAGE) * WSTAGE;      // quads per wave, whole stages

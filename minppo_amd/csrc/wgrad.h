@@ -35,7 +35,10 @@ struct WgradArgs {
   float ent_coef, vf_coef, ent_weight;
   float* loss4;
   int npad, pad_off[13], pad_cnt[13];  // alignment words of the flat layout (ppo_layout.h): written as zeros
-  unsigned short order[kSqSlots];  // workgroup id -> tile (wgrad_plan): tiles that share operand bands sit on the same XCD
+  // workgroup id -> its tile, resolved on the host (wgrad_plan): problem | row band << 4 | column band << 12 | (tile 0) << 20.  Tiles that
+  // share operand bands sit on the same XCD.  (One scalar load; a tile NUMBER cost the kernel a search through p[].tile0 first:
+  // up to `count` dependent scalar loads ahead of the first operand request.)
+  unsigned order[kSqSlots];
   int dbg;  // timing experiments only (MPPO_WGRAD_DBG bit mask): 4 launch twice (warm operands), 8 big problems only
 };
 
