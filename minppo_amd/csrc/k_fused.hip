@@ -62,13 +62,12 @@ struct FusedArgs {
   float *action, *log_prob, *value, *mean_out;
   int net0;  // first network of the launch: 0 = actor + critic, 1 = critic only (bootstrap value, train.py:182)
   // engine minibatch loop (PRE = true instantiations, ppo_layout.h XPre): this step's rows, already gathered, in k-quad layout; the
-  // workgroups with blockIdx.y >= gather_y0 gather the NEXT step's rows (idx_next) into xnext while the others compute.  They are
+  // workgroups with blockIdx.y >= 2 gather the NEXT step's rows (idx_next) into xnext while the others compute.  They are
   // the LAST rows of the grid: workgroups are dispatched in linear order, so the gather fills the CUs the row tiles leave idle
   // (96 of 256 at the headline shape) and never delays a row tile (it did, by 2 us, as columns of the grid at 8192 environments)
   const float* xpre;
   float* xnext;
   const int* idx_next;
-  int gather_y0;
   int skip;  // timing experiments only (MPPO_FUSED_SKIP bit mask): 1 L1, 2 L2, 4 heads, 8 dZ2, 16 dZ1, 32 activation stores, 64 gather
 };
 
@@ -303,13 +302,16 @@ __device__ __forceinline__ void gather_rows_tile(const FusedArgs& a, int tile, i
 // OT = 16-wide output tiles of the head GEMM: 1 for A <= 16, 2 for A <= 32 (BASELINE configs[4]: 20 actuators)
 // W2T: the backward product reads the transposed shadow copy of W2 (GradBufs::w2t) through the forward-style pipe: 23.9 -> 21.9 us
 // PRE: engine minibatch loop - the x tile comes from the pre-gathered k-quad buffer (one trip to memory instead of index -> row), the
-// gathered rows are not written again, and the grid rows from `gather_y0` on gather the next step's rows
+// gathered rows are not written again, and grid rows 2 and 3 gather the next step's rows
 template <bool BF16, bool ROLLOUT, int OT, bool W2T = false, bool PRE = false>
 __global__ void __launch_bounds__(512, ROLLOUT ? MPPO_ROLLOUT_WAVES : 2) fused_mlp_kernel(FusedArgs a) {
   constexpr int SD = 16 * OT;  // row stride of the per-row output-space tiles
   FT(0);
-  if (PRE && (int)blockIdx.y >= a.gather_y0) {  // uniform per workgroup
-    gather_rows_tile<BF16>(a, (int)blockIdx.x, (int)blockIdx.y - a.gather_y0);
+  // The role is decided from the launch geometry alone (grid rows 0, 1: the two networks; rows 2, 3: gather), not from a kernel
+  // argument: a scalar load ahead of this branch would put one more (cold) trip to the argument segment in front of every row tile.
+  // <ROLLOUT, PRE> together name the gather-ONLY launch (fused_gather_rows): every workgroup gathers.
+  if (PRE && (ROLLOUT || blockIdx.y >= 2)) {  // uniform per workgroup
+    gather_rows_tile<BF16>(a, (int)blockIdx.x, ROLLOUT ? (int)blockIdx.y : (int)blockIdx.y - 2);
     return;
   }
   MPPO_DYN_SMEM(smem_raw);
@@ -339,6 +341,19 @@ __global__ void __launch_bounds__(512, ROLLOUT ? MPPO_ROLLOUT_WAVES : 2) fused_m
 
   const int n0 = 32 * wave;
   const int cj = lane & 15, rq = lane >> 4;
+  // PRE: this step's observation tile is a contiguous block of the pre-gathered buffer: it depends on nothing but the kernel arguments and
+  // is the longest chain in front of the first MFMA (memory -> registers -> LDS -> barrier), so it is requested before anything else
+  float4 xq0 = make_float4(0.f, 0.f, 0.f, 0.f), xq1 = xq0;
+  const int nxq = 4 * OP;  // float4 elements of the k-quad tile, element e = (quad e / OP, column e % OP); contiguous in memory
+  const float* xtile = PRE ? a.xpre + (size_t)(row0 >> 2) * OP * (BF16 ? 2 : 4) : nullptr;  // (bf16 network: 8-byte quads, see store_quad)
+  auto load_xq = [&](int e) {
+    if (BF16) { const float2 b = *reinterpret_cast<const float2*>(xtile + 2 * e); return bf16x4_unpack(b.x, b.y); }
+    return *reinterpret_cast<const float4*>(xtile + 4 * e);
+  };
+  if (PRE) {
+    if (t < nxq) xq0 = load_xq(t);
+    if (t + nthr < nxq) xq1 = load_xq(t + nthr);
+  }
   // ---- everything that depends on nothing computed here is requested now and consumed phases later: the first two
   // weight stages of layer 1, the biases, and the per-row scalars of the loss (index -> action / log_prob / advantage /
   // value / target: a dependent HBM chain of ~3 us that would otherwise sit between the head GEMM and the loss) ----
@@ -397,17 +412,7 @@ __global__ void __launch_bounds__(512, ROLLOUT ? MPPO_ROLLOUT_WAVES : 2) fused_m
   }
   if (gather && !PRE) { xrow0 = a.idx[gi0]; xrow1 = a.idx[gi1]; }
   // dependent batch: the observation chunks (needed first), then the per-row scalars of the loss (needed four phases later)
-  float4 xq0 = make_float4(0.f, 0.f, 0.f, 0.f), xq1 = xq0;
-  const int nxq = 4 * OP;  // PRE: float4 elements of the k-quad tile, element e = (quad e / OP, column e % OP); contiguous in memory
-  const float* xtile = PRE ? a.xpre + (size_t)(row0 >> 2) * OP * (BF16 ? 2 : 4) : nullptr;  // (bf16 network: 8-byte quads, see store_quad)
-  auto load_xq = [&](int e) {
-    if (BF16) { const float2 b = *reinterpret_cast<const float2*>(xtile + 2 * e); return bf16x4_unpack(b.x, b.y); }
-    return *reinterpret_cast<const float4*>(xtile + 4 * e);
-  };
-  if (PRE) {  // depends on nothing but the kernel arguments
-    if (e0 < nxq) xq0 = load_xq(e0);
-    if (e1 < nxq) xq1 = load_xq(e1);
-  } else {
+  if (!PRE) {
     if (e0 < nx && xc0 < OP) xq0 = *reinterpret_cast<const float4*>(a.b.obs + xrow0 * a.b.obs_ld + xc0);
     if (e1 < nx && xc1 < OP) xq1 = *reinterpret_cast<const float4*>(a.b.obs + xrow1 * a.b.obs_ld + xc1);
   }
@@ -808,7 +813,6 @@ int32_t fused_forward_backward(const mppo_net_t& net, const float* params, const
     attr_for = smem;
   }
   MPPO_REQUIRE(!pre || (w2t && idx), "fused_forward_backward: pre-gathered rows need the shadow copies and a permutation");
-  a.gather_y0 = 2;
   if (pre) { a.xpre = pre->cur; a.xnext = pre->next; a.idx_next = pre->idx_next; }
   const dim3 grid(cdiv(mb, FRT), pre && pre->idx_next ? 4 : 2), block(2 * net.H);
 #define MPPO_FUSED_GO(B, T) do { if (pre) hipLaunchKernelGGL((fused_mlp_kernel<B, false, T, true, true>), grid, block, smem, stream, a); \
@@ -825,13 +829,13 @@ int32_t fused_forward_backward(const mppo_net_t& net, const float* params, const
 }
 
 // The first optimizer step of an update has no previous launch to gather its rows: the gather role alone (every workgroup of a PRE
-// launch with gather_y0 = 0).
+// <ROLLOUT, PRE> instantiation).
 int32_t fused_gather_rows(const mppo_net_t& net, const mppo_batch_t& batch, const int* idx, int mb, float* dst, hipStream_t stream) {
   MPPO_REQUIRE(idx && dst && batch.obs, "fused_gather_rows: null argument");
   FusedArgs a{};
-  a.mb = mb; a.O = net.O; a.OP = net.OP; a.H = net.H; a.b = batch; a.idx_next = idx; a.xnext = dst; a.gather_y0 = 0;
-  if (net.bf16) hipLaunchKernelGGL((fused_mlp_kernel<true, false, 1, true, true>), dim3(cdiv(mb, FRT), 2), dim3(256), 0, stream, a);  // (bf16 quads)
-  else hipLaunchKernelGGL((fused_mlp_kernel<false, false, 1, true, true>), dim3(cdiv(mb, FRT), 2), dim3(256), 0, stream, a);
+  a.mb = mb; a.O = net.O; a.OP = net.OP; a.H = net.H; a.b = batch; a.idx_next = idx; a.xnext = dst;
+  if (net.bf16) hipLaunchKernelGGL((fused_mlp_kernel<true, true, 1, true, true>), dim3(cdiv(mb, FRT), 2), dim3(256), 0, stream, a);  // (bf16 quads)
+  else hipLaunchKernelGGL((fused_mlp_kernel<false, true, 1, true, true>), dim3(cdiv(mb, FRT), 2), dim3(256), 0, stream, a);
   MPPO_CHECK_LAUNCH("fused_mlp_kernel<gather>");
   return MPPO_OK;
 }
