@@ -372,6 +372,44 @@ __device__ __forceinline__ void shadow_write_tile(const ShadowRef& sh, const flo
 __global__ void __launch_bounds__(256) adam_kernel(size_t P, float* __restrict__ p, float* __restrict__ m, float* __restrict__ v,
                                                    const float* __restrict__ g, const float* __restrict__ partial, const int* __restrict__ count_base,
                                                    int step_offset, mppo_adam_cfg_t c, ShadowRef sh) {
+  // ---- addresses depend on the kernel arguments only: the four arrays are REQUESTED FIRST, and the clip scale, learning rate and
+  // bias corrections (a wave reduction, a square root, two powf: ~0.7 us of scalar-ish work on a lone wave) are computed while they
+  // fly.  (In program order the other way round, the loads left only after all of that: two memory latencies and the powf in series.)
+  const bool tile_wg = sh.w2t && blockIdx.x >= sh.flat_blocks;
+  // tile workgroup: W2 (and, for a bf16 network, W1) of the actor / critic, one 32 x 32 tile (k x n) per workgroup; thread =
+  // (row k = t / 8, four columns n = 4 (t % 8) ..): one float4 per array, exactly like a flat thread
+  int tb = 0, tn = 1, w2_tiles = 1, netc = 0, k0 = 0, n0 = 0;
+  bool is_w1 = false, row_on = true;
+  const int kr = threadIdx.x >> 3, nq = (threadIdx.x & 7) * 4;
+  size_t i = 0;       // first of this thread's four parameters
+  bool have4 = false;  // a whole float4 inside [0, P)
+  if (tile_wg) {
+    tb = blockIdx.x - sh.flat_blocks; tn = sh.H / 32; w2_tiles = tn * tn;
+    is_w1 = tb >= 2 * w2_tiles;
+    const int kt1 = (sh.O + 31) / 32, per_net = is_w1 ? kt1 * tn : w2_tiles, tb2 = is_w1 ? tb - 2 * w2_tiles : tb;
+    netc = tb2 / per_net;
+    const int tt = tb2 - netc * per_net;
+    k0 = 32 * (tt / tn); n0 = 32 * (tt % tn);
+    const int krows = is_w1 ? sh.O : sh.H;  // rows of the matrix (W1's last tile is ragged)
+    const size_t base = (size_t)(is_w1 ? (netc ? sh.c_w1 : sh.a_w1) : (netc ? sh.c_w2 : sh.a_w2));
+    row_on = k0 + kr < krows;
+    i = base + (size_t)(row_on ? k0 + kr : 0) * sh.H + n0 + nq;
+    have4 = true;
+  } else {
+    // four parameters per thread (the flat layout is a whole number of float4: ppo_layout.h): a quarter of the workgroups to dispatch.
+    // The flat workgroups enumerate everything EXCEPT the ranges the tile workgroups own, so the grid is no larger than without
+    // the shadow copies; all boundaries are multiples of four floats (16-byte aligned tensors)
+    size_t i4 = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) i4 += ((int)(r < sh.nskip) & (int)(i4 >= sh.skip_start4[r])) ? sh.skip_len4[r] : 0u;  // (static indices, no branches: one batch of scalar loads)
+    i = 4 * i4;
+    have4 = i + 3 < P;
+  }
+  float4 gq = make_float4(0.f, 0.f, 0.f, 0.f), mq = gq, vq = gq, pq = gq;
+  if (have4) {
+    gq = *reinterpret_cast<const float4*>(g + i); mq = *reinterpret_cast<const float4*>(m + i); vq = *reinterpret_cast<const float4*>(v + i);
+    pq = *reinterpret_cast<const float4*>(p + i);
+  }
   // every wave adds the same kSqSlots (= 512) partials in the same order (eight per lane, fixed reduction tree):
   // bitwise-identical clip scale everywhere without a second pass
   const int ln = threadIdx.x & 63;
@@ -384,36 +422,21 @@ __global__ void __launch_bounds__(256) adam_kernel(size_t P, float* __restrict__
   if (c.anneal) lr = c.lr * (1.f - (float)(count / c.sched_div) / (float)c.num_updates);
   const float t = (float)(count + 1);
   const float bc1 = 1.f - powf(c.b1, t), bc2 = 1.f - powf(c.b2, t);
-  auto step = [&](float gi, float mo, float vo, float po, float& mn, float& vn, float& pn) {
-    const float gs = gi * scale;
-    mn = c.b1 * mo + (1.f - c.b1) * gs;
-    vn = c.b2 * vo + (1.f - c.b2) * gs * gs;
-    pn = po - lr * (mn / bc1) / (sqrtf(vn / bc2) + c.eps);
-  };
-  if (sh.w2t && blockIdx.x >= sh.flat_blocks) {
-    // W2 (and, for a bf16 network, W1) of the actor / critic, one 32 x 32 tile (k x n) per workgroup: the same update, and the
-    // tile goes into the shadow copies through LDS - W2^T as floats (128-byte row segments both ways; a flat thread would
-    // scatter four 4-byte stores), bf16 fragments as one contiguous 2 KB block per copy.
-    __shared__ float tile[32][33];
-    const int tb = blockIdx.x - sh.flat_blocks, tn = sh.H / 32, w2_tiles = tn * tn;
-    const bool is_w1 = tb >= 2 * w2_tiles;
-    const int kt1 = (sh.O + 31) / 32, per_net = is_w1 ? kt1 * tn : w2_tiles, tb2 = is_w1 ? tb - 2 * w2_tiles : tb;
-    const int netc = tb2 / per_net, tt = tb2 - netc * per_net, k0 = 32 * (tt / tn), n0 = 32 * (tt % tn);
-    const int krows = is_w1 ? sh.O : sh.H;  // rows of the matrix (W1's last tile is ragged)
-    const size_t base = (size_t)(is_w1 ? (netc ? sh.c_w1 : sh.a_w1) : (netc ? sh.c_w2 : sh.a_w2));
-    // thread = (row k = t / 8, four columns n = 4 (t % 8) ..): one float4 per array, exactly like a flat thread
-    const int kr = threadIdx.x >> 3, nq = (threadIdx.x & 7) * 4;
-    const bool row_on = k0 + kr < krows;
-    const size_t i = base + (size_t)(row_on ? k0 + kr : 0) * sh.H + n0 + nq;
-    const float4 gq = *reinterpret_cast<const float4*>(g + i), mq = *reinterpret_cast<const float4*>(m + i), vq = *reinterpret_cast<const float4*>(v + i);
-    const float4 pq = *reinterpret_cast<const float4*>(p + i);
-    const float gi[4] = {gq.x, gq.y, gq.z, gq.w}, mo[4] = {mq.x, mq.y, mq.z, mq.w}, vo[4] = {vq.x, vq.y, vq.z, vq.w}, po[4] = {pq.x, pq.y, pq.z, pq.w};
-    float mn[4], vn[4], pn[4];
+  const float gs[4] = {gq.x * scale, gq.y * scale, gq.z * scale, gq.w * scale};
+  const float mo[4] = {mq.x, mq.y, mq.z, mq.w}, vo[4] = {vq.x, vq.y, vq.z, vq.w}, po[4] = {pq.x, pq.y, pq.z, pq.w};
+  float mn[4], vn[4], pn[4];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      step(gi[q], mo[q], vo[q], po[q], mn[q], vn[q], pn[q]);
-      tile[kr][nq + q] = row_on ? pn[q] : 0.f;  // rows past the matrix are the zero padding of the fragments
-    }
+  for (int k = 0; k < 4; ++k) {
+    mn[k] = c.b1 * mo[k] + (1.f - c.b1) * gs[k];
+    vn[k] = c.b2 * vo[k] + (1.f - c.b2) * gs[k] * gs[k];
+    pn[k] = po[k] - lr * (mn[k] / bc1) / (sqrtf(vn[k] / bc2) + c.eps);
+  }
+  if (tile_wg) {
+    // the tile goes into the shadow copies through LDS - W2^T as floats (128-byte row segments both ways; a flat thread would
+    // scatter four 4-byte stores), bf16 fragments as one contiguous 2 KB block per copy
+    __shared__ float tile[32][33];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) tile[kr][nq + q] = row_on ? pn[q] : 0.f;  // rows past the matrix are the zero padding of the fragments
     if (row_on) {
       stream_store(m + i, make_float4(mn[0], mn[1], mn[2], mn[3]));  // like the flat path: next read by the next step's Adam
       stream_store(v + i, make_float4(vn[0], vn[1], vn[2], vn[3]));
@@ -423,34 +446,18 @@ __global__ void __launch_bounds__(256) adam_kernel(size_t P, float* __restrict__
     shadow_write_tile(sh, tile, is_w1, netc, k0, n0);
     return;
   }
-  // four parameters per thread (the flat layout is a whole number of float4: ppo_layout.h): a quarter of the workgroups to dispatch
-  size_t i4 = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  // the flat workgroups enumerate everything EXCEPT the ranges the tile workgroups own, so the grid is no larger than without
-  // the shadow copies; all boundaries are multiples of four floats (16-byte aligned tensors)
-  for (int r = 0; r < sh.nskip; ++r) if (i4 >= sh.skip_start4[r]) i4 += sh.skip_len4[r];
-  if (4 * i4 >= P) return;
-  if (4 * i4 + 3 < P) {
-    const float4 gq = reinterpret_cast<const float4*>(g)[i4], mq = reinterpret_cast<const float4*>(m)[i4], vq = reinterpret_cast<const float4*>(v)[i4];
-    float4 pq = reinterpret_cast<float4*>(p)[i4];
-    const float gs[4] = {gq.x * scale, gq.y * scale, gq.z * scale, gq.w * scale};
-    const float mo[4] = {mq.x, mq.y, mq.z, mq.w}, vo[4] = {vq.x, vq.y, vq.z, vq.w};
-    float pn[4] = {pq.x, pq.y, pq.z, pq.w}, mn[4], vn[4];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      mn[k] = c.b1 * mo[k] + (1.f - c.b1) * gs[k];
-      vn[k] = c.b2 * vo[k] + (1.f - c.b2) * gs[k] * gs[k];
-      pn[k] = pn[k] - lr * (mn[k] / bc1) / (sqrtf(vn[k] / bc2) + c.eps);
-    }
-    stream_store(m + 4 * i4, make_float4(mn[0], mn[1], mn[2], mn[3]));  // the moments are next read by the next step's Adam, two kernels and ~40 MB of traffic later
-    stream_store(v + 4 * i4, make_float4(vn[0], vn[1], vn[2], vn[3]));
-    reinterpret_cast<float4*>(p)[i4] = make_float4(pn[0], pn[1], pn[2], pn[3]);
+  if (i >= P) return;
+  if (have4) {
+    stream_store(m + i, make_float4(mn[0], mn[1], mn[2], mn[3]));  // the moments are next read by the next step's Adam, two kernels and ~40 MB of traffic later
+    stream_store(v + i, make_float4(vn[0], vn[1], vn[2], vn[3]));
+    *reinterpret_cast<float4*>(p + i) = make_float4(pn[0], pn[1], pn[2], pn[3]);
   } else {
-    for (size_t i = 4 * i4; i < P; ++i) {
-      const float gi = g[i] * scale;
-      const float mi = c.b1 * m[i] + (1.f - c.b1) * gi;
-      const float vi = c.b2 * v[i] + (1.f - c.b2) * gi * gi;
-      m[i] = mi; v[i] = vi;
-      p[i] = p[i] - lr * (mi / bc1) / (sqrtf(vi / bc2) + c.eps);
+    for (size_t e = i; e < P; ++e) {  // (a parameter count that is not a multiple of four: the stand-alone entry point only)
+      const float gi = g[e] * scale;
+      const float mi = c.b1 * m[e] + (1.f - c.b1) * gi;
+      const float vi = c.b2 * v[e] + (1.f - c.b2) * gi * gi;
+      m[e] = mi; v[e] = vi;
+      p[e] = p[e] - lr * (mi / bc1) / (sqrtf(vi / bc2) + c.eps);
     }
   }
 }
