@@ -416,33 +416,43 @@ __global__ void __launch_bounds__(512, ROLLOUT ? MPPO_ROLLOUT_WAVES : 2) fused_m
     if (e0 < nx && xc0 < OP) xq0 = *reinterpret_cast<const float4*>(a.b.obs + xrow0 * a.b.obs_ld + xc0);
     if (e1 < nx && xc1 < OP) xq1 = *reinterpret_cast<const float4*>(a.b.obs + xrow1 * a.b.obs_ld + xc1);
   }
-  float pf0[OT][4], pf1[4], pf2[4];  // actor: action[o], old log_prob, advantage | critic: old value, target, -  (rollout: noise[o])
+  // actor: action[o], old log_prob, advantage | critic: old value, target, -  (rollout: noise[o]).  RAW loads on clamped addresses, no
+  // masking here: every use below is guarded by the same row / column conditions.  (A select on the loaded value in this place makes
+  // it the value's first use, and the s_waitcnt goes where the first use is: with the network branch inside the row loop that was one
+  // wait per row and array, eight memory latencies in series in front of the first MFMA - read off the ISA.)
+  float pf0[OT][4], pf1[4], pf2[4];
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     pf1[r] = pf2[r] = 0.f;
 #pragma unroll
     for (int ot = 0; ot < OT; ++ot) pf0[ot][r] = 0.f;
-    if (ROLLOUT) {
-      if (net == 0 && a.noise) {
+  }
+  if (ROLLOUT) {
+    if (net == 0 && a.noise) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
 #pragma unroll
         for (int ot = 0; ot < OT; ++ot) {
           const int o = cj + 16 * ot;
-          const float v = a.noise[(size_t)prow[r] * A + (o < A ? o : A - 1)];
-          pf0[ot][r] = (pon[r] && o < A) ? v : 0.f;
+          pf0[ot][r] = a.noise[(size_t)prow[r] * A + (o < A ? o : A - 1)];
         }
-      }
-    } else if (net == 0) {
+    }
+  } else if (net == 0) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
 #pragma unroll
       for (int ot = 0; ot < OT; ++ot) {
         const int o = cj + 16 * ot;
-        const float v = a.b.action[prow[r] * a.b.act_ld + (o < A ? o : A - 1)];
-        pf0[ot][r] = (pon[r] && o < A) ? v : 0.f;
+        pf0[ot][r] = a.b.action[prow[r] * a.b.act_ld + (o < A ? o : A - 1)];
       }
-      const float lp = a.b.log_prob[prow[r]], ad = a.b.adv[prow[r]];
-      pf1[r] = pon[r] ? lp : 0.f; pf2[r] = pon[r] ? ad : 0.f;
-    } else {
-      const float ov = a.b.value[prow[r]], tg = a.b.target[prow[r]];
-      pf0[0][r] = pon[r] ? ov : 0.f; pf1[r] = pon[r] ? tg : 0.f;
+      pf1[r] = a.b.log_prob[prow[r]];
+      pf2[r] = a.b.adv[prow[r]];
+    }
+  } else {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      pf0[0][r] = a.b.value[prow[r]];
+      pf1[r] = a.b.target[prow[r]];
     }
   }
 
