@@ -461,14 +461,15 @@ __global__ void __launch_bounds__(512, ROLLOUT ? MPPO_ROLLOUT_WAVES : 2) fused_m
   if (PRE) {
     // a k-quad element is one column of four consecutive rows: four LDS words a row stride apart (consecutive lanes hold consecutive columns)
     auto put = [&](int e, const float4& q) {
-      const int qd = e / OP, c = e - qd * OP;
+      const int qd = (int)(e >= OP) + (int)(e >= 2 * OP) + (int)(e >= 3 * OP), c = e - qd * OP;  // e / OP for e < 4 OP, without the division
       float* d = xt + (4 * qd) * XS + c;
       d[0] = q.x; d[XS] = q.y; d[2 * XS] = q.z; d[3 * XS] = q.w;
     };
     if (e0 < nxq) put(e0, xq0);
     if (e1 < nxq) put(e1, xq1);
     for (int e = t + 2 * nthr; e < nxq; e += nthr) put(e, load_xq(e));
-    for (int e = t; e < FRT * (KP - OP); e += nthr) xt[(e / (KP - OP)) * XS + OP + e % (KP - OP)] = 0.f;  // K padding of the first layer
+    for (int r = t >> 5; r < FRT; r += nthr >> 5)  // K padding of the first layer: fewer than 32 columns per row, one lane each
+      if (OP + (t & 31) < KP) xt[r * XS + OP + (t & 31)] = 0.f;
   } else {
   if (e0 < nx) *reinterpret_cast<float4*>(xt + xr0 * XS + xc0) = xq0;
   if (e1 < nx) *reinterpret_cast<float4*>(xt + xr1 * XS + xc1) = xq1;
