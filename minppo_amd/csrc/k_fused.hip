@@ -428,13 +428,16 @@ __global__ void __launch_bounds__(512, ROLLOUT ? MPPO_ROLLOUT_WAVES : 2) fused_m
     for (int ot = 0; ot < OT; ++ot) pf0[ot][r] = 0.f;
   }
   if (ROLLOUT) {
+    // (the rollout launch - four waves per SIMD, two workgroups per CU - measures 2 us FASTER with the masking select here, i.e. with the
+    // wait for its noise in the prologue: 24.5 against 26.6 us; it keeps the masked form)
     if (net == 0 && a.noise) {
 #pragma unroll
       for (int r = 0; r < 4; ++r)
 #pragma unroll
         for (int ot = 0; ot < OT; ++ot) {
           const int o = cj + 16 * ot;
-          pf0[ot][r] = a.noise[(size_t)prow[r] * A + (o < A ? o : A - 1)];
+          const float v = a.noise[(size_t)prow[r] * A + (o < A ? o : A - 1)];
+          pf0[ot][r] = (pon[r] && o < A) ? v : 0.f;
         }
     }
   } else if (net == 0) {
