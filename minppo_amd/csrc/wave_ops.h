@@ -139,6 +139,13 @@ __device__ __forceinline__ float2 buf_load_f2(const BufView& b, int lane_off_byt
   return make_float2(q.x, q.y);
 }
 
+// write-through stores (sc0 sc1): data written once for ANOTHER kernel leaves this XCD's L2 as it is written instead of staying
+// dirty until the end-of-kernel release has to flush it (MI355X_MICROARCH.md, "boundary": + B / 6 TB/s for B dirty bytes; "publish-large":
+// write-through wins for tens of KB per workgroup).  A raw buffer store bound by name, cache policy in `aux` (1 = sc0, 2 = nt, 16 = sc1).
+#ifndef MPPO_WT_STORES
+#define MPPO_WT_STORES 1
+#endif
+__device__ void mppo_raw_buffer_store_f32x4(f32x4_native data, i32x4_rsrc rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.store.v4f32");
 // streaming stores: data written once for ANOTHER kernel (possibly on another XCD) goes to memory without staying dirty in this
 // XCD's L2 - the end-of-kernel write-back has less to flush (MPPO_NT_STORES=0 at compile time restores plain stores)
 #ifndef MPPO_NT_STORES
@@ -200,4 +207,14 @@ __device__ __forceinline__ int wave_uniform(int x) { return __builtin_amdgcn_rea
 // lane l supplies A[i = l&15][k = l>>4] and B[k = l>>4][j = l&15]; acc[r] is D[row = 4*(l>>4) + r][col = l&15].
 __device__ __forceinline__ void mfma_f32_16x16x4(float a, float b, f32x4& acc) {
   acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc, 0, 0, 0);
+}
+
+// 16 bytes at base[idx .. idx + 4): `base` must be wave-uniform (it becomes the buffer descriptor), idx * 4 below 2 GB
+__device__ __forceinline__ void wt_store(float* base, size_t idx, float4 v) {
+#if MPPO_WT_STORES
+  const BufView b = make_buf(base, 0x7FFFFFFFu);
+  mppo_raw_buffer_store_f32x4(f32x4_native{v.x, v.y, v.z, v.w}, b.r, (int)(idx * 4), 0, 17);  // cache policy bits of this target: 1 = sc0, 2 = nt, 16 = sc1
+#else
+  stream_store(base + idx, v);
+#endif
 }

@@ -172,6 +172,7 @@ inline float __shfl_xor(float x, int mask) {
 inline void stream_store(float* p, float v) { *p = v; }
 inline void stream_store(float* p, float2 v) { *reinterpret_cast<float2*>(p) = v; }
 inline void stream_store(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+inline void wt_store(float* base, size_t idx, float4 v) { *reinterpret_cast<float4*>(base + idx) = v; }
 struct BufView { const char* base; unsigned bytes; };
 inline BufView make_buf(const float* base, unsigned bytes) { return BufView{reinterpret_cast<const char*>(base), bytes}; }
 inline float2 buf_load_f2(const BufView& b, int lane_off_bytes, int uniform_off_bytes) {  // per-dword range check, 0 outside (as the hardware)
