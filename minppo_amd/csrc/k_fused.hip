@@ -266,19 +266,28 @@ __device__ __forceinline__ void store_quad(float* base, size_t qi, const float (
 // end-of-kernel flush, and the weight-gradient launch finds them in memory: 13.9 -> 12.6 us there.  The row pass itself pays 0.9 us for it
 // (a wave retires when its write-through stores are acknowledged); net 6.59 -> 6.555 ms per update.  All four operand stores or none:
 // write-through for h1 / h2 / dZ2 and a streaming store for the last one (dZ1) measured 6.82 ms.
+// float networks: SPLIT-PAIR column order inside a quad row (wgrad.h) - the even column of the lane's pair at qi, the odd one at qi2, half
+// a quad row further: each of the two store instructions then writes whole lines across the lanes
 template <bool BF16, bool WT = true>
-__device__ __forceinline__ void store_quad2(float* base, size_t qi, const float (&q0)[4], const float (&q1)[4]) {
+__device__ __forceinline__ void store_quad2(float* base, size_t qi, size_t qi2, const float (&q0)[4], const float (&q1)[4]) {
   if (BF16) {
     const float2 a = bf16x4_bits(pack_bf16x4(q0[0], q0[1], q0[2], q0[3])), b = bf16x4_bits(pack_bf16x4(q1[0], q1[1], q1[2], q1[3]));
     if (WT) wt_store(base, qi >> 1, make_float4(a.x, a.y, b.x, b.y));
     else stream_store(base + (qi >> 1), make_float4(a.x, a.y, b.x, b.y));
   } else if (WT) {
     wt_store(base, qi, make_float4(q0[0], q0[1], q0[2], q0[3]));
-    wt_store(base, qi + 4, make_float4(q1[0], q1[1], q1[2], q1[3]));
+    wt_store(base, qi2, make_float4(q1[0], q1[1], q1[2], q1[3]));
   } else {
     stream_store(base + qi, make_float4(q0[0], q0[1], q0[2], q0[3]));
-    stream_store(base + qi + 4, make_float4(q1[0], q1[1], q1[2], q1[3]));
+    stream_store(base + qi2, make_float4(q1[0], q1[1], q1[2], q1[3]));
   }
+}
+// positions of the column pair (c0, c0 + 1), c0 even, of quad row `row` in an operand of `cols` columns: plain order for a bf16 network
+// (one 16-byte store holds both), split-pair order for a float network
+template <bool BF16>
+__device__ __forceinline__ void pair_index(size_t row, size_t c0, size_t cols, size_t& qi, size_t& qi2) {
+  if (BF16) { qi = quad_index(row, c0, cols); qi2 = qi + 4; }
+  else { qi = ((row >> 2) * cols + (c0 >> 1)) * 4; qi2 = qi + (cols >> 1) * 4; }
 }
 
 // Gather role of a PRE launch: 16 rows of the NEXT minibatch (half = blockIdx.y picks two of the tile's four quads) from the
@@ -544,7 +553,11 @@ __global__ void __launch_bounds__(512, ROLLOUT ? MPPO_ROLLOUT_WAVES : 2) fused_m
       const bool on = row0 + rr < a.mb;  // rows past the minibatch are zero in the quad buffers (they are contracted over)
       q0[r] = on ? v0 : 0.f; q1[r] = on ? v1 : 0.f;
     }
-    if (!ROLLOUT && !(a.skip & 32)) store_quad2<BF16>(hg, quad_index(row0 + 4 * rq, c0, H), q0, q1);  // two adjacent columns: 32 bytes per lane (bf16: 16)
+    if (!ROLLOUT && !(a.skip & 32)) {  // two adjacent columns: 32 bytes per lane (bf16: 16)
+      size_t qi, qi2;
+      pair_index<BF16>(row0 + 4 * rq, c0, H, qi, qi2);
+      store_quad2<BF16>(hg, qi, qi2, q0, q1);
+    }
     __syncthreads();
     FT(5 + 2 * layer);
   }
@@ -744,7 +757,11 @@ __global__ void __launch_bounds__(512, ROLLOUT ? MPPO_ROLLOUT_WAVES : 2) fused_m
       const bool on = row0 + rr < a.mb;
       q0[r] = on ? z0 : 0.f; q1[r] = on ? z1 : 0.f;
     }
-    if (!(a.skip & 32)) store_quad2<BF16>(a.dz2[net], quad_index(row0 + 4 * rq, c0, H), q0, q1);
+    if (!(a.skip & 32)) {
+      size_t qi, qi2;
+      pair_index<BF16>(row0 + 4 * rq, c0, H, qi, qi2);
+      store_quad2<BF16>(a.dz2[net], qi, qi2, q0, q1);
+    }
   }
   __syncthreads();
   FT(12);
@@ -765,7 +782,11 @@ __global__ void __launch_bounds__(512, ROLLOUT ? MPPO_ROLLOUT_WAVES : 2) fused_m
       const float d1 = tanh_act ? acc1[r] * (1.f - gq.y * gq.y) : (gq.y > 0.f ? acc1[r] : 0.f);
       q0[r] = on ? d0 : 0.f; q1[r] = on ? d1 : 0.f;
     }
-    store_quad2<BF16>(a.dz1[net], quad_index(row0 + 4 * rq, c0, H), q0, q1);
+    {
+      size_t qi, qi2;
+      pair_index<BF16>(row0 + 4 * rq, c0, H, qi, qi2);
+      store_quad2<BF16>(a.dz1[net], qi, qi2, q0, q1);
+    }
   }
   FT(14);
 }

@@ -641,12 +641,13 @@ int32_t minibatch_grad(const mppo_net_t& net, const float* params, const mppo_ba
       return p;
     };
     w.count = 6; w.grad = grad; w.sq_partial = sq_partial;
-    w.p[0] = wp(gbuf.f.h1a, H, H, gbuf.dz2a, H, H, H, L.a_w2, L.a_b2);
-    w.p[1] = wp(xq, net.OP, O, gbuf.dz1a, H, H, H, L.a_w1, L.a_b1);
-    w.p[2] = wp(gbuf.f.h1c, H, H, gbuf.dz2c, H, H, H, L.c_w2, L.c_b2);
-    w.p[3] = wp(xq, net.OP, O, gbuf.dz1c, H, H, H, L.c_w1, L.c_b1);
-    w.p[4] = wp(gbuf.f.h2a, H, H, gbuf.dout, DP, AP, A, L.a_w3, L.a_b3);
-    w.p[5] = wp(gbuf.f.h2c, H, H, gbuf.dout + (net.bf16 ? 2 : 4) * AP, DP, 4, 1, L.c_w3, L.c_b3);  // column AP of the quad rows (a bf16 network's quads are 8 bytes)
+    const int sp = net.bf16 ? 0 : 1;  // float networks: hidden activations and dZ in split-pair column order (wgrad.h); x and dOut plain
+    w.p[0] = wp(gbuf.f.h1a, H, H, gbuf.dz2a, H, H, H, L.a_w2, L.a_b2);  w.p[0].a_split = sp; w.p[0].b_split = sp;
+    w.p[1] = wp(xq, net.OP, O, gbuf.dz1a, H, H, H, L.a_w1, L.a_b1);          w.p[1].b_split = sp;
+    w.p[2] = wp(gbuf.f.h1c, H, H, gbuf.dz2c, H, H, H, L.c_w2, L.c_b2);  w.p[2].a_split = sp; w.p[2].b_split = sp;
+    w.p[3] = wp(xq, net.OP, O, gbuf.dz1c, H, H, H, L.c_w1, L.c_b1);          w.p[3].b_split = sp;
+    w.p[4] = wp(gbuf.f.h2a, H, H, gbuf.dout, DP, AP, A, L.a_w3, L.a_b3);    w.p[4].a_split = sp;
+    w.p[5] = wp(gbuf.f.h2c, H, H, gbuf.dout + (net.bf16 ? 2 : 4) * AP, DP, 4, 1, L.c_w3, L.c_b3);  w.p[5].a_split = sp;  // column AP of the quad rows (a bf16 network's quads are 8 bytes)
     w.ls_off = L.log_std; w.A = A; w.AP = AP; w.nblk = nblk; w.partial = gbuf.partial; w.log_std = params + L.log_std;
     w.ent_coef = lc.ent_coef; w.vf_coef = lc.vf_coef; w.ent_weight = ent_weight; w.loss4 = loss4;
     w.npad = L.npad;

@@ -60,8 +60,10 @@ __global__ void __launch_bounds__(WTHREADS) wgrad_kernel(WgradArgs a) {
   const BufView bufA = make_buf(p.A, (unsigned)a.Kq * (unsigned)p.lda * (unsigned)QB);
   const BufView bufB = make_buf(p.B, (unsigned)a.Kq * (unsigned)p.ldb * (unsigned)QB);
   constexpr int kOutOfRange = 0x40000000;
-  const int offa = m0 + i < p.acols ? (h * p.lda + m0 + i) * QB : kOutOfRange;
-  const int offb = n0 + i < p.bcols ? (h * p.ldb + n0 + i) * QB : kOutOfRange;
+  const int ca = m0 + i, cb = n0 + i;  // this lane's columns; their position inside the quad row (WgradProb::a_split)
+  const int pa = p.a_split ? (ca >> 1) + (ca & 1) * (p.lda >> 1) : ca, pb = p.b_split ? (cb >> 1) + (cb & 1) * (p.ldb >> 1) : cb;
+  const int offa = ca < p.acols ? (h * p.lda + pa) * QB : kOutOfRange;
+  const int offb = cb < p.bcols ? (h * p.ldb + pb) * QB : kOutOfRange;
   auto ldq = [&](const BufView& b, int lane_off, int uni_off) {  // one quad; bf16: raw bits in .x, .y
     if (BF16) { const float2 r = buf_load_f2(b, lane_off, uni_off); return make_float4(r.x, r.y, 0.f, 0.f); }
     return buf_load_f4(b, lane_off, uni_off);

@@ -21,6 +21,11 @@ struct WgradProb {
   int off_w, off_b;
   int tiles_m, tiles_n, tile0;  // filled by wgrad_plan
   int thin_row0, thin_rows;     // a last row band of <= 4 rows gets no tiles: the first row band's workgroups contract it (wgrad_plan)
+  // SPLIT-PAIR column order of an operand's quad rows (float networks: h1, h2, dZ1, dZ2 as the row pass stores them): the even columns
+  // in the first half of the quad row, the odd ones in the second - column c sits at position (c >> 1) + (c & 1) * (ld / 2).  A lane of
+  // the row pass owns two adjacent columns; this way each of its two 16-byte stores covers whole 256-byte runs across the lanes
+  // (write-through stores of half lines doubled the bytes written)
+  int a_split, b_split;
 };
 
 struct WgradArgs {
