@@ -348,7 +348,7 @@ __device__ __forceinline__ void shadow_write_tile(const ShadowRef& sh, const flo
     // w2t[n0 + nr][k0 + 4 kq ..]: four consecutive k of one column, eight threads per 128-byte row segment
     float* T = sh.w2t + (netc ? (((size_t)sh.H * sh.H + 3) & ~(size_t)3) : 0);
     const int nr = t >> 3, kq = (t & 7) * 4;
-    *reinterpret_cast<float4*>(T + (size_t)(n0 + nr) * sh.H + k0 + kq) = make_float4(tile[kq][nr], tile[kq + 1][nr], tile[kq + 2][nr], tile[kq + 3][nr]);
+    wt_store(T, (size_t)(n0 + nr) * sh.H + k0 + kq, make_float4(tile[kq][nr], tile[kq + 1][nr], tile[kq + 2][nr], tile[kq + 3][nr]));
   }
   if (sh.frag) {
     // fragment block (S = k0 / 32, w = n0 / 32): thread = (lane = t / 4, part = t % 4 = 2 tau + g), four values c = 0..3
@@ -438,9 +438,9 @@ __global__ void __launch_bounds__(256) adam_kernel(size_t P, float* __restrict__
 #pragma unroll
     for (int q = 0; q < 4; ++q) tile[kr][nq + q] = row_on ? pn[q] : 0.f;  // rows past the matrix are the zero padding of the fragments
     if (row_on) {
-      stream_store(m + i, make_float4(mn[0], mn[1], mn[2], mn[3]));  // like the flat path: next read by the next step's Adam
-      stream_store(v + i, make_float4(vn[0], vn[1], vn[2], vn[3]));
-      *reinterpret_cast<float4*>(p + i) = make_float4(pn[0], pn[1], pn[2], pn[3]);
+      wt_store(m, i, make_float4(mn[0], mn[1], mn[2], mn[3]));  // like the flat path: next read by the next step's Adam
+      wt_store(v, i, make_float4(vn[0], vn[1], vn[2], vn[3]));
+      wt_store(p, i, make_float4(pn[0], pn[1], pn[2], pn[3]));
     }
     __syncthreads();
     shadow_write_tile(sh, tile, is_w1, netc, k0, n0);
@@ -448,9 +448,9 @@ __global__ void __launch_bounds__(256) adam_kernel(size_t P, float* __restrict__
   }
   if (i >= P) return;
   if (have4) {
-    stream_store(m + i, make_float4(mn[0], mn[1], mn[2], mn[3]));  // the moments are next read by the next step's Adam, two kernels and ~40 MB of traffic later
-    stream_store(v + i, make_float4(vn[0], vn[1], vn[2], vn[3]));
-    *reinterpret_cast<float4*>(p + i) = make_float4(pn[0], pn[1], pn[2], pn[3]);
+    wt_store(m, i, make_float4(mn[0], mn[1], mn[2], mn[3]));  // the moments are next read by the next step's Adam, two kernels and ~40 MB of traffic later
+    wt_store(v, i, make_float4(vn[0], vn[1], vn[2], vn[3]));
+    wt_store(p, i, make_float4(pn[0], pn[1], pn[2], pn[3]));
   } else {
     for (size_t e = i; e < P; ++e) {  // (a parameter count that is not a multiple of four: the stand-alone entry point only)
       const float gi = g[e] * scale;
