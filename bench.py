@@ -219,16 +219,18 @@ def spawn_ranks(args: argparse.Namespace) -> int:
     one fresh child per GPU (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in the environment, exactly what
     torch.distributed.run would set) and forwards rank 0's JSON line.  It never touches the GPU itself
     (`torch.cuda.device_count()` does not initialise HIP on this image), so nothing that has initialised a GPU is
-    ever re-executed.  If the ranks fail or exceed the time limit with the RCCL calls captured inside the hipGraph
-    (the default), the exact child PIDs are killed and the run is repeated once with eager launches
-    (MPPO_GRAPH_COMM=0)."""
+    ever re-executed.  If the ranks fail or exceed the time limit with the default transport of the gradients (the engine's
+    peer-to-peer exchange inside the hipGraph, csrc/peer.h), the exact child PIDs are killed and the run is repeated once
+    with RCCL all-reduces launched eagerly (MPPO_ALLREDUCE=rccl).  MPPO_BENCH_SHARE_GPU=1: all ranks on GPU 0 (how the
+    multi-rank path is measured on a one-GPU box; rendezvous over gloo)."""
     import socket
     import subprocess
 
     import torch
 
     have = torch.cuda.device_count()
-    if have < args.gpus:
+    share = os.environ.get("MPPO_BENCH_SHARE_GPU") == "1"
+    if have < (1 if share else args.gpus):
         sys.stderr.write(f"bench.py: --gpus {args.gpus} but this machine exposes {have} GPU(s); nothing was run\n")
         return 2
 
@@ -243,7 +245,7 @@ def spawn_ranks(args: argparse.Namespace) -> int:
         port = free_port()
         procs = []
         for r in range(args.gpus):
-            env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), LOCAL_WORLD_SIZE=str(args.gpus),
+            env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(0 if share else r), WORLD_SIZE=str(args.gpus), LOCAL_WORLD_SIZE=str(args.gpus),
                        MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"),
                        MPPO_BENCH_WORKER="1", **extra_env)  # the children measure; this process is already their supervisor
             procs.append(subprocess.Popen([sys.executable, str(Path(__file__).resolve()), *sys.argv[1:]], env=env,
@@ -266,9 +268,9 @@ def spawn_ranks(args: argparse.Namespace) -> int:
 
     limit = float(os.environ.get("MPPO_BENCH_RANK_TIMEOUT", "420"))
     ok, line = attempt({}, limit)
-    if not ok and os.environ.get("MPPO_GRAPH_COMM", "1") != "0":
-        sys.stderr.write("bench.py: ranks failed with RCCL inside the hipGraph; repeating with eager launches (MPPO_GRAPH_COMM=0)\n")
-        ok, line = attempt({"MPPO_GRAPH_COMM": "0"}, limit)
+    if not ok and os.environ.get("MPPO_ALLREDUCE", "peer") != "rccl" and not share:
+        sys.stderr.write("bench.py: ranks failed with the peer-to-peer exchange; repeating with eager RCCL all-reduces (MPPO_ALLREDUCE=rccl)\n")
+        ok, line = attempt({"MPPO_ALLREDUCE": "rccl", "MPPO_GRAPH_COMM": "0"}, limit)
     if not ok:
         sys.stderr.write("bench.py: a rank failed or timed out\n")
         return 1
@@ -284,9 +286,9 @@ def spawn_ranks(args: argparse.Namespace) -> int:
 def supervise_rank(args: argparse.Namespace) -> int:
     """A rank started by `python -m torch.distributed.run ... bench.py --gpus N` (the driver's spelling).  The rank process
     itself stays off the GPU and runs the measurement in ONE child (same file, MPPO_BENCH_WORKER=1), so that a failure or
-    a hang of the first attempt - RCCL calls captured inside the hipGraph, the default - can be answered the same way
-    `spawn_ranks` answers it: every rank kills exactly its own child and the run is repeated once with eager launches
-    (MPPO_GRAPH_COMM=0).  The ranks agree through status files in a per-job directory (one node: nnodes = 1); the retry
+    a hang of the first attempt - the engine's peer-to-peer exchange inside the hipGraph, the default - can be answered the same way
+    `spawn_ranks` answers it: every rank kills exactly its own child and the run is repeated once with eager RCCL all-reduces
+    (MPPO_ALLREDUCE=rccl).  The ranks agree through status files in a per-job directory (one node: nnodes = 1); the retry
     rendezvous on a fresh port picked by rank 0 instead of the launcher's store (which still holds the first attempt's keys)."""
     import signal
     import socket
@@ -345,9 +347,9 @@ def supervise_rank(args: argparse.Namespace) -> int:
         return all_ok, out
 
     ok, out = run_attempt(0, {})
-    if not ok and os.environ.get("MPPO_GRAPH_COMM", "1") != "0":
+    if not ok and os.environ.get("MPPO_ALLREDUCE", "peer") != "rccl":
         if rank == 0:
-            sys.stderr.write("bench.py: ranks failed with RCCL inside the hipGraph; repeating with eager launches (MPPO_GRAPH_COMM=0)\n")
+            sys.stderr.write("bench.py: ranks failed with the peer-to-peer exchange; repeating with eager RCCL all-reduces (MPPO_ALLREDUCE=rccl)\n")
             s = socket.socket()
             s.bind(("127.0.0.1", 0))
             port = s.getsockname()[1]
@@ -360,7 +362,7 @@ def supervise_rank(args: argparse.Namespace) -> int:
             time.sleep(0.2)
         if (d / "retry_port").exists():
             port = (d / "retry_port").read_text().strip()
-            ok, out = run_attempt(1, {"MPPO_GRAPH_COMM": "0", "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": port, "TORCHELASTIC_USE_AGENT_STORE": "False"})
+            ok, out = run_attempt(1, {"MPPO_ALLREDUCE": "rccl", "MPPO_GRAPH_COMM": "0", "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": port, "TORCHELASTIC_USE_AGENT_STORE": "False"})
     # leave nothing behind: every rank has read every verdict by now (run_attempt returns after all status files exist or the wait
     # expired); rank 0 removes the directory a moment later, whatever is still in it
     if rank == 0:
@@ -398,6 +400,9 @@ def main() -> None:
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    share = os.environ.get("MPPO_BENCH_SHARE_GPU") == "1"  # every rank on GPU 0 (measurement of the multi-rank path on a one-GPU box)
+    if share:
+        local_rank = 0
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} does not match WORLD_SIZE {world}")
     if torch.cuda.device_count() <= local_rank:
@@ -405,15 +410,26 @@ def main() -> None:
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if share:
+            dist.init_process_group("gloo", rank=rank, world_size=world)  # RCCL refuses two ranks on one device
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     from minppo_amd.config import load_config_from_cli
     from minppo_amd.train import Trainer
 
     n_global = args.envs_per_gpu * world
-    cfg = load_config_from_cli([args.config, f"training.num_envs={n_global}", *args.set])
-    tr = Trainer(cfg, device=f"cuda:{local_rank}", rank=rank, world_size=world, use_graph=not args.no_graph)
-    tr.init_comm()
+    # MPPO_BENCH_INDEPENDENT=1 (measurement only, with MPPO_BENCH_SHARE_GPU=1): the ranks train independent replicas side by side, no
+    # gradient exchange - what the sharing of one GPU by `world` processes costs by itself, the baseline of the exchange's price
+    indep = world > 1 and os.environ.get("MPPO_BENCH_INDEPENDENT") == "1"
+    if indep:
+        cfg = load_config_from_cli([args.config, f"training.num_envs={args.envs_per_gpu}", *args.set])
+        tr = Trainer(cfg, device=f"cuda:{local_rank}", rank=0, world_size=1, seed=1337 + rank, use_graph=not args.no_graph)
+        transport = "independent replicas (no exchange)"
+    else:
+        cfg = load_config_from_cli([args.config, f"training.num_envs={n_global}", *args.set])
+        tr = Trainer(cfg, device=f"cuda:{local_rank}", rank=rank, world_size=world, use_graph=not args.no_graph)
+        transport = tr.init_comm()  # "peer" (default; csrc/peer.h) or "rccl" ($MPPO_ALLREDUCE), "none" for one rank
     tr.reset()
     # A fresh process stalls ONCE for 70-90 ms some 30-40 ms after its first GPU work (measured per update by
     # tools/ramp_probe.py, graph replay and eager launches alike: profiles/r02_g_ramp.txt); with W = 3 warm-up updates
@@ -444,10 +460,23 @@ def main() -> None:
         tr.update()
     fence()
     dt = time.perf_counter() - t0
+    replicas_identical = None
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=f"cuda:{local_rank}")
+        t = torch.tensor([dt], dtype=torch.float64)
+        t = t if share else t.to(f"cuda:{local_rank}")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+        # replicas must hold bit-identical parameters after the same updates: a checksum of the parameter bits, compared over the ranks
+    if world > 1 and not indep:
+        tr.check_peers()
+        import numpy as _np
+        bits = tr.params_flat().view(_np.uint32).astype(_np.uint64)
+        chk = torch.tensor([int(bits.sum()), int((bits * (_np.arange(bits.size, dtype=_np.uint64) % 65521 + 1)).sum() % (1 << 62))], dtype=torch.int64)
+        chk = chk if share else chk.to(f"cuda:{local_rank}")
+        lo, hi = chk.clone(), chk.clone()
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        replicas_identical = bool((lo == hi).all().item())
     steps_total = tr.T * n_global * args.steps
     stats = tr.rollout_stats()
     lossm = tr.losses().reshape(-1, 4).mean(0)
@@ -490,7 +519,10 @@ def main() -> None:
             "dtype": "bf16" if bf16 else "f32",
             "data": f"synthetic (stand-in robot {tr.cm.name}, random-init weights, Philox action noise)",
             "config": {"workload": f"{args.config}: {args.envs_per_gpu} envs/GPU x T={tr.T} rollout + {tr.E}x{tr.M} minibatch PPO update, O={tr.O} A={tr.A} H={tr.H}, {'bf16-in/f32-acc MLP products, f32 elsewhere' if bf16 else 'fp32'} ({baseline_cfg})",
-                       "global_envs": n_global, "parallelism": f"env-sharded dp{world}, RCCL gradient all-reduce per optimizer step" if world > 1 else "single GPU",
+                       "global_envs": n_global, "parallelism": (f"env-sharded dp{world}, gradients summed per optimizer step: " +
+                                                                           ("peer-to-peer exchange over hipIpc-mapped buffers fused into the weight-gradient and Adam launches (csrc/peer.h)" if transport == "peer"
+                                                                            else "RCCL all-reduce") + (", all ranks on ONE GPU" if share else "")) if world > 1 else "single GPU",
+                       "allreduce": transport + (f" ({tr.peer_form()})" if transport == "peer" else ""), "replicas_identical": replicas_identical,
                        "hipgraph": bool(tr.graph_active()),
                        "pre_warm": f"{pre_warm_s:.1f} s of unrelated device work before the {args.warmup} warm-up steps (one-time start-up stall of the device, see bench.py)"},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,

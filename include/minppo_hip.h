@@ -45,7 +45,7 @@ extern "C" {
 #define MPPO_ENCCL (-5)    /* an RCCL call failed                                         */
 #define MPPO_ENOMEM (-6)   /* caller-provided workspace too small                         */
 
-#define MPPO_ABI_VERSION 2
+#define MPPO_ABI_VERSION 3
 
 const char* mppo_last_error(void);
 int32_t mppo_abi_version(void);
@@ -314,12 +314,37 @@ int32_t mppo_engine_region(const mppo_engine_t* e, const char* name, size_t* off
  * and one of the [E*M*2] float64 advantage sums per update. */
 int32_t mppo_comm_unique_id(void* id128);
 int32_t mppo_engine_comm_init(mppo_engine_t* e, const void* id128);
+/* Peer-to-peer gradient exchange between the ranks of one node, the alternative to RCCL (csrc/peer.h; the reference has no data
+ * parallelism: train.py:136,140).  Every rank allocates one exchange buffer (fine-grained device memory; this call ALLOCATES and
+ * synchronises the device) and exports it as a 64-byte hipIpc handle; the caller gathers the handles of all ranks in rank order
+ * (64 * world_size bytes), hands them to every rank, and places a host-side barrier between the last connect and the first update.
+ * From then on the weight-gradient launch of every optimizer step publishes the local gradient, and the Adam launch reduces this
+ * rank's slice, broadcasts it and waits for the others' (two hops, no extra launch, part of the hipGraph); the advantage sums take one
+ * small kernel per update.  Takes precedence over an RCCL communicator.  Requires HSA_ENABLE_IPC_MODE_LEGACY=0 on this pool.
+ * shared_device != 0: several of the ranks run on ONE GPU (how the path is exercised on a one-GPU box): a kernel that waits for a peer
+ * must then leave room for that peer's kernels on every CU, so the two waits of a step become one-wave kernels of their own and
+ * nothing else waits (five launches per optimizer step instead of three).
+ *   mppo_engine_comm_mode    *out = 0 no exchange, 1 RCCL, 2 peer-to-peer (fused), 3 peer-to-peer in two launches, 4 peer-to-peer,
+ *                            shared-GPU form
+ *   mppo_engine_peer_status  synchronises the device; *timed_out != 0: a rank waited longer than MPPO_PEER_TIMEOUT_MS (default
+ *                            5000) for a peer - the kernels ran to their end, the results are invalid.  info8 (optional, 8 words):
+ *                            the first such wait {kind: 1 a peer's local gradient, 2 a reduced piece, 3 a peer's advantage sums;
+ *                            index; epoch waited for; value seen}, then {optimizer steps, updates, local arrivals, pieces per slice} */
+int32_t mppo_engine_peer_export(mppo_engine_t* e, void* handle64);
+int32_t mppo_engine_peer_connect(mppo_engine_t* e, const void* handles, int32_t shared_device);
+int32_t mppo_engine_comm_mode(const mppo_engine_t* e, int32_t* out);
+int32_t mppo_engine_peer_status(const mppo_engine_t* e, int32_t* timed_out, int32_t* info8);
 /* env reset (train.py:142-144) */
 int32_t mppo_engine_reset(mppo_engine_t* e, void* stream);
 /* one full update: T rollout steps, bootstrap value, GAE, E epochs x M minibatches */
 int32_t mppo_engine_update(mppo_engine_t* e, void* stream);
-/* *out = 1 once mppo_engine_update replays a captured hipGraph (with several ranks: RCCL calls included), 0 while it
- * launches eagerly (use_graph = 0, null stream, MPPO_GRAPH_COMM=0 with a communicator, or a failed capture) */
+/* what mppo_engine_update does before it enqueues anything: the one-time capture of the update into a hipGraph (no device work).
+ * Several ranks: call it on every rank, then a host-side barrier, then the first update - the ranks then start their first gradient
+ * exchange together, not a capture time apart (the peer-to-peer exchange bounds every wait by MPPO_PEER_TIMEOUT_MS) */
+int32_t mppo_engine_prepare(mppo_engine_t* e, void* stream);
+/* *out = 1 once mppo_engine_update replays a captured hipGraph, 0 while it launches eagerly (use_graph = 0, null stream, a failed
+ * capture, or an RCCL communicator without MPPO_GRAPH_COMM=1: RCCL calls are captured into the graph only on request, and the
+ * ranks then agree through one eager all-reduce that every capture succeeded) */
 int32_t mppo_engine_graph_active(const mppo_engine_t* e, int32_t* out);
 /* pieces of the update, for stage-wise parity tests */
 int32_t mppo_engine_rollout(mppo_engine_t* e, void* stream);

@@ -83,6 +83,7 @@ class EngineCfg(C.Structure):
 
 
 P = C.POINTER
+ABI_VERSION = 3  # include/minppo_hip.h: MPPO_ABI_VERSION
 
 # name -> (restype, argtypes); restype c_i32 functions are checked and raise NativeError
 SIGNATURES = {
@@ -130,8 +131,13 @@ SIGNATURES = {
     "mppo_engine_region": (c_i32, [c_vp, C.c_char_p, P(c_sz), P(c_sz)]),
     "mppo_comm_unique_id": (c_i32, [c_vp]),
     "mppo_engine_comm_init": (c_i32, [c_vp, c_vp]),
+    "mppo_engine_peer_export": (c_i32, [c_vp, c_vp]),
+    "mppo_engine_peer_connect": (c_i32, [c_vp, c_vp, c_i32]),
+    "mppo_engine_comm_mode": (c_i32, [c_vp, P(c_i32)]),
+    "mppo_engine_peer_status": (c_i32, [c_vp, P(c_i32), P(c_i32)]),
     "mppo_engine_reset": (c_i32, [c_vp, c_vp]),
     "mppo_engine_update": (c_i32, [c_vp, c_vp]),
+    "mppo_engine_prepare": (c_i32, [c_vp, c_vp]),
     "mppo_engine_graph_active": (c_i32, [c_vp, P(c_i32)]),
     "mppo_engine_rollout": (c_i32, [c_vp, c_vp]),
     "mppo_engine_learn": (c_i32, [c_vp, c_vp]),
@@ -200,8 +206,8 @@ def load() -> Lib:
         import torch  # noqa: F401
 
         _LIB = Lib(HIP_LIB_PATH)
-        if _LIB.abi_version() != 2:
-            raise ImportError(f"{HIP_LIB_PATH}: ABI version {_LIB.abi_version()} != 2")
+        if _LIB.abi_version() != ABI_VERSION:
+            raise ImportError(f"{HIP_LIB_PATH}: ABI version {_LIB.abi_version()} != {ABI_VERSION} (rebuild: python -m minppo_amd.build)")
     return _LIB
 
 

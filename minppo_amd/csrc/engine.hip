@@ -18,6 +18,7 @@
 #include "model_view.h"
 #include "ppo_layout.h"
 #include "platform.h"
+#include "peer.h"
 
 #include <cstdlib>
 #include <cstring>
@@ -28,7 +29,7 @@ namespace mppo {
 const ModelView& model_view(const mppo_model* m);
 
 __global__ void advance_counters_kernel(int* count, int opt_steps) {
-  if (threadIdx.x == 0 && blockIdx.x == 0) { count[0] += opt_steps; count[1] += 1; }
+  if (threadIdx.x == 0 && blockIdx.x == 0 && opt_steps > 0) { count[0] += opt_steps; count[1] += 1; }
 }
 
 // Per-update rollout statistics: the device-side reduction of what the reference returns as the full [T,N] history of
@@ -94,8 +95,10 @@ struct mppo_engine {
   void* perm_ws;
   size_t perm_ws_bytes;
   mppo::Comm* comm;
+  mppo::PeerComm* peer;  // the ranks' peer-to-peer exchange (peer.h); takes precedence over `comm` once connected
   mppo::GraphExec* graph;
-  bool graph_failed, was_reset;
+  bool graph_failed, was_reset, graph_agreed;
+  float* flag_ws;        // one float of the arena: the ranks' agreement on the graph capture (RCCL path)
 };
 
 namespace mppo {
@@ -145,6 +148,7 @@ static size_t layout(mppo_engine* e, bool assign) {
   e->fwd_ws = (float*)take("fwd_ws", fwd_bufs_floats(net, (int)N) * 4);
   e->grad_ws = (float*)take("grad_ws", grad_bufs_floats(net, e->mb) * 4);
   e->adam_ws = (float*)take("adam_ws", mppo_adam_ws_bytes(P));
+  e->flag_ws = (float*)take("comm_flag", 256);
   e->jax_rounds = threefry_rounds((int)B);
   e->jax_rng = (unsigned*)take("jax_rng", (2 + 2 * T + 2 * (size_t)e->E * e->jax_rounds) * 4);
   e->perm_ws_bytes = mppo_permutation_ws_bytes((int)B);
@@ -251,7 +255,9 @@ static int32_t do_learn(mppo_engine* e, hipStream_t s) {
   // MPPO_FORCE_COMM=1 runs the collectives also at world size 1 (identity all-reduce): hardware check of the RCCL path
   const char* fc = getenv("MPPO_FORCE_COMM");
   const bool force_comm = fc && fc[0] == '1';
-  const bool use_comm = c.world_size > 1 || (force_comm && e->comm);
+  const bool use_peer = peer_connected(e->peer);  // gradients travel through the ranks' hipIpc-mapped exchange buffers (peer.h)
+  const bool use_comm = !use_peer && (c.world_size > 1 || (force_comm && e->comm));
+  if (use_peer) MPPO_TRY(peer_allreduce_f64(e->peer, e->adv_sums, (size_t)EM * 2, s));
   if (use_comm) MPPO_TRY(comm_allreduce_f64(e->comm, e->adv_sums, (size_t)EM * 2, s));
   MPPO_TRY(mppo_adv_stats_finalize(e->adv_sums, EM, (double)e->mb * c.world_size, e->adv_stats, s));
   mppo_batch_t batch;
@@ -260,6 +266,8 @@ static int32_t do_learn(mppo_engine* e, hipStream_t s) {
   GradBufs gb = carve_grad(c.net, e->mb, e->grad_ws);
   // W2^T shadow copies for the backward row pass: rebuilt from the parameters once per update (they may have been written from
   // outside: upload, checkpoint), then kept current by every Adam step of the update
+  static const char* nofuse = getenv("MPPO_NO_FUSED");
+  const bool fused_path = fused_supported(c.net, batch) && !(nofuse && nofuse[0] == '1');
   const bool use_shadow = fused_supported(c.net, batch) && shadow_enabled();
   ShadowRef shadow = make_shadow_ref(c.net, gb);
   if (use_shadow) {
@@ -277,15 +285,35 @@ static int32_t do_learn(mppo_engine* e, hipStream_t s) {
   for (int ep = 0; ep < e->E; ++ep) {
     for (int k = 0; k < e->M; ++k) {
       const int st = ep * e->M + k;
-      const bool single = !use_comm;  // then the reduce kernel's sums of squares are those of the final gradient
+      const bool single = !use_comm && !use_peer;  // then the reduce kernel's sums of squares are those of the final gradient
       XPre pre{(st & 1) ? gb.xmb2 : gb.xmb, (st & 1) ? gb.xmb : gb.xmb2,
                st + 1 < EM ? e->perm + (size_t)((st + 1) / e->M) * e->B + (size_t)((st + 1) % e->M) * e->mb : nullptr};
-      MPPO_TRY(minibatch_grad(c.net, e->params, batch, e->perm + (size_t)ep * e->B + (size_t)k * e->mb, e->mb, e->adv_stats + 2 * st, inv_count, c.loss, e->grad,
+      const int* idx = e->perm + (size_t)ep * e->B + (size_t)k * e->mb;
+      if (use_peer) {
+        // the local gradient goes straight into this rank's exchange buffer (the weight-gradient launch signals the peers; the
+        // layer-wise path's gradient is copied there by a publish kernel), and the Adam launch reduces this rank's slice,
+        // broadcasts it, waits for the others' and applies the update: the same three launches as on one GPU
+        const PeerStep ps = peer_step(e->peer, st);
+        if (fused_path) {
+          MPPO_TRY(minibatch_grad(c.net, e->params, batch, idx, e->mb, e->adv_stats + 2 * st, inv_count, c.loss, peer_pub(e->peer), e->losses + 4 * st, nullptr, gb, s,
+                                  use_pre ? &pre : nullptr, &ps));
+        } else {
+          MPPO_TRY(minibatch_grad(c.net, e->params, batch, idx, e->mb, e->adv_stats + 2 * st, inv_count, c.loss, e->grad, e->losses + 4 * st, nullptr, gb, s, nullptr));
+          MPPO_TRY(peer_publish(e->peer, e->grad, (size_t)e->P, st, s));
+        }
+        MPPO_TRY(clip_adam((size_t)e->P, e->params, e->adam_m, e->adam_v, peer_red(e->peer), e->count, st, ac, const_cast<float*>(peer_red(e->peer)) + e->P, true, s,
+                           use_shadow ? &shadow : nullptr, &ps));
+        continue;
+      }
+      MPPO_TRY(minibatch_grad(c.net, e->params, batch, idx, e->mb, e->adv_stats + 2 * st, inv_count, c.loss, e->grad,
                               e->losses + 4 * st, single ? e->adam_ws : nullptr, gb, s, use_pre ? &pre : nullptr));  // train.py:246-247
       if (!single) MPPO_TRY(comm_allreduce_f32(e->comm, e->grad, (size_t)e->P, s));
       MPPO_TRY(clip_adam((size_t)e->P, e->params, e->adam_m, e->adam_v, e->grad, e->count, st, ac, e->adam_ws, single, s, use_shadow ? &shadow : nullptr));  // train.py:248
+      static const int extra = [] { const char* v = getenv("MPPO_EXTRA_LAUNCHES"); return v ? atoi(v) : 0; }();  // timing experiment: what does ONE more trivial launch cost here?
+      for (int x = 0; x < extra; ++x) hipLaunchKernelGGL(advance_counters_kernel, dim3(1), dim3(64), 0, s, e->count, 0);
     }
   }
+  if (use_peer) MPPO_TRY(peer_advance(e->peer, EM, s));
   hipLaunchKernelGGL(advance_counters_kernel, dim3(1), dim3(64), 0, s, e->count, EM);
   MPPO_CHECK_LAUNCH("advance_counters_kernel");
   // carry last_obs into slot 0 of the next rollout (RunnerState.last_obs, train.py:174,279)
@@ -318,7 +346,7 @@ extern "C" int32_t mppo_engine_create(const mppo_model_t* m, const mppo_engine_c
   fill_dims(e);
   const size_t need = layout(e, true);
   if (arena_bytes < need) { delete e; return fail(MPPO_ENOMEM, "mppo_engine_create: arena %zu < %zu bytes", arena_bytes, need); }
-  e->comm = nullptr; e->graph = nullptr; e->graph_failed = false; e->was_reset = false;
+  e->comm = nullptr; e->peer = nullptr; e->graph = nullptr; e->graph_failed = false; e->was_reset = false; e->graph_agreed = false;
   *out = e;
   return MPPO_OK;
 }
@@ -327,6 +355,7 @@ extern "C" int32_t mppo_engine_destroy(mppo_engine_t* e) {
   if (!e) return MPPO_OK;
   if (e->graph) graph_destroy(e->graph);
   if (e->comm) comm_destroy(e->comm);
+  if (e->peer) peer_destroy(e->peer);
   delete e;
   return MPPO_OK;
 }
@@ -372,7 +401,8 @@ extern "C" int32_t mppo_engine_reset(mppo_engine_t* e, void* stream) {
 static int32_t require_ready(mppo_engine_t* e, bool needs_comm) {
   MPPO_REQUIRE(e, "null engine");
   if (!e->was_reset) return fail(MPPO_ESTATE, "engine: call mppo_engine_reset before stepping");
-  if (needs_comm && e->cfg.world_size > 1 && !e->comm) return fail(MPPO_ESTATE, "engine: world_size = %d but mppo_engine_comm_init was not called", e->cfg.world_size);
+  if (needs_comm && e->cfg.world_size > 1 && !e->comm && !peer_connected(e->peer))
+    return fail(MPPO_ESTATE, "engine: world_size = %d but neither mppo_engine_comm_init nor mppo_engine_peer_connect was called", e->cfg.world_size);
   return MPPO_OK;
 }
 
@@ -392,14 +422,31 @@ extern "C" int32_t mppo_engine_graph_active(const mppo_engine_t* e, int32_t* out
   return MPPO_OK;
 }
 
-extern "C" int32_t mppo_engine_update(mppo_engine_t* e, void* stream) {
-  MPPO_TRY(require_ready(e, true));
-  hipStream_t s = static_cast<hipStream_t>(stream);
-  // The RCCL all-reduces are captured into the graph together with the kernels (MPPO_GRAPH_COMM=0: multi-rank updates
-  // run as eager launches instead).  Every rank takes the same decision: the setting is an environment variable of the
-  // job and a capture failure is a property of the installation, not of the rank.
-  static const bool graph_comm = [] { const char* v = getenv("MPPO_GRAPH_COMM"); return !(v && v[0] == '0'); }();
-  const bool with_comm = e->cfg.world_size > 1 || e->comm;
+// RCCL path, first update of several ranks: the ranks agree on whether they replay a graph.  A capture that failed on ONE rank would
+// leave that rank launching eagerly while the others replay captured collectives; so every rank contributes its outcome to one eager
+// all-reduce and all of them fall back to eager launches if any capture failed.  (The peer-to-peer path needs no such agreement:
+// its exchange is made of ordinary kernels and flags, the same whether a rank replays or launches them.)
+static int32_t agree_on_graph(mppo_engine_t* e, hipStream_t s) {
+  const float mine = e->graph ? 0.f : 1.f;
+  MPPO_CHECK_HIP(hipMemcpyAsync(e->flag_ws, &mine, 4, hipMemcpyHostToDevice, s));
+  MPPO_TRY(comm_allreduce_f32(e->comm, e->flag_ws, 1, s));
+  float sum = 0.f;
+  MPPO_CHECK_HIP(hipMemcpyAsync(&sum, e->flag_ws, 4, hipMemcpyDeviceToHost, s));
+  MPPO_CHECK_HIP(hipStreamSynchronize(s));
+  if (sum != 0.f && e->graph) { graph_destroy(e->graph); e->graph = nullptr; }
+  if (sum != 0.f) e->graph_failed = true;
+  e->graph_agreed = true;
+  return MPPO_OK;
+}
+
+static int32_t prepare_update(mppo_engine_t* e, hipStream_t s, bool* replay) {
+  // RCCL path: the all-reduces are captured into the graph together with the kernels only on request (MPPO_GRAPH_COMM=1; it has never
+  // run on more than one GPU), by default several ranks with an RCCL communicator launch eagerly.  The peer-to-peer path is captured
+  // like any sequence of kernels.
+  const char* gc = getenv("MPPO_GRAPH_COMM");  // (read at every call: a process may hold engines of both kinds)
+  const bool graph_comm = gc && gc[0] == '1';
+  const bool with_peer = peer_connected(e->peer);
+  const bool with_comm = !with_peer && (e->cfg.world_size > 1 || e->comm);
   const bool want_graph = e->cfg.use_graph && !e->graph_failed && s != nullptr && (!with_comm || graph_comm);
   if (want_graph) {
     if (!e->graph) {
@@ -412,9 +459,57 @@ extern "C" int32_t mppo_engine_update(mppo_engine_t* e, void* stream) {
       } else {
         e->graph_failed = true;
       }
+      if (with_comm && e->cfg.world_size > 1 && !e->graph_agreed) MPPO_TRY(agree_on_graph(e, s));
     }
-    if (e->graph) return graph_launch(e->graph, s);
   }
+  *replay = want_graph && e->graph;
+  return MPPO_OK;
+}
+
+extern "C" int32_t mppo_engine_update(mppo_engine_t* e, void* stream) {
+  MPPO_TRY(require_ready(e, true));
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  bool replay = false;
+  MPPO_TRY(prepare_update(e, s, &replay));
+  if (replay) return graph_launch(e->graph, s);
   MPPO_TRY(do_rollout(e, s));
   return do_learn(e, s);
+}
+
+// Everything mppo_engine_update does BEFORE it enqueues work: the one-time capture of the update into a hipGraph (which also loads
+// the kernels' code objects).  With several ranks the caller puts a host-side barrier between this call and the first update, so
+// that the ranks start their first exchange within milliseconds of each other instead of a capture time apart.
+extern "C" int32_t mppo_engine_prepare(mppo_engine_t* e, void* stream) {
+  MPPO_TRY(require_ready(e, true));
+  bool replay = false;
+  return prepare_update(e, static_cast<hipStream_t>(stream), &replay);
+}
+
+// ---- peer-to-peer gradient exchange (peer.h): every rank exports its exchange buffer, the caller gathers the 64-byte handles of all
+// ranks (rank order) and hands them to every rank; a host-side barrier between the last connect and the first update is the caller's.
+extern "C" int32_t mppo_engine_peer_export(mppo_engine_t* e, void* handle64) {
+  MPPO_REQUIRE(e && handle64, "mppo_engine_peer_export: null argument");
+  MPPO_REQUIRE(!e->peer, "mppo_engine_peer_export: already exported");
+  MPPO_REQUIRE(e->cfg.world_size >= 2, "mppo_engine_peer_export: one rank has nobody to exchange with");
+  return peer_create(e->cfg.rank, e->cfg.world_size, (size_t)e->P, (size_t)e->E * e->M * 2, &e->peer, handle64);
+}
+
+extern "C" int32_t mppo_engine_peer_connect(mppo_engine_t* e, const void* handles, int32_t shared_device) {
+  MPPO_REQUIRE(e && handles && e->peer, "mppo_engine_peer_connect: call mppo_engine_peer_export first");
+  MPPO_REQUIRE(!e->graph, "mppo_engine_peer_connect: the update has been captured already");
+  return peer_connect(e->peer, handles, shared_device);
+}
+
+extern "C" int32_t mppo_engine_comm_mode(const mppo_engine_t* e, int32_t* out) {
+  MPPO_REQUIRE(e && out, "mppo_engine_comm_mode: null argument");
+  *out = peer_connected(e->peer) ? 2 + peer_mode(e->peer) : (e->comm ? 1 : 0);
+  return MPPO_OK;
+}
+
+extern "C" int32_t mppo_engine_peer_status(const mppo_engine_t* e, int32_t* timed_out, int32_t* info8) {
+  MPPO_REQUIRE(e && timed_out, "mppo_engine_peer_status: null argument");
+  *timed_out = 0;
+  if (info8) for (int k = 0; k < 8; ++k) info8[k] = 0;
+  if (!e->peer) return MPPO_OK;
+  return peer_status(e->peer, timed_out, info8);
 }

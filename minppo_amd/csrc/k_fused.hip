@@ -21,6 +21,7 @@
 
 #include "mppo_common.h"
 #include "ppo_layout.h"
+#include "wgrad.h"
 
 namespace mppo {
 
@@ -810,7 +811,8 @@ size_t fused_smem_bytes(int O, int A, int H) {
 bool fused_supported(const mppo_net_t& net, const mppo_batch_t& b) {
   return net_layers(net) == 2 && net.H % 32 == 0 && net.H >= 32 && net.H <= 256 && net.A <= 32 && b.obs_ld == net.OP && (net.OP % 4) == 0 &&
          (reinterpret_cast<uintptr_t>(b.obs) & 15) == 0 && fused_smem_bytes(net.O, net.A, net.H) <= 160 * 1024 &&
-         (param_layout(net).c_w2 % 4) == 0;  // float4 rows of W2 in the backward product
+         (param_layout(net).c_w2 % 4) == 0 &&  // float4 rows of W2 in the backward product
+         wgrad_tile_bound(net.O, net.A, net.H) <= kSqSlots;  // the weight-gradient launch that follows the row pass: one workgroup per 32 x 32 tile, at most kSqSlots
 }
 
 bool fused_rollout_supported(const mppo_net_t& net, const float* obs, int obs_ld) {

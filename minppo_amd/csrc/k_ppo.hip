@@ -10,6 +10,7 @@
 #include "mppo_common.h"
 #include "ppo_layout.h"
 #include "wgrad.h"
+#include "peer.h"
 
 namespace mppo {
 
@@ -369,9 +370,21 @@ __device__ __forceinline__ void shadow_write_tile(const ShadowRef& sh, const flo
   }
 }
 
-__global__ void __launch_bounds__(256) adam_kernel(size_t P, float* __restrict__ p, float* __restrict__ m, float* __restrict__ v,
+// PEER (several ranks, peer.h): `g` / `partial` are the reduced gradient and its sums of squares in this rank's exchange buffer.  The
+// launch first reduces and broadcasts this rank's slice of the gradient (phase bit 1: workgroups < nA), then waits until every slice
+// has arrived (phase bit 2) and applies the update.  One launch does both on the GPU (no workgroup waits for a workgroup of its own
+// launch that has not had its turn: phase A comes first in every workgroup); the CPU emulator, which runs workgroups one after
+// another, launches the two phases separately.
+// The PEER instantiation is held to 64 registers: its workgroups WAIT (phase B) while other kernels must still find room on the same
+// CUs when several ranks share one GPU - a weight-gradient workgroup needs 432 of a SIMD's 512 registers per lane (csrc/peer.h).
+template <bool PEER>
+__global__ void __launch_bounds__(256, PEER ? 8 : 1) adam_kernel(size_t P, float* __restrict__ p, float* __restrict__ m, float* __restrict__ v,
                                                    const float* __restrict__ g, const float* __restrict__ partial, const int* __restrict__ count_base,
-                                                   int step_offset, mppo_adam_cfg_t c, ShadowRef sh) {
+                                                   int step_offset, mppo_adam_cfg_t c, ShadowRef sh, PeerStep ps, int phase) {
+  if (PEER) {
+    if ((phase & 1) && (int)blockIdx.x < ps.v.nA) peer_reduce_piece(ps.v, ps.epoch[0] + ps.step + 1, (int)blockIdx.x, !(phase & 4));
+    if (!(phase & 2)) return;
+  }
   // ---- addresses depend on the kernel arguments only: the four arrays are REQUESTED FIRST, and the clip scale, learning rate and
   // bias corrections (a wave reduction, a square root, two powf: ~0.7 us of scalar-ish work on a lone wave) are computed while they
   // fly.  (In program order the other way round, the loads left only after all of that: two memory latencies and the powf in series.)
@@ -407,14 +420,24 @@ __global__ void __launch_bounds__(256) adam_kernel(size_t P, float* __restrict__
   }
   float4 gq = make_float4(0.f, 0.f, 0.f, 0.f), mq = gq, vq = gq, pq = gq;
   if (have4) {
-    gq = *reinterpret_cast<const float4*>(g + i); mq = *reinterpret_cast<const float4*>(m + i); vq = *reinterpret_cast<const float4*>(v + i);
+    if (!PEER) gq = *reinterpret_cast<const float4*>(g + i);
+    mq = *reinterpret_cast<const float4*>(m + i); vq = *reinterpret_cast<const float4*>(v + i);
     pq = *reinterpret_cast<const float4*>(p + i);
   }
   // every wave adds the same kSqSlots (= 512) partials in the same order (eight per lane, fixed reduction tree):
   // bitwise-identical clip scale everywhere without a second pass
   const int ln = threadIdx.x & 63;
-  const float ss = wave_sum(((partial[ln] + partial[ln + 64]) + (partial[ln + 128] + partial[ln + 192])) +
-                            ((partial[ln + 256] + partial[ln + 320]) + (partial[ln + 384] + partial[ln + 448])));
+  float pr[8];
+  if (PEER) {
+    if (!(phase & 4)) peer_wait_reduced(ps.v, ps.epoch[0] + ps.step + 1);  // (the moments and the parameters are in flight meanwhile)
+    if (have4) gq = sys_load_f4(g, i * 4);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) pr[k] = sys_load_f32(partial + ln + 64 * k);
+  } else {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) pr[k] = partial[ln + 64 * k];
+  }
+  const float ss = wave_sum(((pr[0] + pr[1]) + (pr[2] + pr[3])) + ((pr[4] + pr[5]) + (pr[6] + pr[7])));
   const float norm = sqrtf(ss);
   const float scale = norm < c.max_grad_norm ? 1.f : c.max_grad_norm / norm;
   const int count = count_base[0] + step_offset;
@@ -453,7 +476,7 @@ __global__ void __launch_bounds__(256) adam_kernel(size_t P, float* __restrict__
     wt_store(p, i, make_float4(pn[0], pn[1], pn[2], pn[3]));
   } else {
     for (size_t e = i; e < P; ++e) {  // (a parameter count that is not a multiple of four: the stand-alone entry point only)
-      const float gi = g[e] * scale;
+      const float gi = (PEER ? sys_load_f32(g + e) : g[e]) * scale;
       const float mi = c.b1 * m[e] + (1.f - c.b1) * gi;
       const float vi = c.b2 * v[e] + (1.f - c.b2) * gi * gi;
       m[e] = mi; v[e] = vi;
@@ -622,12 +645,14 @@ int32_t minibatch_rowpass(const mppo_net_t& net, const float* params, const mppo
 }
 
 int32_t minibatch_grad(const mppo_net_t& net, const float* params, const mppo_batch_t& batch, const int* idx, int mb, const float* adv_stat,
-                       float inv_count, const mppo_loss_cfg_t& lc, float* grad, float* loss4, float* sq_partial, const GradBufs& gbuf, hipStream_t stream, const XPre* pre) {
+                       float inv_count, const mppo_loss_cfg_t& lc, float* grad, float* loss4, float* sq_partial, const GradBufs& gbuf, hipStream_t stream, const XPre* pre,
+                       const PeerStep* peer) {
   const ParamLayout L = param_layout(net);
   const int H = net.H, A = net.A, AP = gbuf.f.AP, DP = AP + 4, O = net.O;
   int nblk = 0;
   bool fused = false;
   MPPO_TRY(minibatch_rowpass(net, params, batch, idx, mb, adv_stat, inv_count, lc, gbuf, &nblk, &fused, stream, pre));
+  MPPO_REQUIRE(fused || !peer, "minibatch_grad: the layer-wise path writes a plain gradient (the engine publishes it with peer_publish)");
   const float* xq = (pre && fused) ? pre->cur : gbuf.xmb;  // the step's observation rows, k-quad layout (the layer-wise path gathers for itself)
   const float ent_weight = (float)mb * inv_count;
   static const char* old_wgrad = getenv("MPPO_OLD_WGRAD");  // (no longer selectable with the fused row pass: its outputs are k-quad operands)
@@ -655,7 +680,7 @@ int32_t minibatch_grad(const mppo_net_t& net, const float* params, const mppo_ba
     { static const char* e8 = getenv("MPPO_WGRAD_DBG"); if (e8 && (atoi(e8) & 8)) w.count = 4; }  // timing experiment: big problems only
     MPPO_TRY(wgrad_plan(w, mb));
     MPPO_REQUIRE(wgrad_supported(w), "minibatch_grad: weight-gradient launch not applicable (%d tiles)", w.ntiles);
-    return wgrad_launch(w, net.bf16 != 0, stream);
+    return wgrad_launch(w, net.bf16 != 0, stream, peer);  // (peer: `grad` is the rank's exchange buffer, the launch signals the peers)
   }
   {
   GemmBatch gb{};
@@ -726,7 +751,8 @@ int32_t shadow_refresh(const mppo_net_t& net, const float* params, const GradBuf
 }
 
 int32_t clip_adam(size_t P, float* params, float* m, float* v, const float* grad, const int* count_base, int step_offset, const mppo_adam_cfg_t& cfg,
-                  float* ws, bool have_sumsq, hipStream_t stream, const ShadowRef* shadow) {
+                  float* ws, bool have_sumsq, hipStream_t stream, const ShadowRef* shadow, const PeerStep* peer) {
+  MPPO_REQUIRE(!peer || have_sumsq, "clip_adam: with the peer exchange the sums of squares come with the reduced gradient");
   if (!have_sumsq) {
     hipLaunchKernelGGL(sumsq_kernel, dim3(kNormBlocks), dim3(256), 0, stream, P, grad, ws);
     MPPO_CHECK_LAUNCH("sumsq_kernel");
@@ -750,8 +776,32 @@ int32_t clip_adam(size_t P, float* params, float* m, float* v, const float* grad
   }
   const int flat_blocks = cdiv((long)((P + 3) / 4) - owned4, 256);
   sh.flat_blocks = flat_blocks;
-  hipLaunchKernelGGL(adam_kernel, dim3(flat_blocks + tile_blocks), dim3(256), 0, stream, P, params, m, v, grad, ws, count_base, step_offset, cfg,
-                     sh);
+  if (peer) {
+    MPPO_REQUIRE(flat_blocks + tile_blocks >= peer->v.nA, "clip_adam: %d workgroups cannot reduce %d pieces of the gradient", flat_blocks + tile_blocks, peer->v.nA);
+    const dim3 gridA(peer->v.nA), gridB(flat_blocks + tile_blocks);
+#ifdef MPPO_EMU  // workgroups run one after another: a workgroup of phase B would wait for a piece whose workgroup comes after it
+    const int mode = 1;
+#else
+    const int mode = peer->mode;
+#endif
+    if (mode == 2) {
+      // several ranks on ONE GPU: nothing that occupies more than one wave may wait, or the peer's kernels find no room beside the
+      // waiting workgroups.  A one-wave kernel does each of the two waits; the reduction and the update run without waiting.
+      MPPO_TRY(peer_wait_launch(*peer, 1, stream));
+      hipLaunchKernelGGL(adam_kernel<true>, gridA, dim3(256), 0, stream, P, params, m, v, grad, ws, count_base, step_offset, cfg, sh, *peer, 1 | 4);
+      MPPO_TRY(peer_wait_launch(*peer, 2, stream));
+      hipLaunchKernelGGL(adam_kernel<true>, gridB, dim3(256), 0, stream, P, params, m, v, grad, ws, count_base, step_offset, cfg, sh, *peer, 2 | 4);
+    } else if (mode == 1) {  // two launches, each waiting for itself (the emulator's form; MPPO_PEER_MODE=split on the GPU: measurements)
+      hipLaunchKernelGGL(adam_kernel<true>, gridA, dim3(256), 0, stream, P, params, m, v, grad, ws, count_base, step_offset, cfg, sh, *peer, 1);
+      hipLaunchKernelGGL(adam_kernel<true>, gridB, dim3(256), 0, stream, P, params, m, v, grad, ws, count_base, step_offset, cfg, sh, *peer, 2);
+    } else {
+      hipLaunchKernelGGL(adam_kernel<true>, gridB, dim3(256), 0, stream, P, params, m, v, grad, ws, count_base, step_offset, cfg, sh, *peer, 3);
+    }
+    MPPO_CHECK_LAUNCH("adam_kernel<peer>");
+    return MPPO_OK;
+  }
+  hipLaunchKernelGGL(adam_kernel<false>, dim3(flat_blocks + tile_blocks), dim3(256), 0, stream, P, params, m, v, grad, ws, count_base, step_offset, cfg,
+                     sh, PeerStep{}, 0);
   MPPO_CHECK_LAUNCH("adam_kernel");
   return MPPO_OK;
 }

@@ -30,6 +30,7 @@
 #include "mppo_common.h"
 #include "ppo_layout.h"
 #include "wgrad.h"
+#include "peer.h"
 
 namespace mppo {
 
@@ -40,8 +41,16 @@ constexpr int WSTAGE = 8;  // quads per stage = 32 k
 constexpr float kLog2PiW = 1.8378770664093453f;
 constexpr int kThinQuads = 1280;  // LDS quads for a thin band: Kq x rows (20 KB)
 
-template <bool BF16>
-__global__ void __launch_bounds__(WTHREADS) wgrad_kernel(WgradArgs a) {
+// PEER: the gradient goes into this rank's exchange buffer (peer.h) with system-scope write-through stores and the launch ends with the
+// completion signal to the peers; the clip's sums of squares are then those of the REDUCED gradient and are not computed here.
+template <bool PEER>
+__device__ __forceinline__ void gstore(float* p, float v) {
+  if (PEER) sys_store_f32(p, v);
+  else *p = v;
+}
+
+template <bool BF16, bool PEER = false>
+__global__ void __launch_bounds__(WTHREADS) wgrad_kernel(WgradArgs a, PeerStep ps) {
   __shared__ float red[WWAVES][WTILE * (WTILE + 1)];
   __shared__ float cred[WWAVES][WTILE];
   __shared__ float s_red[WWAVES];
@@ -170,7 +179,7 @@ __global__ void __launch_bounds__(WTHREADS) wgrad_kernel(WgradArgs a) {
 #pragma unroll
     for (int k = 0; k < WWAVES; ++k) v += red[k][row * (WTILE + 1) + col];
     if (m0 + row < p.M && n0 + col < p.N) {
-      a.grad[p.off_w + (size_t)(m0 + row) * p.N + n0 + col] = v;
+      gstore<PEER>(&a.grad[p.off_w + (size_t)(m0 + row) * p.N + n0 + col], v);
       sq += v * v;
     }
   }
@@ -180,7 +189,7 @@ __global__ void __launch_bounds__(WTHREADS) wgrad_kernel(WgradArgs a) {
       float v = 0.f;
 #pragma unroll
       for (int k = 0; k < WWAVES; ++k) v += tred[k][rr][t & 31];
-      a.grad[p.off_w + (size_t)(p.thin_row0 + rr) * p.N + col] = v;
+      gstore<PEER>(&a.grad[p.off_w + (size_t)(p.thin_row0 + rr) * p.N + col], v);
       sq += v * v;
     }
   }
@@ -188,7 +197,7 @@ __global__ void __launch_bounds__(WTHREADS) wgrad_kernel(WgradArgs a) {
     float v = 0.f;
 #pragma unroll
     for (int k = 0; k < WWAVES; ++k) v += cred[k][t];
-    a.grad[p.off_b + n0 + t] = v;
+    gstore<PEER>(&a.grad[p.off_b + n0 + t], v);
     sq += v * v;
   }
   // ---- tile 0: second level of the partial sums (s_part was written before the K loop; the barrier above orders it) ----
@@ -202,7 +211,7 @@ __global__ void __launch_bounds__(WTHREADS) wgrad_kernel(WgradArgs a) {
     __syncthreads();
     if (t < a.A) {
       const float d = s_col[4 + t] - a.ent_coef * a.ent_weight;
-      a.grad[a.ls_off + t] = d;
+      gstore<PEER>(&a.grad[a.ls_off + t], d);
       sq += d * d;
     }
     if (t == 0 && a.loss4) {
@@ -212,7 +221,7 @@ __global__ void __launch_bounds__(WTHREADS) wgrad_kernel(WgradArgs a) {
       a.loss4[2] = s_col[0];
       a.loss4[3] = ent;
     }
-    if (t < a.npad) for (int k = 0; k < a.pad_cnt[t]; ++k) a.grad[a.pad_off[t] + k] = 0.f;  // alignment words of the flat layout
+    if (t < a.npad) for (int k = 0; k < a.pad_cnt[t]; ++k) gstore<PEER>(&a.grad[a.pad_off[t] + k], 0.f);  // alignment words of the flat layout
     if (a.sq_partial)  // slots of workgroups that do not exist
       for (int e = a.ntiles + t; e < kSqSlots; e += WTHREADS) a.sq_partial[e] = 0.f;  // (slots are indexed by workgroup id)
   }
@@ -225,6 +234,7 @@ __global__ void __launch_bounds__(WTHREADS) wgrad_kernel(WgradArgs a) {
     for (int k = 0; k < WWAVES; ++k) s += s_red[k];
     a.sq_partial[blockIdx.x] = s;
   }
+  if (PEER) peer_publish_done(ps.v, ps.epoch[0] + ps.step + 1, gridDim.x);  // every store of the gradient is above this line
 }
 
 bool wgrad_supported(const WgradArgs& a) {
@@ -232,6 +242,7 @@ bool wgrad_supported(const WgradArgs& a) {
   for (int k = 0; k < a.count; ++k) {
     const WgradProb& p = a.p[k];
     if (p.tiles_m > 256 || p.tiles_n > 256) return false;  // (8 bits each in WgradArgs::order)
+    if (p.a_split && p.thin_rows > 0) return false;          // the thin band's staging load reads A in plain column order
     if ((reinterpret_cast<uintptr_t>(p.A) & 15) || (reinterpret_cast<uintptr_t>(p.B) & 15) || p.acols < p.M || p.bcols < p.N || p.acols > p.lda || p.bcols > p.ldb)
       return false;
   }
@@ -304,16 +315,24 @@ int32_t wgrad_plan(WgradArgs& a, int mb) {
   return MPPO_OK;
 }
 
-int32_t wgrad_launch(const WgradArgs& a_in, bool bf16, hipStream_t stream) {
+int32_t wgrad_launch(const WgradArgs& a_in, bool bf16, hipStream_t stream, const PeerStep* peer) {
   WgradArgs a = a_in;
+  if (peer) {
+    MPPO_REQUIRE(!a.sq_partial, "wgrad_launch: with the peer exchange the sums of squares are those of the reduced gradient (sq_partial must be null)");
+    if (bf16) hipLaunchKernelGGL((wgrad_kernel<true, true>), dim3(a.ntiles), dim3(WTHREADS), 0, stream, a, *peer);
+    else hipLaunchKernelGGL((wgrad_kernel<false, true>), dim3(a.ntiles), dim3(WTHREADS), 0, stream, a, *peer);
+    MPPO_CHECK_LAUNCH("wgrad_kernel<peer>");
+    return MPPO_OK;
+  }
+  const PeerStep nops{};
   static const int dbg = [] { const char* e = getenv("MPPO_WGRAD_DBG"); return e ? atoi(e) : 0; }();
   a.dbg = dbg;
   MPPO_REQUIRE(wgrad_supported(a), "wgrad_launch: operands must be 16-byte aligned k-quad buffers, at most %d tiles", kSqSlots);
-  if (bf16) hipLaunchKernelGGL(wgrad_kernel<true>, dim3(a.ntiles), dim3(WTHREADS), 0, stream, a);
-  else hipLaunchKernelGGL(wgrad_kernel<false>, dim3(a.ntiles), dim3(WTHREADS), 0, stream, a);
+  if (bf16) hipLaunchKernelGGL((wgrad_kernel<true, false>), dim3(a.ntiles), dim3(WTHREADS), 0, stream, a, nops);
+  else hipLaunchKernelGGL((wgrad_kernel<false, false>), dim3(a.ntiles), dim3(WTHREADS), 0, stream, a, nops);
   if (dbg & 4) {  // timing experiment: the same launch again, operands now warm in the L2s
-    if (bf16) hipLaunchKernelGGL(wgrad_kernel<true>, dim3(a.ntiles), dim3(WTHREADS), 0, stream, a);
-    else hipLaunchKernelGGL(wgrad_kernel<false>, dim3(a.ntiles), dim3(WTHREADS), 0, stream, a);
+    if (bf16) hipLaunchKernelGGL((wgrad_kernel<true, false>), dim3(a.ntiles), dim3(WTHREADS), 0, stream, a, nops);
+    else hipLaunchKernelGGL((wgrad_kernel<false, false>), dim3(a.ntiles), dim3(WTHREADS), 0, stream, a, nops);
   }
   MPPO_CHECK_LAUNCH("wgrad_kernel");
   return MPPO_OK;

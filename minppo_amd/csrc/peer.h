@@ -1,0 +1,175 @@
+// peer.h — the ranks' gradient exchange WITHOUT a collective library: every rank (one process per GPU) owns one
+// exchange buffer in fine-grained device memory, exported with hipIpcGetMemHandle and mapped by every peer of the node
+// (hipIpcOpenMemHandle: a peer GPU's HBM over xGMI, or - several ranks on ONE GPU, how the path is tested on a one-GPU box - the same
+// HBM).  Replaces RCCL's all-reduce of the [P] gradient per optimizer step (the reference has no data parallelism at all:
+// minppo/train.py:136,140 vmap only) by a two-hop exchange fused into the kernels that stand on either side of it:
+//
+//   wgrad_kernel<.., PEER>   writes the rank's local gradient into `pub` of its own buffer with system-scope write-through stores; the
+//                            LAST workgroup to finish (local arrival counter) raises wg_done[rank] in every peer's buffer.
+//   adam_kernel<PEER>        phase A (the first nA workgroups): wait for every peer's wg_done, PULL slice `rank` of every rank's
+//                            `pub` (1/G of the gradient from each of G - 1 peers: all links busy, P/G floats per link), add the G
+//                            contributions in rank order, PUSH the reduced slice and its sum of squares into `red` of EVERY rank's
+//                            buffer, raise red_done there.  Phase B (every workgroup): wait for all G * nA red_done words, then
+//                            clip_by_global_norm + adam (train.py:115-124,248) on the reduced gradient in its OWN buffer.
+//
+// A slice is reduced ONCE, by its owner, and broadcast: the replicas see bit-identical gradients by construction.  Two hops of
+// latency and 2 P/G floats per link and step (RCCL's ring: 2 (G-1) hops); no extra launch, no host involvement, capturable in the
+// hipGraph like any kernel.  Flags are epochs (optimizer steps since the buffers were created, a device word advanced once per
+// update): nothing is ever reset, a flag can be waited for with >=.  Reuse is safe with single buffers: a rank reaches wgrad of
+// step s + 1 only after its adam of step s, which waited for every owner's reduction of step s, i.e. for the last reader of
+// every `pub`; and an owner pushes step s + 1 into `red` only after every peer's wgrad of step s + 1, i.e. after every reader of
+// step s's `red` has finished.  Every spin is bounded (time limit -> error word, the kernel runs to its end with garbage).
+#pragma once
+#include <wave_ops.h>
+
+#include "wgrad.h"
+
+namespace mppo {
+
+constexpr int kPeerMaxRanks = 8;
+constexpr int kPeerThreads = 256;  // threads of a workgroup that reduces a piece (= adam_kernel's)
+
+struct PeerHdr {
+  int wg_done[kPeerMaxRanks][16];   // [q][0]: epoch of rank q's last complete local gradient (one 64-byte line per writer)
+  int adv_done[kPeerMaxRanks][16];  // [q][0]: update epoch of rank q's published advantage sums
+  int red_done[kSqSlots];           // [q * nA + b]: epoch of piece b of slice q in `red`
+  int arrive;                       // fan-in of this rank's weight-gradient workgroups (monotonic, wraps)
+  int error;                        // != 0: a wait ran into its time limit (the run is invalid)
+  int epoch[2];                     // optimizer steps / updates completed since creation (peer_advance_kernel)
+  int error_info[4];                // the first wait that timed out: kind (1 wg_done, 2 red_done, 3 adv_done), index, epoch waited for, value seen
+  int pad[56];
+};
+static_assert(sizeof(PeerHdr) % 256 == 0, "the regions behind the header stay 256-byte aligned");
+
+struct PeerView {  // kernel argument: the G exchange buffers as mapped in THIS process
+  unsigned char* base[kPeerMaxRanks];
+  int rank, world;
+  int nA, K;    // pieces per slice; float4 per thread and piece (piece = 256 K float4)
+  int P4, S4;   // float4 in the gradient / in a slice
+  unsigned pub_off, red_off, adv_off;  // byte offsets of pub [4 P4], red [4 P4 + kSqSlots], adv [n] doubles
+  unsigned long long limit_ticks;      // time limit of one wait, 100 MHz ticks
+  int poll_rmw;                        // experiment (MPPO_PEER_POLL_RMW=1): poll with a system-scope atomic OR of 0 instead of a load
+};
+
+// what a launch needs to take part: the view, where the epoch lives, and the optimizer step inside the update.
+// mode (host side only): 0 fused - the Adam launch reduces, waits and applies (ranks on distinct GPUs); 1 split - two launches, each
+// waiting for itself; 2 shared - the ranks share a GPU: one-wave wait kernels, nothing else waits (see clip_adam, k_ppo.hip)
+struct PeerStep { PeerView v; const int* epoch; int step; int mode; };
+
+__device__ __forceinline__ PeerHdr* peer_hdr(const PeerView& v, int q) { return reinterpret_cast<PeerHdr*>(v.base[q]); }
+
+// waits until *flag has reached `epoch` (wrap-safe); gives up at the time limit and records it.  Once a wait of this rank has timed
+// out no later one waits at all: a dead peer costs ONE time limit, not one per optimizer step.
+__device__ __forceinline__ void peer_wait(const int* flag, int epoch, PeerHdr* me, unsigned long long limit, int kind, int index, int rmw = 0) {
+  unsigned long long t0 = 0;
+  unsigned spins = 0;
+  int seen;
+  while ((int)((seen = rmw ? sys_poll_rmw(flag) : sys_load_i32(flag)) - epoch) < 0) {
+    if ((spins++ & 127u) == 0) {
+      if (sys_load_i32(&me->error)) return;
+      const unsigned long long now = realtime_ticks();
+      if (t0 == 0) t0 = now;
+      if (now - t0 > limit) {
+        if (agent_fetch_add(&me->error, 1) == 0) { me->error_info[0] = kind; me->error_info[1] = index; me->error_info[2] = epoch; me->error_info[3] = seen; }
+        return;
+      }
+    }
+    spin_pause();
+  }
+}
+
+// End of a launch that wrote this rank's local gradient into `pub` (system-scope stores): called by EVERY thread of EVERY workgroup
+// after its last store.  The last workgroup to arrive tells the peers.
+__device__ __forceinline__ void peer_publish_done(const PeerView& v, int epoch, unsigned nblocks) {
+  drain_stores();
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    PeerHdr* me = peer_hdr(v, v.rank);
+    const unsigned old = (unsigned)agent_fetch_add(&me->arrive, 1);
+    if (old + 1u == (unsigned)epoch * nblocks) {
+#pragma unroll
+      for (int q = 0; q < kPeerMaxRanks; ++q)
+        if (q < v.world && q != v.rank) sys_store_i32(&peer_hdr(v, q)->wg_done[v.rank][0], epoch);
+    }
+  }
+}
+
+// Phase A of the fused exchange: workgroup b < nA (kPeerThreads threads) reduces piece b of slice `rank` and broadcasts it.
+__device__ __forceinline__ void peer_reduce_piece(const PeerView& v, int epoch, int b, bool wait = true) {
+  __shared__ float s_sq[kPeerThreads / 64];
+  const int t = threadIdx.x;
+  PeerHdr* me = peer_hdr(v, v.rank);
+  if (wait && t < v.world && t != v.rank) peer_wait(&me->wg_done[t][0], epoch, me, v.limit_ticks, 1, t, v.poll_rmw);
+  __syncthreads();
+  float sq = 0.f;
+  for (int k = 0; k < v.K; ++k) {
+    const int s4 = (b * v.K + k) * kPeerThreads + t, i4 = v.rank * v.S4 + s4;  // float4 index in the slice / in the gradient
+    if (s4 < v.S4 && i4 < v.P4) {
+      // the G contributions are added in rank order (one fixed summation chain), four loads in flight at a time (the kernel that
+      // hosts this is held to 64 registers, see adam_kernel)
+      float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+      for (int h = 0; h < kPeerMaxRanks; h += 4) {
+        if (h < v.world) {
+          float4 g[4];
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+            if (h + q < v.world) g[q] = sys_load_f4(v.base[h + q] + v.pub_off, (size_t)i4 * 16);
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+            if (h + q < v.world) {
+              if (h + q == 0) a = g[0];
+              else { a.x += g[q].x; a.y += g[q].y; a.z += g[q].z; a.w += g[q].w; }
+            }
+        }
+      }
+#pragma unroll
+      for (int q = 0; q < kPeerMaxRanks; ++q)
+        if (q < v.world) sys_store_f4(v.base[q] + v.red_off, (size_t)i4 * 16, a);
+      sq += (a.x * a.x + a.y * a.y) + (a.z * a.z + a.w * a.w);
+    }
+  }
+  sq = wave_sum(sq);
+  if ((t & 63) == 0) s_sq[t >> 6] = sq;
+  __syncthreads();
+  if (t == 0) {
+    float s = 0.f;
+    for (int w = 0; w < kPeerThreads / 64; ++w) s += s_sq[w];
+#pragma unroll
+    for (int q = 0; q < kPeerMaxRanks; ++q)
+      if (q < v.world) sys_store_f32(reinterpret_cast<float*>(v.base[q] + v.red_off) + (size_t)4 * v.P4 + v.rank * v.nA + b, s);
+  }
+  drain_stores();
+  __syncthreads();
+  if (t == 0) {
+#pragma unroll
+    for (int q = 0; q < kPeerMaxRanks; ++q)
+      if (q < v.world) sys_store_i32(&peer_hdr(v, q)->red_done[v.rank * v.nA + b], epoch);
+  }
+}
+
+// Phase B: every piece of every slice of this step has arrived in my `red` (called by every thread; a workgroup barrier inside)
+__device__ __forceinline__ void peer_wait_reduced(const PeerView& v, int epoch) {
+  PeerHdr* me = peer_hdr(v, v.rank);
+  if (threadIdx.x < 64)
+    for (int s = threadIdx.x; s < v.world * v.nA; s += 64) peer_wait(&me->red_done[s], epoch, me, v.limit_ticks, 2, s, v.poll_rmw);
+  __syncthreads();
+}
+
+// ---- host side (k_peer.hip) ----
+struct PeerComm;
+int32_t peer_wait_launch(const PeerStep& ps, int kind, hipStream_t s);  // one wave waits for every peer's gradient (1) / every reduced piece (2)
+int32_t peer_create(int rank, int world, size_t P, size_t adv_doubles, PeerComm** out, void* handle64);
+int32_t peer_connect(PeerComm* c, const void* handles, int shared_device);  // world x 64 bytes, rank order; shared_device: several ranks on one GPU
+bool peer_connected(const PeerComm* c);
+void peer_destroy(PeerComm* c);
+PeerStep peer_step(const PeerComm* c, int step);
+int peer_mode(const PeerComm* c);
+float* peer_pub(const PeerComm* c);                 // this rank's local gradient [P] (what the weight-gradient launch writes)
+const float* peer_red(const PeerComm* c);           // the reduced gradient [P] + kSqSlots sums of squares (what Adam reads)
+int32_t peer_publish(const PeerComm* c, const float* grad, size_t P, int step, hipStream_t s);  // a gradient computed elsewhere -> pub + signal
+int32_t peer_allreduce_f64(const PeerComm* c, double* buf, size_t n, hipStream_t s);            // in-place sum over the ranks, once per update
+int32_t peer_advance(const PeerComm* c, int steps, hipStream_t s);                              // end of an update
+int32_t peer_status(const PeerComm* c, int32_t* timed_out, int32_t* info8);                      // synchronises the device; info8 (optional): what timed out + counters
+
+}  // namespace mppo

@@ -156,8 +156,11 @@ struct XPre { const float* cur; float* next; const int* idx_next; };
 int32_t policy_forward(const mppo_net_t& net, const float* params, int n, const float* obs, int obs_ld, const FwdBufs& fb, const float* noise, float* action,
                        float* log_prob, float* value, float* mean_out, hipStream_t stream);
 // sq_partial (optional): per-workgroup sums of squares of the reduced gradient, consumed by clip_adam(have_sumsq = true)
+struct PeerStep;  // peer.h: the ranks' peer-to-peer gradient exchange
+// peer (optional, fused path only): `grad` is this rank's exchange buffer; the weight-gradient launch writes it with system-scope stores and signals the peers
 int32_t minibatch_grad(const mppo_net_t& net, const float* params, const mppo_batch_t& batch, const int* idx, int mb, const float* adv_stat, float inv_count,
-                       const mppo_loss_cfg_t& lc, float* grad, float* loss4, float* sq_partial, const GradBufs& gbuf, hipStream_t stream, const XPre* pre = nullptr);
+                       const mppo_loss_cfg_t& lc, float* grad, float* loss4, float* sq_partial, const GradBufs& gbuf, hipStream_t stream, const XPre* pre = nullptr,
+                       const PeerStep* peer = nullptr);
 // shadow (optional): the W2^T copies to keep in step with the parameters (GradBufs::w2t of the workspace the row pass reads)
 struct ShadowRef {
   float* w2t; int a_w2, c_w2, H;
@@ -172,8 +175,9 @@ __host__ __device__ inline size_t frag_index(int k, int n, int N) {
   const int w = n >> 5, nn = n & 31, j = nn >> 1, tau = nn & 1;
   return (((size_t)S * (N >> 5) + w) * 64 + 16 * kq + j) * 16 + 8 * tau + 4 * g + c;
 }
+// peer (optional): `grad` / `ws` are the reduced gradient and its sums of squares in the exchange buffer; the launch reduces this rank's slice first (peer.h)
 int32_t clip_adam(size_t P, float* params, float* m, float* v, const float* grad, const int* count_base, int step_offset, const mppo_adam_cfg_t& cfg, float* ws,
-                  bool have_sumsq, hipStream_t stream, const ShadowRef* shadow = nullptr);
+                  bool have_sumsq, hipStream_t stream, const ShadowRef* shadow = nullptr, const PeerStep* peer = nullptr);
 int32_t shadow_refresh(const mppo_net_t& net, const float* params, const GradBufs& gbuf, hipStream_t stream);
 inline ShadowRef make_shadow_ref(const mppo_net_t& net, const GradBufs& g) {
   const ParamLayout L = param_layout(net);

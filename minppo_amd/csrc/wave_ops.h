@@ -218,3 +218,28 @@ __device__ __forceinline__ void wt_store(float* base, size_t idx, float4 v) {
   stream_store(base + idx, v);
 #endif
 }
+
+// ---- system-scope accesses for data exchanged between PROCESSES / GPUs (csrc/peer.h: the ranks' gradient exchange through hipIpc
+// mappings).  sc0 sc1 on gfx950: a store writes through to the memory that owns the address (a peer's HBM over xGMI for a mapped
+// peer buffer) and a load bypasses this GPU's L1 and L2.  `base` must be wave-uniform (it becomes the buffer descriptor).
+__device__ __forceinline__ void sys_store_f4(void* base, size_t byte_off, float4 v) {
+  const BufView b = make_buf(static_cast<const float*>(base), 0x7FFFFFFFu);
+  mppo_raw_buffer_store_f32x4(f32x4_native{v.x, v.y, v.z, v.w}, b.r, (int)byte_off, 0, 17);
+}
+__device__ __forceinline__ float4 sys_load_f4(const void* base, size_t byte_off) {
+  const BufView b = make_buf(static_cast<const float*>(base), 0x7FFFFFFFu);
+  const f32x4_native q = mppo_raw_buffer_load_f32x4(b.r, (int)byte_off, 0, 17);
+  return make_float4(q.x, q.y, q.z, q.w);
+}
+__device__ __forceinline__ void sys_store_f32(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+__device__ __forceinline__ float sys_load_f32(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+__device__ __forceinline__ void sys_store_i32(int* p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+__device__ __forceinline__ int sys_load_i32(const int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+__device__ __forceinline__ int sys_poll_rmw(const int* p) { return __hip_atomic_fetch_or(const_cast<int*>(p), 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+__device__ __forceinline__ void sys_store_f64(double* p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+__device__ __forceinline__ double sys_load_f64(const double* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+// every store of this wave has been acknowledged by the memory it went to (inline asm: the compiler may not drop or move it,
+// MI355X_MICROARCH.md "Compiler hazard")
+__device__ __forceinline__ void drain_stores() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+__device__ __forceinline__ void spin_pause() { __builtin_amdgcn_s_sleep(2); }
+__device__ __forceinline__ unsigned long long realtime_ticks() { return __builtin_amdgcn_s_memrealtime(); }  // 100 MHz, constant

@@ -47,8 +47,15 @@ struct WgradArgs {
   int dbg;  // timing experiments only (MPPO_WGRAD_DBG bit mask): 4 launch twice (warm operands), 8 big problems only
 };
 
+// upper bound of the launch's workgroups for a two-hidden-layer network (thin bands not discounted): the fused path is only taken
+// when it fits the kSqSlots tile table (fused_supported, k_fused.hip); wider observation vectors run the layer-wise kernels
+inline int wgrad_tile_bound(int O, int A, int H) {
+  const int tn = (H + 31) / 32, th = (H + 31) / 32, to = (O + 31) / 32;
+  return 2 * th * tn + 2 * to * tn + th * ((A + 31) / 32) + th;
+}
 int32_t wgrad_plan(WgradArgs& a, int mb);  // tile table + K ranges (a.count, a.p[].{M,N} set by the caller)
 bool wgrad_supported(const WgradArgs& a);
-int32_t wgrad_launch(const WgradArgs& a, bool bf16, hipStream_t stream);
+struct PeerStep;  // peer.h
+int32_t wgrad_launch(const WgradArgs& a, bool bf16, hipStream_t stream, const PeerStep* peer = nullptr);
 
 }  // namespace mppo

@@ -266,6 +266,7 @@ class Trainer:
         self.lib.engine_create(self._model, C.byref(self.ecfg), nat.ptr(self.arena), self.arena_bytes, C.byref(self._engine))
         self.P = int(self.lib.param_count(C.byref(self.net)))
         self.updates_done = 0
+        self._prepared = False
         self.set_params_flat(init_flat_params(self.seed, self.O, self.A, self.H, self.L))
 
     @staticmethod
@@ -388,32 +389,113 @@ class Trainer:
         return flat_to_tree(self.params_flat(), self.O, self.A, self.H, self.L)
 
     # -- multi-GPU ---------------------------------------------------------------
-    def init_comm(self) -> None:
-        """Creates the engine's RCCL communicator; the 128-byte id travels through torch.distributed."""
+    def init_comm(self, mode: Optional[str] = None) -> str:
+        """Connects this rank's engine to the other ranks' (one process per GPU, environments sharded, gradients summed
+        per optimizer step).  Two transports, `mode` or $MPPO_ALLREDUCE:
+
+          "peer" (default)  the engine's own exchange through hipIpc-mapped buffers, fused into the weight-gradient and Adam
+                            launches (csrc/peer.h); the 64-byte handles travel through torch.distributed.  Works for ranks on
+                            different GPUs of a node and for ranks that share one GPU.
+          "rccl"            ncclAllReduce on the compute stream; the 128-byte id travels through torch.distributed.
+
+        "peer" falls back to "rccl" when any rank cannot set the exchange up (the ranks agree through an all-reduce).  Returns
+        the transport in use ("none" for a single rank)."""
+        mode = (mode or os.environ.get("MPPO_ALLREDUCE", "peer")).lower()
+        if mode not in ("peer", "rccl"):
+            raise ValueError(f"MPPO_ALLREDUCE / mode must be 'peer' or 'rccl', got {mode!r}")
         if self.world_size == 1:
             if os.environ.get("MPPO_FORCE_COMM") == "1":  # single-rank communicator: exercises the RCCL path on one GPU
                 host = np.zeros(128, np.uint8)
                 self.lib.comm_unique_id(host.ctypes.data)
                 with self.torch.cuda.device(self.device):
                     self.lib.engine_comm_init(self._engine, host.ctypes.data)
-            return
+                return "rccl"
+            return "none"
         import torch
         import torch.distributed as dist
 
+        on_gpu = self.xp == "torch" and dist.get_backend() == "nccl"
+
+        def all_ok(ok: bool) -> bool:
+            t = torch.tensor([1 if ok else 0], dtype=torch.int32)
+            if on_gpu:
+                t = t.to(self.device)
+            dist.all_reduce(t, op=dist.ReduceOp.MIN)
+            return bool(int(t.item()))
+
+        def device_ctx():
+            import contextlib
+            return self.torch.cuda.device(self.device) if self.xp == "torch" else contextlib.nullcontext()
+
+        if mode == "peer":
+            handle, err = np.zeros(64, np.uint8), None
+            try:
+                with device_ctx():
+                    self.lib.engine_peer_export(self._engine, handle.ctypes.data)
+            except nat.NativeError as exc:
+                err = exc
+            if all_ok(err is None):
+                mine = torch.from_numpy(handle)
+                if on_gpu:
+                    mine = mine.to(self.device)
+                gathered = [torch.zeros_like(mine) for _ in range(self.world_size)]
+                dist.all_gather(gathered, mine)
+                handles = np.concatenate([g.cpu().numpy() for g in gathered]).astype(np.uint8)
+                # do several ranks drive the same GPU (a one-GPU box)?  Then nothing larger than one wave may wait for a peer (csrc/peer.h)
+                ids = [None] * self.world_size
+                dist.all_gather_object(ids, self._device_identity())
+                shared = len(set(ids)) < len(ids)
+                try:
+                    with device_ctx():
+                        self.lib.engine_peer_connect(self._engine, handles.ctypes.data, int(shared))
+                except nat.NativeError as exc:
+                    err = exc
+                if all_ok(err is None):
+                    dist.barrier()  # every rank has mapped every buffer before anybody's first update writes a flag
+                    return "peer"
+                raise RuntimeError(f"peer-to-peer exchange: mapping the ranks' buffers failed on some rank ({err}); set MPPO_ALLREDUCE=rccl")
+            logger.warning("peer-to-peer exchange unavailable on some rank (%s); falling back to RCCL", err)
         host = np.zeros(128, np.uint8)
         if self.rank == 0:
             self.lib.comm_unique_id(host.ctypes.data)
         idbuf = torch.from_numpy(host)
-        on_gpu = self.xp == "torch" and dist.get_backend() == "nccl"
         if on_gpu:
             idbuf = idbuf.to(self.device)
         dist.broadcast(idbuf, src=0)
         host = idbuf.cpu().numpy().copy()
-        if self.xp == "torch":
-            with self.torch.cuda.device(self.device):
-                self.lib.engine_comm_init(self._engine, host.ctypes.data)
-        else:  # emulator build: the "communicator" is a shared-memory segment between the rank processes (tests/emu)
+        with device_ctx():  # (emulator build: the "communicator" is a shared-memory segment between the rank processes, tests/emu)
             self.lib.engine_comm_init(self._engine, host.ctypes.data)
+        return "rccl"
+
+    def _device_identity(self) -> str:
+        if self.xp != "torch":
+            return f"emulator-rank-{self.rank}"  # (rank processes of a CPU test: nothing is shared)
+        import socket
+
+        p = self.torch.cuda.get_device_properties(self.device)
+        ident = getattr(p, "uuid", None) or (getattr(p, "pci_domain_id", 0), getattr(p, "pci_bus_id", self.device.index), getattr(p, "pci_device_id", 0))
+        return f"{socket.gethostname()}/{ident}"
+
+    def comm_mode(self) -> str:
+        out = C.c_int32(0)
+        self.lib.engine_comm_mode(self._engine, C.byref(out))
+        return ("none", "rccl", "peer", "peer", "peer")[out.value]
+
+    def peer_form(self) -> str:
+        """How the peer-to-peer exchange is launched: "fused" (three launches per optimizer step), "split", "shared" (ranks on one GPU)."""
+        out = C.c_int32(0)
+        self.lib.engine_comm_mode(self._engine, C.byref(out))
+        return {2: "fused", 3: "split", 4: "shared"}.get(out.value, "")
+
+    def check_peers(self) -> None:
+        """Synchronises the device and raises if a wait for a peer rank ran into its time limit (MPPO_PEER_TIMEOUT_MS): the kernels
+        then ran to their end on whatever was in the exchange buffers and the parameters are invalid."""
+        out, info = C.c_int32(0), (C.c_int32 * 8)()
+        self.lib.engine_peer_status(self._engine, C.byref(out), info)
+        if out.value:
+            kind = {1: "the local gradient of rank", 2: "the reduced piece", 3: "the advantage sums of rank"}.get(info[0], "?")
+            raise RuntimeError(f"rank {self.rank}: a wait for {kind} {info[1]} timed out (epoch {info[2]}, flag read {info[3]}; this rank: {info[4]} optimizer steps, "
+                               f"{info[5]} updates, {info[6]} arrivals, {info[7]} pieces per slice, {out.value} waits gave up); this run's results are invalid")
 
     # -- stepping ----------------------------------------------------------------
     def reset(self) -> None:
@@ -423,8 +505,20 @@ class Trainer:
             self._seed_jax_rng()
 
     def update(self) -> None:
+        if self.world_size > 1 and not self._prepared:
+            self.prepare()
         self.lib.engine_update(self._engine, self._stream_ptr)
         self.updates_done += 1
+
+    def prepare(self) -> None:
+        """Several ranks, before the first update: capture the update (hipGraph) on every rank, then meet at a barrier, so that the
+        ranks enter their first gradient exchange together rather than a capture time apart (csrc/peer.h bounds every wait)."""
+        import torch.distributed as dist
+
+        self.lib.engine_prepare(self._engine, self._stream_ptr)
+        self._sync()
+        dist.barrier()
+        self._prepared = True
 
     def graph_active(self) -> bool:
         """True once `update()` replays a captured hipGraph (false: eager launches)."""

@@ -39,13 +39,17 @@ def run_rank(rank, world, port, overrides, updates, out_path):
 
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
-    be = get_backend("emu")
+    dist.init_process_group("gloo", rank=rank, world_size=world)  # rendezvous on the CPU: the ranks may share one GPU, which RCCL refuses
+    be = get_backend(os.environ.get("MPPO_TEST_BACKEND", "emu"))  # "hip": every rank on cuda:0 (tests/test_distributed.py, -m gpu)
+    use_graph = os.environ.get("MPPO_TEST_GRAPH") == "1"
     cfg = make_config({"kscale_id": "5eb3cb7f23232298", "visualization": {"camera_name": "track"}}, overrides)
-    tr = be.trainer(cfg, rank=rank, world_size=world, external_random=True, use_graph=False)
+    tr = be.trainer(cfg, rank=rank, world_size=world, external_random=True, use_graph=use_graph)
     host_driven = os.environ.get("MPPO_TEST_HOST_DRIVEN") == "1"
     if not host_driven:
-        tr.init_comm()  # the engine's own communicator (emulator build: shared memory between the rank processes)
+        got = tr.init_comm()  # $MPPO_ALLREDUCE: the engine's peer-to-peer exchange or its communicator (emulator build: shared memory either way)
+        assert got == os.environ.get("MPPO_ALLREDUCE", "peer") == tr.comm_mode(), (got, tr.comm_mode())
+        want_form = os.environ.get("MPPO_TEST_PEER_FORM")
+        assert not want_form or tr.peer_form() == want_form, (tr.peer_form(), want_form)
     tr.reset()
     N, Nl, T, A, E, M = cfg.training.num_envs, tr.N, tr.T, tr.A, tr.E, tr.M
 
@@ -55,14 +59,21 @@ def run_rank(rank, world, port, overrides, updates, out_path):
 
     for u in range(updates):
         noise, local, _ = make_inputs(N, T, A, E, M, world, seed=100 + u)
-        tr.region("noise", (T, Nl, A))[:] = noise[:, rank * Nl:(rank + 1) * Nl]
-        tr.region("perm", (E, T * Nl))[:] = local[rank]
-        tr.rollout()
-        if host_driven:
-            tr.learn_host_driven(allreduce_sum)  # the stage calls driven from Python with gloo collectives
+        be.put(tr.region("noise", (T, Nl, A)), noise[:, rank * Nl:(rank + 1) * Nl])
+        be.put(tr.region("perm", (E, T * Nl)), local[rank])
+        if use_graph:
+            tr.update()  # mppo_engine_update: rollout + learn replayed from the hipGraph, the exchange's kernels inside it
+            tr._sync()
         else:
-            tr.learn()  # mppo_engine_learn: csrc/engine.hip do_learn with its communicator branch
-    np.savez(out_path, params=tr.params_flat(), losses=tr.losses(), reward=np.array(tr.region("reward", (T, Nl))))
+            tr.rollout()
+            if host_driven:
+                tr.learn_host_driven(allreduce_sum)  # the stage calls driven from Python with gloo collectives
+            else:
+                tr.learn()  # mppo_engine_learn: csrc/engine.hip do_learn, peer-to-peer or communicator branch
+    tr.check_peers()
+    graph = tr.graph_active()
+    np.savez(out_path, params=tr.params_flat(), losses=tr.losses(), reward=be.host(tr.region("reward", (T, Nl))), graph=np.array(graph))
+    dist.barrier()  # nobody unmaps an exchange buffer a peer might still read
     tr.close()
     dist.barrier()
     dist.destroy_process_group()

@@ -19,6 +19,61 @@
 #include "platform.h"
 #include "ppo_layout.h"
 
+// ---- the engine's own "device" allocations: shared memory segments that other rank processes can map (hip_runtime.h) ----
+#include <map>
+#include <string>
+namespace {
+struct ShmAlloc { std::string name; size_t bytes; bool owner; };
+std::map<void*, ShmAlloc>& shm_allocs() { static std::map<void*, ShmAlloc> m; return m; }
+void* shm_map(const char* name, size_t bytes, bool create) {
+  const int fd = shm_open(name, create ? (O_CREAT | O_EXCL | O_RDWR) : O_RDWR, 0600);
+  if (fd < 0) return nullptr;
+  if (create && ftruncate(fd, (off_t)bytes) != 0) { close(fd); shm_unlink(name); return nullptr; }
+  void* m = mmap(nullptr, bytes, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+  close(fd);
+  return m == MAP_FAILED ? nullptr : m;
+}
+}  // namespace
+hipError_t hipExtMallocWithFlags(void** p, size_t n, unsigned) {
+  static std::atomic<unsigned> serial{0};
+  char name[64];
+  snprintf(name, sizeof(name), "/mppo_emu_x_%d_%u", (int)getpid(), serial.fetch_add(1));
+  void* m = shm_map(name, n, true);
+  if (!m) return hipErrorInvalidValue;
+  shm_allocs()[m] = ShmAlloc{name, n, true};
+  *p = m;
+  return hipSuccess;
+}
+hipError_t hipMalloc(void** p, size_t n) { return hipExtMallocWithFlags(p, n, 0); }
+hipError_t hipFree(void* p) {
+  auto it = shm_allocs().find(p);
+  if (it == shm_allocs().end()) return hipErrorInvalidValue;
+  munmap(p, it->second.bytes);
+  if (it->second.owner) shm_unlink(it->second.name.c_str());
+  shm_allocs().erase(it);
+  return hipSuccess;
+}
+hipError_t hipIpcGetMemHandle(hipIpcMemHandle_t* h, void* p) {
+  auto it = shm_allocs().find(p);
+  if (it == shm_allocs().end() || !it->second.owner) return hipErrorInvalidValue;
+  memset(h, 0, sizeof(*h));
+  snprintf(h->reserved, 48, "%s", it->second.name.c_str());
+  const unsigned long long n = it->second.bytes;
+  memcpy(h->reserved + 48, &n, 8);
+  return hipSuccess;
+}
+hipError_t hipIpcOpenMemHandle(void** p, hipIpcMemHandle_t h, unsigned) {
+  h.reserved[47] = 0;
+  unsigned long long n = 0;
+  memcpy(&n, h.reserved + 48, 8);
+  void* m = shm_map(h.reserved, (size_t)n, false);
+  if (!m) return hipErrorInvalidValue;
+  shm_allocs()[m] = ShmAlloc{h.reserved, (size_t)n, false};
+  *p = m;
+  return hipSuccess;
+}
+hipError_t hipIpcCloseMemHandle(void* p) { return hipFree(p); }
+
 extern "C" size_t mppo_permutation_ws_bytes(int32_t B) { return B < 1 ? 0 : 2 * (size_t)B * 4; }
 
 namespace mppo {

@@ -40,6 +40,19 @@ enum hipMemcpyKind { hipMemcpyHostToDevice, hipMemcpyDeviceToHost, hipMemcpyDevi
 inline hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMemcpyKind, hipStream_t) { memmove(d, s, n); return hipSuccess; }
 inline hipError_t hipMemsetAsync(void* d, int v, size_t n, hipStream_t) { memset(d, v, n); return hipSuccess; }
 inline hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
+inline hipError_t hipDeviceSynchronize() { return hipSuccess; }
+inline hipError_t hipMemcpy(void* d, const void* s, size_t n, hipMemcpyKind) { memmove(d, s, n); return hipSuccess; }
+inline hipError_t hipMemset(void* d, int v, size_t n) { memset(d, v, n); return hipSuccess; }
+// "device" allocations of the engine itself (the ranks' exchange buffers, csrc/k_peer.hip): POSIX shared memory, so that the rank
+// PROCESSES of a CPU test can map each other's buffers the way hipIpc maps a peer GPU's (emu_stubs.cpp)
+enum { hipDeviceMallocFinegrained = 1, hipDeviceMallocUncached = 3, hipIpcMemLazyEnablePeerAccess = 1 };
+struct hipIpcMemHandle_t { char reserved[64]; };
+hipError_t hipMalloc(void** p, size_t n);
+hipError_t hipExtMallocWithFlags(void** p, size_t n, unsigned flags);
+hipError_t hipFree(void* p);
+hipError_t hipIpcGetMemHandle(hipIpcMemHandle_t* h, void* p);
+hipError_t hipIpcOpenMemHandle(void** p, hipIpcMemHandle_t h, unsigned flags);
+hipError_t hipIpcCloseMemHandle(void* p);
 
 #define __global__
 #define __device__

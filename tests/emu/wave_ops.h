@@ -215,3 +215,27 @@ inline int agent_fetch_add(int* p, int v) { const int o = *p; *p = o + v; return
 inline int wave_uniform(int x) { return x; }
 inline void wg_release_fence() {}
 inline void agent_acquire_fence() {}
+
+// system-scope accesses between rank PROCESSES (csrc/peer.h): the emulator's exchange buffers are POSIX shared memory
+#include <sched.h>
+#include <time.h>
+inline void sys_store_f4(void* base, size_t byte_off, float4 v) {
+  float* p = reinterpret_cast<float*>(static_cast<char*>(base) + byte_off);
+  __atomic_store_n(reinterpret_cast<unsigned*>(p), __float_as_uint(v.x), __ATOMIC_RELAXED); __atomic_store_n(reinterpret_cast<unsigned*>(p + 1), __float_as_uint(v.y), __ATOMIC_RELAXED);
+  __atomic_store_n(reinterpret_cast<unsigned*>(p + 2), __float_as_uint(v.z), __ATOMIC_RELAXED); __atomic_store_n(reinterpret_cast<unsigned*>(p + 3), __float_as_uint(v.w), __ATOMIC_RELAXED);
+}
+inline float4 sys_load_f4(const void* base, size_t byte_off) {
+  const unsigned* p = reinterpret_cast<const unsigned*>(static_cast<const char*>(base) + byte_off);
+  return make_float4(__uint_as_float(__atomic_load_n(p, __ATOMIC_RELAXED)), __uint_as_float(__atomic_load_n(p + 1, __ATOMIC_RELAXED)),
+                     __uint_as_float(__atomic_load_n(p + 2, __ATOMIC_RELAXED)), __uint_as_float(__atomic_load_n(p + 3, __ATOMIC_RELAXED)));
+}
+inline void sys_store_f32(float* p, float v) { __atomic_store_n(reinterpret_cast<unsigned*>(p), __float_as_uint(v), __ATOMIC_RELAXED); }
+inline float sys_load_f32(const float* p) { return __uint_as_float(__atomic_load_n(reinterpret_cast<const unsigned*>(p), __ATOMIC_RELAXED)); }
+inline void sys_store_i32(int* p, int v) { __atomic_store_n(p, v, __ATOMIC_RELEASE); }  // flags: release / acquire order the payload
+inline int sys_load_i32(const int* p) { return __atomic_load_n(p, __ATOMIC_ACQUIRE); }
+inline int sys_poll_rmw(const int* p) { return __atomic_fetch_or(const_cast<int*>(p), 0, __ATOMIC_ACQ_REL); }
+inline void sys_store_f64(double* p, double v) { unsigned long long u; memcpy(&u, &v, 8); __atomic_store_n(reinterpret_cast<unsigned long long*>(p), u, __ATOMIC_RELAXED); }
+inline double sys_load_f64(const double* p) { const unsigned long long u = __atomic_load_n(reinterpret_cast<const unsigned long long*>(p), __ATOMIC_RELAXED); double v; memcpy(&v, &u, 8); return v; }
+inline void drain_stores() { __atomic_thread_fence(__ATOMIC_SEQ_CST); }
+inline void spin_pause() { sched_yield(); }
+inline unsigned long long realtime_ticks() { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return (unsigned long long)ts.tv_sec * 100000000ull + (unsigned long long)ts.tv_nsec / 10ull; }

@@ -36,8 +36,8 @@ import json, os, sys, time
 rank = int(os.environ["RANK"])
 assert os.environ.get("MPPO_BENCH_WORKER") == "1"
 mode = os.environ["FAKE_MODE"]
-graph_comm = os.environ.get("MPPO_GRAPH_COMM", "1")
-if mode == "rank1_fails_with_graph" and graph_comm != "0":
+transport = os.environ.get("MPPO_ALLREDUCE", "peer")
+if mode == "rank1_fails_with_peer" and transport != "rccl":
     if rank == 1:
         sys.exit(3)          # this rank dies at once ...
     time.sleep(600)          # ... the others would hang in a collective: their supervisors must kill them
@@ -45,7 +45,8 @@ if mode == "always_fails":
     sys.exit(4)
 if rank == 0:
     print("RCCL banner on stdout")
-    print(json.dumps({"metric": "fake", "graph_comm": graph_comm, "port": os.environ["MASTER_PORT"], "agent_store": os.environ.get("TORCHELASTIC_USE_AGENT_STORE", "")}))
+    print(json.dumps({"metric": "fake", "transport": transport, "graph_comm": os.environ.get("MPPO_GRAPH_COMM", ""), "port": os.environ["MASTER_PORT"],
+                      "agent_store": os.environ.get("TORCHELASTIC_USE_AGENT_STORE", "")}))
 '''
 
 
@@ -60,6 +61,7 @@ def _run_supervised(tmp_path, mode, world=2, timeout=120):
                    MPPO_BENCH_WORKER_SCRIPT=str(fake), MPPO_BENCH_STATUS_DIR=str(tmp_path), MPPO_BENCH_JOB=f"test_{mode}", MPPO_BENCH_RANK_TIMEOUT="60")
         env.pop("MPPO_BENCH_WORKER", None)
         env.pop("MPPO_GRAPH_COMM", None)
+        env.pop("MPPO_ALLREDUCE", None)
         procs.append(subprocess.Popen([sys.executable, str(ROOT / "bench.py"), "--gpus", str(world), "--steps", "1", "--warmup", "0"], env=env,
                                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
     outs = [p.communicate(timeout=timeout) for p in procs]
@@ -74,20 +76,21 @@ def test_rank_supervisor_forwards_rank0_json(tmp_path):
     rcs, outs = _run_supervised(tmp_path, "ok")
     assert rcs == [0, 0], (rcs, outs)
     lines = outs[0][0].strip().splitlines()
-    assert len(lines) == 1 and json.loads(lines[0])["graph_comm"] == "1"
+    assert len(lines) == 1 and json.loads(lines[0])["transport"] == "peer"
     assert outs[1][0].strip() == ""
 
 
-def test_rank_supervisor_retries_with_eager_launches_when_a_rank_fails(tmp_path):
-    """One rank dying with the RCCL calls inside the hipGraph: every supervisor kills its own child (the survivors would
-    hang in a collective) and all ranks repeat with MPPO_GRAPH_COMM=0 on a fresh rendezvous port."""
+def test_rank_supervisor_retries_with_rccl_when_a_rank_fails(tmp_path):
+    """One rank dying with the default transport (the peer-to-peer exchange inside the hipGraph): every supervisor kills its own
+    child (the survivors would wait for the dead rank's gradient until their time limit) and all ranks repeat with eager RCCL
+    all-reduces (MPPO_ALLREDUCE=rccl, MPPO_GRAPH_COMM=0) on a fresh rendezvous port."""
     import json
 
-    rcs, outs = _run_supervised(tmp_path, "rank1_fails_with_graph")
+    rcs, outs = _run_supervised(tmp_path, "rank1_fails_with_peer")
     assert rcs == [0, 0], (rcs, outs)
     d = json.loads(outs[0][0].strip().splitlines()[-1])
-    assert d["graph_comm"] == "0" and d["port"] != "29999" and d["agent_store"] == "False"
-    assert "repeating with eager launches" in outs[0][1]
+    assert d["transport"] == "rccl" and d["graph_comm"] == "0" and d["port"] != "29999" and d["agent_store"] == "False"
+    assert "repeating with eager RCCL all-reduces" in outs[0][1]
 
 
 def test_rank_supervisor_reports_failure(tmp_path):

@@ -32,14 +32,19 @@ import os
 import pytest
 
 
-@pytest.mark.parametrize("world,host_driven", [(2, False), (4, False), (2, True)])
-def test_ranks_equal_one_process_on_the_union(tmp_path, world, host_driven):
-    """world ranks through `mppo_engine_learn` (engine.hip do_learn, communicator branch) == one process on the union;
-    `host_driven`: the same stages driven from Python (`Trainer.learn_host_driven`) with gloo all-reduces."""
+@pytest.mark.parametrize("world,transport", [(2, "peer"), (4, "peer"), (3, "peer"), (2, "rccl"), (4, "rccl"), (2, "host")])
+def test_ranks_equal_one_process_on_the_union(tmp_path, world, transport):
+    """world ranks through `mppo_engine_learn` (engine.hip do_learn) == one process on the union, for both transports of the
+    gradient: "peer" - the exchange fused into the weight-gradient and Adam launches (csrc/peer.h; the emulator's exchange buffers
+    are shared-memory segments mapped by every rank process, as hipIpc maps them on the GPU), "rccl" - the communicator branch (the
+    emulator's stand-in for ncclAllReduce); "host": the same stages driven from Python (`Trainer.learn_host_driven`) with gloo
+    all-reduces.  Three ranks: slices of the gradient that do not divide evenly."""
     updates = 2
     port = _free_port()
-    env = dict(os.environ, MPPO_TEST_HOST_DRIVEN="1" if host_driven else "0")
-    procs = [subprocess.Popen([sys.executable, str(HERE / "dist_worker.py"), str(r), str(world), str(port), str(updates), str(tmp_path / f"r{r}.npz"), *OVR],
+    host_driven = transport == "host"
+    ovr = [o if not o.startswith("training.num_envs=") else f"training.num_envs={12 if world == 3 else 8}" for o in OVR]
+    env = dict(os.environ, MPPO_TEST_HOST_DRIVEN="1" if host_driven else "0", MPPO_ALLREDUCE="rccl" if host_driven else transport)
+    procs = [subprocess.Popen([sys.executable, str(HERE / "dist_worker.py"), str(r), str(world), str(port), str(updates), str(tmp_path / f"r{r}.npz"), *ovr],
                               stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, env=env) for r in range(world)]
     outs = [p.communicate(timeout=900)[0] for p in procs]
     assert all(p.returncode == 0 for p in procs), "\n".join(outs)
@@ -49,7 +54,7 @@ def test_ranks_equal_one_process_on_the_union(tmp_path, world, host_driven):
         np.testing.assert_array_equal(ranks[0]["params"], ranks[r]["params"])
 
     be = get_backend("emu")
-    cfg = make_config({"kscale_id": "5eb3cb7f23232298", "visualization": {"camera_name": "track"}}, OVR)
+    cfg = make_config({"kscale_id": "5eb3cb7f23232298", "visualization": {"camera_name": "track"}}, ovr)
     tr = be.trainer(cfg, external_random=True, use_graph=False)
     tr.reset()
     p0 = tr.params_flat()
@@ -69,4 +74,61 @@ def test_ranks_equal_one_process_on_the_union(tmp_path, world, host_driven):
     # the parameters differ by summation order after the first one, so equality is to rounding, not bitwise)
     rew = np.array(tr.region("reward", (T, N)))
     np.testing.assert_allclose(np.concatenate([r["reward"] for r in ranks], 1), rew, atol=5e-3)
+    tr.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world,form", [(2, "shared"), (4, "shared"), (2, "fused")])
+def test_peer_exchange_between_processes_on_one_gpu(tmp_path, world, form):
+    """The peer-to-peer gradient exchange on hardware: `world` rank PROCESSES share cuda:0 (hipIpc maps a buffer of the same device as
+    readily as a peer's; RCCL would refuse the duplicate device), each with N / world environments, the exchange's kernels captured
+    in every rank's hipGraph.  Ranks == one process on the union of the shards; replicas bit-identical; no wait timed out.
+    "shared": the form the engine picks by itself when ranks share a GPU (the two waits of a step are one-wave kernels, so that a
+    waiting rank never keeps the peer's kernels off the CUs); "fused": the form for ranks on distinct GPUs - three launches per
+    step, the Adam launch waits - forced here at two ranks, where its 64-register waiting workgroups still leave every CU room for
+    the peer's largest workgroup (at four ranks on one GPU they would not: csrc/peer.h)."""
+    updates = 3
+    port = _free_port()
+    ovr = ["training.num_envs=256", "training.num_minibatches=4", "training.update_epochs=2", "training.total_timesteps=100000000"]
+    env = dict(os.environ, MPPO_TEST_BACKEND="hip", MPPO_TEST_GRAPH="1", MPPO_ALLREDUCE="peer", MPPO_TEST_HOST_DRIVEN="0", MPPO_TEST_PEER_FORM=form,
+               HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    if form == "fused":
+        env["MPPO_PEER_MODE"] = "fused"
+    else:
+        env.pop("MPPO_PEER_MODE", None)
+    procs = [subprocess.Popen([sys.executable, str(HERE / "dist_worker.py"), str(r), str(world), str(port), str(updates), str(tmp_path / f"r{r}.npz"), *ovr],
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, env=env) for r in range(world)]
+    try:
+        outs = [p.communicate(timeout=600)[0] for p in procs]
+    finally:
+        for p in procs:  # exactly the PIDs started above
+            if p.poll() is None:
+                p.kill()
+                p.wait()
+    assert all(p.returncode == 0 for p in procs), "\n".join(outs)
+    ranks = [np.load(tmp_path / f"r{r}.npz") for r in range(world)]
+    assert all(bool(r["graph"]) for r in ranks), "a rank did not replay its hipGraph"
+    for r in range(1, world):
+        np.testing.assert_array_equal(ranks[0]["params"], ranks[r]["params"])
+
+    be = get_backend("hip")
+    cfg = make_config({"kscale_id": "5eb3cb7f23232298", "visualization": {"camera_name": "track"}}, ovr)
+    tr = be.trainer(cfg, external_random=True, use_graph=True)
+    tr.reset()
+    p0 = tr.params_flat()
+    N, T, A, E, M = tr.N, tr.T, tr.A, tr.E, tr.M
+    for u in range(updates):
+        noise, _, glob = make_inputs(N, T, A, E, M, world, seed=100 + u)
+        be.put(tr.region("noise", (T, N, A)), noise)
+        be.put(tr.region("perm", (E, T * N)), glob)
+        tr.update()
+        tr._sync()
+    single = tr.params_flat()
+    step = np.abs(single - p0).max()
+    assert step > 1e-4
+    # the gradient's summation order differs (per-rank partial sums added in rank order): rounding-level drift over 24 Adam steps, whose
+    # normalisation by sqrt(v) turns a rounding difference of a near-zero gradient into a fraction of one step (lr = 3e-4) for that element
+    diff = np.abs(ranks[0]["params"] - single)
+    assert diff.max() < 0.1 * step + 1e-7 and np.median(diff) < 1e-3 * step, (diff.max(), np.median(diff), step)
+    np.testing.assert_allclose(sum(r["losses"] for r in ranks), tr.losses(), rtol=2e-3, atol=2e-4)
     tr.close()

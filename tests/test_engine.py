@@ -329,6 +329,7 @@ def test_graph_with_collectives_equals_eager_with_collectives(monkeypatch):
     be = get_backend("hip")
     cfg = _cfg("training.num_envs=256", "training.num_minibatches=8", "training.update_epochs=2", "training.total_timesteps=100000000")
     monkeypatch.setenv("MPPO_FORCE_COMM", "1")
+    monkeypatch.setenv("MPPO_GRAPH_COMM", "1")  # (RCCL calls inside the graph are opt-in: never verified on more than one GPU)
     res = []
     for use_graph in (False, True):
         tr = be.trainer(cfg, use_graph=use_graph)
