@@ -19,8 +19,9 @@ def main() -> None:
 
         env_main(other_args)
     elif args.command == "infer":
-        # the reference's `minppo infer` is a stub as well (`minppo/infer.py:22-27` raises NotImplementedError)
-        raise NotImplementedError("Inference is not implemented yet (as in the reference)")
+        from minppo_amd.infer import main as infer_main  # a stub upstream too (`minppo/infer.py:22-27` raises NotImplementedError)
+
+        infer_main(other_args)
     else:
         raise ValueError(f"Invalid command: {args.command}")
 

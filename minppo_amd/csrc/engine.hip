@@ -169,11 +169,12 @@ static int32_t validate_cfg(const mppo_model* m, const mppo_engine_cfg_t* c) {
   MPPO_REQUIRE(c->net.O == mv.obs_dim && c->net.OP == mv.obs_pad, "engine: net O/OP (%d/%d) do not match the model's observation (%d/%d)", c->net.O, c->net.OP,
                mv.obs_dim, mv.obs_pad);
   MPPO_REQUIRE(c->net.A == mv.nu, "engine: net A = %d but the model has %d actuators", c->net.A, mv.nu);
-  MPPO_REQUIRE(c->net.A >= 1 && c->net.A <= 32 && c->net.H >= 4 && c->net.H % 4 == 0, "engine: unsupported A / H");
+  // (up to 32 action dimensions take the fused kernels, 33 .. 63 the layer-wise path: fused_supported, k_fused.hip)
+  MPPO_REQUIRE(c->net.A >= 1 && c->net.A <= 63 && c->net.H >= 4 && c->net.H % 4 == 0, "engine: unsupported A / H (1 <= A <= 63, H a multiple of 4)");
   MPPO_REQUIRE(c->net.num_layers >= 0 && c->net.num_layers <= kMaxHidden, "engine: model.num_layers = %d (1 .. %d hidden layers)", c->net.num_layers, kMaxHidden);
   // bf16-in / f32-accumulate products exist in the fused kernels (two hidden layers, H a multiple of 32 up to 256); the layer-wise path is float only
-  MPPO_REQUIRE(!c->net.bf16 || (net_layers(c->net) == 2 && c->net.H % 32 == 0 && c->net.H <= 256),
-               "engine: training.mlp_dtype=bf16 needs the fused kernels (model.num_layers = 2, hidden_size a multiple of 32 up to 256)");
+  MPPO_REQUIRE(!c->net.bf16 || (net_layers(c->net) == 2 && c->net.H % 32 == 0 && c->net.H <= 256 && c->net.A <= 32),
+               "engine: training.mlp_dtype=bf16 needs the fused kernels (model.num_layers = 2, hidden_size a multiple of 32 up to 256, at most 32 actuators)");
   MPPO_REQUIRE(c->num_updates >= 1, "engine: num_updates must be >= 1 (total_timesteps too small)");
   MPPO_REQUIRE(c->rng_impl == 0 || c->rng_impl == 1, "engine: rng_impl %d (0 philox, 1 threefry)", c->rng_impl);
   MPPO_REQUIRE(c->rng_impl == 0 || c->world_size == 1, "engine: the threefry streams follow the reference's single-device key plumbing (world_size must be 1)");

@@ -53,7 +53,8 @@ __global__ void __launch_bounds__(256) gae_kernel(int T, int N, float gamma, flo
 template <int LR>
 __device__ __forceinline__ float row_sum(float x) {
   x = group16_sum(x);
-  if (LR == 32) x += __shfl_xor(x, 16);
+  if (LR >= 32) x += __shfl_xor(x, 16);
+  if (LR == 64) x += __shfl_xor(x, 32);
   return x;
 }
 
@@ -194,15 +195,24 @@ __global__ void __launch_bounds__(256) head_kernel(HeadArgs a) {
 static size_t head_smem_bytes(int LR, int H, int A) { const int RT = 256 / LR; return sizeof(float) * ((size_t)2 * RT * (H + 4) + (size_t)H * A + H + 2 * RT * LR); }
 
 int32_t head_launch(const HeadArgs& a, bool loss, hipStream_t stream) {
-  MPPO_REQUIRE(a.A + 1 <= 32 && (a.H % 4) == 0, "head kernel: A = %d must be <= 31 and H %% 4 == 0", a.A);
-  const int LR = 32;  // 8 rows per workgroup: 160 workgroups at mb = 1280
+  // lanes per row: one per action dimension + one for the value; a whole wave per row covers up to 63 action dimensions
+  MPPO_REQUIRE(a.A + 1 <= 64 && (a.H % 4) == 0, "head kernel: A = %d must be <= 63 and H %% 4 == 0", a.A);
+  const int LR = a.A + 1 <= 32 ? 32 : 64;  // 8 (4) rows per workgroup: 160 (320) workgroups at mb = 1280
   const int RT = 256 / LR;
   const size_t smem = head_smem_bytes(LR, a.H, a.A);
-  MPPO_REQUIRE(smem <= 64 * 1024, "head kernel: %zu bytes of LDS needed (H = %d too large)", smem, a.H);
+  MPPO_REQUIRE(smem <= 160 * 1024, "head kernel: %zu bytes of LDS needed (H = %d, A = %d too large)", smem, a.H, a.A);
+  static thread_local size_t attr_for = 0;
+  if (smem > 64 * 1024 && attr_for < smem) {
+    MPPO_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(head_kernel<32, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+    MPPO_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(head_kernel<32, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+    MPPO_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(head_kernel<64, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+    MPPO_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(head_kernel<64, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+    attr_for = smem;
+  }
   dim3 grid(cdiv(a.n, RT));
-  if (LR == 16) {
-    if (loss) hipLaunchKernelGGL((head_kernel<16, true>), grid, dim3(256), smem, stream, a);
-    else hipLaunchKernelGGL((head_kernel<16, false>), grid, dim3(256), smem, stream, a);
+  if (LR == 64) {
+    if (loss) hipLaunchKernelGGL((head_kernel<64, true>), grid, dim3(256), smem, stream, a);
+    else hipLaunchKernelGGL((head_kernel<64, false>), grid, dim3(256), smem, stream, a);
   } else {
     if (loss) hipLaunchKernelGGL((head_kernel<32, true>), grid, dim3(256), smem, stream, a);
     else hipLaunchKernelGGL((head_kernel<32, false>), grid, dim3(256), smem, stream, a);
@@ -233,7 +243,7 @@ __global__ void __launch_bounds__(256) grad_reduce_kernel(size_t P, int ksplit, 
                                                           float ent_coef, float vf_coef, float ent_weight, float* __restrict__ grad,
                                                           float* __restrict__ loss4, float* __restrict__ sq_partial, PadList pl) {
   __shared__ float red[4];
-  __shared__ float s_part[16][40];
+  __shared__ float s_part[16][72];  // (4 + AP columns: up to 63 action dimensions on the layer-wise path)
   float sq = 0.f;
 #pragma unroll
   for (int it = 0; it < kReduceIter; ++it) {
@@ -265,7 +275,7 @@ __global__ void __launch_bounds__(256) grad_reduce_kernel(size_t P, int ksplit, 
       s_part[threadIdx.x >> 4][c] = s0;
     }
     __syncthreads();
-    __shared__ float s_col[40];
+    __shared__ float s_col[72];
     if (threadIdx.x < W) {
       float s0 = 0.f;
       for (int gq = 0; gq < 16; ++gq) s0 += s_part[gq][threadIdx.x];
@@ -631,7 +641,7 @@ int32_t minibatch_rowpass(const mppo_net_t& net, const float* params, const mppo
   ha.idx = idx; ha.b = batch; ha.adv_stat = adv_stat; ha.inv_count = inv_count; ha.lc = lc;
   ha.dout = gbuf.dout; ha.dz2a = gbuf.dz2a; ha.dz2c = gbuf.dz2c; ha.partial = gbuf.partial;
   MPPO_TRY(head_launch(ha, true, stream));  // heads + loss + dZ2
-  *nblk_out = cdiv(mb, 8);
+  *nblk_out = cdiv(mb, net.A + 1 <= 32 ? 8 : 4);  // (rows per workgroup of the head kernel)
   GemmBatch gb{};
   gb.count = 2; gb.ksplit = 1;
   for (int l = L.nl - 2; l >= 0; --l) {  // dZ_l = (dZ_{l+1} . W_{l+1}^T) * act'(h_l)
@@ -822,7 +832,7 @@ using namespace mppo;
 
 static int32_t check_net(const mppo_net_t* net) {
   MPPO_REQUIRE(net, "null net");
-  MPPO_REQUIRE(net->O >= 1 && net->A >= 1 && net->A <= 32 && net->H >= 4 && (net->H % 4) == 0, "unsupported network geometry O=%d A=%d H=%d (need A<=32, H%%4==0)",
+  MPPO_REQUIRE(net->O >= 1 && net->A >= 1 && net->A <= 63 && net->H >= 4 && (net->H % 4) == 0, "unsupported network geometry O=%d A=%d H=%d (need A<=63, H%%4==0)",
                net->O, net->A, net->H);
   MPPO_REQUIRE(net->OP >= net->O && (net->OP % 4) == 0, "OP=%d must be a multiple of 4 and >= O=%d", net->OP, net->O);
   MPPO_REQUIRE(net->num_layers >= 0 && net->num_layers <= kMaxHidden, "num_layers=%d: 1 .. %d hidden layers (0 = 2)", net->num_layers, kMaxHidden);

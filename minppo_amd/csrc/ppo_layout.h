@@ -118,7 +118,7 @@ inline size_t grad_bufs_floats(const mppo_net_t& net, int mb) {
   const size_t mbp = pad16((size_t)mb);  // the quad-layout operands are written in whole 16-row tiles
   const size_t AP = pad4((size_t)net.A), nh = pad4(mbp * net.H);
   const size_t P = pad4((size_t)param_layout(net).total);
-  const size_t nblk = (size_t)(mb + 7) / 8;  // head kernel: 8 rows per workgroup (fused kernel: 16)
+  const size_t nblk = (size_t)(mb + 3) / 4;  // head kernel: 8 rows per workgroup, 4 with more than 31 action dimensions (fused kernel: 16)
   return fwd_bufs_floats(net, (int)mbp) + pad4(mbp * (AP + 4)) + 2 * (size_t)net_layers(net) * nh + pad4(nblk * (4 + AP)) + (size_t)kGradKSplitMax * P + 2 * pad4(mbp * net.OP) + 2 * pad4((size_t)net.H * net.H) +  // (xmb, xmb2)
          (net.bf16 ? pad4((size_t)(((net.O + 31) & ~31) + 2 * net.H) * net.H) : 0);  // bf16 fragments: 2 networks x (KP + 2H) x H halves = that many floats
 }
@@ -133,7 +133,7 @@ inline GradBufs carve_grad(const mppo_net_t& net, int mb, float* ws) {
   for (int l = 0; l < kMaxHidden; ++l) g.dza[l] = g.dzc[l] = nullptr;
   for (int l = nl - 1; l >= 0; --l) { g.dza[l] = ws; ws += nh; g.dzc[l] = ws; ws += nh; }
   g.dz2a = g.dza[nl - 1]; g.dz2c = g.dzc[nl - 1]; g.dz1a = g.dza[0]; g.dz1c = g.dzc[0];
-  const size_t nblk = (size_t)(mb + 7) / 8;
+  const size_t nblk = (size_t)(mb + 3) / 4;
   g.partial = ws; ws += pad4(nblk * (4 + AP));
   g.slabs = ws;
   g.xmb = ws + (size_t)kGradKSplitMax * pad4((size_t)param_layout(net).total);

@@ -342,7 +342,8 @@ class Trainer:
 
     def _ckpt_meta(self) -> Dict[str, Any]:
         return dict(version=self._CKPT_VERSION, model=self.cm.name, num_envs=self.N, num_steps=self.T, obs_dim=self.O, act_dim=self.A, hidden=self.H,
-                    params=self.P, rec_dim=int(self.dims.rec_dim), seed=int(self.seed), rank=self.rank, world_size=self.world_size)
+                    params=self.P, rec_dim=int(self.dims.rec_dim), seed=int(self.seed), rank=self.rank, world_size=self.world_size,
+                    rng_impl="threefry" if self.ecfg.rng_impl == 1 else "philox")
 
     def save_checkpoint(self, path: str) -> None:
         self._sync()
@@ -365,7 +366,9 @@ class Trainer:
                 raise ValueError(f"checkpoint {path}: metadata is not JSON (written by an older version?)") from exc
             want = self._ckpt_meta()
             # the seed keys the engine's Philox streams: only the same seed continues the same noise / permutation sequence
-            for k in ("version", "model", "num_envs", "num_steps", "obs_dim", "act_dim", "hidden", "params", "rec_dim", "world_size", "rank", "seed"):
+            meta.setdefault("rng_impl", "philox")  # (files written before the field existed: the engine's own streams)
+            # rng_impl: a philox checkpoint carries an all-zero "jax_rng" region; continued with threefry it would silently draw from key (0, 0)
+            for k in ("version", "model", "num_envs", "num_steps", "obs_dim", "act_dim", "hidden", "params", "rec_dim", "world_size", "rank", "seed", "rng_impl"):
                 if meta.get(k) != want[k]:
                     raise ValueError(f"checkpoint {path}: {k} = {meta.get(k)!r} does not match this run ({want[k]!r})")
             self.reset()  # (re)builds the constant reset record; everything else is overwritten below

@@ -277,14 +277,14 @@ def test_hipgraph_replay_equals_eager_launches():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("robot,num_envs", [("synth_stompy_pro", 4096), ("synth_stompy_full", 8192)])
-def test_full_size_properties_on_gpu(robot, num_envs):
-    """BASELINE configs[1] (stompy_pro stand-in, 4096 envs) and configs[4] (20-actuator stand-in, 8192 envs) at full size:
-    size-independent properties of whole updates."""
+@pytest.mark.parametrize("robot,num_envs,dtype", [("synth_stompy_pro", 4096, "f32"), ("synth_stompy_full", 8192, "f32"), ("synth_stompy_pro", 4096, "bf16")])
+def test_full_size_properties_on_gpu(robot, num_envs, dtype):
+    """BASELINE configs[1] (stompy_pro stand-in, 4096 envs), configs[4] (20-actuator stand-in, 8192 envs) and configs[3] (bf16-in /
+    f32-accumulate MLP products, 4096 envs) at full size, through the engine and its hipGraph: size-independent properties of whole updates."""
     from backends import get_backend
 
     be = get_backend("hip")
-    cfg = _cfg(f"training.num_envs={num_envs}", f"environment.model={robot}")
+    cfg = _cfg(f"training.num_envs={num_envs}", f"environment.model={robot}", f"training.mlp_dtype={dtype}")
     tr = be.trainer(cfg, use_graph=True)
     tr.reset()
     for _ in range(2):

@@ -95,7 +95,8 @@ def test_gae_random_shapes_match_oracle():
     check()
 
 
-@pytest.mark.parametrize("O,A,H,n,tanh", [(225, 10, 256, 150, 1), (37, 3, 64, 70, 0), (415, 20, 256, 33, 1), (40, 4, 512, 20, 1), (24, 2, 48, 19, 0), (50, 32, 64, 21, 0)])
+@pytest.mark.parametrize("O,A,H,n,tanh", [(225, 10, 256, 150, 1), (37, 3, 64, 70, 0), (415, 20, 256, 33, 1), (40, 4, 512, 20, 1), (24, 2, 48, 19, 0), (50, 32, 64, 21, 0),
+                                          (30, 31, 48, 19, 1), (30, 32, 48, 19, 0), (44, 32, 512, 17, 1), (52, 45, 64, 23, 1)])  # layer-wise path: 31 / 32 outputs, H = 512, > 32 outputs
 def test_policy_forward_sample_logprob(be, O, A, H, n, tanh):
     rng = np.random.default_rng(1)
     net = _net(O, A, H, tanh)
@@ -129,7 +130,11 @@ def test_policy_forward_sample_logprob(be, O, A, H, n, tanh):
                                                   (415, 20, 256, 120, 72, 1, 0.01),   # stompy_full: 20 outputs = two head tiles
                                                   (50, 32, 64, 64, 40, 0, 0.0),       # the widest head the fused kernel covers
                                                   (35, 3, 64, 90, 70, 1, 0.0),        # 35 = 32 + 3 observation rows: a "thin" last row band of the first layer's gradient
-                                                  (60, 7, 64, 100, 80, 1, 0.0), (33, 11, 96, 90, 64, 0, 0.01)])  # odd action dimensions (fused path, see below)
+                                                  (60, 7, 64, 100, 80, 1, 0.0), (33, 11, 96, 90, 64, 0, 0.01),  # odd action dimensions (fused path, see below)
+                                                  # the layer-wise path at the head kernel's lane limits: 31 outputs + the value fill a 32-lane row, 32 outputs need a wave per
+                                                  # row; H = 512 with a 32-wide head (LDS above 64 KB); more outputs than the fused kernels cover; O above the fused path's tile table
+                                                  (30, 31, 48, 70, 50, 1, 0.0), (30, 32, 48, 70, 50, 0, 0.01), (44, 32, 512, 60, 40, 1, 0.0), (52, 45, 64, 80, 60, 1, 0.0),
+                                                  (800, 6, 256, 60, 40, 1, 0.0)])
 def test_minibatch_grad_matches_oracle(be, O, A, H, B, mb, tanh, ent):
     if be.name == "emu" and mb > 400:
         pytest.skip("full-size minibatch only on the GPU")
@@ -158,7 +163,8 @@ def test_minibatch_grad_matches_oracle(be, O, A, H, B, mb, tanh, ent):
     ws = be.full((wsb // 4 + 4,), np.nan)
     fused = C.c_int32(-1)
     be.lib.minibatch_path(C.byref(net), C.byref(batch), C.byref(fused))
-    assert fused.value == (1 if H % 32 == 0 and H <= 256 else 0)  # which kernels run: the fused row pass + k_wgrad.hip, or the layer-wise fallback
+    # which kernels run: the fused row pass + k_wgrad.hip (H a multiple of 32 up to 256, at most 32 outputs, the weight-gradient tile table fits), or the layer-wise fallback
+    assert fused.value == (1 if H % 32 == 0 and H <= 256 and A <= 32 and O <= 700 else 0)
     be.lib.minibatch_grad(C.byref(net), be.ptr(d["flat"]), C.byref(batch), be.ptr(d["idx"]), mb, be.ptr(stats), 1.0 / mb, C.byref(lc), be.ptr(grad),
                           be.ptr(loss4), be.ptr(ws), wsb, be.stream)
     lo, gr = po.loss_and_grad(n64, bobs[idx][:, :O].astype(np.float64), bact[idx].astype(np.float64), bval[idx].astype(np.float64),

@@ -85,6 +85,23 @@ def _resume_case(be, tmp_path, trainer_kw):
     with pytest.raises(ValueError, match="seed"):
         c.load_checkpoint(ck)
     c.close()
+    # ... and so is one written with the other random-stream implementation (its "jax_rng" region would be all zeros)
+    d = be.trainer(make_config(BASE, over + ["training.rng_impl=threefry"]), **trainer_kw)
+    with pytest.raises(ValueError, match="rng_impl"):
+        d.load_checkpoint(ck)
+    d.close()
+
+
+def test_infer_surface(tmp_path):
+    """`minppo.infer.load_model` (reference infer.py:17-19) reads what `save_model` wrote; `main` is a stub upstream too."""
+    from minppo_amd import infer
+
+    tree = {"params": {"log_std": np.zeros(3, np.float32)}}
+    T.save_model(tree, str(tmp_path / "sub" / "m.pkl"))
+    got = infer.load_model(str(tmp_path / "sub" / "m.pkl"))
+    np.testing.assert_array_equal(got["params"]["log_std"], tree["params"]["log_std"])
+    with pytest.raises(NotImplementedError):
+        infer.main([])
 
 
 def test_checkpoint_resume_is_bit_exact(tmp_path):
