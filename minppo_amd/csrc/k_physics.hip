@@ -251,17 +251,17 @@ struct RuntimeModel {
   static constexpr bool kStatic = false;
   static constexpr BlobDims dims() { return BlobDims{}; }
 };
-template <int NQ, int NV, int NU, int NBODY, int NJNT, int NCON, int NLIMIT, int NPAIR, int NLEVEL, int NROOT>
+template <int NQ, int NV, int NU, int NBODY, int NJNT, int NCON, int NLIMIT, int NPAIR, int NLEVEL, int NROOT, int NCVX = 0, int NCVXVERT = 0>
 struct StaticModel {
   static constexpr bool kStatic = true;
-  static constexpr BlobDims dims() { return BlobDims{NQ, NV, NU, NBODY, NJNT, NCON, NLIMIT, NPAIR, NLEVEL, NROOT}; }
+  static constexpr BlobDims dims() { return BlobDims{NQ, NV, NU, NBODY, NJNT, NCON, NLIMIT, NPAIR, NLEVEL, NROOT, NCVX, NCVXVERT}; }
 };
 // MODE (EnvArgs::mode) is a template parameter too: the step kernel carries neither the probe's 17 output pointers nor its stores.
 template <class SD, int MODE>
 __global__ void __launch_bounds__(kEnvBlock) env_kernel(ModelView mv, EnvArgs a, PhysLds Prt) {
   constexpr BlobDims kSD = SD::dims();
   constexpr BlobOffsets kSO = blob_offsets(kSD);
-  constexpr PhysLds kSP = make_phys_lds(kSD.nq, kSD.nv, kSD.nu, kSD.nbody, kSD.njnt, kSD.ncon, kSD.nlimit + 4 * kSD.ncon, kSD.nroot);
+  constexpr PhysLds kSP = make_phys_lds(kSD.nq, kSD.nv, kSD.nu, kSD.nbody, kSD.njnt, kSD.ncon, kSD.nlimit + 4 * kSD.ncon, kSD.nroot, kSD.ncvx);
   const PhysLds P = SD::kStatic ? kSP : Prt;
   constexpr bool kDims = SD::kStatic;
   constexpr int NV = kDims ? kSD.nv : 0;
@@ -300,7 +300,8 @@ __global__ void __launch_bounds__(kEnvBlock) env_kernel(ModelView mv, EnvArgs a,
   float* t0 = (float*)__builtin_assume_aligned(S + P.t0, 16); float* t1 = (float*)__builtin_assume_aligned(S + P.t1, 16);
   float* eD = S + P.D; float* earef = S + P.aref; float* jaref = S + P.jaref; float* jv = S + P.jv; float* force = S + P.force;
   float* conpos = S + P.conpos; float* condist = S + P.condist; float* confr = S + P.confr;
-  const int npair = kDims ? kSD.npair : mv.npair, nplane = ncon - npair;
+  const int npair = kDims ? kSD.npair : mv.npair, nplane = ncon - npair, ncvx = kDims ? kSD.ncvx : mv.ncvx;
+  float* cvxsel = S + P.cvxsel; float* cvxok = S + P.cvxok;
   float* ximat = S + P.ximat; float* xmat = S + P.xmat; float* xanchor = S + P.xanchor; float* xaxis = S + P.xaxis;
   float* C1 = S + P.C1; float* C2 = S + P.C2; float* cdofdot = S + P.cdofdot; float* cfrc = S + P.cfrc; float* J = (float*)__builtin_assume_aligned(S + P.J, 16);
 
@@ -420,12 +421,57 @@ __global__ void __launch_bounds__(kEnvBlock) env_kernel(ModelView mv, EnvArgs a,
       if (g == 0) st3(rootcom + 3 * r, {sx * inv, sy * inv, sz * inv});
       if (r == 0) new_comx = sx * inv;  // subtree_com[1].x: body 1 is the first root (env.py:222-223)
     }
-    FOR_G(c, nplane) {  // ground contacts (MJX plane_sphere / plane_capsule; a box corner is a sphere of radius 0)
+    if (ncvx > 0) {
+      // convex (mesh) geoms against the plane, MJX collision_convex.plane_convex: among the hull vertices within 1 mm of the deepest
+      // penetrating one, _manifold_points picks four that span the contact patch (a: the first candidate, b: the farthest from a,
+      // c: the farthest from the line ab, d: the farthest from the edges ac / bc; ties go to the lower index as argmax does);
+      // a vertex picked twice fills only its first slot.  One lane per geom scans its vertices five times.
+      FOR_G(k, ncvx) {
+        const int b = TI(cvx_body)[k], v0 = TI(cvx_vadr)[k], v1 = TI(cvx_vadr)[k + 1];
+        float R[9];
+        qmat(ld4(xquat + 4 * b), R);
+        const V3 nl = {R[6], R[7], R[8]};                 // the plane's normal (+z) in the body frame
+        const float h0 = mv.plane_z - xpos[3 * b + 2];    // support(v) = h0 - nl . vert(v): depth below the plane
+        const float* vt = TF(cvx_vert);
+        float smax = -INFINITY;
+        for (int v = v0; v < v1; ++v) smax = fmaxf(smax, h0 - dot3(nl, ld3(vt + 3 * v)));
+        const float thr = fmaxf(0.f, smax - 1e-3f);
+        auto dm = [&](int v) { return (h0 - dot3(nl, ld3(vt + 3 * v)) > thr) ? 0.f : -1e6f; };
+        int ia = v0;
+        { float best = -INFINITY; for (int v = v0; v < v1; ++v) { const float x = dm(v); if (x > best) { best = x; ia = v; } } }
+        const V3 A = ld3(vt + 3 * ia);
+        int ib = v0;
+        { float best = -INFINITY; for (int v = v0; v < v1; ++v) { const V3 e = sub3(A, ld3(vt + 3 * v)); const float x = dot3(e, e) + dm(v); if (x > best) { best = x; ib = v; } } }
+        const V3 B = ld3(vt + 3 * ib);
+        const V3 ab = cross3(nl, sub3(A, B));
+        int ic = v0;
+        { float best = -INFINITY; for (int v = v0; v < v1; ++v) { const float x = fabsf(dot3(sub3(A, ld3(vt + 3 * v)), ab)) + dm(v); if (x > best) { best = x; ic = v; } } }
+        const V3 Cc = ld3(vt + 3 * ic);
+        const V3 ac = cross3(nl, sub3(A, Cc)), bc = cross3(nl, sub3(B, Cc));
+        int id = v0;
+        {
+          float best = -INFINITY;
+          for (int v = v0; v < v1; ++v) { const float x = fabsf(dot3(sub3(B, ld3(vt + 3 * v)), bc)) + dm(v); if (x > best) { best = x; id = v; } }
+          for (int v = v0; v < v1; ++v) { const float x = fabsf(dot3(sub3(A, ld3(vt + 3 * v)), ac)) + dm(v); if (x > best) { best = x; id = v; } }
+        }
+        const int idx[4] = {ia, ib, ic, id};
+        for (int j = 0; j < 4; ++j) {
+          bool first = true;
+          for (int i = 0; i < j; ++i) first = first && idx[i] != idx[j];
+          st3(cvxsel + 3 * (4 * k + j), ld3(vt + 3 * idx[j]));
+          cvxok[4 * k + j] = first ? 1.f : 0.f;
+        }
+      }
+      SYNC();
+    }
+    FOR_G(c, nplane) {  // ground contacts (MJX plane_sphere / plane_capsule; a box corner is a sphere of radius 0; a convex geom's chosen vertices)
       const int b = TI(con_bodyid)[c];
       const Q4 q = ld4(xquat + 4 * b);
-      const V3 centre = add3(ld3(xpos + 3 * b), qrot(q, ld3(TF(con_lpos) + 3 * c)));
+      const int cs = ncvx > 0 ? TI(con_cvx)[c] : -1;
+      const V3 centre = add3(ld3(xpos + 3 * b), qrot(q, cs >= 0 ? ld3(cvxsel + 3 * cs) : ld3(TF(con_lpos) + 3 * c)));
       const float rad = TF(con_radius)[c];
-      const float dist = centre.z - mv.plane_z - rad;
+      float dist = centre.z - mv.plane_z - rad;
+      if (cs >= 0 && cvxok[cs] == 0.f) dist = 1.f;  // a duplicate of an earlier slot: switched off as MJX does (dist = 1)
       condist[c] = dist;
       st3(conpos + 3 * c, {centre.x, centre.y, centre.z - (rad + 0.5f * dist)});
       // frame: normal +z; the first tangent follows the capsule axis projected on the plane unless that projection is shorter
@@ -1186,7 +1232,7 @@ static int find_spec(const BlobDims& d) {
   for (int i = 0; kSpecs[i].launch; ++i) {
     const BlobDims& s = kSpecs[i].d;
     if (s.nq == d.nq && s.nv == d.nv && s.nu == d.nu && s.nbody == d.nbody && s.njnt == d.njnt && s.ncon == d.ncon && s.nlimit == d.nlimit &&
-        s.npair == d.npair && s.nlevel == d.nlevel && s.nroot == d.nroot)
+        s.npair == d.npair && s.nlevel == d.nlevel && s.nroot == d.nroot && s.ncvx == d.ncvx && s.ncvxvert == d.ncvxvert)
       return i;
   }
   return -1;
@@ -1221,15 +1267,17 @@ extern "C" int32_t mppo_model_open(const void* host_blob, size_t nbytes, const v
   ModelView& v = m->mv;
   v.nq = wi[3]; v.nv = wi[4]; v.nu = wi[5]; v.nbody = wi[6]; v.njnt = wi[7]; v.ncon = wi[8]; v.nlimit = wi[9];
   v.iterations = wi[10]; v.ls_iterations = wi[11]; v.nlevel = wi[12]; v.nroot = wi[13]; v.include_c = wi[14] ? 1 : 0; v.npair = wi[15];
+  v.ncvx = wi[33]; v.ncvxvert = wi[34];
   v.nefc = v.nlimit + 4 * v.ncon;
   v.timestep = wf[16]; v.tolerance = wf[17]; v.ls_tolerance = wf[18]; v.impratio = wf[19]; v.plane_z = wf[20]; v.meaninertia = wf[21];
   auto bad = [&](const char* what) { delete m; return fail(MPPO_EMODEL, "model blob: %s", what); };
   if (v.nq < 1 || v.nv < 1 || v.nbody < 2 || v.nbody > 64 || v.nv > 64 || v.nq > 128 || v.nu < 0 || v.nu > v.nv || v.njnt < 1 ||
-      v.ncon < 0 || v.npair < 0 || v.npair > v.ncon || v.nlimit < 0 || v.nroot < 1 || v.nlevel < 1 || v.iterations < 0 || v.ls_iterations < 0)
+      v.ncon < 0 || v.npair < 0 || v.npair > v.ncon || v.nlimit < 0 || v.nroot < 1 || v.nlevel < 1 || v.iterations < 0 || v.ls_iterations < 0 ||
+      v.ncvx < 0 || 4 * v.ncvx > v.ncon - v.npair || v.ncvxvert < 4 * v.ncvx || v.ncvxvert > 64 * 64)
     return bad("dimension out of the supported range (nbody<=64, nv<=64)");
   if (!(v.timestep > 0.f) || !(v.meaninertia > 0.f) || !(v.impratio > 0.f)) return bad("non-positive timestep / meaninertia / impratio");
   const int32_t* dir = wi + kBlobHeaderWords;
-  const BlobDims bd{v.nq, v.nv, v.nu, v.nbody, v.njnt, v.ncon, v.nlimit, v.npair, v.nlevel, v.nroot};
+  const BlobDims bd{v.nq, v.nv, v.nu, v.nbody, v.njnt, v.ncon, v.nlimit, v.npair, v.nlevel, v.nroot, v.ncvx, v.ncvxvert};
   const BlobOffsets canon = blob_offsets(bd);
   const size_t dir_end = kBlobHeaderWords + 2 * (size_t)BLOB_ARRAY_COUNT;
   if (dir_end > total) return bad("directory past the end");
@@ -1251,8 +1299,14 @@ extern "C" int32_t mppo_model_open(const void* host_blob, size_t nbytes, const v
       !in_range(BI_dof_jntid, 0, v.njnt) || !in_range(BI_dof_parentid, -1, v.nv) || !in_range(BI_dof_qposadr, -1, v.nq) ||
       !in_range(BI_act_dofid, 0, v.nv) || !in_range(BI_act_qposadr, 0, v.nq) || !in_range(BI_con_bodyid, 1, v.nbody) || !in_range(BI_pair_body, 1, v.nbody) ||
       !in_range(BI_lim_jntid, 0, v.njnt) || !in_range(BI_level_adr, 0, v.nbody) || !in_range(BI_level_body, 1, v.nbody) ||
-      !in_range(BI_root_body, 1, v.nbody) || !in_range(BI_body_jntnum, 0, v.njnt + 1) || !in_range(BI_body_jntadr, -1, v.njnt))
+      !in_range(BI_root_body, 1, v.nbody) || !in_range(BI_body_jntnum, 0, v.njnt + 1) || !in_range(BI_body_jntadr, -1, v.njnt) ||
+      !in_range(BI_con_cvx, -1, 4 * v.ncvx) || !in_range(BI_cvx_body, 1, v.nbody) || !in_range(BI_cvx_vadr, 0, v.ncvxvert + 1))
     return bad("index table entry out of range");
+  {
+    const int32_t* va = HI(BI_cvx_vadr);
+    for (int k = 0; k < v.ncvx; ++k) if (va[k + 1] < va[k] + 4 || va[k + 1] - va[k] > 64) return bad("a convex geom needs 4 .. 64 hull vertices");
+    if (v.ncvx > 0 && (va[0] != 0 || va[v.ncvx] != v.ncvxvert)) return bad("cvx_vadr does not cover the vertex table");
+  }
   {
     const int32_t *jt = HI(BI_jnt_type), *qa = HI(BI_jnt_qposadr), *da = HI(BI_jnt_dofadr), *jn = HI(BI_body_jntnum), *ja = HI(BI_body_jntadr),
                   *par = HI(BI_body_parent), *dp = HI(BI_dof_parentid), *la = HI(BI_level_adr);
@@ -1275,7 +1329,7 @@ extern "C" int32_t mppo_model_open(const void* host_blob, size_t nbytes, const v
   v.obs_dim = v.nq + 2 * v.nv + (v.include_c ? 16 * (v.nbody - 1) : 0);  // env.py:246-259
   v.obs_pad = (v.obs_dim + 3) & ~3;
   v.rec_dim = v.obs_pad + ((v.nv + 2 + 3) & ~3);
-  m->lds = make_phys_lds(v.nq, v.nv, v.nu, v.nbody, v.njnt, v.ncon, v.nefc, v.nroot);
+  m->lds = make_phys_lds(v.nq, v.nv, v.nu, v.nbody, v.njnt, v.ncon, v.nefc, v.nroot, v.ncvx);
   m->spec = find_spec(bd);
   m->lds_bytes = (v.blob_words + m->lds.total * kEnvsPerBlock) * 4;
   if (m->lds_bytes > 160 * 1024) { delete m; return fail(MPPO_EMODEL, "model needs %d bytes of LDS per workgroup (limit 163840)", m->lds_bytes); }

@@ -172,15 +172,30 @@ __global__ void __launch_bounds__(WTHREADS) wgrad_kernel(WgradArgs a, PeerStep p
   if (h == 0) cred[g][i] = colsum;
   __syncthreads();
   float sq = 0.f;
+  if (PEER && (p.N & 3) == 0 && (p.off_w & 3) == 0) {
+    // system-scope stores are one fabric write each: four columns of a row per thread and ONE 16-byte store (a dword store moves a
+    // quarter of the bytes for the same cost, MI355X_MICROARCH.md "stores of each flavour"); same sums, same order per element
+    if (t < WTILE * WTILE / 4) {
+      const int row = t >> 3, col = (t & 7) * 4;
+      float v[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-  for (int e = 0; e < 2; ++e) {
-    const int idx = t + WTHREADS * e, row = idx >> 5, col = idx & 31;
-    float v = 0.f;
+      for (int k = 0; k < WWAVES; ++k)
 #pragma unroll
-    for (int k = 0; k < WWAVES; ++k) v += red[k][row * (WTILE + 1) + col];
-    if (m0 + row < p.M && n0 + col < p.N) {
-      gstore<PEER>(&a.grad[p.off_w + (size_t)(m0 + row) * p.N + n0 + col], v);
-      sq += v * v;
+        for (int c = 0; c < 4; ++c) v[c] += red[k][row * (WTILE + 1) + col + c];
+      if (m0 + row < p.M && n0 + col < p.N)  // (N a multiple of four: the quad is inside or outside as a whole)
+        sys_store_f4(a.grad, ((size_t)p.off_w + (size_t)(m0 + row) * p.N + n0 + col) * 4, make_float4(v[0], v[1], v[2], v[3]));
+    }
+  } else {
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      const int idx = t + WTHREADS * e, row = idx >> 5, col = idx & 31;
+      float v = 0.f;
+#pragma unroll
+      for (int k = 0; k < WWAVES; ++k) v += red[k][row * (WTILE + 1) + col];
+      if (m0 + row < p.M && n0 + col < p.N) {
+        gstore<PEER>(&a.grad[p.off_w + (size_t)(m0 + row) * p.N + n0 + col], v);
+        sq += v * v;
+      }
     }
   }
   if (do_thin && t < 4 * WTILE) {

@@ -15,6 +15,7 @@ enum BlobInt {
   BI_act_dofid, BI_act_qposadr, BI_act_ctrllimited, BI_act_forcelimited,
   BI_con_bodyid, BI_lim_jntid, BI_pair_body,
   BI_level_adr, BI_level_body, BI_root_body, BI_body_subtree_mask, BI_body_ancdof_mask, BI_dof_velmask, BI_dof_qposadr,
+  BI_con_cvx, BI_cvx_body, BI_cvx_vadr,
   BI_COUNT
 };
 enum BlobF32 {
@@ -25,11 +26,12 @@ enum BlobF32 {
   BF_act_gear, BF_act_gain, BF_act_bias, BF_act_ctrlrange, BF_act_forcerange,
   BF_con_lpos, BF_con_radius, BF_con_friction, BF_con_axis, BF_pair_geom,
   BF_contact_solref, BF_contact_solimp, BF_limit_solref, BF_limit_solimp,
+  BF_cvx_vert,
   BLOB_ARRAY_COUNT
 };
 
 constexpr uint32_t kBlobMagic = 0x4D50504F;
-constexpr uint32_t kBlobVersion = 3;
+constexpr uint32_t kBlobVersion = 4;
 constexpr int kBlobHeaderWords = 64;
 constexpr int JNT_FREE = 0, JNT_HINGE = 2, JNT_SLIDE = 3;
 constexpr float MJ_MINVAL = 1e-15f, MJ_MINIMP = 0.0001f, MJ_MAXIMP = 0.9999f;
@@ -41,6 +43,7 @@ typedef unsigned long long u64;
 struct ModelView {
   int nq, nv, nu, nbody, njnt, ncon, nlimit, nefc, iterations, ls_iterations, nlevel, nroot;
   int npair;  // the last npair of the ncon contact slots are geom-geom pairs (pair_body / pair_geom); the others are ground contacts
+  int ncvx, ncvxvert;  // convex (mesh) geoms against the plane: four contact slots each (con_cvx), ncvxvert hull vertices in all (cvx_vert, body frame)
   int obs_dim, obs_pad, rec_dim;
   int include_c;  // observation = qpos, qvel, cinert[1:], cvel[1:], qfrc_actuator (1) or qpos, qvel, qfrc_actuator (0): env.py:246-259
   float timestep, tolerance, ls_tolerance, impratio, plane_z, meaninertia;
@@ -52,7 +55,7 @@ struct ModelView {
 // The dims every array length follows from, and the canonical placement of the arrays (model.py _to_blob: directory order, each
 // array padded to 4 words, first array right after the directory).  mppo_model_open refuses a blob laid out differently, so a
 // kernel compiled for fixed dims may take the offsets as constants.
-struct BlobDims { int nq, nv, nu, nbody, njnt, ncon, nlimit, npair, nlevel, nroot; };
+struct BlobDims { int nq, nv, nu, nbody, njnt, ncon, nlimit, npair, nlevel, nroot, ncvx, ncvxvert; };
 struct BlobOffsets { int o[BLOB_ARRAY_COUNT]; int words; };
 __host__ __device__ constexpr inline int blob_array_len(const BlobDims& d, int k) {
   switch (k) {
@@ -61,7 +64,10 @@ __host__ __device__ constexpr inline int blob_array_len(const BlobDims& d, int k
     case BI_jnt_type: case BI_jnt_qposadr: case BI_jnt_dofadr: case BI_jnt_bodyid: case BI_jnt_limited: case BF_jnt_stiffness: return d.njnt;
     case BI_dof_bodyid: case BI_dof_jntid: case BI_dof_parentid: case BI_dof_qposadr: case BF_dof_armature: case BF_dof_damping: case BF_dof_invweight0: return d.nv;
     case BI_act_dofid: case BI_act_qposadr: case BI_act_ctrllimited: case BI_act_forcelimited: case BF_act_gear: case BF_act_gain: return d.nu;
-    case BI_con_bodyid: case BF_con_radius: return d.ncon;
+    case BI_con_bodyid: case BF_con_radius: case BI_con_cvx: return d.ncon;
+    case BI_cvx_body: return d.ncvx;
+    case BI_cvx_vadr: return d.ncvx + 1;
+    case BF_cvx_vert: return 3 * d.ncvxvert;
     case BI_lim_jntid: return d.nlimit;
     case BI_pair_body: return 2 * d.npair;
     case BI_level_adr: return d.nlevel + 1;
@@ -106,13 +112,14 @@ struct PhysLds {
   int qfs, qas, qact, qacc, Ma, grad, Mgrad, search, mv, qfc, t0, t1;
   int D, aref, jaref, jv, force;
   int conpos, condist, confr;  // per contact slot: point, distance, frame rows (normal, first tangent)
+  int cvxsel, cvxok;           // per convex geom: the four hull vertices chosen this step (body frame) and whether each slot is a first occurrence
   int A, ximat, xmat, xanchor, xaxis, C1, C2, cdofdot, cfrc, J, ldj, recbuf;
   int total;
 };
 
 __host__ __device__ constexpr inline int imax_(int a, int b) { return a > b ? a : b; }
 
-__host__ __device__ constexpr inline PhysLds make_phys_lds(int nq, int nv, int nu, int nbody, int njnt, int ncon, int nefc, int nroot) {
+__host__ __device__ constexpr inline PhysLds make_phys_lds(int nq, int nv, int nu, int nbody, int njnt, int ncon, int nefc, int nroot, int ncvx = 0) {
   PhysLds p{};
   int o = 0;
   auto take = [&](int n) { int r = o; o += (n + 3) & ~3; return r; };
@@ -126,6 +133,7 @@ __host__ __device__ constexpr inline PhysLds make_phys_lds(int nq, int nv, int n
   const int ne = nefc > 0 ? nefc : 1;
   p.D = take(ne); p.aref = take(ne); p.jaref = take(ne); p.jv = take(ne); p.force = take(ne);
   p.conpos = take(3 * (ncon > 0 ? ncon : 1)); p.condist = take(ncon > 0 ? ncon : 1); p.confr = take(6 * (ncon > 0 ? ncon : 1));
+  p.cvxsel = take(12 * ncvx); p.cvxok = take(4 * ncvx);
   // region A, four lifetimes (separated by workgroup barriers in the kernel):
   //   A1 kinematics temporaries | A2 Cholesky work copies | A3 velocity/RNE scratch | A4 constraint Jacobian | A5 record staging
   p.A = o;

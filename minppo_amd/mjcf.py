@@ -18,12 +18,16 @@ Subset
   <worldbody>: one <geom type="plane"> (the ground), <body name pos quat|euler|axisangle|xyaxes|zaxis childclass>
       <inertial pos quat|euler mass diaginertia|fullinertia>
       <freejoint/> | <joint type="free|hinge|slide" name pos axis range limited ref damping armature stiffness>
-      <geom type="sphere|capsule|box" size pos quat|euler fromto friction mass density contype conaffinity>
-            (a box collides with the ground through its eight corners; type="cylinder|ellipsoid|mesh" geoms are accepted ONLY with
-             contype="0" conaffinity="0", i.e. visual or inertia-only; cylinder / ellipsoid then still contribute to inertiafromgeom)
+      <geom type="sphere|capsule|box|mesh" size pos quat|euler fromto friction mass density contype conaffinity mesh>
+            (a box collides with the ground through its eight corners; a mesh collides with the ground as its CONVEX HULL, as in
+             MuJoCo / MJX - up to four contacts per step, MJX's plane_convex; type="cylinder|ellipsoid" geoms are accepted ONLY with
+             contype="0" conaffinity="0", i.e. visual or inertia-only, and then still contribute to inertiafromgeom; a mesh never
+             contributes an inertia: its body needs an <inertial>)
+  <asset><mesh name vertex="x y z ..." | file="*.obj|*.stl" scale>: the collision geometry of mesh geoms (files relative to the MJCF,
+            honouring <compiler meshdir>); everything else under <asset> is visual and ignored
   <actuator>: <position joint kp kv gear ctrlrange forcerange>, <motor joint gear ctrlrange forcerange>
 Contacts: geom-vs-ground-plane, and sphere / capsule geom pairs between bodies that MuJoCo would test (contype / conaffinity
-masks, same-body and parent-child pairs filtered); a box that the masks pair with another geom is an error (`compile_model`).
+masks, same-body and parent-child pairs filtered); a box or mesh that the masks pair with another geom is an error (`compile_model`).
 """
 
 from __future__ import annotations
@@ -36,8 +40,8 @@ from typing import Dict, List, Optional, Sequence, Tuple
 
 import numpy as np
 
-from minppo_amd.model import (GEOM_BOX, GEOM_CAPSULE, GEOM_SPHERE, JNT_FREE, JNT_HINGE, JNT_SLIDE, ActuatorSpec, BodySpec, GeomSpec, JointSpec, ModelSpec, _normalize, _qmat,
-                              _qmul)
+from minppo_amd.model import (GEOM_BOX, GEOM_CAPSULE, GEOM_MESH, GEOM_SPHERE, JNT_FREE, JNT_HINGE, JNT_SLIDE, MAX_CONVEX_VERTS, ActuatorSpec, BodySpec, GeomSpec, JointSpec,
+                              ModelSpec, _normalize, _qmat, _qmul)
 
 logger = logging.getLogger(__name__)
 
@@ -245,11 +249,55 @@ def _combine_inertia(parts: List[Tuple[float, np.ndarray, np.ndarray, np.ndarray
 
 
 # ---------------------------------------------------------------------------
+# meshes: vertices -> convex hull
+# ---------------------------------------------------------------------------
+
+
+def _read_mesh_file(path: Path) -> np.ndarray:
+    """Vertex positions of a Wavefront OBJ (`v x y z` lines) or an STL (binary or ASCII) file, [V, 3]."""
+    raw = path.read_bytes()
+    suffix = path.suffix.lower()
+    if suffix == ".obj":
+        v = [[float(x) for x in line.split()[1:4]] for line in raw.decode("utf-8", "replace").splitlines() if line.startswith("v ")]
+        return np.asarray(v, np.float64).reshape(-1, 3)
+    if suffix == ".stl":
+        if raw[:5].lower() == b"solid" and b"facet" in raw[:1000]:
+            v = [[float(x) for x in line.split()[1:4]] for line in raw.decode("utf-8", "replace").splitlines() if line.strip().startswith("vertex")]
+            return np.asarray(v, np.float64).reshape(-1, 3)
+        n = int(np.frombuffer(raw[80:84], "<u4")[0])
+        if len(raw) < 84 + 50 * n:
+            raise ValueError(f"{path}: truncated binary STL ({n} triangles announced)")
+        tri = np.frombuffer(raw[84:84 + 50 * n], np.dtype([("n", "<f4", 3), ("v", "<f4", (3, 3)), ("a", "<u2")]))
+        return tri["v"].reshape(-1, 3).astype(np.float64)
+    raise ValueError(f"{path}: mesh files must be .obj or .stl (or give the vertices inline: <mesh vertex=...>)")
+
+
+def convex_hull_vertices(points: np.ndarray, what: str = "mesh") -> np.ndarray:
+    """The vertices of the convex hull of `points`, in the order they appear in `points` (what MuJoCo keeps of a mesh for
+    collision).  More than MAX_CONVEX_VERTS hull vertices is an error: collision meshes are expected to be decimated."""
+    from scipy.spatial import ConvexHull, QhullError
+
+    pts = np.asarray(points, np.float64).reshape(-1, 3)
+    _, first = np.unique(pts, axis=0, return_index=True)
+    pts = pts[np.sort(first)]  # duplicates dropped, the file's vertex order kept (the order decides ties in plane_convex)
+    if len(pts) < 4:
+        raise ValueError(f"{what}: a mesh needs at least four distinct vertices")
+    try:
+        hull = ConvexHull(pts)
+    except QhullError as exc:
+        raise ValueError(f"{what}: degenerate mesh (flat or collinear): {str(exc).splitlines()[0]}") from exc
+    keep = np.sort(hull.vertices)
+    if len(keep) > MAX_CONVEX_VERTS:
+        raise ValueError(f"{what}: the convex hull has {len(keep)} vertices (limit {MAX_CONVEX_VERTS}); decimate the collision mesh")
+    return pts[keep]
+
+
+# ---------------------------------------------------------------------------
 # parser
 # ---------------------------------------------------------------------------
 
 
-def parse_mjcf(xml: str, name: str = "mjcf") -> ModelSpec:
+def parse_mjcf(xml: str, name: str = "mjcf", base_dir: Optional[Path] = None) -> ModelSpec:
     root = ET.fromstring(xml)
     if root.tag != "mujoco":
         raise ValueError(f"not an MJCF document: root element <{root.tag}>")
@@ -293,6 +341,32 @@ def parse_mjcf(xml: str, name: str = "mjcf") -> ModelSpec:
                          "warmstart": "enable", "frictionloss": "enable", "eulerdamp": "enable", "filterparent": "enable"}.get(k, v) and k not in ("energy", "fwdinv", "multiccd", "island"):
                     raise ValueError(f"<option><flag {k}={v!r}> changes the physics pipeline and is not supported")
 
+    # collision meshes (everything else under <asset> is visual)
+    meshes: Dict[str, np.ndarray] = {}
+    meshdir = ""
+    if root.find("compiler") is not None:
+        meshdir = root.find("compiler").get("meshdir", root.find("compiler").get("assetdir", ""))
+    for asset in root.findall("asset"):
+        for me in asset.findall("mesh"):
+            mname = me.get("name") or (Path(me.get("file", "")).stem if me.get("file") else None)
+            if not mname:
+                raise ValueError("<asset><mesh> needs a name (or a file to take it from)")
+            scale = np.array(_floats(me.get("scale", "1 1 1"), 3, f"mesh {mname} scale"))
+            if "vertex" in me.attrib:
+                pts = np.asarray(_floats(me.get("vertex")), np.float64)
+                if pts.size % 3 or pts.size < 12:
+                    raise ValueError(f"mesh {mname}: vertex needs 3 numbers per vertex, at least four vertices")
+                pts = pts.reshape(-1, 3)
+            elif "file" in me.attrib:
+                if base_dir is None:
+                    raise ValueError(f"mesh {mname}: file={me.get('file')!r} needs the MJCF's directory (load it with load_mjcf / pass base_dir)")
+                pts = _read_mesh_file(Path(base_dir) / meshdir / me.get("file"))
+            else:
+                raise ValueError(f"mesh {mname}: neither vertex nor file")
+            if any(k in me.attrib for k in ("refpos", "refquat")):
+                raise ValueError(f"mesh {mname}: refpos / refquat are not supported")
+            meshes[mname] = pts * scale[None, :]
+
     world = root.find("worldbody")
     if world is None:
         raise ValueError("MJCF has no <worldbody>")
@@ -320,10 +394,25 @@ def parse_mjcf(xml: str, name: str = "mjcf") -> ModelSpec:
             quat = _z_to(ft[3:] - ft[:3])
             half = 0.5 * float(np.linalg.norm(ft[3:] - ft[:3]))
             size = [size[0], half] if gtype in ("capsule", "cylinder") else size
-        if gtype == "mesh":
-            if collides:
-                raise ValueError(f"{what}: mesh geoms cannot collide here (set contype='0' conaffinity='0'; sphere / capsule colliders only)")
-            return "inert", None, None
+        if gtype == "mesh" or ("mesh" in a and "type" not in a):
+            if not collides:
+                return "inert", None, None  # visual only; a mesh contributes no inertia here (the body needs an <inertial>)
+            mname = a.get("mesh")
+            if mname not in meshes:
+                raise ValueError(f"{what}: mesh {mname!r} is not defined under <asset> (with vertex=... or an .obj / .stl file)")
+            if "margin" in a and float(a["margin"]) != 0 or "gap" in a and float(a["gap"]) != 0:
+                raise ValueError(f"{what}: contact margin / gap are not supported")
+            if int(a.get("condim", "3")) != 3:
+                raise ValueError(f"{what}: condim {a['condim']} (only 3: pyramidal sliding friction)")
+            for k in ("solref", "solimp"):
+                if k in a:
+                    solrefs["contact"].add((k, tuple(_floats(a[k]))))
+            fr = tuple((_floats(a["friction"]) + [0.005, 0.0001])[:3]) if "friction" in a else (1.0, 0.005, 0.0001)
+            # MuJoCo re-centres a mesh on its centre of mass and principal axes and compensates in the geom's pose: the shape in the
+            # body frame is unchanged, so the hull is kept in the file's own mesh frame under the geom's pos / quat as written
+            gs = GeomSpec(GEOM_MESH, (), pos=tuple(pos), quat=tuple(quat), friction=fr, contype=contype, conaffinity=conaff,
+                          vertices=tuple(map(tuple, convex_hull_vertices(meshes[mname], f"mesh {mname}"))))
+            return "collide", gs, None
         need = {"sphere": 1, "capsule": 2, "cylinder": 2, "box": 3, "ellipsoid": 3}.get(gtype)
         if need is None:
             raise ValueError(f"{what}: geom type {gtype!r} is outside the supported MJCF subset")
@@ -530,7 +619,7 @@ def parse_mjcf(xml: str, name: str = "mjcf") -> ModelSpec:
 
 def load_mjcf(path: str) -> ModelSpec:
     p = Path(path)
-    return parse_mjcf(p.read_text(), name=p.stem)
+    return parse_mjcf(p.read_text(), name=p.stem, base_dir=p.parent)
 
 
 # ---------------------------------------------------------------------------
@@ -550,6 +639,11 @@ def to_mjcf(spec: ModelSpec) -> str:
     d = ET.SubElement(ET.SubElement(root, "default"), "joint", solreflimit=_fmt(spec.limit_solref), solimplimit=_fmt(spec.limit_solimp))
     del d
     ET.SubElement(root.find("default"), "geom", solref=_fmt(spec.contact_solref), solimp=_fmt(spec.contact_solimp), condim="3")
+    mesh_geoms = [(b.name, gi, g) for b in spec.bodies for gi, g in enumerate(b.geoms) if g.type == GEOM_MESH]
+    if mesh_geoms:
+        asset = ET.SubElement(root, "asset")
+        for bname, gi, g in mesh_geoms:
+            ET.SubElement(asset, "mesh", name=f"{bname}_mesh{gi}", vertex=" ".join(_fmt(v) for v in g.vertices))
     world = ET.SubElement(root, "worldbody")
     if spec.has_plane:
         ET.SubElement(world, "geom", name="floor", type="plane", size="0 0 1", pos=f"0 0 {float(spec.plane_z)!r}", friction=_fmt(spec.plane_friction),
@@ -573,7 +667,11 @@ def to_mjcf(spec: ModelSpec) -> str:
             if j.range is not None:
                 a["range"] = _fmt(j.range)
             ET.SubElement(e, "joint", **a)
-        for g in b.geoms:
+        for gi, g in enumerate(b.geoms):
+            if g.type == GEOM_MESH:
+                ET.SubElement(e, "geom", type="mesh", mesh=f"{b.name}_mesh{gi}", pos=_fmt(g.pos), quat=_fmt(g.quat), friction=_fmt(g.friction), contype=str(g.contype),
+                              conaffinity=str(g.conaffinity))
+                continue
             ET.SubElement(e, "geom", type={GEOM_SPHERE: "sphere", GEOM_CAPSULE: "capsule", GEOM_BOX: "box"}[g.type], size=_fmt(g.size), pos=_fmt(g.pos), quat=_fmt(g.quat), friction=_fmt(g.friction),
                           contype=str(g.contype), conaffinity=str(g.conaffinity))
     act = ET.SubElement(root, "actuator")

@@ -32,12 +32,13 @@ from typing import Dict, List, Optional, Sequence, Tuple
 import numpy as np
 
 JNT_FREE, JNT_HINGE, JNT_SLIDE = 0, 2, 3  # (ball=1 unsupported)
-GEOM_SPHERE, GEOM_CAPSULE, GEOM_BOX = 2, 3, 6  # MuJoCo's mjtGeom numbering
+GEOM_SPHERE, GEOM_CAPSULE, GEOM_BOX, GEOM_MESH = 2, 3, 6, 7  # MuJoCo's mjtGeom numbering
 
 MJ_MINVAL = 1e-15
+MAX_CONVEX_VERTS = 64  # hull vertices of one mesh collider (the kernel scans them five times per step)
 
 BLOB_MAGIC = 0x4D50504F  # "MPPO"
-BLOB_VERSION = 3  # 2: header word include_c_vals; 3: geom-geom pairs (npair, pair_body, pair_geom) and con_axis
+BLOB_VERSION = 4  # 2: header word include_c_vals; 3: geom-geom pairs (npair, pair_body, pair_geom) and con_axis; 4: convex (mesh) geoms against the plane
 
 
 # ---------------------------------------------------------------------------
@@ -70,6 +71,9 @@ class GeomSpec:
     # (MuJoCo's own default is 1 / 1: every pair that is not parent-child).
     contype: int = 0
     conaffinity: int = 1
+    # GEOM_MESH: the vertices of the mesh's CONVEX HULL in the geom's own frame ([V, 3]; `size` is unused).  A mesh collides as its
+    # convex hull, like in MuJoCo / MJX, and only with the ground plane here.
+    vertices: Optional[Sequence[Sequence[float]]] = None
 
 
 @dataclass
@@ -207,6 +211,11 @@ class CompiledModel:
         return int(self.t["nlimit"])
 
     @property
+    def ncvx(self) -> int:
+        """convex (mesh) geoms that can meet the ground plane: four contact slots each."""
+        return int(self.t["ncvx"])
+
+    @property
     def nefc(self) -> int:
         return self.nlimit + 4 * self.ncon
 
@@ -308,7 +317,13 @@ def compile_model(spec: ModelSpec) -> CompiledModel:
         body_dofnum[bi] = nv - (body_dofadr[bi] if body_dofadr[bi] >= 0 else nv)
         for g in b.geoms:
             size = list(g.size) + [0.0] * (3 - len(g.size))
-            geoms.append((g.type, bi, list(g.pos), list(_normalize(g.quat)), size, list(g.friction), int(g.contype), int(g.conaffinity)))
+            if g.type == GEOM_MESH:
+                if g.vertices is None or len(g.vertices) < 4:
+                    raise ValueError(f"body {b.name}: a mesh geom needs the (at least four) vertices of its convex hull")
+                if len(g.vertices) > MAX_CONVEX_VERTS:
+                    raise ValueError(f"body {b.name}: a mesh collider with {len(g.vertices)} hull vertices (limit {MAX_CONVEX_VERTS}: decimate the collision mesh)")
+            geoms.append((g.type, bi, list(g.pos), list(_normalize(g.quat)), size, list(g.friction), int(g.contype), int(g.conaffinity),
+                          None if g.vertices is None else np.asarray(g.vertices, np.float64).reshape(-1, 3)))
 
     njnt = len(jnt_type)
     # dof_parentid: previous dof in the same body, else last dof of the nearest ancestor with dofs
@@ -411,14 +426,27 @@ def compile_model(spec: ModelSpec) -> CompiledModel:
     def _masks_match(ct1, ca1, ct2, ca2):
         return bool((ct1 & ca2) | (ct2 & ca1))
 
-    con_bodyid, con_lpos, con_radius, con_friction, con_axis = [], [], [], [], []
-    for (gt, bi, gpos, gquat, gsize, gfri, gct, gca) in geoms:
-        if gt not in (GEOM_SPHERE, GEOM_CAPSULE, GEOM_BOX):
+    con_bodyid, con_lpos, con_radius, con_friction, con_axis, con_cvx = [], [], [], [], [], []
+    cvx_body, cvx_vadr, cvx_vert = [], [0], []
+    for (gt, bi, gpos, gquat, gsize, gfri, gct, gca, gverts) in geoms:
+        if gt not in (GEOM_SPHERE, GEOM_CAPSULE, GEOM_BOX, GEOM_MESH):
             raise ValueError(f"unsupported geom type {gt}")
         if not spec.has_plane or not _masks_match(spec.plane_contype, spec.plane_conaffinity, gct, gca):
             continue
         fri = np.maximum(np.asarray(gfri), np.asarray(spec.plane_friction))
         axis_l = np.zeros(3)
+        if gt == GEOM_MESH:
+            # a convex hull against the plane, MJX collision_convex.plane_convex: FOUR slots per geom; which hull vertices fill them
+            # is decided every step (the deepest ones, spread out: _manifold_points), duplicates are switched off
+            k = len(cvx_body)
+            cvx_body.append(bi)
+            for v in gverts:
+                cvx_vert.append(list(np.asarray(gpos) + _qrot(gquat, v)))  # body frame
+            cvx_vadr.append(len(cvx_vert))
+            for j in range(4):
+                con_bodyid.append(bi); con_lpos.append([0.0, 0.0, 0.0]); con_radius.append(0.0); con_friction.append(list(fri)); con_axis.append([0.0, 0.0, 0.0])
+                con_cvx.append(4 * k + j)
+            continue
         if gt == GEOM_SPHERE:
             ends = [np.asarray(gpos, dtype=np.float64)]
         elif gt == GEOM_CAPSULE:
@@ -436,6 +464,7 @@ def compile_model(spec: ModelSpec) -> CompiledModel:
             con_radius.append(0.0 if gt == GEOM_BOX else gsize[0])
             con_friction.append(list(fri))
             con_axis.append(list(axis_l))
+            con_cvx.append(-1)
     nplane = len(con_bodyid)
     # ... then geom-geom pairs between different bodies (sphere / capsule only), filtered as MuJoCo filters them: same weld
     # group and parent-child weld groups are skipped (mj_filterBodyPair), then the contype / conaffinity masks.  geom1 is the
@@ -458,8 +487,9 @@ def compile_model(spec: ModelSpec) -> CompiledModel:
                 continue
             if not _masks_match(gi[6], gi[7], gj[6], gj[7]):
                 continue
-            if GEOM_BOX in (gi[0], gj[0]):
-                raise ValueError("a box geom can only collide with the ground plane: exclude it from geom-geom pairs with contype / conaffinity")
+            if GEOM_BOX in (gi[0], gj[0]) or GEOM_MESH in (gi[0], gj[0]):
+                kind = "box" if GEOM_BOX in (gi[0], gj[0]) else "mesh"
+                raise ValueError(f"a {kind} geom can only collide with the ground plane: exclude it from geom-geom pairs with contype / conaffinity")
             pair_rows.append(((gi[0], gj[0]), gi, gj))
     pair_rows.sort(key=lambda r: r[0])  # stable: geom order inside a group
     pair_body, pair_geom = [], []
@@ -473,7 +503,9 @@ def compile_model(spec: ModelSpec) -> CompiledModel:
         con_radius.append(0.0)
         con_friction.append(list(np.maximum(np.asarray(gi[5]), np.asarray(gj[5]))))
         con_axis.append([0.0, 0.0, 0.0])
+        con_cvx.append(-1)
     npair = len(pair_rows)
+    ncvx, ncvxvert = len(cvx_body), len(cvx_vert)
     ncon = len(con_bodyid)
 
     lim_jnt = [j for j in range(njnt) if jnt_limited[j] and jnt_type[j] != JNT_FREE]
@@ -484,7 +516,7 @@ def compile_model(spec: ModelSpec) -> CompiledModel:
     def put(k, v, dt=np.float64):
         t[k] = np.asarray(v, dtype=dt)
 
-    for k, v in dict(nq=nq, nv=nv, nu=nu, nbody=nbody, njnt=njnt, ncon=ncon, nlimit=nlimit, npair=npair,
+    for k, v in dict(nq=nq, nv=nv, nu=nu, nbody=nbody, njnt=njnt, ncon=ncon, nlimit=nlimit, npair=npair, ncvx=ncvx, ncvxvert=ncvxvert,
                      iterations=spec.iterations, ls_iterations=spec.ls_iterations).items():
         put(k, v, np.int32)
     for k, v in dict(timestep=spec.timestep, tolerance=spec.tolerance, ls_tolerance=spec.ls_tolerance,
@@ -543,6 +575,10 @@ def compile_model(spec: ModelSpec) -> CompiledModel:
     put("con_radius", con_radius)
     put("con_friction", np.reshape(con_friction, (ncon, 3)))
     put("con_axis", np.reshape(con_axis, (ncon, 3)))
+    put("con_cvx", con_cvx, np.int32)
+    put("cvx_body", cvx_body, np.int32)
+    put("cvx_vadr", cvx_vadr, np.int32)
+    put("cvx_vert", np.reshape(cvx_vert, (ncvxvert, 3)))
     put("pair_body", np.reshape(pair_body, (npair, 2)), np.int32)
     put("pair_geom", np.reshape(pair_geom, (npair, 16)))
     put("lim_jntid", lim_jnt, np.int32)
@@ -693,6 +729,7 @@ _BLOB_INT = [
     "act_dofid", "act_qposadr", "act_ctrllimited", "act_forcelimited",
     "con_bodyid", "lim_jntid", "pair_body",
     "level_adr", "level_body", "root_body", "body_subtree_mask", "body_ancdof_mask", "dof_velmask", "dof_qposadr",
+    "con_cvx", "cvx_body", "cvx_vadr",
 ]
 _BLOB_F32 = [
     "gravity", "body_pos", "body_quat", "body_ipos", "body_iquat", "body_mass", "body_inertia",
@@ -702,9 +739,11 @@ _BLOB_F32 = [
     "act_gear", "act_gain", "act_bias", "act_ctrlrange", "act_forcerange",
     "con_lpos", "con_radius", "con_friction", "con_axis", "pair_geom",
     "contact_solref", "contact_solimp", "limit_solref", "limit_solimp",
+    "cvx_vert",
 ]
 _HDR_INT = ["nq", "nv", "nu", "nbody", "njnt", "ncon", "nlimit", "iterations", "ls_iterations", "nlevel", "nroot", "include_c_vals", "npair"]
 _HDR_F32 = ["timestep", "tolerance", "ls_tolerance", "impratio", "plane_z", "meaninertia"]
+_HDR_INT2 = ["ncvx", "ncvxvert"]  # words 33..: dims that arrived after the first header block was full
 BLOB_HEADER_WORDS = 64  # fixed-size header; array directory follows
 
 
@@ -745,6 +784,8 @@ def _to_blob(cm: CompiledModel, include_c_vals: bool = True) -> bytes:
     for i, k in enumerate(_HDR_F32):
         struct.pack_into("<f", hdr, 4 * (16 + i), float(t[k]))
     struct.pack_into("<i", hdr, 4 * 32, ndir)
+    for i, k in enumerate(_HDR_INT2):
+        struct.pack_into("<i", hdr, 4 * (33 + i), int(t[k]))
     d = bytearray()
     for off, n in dir_entries:
         d += struct.pack("<2i", off, n)
@@ -886,6 +927,25 @@ def synth_brick() -> ModelSpec:
     return ModelSpec(name="synth_brick", bodies=bodies, actuators=[], free_root_z=0.12)
 
 
+# hull vertices of an irregular "foot" (no two edges parallel, no symmetric pairs: the argmax steps of plane_convex have no exact ties)
+WEDGE_VERTS = ((0.11, 0.045, -0.021), (0.12, -0.04, -0.019), (-0.09, -0.052, -0.02), (-0.10, 0.038, -0.018), (0.07, 0.03, 0.028), (0.06, -0.025, 0.03),
+               (-0.05, -0.03, 0.035), (-0.06, 0.02, 0.04), (0.0, 0.0, 0.055))
+
+
+def synth_wedge() -> ModelSpec:
+    """A free body whose collider is a convex MESH (nine hull vertices) with a second, hinged mesh body hanging off it: the
+    plane-convex contact of SURVEY 8(f1) (MJX collision_convex.plane_convex: four slots per mesh geom)."""
+    bodies = [
+        BodySpec("wedge", "world", quat=(0.9848078, 0.1227878, 0.1227878, 0.0), mass=1.5, inertia=(0.0021, 0.0052, 0.0061),
+                 joints=[JointSpec("root", JNT_FREE)], geoms=[GeomSpec(GEOM_MESH, (), vertices=WEDGE_VERTS, friction=(0.9, 0.005, 0.0001))]),
+        BodySpec("flap", "wedge", pos=(0.12, 0.0, 0.03), mass=0.3, inertia=(0.0004, 0.0006, 0.0007),
+                 joints=[JointSpec("flap_hinge", JNT_HINGE, axis=(0.0, 1.0, 0.0), range=(-0.8, 0.8), damping=0.05, armature=0.002)],
+                 geoms=[GeomSpec(GEOM_MESH, (), pos=(0.06, 0.0, 0.0), quat=(0.9914449, 0.0, 0.0, 0.1305262),
+                                 vertices=tuple((0.6 * x, 0.7 * y, 0.8 * z) for x, y, z in WEDGE_VERTS))]),
+    ]
+    return ModelSpec(name="synth_wedge", bodies=bodies, actuators=[ActuatorSpec("flap_hinge", kp=6.0, kv=0.3, ctrlrange=(-0.8, 0.8))], free_root_z=0.14)
+
+
 KSCALE_ID_TABLE = {
     "5eb3cb7f23232298": "synth_stompy_pro",  # reference configs/stompy_pro.yaml:1
 }
@@ -898,6 +958,7 @@ BUILTIN_MODELS = {
     "synth_pendulum": synth_pendulum,
     "synth_ball": synth_ball,
     "synth_brick": synth_brick,
+    "synth_wedge": synth_wedge,
 }
 
 _CACHE: Dict[str, CompiledModel] = {}

@@ -172,6 +172,28 @@ def closest_segment_to_segment_points(a0, a1, b0, b1):
     return np.where(pick, new_a, best_a), np.where(pick, best_b, new_b)
 
 
+def manifold_points(poly, mask, n):
+    """MJX collision_convex._manifold_points, batched over environments ([3P-recall]: MuJoCo 3.1 / 3.2; not present under
+    /root/reference): four vertices of `poly` [V, 3] that span the contact patch of the candidates `mask` [N, V] seen along the
+    normal `n` [N, 3] - a: the first candidate, b: the candidate farthest from a, c: the one farthest from the line a-b (in the
+    plane orthogonal to n), d: the one farthest from the edges a-c / b-c.  Non-candidates carry -1e6; argmax takes the first maximum."""
+    dist_mask = np.where(mask, 0.0, -1e6)
+    a_idx = np.argmax(dist_mask, axis=1)
+    a = poly[a_idx]                                                     # [N, 3]
+    b_idx = np.argmax(((a[:, None, :] - poly[None]) ** 2).sum(-1) + dist_mask, axis=1)
+    b = poly[b_idx]
+    ab = np.cross(n, a - b)
+    ap = a[:, None, :] - poly[None]                                     # [N, V, 3]
+    c_idx = np.argmax(np.abs(np.einsum("nvk,nk->nv", ap, ab)) + dist_mask, axis=1)
+    c = poly[c_idx]
+    ac, bc = np.cross(n, a - c), np.cross(n, b - c)
+    bp = b[:, None, :] - poly[None]
+    dist_bp = np.abs(np.einsum("nvk,nk->nv", bp, bc)) + dist_mask
+    dist_ap = np.abs(np.einsum("nvk,nk->nv", ap, ac)) + dist_mask
+    d_idx = np.argmax(np.concatenate([dist_bp, dist_ap], axis=1), axis=1) % poly.shape[0]
+    return np.stack([a_idx, b_idx, c_idx, d_idx], axis=1)
+
+
 def sphere_sphere(pos1, r1, pos2, r2):
     """MJX collision_primitive._sphere_sphere -> dist, contact point, normal (from geom 1 to geom 2; +x when the centres coincide)."""
     n, dist = _normalize_with_norm(pos2 - pos1)
@@ -352,11 +374,29 @@ class Physics:
         cpos = np.zeros((N, nc, 3), dt)
         frame = np.zeros((N, nc, 3, 3), dt)
         n = np.array([0.0, 0.0, 1.0], dt)
+        # convex (mesh) geoms: which hull vertices fill the geom's four slots this step (MJX collision_convex.plane_convex)
+        ncvx = int(t["ncvx"]) if "ncvx" in t else 0
+        sel_pos = np.zeros((N, 4 * ncvx, 3), dt)
+        sel_ok = np.ones((N, 4 * ncvx), bool)
+        for k in range(ncvx):
+            b = t["cvx_body"][k]
+            vert = np.asarray(t["cvx_vert"][t["cvx_vadr"][k]:t["cvx_vadr"][k + 1]], dt)  # [V, 3], body frame
+            R = qmat(d.xquat[:, b])                                                        # [N, 3, 3]: world = R . local
+            nl = R[:, 2, :]                                                                # the plane's normal (+z) in the body frame
+            support = (t["plane_z"] - d.xpos[:, b, 2])[:, None] - nl @ vert.T               # [N, V]: depth below the plane
+            idx = manifold_points(vert, support > np.maximum(0.0, support.max(1) - 1e-3)[:, None], nl)  # [N, 4]
+            for j in range(4):
+                sel_pos[:, 4 * k + j] = vert[idx[:, j]]
+                sel_ok[:, 4 * k + j] = ~np.any(idx[:, :j] == idx[:, j:j + 1], axis=1)      # unique = first occurrence of the vertex
         for c in range(nc - npair):
             b = t["con_bodyid"][c]
-            centre = d.xpos[:, b] + qrot(d.xquat[:, b], t["con_lpos"][c])
+            cs = int(t["con_cvx"][c]) if ncvx else -1
+            lpos = sel_pos[:, cs] if cs >= 0 else np.broadcast_to(np.asarray(t["con_lpos"][c], dt), (N, 3))
+            centre = d.xpos[:, b] + qrot(d.xquat[:, b], lpos)
             r = t["con_radius"][c]
             dist[:, c] = centre[:, 2] - t["plane_z"] - r
+            if cs >= 0:
+                dist[:, c] = np.where(sel_ok[:, cs], dist[:, c], 1.0)  # a vertex chosen twice: the later slot is switched off (dist = 1)
             cpos[:, c] = centre - n * (r + 0.5 * dist[:, c])[:, None]
             # plane_capsule aligns the first tangent with the capsule axis projected on the plane, unless that projection is
             # shorter than 0.5 (then, and for spheres, make_frame's choice: +y for a z normal)

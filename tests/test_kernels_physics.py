@@ -79,10 +79,12 @@ def _walk(cm, N, steps, seed, scale=0.3):
 
 
 MJCF_ROBOT = str(Path(__file__).parent / "golden" / "hand_leg.xml")  # goes through minppo_amd/mjcf.py
+MJCF_MESH = str(Path(__file__).parent / "golden" / "mesh_foot.xml")   # a foot that collides as the convex hull of an inline <mesh vertex=...>
 
 
 @pytest.mark.parametrize("model,N", [("synth_stompy_pro", 33), ("synth_stompy_full", 17), ("synth_pendulum", 3), ("synth_ball", 2), (MJCF_ROBOT, 4),
-                                     ("synth_brick", 6)])  # a free box: eight corner contacts against the ground (box geoms)
+                                     ("synth_brick", 6),              # a free box: eight corner contacts against the ground (box geoms)
+                                     ("synth_wedge", 6), (MJCF_MESH, 5)])  # mesh geoms: MJX's plane_convex, four slots per geom, vertices chosen every step
 def test_forward_matches_oracle(be, model, N):
     cm = load_model(model)
     h, dims, _keep = be.model(cm)
@@ -210,6 +212,40 @@ def test_box_collider_corner_contacts(be, steps, min_rows, med):
     assert ((ref.efc_D > 0).sum(1) >= min_rows).all(), (ref.efc_D > 0).sum(1)
     got = _probe(be, h, cm, *q32)
     for k, t in dict(qM=1e-5, efc_J=1e-5, efc_D=5e-4, efc_aref=5e-4, xpos=1e-5).items():
+        r = ref[k]
+        assert np.abs(got[k].reshape(r.shape) - r).max() <= t * (np.abs(r).max() + 1e-6), k
+    rel = np.abs(got["qacc"] - ref.qacc).max(1) / (np.abs(ref.qacc).max(1) + np.abs(ref.qacc_smooth).max(1))
+    assert np.median(rel) <= med and rel.max() <= 0.3, (np.median(rel), rel.max())
+    c_got, c_ref = _cost(ref, got["qacc"]), _cost(ref, ref.qacc)
+    np.testing.assert_allclose(c_got, c_ref, rtol=5e-2, atol=1e-3)
+    be.lib.model_close(h)
+
+
+@pytest.mark.parametrize("steps,min_rows,med", [(70, 4, 3e-2), (500, 4, 2e-3)])  # (touch-down is a stiff transient: the unconverged float32 solver sits 1 - 2 % from float64 there)
+def test_mesh_collider_plane_convex_contacts(be, steps, min_rows, med):
+    """SURVEY 8(f1) mesh geoms: a free body whose colliders are convex hulls (synth_wedge: nine vertices + a hinged second hull),
+    dropped tilted.  After 70 steps it touches down on its deepest vertex (one active slot of four: the other three are duplicates
+    and switched off), after 500 it has settled (with MJX's 1 mm skin only the vertices within 1 mm of the deepest one are contacts:
+    one or two per hull on this irregular foot).  From the oracle's state
+    the kernel must pick the SAME hull vertices for its slots (rows compared slot by slot), and reach the same accelerations."""
+    cm = load_model("synth_wedge")
+    assert cm.ncvx == 2 and cm.ncon == 8 and cm.nefc == 1 + 32  # two hulls x four slots x four pyramid rows + one joint limit
+    h, dims, _keep = be.model(cm)
+    N = 6
+    ph = Physics(cm.t)
+    rng = np.random.default_rng(11)
+    q0 = np.tile(cm.t["qpos0"], (N, 1))
+    q0[:, :2] += 0.01 * rng.standard_normal((N, 2))
+    d = ph.pipeline_init(q0, 0.05 * rng.standard_normal((N, cm.nv)))
+    for _ in range(steps):
+        d = ph.pipeline_step(d, 0.1 * rng.standard_normal((N, cm.nu)))
+    ctrl = 0.1 * rng.standard_normal((N, cm.nu))
+    q32 = [x.astype(f32) for x in (d.qpos, d.qvel, ctrl, d.qacc_warmstart)]
+    ref = PhysState(qpos=q32[0].astype(np.float64), qvel=q32[1].astype(np.float64), ctrl=q32[2].astype(np.float64), qacc_warmstart=q32[3].astype(np.float64), time=np.zeros(N))
+    ph.forward(ref)
+    assert ((ref.efc_D[:, cm.nlimit:] > 0).sum(1) >= min_rows).all(), (ref.efc_D > 0).sum(1)
+    got = _probe(be, h, cm, *q32)
+    for k, t in dict(qM=1e-5, efc_J=2e-5, efc_D=5e-4, efc_aref=5e-4, xpos=1e-5).items():
         r = ref[k]
         assert np.abs(got[k].reshape(r.shape) - r).max() <= t * (np.abs(r).max() + 1e-6), k
     rel = np.abs(got["qacc"] - ref.qacc).max(1) / (np.abs(ref.qacc).max(1) + np.abs(ref.qacc_smooth).max(1))

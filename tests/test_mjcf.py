@@ -211,3 +211,55 @@ def test_collision_masks_generate_the_pairs_mujoco_would_test(tmp_path):
                      .replace('name="gb" type="sphere"', 'name="gb" contype="0" type="sphere"').replace('name="gw" type="sphere"', 'name="gw" contype="0" type="sphere"')
                      .replace('name="gc" type="capsule"', 'name="gc" contype="0" type="capsule"'))
     assert pb3 == [] and cm3.ncon == 2 + 1 + 1 + 2 + 8  # everything still meets the ground (plane contype 1 & conaffinity 1)
+
+
+MESH_XML = """<mujoco model="meshy"><compiler angle="radian" meshdir="assets"/><option timestep="0.002"/>
+  <asset>{asset}</asset>
+  <worldbody><geom type="plane" size="0 0 1"/>
+    <body name="rock" pos="0 0 0.3"><freejoint name="root"/><inertial pos="0 0 0" mass="1.0" diaginertia="0.002 0.003 0.004"/>
+      <geom type="mesh" mesh="rock" pos="0.01 0 0" friction="0.7 0.005 0.0001" {gattr}/>{extra}</body></worldbody></mujoco>"""
+CUBE_PLUS = "0 0 0  0.1 0 0  0 0.1 0  0.1 0.1 0  0 0 0.1  0.1 0 0.1  0 0.1 0.1  0.1 0.1 0.1  0.05 0.05 0.05  0.1 0 0"  # 8 corners, the centre, a duplicate
+
+
+def test_mesh_geom_collides_as_its_convex_hull(tmp_path):
+    """mesh geoms.  <asset><mesh vertex=...> (or an .obj / .stl file next to the MJCF) becomes the vertices of its convex
+    hull in the file's order - interior points and duplicates dropped - under the geom's pose, in the body frame; the geom gets four
+    contact slots against the ground (MJX plane_convex).  Written back by to_mjcf, it compiles to the same tables."""
+    cm = compile_model(mjcf.parse_mjcf(MESH_XML.format(asset=f'<mesh name="rock" vertex="{CUBE_PLUS}" scale="2 1 1"/>', gattr='contype="0"', extra="")))
+    assert (cm.ncvx, cm.ncon, cm.nefc) == (1, 4, 16)
+    v = np.asarray(cm.t["cvx_vert"])
+    want = np.array([[0, 0, 0], [0.2, 0, 0], [0, 0.1, 0], [0.2, 0.1, 0], [0, 0, 0.1], [0.2, 0, 0.1], [0, 0.1, 0.1], [0.2, 0.1, 0.1]]) + [0.01, 0, 0]
+    np.testing.assert_allclose(v, want, atol=1e-12)  # scale applied, centre + duplicate gone, file order kept, geom pos added
+    assert list(cm.t["con_cvx"]) == [0, 1, 2, 3] and list(cm.t["cvx_vadr"]) == [0, 8]
+    np.testing.assert_allclose(np.asarray(cm.t["con_friction"])[:, 0], 1.0)  # max(geom 0.7, plane 1.0), like every other ground contact
+    # files: Wavefront OBJ and binary STL with the same corner set
+    (tmp_path / "assets").mkdir()
+    pts = np.array([float(x) for x in CUBE_PLUS.split()]).reshape(-1, 3)
+    (tmp_path / "assets" / "rock.obj").write_text("# cube\n" + "".join(f"v {x} {y} {z}\n" for x, y, z in pts) + "f 1 2 3\n")
+    tri = np.zeros(4, np.dtype([("n", "<f4", 3), ("v", "<f4", (3, 3)), ("a", "<u2")]))
+    tri["v"] = pts[[0, 1, 2, 3, 4, 5, 6, 7, 0, 3, 5, 6]].reshape(4, 3, 3)
+    (tmp_path / "assets" / "rock.stl").write_bytes(b"\0" * 80 + np.uint32(4).tobytes() + tri.tobytes())
+    for fname in ("rock.obj", "rock.stl"):
+        p = tmp_path / "m.xml"
+        p.write_text(MESH_XML.format(asset=f'<mesh file="{fname}"/>', gattr='contype="0"', extra=""))
+        cmf = compile_model(mjcf.load_mjcf(str(p)))
+        assert cmf.ncvx == 1 and {tuple(np.round(r, 6)) for r in np.asarray(cmf.t["cvx_vert"])} == {tuple(np.round(r + [0.01, 0, 0], 6)) for r in pts[:8]}  # (STL keeps float32)
+    # round trip through the writer
+    spec = mjcf.parse_mjcf(MESH_XML.format(asset=f'<mesh name="rock" vertex="{CUBE_PLUS}"/>', gattr='contype="0"', extra=""))
+    cm1, cm2 = compile_model(spec), compile_model(mjcf.parse_mjcf(mjcf.to_mjcf(spec)))
+    for k in ("cvx_vert", "cvx_vadr", "con_cvx", "cvx_body", "con_friction"):
+        np.testing.assert_allclose(cm1.t[k], cm2.t[k], atol=1e-12, err_msg=k)
+
+
+@pytest.mark.parametrize("asset,gattr,extra,msg", [
+    ('<mesh name="other" vertex="0 0 0 1 0 0 0 1 0 0 0 1"/>', 'contype="0"', "", "is not defined under <asset>"),
+    ('<mesh name="rock" vertex="0 0 0 1 0 0 0 1 0"/>', 'contype="0"', "", "at least four vertices"),
+    ('<mesh name="rock" vertex="0 0 0 1 0 0 0 1 0 1 1 0 0.5 0.5 0"/>', 'contype="0"', "", "degenerate mesh"),
+    (f'<mesh name="rock" vertex="{CUBE_PLUS}"/>', "", '<body name="b2" pos="0 0 0.2"><joint name="j" axis="0 1 0"/><inertial pos="0 0 0" mass="1" diaginertia="1 1 1"/>'
+     '<body name="b3" pos="0 0 0.2"><joint name="j3" axis="0 1 0"/><inertial pos="0 0 0" mass="1" diaginertia="1 1 1"/><geom type="sphere" size="0.05"/></body></body>',
+     "can only collide with the ground plane"),
+    ('<mesh name="rock" vertex="' + " ".join(f"{np.cos(a):.6f} {np.sin(a):.6f} {0.3 * np.cos(5 * a):.6f}" for a in np.linspace(0, 6.2, 80)) + '"/>', 'contype="0"', "", "decimate the collision mesh"),
+])
+def test_mesh_geoms_outside_the_subset_are_loud_errors(asset, gattr, extra, msg):
+    with pytest.raises(ValueError, match=msg):
+        compile_model(mjcf.parse_mjcf(MESH_XML.format(asset=asset, gattr=gattr, extra=extra)))

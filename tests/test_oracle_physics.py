@@ -318,3 +318,29 @@ def test_pair_contact_rows_and_capsule_frames():
         np.testing.assert_allclose(fr[~ok, c, 1], np.broadcast_to([0.0, 1.0, 0.0], (int((~ok).sum()), 3)), atol=0)
     # solver sanity with pairs in the active set
     assert np.all(d.efc_force >= 0) and np.all(d.efc_force[~d.efc_active_row] == 0)
+
+
+def test_plane_convex_picks_the_deepest_vertices_like_mjx():
+    """MJX collision_convex.plane_convex / _manifold_points as restated in the oracle: a cube lying flat offers its four bottom
+    vertices (all within 1 mm of the deepest) and each slot gets a different one; tilted onto an edge only the two edge vertices are
+    candidates and the other two slots are duplicates (switched off: dist = 1); above the ground no slot is active."""
+    from minppo_amd.model import GEOM_MESH, BodySpec, GeomSpec, JointSpec, ModelSpec, JNT_FREE, compile_model
+    from oracle.physics_oracle import Physics
+
+    # (a perfect square ties in every argmax step and the algorithm then fills only three slots; the sole here is slightly irregular)
+    cube = [(-0.1, -0.1, -0.1), (-0.1, -0.1, 0.1), (-0.1, 0.11, -0.1), (-0.1, 0.1, 0.1), (0.12, -0.1, -0.1), (0.1, -0.1, 0.1), (0.1, 0.1, -0.1), (0.1, 0.1, 0.1)]
+    cm = compile_model(ModelSpec("cube", [BodySpec("cube", "world", mass=1.0, inertia=(0.01, 0.01, 0.01), joints=[JointSpec("root", JNT_FREE)],
+                                                   geoms=[GeomSpec(GEOM_MESH, (), vertices=cube)])], [], free_root_z=0.5))
+    ph = Physics(cm.t)
+    d = ph.make_data(3)
+    d["qpos"][0, 2] = 0.095                                   # flat, 5 mm deep
+    d["qpos"][1, 2] = 0.13
+    d["qpos"][1, 3:7] = [np.cos(np.pi / 8), np.sin(np.pi / 8), 0.0, 0.0]   # rolled 45 degrees about x: resting on an edge (half diagonal 0.1414)
+    d["qpos"][2, 2] = 0.5                                     # in the air
+    ph.kinematics(d); ph.collision(d)
+    dist, pos = d["con_dist"], d["con_pos"]
+    np.testing.assert_allclose(dist[0], -0.005, atol=1e-12)
+    assert len({tuple(np.round(p[:2], 6)) for p in pos[0]}) == 4 and (np.abs(pos[0][:, :2]) >= 0.1 - 1e-9).all()   # four different bottom corners
+    assert (dist[1] < 0).sum() == 2 and np.isclose(dist[1], 1.0).sum() == 2                                    # the edge's two vertices, two duplicates
+    assert np.allclose(np.sort(pos[1][dist[1] < 0][:, 0]), [-0.1, 0.1], atol=0.021)
+    assert (dist[2] > 0).all()
