@@ -135,6 +135,8 @@ SIGNATURES = {
     "mppo_engine_peer_connect": (c_i32, [c_vp, c_vp, c_i32]),
     "mppo_engine_comm_mode": (c_i32, [c_vp, P(c_i32)]),
     "mppo_engine_peer_status": (c_i32, [c_vp, P(c_i32), P(c_i32)]),
+    "mppo_engine_peer_selftest": (c_i32, [c_vp, P(c_i32)]),
+    "mppo_engine_peer_disable": (c_i32, [c_vp]),
     "mppo_engine_reset": (c_i32, [c_vp, c_vp]),
     "mppo_engine_update": (c_i32, [c_vp, c_vp]),
     "mppo_engine_prepare": (c_i32, [c_vp, c_vp]),

@@ -501,6 +501,43 @@ extern "C" int32_t mppo_engine_peer_connect(mppo_engine_t* e, const void* handle
   return peer_connect(e->peer, handles, shared_device);
 }
 
+// One round trip through the mapped buffers before anything depends on them: every rank publishes (rank + 1) four times, waits for
+// the peers' values and adds them in rank order - the once-per-update all-reduce of the advantage sums, on a known input.  *ok = 0:
+// a wait ran into its time limit or a sum is wrong (the mapping was made but stores from / to a peer do not arrive).
+extern "C" int32_t mppo_engine_peer_selftest(mppo_engine_t* e, int32_t* ok) {
+  MPPO_REQUIRE(e && ok && peer_connected(e->peer), "mppo_engine_peer_selftest: no connected exchange");
+  MPPO_REQUIRE(!e->graph, "mppo_engine_peer_selftest: the update has been captured already");
+  *ok = 0;
+  const int G = e->cfg.world_size;
+  double host[4], *dev = nullptr;
+  for (double& x : host) x = (double)(e->cfg.rank + 1);
+  MPPO_CHECK_HIP(hipMalloc(reinterpret_cast<void**>(&dev), sizeof(host)));
+  int32_t rc = MPPO_OK, timed_out = 0;
+  hipError_t he = hipMemcpy(dev, host, sizeof(host), hipMemcpyHostToDevice);
+  if (he == hipSuccess) {
+    rc = peer_allreduce_f64(e->peer, dev, 4, nullptr);
+    if (rc == MPPO_OK) rc = peer_advance(e->peer, 0, nullptr);
+    if (rc == MPPO_OK) rc = peer_status(e->peer, &timed_out, nullptr);  // synchronises
+    if (rc == MPPO_OK) he = hipMemcpy(host, dev, sizeof(host), hipMemcpyDeviceToHost);
+  }
+  (void)hipFree(dev);
+  if (he != hipSuccess) return fail(MPPO_EHIP, "mppo_engine_peer_selftest: %s", hipGetErrorString(he));
+  if (rc != MPPO_OK) return rc;
+  bool good = !timed_out;
+  for (double x : host) good = good && x == 0.5 * G * (G + 1);
+  *ok = good ? 1 : 0;
+  return MPPO_OK;
+}
+
+// drops the exchange (a self-test failed on some rank): the engine is back to "no transport", mppo_engine_comm_init may follow
+extern "C" int32_t mppo_engine_peer_disable(mppo_engine_t* e) {
+  MPPO_REQUIRE(e, "mppo_engine_peer_disable: null argument");
+  MPPO_REQUIRE(!e->graph, "mppo_engine_peer_disable: the update has been captured already");
+  peer_destroy(e->peer);
+  e->peer = nullptr;
+  return MPPO_OK;
+}
+
 extern "C" int32_t mppo_engine_comm_mode(const mppo_engine_t* e, int32_t* out) {
   MPPO_REQUIRE(e && out, "mppo_engine_comm_mode: null argument");
   *out = peer_connected(e->peer) ? 2 + peer_mode(e->peer) : (e->comm ? 1 : 0);

@@ -455,8 +455,20 @@ class Trainer:
                     err = exc
                 if all_ok(err is None):
                     dist.barrier()  # every rank has mapped every buffer before anybody's first update writes a flag
-                    return "peer"
-                raise RuntimeError(f"peer-to-peer exchange: mapping the ranks' buffers failed on some rank ({err}); set MPPO_ALLREDUCE=rccl")
+                    # one known all-reduce through the mapped buffers: a mapping that "succeeded" but carries no stores is found
+                    # here, in seconds, and not as a time-out inside the first update
+                    ok = C.c_int32(0)
+                    try:
+                        with device_ctx():
+                            self.lib.engine_peer_selftest(self._engine, C.byref(ok))
+                    except nat.NativeError as exc:
+                        err = exc
+                    if all_ok(err is None and ok.value == 1):
+                        return "peer"
+                    err = err or "the self-test all-reduce timed out or returned a wrong sum"
+                with device_ctx():
+                    self.lib.engine_peer_disable(self._engine)
+                dist.barrier()  # nobody unmaps while a peer still reads
             logger.warning("peer-to-peer exchange unavailable on some rank (%s); falling back to RCCL", err)
         host = np.zeros(128, np.uint8)
         if self.rank == 0:

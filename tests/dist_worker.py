@@ -46,8 +46,20 @@ def run_rank(rank, world, port, overrides, updates, out_path):
     tr = be.trainer(cfg, rank=rank, world_size=world, external_random=True, use_graph=use_graph)
     host_driven = os.environ.get("MPPO_TEST_HOST_DRIVEN") == "1"
     if not host_driven:
+        want = os.environ.get("MPPO_ALLREDUCE", "peer")
+        fail_rank = os.environ.get("MPPO_TEST_SELFTEST_FAIL_RANK")
+        if fail_rank is not None:  # this rank's self-test of the mapped buffers reports failure: every rank must end up on the communicator
+            want = "rccl"
+            if int(fail_rank) == rank:
+                real = tr.lib.engine_peer_selftest
+
+                def failing(engine, ok_ref):
+                    real(engine, ok_ref)  # (collective: the peers wait for this rank's contribution)
+                    ok_ref._obj.value = 0
+
+                tr.lib.engine_peer_selftest = failing
         got = tr.init_comm()  # $MPPO_ALLREDUCE: the engine's peer-to-peer exchange or its communicator (emulator build: shared memory either way)
-        assert got == os.environ.get("MPPO_ALLREDUCE", "peer") == tr.comm_mode(), (got, tr.comm_mode())
+        assert got == want == tr.comm_mode(), (got, want, tr.comm_mode())
         want_form = os.environ.get("MPPO_TEST_PEER_FORM")
         assert not want_form or tr.peer_form() == want_form, (tr.peer_form(), want_form)
     tr.reset()

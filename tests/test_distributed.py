@@ -32,18 +32,21 @@ import os
 import pytest
 
 
-@pytest.mark.parametrize("world,transport", [(2, "peer"), (4, "peer"), (3, "peer"), (2, "rccl"), (4, "rccl"), (2, "host")])
+@pytest.mark.parametrize("world,transport", [(2, "peer"), (4, "peer"), (3, "peer"), (2, "rccl"), (4, "rccl"), (2, "host"), (2, "peer_selftest_fails")])
 def test_ranks_equal_one_process_on_the_union(tmp_path, world, transport):
     """world ranks through `mppo_engine_learn` (engine.hip do_learn) == one process on the union, for both transports of the
     gradient: "peer" - the exchange fused into the weight-gradient and Adam launches (csrc/peer.h; the emulator's exchange buffers
     are shared-memory segments mapped by every rank process, as hipIpc maps them on the GPU), "rccl" - the communicator branch (the
     emulator's stand-in for ncclAllReduce); "host": the same stages driven from Python (`Trainer.learn_host_driven`) with gloo
-    all-reduces.  Three ranks: slices of the gradient that do not divide evenly."""
+    all-reduces.  Three ranks: slices of the gradient that do not divide evenly.  "peer_selftest_fails": rank 1's self-test of the
+    mapped buffers (Trainer.init_comm) reports failure - all ranks drop the exchange and continue on the communicator."""
     updates = 2
     port = _free_port()
     host_driven = transport == "host"
     ovr = [o if not o.startswith("training.num_envs=") else f"training.num_envs={12 if world == 3 else 8}" for o in OVR]
     env = dict(os.environ, MPPO_TEST_HOST_DRIVEN="1" if host_driven else "0", MPPO_ALLREDUCE="rccl" if host_driven else transport)
+    if transport == "peer_selftest_fails":
+        env.update(MPPO_ALLREDUCE="peer", MPPO_TEST_SELFTEST_FAIL_RANK="1")
     procs = [subprocess.Popen([sys.executable, str(HERE / "dist_worker.py"), str(r), str(world), str(port), str(updates), str(tmp_path / f"r{r}.npz"), *ovr],
                               stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, env=env) for r in range(world)]
     outs = [p.communicate(timeout=900)[0] for p in procs]
