@@ -21,7 +21,17 @@
 #include "mppo_common.h"
 #include <wave_ops.h>
 
+#include <utility>
+
 namespace mppo {
+
+// f(integral_constant<int, 0>) ... f(integral_constant<int, N - 1>): a loop whose counter is a compile-time constant in the body
+// (the unroll pragma gives up on the 26-step elimination loop of the larger robot; this cannot)
+template <class F, int... I>
+__device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, I...>) { (f(std::integral_constant<int, I>{}), ...); }
+template <int N, class F>
+__device__ __forceinline__ void static_for(F&& f) { static_for_impl(f, std::make_integer_sequence<int, N>{}); }
+
 
 struct EnvArgs {
   int N, mode, n_frames;  // mode 0: reset (pipeline_init), 1: step, 2: probe (one forward on given inputs)
@@ -48,6 +58,12 @@ struct EnvArgs {
 #define SYNC() __builtin_amdgcn_wave_barrier()
 #endif
 #define FOR_G(i, n) for (int i = g; i < (n); i += kGroupLanes)
+// the instruction scheduler moves nothing across this point
+#ifdef MPPO_EMU
+#define SCHED_FENCE() do { } while (0)
+#else
+#define SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
+#endif
 // Phase timers (profiling builds only, -DMPPO_PHYS_TIMERS: tools/env_phases.py): wave 0 of workgroup 0 stamps s_memtime at the phase
 // boundaries of its first frame into a device array that mppo_debug_phys_timers() copies out.
 #ifdef MPPO_PHYS_TIMERS
@@ -258,7 +274,7 @@ struct StaticModel {
 };
 // MODE (EnvArgs::mode) is a template parameter too: the step kernel carries neither the probe's 17 output pointers nor its stores.
 template <class SD, int MODE>
-__global__ void __launch_bounds__(kEnvBlock) env_kernel(ModelView mv, EnvArgs a, PhysLds Prt) {
+__global__ void __launch_bounds__(64 * kMaxWavesPerBlock) env_kernel(ModelView mv, EnvArgs a, PhysLds Prt) {
   constexpr BlobDims kSD = SD::dims();
   constexpr BlobOffsets kSO = blob_offsets(kSD);
   constexpr PhysLds kSP = make_phys_lds(kSD.nq, kSD.nv, kSD.nu, kSD.nbody, kSD.njnt, kSD.ncon, kSD.nlimit + 4 * kSD.ncon, kSD.nroot, kSD.ncvx);
@@ -270,7 +286,7 @@ __global__ void __launch_bounds__(kEnvBlock) env_kernel(ModelView mv, EnvArgs a,
   const int g = tid & (kGroupLanes - 1);
   const int row = (tid & 63) / kGroupLanes;                 // DPP row inside the wave
   const int el = (tid >> 6) * kEnvsPerWave + row;          // environment inside the workgroup
-  int env = blockIdx.x * kEnvsPerBlock + el;
+  int env = blockIdx.x * ((int)(blockDim.x >> 6) * kEnvsPerWave) + el;  // the launch chooses the waves per workgroup (launch_env)
   const bool valid = env < a.N;
   if (!valid) env = a.N - 1;  // surplus groups shadow the last environment and never store
   // model tables: one coalesced copy of the blob into LDS per workgroup, then every table read is a ds_read
@@ -279,7 +295,7 @@ __global__ void __launch_bounds__(kEnvBlock) env_kernel(ModelView mv, EnvArgs a,
   {
     const float4* src = reinterpret_cast<const float4*>(mv.blob);
     float4* dst = reinterpret_cast<float4*>(smem_raw);
-    for (int i = tid; i < mv.blob_words / 4; i += kEnvBlock) dst[i] = src[i];
+    for (int i = tid; i < mv.blob_words / 4; i += (int)blockDim.x) dst[i] = src[i];
   }
   __syncthreads();  // the only workgroup-wide barrier: model tables are shared by the waves of the block
   if (row >= kEnvsPerWave) return;  // rows without an environment
@@ -292,8 +308,9 @@ __global__ void __launch_bounds__(kEnvBlock) env_kernel(ModelView mv, EnvArgs a,
   const float h = mv.timestep;
   const int O = mv.obs_dim, OP = mv.obs_pad;
   float* qpos = S + P.qpos; float* qvel = (float*)__builtin_assume_aligned(S + P.qvel, 16); float* ctrl = S + P.ctrl; float* warm = S + P.warm;
-  float* xpos = S + P.xpos; float* xquat = S + P.xquat; float* xipos = S + P.xipos; float* rootcom = S + P.rootcom;
+  float* xpos = S + P.xpos; float* xquat = S + P.xquat; float* xipos = S + P.xipos; float* rootcom = S + P.rootcom;  // (poses: region A1)
   float* cinert = S + P.cinert; float* cdof = S + P.cdof; float* cvel = S + P.cvel;
+  float* dsgn = S + P.dsgn; int* drow = reinterpret_cast<int*>(S + P.drow);
   float* M = (float*)__builtin_assume_aligned(S + P.M, 16); float* LL = (float*)__builtin_assume_aligned(S + P.LL, 16);
   float* qfs = (float*)__builtin_assume_aligned(S + P.qfs, 16); float* qas = (float*)__builtin_assume_aligned(S + P.qas, 16); float* qact = (float*)__builtin_assume_aligned(S + P.qact, 16); float* qacc = (float*)__builtin_assume_aligned(S + P.qacc, 16); float* Ma = (float*)__builtin_assume_aligned(S + P.Ma, 16);
   float* grad = (float*)__builtin_assume_aligned(S + P.grad, 16); float* Mgrad = (float*)__builtin_assume_aligned(S + P.Mgrad, 16); float* search = (float*)__builtin_assume_aligned(S + P.search, 16); float* mvv = (float*)__builtin_assume_aligned(S + P.mv, 16); float* qfc = (float*)__builtin_assume_aligned(S + P.qfc, 16);
@@ -303,7 +320,7 @@ __global__ void __launch_bounds__(kEnvBlock) env_kernel(ModelView mv, EnvArgs a,
   const int npair = kDims ? kSD.npair : mv.npair, nplane = ncon - npair, ncvx = kDims ? kSD.ncvx : mv.ncvx;
   float* cvxsel = S + P.cvxsel; float* cvxok = S + P.cvxok;
   float* ximat = S + P.ximat; float* xmat = S + P.xmat; float* xanchor = S + P.xanchor; float* xaxis = S + P.xaxis;
-  float* C1 = S + P.C1; float* C2 = S + P.C2; float* cdofdot = S + P.cdofdot; float* cfrc = S + P.cfrc; float* J = (float*)__builtin_assume_aligned(S + P.J, 16);
+  float* Cw = S + P.C; float* cdofdot = S + P.cdofdot; float* cfrc = S + P.cfrc; float* J = (float*)__builtin_assume_aligned(S + P.J, 16);
 
   const float* rec = a.state ? a.state + (size_t)env * mv.rec_dim : nullptr;
 
@@ -332,14 +349,27 @@ __global__ void __launch_bounds__(kEnvBlock) env_kernel(ModelView mv, EnvArgs a,
     pre_comx = rec[OP + nv];
     time_in = rec[OP + nv + 1];
   }
-  if (g == 0) { st3(xpos, {0.f, 0.f, 0.f}); st4(xquat, {1.f, 0.f, 0.f, 0.f}); }
-  SYNC();
+  // observation = the PRE-step record (env.py:163, quirk C-5): copied out before anything of the new record is written (cinert and
+  // cvel of the new state go to the record in the middle of the step); the reset observation replaces it at the end when done
+  if (MODE == 1) {
+    constexpr int kChunk = 32;  // (one memory round trip for observations of up to 512 words)
+    for (int i0 = g; i0 < OP; i0 += kGroupLanes * kChunk) {
+      float old[kChunk];
+      _Pragma("unroll") for (int u = 0; u < kChunk; ++u) { const int i = i0 + kGroupLanes * u; old[u] = rec[i < OP ? i : OP - 1]; }
+      _Pragma("unroll") for (int u = 0; u < kChunk; ++u) { const int i = i0 + kGroupLanes * u; if (valid && i < OP) a.obs[(size_t)env * a.obs_ld + i] = old[u]; }
+    }
+  }
+  float* recw = a.state ? a.state + (size_t)env * mv.rec_dim : nullptr;
+  const int o_ci = nq + nv, o_cv = o_ci + (mv.include_c ? 10 * (nb - 1) : 0), o_qa = o_cv + (mv.include_c ? 6 * (nb - 1) : 0);  // the record's fields
+  int badi = 0;  // NaN anywhere in the stepped state (env.py:173-176), accumulated where the values are at hand
 
   float new_comx = 0.f;
   int niter_out = 0;
   const int frames = MODE == 1 ? a.n_frames : 1;
   for (int frame = 0; frame < frames; ++frame) {
     PT(1);
+    if (g == 0) { st3(xpos, {0.f, 0.f, 0.f}); st4(xquat, {1.f, 0.f, 0.f, 0.f}); }  // the world body (region A1 is rewritten by every frame)
+    SYNC();  // the state loaded above (or integrated by the previous frame) is visible to every lane
     // ================= fwd_position: kinematics ================================================================
     // The tree is deep and narrow (a level holds one or two bodies of a humanoid), so the level-synchronous sweep runs on one
     // or two lanes.  Only what truly depends on the parent is done there: pose = parent pose o local pose.  Everything else -
@@ -405,6 +435,7 @@ __global__ void __launch_bounds__(kEnvBlock) env_kernel(ModelView mv, EnvArgs a,
       }
     }
     SYNC();
+    if (MODE == 2 && valid && a.probe.xpos) FOR_G(i, nb * 3) a.probe.xpos[(size_t)env * nb * 3 + i] = xpos[i];  // (the poses are gone by the end of the step)
     PT(2);
     // ---- com_pos: centre of mass of every kinematic tree; contact candidates --------------------
     for (int r = 0; r < nroot; ++r) {
@@ -576,102 +607,128 @@ __global__ void __launch_bounds__(kEnvBlock) env_kernel(ModelView mv, EnvArgs a,
     }
     SYNC();
     PT(5);
-    constexpr bool kRegChol = kDims && kSD.nv <= kGroupLanes;  // two rows per lane (nv > 16) no longer fit the register file
+    constexpr bool kRegChol = kDims && kSD.nv <= 2 * kGroupLanes;
+    // ---- factor_m: Cholesky of M and of M + h*diag(damping) (implicit joint damping, Euler), then the inverse factors ---------
     if (kRegChol) {
-      // ---- fixed-size kernel: both factorisations with a lane's matrix row(s) in registers ---------------------------------
-      // Same arithmetic, element by element, as the run-time-sized branch below (right-looking Cholesky that keeps L_kk^2 on
-      // the diagonal; inverse factors by forward substitution, one column per lane), but the only LDS traffic is one column
-      // exchange per elimination step and the finished rows: 48 k -> 11 k cycles for nv = 16.
+      // fixed-size kernel, up to 32 dofs: a lane's matrix rows (g and g + 16) in registers.  Same arithmetic, element by element, as
+      // the run-time-sized branch below (right-looking Cholesky that keeps L_kk^2 on the diagonal; inverse factors by forward
+      // substitution, a lane's columns g and g + 16), but the only LDS traffic is one column exchange per elimination step and the
+      // finished rows: 48 k -> 11 k cycles for nv = 16, 166 k -> see DESIGN.md for nv = 26.
       constexpr int NVc = kRegChol ? kSD.nv : 1;
+      constexpr int R = (NVc + kGroupLanes - 1) / kGroupLanes;  // rows (and, in the inverse, columns) per lane
       const int ldc = P.ldc;
-      const int ic = g < NVc ? g : NVc - 1;  // surplus lanes shadow the last row / column and never publish
+      int ir[R];       // this lane's rows; a surplus slot shadows the last row and never publishes
+      bool own[R];
+      _Pragma("unroll") for (int q = 0; q < R; ++q) { const int i = g + kGroupLanes * q; own[q] = i < NVc; ir[q] = own[q] ? i : NVc - 1; }
       float* col = t0;  // the column being eliminated, all rows (t0 is free here)
-      // the two matrices one after the other (not unrolled): both at once need more registers than a lane has, and what is
-      // spilled then is paid for in every later phase
+      // one matrix after the other through one work copy (not unrolled: both at once need more registers than a lane has, and
+      // what is spilled then is paid for in every later phase)
       _Pragma("unroll 1") for (int m = 0; m < 2; ++m) {
-        float* C = m ? C2 : C1;
-        float c[NVc];
-        {
-          const float hd = m ? h * TF(dof_damping)[ic] : 0.f;
+        float c[R][NVc];
+        _Pragma("unroll") for (int q = 0; q < R; ++q) {
+          const int i = ir[q];
+          const float hd = m ? h * TF(dof_damping)[i] : 0.f;
           _Pragma("unroll") for (int k = 0; k < NVc; ++k) {
-            const float v = M[ic * ldm + k];
-            c[k] = (m && k == ic) ? v + hd : v;  // M + h diag(damping): implicit joint damping (Euler)
+            const float v = M[i * ldm + k];
+            c[q][k] = (m && k == i) ? v + hd : v;
           }
         }
-        _Pragma("unroll") for (int k = 0; k < NVc; ++k) {
-          if (g < NVc) col[g] = c[k];
+        static_for<NVc>([&](auto kc) {
+          constexpr int k = decltype(kc)::value;
+          _Pragma("unroll") for (int q = 0; q < R; ++q) if (own[q]) col[ir[q]] = c[q][k];
           SYNC();
           const float r = rsqrtf(fmaxf(col[k], MJ_MINVAL));
           float l[NVc];  // the scaled column below the diagonal (rows k + 1 ..)
           _Pragma("unroll") for (int j = k + 1; j < NVc; ++j) l[j] = col[j] * r;
           SYNC();  // the column buffer is rewritten in the next step
-          const bool below = g > k;
-          const float a = c[k] * r;
-          // entries right of the diagonal (j > i) are updated too: they are never read, and skipping them would cost a compare each
-          _Pragma("unroll") for (int j = k + 1; j < NVc; ++j) c[j] = below ? c[j] - a * l[j] : c[j];
-          c[k] = below ? a : c[k];
-        }
+          _Pragma("unroll") for (int q = 0; q < R; ++q) {
+            if (kGroupLanes * (q + 1) - 1 > k) {  // (otherwise every row of this slot lies on or above the diagonal by now)
+              const bool below = ir[q] > k;
+              const float a = c[q][k] * r;
+              // entries right of the diagonal (j > i) are updated too: they are never read, and skipping them would cost a compare each
+              _Pragma("unroll") for (int j = k + 1; j < NVc; ++j) c[q][j] = below ? c[q][j] - a * l[j] : c[q][j];
+              c[q][k] = below ? a : c[q][k];
+            }
+          }
+          SCHED_FENCE();
+        });
         // publish the rows (lower triangle + squared diagonal)
-        if (g < NVc) {
-          _Pragma("unroll") for (int k = 0; k < NVc; ++k) C[g * ldc + k] = c[k];
+        _Pragma("unroll") for (int q = 0; q < R; ++q) {
+          if (own[q]) { _Pragma("unroll") for (int k = 0; k < NVc; ++k) Cw[ir[q] * ldc + k] = c[q][k]; }
         }
-      }
-      SYNC();
-      PT(6);
-      // inverse factors by forward substitution, one column per lane: x[k] = 0 above the column's diagonal
-      _Pragma("unroll 1") for (int m = 0; m < 2; ++m) {
-        const float* C = m ? C2 : C1;
-        float x[NVc];
+        SYNC();
+        if (m == 0) PT(6);
+        // inverse factor by forward substitution, a lane's columns: x[k] = 0 above the column's diagonal
+        float x[R][NVc];
         _Pragma("unroll") for (int i = 0; i < NVc; ++i) {
-          const float d = rsqrtf(fmaxf(C[i * ldc + i], MJ_MINVAL));
-          float s = 0.f;
-          _Pragma("unroll") for (int k = 0; k < i; ++k) s += C[i * ldc + k] * x[k];
-          x[i] = i == g ? d : i > g ? -s * d : 0.f;
+          const float d = rsqrtf(fmaxf(Cw[i * ldc + i], MJ_MINVAL));
+          float s[R];
+          _Pragma("unroll") for (int q = 0; q < R; ++q) s[q] = 0.f;
+          _Pragma("unroll") for (int k = 0; k < i; ++k) {
+            const float cik = Cw[i * ldc + k];
+            _Pragma("unroll") for (int q = 0; q < R; ++q) if (kGroupLanes * q <= k) s[q] += cik * x[q][k];  // (x[q][k] = 0 for k < 16 q: skipped)
+          }
+          _Pragma("unroll") for (int q = 0; q < R; ++q) x[q][i] = i == ir[q] ? d : i > ir[q] ? -s[q] * d : 0.f;
+          if (R > 1) SCHED_FENCE();  // (two columns per lane: keep the rows' loads from piling up in registers ahead of their use)
         }
-        if (g < NVc) {
-          _Pragma("unroll") for (int i = 0; i < NVc; ++i) {
-            if (i >= g) LL[m ? g * ldm + i + 1 : i * ldm + g] = x[i];  // Li[i][g] / Le[i][g] (transposed slot)
+        _Pragma("unroll") for (int q = 0; q < R; ++q) {
+          if (own[q]) {
+            const int cq = ir[q];
+            _Pragma("unroll") for (int i = kGroupLanes * q; i < NVc; ++i) {
+              if (i >= cq) LL[m ? cq * ldm + i + 1 : i * ldm + cq] = x[q][i];  // Li[i][cq] / Le[i][cq] (transposed slot)
+            }
           }
         }
+        SYNC();  // the work copy is rewritten by the second matrix
       }
     } else {
-      // work copies for the two factorisations (region A2; the kinematics temporaries are dead)
+      // run-time-sized kernel / more than 16 dofs: both matrices in the same column sweep (a column costs two synchronisation
+      // points, whichever the number of matrices), work copies stored as lower triangles (row i at i (i + 1) / 2) - the two
+      // squares would be the largest thing in region A.  The diagonal keeps L_kk^2 (never overwritten).
+      const int ntri = (nv * (nv + 1) / 2 + 3) & ~3;
+      float* C1 = Cw; float* C2 = Cw + ntri;
       FOR_G(i, nv) {
-        for (int k = 0; k < nv; ++k) {
+        const int ti = i * (i + 1) / 2;
+        const float hd = h * TF(dof_damping)[i];
+        for (int k = 0; k <= i; ++k) {
           const float v = M[i * ldm + k];
-          C1[i * ldm + k] = v;
-          C2[i * ldm + k] = (k == i) ? v + h * TF(dof_damping)[i] : v;  // implicit joint damping (Euler)
+          C1[ti + k] = v;
+          C2[ti + k] = (k == i) ? v + hd : v;
         }
       }
-      // ---- factor_m: Cholesky of M and of M + h*diag(damping), both in the same column sweep ---------
-      // The diagonal keeps L_kk^2 (never overwritten), so a column needs only two barriers.
       for (int k = 0; k < nv; ++k) {
         SYNC();  // trailing update of column k-1 (or the copy) is complete
-        const float r1 = rsqrtf(fmaxf(C1[k * ldm + k], MJ_MINVAL)), r2 = rsqrtf(fmaxf(C2[k * ldm + k], MJ_MINVAL));
-        FOR_G(i, nv) if (i > k) { C1[i * ldm + k] *= r1; C2[i * ldm + k] *= r2; }
+        const int tk = k * (k + 1) / 2;
+        const float r1 = rsqrtf(fmaxf(C1[tk + k], MJ_MINVAL)), r2 = rsqrtf(fmaxf(C2[tk + k], MJ_MINVAL));
+        FOR_G(i, nv) if (i > k) { const int ti = i * (i + 1) / 2; C1[ti + k] *= r1; C2[ti + k] *= r2; }
         SYNC();
         FOR_G(i, nv) {
           if (i > k) {
-            const float l1 = C1[i * ldm + k], l2 = C2[i * ldm + k];
+            const int ti = i * (i + 1) / 2;
+            const float l1 = C1[ti + k], l2 = C2[ti + k];
+            int tj = tk + k + 1;  // row k + 1
   #pragma unroll 4
             for (int j = k + 1; j <= i; ++j) {
-              C1[i * ldm + j] -= l1 * C1[j * ldm + k];
-              C2[i * ldm + j] -= l2 * C2[j * ldm + k];
+              C1[ti + j] -= l1 * C1[tj + k];
+              C2[ti + j] -= l2 * C2[tj + k];
+              tj += j + 1;
             }
           }
         }
       }
       SYNC();
-      // ---- triangular inverses, one column per lane (no cross-lane dependency inside a column) -------
+      // triangular inverses, one column per lane (no cross-lane dependency inside a column)
       FOR_G(j, nv) {
-        LL[j * ldm + j] = rsqrtf(fmaxf(C1[j * ldm + j], MJ_MINVAL));      // Li[j][j]
-        LL[j * ldm + j + 1] = rsqrtf(fmaxf(C2[j * ldm + j], MJ_MINVAL));  // Le[j][j] (transposed slot)
+        const int tjj = j * (j + 1) / 2 + j;
+        LL[j * ldm + j] = rsqrtf(fmaxf(C1[tjj], MJ_MINVAL));      // Li[j][j]
+        LL[j * ldm + j + 1] = rsqrtf(fmaxf(C2[tjj], MJ_MINVAL));  // Le[j][j] (transposed slot)
         for (int i = j + 1; i < nv; ++i) {
+          const int ti = i * (i + 1) / 2;
           float s1 = 0.f, s2 = 0.f;
   #pragma unroll 4
-          for (int k = j; k < i; ++k) { s1 += C1[i * ldm + k] * LL[k * ldm + j]; s2 += C2[i * ldm + k] * LL[j * ldm + k + 1]; }
-          LL[i * ldm + j] = -s1 * rsqrtf(fmaxf(C1[i * ldm + i], MJ_MINVAL));      // Li[i][j]
-          LL[j * ldm + i + 1] = -s2 * rsqrtf(fmaxf(C2[i * ldm + i], MJ_MINVAL));  // Le[i][j]
+          for (int k = j; k < i; ++k) { s1 += C1[ti + k] * LL[k * ldm + j]; s2 += C2[ti + k] * LL[j * ldm + k + 1]; }
+          LL[i * ldm + j] = -s1 * rsqrtf(fmaxf(C1[ti + i], MJ_MINVAL));      // Li[i][j]
+          LL[j * ldm + i + 1] = -s2 * rsqrtf(fmaxf(C2[ti + i], MJ_MINVAL));  // Le[i][j]
         }
       }
     }
@@ -765,12 +822,37 @@ __global__ void __launch_bounds__(kEnvBlock) env_kernel(ModelView mv, EnvArgs a,
         if (valid && a.probe.qfrc_passive) a.probe.qfrc_passive[(size_t)env * nv + d] = passive;
       }
     }
-    SYNC();  // cfrc / cdofdot (region A3) are dead from here: the Jacobian (A4) may overwrite them
+    // cinert and cvel have done their work in the dynamics (RNE above was the last reader); what remains is their place in the
+    // new state record / observation (env.py:246-259) and the NaN guard: both are served here, and their LDS goes to the Jacobian
+    FOR_G(i, 10 * nb) badi |= (int)isnan(cinert[i]);
+    FOR_G(i, 6 * nb) badi |= (int)isnan(cvel[i]);
+    if (MODE != 2 && frame == frames - 1 && mv.include_c && valid) {
+      FOR_G(i, 10 * (nb - 1)) {
+        const float v = cinert[10 + i];
+        recw[o_ci + i] = v;
+        if (MODE == 0) { if (env == 0 && a.reset_out) a.reset_out[o_ci + i] = v; if (a.obs) a.obs[(size_t)env * a.obs_ld + o_ci + i] = v; }
+      }
+      FOR_G(i, 6 * (nb - 1)) {
+        const float v = cvel[6 + i];
+        recw[o_cv + i] = v;
+        if (MODE == 0) { if (env == 0 && a.reset_out) a.reset_out[o_cv + i] = v; if (a.obs) a.obs[(size_t)env * a.obs_ld + o_cv + i] = v; }
+      }
+    }
+    if (MODE == 2 && valid) {
+      if (a.probe.cinert) FOR_G(i, nb * 10) a.probe.cinert[(size_t)env * nb * 10 + i] = cinert[i];
+      if (a.probe.cvel) FOR_G(i, nb * 6) a.probe.cvel[(size_t)env * nb * 6 + i] = cvel[i];
+    }
+    SYNC();  // cfrc / cdofdot / cvel (region A3) and cinert are dead from here: the Jacobian (A4) may overwrite them
     PT(9);
     solve_linv<false, NV>(LL, ldm, nv, qfs, t0, qas, g);  // fwd_acceleration: qacc_smooth = M^-1 qfrc_smooth
     PT(10);
     // ================= make_constraint ===================================================================
-    FOR_G(r, nefc) for (int k = 0; k < nv; ++k) J[r * ldj + k] = 0.f;
+    // Rows: nlim joint limits, then four pyramid rows per contact slot.  A limit row has ONE non-zero entry (+-1 at the joint's
+    // dof): it is kept as that sign (dsgn, per dof; 0 = no active limit) and its row index (drow), and only the contact rows are
+    // a dense [4 ncon][nv] matrix in LDS.  Products with the limit rows are written out where they occur; they equal what the
+    // dense row gave bit for bit (the other terms of that row's sum were exact zeros).
+    FOR_G(r, 4 * ncon) for (int k = 0; k < nv; ++k) J[r * ldj + k] = 0.f;
+    FOR_G(i, nv) { dsgn[i] = 0.f; drow[i] = 0; }
     SYNC();
     FOR_G(r, nlim) {  // joint limits: one row each
       const int jid = TI(lim_jntid)[r];
@@ -778,9 +860,9 @@ __global__ void __launch_bounds__(kEnvBlock) env_kernel(ModelView mv, EnvArgs a,
       const float dlo = qpos[qa] - TF(jnt_range)[2 * jid], dhi = TF(jnt_range)[2 * jid + 1] - qpos[qa];
       const float pos = fminf(dlo, dhi);
       const bool act = pos < 0.f;
-      if (act) J[r * ldj + da] = dlo < dhi ? 1.f : -1.f;
+      if (act) { dsgn[da] = dlo < dhi ? 1.f : -1.f; drow[da] = r; }
       jv[r] = act ? pos : 0.f;               // pos, parked in jv until the row parameters are built
-      force[r] = act ? TF(dof_invweight0)[da] : 0.f;  // invweight, parked in force
+      jaref[r] = act ? TF(dof_invweight0)[da] : 0.f;  // invweight, parked in jaref
     }
     for (int item = g; item < ncon * nv; item += kGroupLanes) {  // contacts: 4 pyramid rows, (contact, dof) per item
       const int c = item / nv, d = item - c * nv;
@@ -804,7 +886,7 @@ __global__ void __launch_bounds__(kEnvBlock) env_kernel(ModelView mv, EnvArgs a,
           const V3 n = ld3(confr + 6 * c), t1 = ld3(confr + 6 * c + 3), t2 = cross3(n, t1);
           const float jn = dot3(n, jp), jt1 = dot3(t1, jp), jt2 = dot3(t2, jp);
           const float mu = TF(con_friction)[3 * c];
-          const int r0 = nlim + 4 * c;
+          const int r0 = 4 * c;
           J[(r0 + 0) * ldj + d] = jn + mu * jt1;
           J[(r0 + 1) * ldj + d] = jn - mu * jt1;
           J[(r0 + 2) * ldj + d] = jn + mu * jt2;
@@ -820,21 +902,39 @@ __global__ void __launch_bounds__(kEnvBlock) env_kernel(ModelView mv, EnvArgs a,
       const float iw = (tw + mu * mu * tw) * 2.f * mu * mu / mv.impratio;
       for (int k = 0; k < 4; ++k) {
         jv[nlim + 4 * c + k] = act ? condist[c] : 0.f;
-        force[nlim + 4 * c + k] = act ? iw : 0.f;
+        jaref[nlim + 4 * c + k] = act ? iw : 0.f;
       }
     }
     SYNC();
     float k_lim, b_lim, k_con, b_con;
     kb_params(TF(limit_solref), TF(limit_solimp), h, k_lim, b_lim);
     kb_params(TF(contact_solref), TF(contact_solimp), h, k_con, b_con);
+    // row r of the constraint Jacobian times an nv-vector / column i times an nefc-vector
+    auto jrow_dot = [&](int r, const float* x) {
+      if (r < nlim) { const int da = TI(jnt_dofadr)[TI(lim_jntid)[r]]; return dsgn[da] * x[da]; }
+      const float* jr = J + (r - nlim) * ldj;
+      float s = 0.f;
+      _Pragma("unroll 8") for (int k = 0; k < nv; ++k) s += jr[k] * x[k];
+      return s;
+    };
+    auto jcol_dot = [&](int i, const float* f) {
+      float s = nlim > 0 ? dsgn[i] * f[drow[i]] : 0.f;
+      const int nc4 = 4 * ncon;
+      _Pragma("unroll 8") for (int r = 0; r < nc4; ++r) s += J[r * ldj + i] * f[nlim + r];
+      return s;
+    };
+    auto mrow_dot = [&](int i, const float* x) {
+      float s = 0.f;
+      _Pragma("unroll 8") for (int k = 0; k < nv; ++k) s += M[i * ldm + k] * x[k];
+      return s;
+    };
     FOR_G(r, nefc) {
-      const float pos = jv[r], iw = force[r];
+      const float pos = jv[r], iw = jaref[r];
       const bool act = iw > 0.f;  // inactive rows are inert: J = 0, aref = 0, D = 0
       const bool lim = r < nlim;
       const float k = lim ? k_lim : k_con, b = lim ? b_lim : b_con;
       const float imp = impedance(lim ? TF(limit_solimp) : TF(contact_solimp), pos);
-      float s = 0.f;
-      _Pragma("unroll 8") for (int d = 0; d < nv; ++d) s += J[r * ldj + d] * qvel[d];
+      const float s = jrow_dot(r, qvel);
       const float R = fmaxf(iw * (1.f - imp) / imp, MJ_MINVAL);
       eD[r] = act ? 1.f / R : 0.f;
       earef[r] = act ? -b * s - k * imp * pos : 0.f;
@@ -854,8 +954,8 @@ __global__ void __launch_bounds__(kEnvBlock) env_kernel(ModelView mv, EnvArgs a,
         if (take) FOR_G(i, nv) qacc[i] = src[i];
         SYNC();
         if (take) {
-          FOR_G(i, nv) { float s = 0.f; _Pragma("unroll 8") for (int k = 0; k < nv; ++k) s += M[i * ldm + k] * qacc[k]; Ma[i] = s; }
-          FOR_G(r, nefc) { float s = 0.f; _Pragma("unroll 8") for (int k = 0; k < nv; ++k) s += J[r * ldj + k] * qacc[k]; jaref[r] = s - earef[r]; }
+          FOR_G(i, nv) Ma[i] = mrow_dot(i, qacc);
+          FOR_G(r, nefc) jaref[r] = jrow_dot(r, qacc) - earef[r];
         }
         SYNC();
         float gs = 0.f, cs = 0.f;
@@ -893,7 +993,7 @@ __global__ void __launch_bounds__(kEnvBlock) env_kernel(ModelView mv, EnvArgs a,
       // update_constraint + update_gradient at the starting point
       FOR_G(r, nefc) { const float x = jaref[r]; force[r] = x < 0.f ? -eD[r] * x : 0.f; }
       SYNC();
-      FOR_G(i, nv) { float s = 0.f; _Pragma("unroll 8") for (int r = 0; r < nefc; ++r) s += J[r * ldj + i] * force[r]; qfc[i] = s; grad[i] = Ma[i] - qfs[i] - s; }
+      FOR_G(i, nv) { const float s = jcol_dot(i, force); qfc[i] = s; grad[i] = Ma[i] - qfs[i] - s; }
       SYNC();
       solve_linv<false, NV>(LL, ldm, nv, grad, t0, Mgrad, g);
       FOR_G(i, nv) search[i] = -Mgrad[i];
@@ -909,8 +1009,8 @@ __global__ void __launch_bounds__(kEnvBlock) env_kernel(ModelView mv, EnvArgs a,
         PT(13 + (it < 6 ? it : 6));
         // ---------------- line search ----------------
         float sn = 0.f, sMa = 0.f, sq = 0.f;
-        FOR_G(i, nv) { float s = 0.f; _Pragma("unroll 8") for (int k = 0; k < nv; ++k) s += M[i * ldm + k] * search[k]; mvv[i] = s; }
-        FOR_G(r, nefc) { float s = 0.f; _Pragma("unroll 8") for (int k = 0; k < nv; ++k) s += J[r * ldj + k] * search[k]; jv[r] = s; }
+        FOR_G(i, nv) mvv[i] = mrow_dot(i, search);
+        FOR_G(r, nefc) jv[r] = jrow_dot(r, search);
         FOR_G(i, nv) { sn += search[i] * search[i]; sMa += search[i] * Ma[i]; sq += search[i] * qfs[i]; }
         SYNC();
         if (it == 0) PT(24);
@@ -1021,8 +1121,7 @@ __global__ void __launch_bounds__(kEnvBlock) env_kernel(ModelView mv, EnvArgs a,
         pgm = group16_sum(pgm);
         if (run) { prev_cost = cost; cost = cs; gauss = gs; }
         FOR_G(i, nv) {
-          float s = 0.f;
-          _Pragma("unroll 8") for (int r = 0; r < nefc; ++r) s += J[r * ldj + i] * force[r];
+          const float s = jcol_dot(i, force);
           if (run) { qfc[i] = s; grad[i] = Ma[i] - qfs[i] - s; }
         }
         SYNC();
@@ -1049,12 +1148,10 @@ __global__ void __launch_bounds__(kEnvBlock) env_kernel(ModelView mv, EnvArgs a,
       if (pr.qfrc_actuator) FOR_G(i, nv) pr.qfrc_actuator[(size_t)env * nv + i] = qact[i];
       if (pr.qacc_smooth) FOR_G(i, nv) pr.qacc_smooth[(size_t)env * nv + i] = qas[i];
       if (pr.qacc) FOR_G(i, nv) pr.qacc[(size_t)env * nv + i] = qacc[i];
-      if (pr.efc_J) FOR_G(r, nefc) for (int k = 0; k < nv; ++k) pr.efc_J[((size_t)env * nefc + r) * nv + k] = J[r * ldj + k];
+      if (pr.efc_J) FOR_G(r, nefc) for (int k = 0; k < nv; ++k)
+        pr.efc_J[((size_t)env * nefc + r) * nv + k] = r >= nlim ? J[(r - nlim) * ldj + k] : (k == TI(jnt_dofadr)[TI(lim_jntid)[r]] ? dsgn[k] : 0.f);
       if (pr.efc_D) FOR_G(r, nefc) pr.efc_D[(size_t)env * nefc + r] = eD[r];
       if (pr.efc_aref) FOR_G(r, nefc) pr.efc_aref[(size_t)env * nefc + r] = earef[r];
-      if (pr.cinert) FOR_G(i, nb * 10) pr.cinert[(size_t)env * nb * 10 + i] = cinert[i];
-      if (pr.cvel) FOR_G(i, nb * 6) pr.cvel[(size_t)env * nb * 6 + i] = cvel[i];
-      if (pr.xpos) FOR_G(i, nb * 3) pr.xpos[(size_t)env * nb * 3 + i] = xpos[i];
       if (pr.subtree_com1 && g == 0) pr.subtree_com1[env] = new_comx;
       if (pr.solver_niter && g == 0) pr.solver_niter[env] = niter;
     }
@@ -1091,16 +1188,14 @@ __global__ void __launch_bounds__(kEnvBlock) env_kernel(ModelView mv, EnvArgs a,
   // ================= epilogue: observation, reward, done, auto-reset, metrics, new record ====================
   // The new record's derived fields (cinert, cvel, qfrc_actuator, subtree_com) are those of the LAST forward
   // pass, i.e. they belong to the pre-integration pose: exactly what the MJX data carries.
-  float* recw = a.state + (size_t)env * mv.rec_dim;
   if (MODE == 0) {
     // reset: record = [qpos0, 0, cinert[1:], cvel[1:], qfrc_actuator | pad | qacc_warmstart = qacc | com_x | time = 0]
-    const int o_ci = nq + nv, o_cv = o_ci + (mv.include_c ? 10 * (nb - 1) : 0), o_qa = o_cv + (mv.include_c ? 6 * (nb - 1) : 0);
+    // (cinert / cvel were written when RNE had read them)
     FOR_G(i, mv.rec_dim) {
+      if (i >= o_ci && i < o_qa) continue;
       float v = 0.f;
       if (i < nq) v = qpos[i];
       else if (i < o_ci) v = 0.f;
-      else if (i < o_cv) v = cinert[10 + (i - o_ci)];
-      else if (i < o_qa) v = cvel[6 + (i - o_cv)];
       else if (i < O) v = qact[i - o_qa];
       else if (i < OP) v = 0.f;
       else if (i < OP + nv) v = qacc[i - OP];
@@ -1132,49 +1227,36 @@ __global__ void __launch_bounds__(kEnvBlock) env_kernel(ModelView mv, EnvArgs a,
   const float dt_env = h * (float)a.n_frames;
   const float vel = (new_comx - pre_comx) / dt_env;
   const float reward = rc.w_ctrl_cost * (-asq) + rc.w_original_pos * pos_r + rc.w_velocity * vel + rc.w_is_healthy * healthy;
-  // done: height window on the POST-step state (env.py:171,238-242) or any NaN in the stepped state (env.py:173-176)
+  // done: height window on the POST-step state (env.py:171,238-242) or any NaN in the stepped state (env.py:173-176; cinert and
+  // cvel were checked when they left LDS)
   const float z = qpos[2];
   // (bitwise accumulation: a short-circuit || would put every load behind its own branch)
-  int badi = 0;
   FOR_G(i, nq) badi |= (int)isnan(qpos[i]);
   FOR_G(i, nv) badi |= (int)isnan(qvel[i]) | (int)isnan(warm[i]) | (int)isnan(qact[i]);
-  FOR_G(i, 10 * nb) badi |= (int)isnan(cinert[i]);
-  FOR_G(i, 6 * nb) badi |= (int)isnan(cvel[i]);
   badi |= (int)isnan(new_comx);
   const bool bad = badi != 0;
   const bool done = (bool)((int)!((rc.height_min_z < z) & (z < rc.height_max_z)) | (int)group16_any(bad));
-  const int o_ci = nq + nv, o_cv = o_ci + (mv.include_c ? 10 * (nb - 1) : 0), o_qa = o_cv + (mv.include_c ? 6 * (nb - 1) : 0);
-  // The new record is assembled in LDS first (segment copies, region A5: the Jacobian is dead), then written out eight words per
-  // lane at a time: all the global loads of a chunk (old record = the observation to emit, reset record) are issued before its
-  // first store, so a chunk costs one memory round trip (a plain loop pays one per word: the stores to the record keep the next
-  // word's load from moving up).
-  float* recbuf = S + P.recbuf;
+  // The new record: qpos, qvel, qfrc_actuator, the warm start, com_x and the time from LDS (cinert / cvel are in place already) - or,
+  // when the episode ended, the reset record, which is also the observation to emit (env.py:179-180).  Ended episodes are rare: the
+  // reset record is not even loaded otherwise.
   const int rec_dim = mv.rec_dim;
-  FOR_G(i, rec_dim) recbuf[i] = 0.f;
-  SYNC();
-  FOR_G(i, nq) recbuf[i] = qpos[i];
-  FOR_G(i, nv) { recbuf[nq + i] = qvel[i]; recbuf[o_qa + i] = qact[i]; recbuf[OP + i] = warm[i]; }
-  if (mv.include_c) {
-    FOR_G(i, 10 * (nb - 1)) recbuf[o_ci + i] = cinert[10 + i];
-    FOR_G(i, 6 * (nb - 1)) recbuf[o_cv + i] = cvel[6 + i];
-  }
-  if (g == 0) { recbuf[OP + nv] = new_comx; recbuf[OP + nv + 1] = time_in + dt_env; }
-  SYNC();
-  constexpr int kChunk = 8;
-  for (int i0 = g; i0 < rec_dim; i0 += kGroupLanes * kChunk) {
-    float old[kChunk], rst[kChunk];
-    _Pragma("unroll") for (int u = 0; u < kChunk; ++u) {
-      const int i = i0 + kGroupLanes * u, ii = i < rec_dim ? i : rec_dim - 1;
-      old[u] = recw[ii];
-      rst[u] = a.reset_in[ii];
-    }
-    _Pragma("unroll") for (int u = 0; u < kChunk; ++u) {
-      const int i = i0 + kGroupLanes * u;
-      if (valid && i < rec_dim) {
-        // observation = the PRE-step record (env.py:163, quirk C-5), or the reset observation when done (env.py:180)
-        if (i < OP) a.obs[(size_t)env * a.obs_ld + i] = done ? rst[u] : old[u];
-        recw[i] = done ? rst[u] : recbuf[i];
+  if (valid) {
+    if (done) {
+      constexpr int kChunk = 8;
+      for (int i0 = g; i0 < rec_dim; i0 += kGroupLanes * kChunk) {
+        float rst[kChunk];
+        _Pragma("unroll") for (int u = 0; u < kChunk; ++u) { const int i = i0 + kGroupLanes * u; rst[u] = a.reset_in[i < rec_dim ? i : rec_dim - 1]; }
+        _Pragma("unroll") for (int u = 0; u < kChunk; ++u) {
+          const int i = i0 + kGroupLanes * u;
+          if (i < rec_dim) { recw[i] = rst[u]; if (i < OP) a.obs[(size_t)env * a.obs_ld + i] = rst[u]; }
+        }
       }
+    } else {
+      FOR_G(i, nq) recw[i] = qpos[i];
+      FOR_G(i, nv) { recw[nq + i] = qvel[i]; recw[o_qa + i] = qact[i]; recw[OP + i] = warm[i]; }
+      for (int i = O + g; i < OP; i += kGroupLanes) recw[i] = 0.f;
+      for (int i = OP + nv + 2 + g; i < rec_dim; i += kGroupLanes) recw[i] = 0.f;
+      if (g == 0) { recw[OP + nv] = new_comx; recw[OP + nv + 1] = time_in + dt_env; }
     }
   }
   if (valid && g == 0) {
@@ -1203,21 +1285,21 @@ __global__ void __launch_bounds__(kEnvBlock) env_kernel(ModelView mv, EnvArgs a,
 // =================================================================================================
 namespace mppo {
 template <class SD>
-static int32_t launch_env_t(const ModelView& mv, const EnvArgs& a, const PhysLds& lds, int lds_bytes, int blocks, hipStream_t stream) {
+static int32_t launch_env_t(const ModelView& mv, const EnvArgs& a, const PhysLds& lds, int lds_bytes, int blocks, int waves, hipStream_t stream) {
   void (*kern)(ModelView, EnvArgs, PhysLds) = a.mode == 0 ? &env_kernel<SD, 0> : a.mode == 1 ? &env_kernel<SD, 1> : &env_kernel<SD, 2>;
   static thread_local bool attr_set[3] = {false, false, false};
   if (!attr_set[a.mode] && lds_bytes > 64 * 1024) {
     MPPO_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
     attr_set[a.mode] = true;
   }
-  hipLaunchKernelGGL(kern, dim3(blocks), dim3(kEnvBlock), lds_bytes, stream, mv, a, lds);
+  hipLaunchKernelGGL(kern, dim3(blocks), dim3(64 * waves), lds_bytes, stream, mv, a, lds);
   MPPO_CHECK_LAUNCH("env_kernel");
   return MPPO_OK;
 }
 
 struct SpecEntry {
   BlobDims d;
-  int32_t (*launch)(const ModelView&, const EnvArgs&, const PhysLds&, int, int, hipStream_t);
+  int32_t (*launch)(const ModelView&, const EnvArgs&, const PhysLds&, int, int, int, hipStream_t);
 };
 #define MPPO_SPEC(...) {BlobDims{__VA_ARGS__}, &launch_env_t<StaticModel<__VA_ARGS__>>},
 static const SpecEntry kSpecs[] = {
@@ -1243,6 +1325,7 @@ struct mppo_model {
   mppo::ModelView mv;
   mppo::PhysLds lds;
   int lds_bytes;
+  int waves;  // wavefronts per workgroup (4 environments each; one copy of the model tables per workgroup)
   int spec;  // index into the table of model-specialised kernels (spec_dims.inc), -1: the run-time-sized kernel
 };
 
@@ -1331,7 +1414,17 @@ extern "C" int32_t mppo_model_open(const void* host_blob, size_t nbytes, const v
   v.rec_dim = v.obs_pad + ((v.nv + 2 + 3) & ~3);
   m->lds = make_phys_lds(v.nq, v.nv, v.nu, v.nbody, v.njnt, v.ncon, v.nefc, v.nroot, v.ncvx);
   m->spec = find_spec(bd);
-  m->lds_bytes = (v.blob_words + m->lds.total * kEnvsPerBlock) * 4;
+  // waves per workgroup: whatever puts the most waves on a CU (160 KB of LDS; every workgroup holds one copy of the model tables and
+  // waves x 4 environments), the smaller workgroup on a tie.  MPPO_ENV_WAVES=1..4 overrides (measurements).
+  auto lds_of = [&](int w) { return (v.blob_words + m->lds.total * kEnvsPerWave * w) * 4; };
+  int best = 1, best_per_cu = 0;
+  for (int w = 1; w <= kMaxWavesPerBlock; ++w) {
+    const int per_cu = lds_of(w) <= 160 * 1024 ? (160 * 1024 / lds_of(w)) * w : 0;
+    if (per_cu > best_per_cu) { best = w; best_per_cu = per_cu; }
+  }
+  if (const char* e = getenv("MPPO_ENV_WAVES")) { const int w = atoi(e); if (w >= 1 && w <= kMaxWavesPerBlock) best = w; }
+  m->waves = best;
+  m->lds_bytes = lds_of(best);
   if (m->lds_bytes > 160 * 1024) { delete m; return fail(MPPO_EMODEL, "model needs %d bytes of LDS per workgroup (limit 163840)", m->lds_bytes); }
   *out = m;
   return MPPO_OK;
@@ -1359,8 +1452,8 @@ extern "C" int32_t mppo_model_get_dims(const mppo_model_t* m, mppo_model_dims_t*
 
 namespace mppo {
 static int32_t launch_env(const mppo_model_t* m, const EnvArgs& a, hipStream_t stream) {
-  const int blocks = cdiv(a.N, kEnvsPerBlock);
-  return (m->spec >= 0 ? kSpecs[m->spec].launch : &launch_env_t<RuntimeModel>)(m->mv, a, m->lds, m->lds_bytes, blocks, stream);
+  const int blocks = cdiv(a.N, kEnvsPerWave * m->waves);
+  return (m->spec >= 0 ? kSpecs[m->spec].launch : &launch_env_t<RuntimeModel>)(m->mv, a, m->lds, m->lds_bytes, blocks, m->waves, stream);
 }
 }  // namespace mppo
 

@@ -101,19 +101,27 @@ __host__ __device__ constexpr inline BlobOffsets blob_offsets(const BlobDims& d)
   return b;
 }
 
-// Per-environment LDS layout (offsets in floats).  Region "A" is time-shared: kinematics
-// temporaries and the RNE scratch live there until the constraint Jacobian is built.
+// Per-environment LDS layout (offsets in floats).  What is alive from one end of a step to the other sits in front; region "A" is
+// time-shared by five lifetimes that follow one another (each separated from the next by a synchronisation point of the kernel):
+//   A1 kinematics: poses (xpos, xquat, xipos), rotation matrices, joint anchors / axes        - until the contact frames are built
+//   A2 factorisation work copies: a [nv][ldc] square, M then M + h D (<= 32 dofs, fixed-size kernel: rows in registers) or the
+//      lower triangles of both (run-time-sized kernel, > 32 dofs)                              - inside the Cholesky phase
+//   A3 velocity / RNE scratch: cdofdot, cfrc, cvel                                             - until qfrc_bias is done
+//   A4 the contact rows of the constraint Jacobian (joint-limit rows are a sign and a dof: dsgn / drow, never a dense row)
+// (a second time-shared region, B, holds cdof + contact geometry, then the solver's vectors)
+//   cinert spans A1 .. A3 (computed during A1, last read by RNE) and therefore starts behind the longest of the three.
+// cinert and cvel leave LDS for the state record as soon as RNE has read them (they are part of the observation, not of the solver).
 struct PhysLds {
   int qpos, qvel, ctrl, warm;
-  int xpos, xquat, xipos, rootcom;
-  int cinert, cdof, cvel;
-  int ldc;         // row stride of the factorisation work copies C1 / C2 in a fixed-size kernel: nv rounded up to 4 (rows are read as float4)
+  int rootcom, cdof;
+  int ldc;         // row stride of the factorisation work copy in a fixed-size kernel: nv rounded up to 4 (rows are read as float4)
   int M, LL, ldm;  // LL packs L^-1 of M (lower part, [i][k<=i]) and of M + h*D (stored transposed at [k][i+1])
   int qfs, qas, qact, qacc, Ma, grad, Mgrad, search, mv, qfc, t0, t1;
-  int D, aref, jaref, jv, force;
+  int dsgn, drow;  // per dof: sign of its active joint-limit row (0: none) and that row's index
+  int D, aref, jaref, jv, force;  // force shares jv's storage (jv is dead once the step along the search direction is taken)
   int conpos, condist, confr;  // per contact slot: point, distance, frame rows (normal, first tangent)
   int cvxsel, cvxok;           // per convex geom: the four hull vertices chosen this step (body frame) and whether each slot is a first occurrence
-  int A, ximat, xmat, xanchor, xaxis, C1, C2, cdofdot, cfrc, J, ldj, recbuf;
+  int A, xpos, xquat, xipos, ximat, xmat, xanchor, xaxis, C, cdofdot, cfrc, cvel, cinert, J, ldj;
   int total;
 };
 
@@ -124,27 +132,35 @@ __host__ __device__ constexpr inline PhysLds make_phys_lds(int nq, int nv, int n
   int o = 0;
   auto take = [&](int n) { int r = o; o += (n + 3) & ~3; return r; };
   p.qpos = take(nq); p.qvel = take(nv); p.ctrl = take(nu > 0 ? nu : 1); p.warm = take(nv);
-  p.xpos = take(3 * nbody); p.xquat = take(4 * nbody); p.xipos = take(3 * nbody); p.rootcom = take(3 * (nroot > 0 ? nroot : 1));
-  p.cinert = take(10 * nbody); p.cdof = take(6 * nv); p.cvel = take(6 * nbody);
+  p.rootcom = take(3 * (nroot > 0 ? nroot : 1));
   p.ldm = nv + 1;  // odd row stride: a column read by 16 lanes hits 16 different banks
   p.M = take(nv * p.ldm); p.LL = take(nv * p.ldm);
-  p.qfs = take(nv); p.qas = take(nv); p.qact = take(nv); p.qacc = take(nv); p.Ma = take(nv); p.grad = take(nv);
-  p.Mgrad = take(nv); p.search = take(nv); p.mv = take(nv); p.qfc = take(nv); p.t0 = take(nv); p.t1 = take(nv);
+  p.qfs = take(nv); p.qas = take(nv); p.qact = take(nv); p.t0 = take(nv); p.t1 = take(nv);
+  p.dsgn = take(nv); p.drow = take(nv);
   const int ne = nefc > 0 ? nefc : 1;
-  p.D = take(ne); p.aref = take(ne); p.jaref = take(ne); p.jv = take(ne); p.force = take(ne);
-  p.conpos = take(3 * (ncon > 0 ? ncon : 1)); p.condist = take(ncon > 0 ? ncon : 1); p.confr = take(6 * (ncon > 0 ? ncon : 1));
+  p.D = take(ne); p.aref = take(ne); p.jaref = take(ne); p.jv = take(ne); p.force = p.jv;
   p.cvxsel = take(12 * ncvx); p.cvxok = take(4 * ncvx);
-  // region A, four lifetimes (separated by workgroup barriers in the kernel):
-  //   A1 kinematics temporaries | A2 Cholesky work copies | A3 velocity/RNE scratch | A4 constraint Jacobian | A5 record staging
+  // region B, two lifetimes: the dynamics' cdof and the contact geometry, dead once the Jacobian is built | the solver's nv-vectors,
+  // born after that (qacc stays until the end of the step: it is the next step's warm start)
+  const int B = o;
+  p.cdof = take(6 * nv); p.conpos = take(3 * (ncon > 0 ? ncon : 1)); p.condist = take(ncon > 0 ? ncon : 1); p.confr = take(6 * (ncon > 0 ? ncon : 1));
+  const int B1 = o;
+  o = B; p.qacc = take(nv); p.Ma = take(nv); p.grad = take(nv); p.Mgrad = take(nv); p.search = take(nv); p.mv = take(nv); p.qfc = take(nv);
+  o = imax_(o, B1);
   p.A = o;
+  p.xpos = take(3 * nbody); p.xquat = take(4 * nbody); p.xipos = take(3 * nbody);
   p.ximat = take(9 * nbody); p.xmat = take(9 * nbody); p.xanchor = take(3 * njnt); p.xaxis = take(3 * njnt);
-  int end = o;
+  int span = o;  // end of the longest of A1 .. A3
   p.ldc = (nv + 3) & ~3;
-  o = p.A; p.C1 = take(nv * imax_(p.ldm, p.ldc)); p.C2 = take(nv * imax_(p.ldm, p.ldc)); end = imax_(end, o);
-  o = p.A; p.cdofdot = take(6 * nv); p.cfrc = take(6 * nbody); end = imax_(end, o);
-  o = p.A; p.ldj = nv + 1; p.J = take(ne * p.ldj); end = imax_(end, o);
-  o = p.A; p.recbuf = take(nq + 3 * nv + 16 * (nbody - 1) + 12); end = imax_(end, o);  // A5: the new state record, assembled before it is written out
-  p.total = (end + 3) & ~3;
+  o = p.A; p.C = take(imax_(nv <= 32 ? nv * imax_(p.ldm, p.ldc) : 0, 2 * ((nv * (nv + 1) / 2 + 3) & ~3))); span = imax_(span, o);
+  o = p.A; p.cdofdot = take(6 * nv); p.cfrc = take(6 * nbody); p.cvel = take(6 * nbody); span = imax_(span, o);
+  o = span; p.cinert = take(10 * nbody);
+  int end = o;
+  p.ldj = nv + 1;
+  o = p.A; p.J = take((ncon > 0 ? 4 * ncon : 1) * p.ldj); end = imax_(end, o);
+  // an environment's arrays start 16 banks after its neighbour's (total = 16 mod 64 words): the four environments of a wave read the
+  // same logical address at the same time, 16 consecutive words or 16 rows of odd stride each - disjoint sets of the 64 banks
+  p.total = ((end + 47) & ~63) + 16;
   return p;
 }
 
@@ -158,13 +174,9 @@ __host__ __device__ constexpr inline PhysLds make_phys_lds(int nq, int nv, int n
 #ifndef MPPO_ENVS_PER_WAVE
 #define MPPO_ENVS_PER_WAVE 4
 #endif
-#ifndef MPPO_WAVES_PER_BLOCK
-#define MPPO_WAVES_PER_BLOCK 1
-#endif
 constexpr int kGroupLanes = 16;                      // lanes that cooperate on one environment
 constexpr int kEnvsPerWave = MPPO_ENVS_PER_WAVE;     // 1, 2 or 4
-constexpr int kWavesPerBlock = MPPO_WAVES_PER_BLOCK;
-constexpr int kEnvBlock = 64 * kWavesPerBlock;       // threads per workgroup
-constexpr int kEnvsPerBlock = kEnvsPerWave * kWavesPerBlock;
+constexpr int kMaxWavesPerBlock = 4;                 // the number of waves per workgroup is chosen per model (mppo_model_open): the most
+                                                     // waves per CU that 160 KB of LDS hold, one copy of the model tables per workgroup
 
 }  // namespace mppo
