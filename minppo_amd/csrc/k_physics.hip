@@ -955,7 +955,9 @@ __global__ void __launch_bounds__(64 * kMaxWavesPerBlock) env_kernel(ModelView m
         SYNC();
         if (take) {
           FOR_G(i, nv) Ma[i] = mrow_dot(i, qacc);
-          FOR_G(r, nefc) jaref[r] = jrow_dot(r, qacc) - earef[r];
+          // (limit rows and contact rows in loops of their own: 16 lanes on 16 dense rows at a time, not on a mixture)
+          FOR_G(r, nlim) jaref[r] = jrow_dot(r, qacc) - earef[r];
+          FOR_G(rc, 4 * ncon) jaref[nlim + rc] = jrow_dot(nlim + rc, qacc) - earef[nlim + rc];
         }
         SYNC();
         float gs = 0.f, cs = 0.f;
@@ -1010,7 +1012,8 @@ __global__ void __launch_bounds__(64 * kMaxWavesPerBlock) env_kernel(ModelView m
         // ---------------- line search ----------------
         float sn = 0.f, sMa = 0.f, sq = 0.f;
         FOR_G(i, nv) mvv[i] = mrow_dot(i, search);
-        FOR_G(r, nefc) jv[r] = jrow_dot(r, search);
+        FOR_G(r, nlim) jv[r] = jrow_dot(r, search);
+        FOR_G(rc, 4 * ncon) jv[nlim + rc] = jrow_dot(nlim + rc, search);
         FOR_G(i, nv) { sn += search[i] * search[i]; sMa += search[i] * Ma[i]; sq += search[i] * qfs[i]; }
         SYNC();
         if (it == 0) PT(24);
