@@ -384,6 +384,41 @@ def test_colliding_spheres_conserve_momentum(be):
     be.lib.model_close(h)
 
 
+def test_waves_per_workgroup_change_nothing(be, monkeypatch):
+    """mppo_model_open picks the number of waves per workgroup that puts the most waves on a CU (160 KB of LDS, one copy of the model
+    tables per workgroup): three for the 26-dof robot.  The choice is a launch geometry, not arithmetic: env steps with one, two and
+    three waves per workgroup (MPPO_ENV_WAVES) agree bit for bit, at an environment count that fills the last workgroup only partly."""
+    cm = load_model("synth_stompy_full")
+    N = 29
+    res, lds = [], []
+    for waves in (None, "1", "2"):
+        if waves is None:
+            monkeypatch.delenv("MPPO_ENV_WAVES", raising=False)
+        else:
+            monkeypatch.setenv("MPPO_ENV_WAVES", waves)
+        h, dims, _keep = be.model(cm)
+        lds.append(dims.lds_bytes)
+        OP, R = dims.obs_pad, dims.rec_dim
+        state, reset_rec, obs = be.zeros((N, R)), be.zeros((R,)), be.zeros((N, OP))
+        rew, done = be.zeros((N,)), be.zeros((N,), np.uint8)
+        be.lib.env_reset(h, N, be.ptr(state), be.ptr(reset_rec), be.ptr(obs), OP, be.ptr(rew), be.ptr(done), None, be.stream)
+        rc = nat.RewardCfg(0.95, 2.0, 2.0, 0.2, 0.5, 0.1, 4.0, 1.0, 1.25)
+        r2 = np.random.default_rng(11)
+        for _ in range(5):
+            act = be.arr((0.8 * r2.standard_normal((N, cm.nu))).astype(f32))
+            be.lib.env_step(h, N, 1, C.byref(rc), be.ptr(state), be.ptr(reset_rec), be.ptr(act), cm.nu, be.ptr(obs), OP, be.ptr(rew), be.ptr(done), None, be.stream)
+            be.sync()
+        res.append(dict(state=be.host(state).copy(), obs=be.host(obs).copy(), rew=be.host(rew).copy(), done=be.host(done).copy()))
+        be.lib.model_close(h)
+    monkeypatch.delenv("MPPO_ENV_WAVES", raising=False)
+    assert lds[1] < lds[2] < lds[0] <= 160 * 1024, lds  # the default is three waves: more than half of a CU's LDS in one workgroup
+    per_env = (lds[2] - lds[1]) // 4
+    assert lds[0] - lds[2] == 4 * per_env and 2 * lds[2] > 160 * 1024, lds  # ... because two two-wave workgroups would not fit
+    for other in res[1:]:
+        for k in res[0]:
+            np.testing.assert_array_equal(res[0][k], other[k], err_msg=k)
+
+
 def test_specialised_kernel_equals_the_runtime_sized_kernel(be, monkeypatch):
     """The BASELINE robots run an env_kernel instantiation compiled for their dimensions (csrc/spec_dims.inc); every other
     model - and these two under MPPO_ENV_GENERIC=1 - runs the run-time-sized instantiation of the same source.  Same
