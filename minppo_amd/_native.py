@@ -154,7 +154,9 @@ class Lib:
 
     def __init__(self, path: os.PathLike | str):
         self.path = str(path)
-        self._dll = C.CDLL(self.path, mode=C.RTLD_GLOBAL)
+        # RTLD_LOCAL (the default): the test-suite's emulator build exports the same C++ symbols; with global visibility whichever
+        # library came first would serve the other's internal calls
+        self._dll = C.CDLL(self.path)
         self._fn = {}
         for name, (res, args) in SIGNATURES.items():
             try:

@@ -8,6 +8,6 @@ SRC="$ROOT/minppo_amd/csrc"
 OUT="$HERE/libminppo_emu.so"
 FILES=""
 for f in $(cat "$SRC/SOURCES.txt"); do FILES="$FILES $SRC/$f"; done
-g++ -std=c++17 -O2 -g -fPIC -shared -x c++ -DMPPO_EMU=1 -I"$HERE" -I"$SRC" -Wno-attributes -Wno-unused-value "$@" \
+g++ -std=c++17 -O2 -g -fPIC -shared -Wl,-Bsymbolic -x c++ -DMPPO_EMU=1 -I"$HERE" -I"$SRC" -Wno-attributes -Wno-unused-value "$@" \
     $FILES "$HERE/emu_runtime.cpp" $( [ -f "$HERE/emu_stubs.cpp" ] && echo "$HERE/emu_stubs.cpp" ) -o "$OUT"
 echo "built $OUT"
