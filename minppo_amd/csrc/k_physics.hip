@@ -7,16 +7,15 @@
 // (env.py:238-242), the NaN guard (env.py:173-176), the auto-reset select (env.py:179-180),
 // `get_obs` (env.py:245-261) and the episode metrics (env.py:183-194).
 //
-// Mapping (MI355X): 16 lanes (one DPP row) cooperate on one environment, 4 environments per
-// 64-wide wavefront, one wavefront per workgroup -> N/4 workgroups (1024 at N = 4096 = one wave
-// per SIMD on 256 CUs).  Every per-environment array lives in LDS (about 9.5 KB per environment
-// for the 16-dof stand-in, four workgroups per CU); lanes own dofs / bodies / constraint rows
-// with stride 16, reductions run as DPP row rotations (wave_ops.h), and the only sequential
-// parts are the kinematic-tree levels and the Cholesky columns.  All tree recursions of
-// MuJoCo (composite inertia, body velocities, RNE) are evaluated in closed form over ancestor /
-// subtree bitmasks from the model blob, so they need no level-by-level synchronisation.
-// HBM traffic per environment step: the state record in and out, the action in, the observation
-// out (about 2.9 KB at O = 225).  The kernel is latency-bound, not bandwidth-bound.
+// Mapping (MI355X): 16 lanes (one DPP row) cooperate on one environment, 4 environments per 64-wide wavefront, one to four
+// wavefronts per workgroup (chosen per model in mppo_model_open: whatever puts the most waves on a CU's 160 KB of LDS; 1024
+// one-wave workgroups at N = 4096 for the 16-dof stand-in = one wave per SIMD on 256 CUs).  Every per-environment array lives in
+// LDS, laid out by lifetime (model_view.h: 6.5 KB per environment for the 16-dof stand-in, 12.9 KB for the 26-dof robot); lanes own
+// dofs / bodies / constraint rows with stride 16, reductions run as DPP row rotations (wave_ops.h), and the only sequential parts
+// are the kinematic-tree levels and the Cholesky columns.  All tree recursions of MuJoCo (composite inertia, body velocities, RNE)
+// are evaluated in closed form over ancestor / subtree bitmasks from the model blob, so they need no level-by-level
+// synchronisation.  HBM traffic per environment step: the state record in and out, the action in, the observation out (about
+// 2.9 KB at O = 225).  The kernel is bound by the instructions one wave issues, not by bandwidth.
 #include "model_view.h"
 #include "mppo_common.h"
 #include <wave_ops.h>

@@ -166,7 +166,7 @@ __host__ __device__ constexpr inline PhysLds make_phys_lds(int nq, int nv, int n
 
 // Geometry of the environment kernel.  An environment is private to ONE wavefront (16 lanes = one DPP row), so everything
 // after the staging of the model tables synchronises at wave level only (program order; no s_barrier).  A wave carries
-// kEnvsPerWave environments on its first rows (the other rows retire after the staging); kWavesPerBlock waves share one LDS
+// kEnvsPerWave environments on its first rows (the other rows retire after the staging); the waves of a workgroup share one LDS
 // copy of the model tables.  Measured on MI355X, 4096 envs, synth_stompy_pro (tools/env_iters_probe.py), envs/wave x waves/block:
 //   4 x 1: 158 us (default)   2 x 8: 183 us   2 x 4 and 2 x 2: 300 us (LDS lets only one block per CU run)   1 x 4: 600 us
 // i.e. the kernel is bound by the instruction stream each WAVE issues (the same ~27 k VALU instructions whether 16 or 64 lanes
