@@ -674,11 +674,16 @@ def make_train(config: Config, **trainer_kwargs: Any) -> Callable[[Any], TrainOu
         metrics = {"mean_reward": [], "done_fraction": [], "episodes": [], "mean_episode_return": [], "mean_episode_length": [], "total_loss": [], "value_loss": [],
                    "actor_loss": [], "entropy": []}
         t0 = time.time()
+        peers = tr.world_size > 1 and tr.comm_mode() == "peer"
         for u in range(first, n):
             tr.update()
             if ckpt and tc.checkpoint_every > 0 and (u + 1) % tc.checkpoint_every == 0 and u + 1 < n:
+                if peers:
+                    tr.check_peers()  # never checkpoint parameters that were updated with a timed-out exchange
                 tr.save_checkpoint(ckpt)
             if log_every and ((u + 1) % log_every == 0 or u + 1 == n):
+                if peers:
+                    tr.check_peers()  # (the statistics below synchronise anyway) a dead peer ends the job here, not as silent garbage
                 st, lo = tr.rollout_stats(reduce=True), tr.losses(reduce=True).reshape(-1, 4).mean(0)
                 for k, v in st.items():
                     metrics[k].append(v)
@@ -687,6 +692,8 @@ def make_train(config: Config, **trainer_kwargs: Any) -> Callable[[Any], TrainOu
                 sps = (u + 1 - first) * tr.T * tr.N * tr.world_size / (time.time() - t0)
                 logger.info("update %d/%d  reward %.3f  done %.4f  episode return %.2f length %.1f  loss %.4f  %.0f env-steps/s", u + 1, n, st["mean_reward"],
                             st["done_fraction"], st["mean_episode_return"], st["mean_episode_length"], lo[0], sps)
+        if peers:
+            tr.check_peers()
         if ckpt:
             tr.save_checkpoint(ckpt)
         params = tr.params
