@@ -363,7 +363,6 @@ __global__ void __launch_bounds__(64 * kMaxWavesPerBlock) env_kernel(ModelView m
   int badi = 0;  // NaN anywhere in the stepped state (env.py:173-176), accumulated where the values are at hand
 
   float new_comx = 0.f;
-  int niter_out = 0;
   const int frames = MODE == 1 ? a.n_frames : 1;
   for (int frame = 0; frame < frames; ++frame) {
     PT(1);
@@ -1142,7 +1141,6 @@ __global__ void __launch_bounds__(64 * kMaxWavesPerBlock) env_kernel(ModelView m
       }
     }
     PT(20);
-    niter_out = niter;
     // ---- probe outputs (parity tests) ---------------------------------------------------------------------
     if (MODE == 2 && valid) {
       const mppo_forward_probe_t& pr = a.probe;
