@@ -384,6 +384,58 @@ def test_colliding_spheres_conserve_momentum(be):
     be.lib.model_close(h)
 
 
+def _many_dof_robot():
+    """The 26-dof stand-in with a 4-joint neck and two 5-joint tails: 40 dofs, 37 bodies - past what the model-specialised kernels and the
+    register Cholesky cover (32 dofs), so the run-time-sized kernel's LDS factorisation (two triangular work copies) is what runs."""
+    from minppo_amd import model as M
+
+    spec = M.synth_stompy_full()
+    extra, acts = [], []
+
+    def chain(prefix, parent, n, pos0, axis_cycle, step):
+        par = parent
+        for k in range(n):
+            name = f"{prefix}{k}"
+            extra.append(M.BodySpec(name, par, pos=pos0 if k == 0 else step, mass=0.3, inertia=(0.0008, 0.0008, 0.0004), ipos=(0.0, 0.0, 0.5 * step[2]),
+                                    joints=[M.JointSpec(name, M.JNT_HINGE, axis=axis_cycle[k % len(axis_cycle)], range=(-0.7, 0.7), damping=0.5, armature=0.02)],
+                                    geoms=[M.GeomSpec(M.GEOM_SPHERE, (0.03,), pos=(0.0, 0.0, step[2]))] if k == n - 1 else []))
+            acts.append(M.ActuatorSpec(name, kp=8.0, kv=0.0, ctrlrange=(-1.0, 1.0), forcerange=(-10.0, 10.0)))
+            par = name
+
+    chain("neck", "torso", 4, (0.0, 0.0, 0.40), [(0, 1, 0), (1, 0, 0), (0, 0, 1)], (0.0, 0.0, 0.06))
+    chain("tail_l", "torso", 5, (-0.10, 0.05, 0.0), [(0, 1, 0), (1, 0, 0)], (0.0, 0.0, -0.09))
+    chain("tail_r", "torso", 5, (-0.10, -0.05, 0.0), [(0, 1, 0), (1, 0, 0)], (0.0, 0.0, -0.09))
+    return M.compile_model(M.ModelSpec(name="many_dof", bodies=spec.bodies + extra, actuators=spec.actuators + acts, free_root_z=spec.free_root_z))
+
+
+def test_forty_dof_robot_runs_the_runtime_sized_kernel(be):
+    """More dofs than the register Cholesky / model-specialised kernels cover: dims, the LDS budget of one four-environment wave,
+    the forward pass against the oracle and a few steps against the environment oracle's done flags."""
+    cm = _many_dof_robot()
+    assert cm.nv == 40 and cm.nu == 34
+    h, dims, _keep = be.model(cm)
+    flag = C.c_int32(-1)
+    be.lib.model_is_specialized(h, C.byref(flag))
+    assert flag.value == 0 and dims.lds_bytes <= 160 * 1024
+    N = 6
+    ph, d, rng = _walk(cm, N, 5, 21)
+    ctrl = 0.3 * rng.standard_normal((N, cm.nu))
+    q32 = [x.astype(f32) for x in (d.qpos, d.qvel, ctrl, d.qacc_warmstart)]
+    ref = PhysState(qpos=q32[0].astype(np.float64), qvel=q32[1].astype(np.float64), ctrl=q32[2].astype(np.float64),
+                    qacc_warmstart=q32[3].astype(np.float64), time=np.zeros(N))
+    ph.forward(ref)
+    got = _probe(be, h, cm, *q32)
+    for k, t in dict(qM=1e-5, qfrc_bias=2e-4, qacc_smooth=5e-4, efc_J=1e-5, efc_D=5e-4, efc_aref=5e-4, cinert=1e-5, cvel=1e-4, xpos=1e-5).items():
+        r = ref[k]
+        scale = np.abs(r).max() + 1e-6
+        assert np.abs(got[k].reshape(r.shape) - r).max() <= t * scale, (k, np.abs(got[k].reshape(r.shape) - r).max(), scale)
+    np.testing.assert_allclose(_cost(ref, got["qacc"]), _cost(ref, ref.qacc), rtol=5e-2, atol=1e-3)
+    # the Euler solve goes through the second factor (M + h D)
+    acc = _euler_acc(cm, ref)
+    assert np.median(np.abs(got["qacc_euler"] - acc)) <= 5e-3 * (np.abs(acc).max() + 1e-6)
+    be.lib.model_close(h)
+
+
 def test_waves_per_workgroup_change_nothing(be, monkeypatch):
     """mppo_model_open picks the number of waves per workgroup that puts the most waves on a CU (160 KB of LDS, one copy of the model
     tables per workgroup): three for the 26-dof robot.  The choice is a launch geometry, not arithmetic: env steps with one, two and
