@@ -971,7 +971,7 @@ __global__ void __launch_bounds__(64 * kMaxWavesPerBlock) env_kernel(ModelView m
       ctx_eval(warm, true, gauss_w, cost_w);
       // fixed-size kernel: the warm-start context (this lane's entries of Ma and Jaref) is parked in registers while the smooth
       // start is evaluated, and put back if it wins - the run-time-sized kernel evaluates it a second time instead
-      constexpr int kNvR = kDims ? (kSD.nv + kGroupLanes - 1) / kGroupLanes : 1, kEfR = kDims ? (kSD.nlimit + 4 * kSD.ncon + kGroupLanes - 1) / kGroupLanes : 1;
+      constexpr int kNvR = kDims ? (kSD.nv + kGroupLanes - 1) / kGroupLanes : 1, kEfR = kDims && kSD.nlimit + 4 * kSD.ncon > 0 ? (kSD.nlimit + 4 * kSD.ncon + kGroupLanes - 1) / kGroupLanes : 1;  // (a model without constraint rows never gets here)
       float keep_ma[kNvR], keep_ja[kEfR];
       if (kDims) {
         _Pragma("unroll") for (int j = 0; j < kNvR; ++j) { const int i = g + kGroupLanes * j; keep_ma[j] = i < nv ? Ma[i] : 0.f; }
@@ -1023,7 +1023,7 @@ __global__ void __launch_bounds__(64 * kMaxWavesPerBlock) env_kernel(ModelView m
         // three trial steps at once: sums of the active rows' quadratics
         // A lane's rows (g, g + 16, ...) do not change during the line search.  With compile-time dims their quadratics live in
         // registers for the whole search (kRows of them per lane); the run-time-sized kernel re-reads them from LDS per trial.
-        constexpr int kRows = kDims ? (kSD.nlimit + 4 * kSD.ncon + kGroupLanes - 1) / kGroupLanes : 1;
+        constexpr int kRows = kDims && kSD.nlimit + 4 * kSD.ncon > 0 ? (kSD.nlimit + 4 * kSD.ncon + kGroupLanes - 1) / kGroupLanes : 1;
         float rja[kRows], rv[kRows], rc0[kRows], rc1[kRows], rc2[kRows];
         if (kDims) {
           _Pragma("unroll") for (int j = 0; j < kRows; ++j) {
