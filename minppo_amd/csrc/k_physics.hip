@@ -1287,10 +1287,11 @@ namespace mppo {
 template <class SD>
 static int32_t launch_env_t(const ModelView& mv, const EnvArgs& a, const PhysLds& lds, int lds_bytes, int blocks, int waves, hipStream_t stream) {
   void (*kern)(ModelView, EnvArgs, PhysLds) = a.mode == 0 ? &env_kernel<SD, 0> : a.mode == 1 ? &env_kernel<SD, 1> : &env_kernel<SD, 2>;
-  static thread_local bool attr_set[3] = {false, false, false};
-  if (!attr_set[a.mode] && lds_bytes > 64 * 1024) {
+  // (the run-time-sized instantiation serves robots of different sizes: the limit follows the largest one seen)
+  static thread_local int attr_lds[3] = {64 * 1024, 64 * 1024, 64 * 1024};
+  if (lds_bytes > attr_lds[a.mode]) {
     MPPO_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
-    attr_set[a.mode] = true;
+    attr_lds[a.mode] = lds_bytes;
   }
   hipLaunchKernelGGL(kern, dim3(blocks), dim3(64 * waves), lds_bytes, stream, mv, a, lds);
   MPPO_CHECK_LAUNCH("env_kernel");
