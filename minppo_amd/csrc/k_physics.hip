@@ -57,6 +57,15 @@ struct EnvArgs {
 #define SYNC() __builtin_amdgcn_wave_barrier()
 #endif
 #define FOR_G(i, n) for (int i = g; i < (n); i += kGroupLanes)
+#ifndef MPPO_DOT_UNROLL_RT
+#define MPPO_DOT_UNROLL_RT 8
+#endif
+// How many terms of a dot product are requested from LDS before the first is consumed (one wave per SIMD: nothing else hides an LDS
+// round trip, and a third of a wave's life is spent waiting for LDS).  Measured (tools/env_time.py): 8 / 16 / 32 terms give 89.9 / 85.5 /
+// 87.9 us for the 16-dof robot and 547 / 531 / 510 us for the 26-dof one: a whole row of M or J at a time.  The summation order does
+// not change.  kDotU is a constant of the enclosing function (model-specialised kernels: by the number of dofs; run-time-sized: 8).
+#define DOT_UNROLL _Pragma("unroll kDotU")
+constexpr int dot_unroll(int nv_static) { return nv_static == 0 ? MPPO_DOT_UNROLL_RT : nv_static <= 16 ? 16 : 32; }
 // the instruction scheduler moves nothing across this point
 #ifdef MPPO_EMU
 #define SCHED_FENCE() do { } while (0)
@@ -181,12 +190,13 @@ __device__ __forceinline__ void cross_force(const float* vel, const float* f, fl
 template <bool EUL, int NV>
 __device__ __forceinline__ void solve_linv(const float* LL, int ldm, int nv_rt, const float* b, float* tmp, float* x, int g) {
   const int nv = NV ? NV : nv_rt;
+  constexpr int kDotU = dot_unroll(NV);
   // Both triangular products run over the FULL row with the entries outside the triangle masked to 0 (LL packs two inverse
   // factors in one square): a lane-independent trip count lets the compiler request eight LDS operands at a time and wait once,
   // where the triangular loop waited for every single one (one wave per SIMD: nothing else hides an LDS round trip).
   FOR_G(i, nv) {
     float s = 0.f;
-#pragma unroll 8
+DOT_UNROLL
     for (int k = 0; k < nv; ++k) {
       const float l = EUL ? LL[k * ldm + i + 1] : LL[i * ldm + k];
       s += (k <= i ? l : 0.f) * b[k];
@@ -196,7 +206,7 @@ __device__ __forceinline__ void solve_linv(const float* LL, int ldm, int nv_rt, 
   SYNC();
   FOR_G(i, nv) {
     float s = 0.f;
-#pragma unroll 8
+DOT_UNROLL
     for (int k = 0; k < nv; ++k) {
       const float l = EUL ? LL[i * ldm + k + 1] : LL[k * ldm + i];
       s += (k >= i ? l : 0.f) * tmp[k];
@@ -280,6 +290,7 @@ __global__ void __launch_bounds__(64 * kMaxWavesPerBlock) env_kernel(ModelView m
   const PhysLds P = SD::kStatic ? kSP : Prt;
   constexpr bool kDims = SD::kStatic;
   constexpr int NV = kDims ? kSD.nv : 0;
+  constexpr int kDotU = dot_unroll(NV);
   MPPO_DYN_SMEM(smem_raw);
   const int tid = threadIdx.x;
   const int g = tid & (kGroupLanes - 1);
@@ -912,18 +923,18 @@ __global__ void __launch_bounds__(64 * kMaxWavesPerBlock) env_kernel(ModelView m
       if (r < nlim) { const int da = TI(jnt_dofadr)[TI(lim_jntid)[r]]; return dsgn[da] * x[da]; }
       const float* jr = J + (r - nlim) * ldj;
       float s = 0.f;
-      _Pragma("unroll 8") for (int k = 0; k < nv; ++k) s += jr[k] * x[k];
+      DOT_UNROLL for (int k = 0; k < nv; ++k) s += jr[k] * x[k];
       return s;
     };
     auto jcol_dot = [&](int i, const float* f) {
       float s = nlim > 0 ? dsgn[i] * f[drow[i]] : 0.f;
       const int nc4 = 4 * ncon;
-      _Pragma("unroll 8") for (int r = 0; r < nc4; ++r) s += J[r * ldj + i] * f[nlim + r];
+      DOT_UNROLL for (int r = 0; r < nc4; ++r) s += J[r * ldj + i] * f[nlim + r];
       return s;
     };
     auto mrow_dot = [&](int i, const float* x) {
       float s = 0.f;
-      _Pragma("unroll 8") for (int k = 0; k < nv; ++k) s += M[i * ldm + k] * x[k];
+      DOT_UNROLL for (int k = 0; k < nv; ++k) s += M[i * ldm + k] * x[k];
       return s;
     };
     FOR_G(r, nefc) {
