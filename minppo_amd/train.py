@@ -488,7 +488,8 @@ class Trainer:
         import socket
 
         p = self.torch.cuda.get_device_properties(self.device)
-        ident = getattr(p, "uuid", None) or (getattr(p, "pci_domain_id", 0), getattr(p, "pci_bus_id", self.device.index), getattr(p, "pci_device_id", 0))
+        # both the uuid and the PCI address: ranks count as sharing a GPU only if every identifier the runtime offers agrees
+        ident = (str(getattr(p, "uuid", "")), getattr(p, "pci_domain_id", None), getattr(p, "pci_bus_id", None), getattr(p, "pci_device_id", None))
         return f"{socket.gethostname()}/{ident}"
 
     def comm_mode(self) -> str:
