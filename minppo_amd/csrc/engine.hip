@@ -192,12 +192,12 @@ constexpr unsigned long long kStreamPerm = 0x5045524Dull << 24;     // "PERM"
 
 
 static bool shadow_enabled() {  // MPPO_NO_SHADOW=1: A/B switch for measurements
-  static const bool no_shadow = [] { const char* v = getenv("MPPO_NO_SHADOW"); return v && v[0] == '1'; }();
+  static const bool no_shadow = [] { const char* v = MPPO_EXPERIMENT_ENV("MPPO_NO_SHADOW"); return v && v[0] == '1'; }();
   return !no_shadow;
 }
 
 static bool pregather_enabled() {  // MPPO_NO_PREGATHER=1: A/B switch for measurements
-  static const bool off = [] { const char* v = getenv("MPPO_NO_PREGATHER"); return v && v[0] == '1'; }();
+  static const bool off = [] { const char* v = MPPO_EXPERIMENT_ENV("MPPO_NO_PREGATHER"); return v && v[0] == '1'; }();
   return !off;
 }
 
@@ -267,7 +267,7 @@ static int32_t do_learn(mppo_engine* e, hipStream_t s) {
   GradBufs gb = carve_grad(c.net, e->mb, e->grad_ws);
   // W2^T shadow copies for the backward row pass: rebuilt from the parameters once per update (they may have been written from
   // outside: upload, checkpoint), then kept current by every Adam step of the update
-  static const char* nofuse = getenv("MPPO_NO_FUSED");
+  static const char* nofuse = MPPO_EXPERIMENT_ENV("MPPO_NO_FUSED");
   const bool fused_path = fused_supported(c.net, batch) && !(nofuse && nofuse[0] == '1');
   const bool use_shadow = fused_supported(c.net, batch) && shadow_enabled();
   ShadowRef shadow = make_shadow_ref(c.net, gb);
@@ -310,8 +310,10 @@ static int32_t do_learn(mppo_engine* e, hipStream_t s) {
                               e->losses + 4 * st, single ? e->adam_ws : nullptr, gb, s, use_pre ? &pre : nullptr));  // train.py:246-247
       if (!single) MPPO_TRY(comm_allreduce_f32(e->comm, e->grad, (size_t)e->P, s));
       MPPO_TRY(clip_adam((size_t)e->P, e->params, e->adam_m, e->adam_v, e->grad, e->count, st, ac, e->adam_ws, single, s, use_shadow ? &shadow : nullptr));  // train.py:248
+#ifdef MPPO_EXPERIMENTS
       static const int extra = [] { const char* v = getenv("MPPO_EXTRA_LAUNCHES"); return v ? atoi(v) : 0; }();  // timing experiment: what does ONE more trivial launch cost here?
       for (int x = 0; x < extra; ++x) hipLaunchKernelGGL(advance_counters_kernel, dim3(1), dim3(64), 0, s, e->count, 0);
+#endif
     }
   }
   if (use_peer) MPPO_TRY(peer_advance(e->peer, EM, s));

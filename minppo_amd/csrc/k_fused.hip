@@ -849,8 +849,12 @@ int32_t fused_forward_backward(const mppo_net_t& net, const float* params, const
   const bool w2t = g.w2t_valid && g.w2t;
   a.w2t[0] = g.w2t; a.w2t[1] = g.w2t ? g.w2t + pad4((size_t)net.H * net.H) : nullptr;
   a.frag[0] = g.frag; a.frag[1] = g.frag ? g.frag + g.frag_net_stride : nullptr;
-  static const int skip = [] { const char* e = getenv("MPPO_FUSED_SKIP"); return e ? atoi(e) : 0; }();
+#ifdef MPPO_EXPERIMENTS
+  static const int skip = [] { const char* e = getenv("MPPO_FUSED_SKIP"); return e ? atoi(e) : 0; }();  // phase-budget measurements: skips GEMM phases (results are garbage)
   a.skip = skip;
+#else
+  a.skip = 0;
+#endif
   const size_t smem = fused_smem_bytes(net.O, net.A, net.H);
   static thread_local size_t attr_for = 0;
   if (smem > 64 * 1024 && attr_for < smem) {

@@ -328,7 +328,7 @@ int32_t gemm_launch(const GemmBatch& gb, int a_t, int b_t, int epi, int bf16, hi
   const int v = a_t * 2 + b_t;
   // implementation per variant: direct-to-register everywhere (gathered weight-gradient operands fall back to LDS).
   // MPPO_GEMM_IMPL = "ddd" / "lll" / ... overrides per variant (d = direct, l = LDS) for A/B measurements.
-  static const char* impl = getenv("MPPO_GEMM_IMPL");
+  static const char* impl = MPPO_EXPERIMENT_ENV("MPPO_GEMM_IMPL");
   const char choice = (impl && (int)strlen(impl) > v) ? impl[v] : 'd';
   // bf16-in / f32-accumulate exists for the direct forward and weight-gradient kernels only (the fused row pass covers the rest)
   if (choice == 'l') { MPPO_REQUIRE(!bf16, "gemm_launch: no bf16 variant of the LDS-staged kernels"); return gemm_launch_lds(gb, a_t, b_t, epi, stream); }

@@ -98,10 +98,10 @@ int32_t peer_create(int rank, int world, size_t P, size_t adv_doubles, PeerComm*
   v.adv_off = (unsigned)align_up(v.red_off + (P + kSqSlots) * 4, 256);
   c->bytes = align_up(v.adv_off + adv_doubles * 8, 256);
   v.limit_ticks = limit_ticks();
-  { const char* e = getenv("MPPO_PEER_POLL_RMW"); v.poll_rmw = e && e[0] == '1'; }
+  { const char* e = MPPO_EXPERIMENT_ENV("MPPO_PEER_POLL_RMW"); v.poll_rmw = e && e[0] == '1'; }
   // fine-grained device memory: coherent for accesses from other agents (what RCCL allocates for its own peer buffers);
   // MPPO_PEER_ALLOC=uncached | plain select the other two kinds hipIpc can export (measurements)
-  const char* kind = getenv("MPPO_PEER_ALLOC");
+  const char* kind = MPPO_EXPERIMENT_ENV("MPPO_PEER_ALLOC");
   hipError_t e;
   if (kind && !strcmp(kind, "plain")) e = hipMalloc(reinterpret_cast<void**>(&c->mine), c->bytes);
   else e = hipExtMallocWithFlags(reinterpret_cast<void**>(&c->mine), c->bytes, kind && !strcmp(kind, "uncached") ? hipDeviceMallocUncached : hipDeviceMallocFinegrained);

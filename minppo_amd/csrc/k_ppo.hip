@@ -607,7 +607,7 @@ static HeadArgs head_args(const mppo_net_t& net, const float* params, int n, con
 // full policy step on n rows: hidden layers, heads, sample + log-prob (noise may be null: value only)
 int32_t policy_forward(const mppo_net_t& net, const float* params, int n, const float* obs, int obs_ld, const FwdBufs& fb, const float* noise, float* action,
                        float* log_prob, float* value, float* mean_out, hipStream_t stream) {
-  static const char* nofuse = getenv("MPPO_NO_FUSED");  // A/B switch for measurements
+  static const char* nofuse = MPPO_EXPERIMENT_ENV("MPPO_NO_FUSED");  // A/B switch for measurements
   if (fused_rollout_supported(net, obs, obs_ld) && !(nofuse && nofuse[0] == '1'))
     return fused_policy_forward(net, params, n, obs, obs_ld, noise, action, log_prob, value, noise ? mean_out : nullptr, fb.AP, stream, fb.frag, fb.frag_net_stride);  // one launch
   MPPO_TRY(mlp_hidden_forward(net, params, n, obs, obs_ld, nullptr, fb, nullptr, stream));
@@ -628,7 +628,7 @@ int32_t minibatch_rowpass(const mppo_net_t& net, const float* params, const mppo
   const int H = net.H;
   const int act_a = net.use_tanh ? ACT_TANH : ACT_RELU;
   MPPO_REQUIRE(batch.obs_ld == net.OP, "minibatch_grad: obs_ld (%d) must equal the padded observation width OP (%d)", batch.obs_ld, net.OP);
-  static const char* nofuse = getenv("MPPO_NO_FUSED");  // A/B switch for measurements
+  static const char* nofuse = MPPO_EXPERIMENT_ENV("MPPO_NO_FUSED");  // A/B switch for measurements
   const bool fused = fused_supported(net, batch) && !(nofuse && nofuse[0] == '1');
   if (fused_out) *fused_out = fused;
   if (fused) {
@@ -665,8 +665,6 @@ int32_t minibatch_grad(const mppo_net_t& net, const float* params, const mppo_ba
   MPPO_REQUIRE(fused || !peer, "minibatch_grad: the layer-wise path writes a plain gradient (the engine publishes it with peer_publish)");
   const float* xq = (pre && fused) ? pre->cur : gbuf.xmb;  // the step's observation rows, k-quad layout (the layer-wise path gathers for itself)
   const float ent_weight = (float)mb * inv_count;
-  static const char* old_wgrad = getenv("MPPO_OLD_WGRAD");  // (no longer selectable with the fused row pass: its outputs are k-quad operands)
-  (void)old_wgrad;
   if (fused) {
     // the row pass left its outputs in k-quad layout: one launch produces the complete gradient (k_wgrad.hip)
     WgradArgs w{};
@@ -687,7 +685,9 @@ int32_t minibatch_grad(const mppo_net_t& net, const float* params, const mppo_ba
     w.ent_coef = lc.ent_coef; w.vf_coef = lc.vf_coef; w.ent_weight = ent_weight; w.loss4 = loss4;
     w.npad = L.npad;
     for (int k = 0; k < L.npad; ++k) { w.pad_off[k] = L.pad_off[k]; w.pad_cnt[k] = L.pad_cnt[k]; }
+#ifdef MPPO_EXPERIMENTS
     { static const char* e8 = getenv("MPPO_WGRAD_DBG"); if (e8 && (atoi(e8) & 8)) w.count = 4; }  // timing experiment: big problems only
+#endif
     MPPO_TRY(wgrad_plan(w, mb));
     MPPO_REQUIRE(wgrad_supported(w), "minibatch_grad: weight-gradient launch not applicable (%d tiles)", w.ntiles);
     return wgrad_launch(w, net.bf16 != 0, stream, peer);  // (peer: `grad` is the rank's exchange buffer, the launch signals the peers)
@@ -864,7 +864,7 @@ extern "C" int32_t mppo_gae(int32_t T, int32_t N, float gamma, float lam, const 
 extern "C" int32_t mppo_minibatch_path(const mppo_net_t* net, const mppo_batch_t* batch, int32_t* fused) {
   MPPO_TRY(check_net(net));
   MPPO_REQUIRE(batch && fused, "mppo_minibatch_path: null argument");
-  static const char* nofuse = getenv("MPPO_NO_FUSED");
+  static const char* nofuse = MPPO_EXPERIMENT_ENV("MPPO_NO_FUSED");
   *fused = (fused_supported(*net, *batch) && !(nofuse && nofuse[0] == '1')) ? 1 : 0;
   return MPPO_OK;
 }

@@ -340,7 +340,11 @@ int32_t wgrad_launch(const WgradArgs& a_in, bool bf16, hipStream_t stream, const
     return MPPO_OK;
   }
   const PeerStep nops{};
+#ifdef MPPO_EXPERIMENTS
   static const int dbg = [] { const char* e = getenv("MPPO_WGRAD_DBG"); return e ? atoi(e) : 0; }();
+#else
+  constexpr int dbg = 0;
+#endif
   a.dbg = dbg;
   MPPO_REQUIRE(wgrad_supported(a), "wgrad_launch: operands must be 16-byte aligned k-quad buffers, at most %d tiles", kSqSlots);
   if (bf16) hipLaunchKernelGGL((wgrad_kernel<true, false>), dim3(a.ntiles), dim3(WTHREADS), 0, stream, a, nops);

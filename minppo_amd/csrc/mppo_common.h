@@ -6,7 +6,18 @@
 #include <cstdint>
 #include <cstdio>
 
+#include <cstdlib>
+
 #include "../../include/minppo_hip.h"
+
+// Measurement switches (A/B experiments that skip work, add launches or change the launch structure) exist only in variant libraries built
+// with -DMPPO_EXPERIMENTS (tools/build_variant.sh); the product library does not read them - not even their names are in it
+// (tests/test_abi.py lists the environment variables the shipped library may read).
+#ifdef MPPO_EXPERIMENTS
+#define MPPO_EXPERIMENT_ENV(name) getenv(name)
+#else
+#define MPPO_EXPERIMENT_ENV(name) (static_cast<const char*>(nullptr))
+#endif
 
 namespace mppo {
 

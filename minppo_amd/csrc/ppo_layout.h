@@ -8,6 +8,7 @@
 #include <cstdlib>
 
 #include "../../include/minppo_hip.h"
+#include "mppo_common.h"
 
 namespace mppo {
 
@@ -85,7 +86,7 @@ inline FwdBufs carve_fwd(const mppo_net_t& net, int n, float* ws) {
 
 constexpr int kGradKSplitMax = 8;  // slabs reserved in the workspace
 inline int grad_ksplit() {  // K-slices of the weight-gradient product; MPPO_KSPLIT overrides for measurements
-  static const int v = [] { const char* e = getenv("MPPO_KSPLIT"); int k = e ? atoi(e) : 8; return k < 1 ? 1 : (k > kGradKSplitMax ? kGradKSplitMax : k); }();
+  static const int v = [] { const char* e = MPPO_EXPERIMENT_ENV("MPPO_KSPLIT"); int k = e ? atoi(e) : 8; return k < 1 ? 1 : (k > kGradKSplitMax ? kGradKSplitMax : k); }();
   return v;
 }
 
