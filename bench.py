@@ -248,7 +248,7 @@ def spawn_ranks(args: argparse.Namespace) -> int:
             env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(0 if share else r), WORLD_SIZE=str(args.gpus), LOCAL_WORLD_SIZE=str(args.gpus),
                        MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"),
                        MPPO_BENCH_WORKER="1", **extra_env)  # the children measure; this process is already their supervisor
-            procs.append(subprocess.Popen([sys.executable, str(Path(__file__).resolve()), *sys.argv[1:]], env=env,
+            procs.append(subprocess.Popen([sys.executable, os.environ.get("MPPO_BENCH_WORKER_SCRIPT", str(Path(__file__).resolve())), *sys.argv[1:]], env=env,
                                           stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, stderr=None))
         deadline = time.monotonic() + limit_s
         line, ok = b"", True

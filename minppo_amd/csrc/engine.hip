@@ -20,6 +20,7 @@
 #include "platform.h"
 #include "peer.h"
 
+#include <cmath>
 #include <cstdlib>
 #include <cstring>
 #include <string>
@@ -494,7 +495,8 @@ extern "C" int32_t mppo_engine_peer_export(mppo_engine_t* e, void* handle64) {
   MPPO_REQUIRE(e && handle64, "mppo_engine_peer_export: null argument");
   MPPO_REQUIRE(!e->peer, "mppo_engine_peer_export: already exported");
   MPPO_REQUIRE(e->cfg.world_size >= 2, "mppo_engine_peer_export: one rank has nobody to exchange with");
-  return peer_create(e->cfg.rank, e->cfg.world_size, (size_t)e->P, (size_t)e->E * e->M * 2, &e->peer, handle64);
+  const size_t adv = (size_t)e->E * e->M * 2;
+  return peer_create(e->cfg.rank, e->cfg.world_size, (size_t)e->P, adv < 4 ? 4 : adv, &e->peer, handle64);  // (the self-test sums four values)
 }
 
 extern "C" int32_t mppo_engine_peer_connect(mppo_engine_t* e, const void* handles, int32_t shared_device) {
@@ -503,30 +505,77 @@ extern "C" int32_t mppo_engine_peer_connect(mppo_engine_t* e, const void* handle
   return peer_connect(e->peer, handles, shared_device);
 }
 
-// One round trip through the mapped buffers before anything depends on them: every rank publishes (rank + 1) four times, waits for
-// the peers' values and adds them in rank order - the once-per-update all-reduce of the advantage sums, on a known input.  *ok = 0:
-// a wait ran into its time limit or a sum is wrong (the mapping was made but stores from / to a peer do not arrive).
+// Everything the gradient path depends on, once, on known inputs, before anything depends on it:
+//  1. the once-per-update all-reduce of the advantage sums: every rank publishes (rank + 1) four times, waits for the peers' values and
+//     adds them in rank order (scalar system-scope stores / loads, the adv_done flags);
+//  2. ONE full optimizer step's exchange in the form the engine will launch it (fused / split / shared): a known local gradient
+//     g_r[i] = (r + 1) c(i), c(i) a multiple of 1/256, goes into `pub` through the publish kernel (16-byte system-scope stores, the
+//     arrival counter, the wg_done flags), then clip_adam<PEER> on SCRATCH parameters and moments: phase A pulls this rank's slice of
+//     every rank's `pub`, reduces, pushes it into every rank's `red` with its sums of squares and raises red_done; phase B waits for
+//     all pieces and applies Adam.  Checked on every rank: red == c(i) G (G + 1) / 2 EXACTLY for all i, the sums of squares, and the
+//     scratch first moment (what phase B read).
+// *ok = 0: a wait ran into its time limit or a value is wrong (the mapping was made but stores from / to a peer do not arrive, or arrive
+// out of order): the caller drops the exchange on all ranks and continues on RCCL (Trainer.init_comm).
+static inline float selftest_pattern(size_t i) { return (float)((int)(((unsigned)i * 2654435761u) >> 24) - 128) / 256.f; }
+
 extern "C" int32_t mppo_engine_peer_selftest(mppo_engine_t* e, int32_t* ok) {
   MPPO_REQUIRE(e && ok && peer_connected(e->peer), "mppo_engine_peer_selftest: no connected exchange");
   MPPO_REQUIRE(!e->graph, "mppo_engine_peer_selftest: the update has been captured already");
   *ok = 0;
   const int G = e->cfg.world_size;
+  const size_t P = (size_t)e->P;
   double host[4], *dev = nullptr;
   for (double& x : host) x = (double)(e->cfg.rank + 1);
+  float* scratch = nullptr;  // g | p | m | v, [P] each
   MPPO_CHECK_HIP(hipMalloc(reinterpret_cast<void**>(&dev), sizeof(host)));
+  hipError_t he = hipMalloc(reinterpret_cast<void**>(&scratch), 4 * P * sizeof(float));
+  if (he != hipSuccess) { (void)hipFree(dev); return fail(MPPO_EHIP, "mppo_engine_peer_selftest: %s", hipGetErrorString(he)); }
+  std::vector<float> g(P), red(P + kSqSlots), m1(P);
+  for (size_t i = 0; i < P; ++i) g[i] = (float)(e->cfg.rank + 1) * selftest_pattern(i);
   int32_t rc = MPPO_OK, timed_out = 0;
-  hipError_t he = hipMemcpy(dev, host, sizeof(host), hipMemcpyHostToDevice);
+  he = hipMemcpy(dev, host, sizeof(host), hipMemcpyHostToDevice);
+  if (he == hipSuccess) he = hipMemcpy(scratch, g.data(), P * sizeof(float), hipMemcpyHostToDevice);
+  if (he == hipSuccess) he = hipMemset(scratch + P, 0, 3 * P * sizeof(float));
+  mppo_adam_cfg_t ac = e->cfg.adam;
+  ac.anneal = 0; ac.sched_div = 1; ac.num_updates = 1;
+  // a stream of this engine's own: several engines of one process (one per GPU, or ranks sharing a GPU in the tests) run their
+  // self-tests at the same time, and each one's kernels wait for the others' - on a stream they shared, the first wait would block them all
+  hipStream_t st = nullptr;
+  if (he == hipSuccess) he = hipStreamCreateWithFlags(&st, hipStreamNonBlocking);
   if (he == hipSuccess) {
-    rc = peer_allreduce_f64(e->peer, dev, 4, nullptr);
-    if (rc == MPPO_OK) rc = peer_advance(e->peer, 0, nullptr);
+    rc = peer_allreduce_f64(e->peer, dev, 4, st);
+    const PeerStep ps = peer_step(e->peer, 0);
+    if (rc == MPPO_OK) rc = peer_publish(e->peer, scratch, P, 0, st);
+    if (rc == MPPO_OK)
+      rc = clip_adam(P, scratch + P, scratch + 2 * P, scratch + 3 * P, peer_red(e->peer), e->count, 0, ac, const_cast<float*>(peer_red(e->peer)) + P, true, st, nullptr, &ps);
+    if (rc == MPPO_OK) rc = peer_advance(e->peer, 1, st);
     if (rc == MPPO_OK) rc = peer_status(e->peer, &timed_out, nullptr);  // synchronises
     if (rc == MPPO_OK) he = hipMemcpy(host, dev, sizeof(host), hipMemcpyDeviceToHost);
+    if (rc == MPPO_OK && he == hipSuccess) he = hipMemcpy(red.data(), peer_red(e->peer), (P + kSqSlots) * sizeof(float), hipMemcpyDeviceToHost);
+    if (rc == MPPO_OK && he == hipSuccess) he = hipMemcpy(m1.data(), scratch + 2 * P, P * sizeof(float), hipMemcpyDeviceToHost);
   }
+  if (st) { (void)hipStreamSynchronize(st); (void)hipStreamDestroy(st); }
   (void)hipFree(dev);
+  (void)hipFree(scratch);
   if (he != hipSuccess) return fail(MPPO_EHIP, "mppo_engine_peer_selftest: %s", hipGetErrorString(he));
   if (rc != MPPO_OK) return rc;
   bool good = !timed_out;
   for (double x : host) good = good && x == 0.5 * G * (G + 1);
+  const float tri = 0.5f * (float)G * (float)(G + 1);
+  double ss = 0.0, ss_dev = 0.0;
+  for (size_t i = 0; i < P && good; ++i) {
+    const float want = tri * selftest_pattern(i);  // (multiples of 1/256 below 2^24: every partial sum is exact in float32)
+    good = red[i] == want;
+    ss += (double)want * (double)want;
+  }
+  for (int k = 0; k < kSqSlots; ++k) ss_dev += (double)red[P + k];
+  good = good && fabs(ss_dev - ss) <= 1e-4 * ss + 1e-12;
+  // phase B: first moment of the scratch state = (1 - b1) * clip scale * reduced gradient
+  const double norm = sqrt(ss), scale = norm < (double)ac.max_grad_norm ? 1.0 : (double)ac.max_grad_norm / norm;
+  for (size_t i = 0; i < P && good; ++i) {
+    const double want = (1.0 - (double)ac.b1) * scale * (double)tri * (double)selftest_pattern(i);
+    good = fabs((double)m1[i] - want) <= 1e-4 * fabs(want) + 1e-12;
+  }
   *ok = good ? 1 : 0;
   return MPPO_OK;
 }

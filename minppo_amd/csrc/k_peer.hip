@@ -3,8 +3,11 @@
 // sums, the publish kernel for gradients that were not written by wgrad_kernel<.., PEER>, the epoch counter.
 #include "peer.h"
 
+#include <array>
 #include <cstdlib>
 #include <cstring>
+#include <map>
+#include <mutex>
 
 #include "mppo_common.h"
 
@@ -15,10 +18,18 @@ struct PeerComm {
   size_t P, adv_doubles, bytes;
   unsigned char* mine;
   void* mapped[kPeerMaxRanks];
+  bool local[kPeerMaxRanks];  // a peer engine of THIS process: its buffer is used through its own pointer, nothing to unmap
+  std::array<unsigned char, 64> handle;
   bool connected;
   int mode;  // PeerStep::mode
   PeerView view;
 };
+
+// Exchange buffers created in this process, by exported handle: hipIpcOpenMemHandle refuses a handle of the opening process, so several
+// engines in ONE process (one per GPU driven by a single host process, or - how eight ranks are run on a one-GPU box whose process limit is
+// six - two ranks per process) reach each other's buffers through the pointers themselves.
+static std::mutex g_reg_mu;
+static std::map<std::array<unsigned char, 64>, void*>& registry() { static std::map<std::array<unsigned char, 64>, void*> m; return m; }
 
 // The waits of the shared-GPU form as kernels of ONE wave: whatever else the GPU has to run for a peer rank finds room beside them.
 __global__ void __launch_bounds__(64) peer_wait_kernel(PeerView v, const int* epoch_base, int step, int kind) {
@@ -62,7 +73,7 @@ __global__ void __launch_bounds__(256) peer_publish_kernel(PeerView v, const flo
   const int nthr = gridDim.x * blockDim.x;
   for (int i4 = blockIdx.x * blockDim.x + threadIdx.x; i4 < v.P4; i4 += nthr)
     sys_store_f4(v.base[v.rank] + v.pub_off, (size_t)i4 * 16, *reinterpret_cast<const float4*>(grad + 4 * (size_t)i4));
-  peer_publish_done(v, epoch, gridDim.x);
+  peer_publish_all_done(v, epoch, (int)gridDim.x);
 }
 
 __global__ void peer_advance_kernel(PeerView v, int steps) {
@@ -74,7 +85,7 @@ static unsigned long long limit_ticks() {
 #ifdef MPPO_EMU
   const double ms = e ? atof(e) : 600000.0;  // emulated peers are slow
 #else
-  const double ms = e ? atof(e) : 5000.0;
+  const double ms = e ? atof(e) : 60000.0;  // host-side skew between ranks (a checkpoint on a slow disk, a paused process) must not end a run
 #endif
   return (unsigned long long)(ms * 1e5);
 }
@@ -112,6 +123,9 @@ int32_t peer_create(int rank, int world, size_t P, size_t adv_doubles, PeerComm*
   if (e != hipSuccess) { (void)hipFree(c->mine); delete c; return fail(MPPO_EHIP, "peer exchange: exporting the exchange buffer failed: %s (HSA_ENABLE_IPC_MODE_LEGACY=0 set?)", hipGetErrorString(e)); }
   c->mapped[rank] = c->mine;
   v.base[rank] = c->mine;
+  for (int q = 0; q < kPeerMaxRanks; ++q) c->local[q] = false;
+  memcpy(c->handle.data(), handle64, 64);
+  { std::lock_guard<std::mutex> lk(g_reg_mu); registry()[c->handle] = c->mine; }
   *out = c;
   return MPPO_OK;
 }
@@ -131,8 +145,28 @@ int32_t peer_connect(PeerComm* c, const void* handles, int shared_device) {
     void* p = nullptr;
     hipIpcMemHandle_t hq;
     memcpy(&hq, &h[q], sizeof(hq));
-    const hipError_t e = hipIpcOpenMemHandle(&p, hq, hipIpcMemLazyEnablePeerAccess);
-    if (e != hipSuccess) return fail(MPPO_EHIP, "peer exchange: mapping rank %d's exchange buffer failed: %s", q, hipGetErrorString(e));
+    {
+      std::array<unsigned char, 64> key;
+      memcpy(key.data(), &h[q], 64);
+      std::lock_guard<std::mutex> lk(g_reg_mu);
+      auto it = registry().find(key);
+      if (it != registry().end()) { p = it->second; c->local[q] = true; }
+    }
+    if (c->local[q]) {
+#ifndef MPPO_EMU
+      // an engine of this process on ANOTHER GPU: its memory is reached once peer access is on (same GPU: nothing to do)
+      hipPointerAttribute_t at;
+      int dev = -1;
+      if (hipPointerGetAttributes(&at, p) == hipSuccess && hipGetDevice(&dev) == hipSuccess && at.device != dev) {
+        const hipError_t pe = hipDeviceEnablePeerAccess(at.device, 0);
+        if (pe != hipSuccess && pe != hipErrorPeerAccessAlreadyEnabled) return fail(MPPO_EHIP, "peer exchange: peer access to GPU %d (rank %d, same process) failed: %s", at.device, q, hipGetErrorString(pe));
+        (void)hipGetLastError();
+      }
+#endif
+    } else {
+      const hipError_t e = hipIpcOpenMemHandle(&p, hq, hipIpcMemLazyEnablePeerAccess);
+      if (e != hipSuccess) return fail(MPPO_EHIP, "peer exchange: mapping rank %d's exchange buffer failed: %s", q, hipGetErrorString(e));
+    }
     c->mapped[q] = p;
     c->view.base[q] = static_cast<unsigned char*>(p);
   }
@@ -149,7 +183,8 @@ void peer_destroy(PeerComm* c) {
   if (!c) return;
   (void)hipDeviceSynchronize();
   for (int q = 0; q < c->world; ++q)
-    if (q != c->rank && c->mapped[q]) (void)hipIpcCloseMemHandle(c->mapped[q]);
+    if (q != c->rank && c->mapped[q] && !c->local[q]) (void)hipIpcCloseMemHandle(c->mapped[q]);
+  { std::lock_guard<std::mutex> lk(g_reg_mu); registry().erase(c->handle); }
   (void)hipFree(c->mine);
   delete c;
 }
@@ -186,8 +221,10 @@ int32_t peer_status(const PeerComm* c, int32_t* timed_out, int32_t* info8) {
   MPPO_CHECK_HIP(hipMemcpy(&h, c->mine, sizeof(h), hipMemcpyDeviceToHost));
   *timed_out = h.error;
   if (const char* dbg = getenv("MPPO_PEER_DEBUG"); dbg && dbg[0] == '1') {  // the whole header, for post-mortems of a wait that gave up
-    fprintf(stderr, "[peer rank %d] error %d info %d %d %d %d epoch %d %d arrive %d nA %d K %d\n  wg_done:", c->rank, h.error, h.error_info[0], h.error_info[1], h.error_info[2],
-            h.error_info[3], h.epoch[0], h.epoch[1], h.arrive, c->view.nA, c->view.K);
+    fprintf(stderr, "[peer rank %d] error %d info %d %d %d %d epoch %d %d nA %d K %d\n  arrive:", c->rank, h.error, h.error_info[0], h.error_info[1], h.error_info[2],
+            h.error_info[3], h.epoch[0], h.epoch[1], c->view.nA, c->view.K);
+    for (int q = 0; q <= kPeerMaxRanks; ++q) fprintf(stderr, " %d", h.arrive[q][0]);
+    fprintf(stderr, "\n  wg_done:");
     for (int q = 0; q < c->world; ++q) fprintf(stderr, " %d", h.wg_done[q][0]);
     fprintf(stderr, "\n  adv_done:");
     for (int q = 0; q < c->world; ++q) fprintf(stderr, " %d", h.adv_done[q][0]);
@@ -197,7 +234,8 @@ int32_t peer_status(const PeerComm* c, int32_t* timed_out, int32_t* info8) {
   }
   if (info8) {
     for (int k = 0; k < 4; ++k) info8[k] = h.error_info[k];
-    info8[4] = h.epoch[0]; info8[5] = h.epoch[1]; info8[6] = h.arrive; info8[7] = c->view.nA;
+    info8[4] = h.epoch[0]; info8[5] = h.epoch[1]; info8[6] = 0; info8[7] = c->view.nA;
+    for (int q = 0; q <= kPeerMaxRanks; ++q) info8[6] += h.arrive[q][0];  // workgroups counted into an unfinished slice (0 between launches)
   }
   return MPPO_OK;
 }

@@ -249,7 +249,7 @@ __global__ void __launch_bounds__(WTHREADS) wgrad_kernel(WgradArgs a, PeerStep p
     for (int k = 0; k < WWAVES; ++k) s += s_red[k];
     a.sq_partial[blockIdx.x] = s;
   }
-  if (PEER) peer_publish_done(ps.v, ps.epoch[0] + ps.step + 1, gridDim.x);  // every store of the gradient is above this line
+  if (PEER) peer_publish_done(ps.v, ps.epoch[0] + ps.step + 1, desc >> 24, a.slice_need);  // every store of the gradient is above this line
 }
 
 bool wgrad_supported(const WgradArgs& a) {
@@ -330,10 +330,52 @@ int32_t wgrad_plan(WgradArgs& a, int mb) {
   return MPPO_OK;
 }
 
+// Which slices of the flat gradient (slice q = float4 [q S4, (q + 1) S4), reduced by rank q: peer.h) does each workgroup store into?  Mirrors the
+// kernel's stores: the 32 x 32 tile, a thin band's rows and the bias sums (first row band's workgroups), tile 0's log_std gradient and
+// alignment words.  Result: the slice masks in bits 24..31 of order[], the number of workgroups per slice in slice_need[].
+static int32_t wgrad_peer_slices(WgradArgs& a, const PeerView& v) {
+  static_assert(kPeerMaxRanks == 8, "order[] keeps eight mask bits");
+  unsigned need[kPeerMaxRanks] = {0, 0, 0, 0, 0, 0, 0, 0};
+  const long S = 4L * v.S4;  // floats per slice
+  for (int w = 0; w < a.ntiles; ++w) {
+    const unsigned desc = a.order[w] & 0x00FFFFFFu;
+    const int pi = desc & 15, mt = (desc >> 4) & 255, nt = (desc >> 12) & 255;
+    const bool tile0 = (desc >> 20) & 1;
+    const WgradProb& p = a.p[pi];
+    const int m0 = mt * WTILE, n0 = nt * WTILE, nc = (p.N - n0 < WTILE ? p.N - n0 : WTILE);
+    unsigned mask = 0;
+    auto touch = [&](long first, long count) {  // floats [first, first + count) of the flat gradient
+      if (count <= 0) return;
+      for (long q = first / S; q <= (first + count - 1) / S; ++q) mask |= 1u << (q < v.world ? q : v.world - 1);
+    };
+    for (int r = m0; r < m0 + WTILE && r < p.M && (p.thin_rows == 0 || r < p.thin_row0); ++r) touch((long)p.off_w + (long)r * p.N + n0, nc);
+    if (mt == 0 && p.thin_rows > 0)
+      for (int rr = 0; rr < p.thin_rows; ++rr) touch((long)p.off_w + (long)(p.thin_row0 + rr) * p.N + n0, nc);
+    if (p.off_b >= 0 && mt == 0) touch((long)p.off_b + n0, nc);
+    if (tile0) {
+      touch(a.ls_off, a.A);
+      for (int k = 0; k < a.npad; ++k) touch(a.pad_off[k], a.pad_cnt[k]);
+    }
+    a.order[w] = desc | (mask << 24);
+    for (int q = 0; q < v.world; ++q) need[q] += (mask >> q) & 1u;
+  }
+  for (int q = 0; q < v.world; ++q) {
+    if (need[q] == 0) {  // (a slice nobody stores into - more ranks than float4 rows: its owner still waits for the flag) workgroup 0 speaks for it
+      a.order[0] |= 1u << (24 + q);
+      need[q] = 1;
+    }
+    MPPO_REQUIRE(need[q] <= 0xFFFFu, "wgrad_launch: %u workgroups store into slice %d", need[q], q);
+    a.slice_need[q] = (unsigned short)need[q];
+  }
+  return MPPO_OK;
+}
+
 int32_t wgrad_launch(const WgradArgs& a_in, bool bf16, hipStream_t stream, const PeerStep* peer) {
   WgradArgs a = a_in;
   if (peer) {
     MPPO_REQUIRE(!a.sq_partial, "wgrad_launch: with the peer exchange the sums of squares are those of the reduced gradient (sq_partial must be null)");
+    MPPO_REQUIRE(wgrad_supported(a), "wgrad_launch: operands must be 16-byte aligned k-quad buffers, at most %d tiles", kSqSlots);
+    MPPO_TRY(wgrad_peer_slices(a, peer->v));
     if (bf16) hipLaunchKernelGGL((wgrad_kernel<true, true>), dim3(a.ntiles), dim3(WTHREADS), 0, stream, a, *peer);
     else hipLaunchKernelGGL((wgrad_kernel<false, true>), dim3(a.ntiles), dim3(WTHREADS), 0, stream, a, *peer);
     MPPO_CHECK_LAUNCH("wgrad_kernel<peer>");

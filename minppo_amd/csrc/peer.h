@@ -4,8 +4,12 @@
 // HBM).  Replaces RCCL's all-reduce of the [P] gradient per optimizer step (the reference has no data parallelism at all:
 // minppo/train.py:136,140 vmap only) by a two-hop exchange fused into the kernels that stand on either side of it:
 //
-//   wgrad_kernel<.., PEER>   writes the rank's local gradient into `pub` of its own buffer with system-scope write-through stores; the
-//                            LAST workgroup to finish (local arrival counter) raises wg_done[rank] in every peer's buffer.
+//   wgrad_kernel<.., PEER>   writes the rank's local gradient into `pub` of its own buffer with system-scope write-through stores.  The
+//                            gradient is cut into G slices (slice q is reduced by rank q); every workgroup knows which slices its
+//                            stores fall into (host-side tile table, k_wgrad.hip) and counts itself into those slices' arrival counters;
+//                            the workgroup that completes SLICE q raises wg_done[rank] in the buffer of rank q - the only reader of that
+//                            slice - as soon as that slice is stored, not when the whole launch has ended (round 4: a fan-in of ~35
+//                            arrivals per counter on eight counters instead of 256 on one, and no slice waits for another's stragglers).
 //   adam_kernel<PEER>        phase A (the first nA workgroups): wait for every peer's wg_done, PULL slice `rank` of every rank's
 //                            `pub` (1/G of the gradient from each of G - 1 peers: all links busy, P/G floats per link), add the G
 //                            contributions in rank order, PUSH the reduced slice and its sum of squares into `red` of EVERY rank's
@@ -30,14 +34,18 @@ constexpr int kPeerMaxRanks = 8;
 constexpr int kPeerThreads = 256;  // threads of a workgroup that reduces a piece (= adam_kernel's)
 
 struct PeerHdr {
-  int wg_done[kPeerMaxRanks][16];   // [q][0]: epoch of rank q's last complete local gradient (one 64-byte line per writer)
+  int wg_done[kPeerMaxRanks][16];   // [q][0]: epoch at which slice `this rank` of rank q's local gradient was complete in q's `pub` (one 64-byte line per writer)
   int adv_done[kPeerMaxRanks][16];  // [q][0]: update epoch of rank q's published advantage sums
   int red_done[kSqSlots];           // [q * nA + b]: epoch of piece b of slice q in `red`
-  int arrive;                       // fan-in of this rank's weight-gradient workgroups (monotonic, wraps)
+  // fan-in counters of this rank's own gradient-writing launches, one line each: [q][0] (q < world) the workgroups that store into
+  // slice q, [kPeerMaxRanks][0] a launch whose workgroups all store everywhere (publish kernel).  The last arriver takes the counter
+  // back to 0: the next launch's workgroups arrive only after this launch has ended (stream order), nothing wraps, and the two kinds
+  // of launch may alternate.
+  int arrive[kPeerMaxRanks + 1][16];
   int error;                        // != 0: a wait ran into its time limit (the run is invalid)
   int epoch[2];                     // optimizer steps / updates completed since creation (peer_advance_kernel)
   int error_info[4];                // the first wait that timed out: kind (1 wg_done, 2 red_done, 3 adv_done), index, epoch waited for, value seen
-  int pad[56];
+  int pad[41];
 };
 static_assert(sizeof(PeerHdr) % 256 == 0, "the regions behind the header stay 256-byte aligned");
 
@@ -78,15 +86,36 @@ __device__ __forceinline__ void peer_wait(const int* flag, int epoch, PeerHdr* m
   }
 }
 
-// End of a launch that wrote this rank's local gradient into `pub` (system-scope stores): called by EVERY thread of EVERY workgroup
-// after its last store.  The last workgroup to arrive tells the peers.
-__device__ __forceinline__ void peer_publish_done(const PeerView& v, int epoch, unsigned nblocks) {
+// End of a workgroup that wrote part of this rank's local gradient into `pub` (system-scope stores): called by EVERY thread of EVERY
+// workgroup after its last store.  `mask`: the slices this workgroup's stores fall into, need[q]: how many workgroups of the launch
+// store into slice q (both from the host's tile table).  Whoever completes slice q tells rank q, the slice's only reader.
+__device__ __forceinline__ void peer_publish_done(const PeerView& v, int epoch, unsigned mask, const unsigned short* need) {
   drain_stores();
   __syncthreads();
   if (threadIdx.x == 0) {
     PeerHdr* me = peer_hdr(v, v.rank);
-    const unsigned old = (unsigned)agent_fetch_add(&me->arrive, 1);
-    if (old + 1u == (unsigned)epoch * nblocks) {
+    int old[kPeerMaxRanks];
+#pragma unroll
+    for (int q = 0; q < kPeerMaxRanks; ++q)  // (all the adds are requested before the first result is looked at)
+      if (q < v.world && ((mask >> q) & 1u)) old[q] = agent_fetch_add(&me->arrive[q][0], 1);
+#pragma unroll
+    for (int q = 0; q < kPeerMaxRanks; ++q)
+      if (q < v.world && ((mask >> q) & 1u) && old[q] + 1 == (int)need[q]) {
+        agent_fetch_add(&me->arrive[q][0], -(int)need[q]);
+        if (q != v.rank) sys_store_i32(&peer_hdr(v, q)->wg_done[v.rank][0], epoch);
+      }
+  }
+}
+
+// the same for a launch whose workgroups store all over the gradient (peer_publish_kernel): one counter, the last of the `nblocks`
+// workgroups tells every peer
+__device__ __forceinline__ void peer_publish_all_done(const PeerView& v, int epoch, int nblocks) {
+  drain_stores();
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    PeerHdr* me = peer_hdr(v, v.rank);
+    if (agent_fetch_add(&me->arrive[kPeerMaxRanks][0], 1) + 1 == nblocks) {
+      agent_fetch_add(&me->arrive[kPeerMaxRanks][0], -nblocks);
 #pragma unroll
       for (int q = 0; q < kPeerMaxRanks; ++q)
         if (q < v.world && q != v.rank) sys_store_i32(&peer_hdr(v, q)->wg_done[v.rank][0], epoch);

@@ -43,7 +43,10 @@ struct WgradArgs {
   // workgroup id -> its tile, resolved on the host (wgrad_plan): problem | row band << 4 | column band << 12 | (tile 0) << 20.  Tiles that
   // share operand bands sit on the same XCD.  (One scalar load; a tile NUMBER cost the kernel a search through p[].tile0 first:
   // up to `count` dependent scalar loads ahead of the first operand request.)
+  // Several ranks (peer.h): bits 24..31 = the gradient slices this workgroup's stores fall into; slice_need[q] = the number of workgroups
+  // that store into slice q (wgrad_launch fills both from the same tile table)
   unsigned order[kSqSlots];
+  unsigned short slice_need[8];
   int dbg;  // timing experiments only (MPPO_WGRAD_DBG bit mask): 4 launch twice (warm operands), 8 big problems only
 };
 

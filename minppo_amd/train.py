@@ -503,15 +503,48 @@ class Trainer:
         self.lib.engine_comm_mode(self._engine, C.byref(out))
         return {2: "fused", 3: "split", 4: "shared"}.get(out.value, "")
 
-    def check_peers(self) -> None:
+    def check_peers(self, collective: bool = True) -> None:
         """Synchronises the device and raises if a wait for a peer rank ran into its time limit (MPPO_PEER_TIMEOUT_MS): the kernels
-        then ran to their end on whatever was in the exchange buffers and the parameters are invalid."""
+        then ran to their end on whatever was in the exchange buffers and the parameters are invalid - on THIS rank and, because a
+        rank whose wait gave up still raises its own flags, on every rank that consumed its contribution.  So the check is a
+        collective (every rank must call it): the ranks take the maximum of their error words over `torch.distributed` and raise
+        together; none of them goes on to write a checkpoint of parameters that a peer's time-out has spoilt.  `collective=False`
+        looks at this rank's word only (drivers without a process group)."""
         out, info = C.c_int32(0), (C.c_int32 * 8)()
         self.lib.engine_peer_status(self._engine, C.byref(out), info)
+        worst, where = int(out.value), self.rank
+        if collective and self.world_size > 1 and self._dist_ready():
+            import torch
+            import torch.distributed as dist
+
+            t = torch.tensor([int(out.value), self.rank if out.value else -1], dtype=torch.int64)
+            if self.xp == "torch" and dist.get_backend() == "nccl":
+                t = t.to(self.device)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            worst, where = int(t[0].item()), int(t[1].item())
         if out.value:
             kind = {1: "the local gradient of rank", 2: "the reduced piece", 3: "the advantage sums of rank"}.get(info[0], "?")
             raise RuntimeError(f"rank {self.rank}: a wait for {kind} {info[1]} timed out (epoch {info[2]}, flag read {info[3]}; this rank: {info[4]} optimizer steps, "
-                               f"{info[5]} updates, {info[6]} arrivals, {info[7]} pieces per slice, {out.value} waits gave up); this run's results are invalid")
+                               f"{info[5]} updates, {info[6]} open arrivals, {info[7]} pieces per slice, {out.value} waits gave up); this run's results are invalid")
+        if worst:
+            raise RuntimeError(f"rank {self.rank}: a wait for a peer timed out on rank {where} ({worst} waits gave up there); the gradients it contributed "
+                               f"to are invalid on every rank, this run's results are invalid")
+
+    @staticmethod
+    def _dist_ready() -> bool:
+        try:
+            import torch.distributed as dist
+        except ImportError:
+            return False
+        return dist.is_available() and dist.is_initialized()
+
+    def barrier(self) -> None:
+        """Host-side meeting point of the ranks after rank-asymmetric host work (a checkpoint written to a slow disk): with the
+        peer-to-peer exchange a rank that enters the next update much later than its peers makes THEIR waits run into the time limit."""
+        if self.world_size > 1 and self._dist_ready():
+            import torch.distributed as dist
+
+            dist.barrier()
 
     # -- stepping ----------------------------------------------------------------
     def reset(self) -> None:
@@ -528,12 +561,18 @@ class Trainer:
 
     def prepare(self) -> None:
         """Several ranks, before the first update: capture the update (hipGraph) on every rank, then meet at a barrier, so that the
-        ranks enter their first gradient exchange together rather than a capture time apart (csrc/peer.h bounds every wait)."""
-        import torch.distributed as dist
-
+        ranks enter their first gradient exchange together rather than a capture time apart (csrc/peer.h bounds every wait).  A
+        driver that does not use `torch.distributed` (handles gathered some other way, `learn_host_driven`-style callers) gets the
+        capture only and is responsible for its own barrier between `prepare()` and the first `update()`."""
         self.lib.engine_prepare(self._engine, self._stream_ptr)
         self._sync()
-        dist.barrier()
+        if self._dist_ready():
+            import torch.distributed as dist
+
+            dist.barrier()
+        else:
+            logger.warning("Trainer.prepare: torch.distributed is not initialised - no barrier between the ranks' captures and their first update; "
+                           "the caller must provide one (the peer-to-peer exchange bounds every wait by MPPO_PEER_TIMEOUT_MS)")
         self._prepared = True
 
     def graph_active(self) -> bool:
@@ -680,8 +719,9 @@ def make_train(config: Config, **trainer_kwargs: Any) -> Callable[[Any], TrainOu
             tr.update()
             if ckpt and tc.checkpoint_every > 0 and (u + 1) % tc.checkpoint_every == 0 and u + 1 < n:
                 if peers:
-                    tr.check_peers()  # never checkpoint parameters that were updated with a timed-out exchange
+                    tr.check_peers()  # collective: never checkpoint parameters that ANY rank updated with a timed-out exchange
                 tr.save_checkpoint(ckpt)
+                tr.barrier()  # the ranks' files take different times to write: nobody starts the next exchange seconds ahead of a peer
             if log_every and ((u + 1) % log_every == 0 or u + 1 == n):
                 if peers:
                     tr.check_peers()  # (the statistics below synchronise anyway) a dead peer ends the job here, not as silent garbage
@@ -697,6 +737,7 @@ def make_train(config: Config, **trainer_kwargs: Any) -> Callable[[Any], TrainOu
             tr.check_peers()
         if ckpt:
             tr.save_checkpoint(ckpt)
+            tr.barrier()
         params = tr.params
         count = int(tr._to_host(tr.region("count"))[0]) if n else 0
         state = TrainState(step=count, params=params, opt_state={"mu": flat_to_tree(tr._to_host(tr.region("adam_m")), tr.O, tr.A, tr.H, tr.L),

@@ -30,6 +30,11 @@ def make_inputs(N, T, A, E, M, world, seed=0):
     return noise, local.astype(np.int32), glob.astype(np.int32)
 
 
+def _save(tr, be, out_path, T, Nl):
+    np.savez(out_path, params=tr.params_flat(), losses=tr.losses(), reward=be.host(tr.region("reward", (T, Nl))), graph=np.array(tr.graph_active()),
+             adam_m=be.host(tr.region("adam_m")), adam_v=be.host(tr.region("adam_v")))
+
+
 def run_rank(rank, world, port, overrides, updates, out_path):
     import torch
     import torch.distributed as dist
@@ -83,13 +88,108 @@ def run_rank(rank, world, port, overrides, updates, out_path):
             else:
                 tr.learn()  # mppo_engine_learn: csrc/engine.hip do_learn, peer-to-peer or communicator branch
     tr.check_peers()
-    graph = tr.graph_active()
-    np.savez(out_path, params=tr.params_flat(), losses=tr.losses(), reward=be.host(tr.region("reward", (T, Nl))), graph=np.array(graph))
+    _save(tr, be, out_path, T, Nl)
     dist.barrier()  # nobody unmaps an exchange buffer a peer might still read
     tr.close()
     dist.barrier()
     dist.destroy_process_group()
 
 
+def run_process_of_ranks(proc, nproc, per_proc, port, overrides, updates, out_paths):
+    """`per_proc` ranks in THIS process (ranks proc * per_proc ...), `nproc` such processes: how world = 8 runs on a one-GPU box that
+    allows six GPU processes (hardware only, shared-GPU form of the exchange).  Same library calls as Trainer.init_comm makes - export,
+    gather the handles, connect, barrier, self-test, agreement - with the ranks of a process reaching each other's exchange buffers
+    through the engine's same-process registry (csrc/k_peer.hip).  A rank's self-test blocks until its peers have run theirs, so the
+    ranks of a process run it from one thread each; updates are enqueued rank after rank (graph launches do not block) and awaited
+    together."""
+    import ctypes as C
+    import threading
+
+    import torch
+    import torch.distributed as dist
+
+    from backends import get_backend
+    from minppo_amd.config import make_config
+
+    world = nproc * per_proc
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=proc, world_size=nproc)
+    be = get_backend("hip")
+    cfg = make_config({"kscale_id": "5eb3cb7f23232298", "visualization": {"camera_name": "track"}}, overrides)
+    mine = [proc * per_proc + j for j in range(per_proc)]
+    soak = os.environ.get("MPPO_TEST_SOAK") == "1"  # many updates on the engine's own random streams (no inputs written from here)
+    trs = [be.trainer(cfg, rank=r, world_size=world, external_random=not soak, use_graph=True) for r in mine]
+    handles = np.zeros((per_proc, 64), np.uint8)
+    for j, tr in enumerate(trs):
+        tr.lib.engine_peer_export(tr._engine, handles[j].ctypes.data)
+    gathered = [torch.zeros(per_proc * 64, dtype=torch.uint8) for _ in range(nproc)]
+    dist.all_gather(gathered, torch.from_numpy(handles.reshape(-1)))
+    allh = np.concatenate([g.numpy() for g in gathered]).astype(np.uint8)  # rank order: process p holds ranks p * per_proc ...
+    for tr in trs:
+        tr.lib.engine_peer_connect(tr._engine, allh.ctypes.data, 1)  # every rank drives cuda:0
+    dist.barrier()
+    oks = [C.c_int32(0) for _ in trs]
+    errs = [None] * len(trs)
+
+    def selftest(j):
+        try:
+            trs[j].lib.engine_peer_selftest(trs[j]._engine, C.byref(oks[j]))
+        except Exception as exc:  # noqa: BLE001
+            errs[j] = exc
+
+    th = [threading.Thread(target=selftest, args=(j,)) for j in range(per_proc)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    good = torch.tensor([int(all(e is None for e in errs) and all(o.value == 1 for o in oks))], dtype=torch.int32)
+    dist.all_reduce(good, op=dist.ReduceOp.MIN)
+    assert int(good.item()) == 1, ("the self-test of the exchange failed on some rank", errs, [o.value for o in oks])
+    assert all(tr.comm_mode() == "peer" and tr.peer_form() == "shared" for tr in trs), [(tr.comm_mode(), tr.peer_form()) for tr in trs]
+    for tr in trs:
+        tr.reset()
+    N, Nl, T, A, E, M = cfg.training.num_envs, trs[0].N, trs[0].T, trs[0].A, trs[0].E, trs[0].M
+    for tr in trs:  # Trainer.prepare, with ONE barrier for the process
+        tr.lib.engine_prepare(tr._engine, tr._stream_ptr)
+        tr._sync()
+        tr._prepared = True
+    dist.barrier()
+    import time
+    t0 = time.perf_counter()
+    for u in range(updates):
+        if not soak:
+            noise, local, _ = make_inputs(N, T, A, E, M, world, seed=100 + u)
+            for tr, r in zip(trs, mine):
+                be.put(tr.region("noise", (T, Nl, A)), noise[:, r * Nl:(r + 1) * Nl])
+                be.put(tr.region("perm", (E, T * Nl)), local[r])
+        for tr in trs:
+            tr.update()
+        if not soak or (u + 1) % 8 == 0:  # (a soak keeps a few updates in flight)
+            for tr in trs:
+                tr._sync()
+    for tr in trs:
+        tr._sync()
+    dt = time.perf_counter() - t0
+    for tr in trs:
+        tr.check_peers(collective=False)
+    dist.barrier()
+    for tr, path in zip(trs, out_paths):
+        _save(tr, be, path, T, Nl)
+    if proc == 0:
+        print(f"[ranks-in-process] world {world} = {nproc} processes x {per_proc} ranks on cuda:0: {updates} updates in {dt:.2f} s "
+              f"({1e3 * dt / max(updates, 1):.2f} ms per update, {N * T * updates / dt:.0f} env-steps/s)", flush=True)
+    dist.barrier()
+    for tr in trs:
+        tr.close()
+    dist.barrier()
+    dist.destroy_process_group()
+
+
 if __name__ == "__main__":
-    run_rank(int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3]), sys.argv[6:], int(sys.argv[4]), sys.argv[5])
+    if sys.argv[1] == "procs":  # procs <proc> <nproc> <per_proc> <port> <updates> <out prefix> overrides...
+        proc, nproc, per_proc, port, updates = (int(x) for x in sys.argv[2:7])
+        prefix = sys.argv[7]
+        run_process_of_ranks(proc, nproc, per_proc, port, sys.argv[8:], updates, [f"{prefix}{proc * per_proc + j}.npz" for j in range(per_proc)])
+    else:
+        run_rank(int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3]), sys.argv[6:], int(sys.argv[4]), sys.argv[5])
