@@ -45,7 +45,7 @@ extern "C" {
 #define MPPO_ENCCL (-5)    /* an RCCL call failed                                         */
 #define MPPO_ENOMEM (-6)   /* caller-provided workspace too small                         */
 
-#define MPPO_ABI_VERSION 3
+#define MPPO_ABI_VERSION 4  /* 4: mppo_engine_peer_selftest runs on the caller's stream */
 
 const char* mppo_last_error(void);
 int32_t mppo_abi_version(void);
@@ -327,18 +327,20 @@ int32_t mppo_engine_comm_init(mppo_engine_t* e, const void* id128);
  *   mppo_engine_comm_mode    *out = 0 no exchange, 1 RCCL, 2 peer-to-peer (fused), 3 peer-to-peer in two launches, 4 peer-to-peer,
  *                            shared-GPU form
  *   mppo_engine_peer_status  synchronises the device; *timed_out != 0: a rank waited longer than MPPO_PEER_TIMEOUT_MS (default
- *                            5000) for a peer - the kernels ran to their end, the results are invalid.  info8 (optional, 8 words):
+ *                            60000) for a peer - the kernels ran to their end, the results are invalid.  info8 (optional, 8 words):
  *                            the first such wait {kind: 1 a peer's local gradient, 2 a reduced piece, 3 a peer's advantage sums;
  *                            index; epoch waited for; value seen}, then {optimizer steps, updates, local arrivals, pieces per slice}
- *   mppo_engine_peer_selftest  collective (every rank, after the barrier that follows connect): one all-reduce of a known vector
- *                            through the mapped buffers; *ok = 0 when a wait timed out or a sum is wrong on THIS rank.  The caller
+ *   mppo_engine_peer_selftest  collective (every rank, after the barrier that follows connect), on `stream`: one all-reduce of a
+ *                            known vector through the mapped buffers, then ONE full optimizer step's exchange on a known gradient and
+ *                            scratch parameters in the form the engine will launch it (publish, reduce + broadcast of this rank's
+ *                            slice, wait for the others, Adam); *ok = 0 when a wait timed out or a value is wrong on THIS rank.  The caller
  *                            agrees on the outcome across ranks and, if any rank failed, calls
  *   mppo_engine_peer_disable   on every rank (frees the exchange; mppo_engine_comm_init may follow) */
 int32_t mppo_engine_peer_export(mppo_engine_t* e, void* handle64);
 int32_t mppo_engine_peer_connect(mppo_engine_t* e, const void* handles, int32_t shared_device);
 int32_t mppo_engine_comm_mode(const mppo_engine_t* e, int32_t* out);
 int32_t mppo_engine_peer_status(const mppo_engine_t* e, int32_t* timed_out, int32_t* info8);
-int32_t mppo_engine_peer_selftest(mppo_engine_t* e, int32_t* ok);
+int32_t mppo_engine_peer_selftest(mppo_engine_t* e, void* stream, int32_t* ok);
 int32_t mppo_engine_peer_disable(mppo_engine_t* e);
 /* env reset (train.py:142-144) */
 int32_t mppo_engine_reset(mppo_engine_t* e, void* stream);

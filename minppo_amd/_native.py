@@ -83,7 +83,7 @@ class EngineCfg(C.Structure):
 
 
 P = C.POINTER
-ABI_VERSION = 3  # include/minppo_hip.h: MPPO_ABI_VERSION
+ABI_VERSION = 4  # include/minppo_hip.h: MPPO_ABI_VERSION
 
 # name -> (restype, argtypes); restype c_i32 functions are checked and raise NativeError
 SIGNATURES = {
@@ -135,7 +135,7 @@ SIGNATURES = {
     "mppo_engine_peer_connect": (c_i32, [c_vp, c_vp, c_i32]),
     "mppo_engine_comm_mode": (c_i32, [c_vp, P(c_i32)]),
     "mppo_engine_peer_status": (c_i32, [c_vp, P(c_i32), P(c_i32)]),
-    "mppo_engine_peer_selftest": (c_i32, [c_vp, P(c_i32)]),
+    "mppo_engine_peer_selftest": (c_i32, [c_vp, c_vp, P(c_i32)]),
     "mppo_engine_peer_disable": (c_i32, [c_vp]),
     "mppo_engine_reset": (c_i32, [c_vp, c_vp]),
     "mppo_engine_update": (c_i32, [c_vp, c_vp]),

@@ -518,7 +518,7 @@ extern "C" int32_t mppo_engine_peer_connect(mppo_engine_t* e, const void* handle
 // out of order): the caller drops the exchange on all ranks and continues on RCCL (Trainer.init_comm).
 static inline float selftest_pattern(size_t i) { return (float)((int)(((unsigned)i * 2654435761u) >> 24) - 128) / 256.f; }
 
-extern "C" int32_t mppo_engine_peer_selftest(mppo_engine_t* e, int32_t* ok) {
+extern "C" int32_t mppo_engine_peer_selftest(mppo_engine_t* e, void* stream, int32_t* ok) {
   MPPO_REQUIRE(e && ok && peer_connected(e->peer), "mppo_engine_peer_selftest: no connected exchange");
   MPPO_REQUIRE(!e->graph, "mppo_engine_peer_selftest: the update has been captured already");
   *ok = 0;
@@ -538,10 +538,11 @@ extern "C" int32_t mppo_engine_peer_selftest(mppo_engine_t* e, int32_t* ok) {
   if (he == hipSuccess) he = hipMemset(scratch + P, 0, 3 * P * sizeof(float));
   mppo_adam_cfg_t ac = e->cfg.adam;
   ac.anneal = 0; ac.sched_div = 1; ac.num_updates = 1;
-  // a stream of this engine's own: several engines of one process (one per GPU, or ranks sharing a GPU in the tests) run their
-  // self-tests at the same time, and each one's kernels wait for the others' - on a stream they shared, the first wait would block them all
-  hipStream_t st = nullptr;
-  if (he == hipSuccess) he = hipStreamCreateWithFlags(&st, hipStreamNonBlocking);
+  // on the CALLER's stream (the one its updates will run on): several engines of one process (one per GPU, or ranks sharing a GPU in the
+  // tests) run their self-tests at the same time and each one's kernels wait for the others' - streams they shared would block them all.
+  // (A stream created here costs more than it looks: measured on a GPU shared by two rank processes, one extra stream per process
+  // - even destroyed again - slowed every later update from 11.7 to 27.8 ms.)
+  hipStream_t st = static_cast<hipStream_t>(stream);
   if (he == hipSuccess) {
     rc = peer_allreduce_f64(e->peer, dev, 4, st);
     const PeerStep ps = peer_step(e->peer, 0);
@@ -554,7 +555,6 @@ extern "C" int32_t mppo_engine_peer_selftest(mppo_engine_t* e, int32_t* ok) {
     if (rc == MPPO_OK && he == hipSuccess) he = hipMemcpy(red.data(), peer_red(e->peer), (P + kSqSlots) * sizeof(float), hipMemcpyDeviceToHost);
     if (rc == MPPO_OK && he == hipSuccess) he = hipMemcpy(m1.data(), scratch + 2 * P, P * sizeof(float), hipMemcpyDeviceToHost);
   }
-  if (st) { (void)hipStreamSynchronize(st); (void)hipStreamDestroy(st); }
   (void)hipFree(dev);
   (void)hipFree(scratch);
   if (he != hipSuccess) return fail(MPPO_EHIP, "mppo_engine_peer_selftest: %s", hipGetErrorString(he));

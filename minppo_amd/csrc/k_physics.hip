@@ -20,6 +20,7 @@
 #include "mppo_common.h"
 #include <wave_ops.h>
 
+#include <type_traits>
 #include <utility>
 
 namespace mppo {
@@ -226,6 +227,9 @@ __device__ __forceinline__ LsPoint ls_make(float alpha, float q0, float q1, floa
   p.d1 = 2.f * q2 + (q2 == 0.f ? MJ_MINVAL : 0.f);
   return p;
 }
+// a dof's active joint-limit row as one int: +-(row + 1), the sign being the row's Jacobian entry (0: no active limit -> sign 0, row 0)
+__device__ __forceinline__ float lim_sign(int dl) { return dl > 0 ? 1.f : dl < 0 ? -1.f : 0.f; }
+__device__ __forceinline__ int lim_row(int dl) { return dl > 0 ? dl - 1 : dl < 0 ? -dl - 1 : 0; }
 __device__ __forceinline__ bool in_bracket(const LsPoint& x, const LsPoint& y) {
   // bitwise on purpose: four compares and three mask operations, no short-circuit branches (each would be a save / restore of exec)
   return (bool)((int)((x.d0 < y.d0) & (y.d0 < 0.f)) | (int)((x.d0 > y.d0) & (y.d0 > 0.f)));
@@ -286,9 +290,11 @@ template <class SD, int MODE>
 __global__ void __launch_bounds__(64 * kMaxWavesPerBlock) env_kernel(ModelView mv, EnvArgs a, PhysLds Prt) {
   constexpr BlobDims kSD = SD::dims();
   constexpr BlobOffsets kSO = blob_offsets(kSD);
-  constexpr PhysLds kSP = make_phys_lds(kSD.nq, kSD.nv, kSD.nu, kSD.nbody, kSD.njnt, kSD.ncon, kSD.nlimit + 4 * kSD.ncon, kSD.nroot, kSD.ncvx);
-  const PhysLds P = SD::kStatic ? kSP : Prt;
   constexpr bool kDims = SD::kStatic;
+  // fixed-size kernel, up to 32 dofs: a lane's rows / columns of the Cholesky factors live in registers (see factor_m below)
+  constexpr bool kRegChol = kDims && kSD.nv <= 2 * kGroupLanes;
+  constexpr PhysLds kSP = make_phys_lds(kSD.nq, kSD.nv, kSD.nu, kSD.nbody, kSD.njnt, kSD.ncon, kSD.nlimit + 4 * kSD.ncon, kSD.nroot, kSD.ncvx, kRegChol);
+  const PhysLds P = SD::kStatic ? kSP : Prt;
   constexpr int NV = kDims ? kSD.nv : 0;
   constexpr int kDotU = dot_unroll(NV);
   MPPO_DYN_SMEM(smem_raw);
@@ -320,16 +326,16 @@ __global__ void __launch_bounds__(64 * kMaxWavesPerBlock) env_kernel(ModelView m
   float* qpos = S + P.qpos; float* qvel = (float*)__builtin_assume_aligned(S + P.qvel, 16); float* ctrl = S + P.ctrl; float* warm = S + P.warm;
   float* xpos = S + P.xpos; float* xquat = S + P.xquat; float* xipos = S + P.xipos; float* rootcom = S + P.rootcom;  // (poses: region A1)
   float* cinert = S + P.cinert; float* cdof = S + P.cdof; float* cvel = S + P.cvel;
-  float* dsgn = S + P.dsgn; int* drow = reinterpret_cast<int*>(S + P.drow);
+  int* dlim = reinterpret_cast<int*>(S + P.dlim);
   float* M = (float*)__builtin_assume_aligned(S + P.M, 16); float* LL = (float*)__builtin_assume_aligned(S + P.LL, 16);
-  float* qfs = (float*)__builtin_assume_aligned(S + P.qfs, 16); float* qas = (float*)__builtin_assume_aligned(S + P.qas, 16); float* qact = (float*)__builtin_assume_aligned(S + P.qact, 16); float* qacc = (float*)__builtin_assume_aligned(S + P.qacc, 16); float* Ma = (float*)__builtin_assume_aligned(S + P.Ma, 16);
+  float* qfs = (float*)__builtin_assume_aligned(S + P.qfs, 16); float* qas = (float*)__builtin_assume_aligned(S + P.qas, 16); float* qacc = (float*)__builtin_assume_aligned(S + P.qacc, 16); float* Ma = (float*)__builtin_assume_aligned(S + P.Ma, 16);
   float* grad = (float*)__builtin_assume_aligned(S + P.grad, 16); float* Mgrad = (float*)__builtin_assume_aligned(S + P.Mgrad, 16); float* search = (float*)__builtin_assume_aligned(S + P.search, 16); float* mvv = (float*)__builtin_assume_aligned(S + P.mv, 16); float* qfc = (float*)__builtin_assume_aligned(S + P.qfc, 16);
   float* t0 = (float*)__builtin_assume_aligned(S + P.t0, 16); float* t1 = (float*)__builtin_assume_aligned(S + P.t1, 16);
   float* eD = S + P.D; float* earef = S + P.aref; float* jaref = S + P.jaref; float* jv = S + P.jv; float* force = S + P.force;
   float* conpos = S + P.conpos; float* condist = S + P.condist; float* confr = S + P.confr;
   const int npair = kDims ? kSD.npair : mv.npair, nplane = ncon - npair, ncvx = kDims ? kSD.ncvx : mv.ncvx;
   float* cvxsel = S + P.cvxsel; float* cvxok = S + P.cvxok;
-  float* ximat = S + P.ximat; float* xmat = S + P.xmat; float* xanchor = S + P.xanchor; float* xaxis = S + P.xaxis;
+  float* xanchor = S + P.xanchor; float* xaxis = S + P.xaxis;
   float* Cw = S + P.C; float* cdofdot = S + P.cdofdot; float* cfrc = S + P.cfrc; float* J = (float*)__builtin_assume_aligned(S + P.J, 16);
 
   const float* rec = a.state ? a.state + (size_t)env * mv.rec_dim : nullptr;
@@ -339,15 +345,12 @@ __global__ void __launch_bounds__(64 * kMaxWavesPerBlock) env_kernel(ModelView m
   if (MODE == 1) {
     FOR_G(i, nq) qpos[i] = rec[i];
     FOR_G(i, nv) { qvel[i] = rec[nq + i]; warm[i] = rec[OP + i]; }
-    FOR_G(i, nu) ctrl[i] = a.action[(size_t)env * a.act_ld + i];
   } else if (MODE == 0) {
     FOR_G(i, nq) qpos[i] = TF(qpos0)[i];
     FOR_G(i, nv) { qvel[i] = 0.f; warm[i] = 0.f; }
-    FOR_G(i, nu) ctrl[i] = 0.f;
   } else {
     FOR_G(i, nq) qpos[i] = a.p_qpos[(size_t)env * nq + i];
     FOR_G(i, nv) { qvel[i] = a.p_qvel[(size_t)env * nv + i]; warm[i] = a.p_warm[(size_t)env * nv + i]; }
-    FOR_G(i, nu) ctrl[i] = a.p_ctrl[(size_t)env * nu + i];
   }
   // pre-step quantities the reward needs (env.py:212-217, 222)
   float pre_p0 = 0.f, pre_z = 0.f, pre_comx = 0.f, time_in = 0.f;
@@ -378,6 +381,10 @@ __global__ void __launch_bounds__(64 * kMaxWavesPerBlock) env_kernel(ModelView m
   for (int frame = 0; frame < frames; ++frame) {
     PT(1);
     if (g == 0) { st3(xpos, {0.f, 0.f, 0.f}); st4(xquat, {1.f, 0.f, 0.f, 0.f}); }  // the world body (region A1 is rewritten by every frame)
+    // the controls: they share the storage of a solver vector (t1, first written in the CG loop), so every frame reads them again
+    if (MODE == 1) { FOR_G(i, nu) ctrl[i] = a.action[(size_t)env * a.act_ld + i]; }
+    else if (MODE == 0) { FOR_G(i, nu) ctrl[i] = 0.f; }
+    else { FOR_G(i, nu) ctrl[i] = a.p_ctrl[(size_t)env * nu + i]; }
     SYNC();  // the state loaded above (or integrated by the previous frame) is visible to every lane
     // ================= fwd_position: kinematics ================================================================
     // The tree is deep and narrow (a level holds one or two bodies of a humanoid), so the level-synchronous sweep runs on one
@@ -428,7 +435,8 @@ __global__ void __launch_bounds__(64 * kMaxWavesPerBlock) env_kernel(ModelView m
       }
       SYNC();
     }
-    // C: joint anchors / axes into the world frame (through the parent's pose), rotation matrices, inertial frames
+    // C: joint anchors / axes into the world frame (through the parent's pose), inertial frames' positions (the rotation matrices
+    // of bodies and inertial frames are formed from the quaternions where they are used: cinert and the free joint's cdof below)
     FOR_G(j, njnt) {
       const int p = TI(body_parent)[TI(jnt_bodyid)[j]];
       const Q4 pq = ld4(xquat + 4 * p);
@@ -438,9 +446,7 @@ __global__ void __launch_bounds__(64 * kMaxWavesPerBlock) env_kernel(ModelView m
     FOR_G(b, nb) {
       if (b > 0) {
         const Q4 quat = ld4(xquat + 4 * b);
-        qmat(quat, xmat + 9 * b);
         st3(xipos + 3 * b, add3(ld3(xpos + 3 * b), qrot(quat, ld3(TF(body_ipos) + 3 * b))));
-        qmat(qmul(quat, ld4(TF(body_iquat) + 4 * b)), ximat + 9 * b);
       }
     }
     SYNC();
@@ -551,7 +557,8 @@ __global__ void __launch_bounds__(64 * kMaxWavesPerBlock) env_kernel(ModelView m
         for (int r = 0; r < nroot; ++r) if (TI(root_body)[r] == TI(body_rootid)[b]) ri = r;
         const V3 off = sub3(ld3(xipos + 3 * b), ld3(rootcom + 3 * ri));
         const float m = TF(body_mass)[b];
-        const float* R = ximat + 9 * b;
+        float R[9];  // ximat
+        qmat(qmul(ld4(xquat + 4 * b), ld4(TF(body_iquat) + 4 * b)), R);
         const float d0 = TF(body_inertia)[3 * b], d1 = TF(body_inertia)[3 * b + 1], d2 = TF(body_inertia)[3 * b + 2];
         const float oo = dot3(off, off);
         ci[0] = R[0] * R[0] * d0 + R[1] * R[1] * d1 + R[2] * R[2] * d2 + m * (oo - off.x * off.x);
@@ -569,8 +576,9 @@ __global__ void __launch_bounds__(64 * kMaxWavesPerBlock) env_kernel(ModelView m
       for (int r = 0; r < nroot; ++r) if (TI(root_body)[r] == TI(body_rootid)[b]) ri = r;
       const V3 off = sub3(ld3(rootcom + 3 * ri), ld3(xanchor + 3 * j));
       if (jt == JNT_FREE) {
-        const float* R = xmat + 9 * b;
-        for (int k = 0; k < 3; ++k) {
+        float R[9];  // xmat
+        qmat(ld4(xquat + 4 * b), R);
+        _Pragma("unroll") for (int k = 0; k < 3; ++k) {
           float* c = cdof + 6 * (da + k);
           c[0] = c[1] = c[2] = 0.f;
           c[3] = k == 0 ? 1.f : 0.f; c[4] = k == 1 ? 1.f : 0.f; c[5] = k == 2 ? 1.f : 0.f;
@@ -616,81 +624,119 @@ __global__ void __launch_bounds__(64 * kMaxWavesPerBlock) env_kernel(ModelView m
     }
     SYNC();
     PT(5);
-    constexpr bool kRegChol = kDims && kSD.nv <= 2 * kGroupLanes;
-    // ---- factor_m: Cholesky of M and of M + h*diag(damping) (implicit joint damping, Euler), then the inverse factors ---------
-    if (kRegChol) {
-      // fixed-size kernel, up to 32 dofs: a lane's matrix rows (g and g + 16) in registers.  Same arithmetic, element by element, as
-      // the run-time-sized branch below (right-looking Cholesky that keeps L_kk^2 on the diagonal; inverse factors by forward
-      // substitution, a lane's columns g and g + 16), but the only LDS traffic is one column exchange per elimination step and the
-      // finished rows: 48 k -> 11 k cycles for nv = 16, 166 k -> see DESIGN.md for nv = 26.
-      constexpr int NVc = kRegChol ? kSD.nv : 1;
-      constexpr int R = (NVc + kGroupLanes - 1) / kGroupLanes;  // rows (and, in the inverse, columns) per lane
-      const int ldc = P.ldc;
-      int ir[R];       // this lane's rows; a surplus slot shadows the last row and never publishes
-      bool own[R];
-      _Pragma("unroll") for (int q = 0; q < R; ++q) { const int i = g + kGroupLanes * q; own[q] = i < NVc; ir[q] = own[q] ? i : NVc - 1; }
-      float* col = t0;  // the column being eliminated, all rows (t0 is free here)
-      // one matrix after the other through one work copy (not unrolled: both at once need more registers than a lane has, and
-      // what is spilled then is paid for in every later phase)
-      _Pragma("unroll 1") for (int m = 0; m < 2; ++m) {
-        float c[R][NVc];
-        _Pragma("unroll") for (int q = 0; q < R; ++q) {
-          const int i = ir[q];
-          const float hd = m ? h * TF(dof_damping)[i] : 0.f;
-          _Pragma("unroll") for (int k = 0; k < NVc; ++k) {
-            const float v = M[i * ldm + k];
-            c[q][k] = (m && k == i) ? v + hd : v;
-          }
-        }
-        static_for<NVc>([&](auto kc) {
-          constexpr int k = decltype(kc)::value;
-          _Pragma("unroll") for (int q = 0; q < R; ++q) if (own[q]) col[ir[q]] = c[q][k];
-          SYNC();
-          const float r = rsqrtf(fmaxf(col[k], MJ_MINVAL));
-          float l[NVc];  // the scaled column below the diagonal (rows k + 1 ..)
-          _Pragma("unroll") for (int j = k + 1; j < NVc; ++j) l[j] = col[j] * r;
-          SYNC();  // the column buffer is rewritten in the next step
-          _Pragma("unroll") for (int q = 0; q < R; ++q) {
-            if (kGroupLanes * (q + 1) - 1 > k) {  // (otherwise every row of this slot lies on or above the diagonal by now)
-              const bool below = ir[q] > k;
-              const float a = c[q][k] * r;
-              // entries right of the diagonal (j > i) are updated too: they are never read, and skipping them would cost a compare each
-              _Pragma("unroll") for (int j = k + 1; j < NVc; ++j) c[q][j] = below ? c[q][j] - a * l[j] : c[q][j];
-              c[q][k] = below ? a : c[q][k];
-            }
-          }
-          SCHED_FENCE();
-        });
-        // publish the rows (lower triangle + squared diagonal)
-        _Pragma("unroll") for (int q = 0; q < R; ++q) {
-          if (own[q]) { _Pragma("unroll") for (int k = 0; k < NVc; ++k) Cw[ir[q] * ldc + k] = c[q][k]; }
-        }
-        SYNC();
-        if (m == 0) PT(6);
-        // inverse factor by forward substitution, a lane's columns: x[k] = 0 above the column's diagonal
-        float x[R][NVc];
-        _Pragma("unroll") for (int i = 0; i < NVc; ++i) {
-          const float d = rsqrtf(fmaxf(Cw[i * ldc + i], MJ_MINVAL));
-          float s[R];
-          _Pragma("unroll") for (int q = 0; q < R; ++q) s[q] = 0.f;
-          _Pragma("unroll") for (int k = 0; k < i; ++k) {
-            const float cik = Cw[i * ldc + k];
-            _Pragma("unroll") for (int q = 0; q < R; ++q) if (kGroupLanes * q <= k) s[q] += cik * x[q][k];  // (x[q][k] = 0 for k < 16 q: skipped)
-          }
-          _Pragma("unroll") for (int q = 0; q < R; ++q) x[q][i] = i == ir[q] ? d : i > ir[q] ? -s[q] * d : 0.f;
-          if (R > 1) SCHED_FENCE();  // (two columns per lane: keep the rows' loads from piling up in registers ahead of their use)
-        }
-        _Pragma("unroll") for (int q = 0; q < R; ++q) {
-          if (own[q]) {
-            const int cq = ir[q];
-            _Pragma("unroll") for (int i = kGroupLanes * q; i < NVc; ++i) {
-              if (i >= cq) LL[m ? cq * ldm + i + 1 : i * ldm + cq] = x[q][i];  // Li[i][cq] / Le[i][cq] (transposed slot)
-            }
-          }
-        }
-        SYNC();  // the work copy is rewritten by the second matrix
+    // ---- factor_m: Cholesky of M (now) and of M + h*diag(damping) (implicit joint damping: at the END of the step, Euler), and the
+    // inverse factors.  The step is wrapped in a two-trip loop around ONE copy of the factorisation code: trip 0 factors M and runs
+    // the step's forward dynamics and solver, trip 1 factors M + h D and leaves the loop for the integrator.
+    // Fixed-size kernel, up to 32 dofs: a lane's matrix rows (g and g + 16) in registers - a right-looking Cholesky that keeps L_kk^2
+    // on the diagonal, one column exchange through LDS per elimination step, the inverse factor by forward substitution, a lane's
+    // columns g and g + 16 - and the inverse factor STAYS in registers: lane i holds row i (for L^-1 b) and column i (for L^-T t),
+    // the rows reaching their owners through the work copy, transposed.  No LL square in LDS, no LDS reads of the factor in the
+    // solver's triangular products (round 4; the arithmetic, element by element and term by term, is that of the run-time-sized
+    // branch: tests/test_kernels_physics.py::test_specialised_kernel_equals_the_runtime_sized_kernel).
+    constexpr int NVc = kRegChol ? kSD.nv : 1;
+    constexpr int RC = (NVc + kGroupLanes - 1) / kGroupLanes;  // rows (and, in the inverse, columns) per lane
+    float Lrow[RC][NVc], Lcol[RC][NVc];  // Linv[i][k] of this lane's rows i / Linv[k][c] of its columns c (entries outside the triangle: 0)
+    // Up to 16 dofs (one row per lane) the solver's two matrices live in registers as well: this lane's row of M, its rows of the
+    // contact Jacobian (row products J x) and its column (J^T f).  The CG iteration then reads only VECTORS from LDS - half the LDS
+    // instructions of an iteration, the same products term by term.
+    constexpr bool kSolverRegs = kRegChol && NVc <= kGroupLanes;
+    constexpr int NRC = kSolverRegs ? 4 * kSD.ncon : 1;                       // contact rows
+    constexpr int RJ = (NRC + kGroupLanes - 1) / kGroupLanes;                 // ... per lane
+    float Mrow[kSolverRegs ? NVc : 1], Jrow[RJ][kSolverRegs ? NVc : 1], Jcol[NRC];
+    int ir[RC];       // this lane's rows; a surplus slot shadows the last row and never publishes
+    bool own[RC];
+    _Pragma("unroll") for (int q = 0; q < RC; ++q) { const int i = g + kGroupLanes * q; own[q] = i < NVc; ir[q] = own[q] ? i : NVc - 1; }
+    if (kSolverRegs) { _Pragma("unroll") for (int k = 0; k < NVc; ++k) Mrow[k] = M[ir[0] * ldm + k]; }
+    // x = (L L^T)^-1 b with the factor in registers: the same two masked full-length products as solve_linv, the operand vector read
+    // once for all of a lane's rows
+    auto solve_regs = [&](const float* bvec, float* tmp, float* x) {
+      float br[NVc];
+      _Pragma("unroll") for (int k = 0; k < NVc; ++k) br[k] = bvec[k];
+      _Pragma("unroll") for (int q = 0; q < RC; ++q) {
+        float sacc = 0.f;
+        _Pragma("unroll") for (int k = 0; k < NVc; ++k) sacc += (k < kGroupLanes * (q + 1) ? Lrow[q][k] : 0.f) * br[k];
+        if (own[q]) tmp[ir[q]] = sacc;
       }
-    } else {
+      SYNC();
+      _Pragma("unroll") for (int k = 0; k < NVc; ++k) br[k] = tmp[k];
+      _Pragma("unroll") for (int q = 0; q < RC; ++q) {
+        float sacc = 0.f;
+        _Pragma("unroll") for (int k = 0; k < NVc; ++k) sacc += (k >= kGroupLanes * q ? Lcol[q][k] : 0.f) * br[k];
+        if (own[q]) x[ir[q]] = sacc;
+      }
+      SYNC();
+    };
+    auto solveL = [&](auto eul_c, const float* bvec, float* tmp, float* x) {
+      if constexpr (kRegChol) { (void)eul_c; solve_regs(bvec, tmp, x); }
+      else solve_linv<decltype(eul_c)::value, NV>(LL, ldm, nv, bvec, tmp, x, g);
+    };
+    _Pragma("unroll 1") for (int pass = 0; pass < 2; ++pass) {
+    if (kRegChol) {
+      const int ldc = P.ldc;
+      const bool eul = pass == 1;
+      float* col = t0;  // the column being eliminated, all rows (t0 is free here)
+      float c[RC][NVc];
+      _Pragma("unroll") for (int q = 0; q < RC; ++q) {
+        const int i = ir[q];
+        const float hd = eul ? h * TF(dof_damping)[i] : 0.f;
+        _Pragma("unroll") for (int k = 0; k < NVc; ++k) {
+          const float v = kSolverRegs ? Mrow[k] : M[i * ldm + k];
+          c[q][k] = (eul && k == i) ? v + hd : v;
+        }
+      }
+      static_for<NVc>([&](auto kc) {
+        constexpr int k = decltype(kc)::value;
+        _Pragma("unroll") for (int q = 0; q < RC; ++q) if (own[q]) col[ir[q]] = c[q][k];
+        SYNC();
+        const float r = rsqrtf(fmaxf(col[k], MJ_MINVAL));
+        float l[NVc];  // the scaled column below the diagonal (rows k + 1 ..)
+        _Pragma("unroll") for (int j = k + 1; j < NVc; ++j) l[j] = col[j] * r;
+        SYNC();  // the column buffer is rewritten in the next step
+        _Pragma("unroll") for (int q = 0; q < RC; ++q) {
+          if (kGroupLanes * (q + 1) - 1 > k) {  // (otherwise every row of this slot lies on or above the diagonal by now)
+            const bool below = ir[q] > k;
+            const float a = c[q][k] * r;
+            // entries right of the diagonal (j > i) are updated too: they are never read, and skipping them would cost a compare each
+            _Pragma("unroll") for (int j = k + 1; j < NVc; ++j) c[q][j] = below ? c[q][j] - a * l[j] : c[q][j];
+            c[q][k] = below ? a : c[q][k];
+          }
+        }
+        SCHED_FENCE();
+      });
+      // publish the rows (lower triangle + squared diagonal)
+      _Pragma("unroll") for (int q = 0; q < RC; ++q) {
+        if (own[q]) { _Pragma("unroll") for (int k = 0; k < NVc; ++k) Cw[ir[q] * ldc + k] = c[q][k]; }
+      }
+      SYNC();
+      if (pass == 0) PT(6);
+      // inverse factor by forward substitution, a lane's columns: x[k] = 0 above the column's diagonal
+      float x[RC][NVc];
+      _Pragma("unroll") for (int i = 0; i < NVc; ++i) {
+        const float d = rsqrtf(fmaxf(Cw[i * ldc + i], MJ_MINVAL));
+        float sq_[RC];
+        _Pragma("unroll") for (int q = 0; q < RC; ++q) sq_[q] = 0.f;
+        _Pragma("unroll") for (int k = 0; k < i; ++k) {
+          const float cik = Cw[i * ldc + k];
+          _Pragma("unroll") for (int q = 0; q < RC; ++q) if (kGroupLanes * q <= k) sq_[q] += cik * x[q][k];  // (x[q][k] = 0 for k < 16 q: skipped)
+        }
+        _Pragma("unroll") for (int q = 0; q < RC; ++q) x[q][i] = i == ir[q] ? d : i > ir[q] ? -sq_[q] * d : 0.f;
+        if (RC > 1) SCHED_FENCE();  // (two columns per lane: keep the rows' loads from piling up in registers ahead of their use)
+      }
+      // the columns stay with their lanes; the rows reach theirs through the work copy (all of its readers are done), transposed:
+      // T[i][c] = Linv[i][c], zeros above the diagonal included
+      SYNC();
+      _Pragma("unroll") for (int q = 0; q < RC; ++q) {
+        if (own[q]) { _Pragma("unroll") for (int i = 0; i < NVc; ++i) Cw[i * ldm + ir[q]] = x[q][i]; }
+      }
+      SYNC();
+      _Pragma("unroll") for (int q = 0; q < RC; ++q) {
+        _Pragma("unroll") for (int k = 0; k < NVc; ++k) {
+          if (k < kGroupLanes * (q + 1)) Lrow[q][k] = Cw[ir[q] * ldm + k];
+          if (k >= kGroupLanes * q) Lcol[q][k] = x[q][k];
+        }
+      }
+      SYNC();  // the work copy's storage goes to the velocity / RNE scratch (trip 0)
+    } else if (pass == 0) {
       // run-time-sized kernel / more than 16 dofs: both matrices in the same column sweep (a column costs two synchronisation
       // points, whichever the number of matrices), work copies stored as lower triangles (row i at i (i + 1) / 2) - the two
       // squares would be the largest thing in region A.  The diagonal keeps L_kk^2 (never overwritten).
@@ -742,6 +788,7 @@ __global__ void __launch_bounds__(64 * kMaxWavesPerBlock) env_kernel(ModelView m
       }
     }
     SYNC();
+    if (pass == 1) break;  // M + h D is factored: on to the integrator
     PT(7);
     // ================= fwd_velocity: com_vel, passive, rne (closed forms over ancestor masks) =======
     FOR_G(b, nb) {
@@ -824,11 +871,17 @@ __global__ void __launch_bounds__(64 * kMaxWavesPerBlock) env_kernel(ModelView m
           act += fo * gear;
         }
       }
-      qact[d] = act;
       qfs[d] = passive - bias + act;
+      // qfrc_actuator is part of the new record / observation (env.py:252) and of the NaN guard, not of the solver: it leaves here
+      badi |= (int)isnan(act);
+      if (MODE != 2 && frame == frames - 1 && valid) {
+        recw[o_qa + d] = act;
+        if (MODE == 0) { if (env == 0 && a.reset_out) a.reset_out[o_qa + d] = act; if (a.obs) a.obs[(size_t)env * a.obs_ld + o_qa + d] = act; }
+      }
       if (MODE == 2) {
         if (valid && a.probe.qfrc_bias) a.probe.qfrc_bias[(size_t)env * nv + d] = bias;
         if (valid && a.probe.qfrc_passive) a.probe.qfrc_passive[(size_t)env * nv + d] = passive;
+        if (valid && a.probe.qfrc_actuator) a.probe.qfrc_actuator[(size_t)env * nv + d] = act;
       }
     }
     // cinert and cvel have done their work in the dynamics (RNE above was the last reader); what remains is their place in the
@@ -853,7 +906,7 @@ __global__ void __launch_bounds__(64 * kMaxWavesPerBlock) env_kernel(ModelView m
     }
     SYNC();  // cfrc / cdofdot / cvel (region A3) and cinert are dead from here: the Jacobian (A4) may overwrite them
     PT(9);
-    solve_linv<false, NV>(LL, ldm, nv, qfs, t0, qas, g);  // fwd_acceleration: qacc_smooth = M^-1 qfrc_smooth
+    solveL(std::false_type{}, qfs, t0, qas);  // fwd_acceleration: qacc_smooth = M^-1 qfrc_smooth
     PT(10);
     // ================= make_constraint ===================================================================
     // Rows: nlim joint limits, then four pyramid rows per contact slot.  A limit row has ONE non-zero entry (+-1 at the joint's
@@ -861,7 +914,7 @@ __global__ void __launch_bounds__(64 * kMaxWavesPerBlock) env_kernel(ModelView m
     // a dense [4 ncon][nv] matrix in LDS.  Products with the limit rows are written out where they occur; they equal what the
     // dense row gave bit for bit (the other terms of that row's sum were exact zeros).
     FOR_G(r, 4 * ncon) for (int k = 0; k < nv; ++k) J[r * ldj + k] = 0.f;
-    FOR_G(i, nv) { dsgn[i] = 0.f; drow[i] = 0; }
+    FOR_G(i, nv) dlim[i] = 0;
     SYNC();
     FOR_G(r, nlim) {  // joint limits: one row each
       const int jid = TI(lim_jntid)[r];
@@ -869,7 +922,7 @@ __global__ void __launch_bounds__(64 * kMaxWavesPerBlock) env_kernel(ModelView m
       const float dlo = qpos[qa] - TF(jnt_range)[2 * jid], dhi = TF(jnt_range)[2 * jid + 1] - qpos[qa];
       const float pos = fminf(dlo, dhi);
       const bool act = pos < 0.f;
-      if (act) { dsgn[da] = dlo < dhi ? 1.f : -1.f; drow[da] = r; }
+      if (act) dlim[da] = dlo < dhi ? r + 1 : -(r + 1);
       jv[r] = act ? pos : 0.f;               // pos, parked in jv until the row parameters are built
       jaref[r] = act ? TF(dof_invweight0)[da] : 0.f;  // invweight, parked in jaref
     }
@@ -920,14 +973,15 @@ __global__ void __launch_bounds__(64 * kMaxWavesPerBlock) env_kernel(ModelView m
     kb_params(TF(contact_solref), TF(contact_solimp), h, k_con, b_con);
     // row r of the constraint Jacobian times an nv-vector / column i times an nefc-vector
     auto jrow_dot = [&](int r, const float* x) {
-      if (r < nlim) { const int da = TI(jnt_dofadr)[TI(lim_jntid)[r]]; return dsgn[da] * x[da]; }
+      if (r < nlim) { const int da = TI(jnt_dofadr)[TI(lim_jntid)[r]]; return lim_sign(dlim[da]) * x[da]; }
       const float* jr = J + (r - nlim) * ldj;
       float s = 0.f;
       DOT_UNROLL for (int k = 0; k < nv; ++k) s += jr[k] * x[k];
       return s;
     };
     auto jcol_dot = [&](int i, const float* f) {
-      float s = nlim > 0 ? dsgn[i] * f[drow[i]] : 0.f;
+      float s = 0.f;
+      if (nlim > 0) { const int dl = dlim[i]; s = lim_sign(dl) * f[lim_row(dl)]; }
       const int nc4 = 4 * ncon;
       DOT_UNROLL for (int r = 0; r < nc4; ++r) s += J[r * ldj + i] * f[nlim + r];
       return s;
@@ -937,16 +991,54 @@ __global__ void __launch_bounds__(64 * kMaxWavesPerBlock) env_kernel(ModelView m
       DOT_UNROLL for (int k = 0; k < nv; ++k) s += M[i * ldm + k] * x[k];
       return s;
     };
-    FOR_G(r, nefc) {
+    if (kSolverRegs) {  // the finished Jacobian into registers: rows for J x, this dof's column for J^T f
+      _Pragma("unroll") for (int j = 0; j < RJ; ++j) {
+        const int rc = g + kGroupLanes * j, rr = rc < NRC ? rc : NRC - 1;
+        _Pragma("unroll") for (int k = 0; k < NVc; ++k) Jrow[j][k] = J[rr * ldj + k];
+      }
+      _Pragma("unroll") for (int r = 0; r < NRC; ++r) Jcol[r] = J[r * ldj + ir[0]];
+    }
+    // contact rows times an nv-vector held in registers (one read of the vector for all of a lane's rows; the run-time-sized and the
+    // larger kernels go through jrow_dot); sink(rc, value) for every contact row rc of this lane
+    auto jrows_regs = [&](const float (&xr)[NVc], auto&& sink) {
+      _Pragma("unroll") for (int j = 0; j < RJ; ++j) {
+        const int rc = g + kGroupLanes * j;
+        float sacc = 0.f;
+        _Pragma("unroll") for (int k = 0; k < NVc; ++k) sacc += Jrow[j][kSolverRegs ? k : 0] * xr[k];
+        if (rc < NRC) sink(rc, sacc);
+      }
+    };
+    auto mrow_regs = [&](const float (&xr)[NVc], float* out) {
+      float sacc = 0.f;
+      _Pragma("unroll") for (int k = 0; k < NVc; ++k) sacc += Mrow[kSolverRegs ? k : 0] * xr[k];
+      if (own[0]) out[ir[0]] = sacc;
+    };
+    // column i of the Jacobian times an nefc-vector, limit row first (jcol_dot's order); i = this lane's dof
+    auto jcol_regs = [&](const float* f) {
+      float fr[NRC];
+      _Pragma("unroll") for (int r = 0; r < NRC; ++r) fr[r] = f[nlim + r];
+      float sacc = 0.f;
+      if (nlim > 0) { const int dl = dlim[ir[0]]; sacc = lim_sign(dl) * f[lim_row(dl)]; }
+      _Pragma("unroll") for (int r = 0; r < NRC; ++r) sacc += Jcol[r] * fr[r];
+      return sacc;
+    };
+    auto row_params = [&](int r, float s) {
       const float pos = jv[r], iw = jaref[r];
       const bool act = iw > 0.f;  // inactive rows are inert: J = 0, aref = 0, D = 0
       const bool lim = r < nlim;
       const float k = lim ? k_lim : k_con, b = lim ? b_lim : b_con;
       const float imp = impedance(lim ? TF(limit_solimp) : TF(contact_solimp), pos);
-      const float s = jrow_dot(r, qvel);
       const float R = fmaxf(iw * (1.f - imp) / imp, MJ_MINVAL);
       eD[r] = act ? 1.f / R : 0.f;
       earef[r] = act ? -b * s - k * imp * pos : 0.f;
+    };
+    if constexpr (kSolverRegs) {
+      float xr[NVc];
+      _Pragma("unroll") for (int k = 0; k < NVc; ++k) xr[k] = qvel[k];
+      FOR_G(r, nlim) row_params(r, jrow_dot(r, qvel));
+      jrows_regs(xr, [&](int rc, float sv) { row_params(nlim + rc, sv); });
+    } else {
+      FOR_G(r, nefc) row_params(r, jrow_dot(r, qvel));
     }
     SYNC();
     PT(11);
@@ -963,10 +1055,18 @@ __global__ void __launch_bounds__(64 * kMaxWavesPerBlock) env_kernel(ModelView m
         if (take) FOR_G(i, nv) qacc[i] = src[i];
         SYNC();
         if (take) {
-          FOR_G(i, nv) Ma[i] = mrow_dot(i, qacc);
-          // (limit rows and contact rows in loops of their own: 16 lanes on 16 dense rows at a time, not on a mixture)
-          FOR_G(r, nlim) jaref[r] = jrow_dot(r, qacc) - earef[r];
-          FOR_G(rc, 4 * ncon) jaref[nlim + rc] = jrow_dot(nlim + rc, qacc) - earef[nlim + rc];
+          if constexpr (kSolverRegs) {
+            float xr[NVc];
+            _Pragma("unroll") for (int k = 0; k < NVc; ++k) xr[k] = qacc[k];
+            mrow_regs(xr, Ma);
+            FOR_G(r, nlim) jaref[r] = jrow_dot(r, qacc) - earef[r];
+            jrows_regs(xr, [&](int rc, float sv) { jaref[nlim + rc] = sv - earef[nlim + rc]; });
+          } else {
+            FOR_G(i, nv) Ma[i] = mrow_dot(i, qacc);
+            // (limit rows and contact rows in loops of their own: 16 lanes on 16 dense rows at a time, not on a mixture)
+            FOR_G(r, nlim) jaref[r] = jrow_dot(r, qacc) - earef[r];
+            FOR_G(rc, 4 * ncon) jaref[nlim + rc] = jrow_dot(nlim + rc, qacc) - earef[nlim + rc];
+          }
         }
         SYNC();
         float gs = 0.f, cs = 0.f;
@@ -1004,9 +1104,10 @@ __global__ void __launch_bounds__(64 * kMaxWavesPerBlock) env_kernel(ModelView m
       // update_constraint + update_gradient at the starting point
       FOR_G(r, nefc) { const float x = jaref[r]; force[r] = x < 0.f ? -eD[r] * x : 0.f; }
       SYNC();
-      FOR_G(i, nv) { const float s = jcol_dot(i, force); qfc[i] = s; grad[i] = Ma[i] - qfs[i] - s; }
+      if constexpr (kSolverRegs) { const float s = jcol_regs(force); if (own[0]) { const int i = ir[0]; qfc[i] = s; grad[i] = Ma[i] - qfs[i] - s; } }
+      else FOR_G(i, nv) { const float s = jcol_dot(i, force); qfc[i] = s; grad[i] = Ma[i] - qfs[i] - s; }
       SYNC();
-      solve_linv<false, NV>(LL, ldm, nv, grad, t0, Mgrad, g);
+      solveL(std::false_type{}, grad, t0, Mgrad);
       FOR_G(i, nv) search[i] = -Mgrad[i];
       SYNC();
       PT(12);
@@ -1020,9 +1121,17 @@ __global__ void __launch_bounds__(64 * kMaxWavesPerBlock) env_kernel(ModelView m
         PT(13 + (it < 6 ? it : 6));
         // ---------------- line search ----------------
         float sn = 0.f, sMa = 0.f, sq = 0.f;
-        FOR_G(i, nv) mvv[i] = mrow_dot(i, search);
-        FOR_G(r, nlim) jv[r] = jrow_dot(r, search);
-        FOR_G(rc, 4 * ncon) jv[nlim + rc] = jrow_dot(nlim + rc, search);
+        if constexpr (kSolverRegs) {
+          float xr[NVc];
+          _Pragma("unroll") for (int k = 0; k < NVc; ++k) xr[k] = search[k];
+          mrow_regs(xr, mvv);
+          FOR_G(r, nlim) jv[r] = jrow_dot(r, search);
+          jrows_regs(xr, [&](int rc, float sv) { jv[nlim + rc] = sv; });
+        } else {
+          FOR_G(i, nv) mvv[i] = mrow_dot(i, search);
+          FOR_G(r, nlim) jv[r] = jrow_dot(r, search);
+          FOR_G(rc, 4 * ncon) jv[nlim + rc] = jrow_dot(nlim + rc, search);
+        }
         FOR_G(i, nv) { sn += search[i] * search[i]; sMa += search[i] * Ma[i]; sq += search[i] * qfs[i]; }
         SYNC();
         if (it == 0) PT(24);
@@ -1132,13 +1241,18 @@ __global__ void __launch_bounds__(64 * kMaxWavesPerBlock) env_kernel(ModelView m
         cs = 0.5f * group16_sum(cs) + gs;
         pgm = group16_sum(pgm);
         if (run) { prev_cost = cost; cost = cs; gauss = gs; }
-        FOR_G(i, nv) {
-          const float s = jcol_dot(i, force);
-          if (run) { qfc[i] = s; grad[i] = Ma[i] - qfs[i] - s; }
+        if constexpr (kSolverRegs) {
+          const float s = jcol_regs(force);
+          if (run && own[0]) { const int i = ir[0]; qfc[i] = s; grad[i] = Ma[i] - qfs[i] - s; }
+        } else {
+          FOR_G(i, nv) {
+            const float s = jcol_dot(i, force);
+            if (run) { qfc[i] = s; grad[i] = Ma[i] - qfs[i] - s; }
+          }
         }
         SYNC();
         if (it == 0) PT(29);
-        solve_linv<false, NV>(LL, ldm, nv, grad, t0, mvv, g);  // candidate Mgrad (mvv is free again)
+        solveL(std::false_type{}, grad, t0, mvv);  // candidate Mgrad (mvv is free again)
         float num = 0.f;
         FOR_G(i, nv) num += grad[i] * (mvv[i] - t1[i]);
         num = group16_sum(num);
@@ -1156,11 +1270,10 @@ __global__ void __launch_bounds__(64 * kMaxWavesPerBlock) env_kernel(ModelView m
     if (MODE == 2 && valid) {
       const mppo_forward_probe_t& pr = a.probe;
       if (pr.qM) FOR_G(i, nv) for (int k = 0; k < nv; ++k) pr.qM[((size_t)env * nv + i) * nv + k] = M[i * ldm + k];
-      if (pr.qfrc_actuator) FOR_G(i, nv) pr.qfrc_actuator[(size_t)env * nv + i] = qact[i];
       if (pr.qacc_smooth) FOR_G(i, nv) pr.qacc_smooth[(size_t)env * nv + i] = qas[i];
       if (pr.qacc) FOR_G(i, nv) pr.qacc[(size_t)env * nv + i] = qacc[i];
       if (pr.efc_J) FOR_G(r, nefc) for (int k = 0; k < nv; ++k)
-        pr.efc_J[((size_t)env * nefc + r) * nv + k] = r >= nlim ? J[(r - nlim) * ldj + k] : (k == TI(jnt_dofadr)[TI(lim_jntid)[r]] ? dsgn[k] : 0.f);
+        pr.efc_J[((size_t)env * nefc + r) * nv + k] = r >= nlim ? J[(r - nlim) * ldj + k] : (k == TI(jnt_dofadr)[TI(lim_jntid)[r]] ? lim_sign(dlim[k]) : 0.f);
       if (pr.efc_D) FOR_G(r, nefc) pr.efc_D[(size_t)env * nefc + r] = eD[r];
       if (pr.efc_aref) FOR_G(r, nefc) pr.efc_aref[(size_t)env * nefc + r] = earef[r];
       if (pr.subtree_com1 && g == 0) pr.subtree_com1[env] = new_comx;
@@ -1171,7 +1284,9 @@ __global__ void __launch_bounds__(64 * kMaxWavesPerBlock) env_kernel(ModelView m
     // ================= euler: implicit damping, semi-implicit integration ====================================
     FOR_G(i, nv) t1[i] = qfs[i] + qfc[i];
     SYNC();
-    solve_linv<true, NV>(LL, ldm, nv, t1, t0, mvv, g);  // mvv = (M + h D)^-1 (qfrc_smooth + qfrc_constraint)
+    }  // (factorisation trips)
+    if (MODE == 0) break;
+    solveL(std::true_type{}, t1, t0, mvv);  // mvv = (M + h D)^-1 (qfrc_smooth + qfrc_constraint)
     if (MODE == 2) {
       if (valid && a.probe.qacc_euler) FOR_G(i, nv) a.probe.qacc_euler[(size_t)env * nv + i] = mvv[i];
       break;
@@ -1201,13 +1316,12 @@ __global__ void __launch_bounds__(64 * kMaxWavesPerBlock) env_kernel(ModelView m
   // pass, i.e. they belong to the pre-integration pose: exactly what the MJX data carries.
   if (MODE == 0) {
     // reset: record = [qpos0, 0, cinert[1:], cvel[1:], qfrc_actuator | pad | qacc_warmstart = qacc | com_x | time = 0]
-    // (cinert / cvel were written when RNE had read them)
+    // (cinert / cvel were written when RNE had read them, qfrc_actuator when it was computed)
     FOR_G(i, mv.rec_dim) {
-      if (i >= o_ci && i < o_qa) continue;
+      if (i >= o_ci && i < O) continue;  // (cinert, cvel, qfrc_actuator: in place)
       float v = 0.f;
       if (i < nq) v = qpos[i];
       else if (i < o_ci) v = 0.f;
-      else if (i < O) v = qact[i - o_qa];
       else if (i < OP) v = 0.f;
       else if (i < OP + nv) v = qacc[i - OP];
       else if (i == OP + nv) v = new_comx;
@@ -1243,11 +1357,11 @@ __global__ void __launch_bounds__(64 * kMaxWavesPerBlock) env_kernel(ModelView m
   const float z = qpos[2];
   // (bitwise accumulation: a short-circuit || would put every load behind its own branch)
   FOR_G(i, nq) badi |= (int)isnan(qpos[i]);
-  FOR_G(i, nv) badi |= (int)isnan(qvel[i]) | (int)isnan(warm[i]) | (int)isnan(qact[i]);
+  FOR_G(i, nv) badi |= (int)isnan(qvel[i]) | (int)isnan(warm[i]);  // (qfrc_actuator was checked when it left for the record)
   badi |= (int)isnan(new_comx);
   const bool bad = badi != 0;
   const bool done = (bool)((int)!((rc.height_min_z < z) & (z < rc.height_max_z)) | (int)group16_any(bad));
-  // The new record: qpos, qvel, qfrc_actuator, the warm start, com_x and the time from LDS (cinert / cvel are in place already) - or,
+  // The new record: qpos, qvel, the warm start, com_x and the time from LDS (cinert / cvel / qfrc_actuator are in place already) - or,
   // when the episode ended, the reset record, which is also the observation to emit (env.py:179-180).  Ended episodes are rare: the
   // reset record is not even loaded otherwise.
   const int rec_dim = mv.rec_dim;
@@ -1264,7 +1378,7 @@ __global__ void __launch_bounds__(64 * kMaxWavesPerBlock) env_kernel(ModelView m
       }
     } else {
       FOR_G(i, nq) recw[i] = qpos[i];
-      FOR_G(i, nv) { recw[nq + i] = qvel[i]; recw[o_qa + i] = qact[i]; recw[OP + i] = warm[i]; }
+      FOR_G(i, nv) { recw[nq + i] = qvel[i]; recw[OP + i] = warm[i]; }
       for (int i = O + g; i < OP; i += kGroupLanes) recw[i] = 0.f;
       for (int i = OP + nv + 2 + g; i < rec_dim; i += kGroupLanes) recw[i] = 0.f;
       if (g == 0) { recw[OP + nv] = new_comx; recw[OP + nv + 1] = time_in + dt_env; }
@@ -1424,8 +1538,9 @@ extern "C" int32_t mppo_model_open(const void* host_blob, size_t nbytes, const v
   v.obs_dim = v.nq + 2 * v.nv + (v.include_c ? 16 * (v.nbody - 1) : 0);  // env.py:246-259
   v.obs_pad = (v.obs_dim + 3) & ~3;
   v.rec_dim = v.obs_pad + ((v.nv + 2 + 3) & ~3);
-  m->lds = make_phys_lds(v.nq, v.nv, v.nu, v.nbody, v.njnt, v.ncon, v.nefc, v.nroot, v.ncvx);
   m->spec = find_spec(bd);
+  // (a model-specialised kernel of up to 32 dofs keeps the inverse Cholesky factor in registers: no LL square in its layout)
+  m->lds = make_phys_lds(v.nq, v.nv, v.nu, v.nbody, v.njnt, v.ncon, v.nefc, v.nroot, v.ncvx, m->spec >= 0 && v.nv <= 2 * kGroupLanes);
   // waves per workgroup: whatever puts the most waves on a CU (160 KB of LDS; every workgroup holds one copy of the model tables and
   // waves x 4 environments), the smaller workgroup on a tie.  MPPO_ENV_WAVES=1..4 overrides (measurements).
   auto lds_of = [&](int w) { return (v.blob_words + m->lds.total * kEnvsPerWave * w) * 4; };

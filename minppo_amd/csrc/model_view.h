@@ -102,43 +102,53 @@ __host__ __device__ constexpr inline BlobOffsets blob_offsets(const BlobDims& d)
 }
 
 // Per-environment LDS layout (offsets in floats).  What is alive from one end of a step to the other sits in front; region "A" is
-// time-shared by five lifetimes that follow one another (each separated from the next by a synchronisation point of the kernel):
-//   A1 kinematics: poses (xpos, xquat, xipos), rotation matrices, joint anchors / axes        - until the contact frames are built
-//   A2 factorisation work copies: a [nv][ldc] square, M then M + h D (<= 32 dofs, fixed-size kernel: rows in registers) or the
-//      lower triangles of both (run-time-sized kernel, > 32 dofs)                              - inside the Cholesky phase
+// time-shared by four lifetimes that follow one another (each separated from the next by a synchronisation point of the kernel):
+//   A1 kinematics: poses (xpos, xquat, xipos), joint anchors / axes (the rotation matrices of bodies and inertial frames are recomputed
+//      from the quaternions where they are used - the same arithmetic, nothing stored)          - until the contact frames are built
+//   A2 factorisation work copy: a [nv][ldc] square (<= 32 dofs, fixed-size kernel: rows in registers; also the square through which the
+//      inverse factor is transposed into the row owners' registers) or the lower triangles of M and M + h D (run-time-sized kernel)
 //   A3 velocity / RNE scratch: cdofdot, cfrc, cvel                                             - until qfrc_bias is done
-//   A4 the contact rows of the constraint Jacobian (joint-limit rows are a sign and a dof: dsgn / drow, never a dense row)
-// (a second time-shared region, B, holds cdof + contact geometry, then the solver's vectors)
-//   cinert spans A1 .. A3 (computed during A1, last read by RNE) and therefore starts behind the longest of the three.
-// cinert and cvel leave LDS for the state record as soon as RNE has read them (they are part of the observation, not of the solver).
+//   A4 the contact rows of the constraint Jacobian (joint-limit rows are a signed row number per dof: dlim, never a dense row)
+// A second time-shared region, B, holds cdof + contact geometry, then the solver's vectors.  cinert (computed after the kinematics, last
+// read by RNE) shares the storage of the constraint rows' vectors D / aref / jaref / jv, which are born in make_constraint, after RNE.
+// cinert, cvel and qfrc_actuator leave LDS for the state record as soon as they are final (they are part of the observation, not of the solver).
+// `li_regs` (fixed-size kernels up to 32 dofs, round 4): the inverse Cholesky factor lives in registers (a lane's rows and columns); there
+// is no LL square, and the factor of M + h D for the Euler step is computed at the END of the step into the same registers instead of
+// being kept from the start - 9.5 instead of 12.9 KB per environment for the 26-dof robot = four waves per CU instead of three.
 struct PhysLds {
-  int qpos, qvel, ctrl, warm;
+  int qpos, qvel, ctrl, warm;  // ctrl shares t1's storage (dead before the solver; re-read from the action every frame)
   int rootcom, cdof;
   int ldc;         // row stride of the factorisation work copy in a fixed-size kernel: nv rounded up to 4 (rows are read as float4)
-  int M, LL, ldm;  // LL packs L^-1 of M (lower part, [i][k<=i]) and of M + h*D (stored transposed at [k][i+1])
-  int qfs, qas, qact, qacc, Ma, grad, Mgrad, search, mv, qfc, t0, t1;
-  int dsgn, drow;  // per dof: sign of its active joint-limit row (0: none) and that row's index
+  int M, LL, ldm;  // LL (run-time-sized kernel only) packs L^-1 of M (lower part, [i][k<=i]) and of M + h*D (stored transposed at [k][i+1])
+  int qfs, qas, qacc, Ma, grad, Mgrad, search, mv, qfc, t0, t1;
+  int dlim;        // per dof, an int: +-(row + 1) of its active joint-limit row, the sign being the row's single Jacobian entry (0: none)
   int D, aref, jaref, jv, force;  // force shares jv's storage (jv is dead once the step along the search direction is taken)
   int conpos, condist, confr;  // per contact slot: point, distance, frame rows (normal, first tangent)
   int cvxsel, cvxok;           // per convex geom: the four hull vertices chosen this step (body frame) and whether each slot is a first occurrence
-  int A, xpos, xquat, xipos, ximat, xmat, xanchor, xaxis, C, cdofdot, cfrc, cvel, cinert, J, ldj;
+  int A, xpos, xquat, xipos, xanchor, xaxis, C, cdofdot, cfrc, cvel, cinert, J, ldj;
   int total;
 };
 
 __host__ __device__ constexpr inline int imax_(int a, int b) { return a > b ? a : b; }
 
-__host__ __device__ constexpr inline PhysLds make_phys_lds(int nq, int nv, int nu, int nbody, int njnt, int ncon, int nefc, int nroot, int ncvx = 0) {
+__host__ __device__ constexpr inline PhysLds make_phys_lds(int nq, int nv, int nu, int nbody, int njnt, int ncon, int nefc, int nroot, int ncvx = 0, bool li_regs = false) {
   PhysLds p{};
   int o = 0;
   auto take = [&](int n) { int r = o; o += (n + 3) & ~3; return r; };
-  p.qpos = take(nq); p.qvel = take(nv); p.ctrl = take(nu > 0 ? nu : 1); p.warm = take(nv);
+  (void)nu;  // (at most nv actuators: mppo_model_open)
+  p.qpos = take(nq); p.qvel = take(nv); p.warm = take(nv);
   p.rootcom = take(3 * (nroot > 0 ? nroot : 1));
   p.ldm = nv + 1;  // odd row stride: a column read by 16 lanes hits 16 different banks
-  p.M = take(nv * p.ldm); p.LL = take(nv * p.ldm);
-  p.qfs = take(nv); p.qas = take(nv); p.qact = take(nv); p.t0 = take(nv); p.t1 = take(nv);
-  p.dsgn = take(nv); p.drow = take(nv);
+  p.M = take(nv * p.ldm);
+  p.LL = li_regs ? p.M : take(nv * p.ldm);  // (li_regs: never addressed)
+  p.qfs = take(nv); p.qas = take(nv); p.t0 = take(nv); p.t1 = take(nv);
+  p.ctrl = p.t1;
+  p.dlim = take(nv);
   const int ne = nefc > 0 ? nefc : 1;
+  const int rows0 = o;
   p.D = take(ne); p.aref = take(ne); p.jaref = take(ne); p.jv = take(ne); p.force = p.jv;
+  const int rows1 = o;
+  o = rows0; p.cinert = take(10 * nbody); o = imax_(o, rows1);
   p.cvxsel = take(12 * ncvx); p.cvxok = take(4 * ncvx);
   // region B, two lifetimes: the dynamics' cdof and the contact geometry, dead once the Jacobian is built | the solver's nv-vectors,
   // born after that (qacc stays until the end of the step: it is the next step's warm start)
@@ -148,14 +158,11 @@ __host__ __device__ constexpr inline PhysLds make_phys_lds(int nq, int nv, int n
   o = B; p.qacc = take(nv); p.Ma = take(nv); p.grad = take(nv); p.Mgrad = take(nv); p.search = take(nv); p.mv = take(nv); p.qfc = take(nv);
   o = imax_(o, B1);
   p.A = o;
-  p.xpos = take(3 * nbody); p.xquat = take(4 * nbody); p.xipos = take(3 * nbody);
-  p.ximat = take(9 * nbody); p.xmat = take(9 * nbody); p.xanchor = take(3 * njnt); p.xaxis = take(3 * njnt);
-  int span = o;  // end of the longest of A1 .. A3
-  p.ldc = (nv + 3) & ~3;
-  o = p.A; p.C = take(imax_(nv <= 32 ? nv * imax_(p.ldm, p.ldc) : 0, 2 * ((nv * (nv + 1) / 2 + 3) & ~3))); span = imax_(span, o);
-  o = p.A; p.cdofdot = take(6 * nv); p.cfrc = take(6 * nbody); p.cvel = take(6 * nbody); span = imax_(span, o);
-  o = span; p.cinert = take(10 * nbody);
+  p.xpos = take(3 * nbody); p.xquat = take(4 * nbody); p.xipos = take(3 * nbody); p.xanchor = take(3 * njnt); p.xaxis = take(3 * njnt);
   int end = o;
+  p.ldc = (nv + 3) & ~3;
+  o = p.A; p.C = take(imax_(nv <= 32 ? nv * imax_(p.ldm, p.ldc) : 0, 2 * ((nv * (nv + 1) / 2 + 3) & ~3))); end = imax_(end, o);
+  o = p.A; p.cdofdot = take(6 * nv); p.cfrc = take(6 * nbody); p.cvel = take(6 * nbody); end = imax_(end, o);
   p.ldj = nv + 1;
   o = p.A; p.J = take((ncon > 0 ? 4 * ncon : 1) * p.ldj); end = imax_(end, o);
   // an environment's arrays start 16 banks after its neighbour's (total = 16 mod 64 words): the four environments of a wave read the

@@ -460,7 +460,7 @@ class Trainer:
                     ok = C.c_int32(0)
                     try:
                         with device_ctx():
-                            self.lib.engine_peer_selftest(self._engine, C.byref(ok))
+                            self.lib.engine_peer_selftest(self._engine, self._stream_ptr, C.byref(ok))
                     except nat.NativeError as exc:
                         err = exc
                     if all_ok(err is None and ok.value == 1):

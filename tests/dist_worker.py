@@ -58,8 +58,8 @@ def run_rank(rank, world, port, overrides, updates, out_path):
             if int(fail_rank) == rank:
                 real = tr.lib.engine_peer_selftest
 
-                def failing(engine, ok_ref):
-                    real(engine, ok_ref)  # (collective: the peers wait for this rank's contribution)
+                def failing(engine, stream, ok_ref):
+                    real(engine, stream, ok_ref)  # (collective: the peers wait for this rank's contribution)
                     ok_ref._obj.value = 0
 
                 tr.lib.engine_peer_selftest = failing
@@ -134,7 +134,7 @@ def run_process_of_ranks(proc, nproc, per_proc, port, overrides, updates, out_pa
 
     def selftest(j):
         try:
-            trs[j].lib.engine_peer_selftest(trs[j]._engine, C.byref(oks[j]))
+            trs[j].lib.engine_peer_selftest(trs[j]._engine, trs[j]._stream_ptr, C.byref(oks[j]))
         except Exception as exc:  # noqa: BLE001
             errs[j] = exc
 

@@ -438,12 +438,14 @@ def test_forty_dof_robot_runs_the_runtime_sized_kernel(be):
 
 def test_waves_per_workgroup_change_nothing(be, monkeypatch):
     """mppo_model_open picks the number of waves per workgroup that puts the most waves on a CU (160 KB of LDS, one copy of the model
-    tables per workgroup): three for the 26-dof robot.  The choice is a launch geometry, not arithmetic: env steps with one, two and
-    three waves per workgroup (MPPO_ENV_WAVES) agree bit for bit, at an environment count that fills the last workgroup only partly."""
+    tables per workgroup): four for the 26-dof robot since round 4 (9.5 KB per environment: the inverse Cholesky factor lives in
+    registers; it was three at 12.9 KB) - one wave on every SIMD of a CU.  The choice is a launch geometry, not arithmetic: env steps with
+    one, two, three and four waves per workgroup (MPPO_ENV_WAVES) agree bit for bit, at an environment count that fills the last
+    workgroup only partly."""
     cm = load_model("synth_stompy_full")
     N = 29
     res, lds = [], []
-    for waves in (None, "1", "2"):
+    for waves in (None, "1", "2", "3"):
         if waves is None:
             monkeypatch.delenv("MPPO_ENV_WAVES", raising=False)
         else:
@@ -463,9 +465,9 @@ def test_waves_per_workgroup_change_nothing(be, monkeypatch):
         res.append(dict(state=be.host(state).copy(), obs=be.host(obs).copy(), rew=be.host(rew).copy(), done=be.host(done).copy()))
         be.lib.model_close(h)
     monkeypatch.delenv("MPPO_ENV_WAVES", raising=False)
-    assert lds[1] < lds[2] < lds[0] <= 160 * 1024, lds  # the default is three waves: more than half of a CU's LDS in one workgroup
+    assert lds[1] < lds[2] < lds[3] < lds[0] <= 160 * 1024, lds  # the default is four waves: all of a CU's LDS in one workgroup
     per_env = (lds[2] - lds[1]) // 4
-    assert lds[0] - lds[2] == 4 * per_env and 2 * lds[2] > 160 * 1024, lds  # ... because two two-wave workgroups would not fit
+    assert lds[0] - lds[2] == 8 * per_env and 2 * lds[2] > 160 * 1024, lds  # ... because two two-wave workgroups would not fit
     for other in res[1:]:
         for k in res[0]:
             np.testing.assert_array_equal(res[0][k], other[k], err_msg=k)
