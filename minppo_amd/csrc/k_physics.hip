@@ -67,6 +67,10 @@ struct EnvArgs {
 // not change.  kDotU is a constant of the enclosing function (model-specialised kernels: by the number of dofs; run-time-sized: 8).
 #define DOT_UNROLL _Pragma("unroll kDotU")
 constexpr int dot_unroll(int nv_static) { return nv_static == 0 ? MPPO_DOT_UNROLL_RT : nv_static <= 16 ? 16 : 32; }
+// solver matrices of robots up to 16 dofs in registers (A/B builds: -DMPPO_SOLVER_REGS=0 / 1; see the factorisation section)
+#ifndef MPPO_SOLVER_REGS
+#define MPPO_SOLVER_REGS 1
+#endif
 // the instruction scheduler moves nothing across this point
 #ifdef MPPO_EMU
 #define SCHED_FENCE() do { } while (0)
@@ -639,7 +643,7 @@ __global__ void __launch_bounds__(64 * kMaxWavesPerBlock) env_kernel(ModelView m
     // Up to 16 dofs (one row per lane) the solver's two matrices live in registers as well: this lane's row of M, its rows of the
     // contact Jacobian (row products J x) and its column (J^T f).  The CG iteration then reads only VECTORS from LDS - half the LDS
     // instructions of an iteration, the same products term by term.
-    constexpr bool kSolverRegs = kRegChol && NVc <= kGroupLanes;
+    constexpr bool kSolverRegs = MPPO_SOLVER_REGS && kRegChol && NVc <= kGroupLanes;
     constexpr int NRC = kSolverRegs ? 4 * kSD.ncon : 1;                       // contact rows
     constexpr int RJ = (NRC + kGroupLanes - 1) / kGroupLanes;                 // ... per lane
     float Mrow[kSolverRegs ? NVc : 1], Jrow[RJ][kSolverRegs ? NVc : 1], Jcol[NRC];

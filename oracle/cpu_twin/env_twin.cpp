@@ -1,0 +1,725 @@
+// env_twin.cpp — a C++17 / OpenMP float32 twin of the environment step, for the CPU baseline of bench.py.     TEST / BENCH INFRASTRUCTURE.
+//
+// PARITY UNPINNED (see oracle/physics_oracle.py).  What it restates: reference `HumanoidEnv.reset / step` (minppo/env.py:124-196) with the
+// third-party `pipeline_init / pipeline_step` behind them (env.py:120,162 -> mujoco.mjx.forward / step, solver CG 6 / 6, env.py:95-97),
+// `compute_reward` (env.py:199-235), `is_done` (env.py:238-242), the NaN guard (env.py:173-176), the auto-reset select (env.py:179-180),
+// `get_obs` (env.py:245-261) and the episode metrics (env.py:183-194) - the same published MuJoCo / MJX algorithm as oracle/physics_oracle.py
+// and oracle/env_oracle.py, written the way a CPU implementation is: ONE environment per thread (`#pragma omp parallel for` over the
+// environments, which are independent: train.py:136,140), scalar float32 loops, the tree recursions leaf -> root / root -> leaf as MuJoCo
+// does them.  It reads the same model blob as the HIP engine (minppo_amd/model.py: to_blob) and keeps the engine's per-environment
+// state record ([qpos | qvel | cinert[1:] | cvel[1:] | qfrc_actuator | pad | qacc_warmstart | subtree_com[1].x | time]), so the golden
+// fixtures check it exactly like they check the kernel (tests/test_cpu_twin.py).
+//
+// SURVEY.md 8(d) "CPU baseline timing" asks for this: the reference's JAX-CPU path cannot run here or on the GPU box (no jax / brax /
+// mujoco), a NumPy port with Python loops over bodies is not what a CPU would be asked to run.  Nothing under minppo_amd/ loads it.
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <vector>
+
+#include "model_view.h"  // blob layout (array order, header words): the one definition the model compiler, the engine and this twin share
+
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+using namespace mppo;
+
+namespace {
+
+struct V3 { float x, y, z; };
+struct Q4 { float w, x, y, z; };
+inline V3 ld3(const float* p) { return {p[0], p[1], p[2]}; }
+inline void st3(float* p, V3 v) { p[0] = v.x; p[1] = v.y; p[2] = v.z; }
+inline Q4 ld4(const float* p) { return {p[0], p[1], p[2], p[3]}; }
+inline void st4(float* p, Q4 q) { p[0] = q.w; p[1] = q.x; p[2] = q.y; p[3] = q.z; }
+inline V3 add3(V3 a, V3 b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
+inline V3 sub3(V3 a, V3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
+inline V3 mul3(V3 a, float s) { return {a.x * s, a.y * s, a.z * s}; }
+inline float dot3(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+inline V3 cross3(V3 a, V3 b) { return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x}; }
+inline Q4 qmul(Q4 a, Q4 b) {
+  return {a.w * b.w - a.x * b.x - a.y * b.y - a.z * b.z, a.w * b.x + a.x * b.w + a.y * b.z - a.z * b.y,
+          a.w * b.y - a.x * b.z + a.y * b.w + a.z * b.x, a.w * b.z + a.x * b.y - a.y * b.x + a.z * b.w};
+}
+inline Q4 qnormalize(Q4 q) {
+  const float n = std::sqrt(q.w * q.w + q.x * q.x + q.y * q.y + q.z * q.z);
+  const float s = n > 0.f ? 1.f / n : 1.f;
+  return {q.w * s, q.x * s, q.y * s, q.z * s};
+}
+inline void qmat(Q4 q, float* m) {
+  const float w = q.w, x = q.x, y = q.y, z = q.z;
+  m[0] = w * w + x * x - y * y - z * z; m[1] = 2.f * (x * y - w * z);         m[2] = 2.f * (x * z + w * y);
+  m[3] = 2.f * (x * y + w * z);         m[4] = w * w - x * x + y * y - z * z; m[5] = 2.f * (y * z - w * x);
+  m[6] = 2.f * (x * z - w * y);         m[7] = 2.f * (y * z + w * x);         m[8] = w * w - x * x - y * y + z * z;
+}
+inline V3 qrot(Q4 q, V3 v) {
+  float m[9];
+  qmat(q, m);
+  return {m[0] * v.x + m[1] * v.y + m[2] * v.z, m[3] * v.x + m[4] * v.y + m[5] * v.z, m[6] * v.x + m[7] * v.y + m[8] * v.z};
+}
+inline Q4 axis_angle(V3 axis, float angle) {
+  const float s = std::sin(0.5f * angle), c = std::cos(0.5f * angle);
+  return {c, axis.x * s, axis.y * s, axis.z * s};
+}
+inline V3 normalize_norm(V3 v, float& n) {  // MJX math.normalize_with_norm
+  n = std::sqrt(dot3(v, v));
+  return mul3(v, 1.f / (n + (n == 0.f ? 1e-6f : 0.f)));
+}
+inline V3 closest_segment_point(V3 a, V3 b, V3 pt) {
+  const V3 ab = sub3(b, a);
+  const float t = dot3(sub3(pt, a), ab) / (dot3(ab, ab) + 1e-6f);
+  return add3(a, mul3(ab, std::min(std::max(t, 0.f), 1.f)));
+}
+inline void closest_segment_points(V3 a0, V3 a1, V3 b0, V3 b1, V3& best_a, V3& best_b) {  // MJX math.closest_segment_to_segment_points
+  float len_a, len_b;
+  const V3 dir_a = normalize_norm(sub3(a1, a0), len_a), dir_b = normalize_norm(sub3(b1, b0), len_b);
+  const float half_a = 0.5f * len_a, half_b = 0.5f * len_b;
+  const V3 a_mid = add3(a0, mul3(dir_a, half_a)), b_mid = add3(b0, mul3(dir_b, half_b));
+  const V3 trans = sub3(a_mid, b_mid);
+  const float dab = dot3(dir_a, dir_b), dat = dot3(dir_a, trans), dbt = dot3(dir_b, trans);
+  const float denom = 1.f - dab * dab;
+  float ta = (-dat + dab * dbt) / (denom + 1e-6f);
+  float tb = dbt + ta * dab;
+  ta = std::min(std::max(ta, -half_a), half_a);
+  tb = std::min(std::max(tb, -half_b), half_b);
+  best_a = add3(a_mid, mul3(dir_a, ta));
+  best_b = add3(b_mid, mul3(dir_b, tb));
+  const V3 new_a = closest_segment_point(a0, a1, best_b), new_b = closest_segment_point(b0, b1, best_a);
+  const V3 e1 = sub3(new_a, best_b), e2 = sub3(new_b, best_a);
+  if (dot3(e1, e1) < dot3(e2, e2)) best_a = new_a; else best_b = new_b;
+}
+inline V3 frame_tangent(V3 n) {  // second row of MJX math.make_frame for a unit n
+  V3 b = (n.y > -0.5f && n.y < 0.5f) ? V3{0.f, 1.f, 0.f} : V3{0.f, 0.f, 1.f};
+  b = sub3(b, mul3(n, dot3(n, b)));
+  const float l = std::sqrt(dot3(b, b));
+  return mul3(b, l > 0.f ? 1.f / l : 1.f);
+}
+inline void inert_mul(const float* i, const float* v, float* r) {  // mju_mulInertVec
+  r[0] = i[0] * v[0] + i[3] * v[1] + i[4] * v[2] - i[8] * v[4] + i[7] * v[5];
+  r[1] = i[3] * v[0] + i[1] * v[1] + i[5] * v[2] + i[8] * v[3] - i[6] * v[5];
+  r[2] = i[4] * v[0] + i[5] * v[1] + i[2] * v[2] - i[7] * v[3] + i[6] * v[4];
+  r[3] = i[8] * v[1] - i[7] * v[2] + i[9] * v[3];
+  r[4] = i[6] * v[2] - i[8] * v[0] + i[9] * v[4];
+  r[5] = i[7] * v[0] - i[6] * v[1] + i[9] * v[5];
+}
+inline void cross_motion(const float* vel, const float* v, float* r) {
+  const V3 w = ld3(vel), l = ld3(vel + 3), a = ld3(v), b = ld3(v + 3);
+  st3(r, cross3(w, a));
+  st3(r + 3, add3(cross3(w, b), cross3(l, a)));
+}
+inline void cross_force(const float* vel, const float* f, float* r) {
+  const V3 w = ld3(vel), l = ld3(vel + 3), a = ld3(f), b = ld3(f + 3);
+  st3(r, add3(cross3(w, a), cross3(l, b)));
+  st3(r + 3, cross3(w, b));
+}
+
+struct RewardCfg {  // = mppo_reward_cfg_t (include/minppo_hip.h)
+  float height_min_z, height_max_z, exp_coefficient, subtraction_factor, max_diff_norm, w_ctrl_cost, w_original_pos, w_is_healthy, w_velocity;
+};
+
+struct Model {
+  std::vector<int32_t> blob;
+  int nq, nv, nu, nb, njnt, ncon, nlim, npair, nroot, ncvx, nefc, iterations, ls_iterations, include_c;
+  int obs_dim, obs_pad, rec_dim;
+  float timestep, tolerance, ls_tolerance, impratio, plane_z, meaninertia;
+  int off[BLOB_ARRAY_COUNT];
+  const int* I(int k) const { return blob.data() + off[k]; }
+  const float* F(int k) const { return reinterpret_cast<const float*>(blob.data()) + off[k]; }
+};
+
+// per-thread working set of one environment's forward pass
+struct Work {
+  std::vector<float> xpos, xquat, xipos, ximat, xmat, xanchor, xaxis, subcom, submass, cinert, cdof, crb, M, L, Le, cvel, cdofdot, cacc, cfrc;
+  std::vector<float> condist, conpos, confr, cvxsel, cvxok, J, D, aref, jaref, jv, force, qfs, qas, qact, qacc, Ma, grad, Mgrad, search, mv, qfc, tmp, t1, bias;
+  std::vector<int> lastdof;
+  explicit Work(const Model& m) {
+    const int nb = m.nb, nv = m.nv, ne = std::max(m.nefc, 1), nc = std::max(m.ncon, 1);
+    xpos.resize(3 * nb); xquat.resize(4 * nb); xipos.resize(3 * nb); ximat.resize(9 * nb); xmat.resize(9 * nb); xanchor.resize(3 * m.njnt); xaxis.resize(3 * m.njnt);
+    subcom.resize(3 * nb); submass.resize(nb); cinert.resize(10 * nb); cdof.resize(6 * nv); crb.resize(10 * nb); M.resize(nv * nv); L.resize(nv * nv); Le.resize(nv * nv);
+    cvel.resize(6 * nb); cdofdot.resize(6 * nv); cacc.resize(6 * nb); cfrc.resize(6 * nb);
+    condist.resize(nc); conpos.resize(3 * nc); confr.resize(9 * nc); cvxsel.resize(12 * std::max(m.ncvx, 1)); cvxok.resize(4 * std::max(m.ncvx, 1));
+    J.resize((size_t)ne * nv); D.resize(ne); aref.resize(ne); jaref.resize(ne); jv.resize(ne); force.resize(ne);
+    for (auto* v : {&qfs, &qas, &qact, &qacc, &Ma, &grad, &Mgrad, &search, &mv, &qfc, &tmp, &t1, &bias}) v->resize(nv);
+    lastdof.resize(nb);
+  }
+};
+
+void kb_params(const float* solref, const float* solimp, float timestep, float& k, float& b) {
+  const float timeconst = std::max(solref[0], 2.f * timestep);
+  const float dampratio = solref[1];
+  const float dmax = std::min(std::max(solimp[1], MJ_MINIMP), MJ_MAXIMP);
+  k = 1.f / (dmax * dmax * timeconst * timeconst * dampratio * dampratio);
+  b = 2.f / (dmax * timeconst);
+  if (solref[0] <= 0.f) k = -solref[0] / (dmax * dmax);
+  if (solref[1] <= 0.f) b = -solref[1] / dmax;
+}
+float impedance(const float* solimp, float pos) {
+  const float dmin = std::min(std::max(solimp[0], MJ_MINIMP), MJ_MAXIMP), dmax = std::min(std::max(solimp[1], MJ_MINIMP), MJ_MAXIMP);
+  const float width = std::max(MJ_MINVAL, solimp[2]), mid = std::min(std::max(solimp[3], MJ_MINIMP), MJ_MAXIMP), power = std::max(1.f, solimp[4]);
+  const float x = std::fabs(pos) / width;
+  const float a = (1.f / std::pow(mid, power - 1.f)) * std::pow(x, power);
+  const float c = 1.f - (1.f / std::pow(1.f - mid, power - 1.f)) * std::pow(std::fabs(1.f - x), power);
+  float imp = dmin + (x < mid ? a : c) * (dmax - dmin);
+  imp = std::min(std::max(imp, dmin), dmax);
+  if (x > 1.f) imp = dmax;
+  return imp;
+}
+
+// in-place lower Cholesky of an nv x nv matrix (row-major copy in L); false: not positive definite (-> NaNs propagate like in MJX)
+void cholesky(const float* A, float* L, int n) {
+  for (int i = 0; i < n; ++i)
+    for (int j = 0; j <= i; ++j) {
+      float s = A[i * n + j];
+      for (int k = 0; k < j; ++k) s -= L[i * n + k] * L[j * n + k];
+      L[i * n + j] = i == j ? std::sqrt(std::max(s, MJ_MINVAL)) : s / L[j * n + j];
+    }
+}
+void chol_solve(const float* L, int n, const float* b, float* x) {  // x = (L L^T)^-1 b
+  for (int i = 0; i < n; ++i) {
+    float s = b[i];
+    for (int k = 0; k < i; ++k) s -= L[i * n + k] * x[k];
+    x[i] = s / L[i * n + i];
+  }
+  for (int i = n - 1; i >= 0; --i) {
+    float s = x[i];
+    for (int k = i + 1; k < n; ++k) s -= L[k * n + i] * x[k];
+    x[i] = s / L[i * n + i];
+  }
+}
+
+struct LsPoint { float alpha, cost, d0, d1; };
+inline LsPoint ls_make(float alpha, float q0, float q1, float q2) {
+  return {alpha, alpha * alpha * q2 + alpha * q1 + q0, 2.f * alpha * q2 + q1, 2.f * q2 + (q2 == 0.f ? MJ_MINVAL : 0.f)};
+}
+inline bool in_bracket(const LsPoint& x, const LsPoint& y) { return (x.d0 < y.d0 && y.d0 < 0.f) || (x.d0 > y.d0 && y.d0 > 0.f); }
+
+// mjx.forward on (qpos, qvel, ctrl, qacc_warmstart): everything up to the solver's qacc; w keeps cinert, cvel, qact, M, qfs, qfc;
+// returns subtree_com[1].x
+float forward(const Model& m, Work& w, const float* qpos, const float* qvel, const float* ctrl, const float* warm) {
+  const int nb = m.nb, nv = m.nv, nq = m.nq, njnt = m.njnt, ncon = m.ncon, nlim = m.nlim, npair = m.npair, nplane = ncon - npair, nefc = m.nefc;
+  (void)nq;
+  const int *body_parent = m.I(BI_body_parent), *body_rootid = m.I(BI_body_rootid), *body_jntadr = m.I(BI_body_jntadr), *body_jntnum = m.I(BI_body_jntnum),
+            *body_dofadr = m.I(BI_body_dofadr), *body_dofnum = m.I(BI_body_dofnum), *jnt_type = m.I(BI_jnt_type), *jnt_qposadr = m.I(BI_jnt_qposadr),
+            *jnt_dofadr = m.I(BI_jnt_dofadr), *jnt_bodyid = m.I(BI_jnt_bodyid), *dof_bodyid = m.I(BI_dof_bodyid), *dof_jntid = m.I(BI_dof_jntid),
+            *dof_parentid = m.I(BI_dof_parentid), *dof_qposadr = m.I(BI_dof_qposadr);
+  const float* qpos0 = m.F(BF_qpos0);
+  // ---- kinematics (mj_kinematics): bodies are topologically ordered
+  st3(&w.xpos[0], {0, 0, 0}); st4(&w.xquat[0], {1, 0, 0, 0});
+  for (int b = 1; b < nb; ++b) {
+    const int p = body_parent[b];
+    const Q4 pq = ld4(&w.xquat[4 * p]);
+    V3 pos = add3(ld3(&w.xpos[3 * p]), qrot(pq, ld3(m.F(BF_body_pos) + 3 * b)));
+    Q4 quat = qmul(pq, ld4(m.F(BF_body_quat) + 4 * b));
+    for (int j = body_jntadr[b]; j < body_jntadr[b] + body_jntnum[b]; ++j) {
+      const int qa = jnt_qposadr[j], jt = jnt_type[j];
+      if (jt == JNT_FREE) {
+        pos = ld3(qpos + qa);
+        quat = qnormalize(ld4(qpos + qa + 3));
+        st3(&w.xanchor[3 * j], pos);
+        st3(&w.xaxis[3 * j], qrot(quat, ld3(m.F(BF_jnt_axis) + 3 * j)));
+      } else {
+        const V3 anchor = add3(pos, qrot(quat, ld3(m.F(BF_jnt_pos) + 3 * j))), axis = qrot(quat, ld3(m.F(BF_jnt_axis) + 3 * j));
+        st3(&w.xanchor[3 * j], anchor); st3(&w.xaxis[3 * j], axis);
+        const float disp = qpos[qa] - qpos0[qa];
+        if (jt == JNT_HINGE) {
+          quat = qmul(quat, axis_angle(ld3(m.F(BF_jnt_axis) + 3 * j), disp));
+          pos = sub3(anchor, qrot(quat, ld3(m.F(BF_jnt_pos) + 3 * j)));
+        } else {
+          pos = add3(pos, mul3(axis, disp));
+        }
+      }
+    }
+    quat = qnormalize(quat);
+    st3(&w.xpos[3 * b], pos); st4(&w.xquat[4 * b], quat);
+    qmat(quat, &w.xmat[9 * b]);
+    st3(&w.xipos[3 * b], add3(pos, qrot(quat, ld3(m.F(BF_body_ipos) + 3 * b))));
+    qmat(qmul(quat, ld4(m.F(BF_body_iquat) + 4 * b)), &w.ximat[9 * b]);
+  }
+  // ---- com_pos: subtree centres of mass leaf -> root, cinert about the tree's centre of mass, cdof
+  const float* mass = m.F(BF_body_mass);
+  for (int b = 0; b < nb; ++b) { w.submass[b] = mass[b]; st3(&w.subcom[3 * b], b ? mul3(ld3(&w.xipos[3 * b]), mass[b]) : V3{0, 0, 0}); }
+  for (int b = nb - 1; b > 0; --b) {
+    const int p = body_parent[b];
+    st3(&w.subcom[3 * p], add3(ld3(&w.subcom[3 * p]), ld3(&w.subcom[3 * b])));
+    w.submass[p] += w.submass[b];
+  }
+  for (int b = 0; b < nb; ++b) st3(&w.subcom[3 * b], mul3(ld3(&w.subcom[3 * b]), 1.f / std::max(w.submass[b], MJ_MINVAL)));
+  const float comx = w.subcom[3 * 1];
+  for (int k = 0; k < 10; ++k) w.cinert[k] = 0.f;
+  for (int b = 1; b < nb; ++b) {
+    float* ci = &w.cinert[10 * b];
+    const V3 off = sub3(ld3(&w.xipos[3 * b]), ld3(&w.subcom[3 * body_rootid[b]]));
+    const float mb = mass[b];
+    const float* R = &w.ximat[9 * b];
+    const float d0 = m.F(BF_body_inertia)[3 * b], d1 = m.F(BF_body_inertia)[3 * b + 1], d2 = m.F(BF_body_inertia)[3 * b + 2];
+    const float oo = dot3(off, off);
+    ci[0] = R[0] * R[0] * d0 + R[1] * R[1] * d1 + R[2] * R[2] * d2 + mb * (oo - off.x * off.x);
+    ci[1] = R[3] * R[3] * d0 + R[4] * R[4] * d1 + R[5] * R[5] * d2 + mb * (oo - off.y * off.y);
+    ci[2] = R[6] * R[6] * d0 + R[7] * R[7] * d1 + R[8] * R[8] * d2 + mb * (oo - off.z * off.z);
+    ci[3] = R[0] * R[3] * d0 + R[1] * R[4] * d1 + R[2] * R[5] * d2 - mb * off.x * off.y;
+    ci[4] = R[0] * R[6] * d0 + R[1] * R[7] * d1 + R[2] * R[8] * d2 - mb * off.x * off.z;
+    ci[5] = R[3] * R[6] * d0 + R[4] * R[7] * d1 + R[5] * R[8] * d2 - mb * off.y * off.z;
+    ci[6] = mb * off.x; ci[7] = mb * off.y; ci[8] = mb * off.z; ci[9] = mb;
+  }
+  for (int j = 0; j < njnt; ++j) {
+    const int b = jnt_bodyid[j], da = jnt_dofadr[j], jt = jnt_type[j];
+    const V3 off = sub3(ld3(&w.subcom[3 * body_rootid[b]]), ld3(&w.xanchor[3 * j]));
+    if (jt == JNT_FREE) {
+      const float* R = &w.xmat[9 * b];
+      for (int k = 0; k < 3; ++k) {
+        float* c = &w.cdof[6 * (da + k)];
+        c[0] = c[1] = c[2] = 0.f; c[3] = k == 0; c[4] = k == 1; c[5] = k == 2;
+        const V3 ax = {R[k], R[3 + k], R[6 + k]};
+        st3(&w.cdof[6 * (da + 3 + k)], ax);
+        st3(&w.cdof[6 * (da + 3 + k) + 3], cross3(ax, off));
+      }
+    } else if (jt == JNT_HINGE) {
+      const V3 ax = ld3(&w.xaxis[3 * j]);
+      st3(&w.cdof[6 * da], ax); st3(&w.cdof[6 * da + 3], cross3(ax, off));
+    } else {
+      st3(&w.cdof[6 * da], {0, 0, 0}); st3(&w.cdof[6 * da + 3], ld3(&w.xaxis[3 * j]));
+    }
+  }
+  // ---- crb: composite inertias leaf -> root, dense M, Cholesky
+  std::copy(w.cinert.begin(), w.cinert.end(), w.crb.begin());
+  for (int b = nb - 1; b > 0; --b) for (int k = 0; k < 10; ++k) w.crb[10 * body_parent[b] + k] += w.crb[10 * b + k];
+  std::fill(w.M.begin(), w.M.end(), 0.f);
+  for (int i = 0; i < nv; ++i) {
+    float buf[6];
+    inert_mul(&w.crb[10 * dof_bodyid[i]], &w.cdof[6 * i], buf);
+    for (int j = i; j >= 0; j = dof_parentid[j]) {
+      const float* cj = &w.cdof[6 * j];
+      float v = cj[0] * buf[0] + cj[1] * buf[1] + cj[2] * buf[2] + cj[3] * buf[3] + cj[4] * buf[4] + cj[5] * buf[5];
+      if (j == i) v += m.F(BF_dof_armature)[i];
+      w.M[i * nv + j] = v; w.M[j * nv + i] = v;
+    }
+  }
+  cholesky(w.M.data(), w.L.data(), nv);
+  // ---- collision: ground contacts (plane-sphere / plane-capsule end / box corner / chosen hull vertices), geom-geom pairs
+  for (int k = 0; k < m.ncvx; ++k) {  // MJX collision_convex.plane_convex + _manifold_points
+    const int b = m.I(BI_cvx_body)[k], v0 = m.I(BI_cvx_vadr)[k], v1 = m.I(BI_cvx_vadr)[k + 1];
+    float R[9];
+    qmat(ld4(&w.xquat[4 * b]), R);
+    const V3 nl = {R[6], R[7], R[8]};
+    const float h0 = m.plane_z - w.xpos[3 * b + 2];
+    const float* vt = m.F(BF_cvx_vert);
+    float smax = -INFINITY;
+    for (int v = v0; v < v1; ++v) smax = std::max(smax, h0 - dot3(nl, ld3(vt + 3 * v)));
+    const float thr = std::max(0.f, smax - 1e-3f);
+    auto dm = [&](int v) { return (h0 - dot3(nl, ld3(vt + 3 * v)) > thr) ? 0.f : -1e6f; };
+    auto argmax = [&](auto&& f) { int best = v0; float bv = -INFINITY; for (int v = v0; v < v1; ++v) { const float x = f(v); if (x > bv) { bv = x; best = v; } } return best; };
+    const int ia = argmax([&](int v) { return dm(v); });
+    const V3 A = ld3(vt + 3 * ia);
+    const int ib = argmax([&](int v) { const V3 e = sub3(A, ld3(vt + 3 * v)); return dot3(e, e) + dm(v); });
+    const V3 B = ld3(vt + 3 * ib);
+    const V3 ab = cross3(nl, sub3(A, B));
+    const int ic = argmax([&](int v) { return std::fabs(dot3(sub3(A, ld3(vt + 3 * v)), ab)) + dm(v); });
+    const V3 Cc = ld3(vt + 3 * ic);
+    const V3 ac = cross3(nl, sub3(A, Cc)), bc = cross3(nl, sub3(B, Cc));
+    int id = v0;
+    {
+      float best = -INFINITY;
+      for (int v = v0; v < v1; ++v) { const float x = std::fabs(dot3(sub3(B, ld3(vt + 3 * v)), bc)) + dm(v); if (x > best) { best = x; id = v; } }
+      for (int v = v0; v < v1; ++v) { const float x = std::fabs(dot3(sub3(A, ld3(vt + 3 * v)), ac)) + dm(v); if (x > best) { best = x; id = v; } }
+    }
+    const int idx[4] = {ia, ib, ic, id};
+    for (int j = 0; j < 4; ++j) {
+      bool first = true;
+      for (int i = 0; i < j; ++i) first = first && idx[i] != idx[j];
+      st3(&w.cvxsel[3 * (4 * k + j)], ld3(vt + 3 * idx[j]));
+      w.cvxok[4 * k + j] = first ? 1.f : 0.f;
+    }
+  }
+  for (int c = 0; c < nplane; ++c) {
+    const int b = m.I(BI_con_bodyid)[c];
+    const Q4 q = ld4(&w.xquat[4 * b]);
+    const int cs = m.ncvx > 0 ? m.I(BI_con_cvx)[c] : -1;
+    const V3 centre = add3(ld3(&w.xpos[3 * b]), qrot(q, cs >= 0 ? ld3(&w.cvxsel[3 * cs]) : ld3(m.F(BF_con_lpos) + 3 * c)));
+    const float rad = m.F(BF_con_radius)[c];
+    float dist = centre.z - m.plane_z - rad;
+    if (cs >= 0 && w.cvxok[cs] == 0.f) dist = 1.f;
+    w.condist[c] = dist;
+    st3(&w.conpos[3 * c], {centre.x, centre.y, centre.z - (rad + 0.5f * dist)});
+    const V3 ax = qrot(q, ld3(m.F(BF_con_axis) + 3 * c));
+    const float bn = std::sqrt(ax.x * ax.x + ax.y * ax.y);
+    const V3 n = {0, 0, 1}, t1 = bn < 0.5f ? V3{0, 1, 0} : V3{ax.x / bn, ax.y / bn, 0.f};
+    st3(&w.confr[9 * c], n); st3(&w.confr[9 * c + 3], t1); st3(&w.confr[9 * c + 6], cross3(n, t1));
+  }
+  for (int k = 0; k < npair; ++k) {
+    const int c = nplane + k, b1 = m.I(BI_pair_body)[2 * k], b2 = m.I(BI_pair_body)[2 * k + 1];
+    const float* gp = m.F(BF_pair_geom) + 16 * k;
+    const Q4 q1 = ld4(&w.xquat[4 * b1]), q2 = ld4(&w.xquat[4 * b2]);
+    const V3 c1 = add3(ld3(&w.xpos[3 * b1]), qrot(q1, ld3(gp))), h1 = qrot(q1, ld3(gp + 3));
+    const V3 c2 = add3(ld3(&w.xpos[3 * b2]), qrot(q2, ld3(gp + 8))), h2 = qrot(q2, ld3(gp + 11));
+    V3 p1, p2;
+    closest_segment_points(sub3(c1, h1), add3(c1, h1), sub3(c2, h2), add3(c2, h2), p1, p2);
+    float dist;
+    V3 n = normalize_norm(sub3(p2, p1), dist);
+    if (dist == 0.f) n = {1, 0, 0};
+    dist -= gp[6] + gp[14];
+    w.condist[c] = dist;
+    st3(&w.conpos[3 * c], add3(p1, mul3(n, gp[6] + 0.5f * dist)));
+    const V3 t1 = frame_tangent(n);
+    st3(&w.confr[9 * c], n); st3(&w.confr[9 * c + 3], t1); st3(&w.confr[9 * c + 6], cross3(n, t1));
+  }
+  // ---- make_constraint: limits (one row each), contacts (four pyramid rows each); inactive rows are inert
+  for (int b = 1; b < nb; ++b) w.lastdof[b] = body_dofnum[b] > 0 ? body_dofadr[b] + body_dofnum[b] - 1 : w.lastdof[body_parent[b]];
+  w.lastdof[0] = -1;
+  std::fill(w.J.begin(), w.J.end(), 0.f);
+  float k_lim, b_lim, k_con, b_con;
+  kb_params(m.F(BF_limit_solref), m.F(BF_limit_solimp), m.timestep, k_lim, b_lim);
+  kb_params(m.F(BF_contact_solref), m.F(BF_contact_solimp), m.timestep, k_con, b_con);
+  auto finish_row = [&](int r, bool act, float pos, float iw, bool lim) {
+    const float imp = impedance(lim ? m.F(BF_limit_solimp) : m.F(BF_contact_solimp), act ? pos : 0.f);
+    float s = 0.f;
+    for (int k = 0; k < nv; ++k) s += w.J[(size_t)r * nv + k] * qvel[k];
+    const float R = std::max((act ? iw : 0.f) * (1.f - imp) / imp, MJ_MINVAL);
+    w.D[r] = act ? 1.f / R : 0.f;
+    w.aref[r] = act ? -(lim ? b_lim : b_con) * s - (lim ? k_lim : k_con) * imp * pos : 0.f;
+  };
+  for (int r = 0; r < nlim; ++r) {
+    const int jid = m.I(BI_lim_jntid)[r], qa = jnt_qposadr[jid], da = jnt_dofadr[jid];
+    const float dlo = qpos[qa] - m.F(BF_jnt_range)[2 * jid], dhi = m.F(BF_jnt_range)[2 * jid + 1] - qpos[qa];
+    const float pos = std::min(dlo, dhi);
+    const bool act = pos < 0.f;
+    if (act) w.J[(size_t)r * nv + da] = dlo < dhi ? 1.f : -1.f;
+    finish_row(r, act, pos, m.F(BF_dof_invweight0)[da], true);
+  }
+  for (int c = 0; c < ncon; ++c) {
+    const bool act = w.condist[c] < 0.f;
+    const float mu = m.F(BF_con_friction)[3 * c];
+    const int b2 = m.I(BI_con_bodyid)[c], b1 = c >= nplane ? m.I(BI_pair_body)[2 * (c - nplane)] : 0;
+    float tw = m.F(BF_body_invweight0)[2 * b2];
+    if (c >= nplane) tw += m.F(BF_body_invweight0)[2 * b1];
+    const float iw = (tw + mu * mu * tw) * 2.f * mu * mu / m.impratio;
+    const int r0 = nlim + 4 * c;
+    if (act) {
+      const V3 n = ld3(&w.confr[9 * c]), t1 = ld3(&w.confr[9 * c + 3]), t2 = ld3(&w.confr[9 * c + 6]);
+      for (int side = 0; side < 2; ++side) {  // mj_jac of the contact point on body 2, minus the same on body 1 (world for ground contacts)
+        const int b = side == 0 ? b2 : b1;
+        if (b == 0) continue;
+        const V3 off = sub3(ld3(&w.conpos[3 * c]), ld3(&w.subcom[3 * body_rootid[b]]));
+        for (int d = w.lastdof[b]; d >= 0; d = dof_parentid[d]) {
+          const V3 jb = add3(ld3(&w.cdof[6 * d + 3]), cross3(ld3(&w.cdof[6 * d]), off));
+          const float sg = side == 0 ? 1.f : -1.f;
+          const float jn = sg * dot3(n, jb), jt1 = sg * dot3(t1, jb), jt2 = sg * dot3(t2, jb);
+          w.J[(size_t)(r0 + 0) * nv + d] += jn + mu * jt1;
+          w.J[(size_t)(r0 + 1) * nv + d] += jn - mu * jt1;
+          w.J[(size_t)(r0 + 2) * nv + d] += jn + mu * jt2;
+          w.J[(size_t)(r0 + 3) * nv + d] += jn - mu * jt2;
+        }
+      }
+    }
+    for (int k = 0; k < 4; ++k) finish_row(r0 + k, act, w.condist[c], iw, false);
+  }
+  // ---- com_vel: cvel, cdof_dot root -> leaf
+  for (int k = 0; k < 6; ++k) w.cvel[k] = 0.f;
+  for (int b = 1; b < nb; ++b) {
+    float v[6];
+    for (int k = 0; k < 6; ++k) v[k] = w.cvel[6 * body_parent[b] + k];
+    for (int j = body_jntadr[b]; j < body_jntadr[b] + body_jntnum[b]; ++j) {
+      const int da = jnt_dofadr[j];
+      if (jnt_type[j] == JNT_FREE) {
+        for (int d = 0; d < 3; ++d) { for (int k = 0; k < 6; ++k) { w.cdofdot[6 * (da + d) + k] = 0.f; v[k] += w.cdof[6 * (da + d) + k] * qvel[da + d]; } }
+        for (int d = 3; d < 6; ++d) cross_motion(v, &w.cdof[6 * (da + d)], &w.cdofdot[6 * (da + d)]);
+        for (int d = 3; d < 6; ++d) for (int k = 0; k < 6; ++k) v[k] += w.cdof[6 * (da + d) + k] * qvel[da + d];
+      } else {
+        cross_motion(v, &w.cdof[6 * da], &w.cdofdot[6 * da]);
+        for (int k = 0; k < 6; ++k) v[k] += w.cdof[6 * da + k] * qvel[da];
+      }
+    }
+    for (int k = 0; k < 6; ++k) w.cvel[6 * b + k] = v[k];
+  }
+  // ---- rne: cacc root -> leaf, cfrc leaf -> root, qfrc_bias; passive; actuation
+  for (int k = 0; k < 3; ++k) { w.cacc[k] = 0.f; w.cacc[3 + k] = -m.F(BF_gravity)[k]; }
+  for (int k = 0; k < 6; ++k) w.cfrc[k] = 0.f;
+  for (int b = 1; b < nb; ++b) {
+    float a[6];
+    for (int k = 0; k < 6; ++k) a[k] = w.cacc[6 * body_parent[b] + k];
+    for (int d = body_dofadr[b]; d < body_dofadr[b] + body_dofnum[b]; ++d) for (int k = 0; k < 6; ++k) a[k] += w.cdofdot[6 * d + k] * qvel[d];
+    for (int k = 0; k < 6; ++k) w.cacc[6 * b + k] = a[k];
+    float ia[6], iv[6], cf[6];
+    inert_mul(&w.cinert[10 * b], a, ia);
+    inert_mul(&w.cinert[10 * b], &w.cvel[6 * b], iv);
+    cross_force(&w.cvel[6 * b], iv, cf);
+    for (int k = 0; k < 6; ++k) w.cfrc[6 * b + k] = ia[k] + cf[k];
+  }
+  for (int b = nb - 1; b > 0; --b) for (int k = 0; k < 6; ++k) w.cfrc[6 * body_parent[b] + k] += w.cfrc[6 * b + k];
+  for (int k = 0; k < 6; ++k) w.cfrc[k] = 0.f;
+  std::fill(w.qact.begin(), w.qact.end(), 0.f);
+  for (int u = 0; u < m.nu; ++u) {
+    const int d = m.I(BI_act_dofid)[u];
+    float c = ctrl[u];
+    if (m.I(BI_act_ctrllimited)[u]) c = std::min(std::max(c, m.F(BF_act_ctrlrange)[2 * u]), m.F(BF_act_ctrlrange)[2 * u + 1]);
+    const float gear = m.F(BF_act_gear)[u];
+    const float len = gear * qpos[m.I(BI_act_qposadr)[u]], vel = gear * qvel[d];
+    float fo = m.F(BF_act_gain)[u] * c + m.F(BF_act_bias)[3 * u] + m.F(BF_act_bias)[3 * u + 1] * len + m.F(BF_act_bias)[3 * u + 2] * vel;
+    if (m.I(BI_act_forcelimited)[u]) fo = std::min(std::max(fo, m.F(BF_act_forcerange)[2 * u]), m.F(BF_act_forcerange)[2 * u + 1]);
+    w.qact[d] += fo * gear;
+  }
+  for (int d = 0; d < nv; ++d) {
+    const float* cd = &w.cdof[6 * d];
+    const float* f = &w.cfrc[6 * dof_bodyid[d]];
+    const float bias = cd[0] * f[0] + cd[1] * f[1] + cd[2] * f[2] + cd[3] * f[3] + cd[4] * f[4] + cd[5] * f[5];
+    float passive = -m.F(BF_dof_damping)[d] * qvel[d];
+    const int qa = dof_qposadr[d];
+    if (qa >= 0) {
+      const float stiff = m.F(BF_jnt_stiffness)[dof_jntid[d]];
+      if (stiff != 0.f) passive -= stiff * (qpos[qa] - m.F(BF_qpos_spring)[qa]);
+    }
+    w.bias[d] = bias;
+    w.qfs[d] = passive - bias + w.qact[d];
+  }
+  chol_solve(w.L.data(), nv, w.qfs.data(), w.qas.data());  // qacc_smooth
+  // ---- solve: CG, Polak-Ribiere, M^-1 preconditioner, bracketed Newton line search (MJX solver.py)
+  if (nefc == 0) {
+    for (int i = 0; i < nv; ++i) { w.qacc[i] = w.qas[i]; w.qfc[i] = 0.f; }
+    return comx;
+  }
+  auto matvec = [&](const float* A, int rows, const float* x, float* y) {
+    for (int r = 0; r < rows; ++r) { float s = 0.f; const float* a = A + (size_t)r * nv; for (int k = 0; k < nv; ++k) s += a[k] * x[k]; y[r] = s; }
+  };
+  float cost = 0.f, gauss = 0.f;
+  auto ctx = [&](const float* src, float& gs, float& cs) {  // Ma, Jaref, gauss, cost at qacc = src
+    for (int i = 0; i < nv; ++i) w.qacc[i] = src[i];
+    matvec(w.M.data(), nv, w.qacc.data(), w.Ma.data());
+    matvec(w.J.data(), nefc, w.qacc.data(), w.jaref.data());
+    for (int r = 0; r < nefc; ++r) w.jaref[r] -= w.aref[r];
+    gs = 0.f; cs = 0.f;
+    for (int i = 0; i < nv; ++i) gs += (w.Ma[i] - w.qfs[i]) * (w.qacc[i] - w.qas[i]);
+    for (int r = 0; r < nefc; ++r) if (w.jaref[r] < 0.f) cs += w.D[r] * w.jaref[r] * w.jaref[r];
+    gs *= 0.5f; cs = 0.5f * cs + gs;
+  };
+  float gw, cw;
+  ctx(warm, gw, cw);
+  ctx(w.qas.data(), gauss, cost);
+  if (cw < cost) ctx(warm, gauss, cost);
+  float prev_cost = INFINITY;
+  auto update_constraint_gradient = [&]() {
+    for (int r = 0; r < nefc; ++r) w.force[r] = w.jaref[r] < 0.f ? -w.D[r] * w.jaref[r] : 0.f;
+    for (int i = 0; i < nv; ++i) { float s = 0.f; for (int r = 0; r < nefc; ++r) s += w.J[(size_t)r * nv + i] * w.force[r]; w.qfc[i] = s; w.grad[i] = w.Ma[i] - w.qfs[i] - s; }
+    chol_solve(w.L.data(), nv, w.grad.data(), w.Mgrad.data());
+  };
+  update_constraint_gradient();
+  for (int i = 0; i < nv; ++i) w.search[i] = -w.Mgrad[i];
+  const float scale = m.meaninertia * (float)std::max(nv, 1);
+  for (int it = 0; it < m.iterations; ++it) {
+    float gn = 0.f;
+    for (int i = 0; i < nv; ++i) gn += w.grad[i] * w.grad[i];
+    gn = std::sqrt(gn) / scale;
+    if ((prev_cost - cost) / scale < m.tolerance || gn < m.tolerance) break;
+    // line search
+    matvec(w.M.data(), nv, w.search.data(), w.mv.data());
+    matvec(w.J.data(), nefc, w.search.data(), w.jv.data());
+    float sn = 0.f, sMa = 0.f, sq = 0.f, smv = 0.f;
+    for (int i = 0; i < nv; ++i) { sn += w.search[i] * w.search[i]; sMa += w.search[i] * w.Ma[i]; sq += w.search[i] * w.qfs[i]; smv += w.search[i] * w.mv[i]; }
+    const float gtol = m.tolerance * m.ls_tolerance * std::sqrt(sn) * scale;
+    const float qg0 = gauss, qg1 = sMa - sq, qg2 = 0.5f * smv;
+    auto eval = [&](float a) {
+      float q0 = 0.f, q1 = 0.f, q2 = 0.f;
+      for (int r = 0; r < nefc; ++r) {
+        const float ja = w.jaref[r], v = w.jv[r], d = w.D[r];
+        if (ja + a * v < 0.f) { q0 += 0.5f * ja * ja * d; q1 += v * ja * d; q2 += 0.5f * v * v * d; }
+      }
+      return ls_make(a, q0 + qg0, q1 + qg1, q2 + qg2);
+    };
+    const LsPoint p0 = eval(0.f);
+    LsPoint lo = eval(p0.alpha - p0.d0 / p0.d1), hi;
+    if (lo.d0 < p0.d0) hi = p0; else { hi = lo; lo = p0; }
+    bool swap = true;
+    for (int li = 0; li < m.ls_iterations; ++li) {
+      if (!swap || (lo.d0 < 0.f && lo.d0 > -gtol) || (hi.d0 > 0.f && hi.d0 < gtol)) break;
+      const LsPoint lo_next = eval(lo.alpha - lo.d0 / lo.d1), hi_next = eval(hi.alpha - hi.d0 / hi.d1), mid = eval(0.5f * (lo.alpha + hi.alpha));
+      LsPoint nlo = lo, nhi = hi;
+      const bool s1 = in_bracket(nlo, lo_next); if (s1) nlo = lo_next;
+      const bool s2 = in_bracket(nlo, mid);     if (s2) nlo = mid;
+      const bool s3 = in_bracket(nlo, hi_next); if (s3) nlo = hi_next;
+      const bool s4 = in_bracket(nhi, hi_next); if (s4) nhi = hi_next;
+      const bool s5 = in_bracket(nhi, mid);     if (s5) nhi = mid;
+      const bool s6 = in_bracket(nhi, lo_next); if (s6) nhi = lo_next;
+      lo = nlo; hi = nhi; swap = s1 || s2 || s3 || s4 || s5 || s6;
+    }
+    if (lo.cost < p0.cost || hi.cost < p0.cost) {
+      const float alpha = lo.cost < hi.cost ? lo.alpha : hi.alpha;
+      for (int i = 0; i < nv; ++i) { w.qacc[i] += alpha * w.search[i]; w.Ma[i] += alpha * w.mv[i]; }
+      for (int r = 0; r < nefc; ++r) w.jaref[r] += alpha * w.jv[r];
+    }
+    // update_constraint, update_gradient, Polak-Ribiere
+    float gs = 0.f, cs = 0.f, pgm = 0.f;
+    for (int i = 0; i < nv; ++i) { w.t1[i] = w.Mgrad[i]; pgm += w.grad[i] * w.Mgrad[i]; gs += (w.Ma[i] - w.qfs[i]) * (w.qacc[i] - w.qas[i]); }
+    for (int r = 0; r < nefc; ++r) if (w.jaref[r] < 0.f) cs += w.D[r] * w.jaref[r] * w.jaref[r];
+    prev_cost = cost; gauss = 0.5f * gs; cost = 0.5f * cs + gauss;
+    update_constraint_gradient();
+    float num = 0.f;
+    for (int i = 0; i < nv; ++i) num += w.grad[i] * (w.Mgrad[i] - w.t1[i]);
+    const float beta = std::max(0.f, num / std::max(MJ_MINVAL, pgm));
+    for (int i = 0; i < nv; ++i) w.search[i] = -w.Mgrad[i] + beta * w.search[i];
+  }
+  return comx;
+}
+
+inline bool any_nan(const float* p, int n) { for (int i = 0; i < n; ++i) if (std::isnan(p[i])) return true; return false; }
+
+}  // namespace
+
+extern "C" {
+
+struct twin_metrics {  // = mppo_env_metrics_t
+  float* episode_returns; int32_t* episode_lengths; float* returned_episode_returns; int32_t* returned_episode_lengths; int32_t* timestep; uint8_t* returned_episode;
+};
+
+void* twin_model_open(const void* host_blob, size_t nbytes) {
+  const int32_t* wi = static_cast<const int32_t*>(host_blob);
+  const uint32_t* wu = static_cast<const uint32_t*>(host_blob);
+  const float* wf = static_cast<const float*>(host_blob);
+  if (nbytes < 4 * (size_t)kBlobHeaderWords || wu[0] != kBlobMagic || wu[1] != kBlobVersion || wi[32] != BLOB_ARRAY_COUNT || (size_t)wu[2] * 4 != nbytes) return nullptr;
+  Model* m = new Model();
+  m->blob.assign(wi, wi + nbytes / 4);
+  m->nq = wi[3]; m->nv = wi[4]; m->nu = wi[5]; m->nb = wi[6]; m->njnt = wi[7]; m->ncon = wi[8]; m->nlim = wi[9]; m->iterations = wi[10]; m->ls_iterations = wi[11];
+  m->nroot = wi[13]; m->include_c = wi[14] ? 1 : 0; m->npair = wi[15]; m->ncvx = wi[33];
+  m->nefc = m->nlim + 4 * m->ncon;
+  m->timestep = wf[16]; m->tolerance = wf[17]; m->ls_tolerance = wf[18]; m->impratio = wf[19]; m->plane_z = wf[20]; m->meaninertia = wf[21];
+  for (int k = 0; k < BLOB_ARRAY_COUNT; ++k) m->off[k] = wi[kBlobHeaderWords + 2 * k];
+  m->obs_dim = m->nq + 2 * m->nv + (m->include_c ? 16 * (m->nb - 1) : 0);
+  m->obs_pad = (m->obs_dim + 3) & ~3;
+  m->rec_dim = m->obs_pad + ((m->nv + 2 + 3) & ~3);
+  return m;
+}
+void twin_model_close(void* h) { delete static_cast<Model*>(h); }
+void twin_model_dims(const void* h, int32_t* out8) {
+  const Model& m = *static_cast<const Model*>(h);
+  out8[0] = m.nq; out8[1] = m.nv; out8[2] = m.nu; out8[3] = m.nb; out8[4] = m.obs_dim; out8[5] = m.obs_pad; out8[6] = m.rec_dim; out8[7] = m.nefc;
+}
+int twin_threads(void) {
+#ifdef _OPENMP
+  return omp_get_max_threads();
+#else
+  return 1;
+#endif
+}
+
+// state record of the reset state (pipeline_init of qpos0, qvel = 0, ctrl = 0: env.py:115-121 with reset_noise_scale = 0)
+static void reset_record(const Model& m, Work& w, float* rec) {
+  const int nq = m.nq, nv = m.nv, nb = m.nb, O = m.obs_dim, OP = m.obs_pad;
+  std::vector<float> qvel(nv, 0.f), ctrl(std::max(m.nu, 1), 0.f), warm(nv, 0.f);
+  const float comx = forward(m, w, m.F(BF_qpos0), qvel.data(), ctrl.data(), warm.data());
+  std::fill(rec, rec + m.rec_dim, 0.f);
+  std::copy(m.F(BF_qpos0), m.F(BF_qpos0) + nq, rec);
+  int o = nq + nv;
+  if (m.include_c) {
+    std::copy(w.cinert.begin() + 10, w.cinert.begin() + 10 * nb, rec + o); o += 10 * (nb - 1);
+    std::copy(w.cvel.begin() + 6, w.cvel.begin() + 6 * nb, rec + o); o += 6 * (nb - 1);
+  }
+  std::copy(w.qact.begin(), w.qact.end(), rec + o);
+  (void)O;
+  std::copy(w.qacc.begin(), w.qacc.end(), rec + OP);  // qacc_warmstart <- qacc of the forward pass
+  rec[OP + nv] = comx;
+  rec[OP + nv + 1] = 0.f;
+}
+
+void twin_env_reset(const void* h, int32_t N, float* state, float* reset_rec, float* obs, int32_t obs_ld, const twin_metrics* met) {
+  const Model& m = *static_cast<const Model*>(h);
+  Work w(m);
+  reset_record(m, w, reset_rec);
+#pragma omp parallel for schedule(static)
+  for (int e = 0; e < N; ++e) {
+    std::copy(reset_rec, reset_rec + m.rec_dim, state + (size_t)e * m.rec_dim);
+    if (obs) std::copy(reset_rec, reset_rec + m.obs_pad, obs + (size_t)e * obs_ld);
+    if (met && met->episode_returns) {
+      met->episode_returns[e] = 0.f; met->episode_lengths[e] = 0; met->returned_episode_returns[e] = 0.f; met->returned_episode_lengths[e] = 0;
+      met->timestep[e] = 0; met->returned_episode[e] = 0;
+    }
+  }
+}
+
+// HumanoidEnv.step for N environments (env.py:148-196), one environment per thread
+void twin_env_step(const void* h, int32_t N, int32_t n_frames, const RewardCfg* rcp, float* state, const float* reset_rec, const float* action, int32_t act_ld,
+                   float* obs, int32_t obs_ld, float* reward, uint8_t* done, const twin_metrics* met) {
+  const Model& m = *static_cast<const Model*>(h);
+  const RewardCfg rc = *rcp;
+  const int nq = m.nq, nv = m.nv, nb = m.nb, OP = m.obs_pad, R = m.rec_dim;
+  const float hstep = m.timestep;
+#pragma omp parallel
+  {
+    Work w(m);
+    std::vector<float> qpos(nq), qvel(nv), warm(nv), rhs(nv), qe(nv);
+#pragma omp for schedule(static)
+    for (int e = 0; e < N; ++e) {
+      float* rec = state + (size_t)e * R;
+      const float* act = action + (size_t)e * act_ld;
+      std::copy(rec, rec + OP, obs + (size_t)e * obs_ld);  // get_obs of the PRE-step state (env.py:163)
+      std::copy(rec, rec + nq, qpos.begin()); std::copy(rec + nq, rec + nq + nv, qvel.begin()); std::copy(rec + OP, rec + OP + nv, warm.begin());
+      float p0 = 0.f;
+      for (int i = 0; i < nq; ++i) { const float d = m.F(BF_qpos0)[i] - qpos[i]; p0 += d * d; }
+      p0 = std::sqrt(p0);
+      const float pre_z = qpos[2], pre_comx = rec[OP + nv], time_in = rec[OP + nv + 1];
+      float comx = 0.f;
+      bool bad = false;
+      for (int f = 0; f < n_frames; ++f) {
+        comx = forward(m, w, qpos.data(), qvel.data(), act, warm.data());
+        bad = bad || any_nan(w.cinert.data(), 10 * nb) || any_nan(w.cvel.data(), 6 * nb) || any_nan(w.qact.data(), nv) || any_nan(w.xpos.data(), 3 * nb) ||
+              any_nan(w.xquat.data(), 4 * nb) || any_nan(w.qfc.data(), nv);
+        // euler: implicit joint damping, semi-implicit integration
+        for (int i = 0; i < nv; ++i) rhs[i] = w.qfs[i] + w.qfc[i];
+        std::copy(w.M.begin(), w.M.end(), w.Le.begin());
+        for (int i = 0; i < nv; ++i) w.Le[i * nv + i] += hstep * m.F(BF_dof_damping)[i];
+        cholesky(w.Le.data(), w.Le.data(), nv);
+        chol_solve(w.Le.data(), nv, rhs.data(), qe.data());
+        for (int i = 0; i < nv; ++i) { qvel[i] += hstep * qe[i]; warm[i] = w.qacc[i]; }
+        for (int j = 0; j < m.njnt; ++j) {
+          const int qa = m.I(BI_jnt_qposadr)[j], da = m.I(BI_jnt_dofadr)[j];
+          if (m.I(BI_jnt_type)[j] == JNT_FREE) {
+            for (int k = 0; k < 3; ++k) qpos[qa + k] += hstep * qvel[da + k];
+            const V3 wv = ld3(&qvel[da + 3]);
+            const float n = std::sqrt(dot3(wv, wv));
+            const V3 ax = n > 0.f ? mul3(wv, 1.f / n) : wv;
+            st4(&qpos[qa + 3], qnormalize(qmul(ld4(&qpos[qa + 3]), axis_angle(ax, n * hstep))));
+          } else {
+            qpos[qa] += hstep * qvel[da];
+          }
+        }
+      }
+      // reward (env.py:199-235: pose and height of the PRE-step state), done (post-step height, NaN guard)
+      float asq = 0.f;
+      for (int i = 0; i < m.nu; ++i) asq += act[i] * act[i];
+      const float pos_r = std::exp(-rc.exp_coefficient * p0) - rc.subtraction_factor * std::min(std::max(p0, 0.f), rc.max_diff_norm);
+      float healthy = pre_z < rc.height_min_z ? 0.f : 1.f;
+      healthy = pre_z > rc.height_max_z ? 0.f : healthy;
+      const float dt_env = hstep * (float)n_frames;
+      const float rew = rc.w_ctrl_cost * (-asq) + rc.w_original_pos * pos_r + rc.w_velocity * ((comx - pre_comx) / dt_env) + rc.w_is_healthy * healthy;
+      const float z = qpos[2];
+      bad = bad || any_nan(qpos.data(), nq) || any_nan(qvel.data(), nv) || any_nan(warm.data(), nv) || std::isnan(comx);
+      const bool dn = !(rc.height_min_z < z && z < rc.height_max_z) || bad;
+      if (dn) {
+        std::copy(reset_rec, reset_rec + R, rec);
+        std::copy(reset_rec, reset_rec + OP, obs + (size_t)e * obs_ld);
+      } else {
+        std::fill(rec, rec + R, 0.f);
+        std::copy(qpos.begin(), qpos.end(), rec); std::copy(qvel.begin(), qvel.end(), rec + nq);
+        int o = nq + nv;
+        if (m.include_c) {
+          std::copy(w.cinert.begin() + 10, w.cinert.begin() + 10 * nb, rec + o); o += 10 * (nb - 1);
+          std::copy(w.cvel.begin() + 6, w.cvel.begin() + 6 * nb, rec + o); o += 6 * (nb - 1);
+        }
+        std::copy(w.qact.begin(), w.qact.end(), rec + o);
+        std::copy(warm.begin(), warm.end(), rec + OP);
+        rec[OP + nv] = comx; rec[OP + nv + 1] = time_in + dt_env;
+      }
+      reward[e] = rew; done[e] = dn ? 1 : 0;
+      if (met && met->episode_returns) {
+        const float nd = dn ? 0.f : 1.f;
+        const int ndi = dn ? 0 : 1;
+        const float new_ret = met->episode_returns[e] + rew;
+        const int new_len = met->episode_lengths[e] + 1;
+        met->episode_returns[e] = new_ret * nd; met->episode_lengths[e] = new_len * ndi;
+        met->returned_episode_returns[e] = met->returned_episode_returns[e] * nd + new_ret * (dn ? 1.f : 0.f);
+        met->returned_episode_lengths[e] = met->returned_episode_lengths[e] * ndi + new_len * (dn ? 1 : 0);
+        met->timestep[e] += 1; met->returned_episode[e] = dn ? 1 : 0;
+      }
+    }
+  }
+}
+
+}  // extern "C"

@@ -620,8 +620,10 @@ def test_env_step_matches_env_oracle(be, model, n_frames, c_vals):
 
 
 @pytest.mark.gpu
-def test_env_step_properties_at_full_size():
-    """BASELINE configs[1] size (4096 envs) through the C ABI: size-independent properties of `HumanoidEnv.step`
+@pytest.mark.parametrize("N", [4096, 8192, 12288])
+def test_env_step_properties_at_full_size(N):
+    """BASELINE configs[1] size (4096 envs; and 8192 / 12288: more workgroups than the chip holds at once, two waves per SIMD where the kernel's
+    registers allow it) through the C ABI: size-independent properties of `HumanoidEnv.step`
     (reference env.py:148-196).  (i) Environments are independent and the kernel is a pure function of (state, action):
     permuting the environments permutes every output, bit for bit - whatever lane group / wave / workgroup an environment
     lands in.  (ii) Identical states + identical actions give identical results in all 4096 slots.  (iii) An environment
@@ -631,7 +633,7 @@ def test_env_step_properties_at_full_size():
     be = get_backend("hip")
     cm = load_model("synth_stompy_pro")
     h, dims, _keep = be.model(cm)
-    N, OP, R, nu, nv, nq = 4096, dims.obs_pad, dims.rec_dim, cm.nu, cm.nv, cm.nq
+    OP, R, nu, nv, nq = dims.obs_pad, dims.rec_dim, cm.nu, cm.nv, cm.nq
     met_np = dict(episode_returns=f32, episode_lengths=np.int32, returned_episode_returns=f32, returned_episode_lengths=np.int32, timestep=np.int32,
                   returned_episode=np.uint8)
     rc = nat.RewardCfg(-0.2, 2.0, 2.0, 0.2, 0.5, 0.1, 4.0, 1.0, 1.25)

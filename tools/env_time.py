@@ -11,7 +11,11 @@ from minppo_amd.model import load_model
 lib = nat.load()
 print("library:", lib.path)
 only = sys.argv[2] if len(sys.argv) > 2 else None  # restrict to one model (needed for single-model experiment builds)
-for model, N in (("synth_stompy_pro", 4096), ("synth_stompy_full", 8192)):
+import os
+cases = [("synth_stompy_pro", 4096), ("synth_stompy_full", 8192)]
+if os.environ.get("MPPO_ENV_TIME_CASES"):  # e.g. "synth_stompy_pro:8192,synth_stompy_pro:16384"
+    cases = [(c.split(":")[0], int(c.split(":")[1])) for c in os.environ["MPPO_ENV_TIME_CASES"].split(",")]
+for model, N in cases:
     if only and model != only:
         continue
     cm = load_model(model)
@@ -23,8 +27,9 @@ for model, N in (("synth_stompy_pro", 4096), ("synth_stompy_full", 8192)):
     state = torch.zeros(N, dims.rec_dim, device="cuda"); reset = torch.zeros(dims.rec_dim, device="cuda")
     obs = torch.zeros(N, dims.obs_pad, device="cuda")
     s = torch.cuda.current_stream().cuda_stream
-    met = nat.EnvMetrics(*[t.data_ptr() for t in (torch.zeros(N, device="cuda"), torch.zeros(N, dtype=torch.int32, device="cuda"), torch.zeros(N, device="cuda"),
-                                                   torch.zeros(N, dtype=torch.int32, device="cuda"), torch.zeros(N, dtype=torch.int32, device="cuda"), torch.zeros(N, dtype=torch.uint8, device="cuda"))])
+    met_keep = (torch.zeros(N, device="cuda"), torch.zeros(N, dtype=torch.int32, device="cuda"), torch.zeros(N, device="cuda"),
+                torch.zeros(N, dtype=torch.int32, device="cuda"), torch.zeros(N, dtype=torch.int32, device="cuda"), torch.zeros(N, dtype=torch.uint8, device="cuda"))
+    met = nat.EnvMetrics(*[t.data_ptr() for t in met_keep])  # (the tensors must outlive the launches: the kernel writes the episode metrics through these pointers)
     lib.env_reset(h, N, state.data_ptr(), reset.data_ptr(), obs.data_ptr(), dims.obs_pad, 0, 0, C.byref(met), s)
     g = torch.Generator(device="cuda"); g.manual_seed(0)
     acts = [torch.randn(N, dims.nu, device="cuda", generator=g) for _ in range(10)]
