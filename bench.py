@@ -119,6 +119,31 @@ def rowpass_probe(tr, launches: int = 64, replays: int = 4):
     return sec, flops, f"fused_mlp_kernel: row pass of one minibatch (mb={mb}, O={O}, H={H}, A={A}, actor+critic; {'bf16 MFMA 16x16x16, f32 accumulate' if tr.net.bf16 else 'f32 MFMA 16x16x4'})"
 
 
+def _usable_cores() -> int:
+    """Host cores this process may actually use: the scheduler affinity mask and the cgroup CPU quota (a GPU box hands a container the
+    CPU share of its GPUs - 16 cores per GPU on this pool - while os.cpu_count() still reports every core of the machine)."""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except (AttributeError, OSError):
+        pass
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(int(txt[0]) / int(txt[1]) + 0.5)))
+            else:
+                q = int(txt[0])
+                if q > 0:
+                    per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                    n = min(n, max(1, int(q / per + 0.5)))
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    return max(1, n)
+
+
 def _cpu_baseline_worker(config_name: str, overrides, n_envs: int, updates: int) -> dict:
     """Runs in a fresh interpreter without a GPU: `updates` + 1 whole updates (rollout + PPO update) of the CPU restatement - the environment
     step by the C++17 / OpenMP float32 twin (oracle/cpu_twin/env_twin.cpp: one environment per thread, all host cores, -O3 -march=native,
@@ -133,11 +158,11 @@ def _cpu_baseline_worker(config_name: str, overrides, n_envs: int, updates: int)
     from oracle.cpu_twin import Twin, ppo_torch as pt
     from oracle.env_oracle import default_hp
 
-    cores = os.cpu_count() or 1
+    cores = int(os.environ.get("MPPO_BENCH_CPU_THREADS", "0")) or _usable_cores()
     torch.set_num_threads(cores)
     cfg = load_config_from_cli([config_name, f"training.num_envs={n_envs}", *overrides])
     cm = load_model(cfg.environment.model or cfg.kscale_id)
-    tw = Twin(cm, include_c_vals=bool(cfg.environment.include_c_vals))
+    tw = Twin(cm, include_c_vals=bool(cfg.environment.include_c_vals), threads=cores)
     N, T, A, H, M, E = n_envs, cfg.training.num_steps, cm.nu, cfg.model.hidden_size, cfg.training.num_minibatches, cfg.training.update_epochs
     O = tw.obs_dim
     named = po.init_params(cfg.training.seed, O, A, H, np.float32)
@@ -149,7 +174,9 @@ def _cpu_baseline_worker(config_name: str, overrides, n_envs: int, updates: int)
     times, rollout_s = [], []
     mean_reward = 0.0
     u = 0
-    while True:  # one warm-up update, then at least `updates` and at least ~10 s of timed updates (at most 40)
+    while True:  # one warm-up update, then ~10 s of timed updates: at least `updates` of them (one, if an update takes more than 15 s), at most 40
+        if u >= 2 and times[0] > 15.0:
+            break
         if u >= updates + 1 and (sum(times[1:]) >= 10.0 or u >= 41):
             break
         u += 1
@@ -165,7 +192,7 @@ def _cpu_baseline_worker(config_name: str, overrides, n_envs: int, updates: int)
         tw.step(a_)
     env_ms = 1e3 * (time.perf_counter() - t0) / len(acts)
     dt = float(np.mean(times[1:]))
-    return {"seconds_per_update": dt, "env_step_ms": env_ms, "omp_threads": tw.threads, "torch_threads": torch.get_num_threads(), "host_cores": cores, "N": N, "T": T,
+    return {"seconds_per_update": dt, "env_step_ms": env_ms, "omp_threads": tw.threads, "torch_threads": torch.get_num_threads(), "host_cores": os.cpu_count() or 1, "usable_cores": cores, "N": N, "T": T,
             "E": E, "M": M, "updates_timed": len(times) - 1, "mean_reward": mean_reward, "finite": bool(all(torch.isfinite(v).all() for v in p.values()))}
 
 
@@ -181,7 +208,11 @@ def cpu_baseline(config_name: str, overrides, n_envs: int):
     env = {k: v for k, v in os.environ.items() if k not in ("OMP_NUM_THREADS", "MKL_NUM_THREADS", "OPENBLAS_NUM_THREADS")}
     env.update(HIP_VISIBLE_DEVICES="", ROCR_VISIBLE_DEVICES="", OMP_PROC_BIND="false")
     updates = int(os.environ.get("MPPO_BENCH_CPU_UPDATES", "3"))
-    r = subprocess.run([sys.executable, "-c", code, config_name, json.dumps(list(overrides)), str(n_envs), str(updates)], env=env, capture_output=True, text=True, timeout=900)
+    try:
+        r = subprocess.run([sys.executable, "-c", code, config_name, json.dumps(list(overrides)), str(n_envs), str(updates)], env=env, capture_output=True, text=True,
+                           timeout=float(os.environ.get("MPPO_BENCH_CPU_TIMEOUT", "150")))
+    except subprocess.TimeoutExpired:
+        return {"value": None, "unit": "env-steps/s", "cores": _usable_cores(), "kind": "port", "sample": "the CPU restatement did not finish its bounded sample within the time limit"}
     if r.returncode != 0:
         raise RuntimeError("the CPU-baseline worker failed:\n" + r.stderr[-2000:])
     w = json.loads(r.stdout.strip().splitlines()[-1])
@@ -191,7 +222,7 @@ def cpu_baseline(config_name: str, overrides, n_envs: int):
             "sample": f"{w['updates_timed']} whole updates (after one warm-up update) at {w['N']} envs x {w['T']} steps + {w['E']}x{w['M']} minibatch steps: "
                       f"{w['seconds_per_update']:.3f} s per update, of which the {w['T']} environment steps {w['T'] * w['env_step_ms'] / 1e3:.3f} s "
                       f"({w['env_step_ms']:.1f} ms per step of {w['N']} envs on {w['omp_threads']} OpenMP threads; torch: {w['torch_threads']} threads)",
-            "host_cores": int(w["host_cores"]), "sanity": {"mean_reward": w["mean_reward"], "finite": w["finite"]}}
+            "host_cores": int(w["host_cores"]), "usable_cores": int(w["usable_cores"]), "sanity": {"mean_reward": w["mean_reward"], "finite": w["finite"]}}
 
 
 def spawn_ranks(args: argparse.Namespace) -> int:
@@ -484,6 +515,16 @@ def main() -> None:
             if key:
                 traffic = k[key]["hbm_bytes_per_launch"]
                 traffic_src = f"profiles/{tfs[-1].name} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, gfx950 corrections)"
+        # matrix-core utilisation of the same kernel from SQ counters (tools/pmc_mlp.sh: rocprofv3 --pmc passes of their own): the newest
+        # committed summary; MFMA-busy cycles / (1024 SIMD pipes x launch duration x 2.4 GHz)
+        mfma_busy, mfma_src = None, None
+        pfs = sorted((ROOT / "profiles").glob("r*_mlp_pmc.json"))
+        if pfs and args.config == "stompy_pro" and args.envs_per_gpu == 4096:
+            kk = json.loads(pfs[-1].read_text())["kernels"]
+            name = "fused_mlp_kernel<true, false, 1, true, true>" if bf16 else "fused_mlp_kernel<false, false, 1, true, true>"
+            if name in kk and "mfma_busy_frac" in kk[name]:
+                mfma_busy = kk[name]["mfma_busy_frac"]
+                mfma_src = f"profiles/{pfs[-1].name} (SQ_VALU_MFMA_BUSY_CYCLES over 1024 SIMD pipes x the launch's duration under the counter pass x 2.4 GHz)"
         out = {
             "metric": ("env-steps/sec (whole node), stompy_pro 4096 envs, 1/2/4/8 MI355X" if args.config == "stompy_pro" and args.envs_per_gpu == 4096
                        else f"env-steps/sec (whole node), {args.config} {args.envs_per_gpu} envs per GPU, {world} MI355X"),
@@ -506,13 +547,13 @@ def main() -> None:
                        "hipgraph": bool(tr.graph_active()),
                        "pre_warm": f"{pre_warm_s:.1f} s of unrelated device work before the {args.warmup} warm-up steps (one-time start-up stall of the device, see bench.py)"},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
-                         "traffic": traffic, "traffic_unit": "bytes/launch", "traffic_source": traffic_src, "kernel": desc, "us_per_launch": sec * 1e6,
+                         "traffic": traffic, "traffic_unit": "bytes/launch", "traffic_source": traffic_src, "mfma_busy_frac": mfma_busy, "mfma_busy_source": mfma_src, "kernel": desc, "us_per_launch": sec * 1e6,
                          "whole_update_mlp_tflops": (26.0 * (2 * tr.O * tr.H + 2 * tr.H * tr.H + tr.H * (tr.A + 1)) + 0.2 * (tr.O * tr.H + tr.H * tr.H + tr.H)) * steps_total / world / dt / 1e12},
             "sanity": {"mean_reward": stats["mean_reward"], "done_fraction": stats["done_fraction"], "mean_total_loss": float(lossm[0])},
         }
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(args.config, args.set, args.cpu_baseline_envs)
-            out["cpu_baseline"]["engine_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]  # (reported, not a target: the roofline fraction is what describes the kernels)
+            out["cpu_baseline"]["engine_over_cpu"] = out["value"] / out["cpu_baseline"]["value"] if out["cpu_baseline"]["value"] else None  # (reported, not a target: the roofline fraction is what describes the kernels)
         else:
             out["cpu_baseline"] = None
     tr.close()

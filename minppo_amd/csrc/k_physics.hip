@@ -67,10 +67,6 @@ struct EnvArgs {
 // not change.  kDotU is a constant of the enclosing function (model-specialised kernels: by the number of dofs; run-time-sized: 8).
 #define DOT_UNROLL _Pragma("unroll kDotU")
 constexpr int dot_unroll(int nv_static) { return nv_static == 0 ? MPPO_DOT_UNROLL_RT : nv_static <= 16 ? 16 : 32; }
-// solver matrices of robots up to 16 dofs in registers (A/B builds: -DMPPO_SOLVER_REGS=0 / 1; see the factorisation section)
-#ifndef MPPO_SOLVER_REGS
-#define MPPO_SOLVER_REGS 1
-#endif
 // the instruction scheduler moves nothing across this point
 #ifdef MPPO_EMU
 #define SCHED_FENCE() do { } while (0)
@@ -640,17 +636,9 @@ __global__ void __launch_bounds__(64 * kMaxWavesPerBlock) env_kernel(ModelView m
     constexpr int NVc = kRegChol ? kSD.nv : 1;
     constexpr int RC = (NVc + kGroupLanes - 1) / kGroupLanes;  // rows (and, in the inverse, columns) per lane
     float Lrow[RC][NVc], Lcol[RC][NVc];  // Linv[i][k] of this lane's rows i / Linv[k][c] of its columns c (entries outside the triangle: 0)
-    // Up to 16 dofs (one row per lane) the solver's two matrices live in registers as well: this lane's row of M, its rows of the
-    // contact Jacobian (row products J x) and its column (J^T f).  The CG iteration then reads only VECTORS from LDS - half the LDS
-    // instructions of an iteration, the same products term by term.
-    constexpr bool kSolverRegs = MPPO_SOLVER_REGS && kRegChol && NVc <= kGroupLanes;
-    constexpr int NRC = kSolverRegs ? 4 * kSD.ncon : 1;                       // contact rows
-    constexpr int RJ = (NRC + kGroupLanes - 1) / kGroupLanes;                 // ... per lane
-    float Mrow[kSolverRegs ? NVc : 1], Jrow[RJ][kSolverRegs ? NVc : 1], Jcol[NRC];
     int ir[RC];       // this lane's rows; a surplus slot shadows the last row and never publishes
     bool own[RC];
     _Pragma("unroll") for (int q = 0; q < RC; ++q) { const int i = g + kGroupLanes * q; own[q] = i < NVc; ir[q] = own[q] ? i : NVc - 1; }
-    if (kSolverRegs) { _Pragma("unroll") for (int k = 0; k < NVc; ++k) Mrow[k] = M[ir[0] * ldm + k]; }
     // x = (L L^T)^-1 b with the factor in registers: the same two masked full-length products as solve_linv, the operand vector read
     // once for all of a lane's rows
     auto solve_regs = [&](const float* bvec, float* tmp, float* x) {
@@ -684,7 +672,7 @@ __global__ void __launch_bounds__(64 * kMaxWavesPerBlock) env_kernel(ModelView m
         const int i = ir[q];
         const float hd = eul ? h * TF(dof_damping)[i] : 0.f;
         _Pragma("unroll") for (int k = 0; k < NVc; ++k) {
-          const float v = kSolverRegs ? Mrow[k] : M[i * ldm + k];
+          const float v = M[i * ldm + k];
           c[q][k] = (eul && k == i) ? v + hd : v;
         }
       }
@@ -995,37 +983,6 @@ __global__ void __launch_bounds__(64 * kMaxWavesPerBlock) env_kernel(ModelView m
       DOT_UNROLL for (int k = 0; k < nv; ++k) s += M[i * ldm + k] * x[k];
       return s;
     };
-    if (kSolverRegs) {  // the finished Jacobian into registers: rows for J x, this dof's column for J^T f
-      _Pragma("unroll") for (int j = 0; j < RJ; ++j) {
-        const int rc = g + kGroupLanes * j, rr = rc < NRC ? rc : NRC - 1;
-        _Pragma("unroll") for (int k = 0; k < NVc; ++k) Jrow[j][k] = J[rr * ldj + k];
-      }
-      _Pragma("unroll") for (int r = 0; r < NRC; ++r) Jcol[r] = J[r * ldj + ir[0]];
-    }
-    // contact rows times an nv-vector held in registers (one read of the vector for all of a lane's rows; the run-time-sized and the
-    // larger kernels go through jrow_dot); sink(rc, value) for every contact row rc of this lane
-    auto jrows_regs = [&](const float (&xr)[NVc], auto&& sink) {
-      _Pragma("unroll") for (int j = 0; j < RJ; ++j) {
-        const int rc = g + kGroupLanes * j;
-        float sacc = 0.f;
-        _Pragma("unroll") for (int k = 0; k < NVc; ++k) sacc += Jrow[j][kSolverRegs ? k : 0] * xr[k];
-        if (rc < NRC) sink(rc, sacc);
-      }
-    };
-    auto mrow_regs = [&](const float (&xr)[NVc], float* out) {
-      float sacc = 0.f;
-      _Pragma("unroll") for (int k = 0; k < NVc; ++k) sacc += Mrow[kSolverRegs ? k : 0] * xr[k];
-      if (own[0]) out[ir[0]] = sacc;
-    };
-    // column i of the Jacobian times an nefc-vector, limit row first (jcol_dot's order); i = this lane's dof
-    auto jcol_regs = [&](const float* f) {
-      float fr[NRC];
-      _Pragma("unroll") for (int r = 0; r < NRC; ++r) fr[r] = f[nlim + r];
-      float sacc = 0.f;
-      if (nlim > 0) { const int dl = dlim[ir[0]]; sacc = lim_sign(dl) * f[lim_row(dl)]; }
-      _Pragma("unroll") for (int r = 0; r < NRC; ++r) sacc += Jcol[r] * fr[r];
-      return sacc;
-    };
     auto row_params = [&](int r, float s) {
       const float pos = jv[r], iw = jaref[r];
       const bool act = iw > 0.f;  // inactive rows are inert: J = 0, aref = 0, D = 0
@@ -1036,14 +993,7 @@ __global__ void __launch_bounds__(64 * kMaxWavesPerBlock) env_kernel(ModelView m
       eD[r] = act ? 1.f / R : 0.f;
       earef[r] = act ? -b * s - k * imp * pos : 0.f;
     };
-    if constexpr (kSolverRegs) {
-      float xr[NVc];
-      _Pragma("unroll") for (int k = 0; k < NVc; ++k) xr[k] = qvel[k];
-      FOR_G(r, nlim) row_params(r, jrow_dot(r, qvel));
-      jrows_regs(xr, [&](int rc, float sv) { row_params(nlim + rc, sv); });
-    } else {
-      FOR_G(r, nefc) row_params(r, jrow_dot(r, qvel));
-    }
+    FOR_G(r, nefc) row_params(r, jrow_dot(r, qvel));
     SYNC();
     PT(11);
     // ================= solve: CG (Polak-Ribiere, M^-1 preconditioner) =====================================
@@ -1059,18 +1009,10 @@ __global__ void __launch_bounds__(64 * kMaxWavesPerBlock) env_kernel(ModelView m
         if (take) FOR_G(i, nv) qacc[i] = src[i];
         SYNC();
         if (take) {
-          if constexpr (kSolverRegs) {
-            float xr[NVc];
-            _Pragma("unroll") for (int k = 0; k < NVc; ++k) xr[k] = qacc[k];
-            mrow_regs(xr, Ma);
-            FOR_G(r, nlim) jaref[r] = jrow_dot(r, qacc) - earef[r];
-            jrows_regs(xr, [&](int rc, float sv) { jaref[nlim + rc] = sv - earef[nlim + rc]; });
-          } else {
-            FOR_G(i, nv) Ma[i] = mrow_dot(i, qacc);
-            // (limit rows and contact rows in loops of their own: 16 lanes on 16 dense rows at a time, not on a mixture)
-            FOR_G(r, nlim) jaref[r] = jrow_dot(r, qacc) - earef[r];
-            FOR_G(rc, 4 * ncon) jaref[nlim + rc] = jrow_dot(nlim + rc, qacc) - earef[nlim + rc];
-          }
+          FOR_G(i, nv) Ma[i] = mrow_dot(i, qacc);
+          // (limit rows and contact rows in loops of their own: 16 lanes on 16 dense rows at a time, not on a mixture)
+          FOR_G(r, nlim) jaref[r] = jrow_dot(r, qacc) - earef[r];
+          FOR_G(rc, 4 * ncon) jaref[nlim + rc] = jrow_dot(nlim + rc, qacc) - earef[nlim + rc];
         }
         SYNC();
         float gs = 0.f, cs = 0.f;
@@ -1108,8 +1050,7 @@ __global__ void __launch_bounds__(64 * kMaxWavesPerBlock) env_kernel(ModelView m
       // update_constraint + update_gradient at the starting point
       FOR_G(r, nefc) { const float x = jaref[r]; force[r] = x < 0.f ? -eD[r] * x : 0.f; }
       SYNC();
-      if constexpr (kSolverRegs) { const float s = jcol_regs(force); if (own[0]) { const int i = ir[0]; qfc[i] = s; grad[i] = Ma[i] - qfs[i] - s; } }
-      else FOR_G(i, nv) { const float s = jcol_dot(i, force); qfc[i] = s; grad[i] = Ma[i] - qfs[i] - s; }
+      FOR_G(i, nv) { const float s = jcol_dot(i, force); qfc[i] = s; grad[i] = Ma[i] - qfs[i] - s; }
       SYNC();
       solveL(std::false_type{}, grad, t0, Mgrad);
       FOR_G(i, nv) search[i] = -Mgrad[i];
@@ -1125,17 +1066,9 @@ __global__ void __launch_bounds__(64 * kMaxWavesPerBlock) env_kernel(ModelView m
         PT(13 + (it < 6 ? it : 6));
         // ---------------- line search ----------------
         float sn = 0.f, sMa = 0.f, sq = 0.f;
-        if constexpr (kSolverRegs) {
-          float xr[NVc];
-          _Pragma("unroll") for (int k = 0; k < NVc; ++k) xr[k] = search[k];
-          mrow_regs(xr, mvv);
-          FOR_G(r, nlim) jv[r] = jrow_dot(r, search);
-          jrows_regs(xr, [&](int rc, float sv) { jv[nlim + rc] = sv; });
-        } else {
-          FOR_G(i, nv) mvv[i] = mrow_dot(i, search);
-          FOR_G(r, nlim) jv[r] = jrow_dot(r, search);
-          FOR_G(rc, 4 * ncon) jv[nlim + rc] = jrow_dot(nlim + rc, search);
-        }
+        FOR_G(i, nv) mvv[i] = mrow_dot(i, search);
+        FOR_G(r, nlim) jv[r] = jrow_dot(r, search);
+        FOR_G(rc, 4 * ncon) jv[nlim + rc] = jrow_dot(nlim + rc, search);
         FOR_G(i, nv) { sn += search[i] * search[i]; sMa += search[i] * Ma[i]; sq += search[i] * qfs[i]; }
         SYNC();
         if (it == 0) PT(24);
@@ -1245,14 +1178,9 @@ __global__ void __launch_bounds__(64 * kMaxWavesPerBlock) env_kernel(ModelView m
         cs = 0.5f * group16_sum(cs) + gs;
         pgm = group16_sum(pgm);
         if (run) { prev_cost = cost; cost = cs; gauss = gs; }
-        if constexpr (kSolverRegs) {
-          const float s = jcol_regs(force);
-          if (run && own[0]) { const int i = ir[0]; qfc[i] = s; grad[i] = Ma[i] - qfs[i] - s; }
-        } else {
-          FOR_G(i, nv) {
-            const float s = jcol_dot(i, force);
-            if (run) { qfc[i] = s; grad[i] = Ma[i] - qfs[i] - s; }
-          }
+        FOR_G(i, nv) {
+          const float s = jcol_dot(i, force);
+          if (run) { qfc[i] = s; grad[i] = Ma[i] - qfs[i] - s; }
         }
         SYNC();
         if (it == 0) PT(29);
