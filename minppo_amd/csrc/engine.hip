@@ -543,6 +543,12 @@ extern "C" int32_t mppo_engine_peer_selftest(mppo_engine_t* e, void* stream, int
   // (A stream created here costs more than it looks: measured on a GPU shared by two rank processes, one extra stream per process
   // - even destroyed again - slowed every later update from 11.7 to 27.8 ms.)
   hipStream_t st = static_cast<hipStream_t>(stream);
+  // the self-test answers in milliseconds when the transport works; when it does not, ten seconds are enough to say so (the run-time limit
+  // of a wait, MPPO_PEER_TIMEOUT_MS, is sized for host-side skew between ranks in the middle of a job: a minute by default)
+  const unsigned long long limit_ms = peer_set_limit_ms(e->peer, 0.0);
+#ifndef MPPO_EMU  // (emulated ranks are slow and share the host's cores: they keep the run-time limit)
+  if (limit_ms > 10000ull) peer_set_limit_ms(e->peer, 10000.0);
+#endif
   if (he == hipSuccess) {
     rc = peer_allreduce_f64(e->peer, dev, 4, st);
     const PeerStep ps = peer_step(e->peer, 0);
@@ -555,6 +561,7 @@ extern "C" int32_t mppo_engine_peer_selftest(mppo_engine_t* e, void* stream, int
     if (rc == MPPO_OK && he == hipSuccess) he = hipMemcpy(red.data(), peer_red(e->peer), (P + kSqSlots) * sizeof(float), hipMemcpyDeviceToHost);
     if (rc == MPPO_OK && he == hipSuccess) he = hipMemcpy(m1.data(), scratch + 2 * P, P * sizeof(float), hipMemcpyDeviceToHost);
   }
+  peer_set_limit_ms(e->peer, (double)limit_ms);
   (void)hipFree(dev);
   (void)hipFree(scratch);
   if (he != hipSuccess) return fail(MPPO_EHIP, "mppo_engine_peer_selftest: %s", hipGetErrorString(he));

@@ -214,6 +214,12 @@ int32_t peer_advance(const PeerComm* c, int steps, hipStream_t s) {
   return MPPO_OK;
 }
 
+unsigned long long peer_set_limit_ms(PeerComm* c, double ms) {
+  const unsigned long long old_ms = c->view.limit_ticks / 100000ull;
+  if (ms > 0.0) c->view.limit_ticks = (unsigned long long)(ms * 1e5);
+  return old_ms;
+}
+
 int32_t peer_status(const PeerComm* c, int32_t* timed_out, int32_t* info8) {
   MPPO_REQUIRE(c && timed_out, "peer_status: null argument");
   MPPO_CHECK_HIP(hipDeviceSynchronize());

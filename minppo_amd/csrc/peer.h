@@ -199,6 +199,7 @@ const float* peer_red(const PeerComm* c);           // the reduced gradient [P] 
 int32_t peer_publish(const PeerComm* c, const float* grad, size_t P, int step, hipStream_t s);  // a gradient computed elsewhere -> pub + signal
 int32_t peer_allreduce_f64(const PeerComm* c, double* buf, size_t n, hipStream_t s);            // in-place sum over the ranks, once per update
 int32_t peer_advance(const PeerComm* c, int steps, hipStream_t s);                              // end of an update
-int32_t peer_status(const PeerComm* c, int32_t* timed_out, int32_t* info8);                      // synchronises the device; info8 (optional): what timed out + counters
+int32_t peer_status(const PeerComm* c, int32_t* timed_out, int32_t* info8);
+unsigned long long peer_set_limit_ms(PeerComm* c, double ms);  // time limit of a wait; returns the previous one in the same unit (ms <= 0: leave it, just return it)                      // synchronises the device; info8 (optional): what timed out + counters
 
 }  // namespace mppo
