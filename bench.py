@@ -518,7 +518,7 @@ def main() -> None:
         # matrix-core utilisation of the same kernel from SQ counters (tools/pmc_mlp.sh: rocprofv3 --pmc passes of their own): the newest
         # committed summary; MFMA-busy cycles / (1024 SIMD pipes x launch duration x 2.4 GHz)
         mfma_busy, mfma_src = None, None
-        pfs = sorted((ROOT / "profiles").glob("r*_mlp_pmc.json"))
+        pfs = sorted((ROOT / "profiles").glob("r*_mlp_pmc_bf16.json" if bf16 else "r*_mlp_pmc.json"))
         if pfs and args.config == "stompy_pro" and args.envs_per_gpu == 4096:
             kk = json.loads(pfs[-1].read_text())["kernels"]
             name = "fused_mlp_kernel<true, false, 1, true, true>" if bf16 else "fused_mlp_kernel<false, false, 1, true, true>"

@@ -39,6 +39,9 @@ constexpr int FRT = 16;  // rows per workgroup
 #ifndef MPPO_ROLLOUT_WAVES
 #define MPPO_ROLLOUT_WAVES 4
 #endif
+#ifndef MPPO_TRAIN_WAVES
+#define MPPO_TRAIN_WAVES 2
+#endif
 
 __device__ __forceinline__ float fused_tanh(float x) {
   const float e = __expf(2.f * x);
@@ -322,7 +325,7 @@ __device__ __forceinline__ void gather_rows_tile(const FusedArgs& a, int tile, i
 // PRE: engine minibatch loop - the x tile comes from the pre-gathered k-quad buffer (one trip to memory instead of index -> row), the
 // gathered rows are not written again, and grid rows 2 and 3 gather the next step's rows
 template <bool BF16, bool ROLLOUT, int OT, bool W2T = false, bool PRE = false>
-__global__ void __launch_bounds__(512, ROLLOUT ? MPPO_ROLLOUT_WAVES : 2) fused_mlp_kernel(FusedArgs a) {
+__global__ void __launch_bounds__(512, ROLLOUT ? MPPO_ROLLOUT_WAVES : MPPO_TRAIN_WAVES) fused_mlp_kernel(FusedArgs a) {
   constexpr int SD = 16 * OT;  // row stride of the per-row output-space tiles
   FT(0);
   // The role is decided from the launch geometry alone (grid rows 0, 1: the two networks; rows 2, 3: gather), not from a kernel

@@ -40,6 +40,7 @@ constexpr int WTHREADS = 64 * WWAVES;
 constexpr int WSTAGE = 8;  // quads per stage = 32 k
 constexpr float kLog2PiW = 1.8378770664093453f;
 constexpr int kThinQuads = 1280;  // LDS quads for a thin band: Kq x rows (20 KB)
+constexpr int kWgradCUs = 256;    // MI355X
 
 // PEER: the gradient goes into this rank's exchange buffer (peer.h) with system-scope write-through stores and the launch ends with the
 // completion signal to the peers; the clip's sums of squares are then those of the REDUCED gradient and are not computed here.
@@ -49,8 +50,12 @@ __device__ __forceinline__ void gstore(float* p, float v) {
   else *p = v;
 }
 
-template <bool BF16, bool PEER = false>
-__global__ void __launch_bounds__(WTHREADS) wgrad_kernel(WgradArgs a, PeerStep ps) {
+// RING: stages in flight per wave.  5 = the whole K range of a wave at mb = 1280 (40 quads): ONE memory latency, 216 registers, one
+// workgroup per CU - right when the launch has no more tiles than the chip has CUs (the headline shape: exactly 256).  2: 64 registers
+// of operands in flight, <= 128 registers in all, TWO workgroups per CU hide each other's latency - for launches with more tiles than
+// CUs (BASELINE configs[4]: 352 tiles were two rounds of one workgroup per CU).  Same products, same order: bit-identical results.
+template <bool BF16, bool PEER = false, int RING = 5>
+__global__ void __launch_bounds__(WTHREADS, RING <= 2 ? 4 : 2) wgrad_kernel(WgradArgs a, PeerStep ps) {
   __shared__ float red[WWAVES][WTILE * (WTILE + 1)];
   __shared__ float cred[WWAVES][WTILE];
   __shared__ float s_red[WWAVES];
@@ -95,7 +100,7 @@ __global__ void __launch_bounds__(WTHREADS) wgrad_kernel(WgradArgs a, PeerStep p
   for (int r = 0; r < 16; ++r) acc[r] = 0.f;
   float colsum = 0.f;  // bias gradient: sum over k of B(k, n); tiles of the first row band only
   const bool do_colsum = p.off_b >= 0 && mt == 0;
-  constexpr int RING = 5;  // stages in flight per wave = the whole K range at mb = 1280 (40 quads): ONE memory latency (measured: a ring of 4 costs 3 us)
+  // (RING = 5: measured - a ring of 4 costs 3 us at the headline shape)
   float4 ra[RING][4], rb[RING][4];
   // a thin band's own operand (its <= 4 rows of A over all K) is tiny: staged in LDS once, read as broadcasts
   __shared__ float4 sx[kThinQuads];
@@ -372,12 +377,18 @@ static int32_t wgrad_peer_slices(WgradArgs& a, const PeerView& v) {
 
 int32_t wgrad_launch(const WgradArgs& a_in, bool bf16, hipStream_t stream, const PeerStep* peer) {
   WgradArgs a = a_in;
+  const bool shallow = a.ntiles > kWgradCUs;  // more tiles than CUs: two lighter workgroups per CU instead of two rounds of one
   if (peer) {
     MPPO_REQUIRE(!a.sq_partial, "wgrad_launch: with the peer exchange the sums of squares are those of the reduced gradient (sq_partial must be null)");
     MPPO_REQUIRE(wgrad_supported(a), "wgrad_launch: operands must be 16-byte aligned k-quad buffers, at most %d tiles", kSqSlots);
     MPPO_TRY(wgrad_peer_slices(a, peer->v));
-    if (bf16) hipLaunchKernelGGL((wgrad_kernel<true, true>), dim3(a.ntiles), dim3(WTHREADS), 0, stream, a, *peer);
-    else hipLaunchKernelGGL((wgrad_kernel<false, true>), dim3(a.ntiles), dim3(WTHREADS), 0, stream, a, *peer);
+    if (shallow) {
+      if (bf16) hipLaunchKernelGGL((wgrad_kernel<true, true, 2>), dim3(a.ntiles), dim3(WTHREADS), 0, stream, a, *peer);
+      else hipLaunchKernelGGL((wgrad_kernel<false, true, 2>), dim3(a.ntiles), dim3(WTHREADS), 0, stream, a, *peer);
+    } else {
+      if (bf16) hipLaunchKernelGGL((wgrad_kernel<true, true>), dim3(a.ntiles), dim3(WTHREADS), 0, stream, a, *peer);
+      else hipLaunchKernelGGL((wgrad_kernel<false, true>), dim3(a.ntiles), dim3(WTHREADS), 0, stream, a, *peer);
+    }
     MPPO_CHECK_LAUNCH("wgrad_kernel<peer>");
     return MPPO_OK;
   }
@@ -389,7 +400,10 @@ int32_t wgrad_launch(const WgradArgs& a_in, bool bf16, hipStream_t stream, const
 #endif
   a.dbg = dbg;
   MPPO_REQUIRE(wgrad_supported(a), "wgrad_launch: operands must be 16-byte aligned k-quad buffers, at most %d tiles", kSqSlots);
-  if (bf16) hipLaunchKernelGGL((wgrad_kernel<true, false>), dim3(a.ntiles), dim3(WTHREADS), 0, stream, a, nops);
+  if (shallow) {
+    if (bf16) hipLaunchKernelGGL((wgrad_kernel<true, false, 2>), dim3(a.ntiles), dim3(WTHREADS), 0, stream, a, nops);
+    else hipLaunchKernelGGL((wgrad_kernel<false, false, 2>), dim3(a.ntiles), dim3(WTHREADS), 0, stream, a, nops);
+  } else if (bf16) hipLaunchKernelGGL((wgrad_kernel<true, false>), dim3(a.ntiles), dim3(WTHREADS), 0, stream, a, nops);
   else hipLaunchKernelGGL((wgrad_kernel<false, false>), dim3(a.ntiles), dim3(WTHREADS), 0, stream, a, nops);
   if (dbg & 4) {  // timing experiment: the same launch again, operands now warm in the L2s
     if (bf16) hipLaunchKernelGGL((wgrad_kernel<true, false>), dim3(a.ntiles), dim3(WTHREADS), 0, stream, a, nops);

@@ -692,6 +692,58 @@ def test_env_step_properties_at_full_size(N):
     be.lib.model_close(h)
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("model,N", [("synth_stompy_pro", 4096), ("synth_stompy_full", 8192)])
+def test_env_step_matches_the_cpu_twin_at_full_size(model, N):
+    """Numerical parity at BASELINE sizes (configs[1]: 4096 envs, configs[4]: 8192 envs of the 26-dof robot), which the NumPy oracle is
+    too slow for: the C++ / OpenMP float32 twin (oracle/cpu_twin, itself held to the oracle and the golden fixtures in
+    tests/test_cpu_twin.py) steps EVERY environment from the kernel's own state with the kernel's action, ten steps of a walking rollout,
+    terminations injected.  `done` exactly; the observation exactly (it is the pre-step record); rewards at 2e-2; positions at 2e-3; the
+    velocity difference inside the float32 solver's envelope (same statistics as test_env_step_matches_env_oracle)."""
+    from backends import get_backend
+    from oracle.cpu_twin import RewardCfg as TwinReward, Twin
+
+    be = get_backend("hip")
+    cm = load_model(model)
+    h, dims, _keep = be.model(cm)
+    OP, R, nu, nv, nq, O = dims.obs_pad, dims.rec_dim, cm.nu, cm.nv, cm.nq, dims.obs_dim
+    tw = Twin(cm, reward=TwinReward(0.9, 2.0, 2.0, 0.2, 0.5, 0.1, 4.0, 1.0, 1.25))
+    tw.reset(N)
+    state, reset_rec, obs = be.zeros((N, R)), be.zeros((R,)), be.zeros((N, OP))
+    rew, done = be.zeros((N,)), be.zeros((N,), np.uint8)
+    be.lib.env_reset(h, N, be.ptr(state), be.ptr(reset_rec), be.ptr(obs), OP, be.ptr(rew), be.ptr(done), None, be.stream)
+    np.testing.assert_allclose(be.host(reset_rec), tw.reset_rec, atol=2e-3)
+    np.testing.assert_allclose(be.host(obs)[:, :O], tw.obs[:, :O], atol=1e-4)
+    rc = nat.RewardCfg(0.9, 2.0, 2.0, 0.2, 0.5, 0.1, 4.0, 1.0, 1.25)  # height_min_z = 0.9: a robot that sinks ends its episode
+    rng = np.random.default_rng(5)
+    dv_all, n_done = [], 0
+    for t in range(10):
+        a = (0.7 * rng.standard_normal((N, nu))).astype(f32)
+        st0 = be.host(state).copy()
+        if t == 4:
+            st0[::61, nq + 2] = -30.0  # every 61st robot slammed down: terminates by height
+            be.put(state, st0)
+        tw.state[...] = st0
+        tw.reset_rec[...] = be.host(reset_rec)
+        da = be.arr(a)
+        be.lib.env_step(h, N, 1, C.byref(rc), be.ptr(state), be.ptr(reset_rec), be.ptr(da), nu, be.ptr(obs), OP, be.ptr(rew), be.ptr(done), None, be.stream)
+        o_t, r_t, d_t = tw.step(a)
+        got_done = be.host(done).astype(bool)
+        assert (got_done == d_t.astype(bool)).all(), (t, int(got_done.sum()), int(d_t.sum()))
+        n_done += int(got_done.sum())
+        np.testing.assert_array_equal(be.host(obs)[~got_done, :O], o_t[~got_done, :O])  # the pre-step record, copied
+        np.testing.assert_allclose(be.host(obs)[got_done, :O], o_t[got_done, :O], atol=1e-4)  # the reset observation
+        np.testing.assert_allclose(be.host(rew), r_t, atol=2e-2)
+        st = be.host(state)
+        np.testing.assert_allclose(st[:, :nq], tw.state[:, :nq], atol=2e-3)
+        dv_all.append(np.abs(st[:, nq:nq + nv] - tw.state[:, nq:nq + nv])[~got_done].max(1))
+    assert n_done >= N // 61
+    dv = np.concatenate(dv_all)
+    assert dv.max() <= 1.0 and np.mean(dv > 0.15) <= 0.05 and np.median(dv) <= 0.02, (dv.max(), np.mean(dv > 0.15), np.median(dv))
+    tw.close()
+    be.lib.model_close(h)
+
+
 def test_model_blob_validation(be):
     cm = load_model("synth_stompy_pro")
     blob = np.frombuffer(cm.to_blob(), np.uint8).copy()

@@ -13,7 +13,7 @@ from minppo_amd.train import Trainer  # noqa: E402
 
 what = sys.argv[1] if len(sys.argv) > 1 else "all"
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 20
-cfg = load_config_from_cli(["stompy_pro", "training.num_envs=4096"])
+cfg = load_config_from_cli(["stompy_pro", "training.num_envs=4096", *sys.argv[3:]])  # further arguments: config overrides (training.mlp_dtype=bf16)
 tr = Trainer(cfg, use_graph=False)
 tr.reset()
 tr.update()
