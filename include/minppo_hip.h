@@ -329,7 +329,8 @@ int32_t mppo_engine_comm_init(mppo_engine_t* e, const void* id128);
  *   mppo_engine_peer_status  synchronises the device; *timed_out != 0: a rank waited longer than MPPO_PEER_TIMEOUT_MS (default
  *                            60000) for a peer - the kernels ran to their end, the results are invalid.  info8 (optional, 8 words):
  *                            the first such wait {kind: 1 a peer's local gradient, 2 a reduced piece, 3 a peer's advantage sums;
- *                            index; epoch waited for; value seen}, then {optimizer steps, updates, local arrivals, pieces per slice}
+ *                            index; epoch waited for; value seen}, then {optimizer steps, updates, workgroups counted into an unfinished gradient slice (0 between
+ *                            launches), pieces per slice}
  *   mppo_engine_peer_selftest  collective (every rank, after the barrier that follows connect), on `stream`: one all-reduce of a
  *                            known vector through the mapped buffers, then ONE full optimizer step's exchange on a known gradient and
  *                            scratch parameters in the form the engine will launch it (publish, reduce + broadcast of this rank's

@@ -530,7 +530,7 @@ extern "C" int32_t mppo_engine_peer_selftest(mppo_engine_t* e, void* stream, int
   MPPO_CHECK_HIP(hipMalloc(reinterpret_cast<void**>(&dev), sizeof(host)));
   hipError_t he = hipMalloc(reinterpret_cast<void**>(&scratch), 4 * P * sizeof(float));
   if (he != hipSuccess) { (void)hipFree(dev); return fail(MPPO_EHIP, "mppo_engine_peer_selftest: %s", hipGetErrorString(he)); }
-  std::vector<float> g(P), red(P + kSqSlots), m1(P);
+  std::vector<float> g(P), red(2 * (P + kSqSlots)), m1(P);  // red: (value, epoch) pairs as they travel (peer.h)
   for (size_t i = 0; i < P; ++i) g[i] = (float)(e->cfg.rank + 1) * selftest_pattern(i);
   int32_t rc = MPPO_OK, timed_out = 0;
   he = hipMemcpy(dev, host, sizeof(host), hipMemcpyHostToDevice);
@@ -558,7 +558,7 @@ extern "C" int32_t mppo_engine_peer_selftest(mppo_engine_t* e, void* stream, int
     if (rc == MPPO_OK) rc = peer_advance(e->peer, 1, st);
     if (rc == MPPO_OK) rc = peer_status(e->peer, &timed_out, nullptr);  // synchronises
     if (rc == MPPO_OK) he = hipMemcpy(host, dev, sizeof(host), hipMemcpyDeviceToHost);
-    if (rc == MPPO_OK && he == hipSuccess) he = hipMemcpy(red.data(), peer_red(e->peer), (P + kSqSlots) * sizeof(float), hipMemcpyDeviceToHost);
+    if (rc == MPPO_OK && he == hipSuccess) he = hipMemcpy(red.data(), peer_red(e->peer), 2 * (P + kSqSlots) * sizeof(float), hipMemcpyDeviceToHost);
     if (rc == MPPO_OK && he == hipSuccess) he = hipMemcpy(m1.data(), scratch + 2 * P, P * sizeof(float), hipMemcpyDeviceToHost);
   }
   peer_set_limit_ms(e->peer, (double)limit_ms);
@@ -572,10 +572,10 @@ extern "C" int32_t mppo_engine_peer_selftest(mppo_engine_t* e, void* stream, int
   double ss = 0.0, ss_dev = 0.0;
   for (size_t i = 0; i < P && good; ++i) {
     const float want = tri * selftest_pattern(i);  // (multiples of 1/256 below 2^24: every partial sum is exact in float32)
-    good = red[i] == want;
+    good = red[2 * i] == want;
     ss += (double)want * (double)want;
   }
-  for (int k = 0; k < kSqSlots; ++k) ss_dev += (double)red[P + k];
+  for (int k = 0; k < kSqSlots; ++k) ss_dev += (double)red[2 * (P + k)];
   good = good && fabs(ss_dev - ss) <= 1e-4 * ss + 1e-12;
   // phase B: first moment of the scratch state = (1 - b1) * clip scale * reduced gradient
   const double norm = sqrt(ss), scale = norm < (double)ac.max_grad_norm ? 1.0 : (double)ac.max_grad_norm / norm;

@@ -106,7 +106,7 @@ int32_t peer_create(int rank, int world, size_t P, size_t adv_doubles, PeerComm*
   v.nA = (v.S4 + kPeerThreads * v.K - 1) / (kPeerThreads * v.K);
   v.pub_off = (unsigned)sizeof(PeerHdr);
   v.red_off = (unsigned)align_up(v.pub_off + P * 4, 256);
-  v.adv_off = (unsigned)align_up(v.red_off + (P + kSqSlots) * 4, 256);
+  v.adv_off = (unsigned)align_up(v.red_off + (P + kSqSlots) * 8, 256);  // (tagged: 8 bytes per float)
   c->bytes = align_up(v.adv_off + adv_doubles * 8, 256);
   v.limit_ticks = limit_ticks();
   { const char* e = MPPO_EXPERIMENT_ENV("MPPO_PEER_POLL_RMW"); v.poll_rmw = e && e[0] == '1'; }

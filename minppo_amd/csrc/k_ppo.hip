@@ -392,7 +392,7 @@ __global__ void __launch_bounds__(256, PEER ? 8 : 1) adam_kernel(size_t P, float
                                                    const float* __restrict__ g, const float* __restrict__ partial, const int* __restrict__ count_base,
                                                    int step_offset, mppo_adam_cfg_t c, ShadowRef sh, PeerStep ps, int phase) {
   if (PEER) {
-    if ((phase & 1) && (int)blockIdx.x < ps.v.nA) peer_reduce_piece(ps.v, ps.epoch[0] + ps.step + 1, (int)blockIdx.x, !(phase & 4));
+    if ((phase & 1) && (int)blockIdx.x < ps.v.nA) peer_reduce_piece(ps.v, ps.epoch[0] + ps.step + 1, (int)blockIdx.x, !(phase & 4), (phase & 4) != 0);
     if (!(phase & 2)) return;
   }
   // ---- addresses depend on the kernel arguments only: the four arrays are REQUESTED FIRST, and the clip scale, learning rate and
@@ -439,10 +439,14 @@ __global__ void __launch_bounds__(256, PEER ? 8 : 1) adam_kernel(size_t P, float
   const int ln = threadIdx.x & 63;
   float pr[8];
   if (PEER) {
-    if (!(phase & 4)) peer_wait_reduced(ps.v, ps.epoch[0] + ps.step + 1);  // (the moments and the parameters are in flight meanwhile)
-    if (have4) gq = sys_load_f4(g, i * 4);
+    // the reduced gradient and its sums of squares arrive tagged with the step's epoch (peer.h): every thread takes its own four floats
+    // when their tags say so - no flag, no barrier (the moments and the parameters are in flight meanwhile).  Ranks sharing a GPU have
+    // waited for the red_done flags in a kernel of their own: the tags are there already.
+    const int epoch = ps.epoch[0] + ps.step + 1;
+    if (have4) gq = peer_load_reduced4(ps.v, g, i, epoch);
+    const int nslots = ps.v.world * ps.v.nA;  // (the other slots are never written: they count as 0)
 #pragma unroll
-    for (int k = 0; k < 8; ++k) pr[k] = sys_load_f32(partial + ln + 64 * k);
+    for (int k = 0; k < 8; ++k) pr[k] = ln + 64 * k < nslots ? peer_load_reduced1(ps.v, g, P + (size_t)(ln + 64 * k), epoch) : 0.f;
   } else {
 #pragma unroll
     for (int k = 0; k < 8; ++k) pr[k] = partial[ln + 64 * k];
@@ -486,7 +490,7 @@ __global__ void __launch_bounds__(256, PEER ? 8 : 1) adam_kernel(size_t P, float
     wt_store(p, i, make_float4(pn[0], pn[1], pn[2], pn[3]));
   } else {
     for (size_t e = i; e < P; ++e) {  // (a parameter count that is not a multiple of four: the stand-alone entry point only)
-      const float gi = (PEER ? sys_load_f32(g + e) : g[e]) * scale;
+      const float gi = (PEER ? sys_load_f32(g + 2 * e) : g[e]) * scale;  // (with the exchange P is a multiple of four: never reached)
       const float mi = c.b1 * m[e] + (1.f - c.b1) * gi;
       const float vi = c.b2 * v[e] + (1.f - c.b2) * gi * gi;
       m[e] = mi; v[e] = vi;

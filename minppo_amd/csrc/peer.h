@@ -13,8 +13,14 @@
 //   adam_kernel<PEER>        phase A (the first nA workgroups): wait for every peer's wg_done, PULL slice `rank` of every rank's
 //                            `pub` (1/G of the gradient from each of G - 1 peers: all links busy, P/G floats per link), add the G
 //                            contributions in rank order, PUSH the reduced slice and its sum of squares into `red` of EVERY rank's
-//                            buffer, raise red_done there.  Phase B (every workgroup): wait for all G * nA red_done words, then
-//                            clip_by_global_norm + adam (train.py:115-124,248) on the reduced gradient in its OWN buffer.
+//                            buffer - TAGGED (round 4): every float of `red` travels as an 8-byte pair (value, epoch), two pairs per
+//                            16-byte store.  Phase B (every workgroup): load its own floats of `red` in its OWN buffer until their tags
+//                            carry this step's epoch, then clip_by_global_norm + adam (train.py:115-124,248).  No flag follows the
+//                            data, so the pusher does not wait for its stores to be acknowledged before it may say so (that drain was a
+//                            device-to-device round trip on the critical path of every step, and the flag one more one-way trip):
+//                            what a reader needs is in the very bytes it reads - the low-latency protocol of the collective
+//                            libraries, for the 1 MB that crosses the links 128 times per update.  (Ranks that SHARE a GPU keep
+//                            the drain and the red_done flags for their one-wave wait kernels: nothing large may spin there.)
 //
 // A slice is reduced ONCE, by its owner, and broadcast: the replicas see bit-identical gradients by construction.  Two hops of
 // latency and 2 P/G floats per link and step (RCCL's ring: 2 (G-1) hops); no extra launch, no host involvement, capturable in the
@@ -36,7 +42,7 @@ constexpr int kPeerThreads = 256;  // threads of a workgroup that reduces a piec
 struct PeerHdr {
   int wg_done[kPeerMaxRanks][16];   // [q][0]: epoch at which slice `this rank` of rank q's local gradient was complete in q's `pub` (one 64-byte line per writer)
   int adv_done[kPeerMaxRanks][16];  // [q][0]: update epoch of rank q's published advantage sums
-  int red_done[kSqSlots];           // [q * nA + b]: epoch of piece b of slice q in `red`
+  int red_done[kSqSlots];           // [q * nA + b]: epoch of piece b of slice q in `red` (raised only for ranks that share a GPU: see above)
   // fan-in counters of this rank's own gradient-writing launches, one line each: [q][0] (q < world) the workgroups that store into
   // slice q, [kPeerMaxRanks][0] a launch whose workgroups all store everywhere (publish kernel).  The last arriver takes the counter
   // back to 0: the next launch's workgroups arrive only after this launch has ended (stream order), nothing wraps, and the two kinds
@@ -54,7 +60,7 @@ struct PeerView {  // kernel argument: the G exchange buffers as mapped in THIS 
   int rank, world;
   int nA, K;    // pieces per slice; float4 per thread and piece (piece = 256 K float4)
   int P4, S4;   // float4 in the gradient / in a slice
-  unsigned pub_off, red_off, adv_off;  // byte offsets of pub [4 P4], red [4 P4 + kSqSlots], adv [n] doubles
+  unsigned pub_off, red_off, adv_off;  // byte offsets of pub [4 P4] floats, red [4 P4 + kSqSlots] (value, epoch) PAIRS, adv [n] doubles
   unsigned long long limit_ticks;      // time limit of one wait, 100 MHz ticks
   int poll_rmw;                        // experiment (MPPO_PEER_POLL_RMW=1): poll with a system-scope atomic OR of 0 instead of a load
 };
@@ -123,11 +129,61 @@ __device__ __forceinline__ void peer_publish_all_done(const PeerView& v, int epo
   }
 }
 
-// Phase A of the fused exchange: workgroup b < nA (kPeerThreads threads) reduces piece b of slice `rank` and broadcasts it.
-__device__ __forceinline__ void peer_reduce_piece(const PeerView& v, int epoch, int b, bool wait = true) {
+// ---- the tagged reduced gradient: float k of `red` is the pair at byte 8 k = (value, bits of the epoch it belongs to) ----
+__device__ __forceinline__ bool peer_tag_ok(float tag, int epoch) { return (int)(__builtin_bit_cast(int, tag) - epoch) >= 0; }
+
+// bounded wait shared by the two tagged loads below: returns false when the wait must end (error word set by somebody, or time is up)
+struct PeerSpin {
+  unsigned long long t0 = 0;
+  unsigned spins = 0;
+  __device__ __forceinline__ bool keep_waiting(PeerHdr* me, unsigned long long limit, int index, int epoch, float seen_tag) {
+    if ((spins++ & 127u) == 0) {
+      if (sys_load_i32(&me->error)) return false;
+      const unsigned long long now = realtime_ticks();
+      if (t0 == 0) t0 = now;
+      if (now - t0 > limit) {
+        if (agent_fetch_add(&me->error, 1) == 0) { me->error_info[0] = 2; me->error_info[1] = index; me->error_info[2] = epoch; me->error_info[3] = __builtin_bit_cast(int, seen_tag); }
+        return false;
+      }
+    }
+    spin_pause();
+    return true;
+  }
+};
+
+// floats [i, i + 4) of the reduced gradient (i a multiple of 4) once all four carry `epoch`; `red` = this rank's own `red` region (wave-uniform)
+__device__ __forceinline__ float4 peer_load_reduced4(const PeerView& v, const float* red, size_t i, int epoch) {
+  PeerHdr* me = peer_hdr(v, v.rank);
+  PeerSpin sp;
+  float4 lo, hi;
+  for (;;) {
+    lo = sys_load_f4(red, i * 8);
+    hi = sys_load_f4(red, i * 8 + 16);
+    if ((int)peer_tag_ok(lo.y, epoch) & (int)peer_tag_ok(lo.w, epoch) & (int)peer_tag_ok(hi.y, epoch) & (int)peer_tag_ok(hi.w, epoch)) break;
+    if (!sp.keep_waiting(me, v.limit_ticks, (int)(i >> 2), epoch, lo.y)) break;
+  }
+  return make_float4(lo.x, lo.z, hi.x, hi.z);
+}
+// one tagged float (the sums of squares behind the gradient: slot k is float 4 P4 + k)
+__device__ __forceinline__ float peer_load_reduced1(const PeerView& v, const float* red, size_t k, int epoch) {
+  PeerHdr* me = peer_hdr(v, v.rank);
+  PeerSpin sp;
+  float2 pr;
+  for (;;) {
+    pr = sys_load_f2(red + 2 * k);
+    if (peer_tag_ok(pr.y, epoch)) break;
+    if (!sp.keep_waiting(me, v.limit_ticks, (int)k, epoch, pr.y)) break;
+  }
+  return pr.x;
+}
+
+// Phase A of the fused exchange: workgroup b < nA (kPeerThreads threads) reduces piece b of slice `rank` and broadcasts it, tagged.
+// flags: also drain the stores and raise red_done (ranks sharing a GPU: their one-wave wait kernel polls those words).
+__device__ __forceinline__ void peer_reduce_piece(const PeerView& v, int epoch, int b, bool wait = true, bool flags = false) {
   __shared__ float s_sq[kPeerThreads / 64];
   const int t = threadIdx.x;
   PeerHdr* me = peer_hdr(v, v.rank);
+  const float ef = __builtin_bit_cast(float, epoch);
   if (wait && t < v.world && t != v.rank) peer_wait(&me->wg_done[t][0], epoch, me, v.limit_ticks, 1, t, v.poll_rmw);
   __syncthreads();
   float sq = 0.f;
@@ -152,9 +208,13 @@ __device__ __forceinline__ void peer_reduce_piece(const PeerView& v, int epoch, 
             }
         }
       }
+      const float4 lo = make_float4(a.x, ef, a.y, ef), hi = make_float4(a.z, ef, a.w, ef);
 #pragma unroll
       for (int q = 0; q < kPeerMaxRanks; ++q)
-        if (q < v.world) sys_store_f4(v.base[q] + v.red_off, (size_t)i4 * 16, a);
+        if (q < v.world) {
+          sys_store_f4(v.base[q] + v.red_off, (size_t)i4 * 32, lo);
+          sys_store_f4(v.base[q] + v.red_off, (size_t)i4 * 32 + 16, hi);
+        }
       sq += (a.x * a.x + a.y * a.y) + (a.z * a.z + a.w * a.w);
     }
   }
@@ -166,23 +226,17 @@ __device__ __forceinline__ void peer_reduce_piece(const PeerView& v, int epoch, 
     for (int w = 0; w < kPeerThreads / 64; ++w) s += s_sq[w];
 #pragma unroll
     for (int q = 0; q < kPeerMaxRanks; ++q)
-      if (q < v.world) sys_store_f32(reinterpret_cast<float*>(v.base[q] + v.red_off) + (size_t)4 * v.P4 + v.rank * v.nA + b, s);
+      if (q < v.world) sys_store_f2(reinterpret_cast<float*>(v.base[q] + v.red_off) + 2 * ((size_t)4 * v.P4 + v.rank * v.nA + b), make_float2(s, ef));
   }
-  drain_stores();
-  __syncthreads();
-  if (t == 0) {
+  if (flags) {
+    drain_stores();
+    __syncthreads();
+    if (t == 0) {
 #pragma unroll
-    for (int q = 0; q < kPeerMaxRanks; ++q)
-      if (q < v.world) sys_store_i32(&peer_hdr(v, q)->red_done[v.rank * v.nA + b], epoch);
+      for (int q = 0; q < kPeerMaxRanks; ++q)
+        if (q < v.world) sys_store_i32(&peer_hdr(v, q)->red_done[v.rank * v.nA + b], epoch);
+    }
   }
-}
-
-// Phase B: every piece of every slice of this step has arrived in my `red` (called by every thread; a workgroup barrier inside)
-__device__ __forceinline__ void peer_wait_reduced(const PeerView& v, int epoch) {
-  PeerHdr* me = peer_hdr(v, v.rank);
-  if (threadIdx.x < 64)
-    for (int s = threadIdx.x; s < v.world * v.nA; s += 64) peer_wait(&me->red_done[s], epoch, me, v.limit_ticks, 2, s, v.poll_rmw);
-  __syncthreads();
 }
 
 // ---- host side (k_peer.hip) ----
@@ -195,7 +249,7 @@ void peer_destroy(PeerComm* c);
 PeerStep peer_step(const PeerComm* c, int step);
 int peer_mode(const PeerComm* c);
 float* peer_pub(const PeerComm* c);                 // this rank's local gradient [P] (what the weight-gradient launch writes)
-const float* peer_red(const PeerComm* c);           // the reduced gradient [P] + kSqSlots sums of squares (what Adam reads)
+const float* peer_red(const PeerComm* c);           // the reduced gradient [P] + kSqSlots sums of squares as (value, epoch) pairs: float k at [2 k] (what Adam reads)
 int32_t peer_publish(const PeerComm* c, const float* grad, size_t P, int step, hipStream_t s);  // a gradient computed elsewhere -> pub + signal
 int32_t peer_allreduce_f64(const PeerComm* c, double* buf, size_t n, hipStream_t s);            // in-place sum over the ranks, once per update
 int32_t peer_advance(const PeerComm* c, int steps, hipStream_t s);                              // end of an update

@@ -231,6 +231,15 @@ __device__ __forceinline__ float4 sys_load_f4(const void* base, size_t byte_off)
   const f32x4_native q = mppo_raw_buffer_load_f32x4(b.r, (int)byte_off, 0, 17);
   return make_float4(q.x, q.y, q.z, q.w);
 }
+// a value and its tag as ONE 8-byte access (p 8-byte aligned)
+__device__ __forceinline__ void sys_store_f2(float* p, float2 v) {
+  const unsigned long long u = (unsigned long long)__builtin_bit_cast(unsigned, v.x) | ((unsigned long long)__builtin_bit_cast(unsigned, v.y) << 32);
+  __hip_atomic_store(reinterpret_cast<unsigned long long*>(p), u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+__device__ __forceinline__ float2 sys_load_f2(const float* p) {
+  const unsigned long long u = __hip_atomic_load(reinterpret_cast<const unsigned long long*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  return make_float2(__builtin_bit_cast(float, (unsigned)u), __builtin_bit_cast(float, (unsigned)(u >> 32)));
+}
 __device__ __forceinline__ void sys_store_f32(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
 __device__ __forceinline__ float sys_load_f32(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
 __device__ __forceinline__ void sys_store_i32(int* p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }

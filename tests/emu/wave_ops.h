@@ -219,15 +219,23 @@ inline void agent_acquire_fence() {}
 // system-scope accesses between rank PROCESSES (csrc/peer.h): the emulator's exchange buffers are POSIX shared memory
 #include <sched.h>
 #include <time.h>
+// (a 16-byte access is two 8-byte single-copy-atomic halves: the tagged exchange of csrc/peer.h keeps a value and its tag in one half)
 inline void sys_store_f4(void* base, size_t byte_off, float4 v) {
-  float* p = reinterpret_cast<float*>(static_cast<char*>(base) + byte_off);
-  __atomic_store_n(reinterpret_cast<unsigned*>(p), __float_as_uint(v.x), __ATOMIC_RELAXED); __atomic_store_n(reinterpret_cast<unsigned*>(p + 1), __float_as_uint(v.y), __ATOMIC_RELAXED);
-  __atomic_store_n(reinterpret_cast<unsigned*>(p + 2), __float_as_uint(v.z), __ATOMIC_RELAXED); __atomic_store_n(reinterpret_cast<unsigned*>(p + 3), __float_as_uint(v.w), __ATOMIC_RELAXED);
+  unsigned long long* p = reinterpret_cast<unsigned long long*>(static_cast<char*>(base) + byte_off);
+  __atomic_store_n(p, (unsigned long long)__float_as_uint(v.x) | ((unsigned long long)__float_as_uint(v.y) << 32), __ATOMIC_RELEASE);
+  __atomic_store_n(p + 1, (unsigned long long)__float_as_uint(v.z) | ((unsigned long long)__float_as_uint(v.w) << 32), __ATOMIC_RELEASE);
 }
 inline float4 sys_load_f4(const void* base, size_t byte_off) {
-  const unsigned* p = reinterpret_cast<const unsigned*>(static_cast<const char*>(base) + byte_off);
-  return make_float4(__uint_as_float(__atomic_load_n(p, __ATOMIC_RELAXED)), __uint_as_float(__atomic_load_n(p + 1, __ATOMIC_RELAXED)),
-                     __uint_as_float(__atomic_load_n(p + 2, __ATOMIC_RELAXED)), __uint_as_float(__atomic_load_n(p + 3, __ATOMIC_RELAXED)));
+  const unsigned long long* p = reinterpret_cast<const unsigned long long*>(static_cast<const char*>(base) + byte_off);
+  const unsigned long long a = __atomic_load_n(p, __ATOMIC_ACQUIRE), b = __atomic_load_n(p + 1, __ATOMIC_ACQUIRE);
+  return make_float4(__uint_as_float((unsigned)a), __uint_as_float((unsigned)(a >> 32)), __uint_as_float((unsigned)b), __uint_as_float((unsigned)(b >> 32)));
+}
+inline void sys_store_f2(float* p, float2 v) {
+  __atomic_store_n(reinterpret_cast<unsigned long long*>(p), (unsigned long long)__float_as_uint(v.x) | ((unsigned long long)__float_as_uint(v.y) << 32), __ATOMIC_RELEASE);
+}
+inline float2 sys_load_f2(const float* p) {
+  const unsigned long long a = __atomic_load_n(reinterpret_cast<const unsigned long long*>(p), __ATOMIC_ACQUIRE);
+  return make_float2(__uint_as_float((unsigned)a), __uint_as_float((unsigned)(a >> 32)));
 }
 inline void sys_store_f32(float* p, float v) { __atomic_store_n(reinterpret_cast<unsigned*>(p), __float_as_uint(v), __ATOMIC_RELAXED); }
 inline float sys_load_f32(const float* p) { return __uint_as_float(__atomic_load_n(reinterpret_cast<const unsigned*>(p), __ATOMIC_RELAXED)); }
