@@ -83,3 +83,37 @@ def test_torch_ppo_reproduces_the_ppo_golden():
     assert np.abs(flat1 - g["params1"]).max() < 1e-3 * step
     m1 = po.named_to_flat({k: v.numpy().astype(np.float64) for k, v in opt.m.items()}, O, A, H)
     np.testing.assert_allclose(m1, g["adam_m"], rtol=1e-3, atol=1e-7)
+
+
+def test_twin_follows_the_oracle_on_the_other_collider_kinds():
+    """The model classes beyond the BASELINE robots: geom-geom pairs (sphere / capsule self-collision candidates), colliding free bodies,
+    and MJCF robots with box and mesh (convex hull) colliders - the twin picks the same hull vertices, slot by slot, or `done` / rewards diverge."""
+    import os
+
+    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    for name, steps, amp in (("synth_stompy_pro_sc", 8, 0.6), ("synth_tumblers", 20, 0.0), (os.path.join(here, "hand_leg.xml"), 25, 0.3),
+                             (os.path.join(here, "mesh_foot.xml"), 40, 0.3)):
+        cm = load_model(name)
+        tw = Twin(cm)
+        env = EnvOracle(cm.t, RewardCfg())
+        N = 8
+        obs0 = tw.reset(N).copy()
+        es = env.reset(N)
+        np.testing.assert_allclose(obs0[:, :tw.obs_dim], es["obs"], atol=1e-5)
+        rng = np.random.default_rng(9)
+        worst = 0.0
+        for t in range(steps):
+            a = amp * rng.standard_normal((N, cm.nu))
+            # re-seed the twin from the oracle's state every step (identical inputs): qpos, qvel, warm start
+            s = es["pipeline_state"]
+            tw.state[:, :cm.nq] = s.qpos
+            tw.state[:, cm.nq:cm.nq + cm.nv] = s.qvel
+            tw.state[:, tw.obs_pad:tw.obs_pad + cm.nv] = s.qacc_warmstart
+            tw.state[:, tw.obs_pad + cm.nv] = s.subtree_com[:, 1, 0]
+            es = env.step(es, a)
+            obs, rew, done = tw.step(a.astype(f32))
+            assert (done.astype(bool) == es["done"]).all(), (name, t)
+            np.testing.assert_allclose(rew, es["reward"], atol=2e-2, err_msg=f"{name} step {t}")
+            worst = max(worst, float(np.abs(tw.state[:, :cm.nq] - es["pipeline_state"].qpos).max()))
+        assert worst < 2e-3, (name, worst)
+        tw.close()
