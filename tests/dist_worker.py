@@ -186,8 +186,39 @@ def run_process_of_ranks(proc, nproc, per_proc, port, overrides, updates, out_pa
     dist.destroy_process_group()
 
 
+def run_make_train(rank, world, port, outdir, overrides):
+    """`make_train(config)(seed)` as one rank of an env-sharded job (emulator kernels, gloo rendezvous): the whole host loop of
+    minppo_amd/train.py with several ranks - init_comm, periodic checkpoints behind the collective check of the exchange, the barrier
+    after them, reduced statistics for the log lines."""
+    import torch.distributed as dist
+
+    from backends import get_backend
+    from minppo_amd import train as T
+    from minppo_amd.config import make_config
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    be = get_backend("emu")
+    cfg = make_config({"kscale_id": "5eb3cb7f23232298", "visualization": {"camera_name": "track"}},
+                      [*overrides, f"training.checkpoint_path={outdir}/ck.npz", "training.checkpoint_every=2"])
+    out = T.make_train(cfg, lib=be.lib, xp="numpy", use_graph=False, rank=rank, world_size=world)(1337, max_updates=5, log_every=1)
+    flat = T.tree_to_flat(out.runner_state.train_state.params, *_dims(out))
+    np.savez(f"{outdir}/train_r{rank}.npz", params=flat, mean_reward=out.metrics["mean_reward"], total_loss=out.metrics["total_loss"])
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _dims(out):
+    t = out.runner_state.train_state.params["params"]
+    k1 = t["MLP_0"]["Dense_0"]["kernel"]
+    return k1.shape[0], t["log_std"].shape[0], k1.shape[1]
+
+
 if __name__ == "__main__":
-    if sys.argv[1] == "procs":  # procs <proc> <nproc> <per_proc> <port> <updates> <out prefix> overrides...
+    if sys.argv[1] == "train":  # train <rank> <world> <port> <outdir> overrides...
+        run_make_train(int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]), sys.argv[5], sys.argv[6:])
+    elif sys.argv[1] == "procs":  # procs <proc> <nproc> <per_proc> <port> <updates> <out prefix> overrides...
         proc, nproc, per_proc, port, updates = (int(x) for x in sys.argv[2:7])
         prefix = sys.argv[7]
         run_process_of_ranks(proc, nproc, per_proc, port, sys.argv[8:], updates, [f"{prefix}{proc * per_proc + j}.npz" for j in range(per_proc)])

@@ -267,3 +267,25 @@ def test_eight_ranks_on_one_gpu(tmp_path):
     assert step > 1e-4 and diff.max() < 0.1 * step + 1e-7 and np.median(diff) < 1e-3 * step, (diff.max(), np.median(diff), step)
     np.testing.assert_allclose(sum(r["losses"] for r in ranks), tr.losses(), rtol=2e-3, atol=2e-4)
     tr.close()
+
+
+def test_make_train_with_two_ranks(tmp_path):
+    """`make_train(config)(seed)` - the host loop a user runs (minppo_amd/train.py, reference train.py:92-291) - as two env-sharded ranks:
+    the peer exchange is set up by `init_comm`, every second update a checkpoint is written behind the COLLECTIVE check of the exchange
+    and followed by a barrier, log lines carry statistics reduced over the ranks.  Both ranks end with bit-identical parameters and
+    identical (reduced) metrics; their checkpoint files agree on the number of updates done."""
+    import json
+
+    world, port = 2, _free_port()
+    env = dict(os.environ, MPPO_ALLREDUCE="peer")
+    _spawn(lambda r: ["train", str(r), str(world), str(port), str(tmp_path), *OVR], world, env, 900)
+    a, b = (np.load(tmp_path / f"train_r{r}.npz") for r in range(world))
+    np.testing.assert_array_equal(a["params"], b["params"])
+    np.testing.assert_array_equal(a["mean_reward"], b["mean_reward"])
+    np.testing.assert_array_equal(a["total_loss"], b["total_loss"])
+    assert len(a["mean_reward"]) == 5 and np.isfinite(a["total_loss"]).all()
+    metas = []
+    for r in range(world):
+        with np.load(tmp_path / f"ck.npz.rank{r}") as z:
+            metas.append(json.loads(z["__meta__"].tobytes().decode()))
+    assert metas[0]["updates_done"] == metas[1]["updates_done"] == 5 and [m["rank"] for m in metas] == [0, 1]
