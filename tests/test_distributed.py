@@ -245,13 +245,19 @@ def test_first_optimizer_step_per_tensor_on_one_gpu(tmp_path, world, per_proc):
 
 
 @pytest.mark.gpu
-def test_eight_ranks_on_one_gpu(tmp_path):
-    """BASELINE configs[2]'s world size on the hardware there is: eight ranks of 512 environments on cuda:0 as four processes of two
-    ranks (the box's process limit is six), the exchange inside every rank's hipGraph, three updates of 2 x 4 optimizer steps: ranks ==
-    one process on the union, replicas bit-identical, no wait timed out."""
-    world, per_proc, updates = 8, 2, 3
+@pytest.mark.parametrize("shape", ["small", "configs2"])
+def test_eight_ranks_on_one_gpu(tmp_path, shape):
+    """BASELINE configs[2]'s world size on the hardware there is: eight ranks on cuda:0 as four processes of two ranks (the box's process
+    limit is six), the exchange inside every rank's hipGraph: ranks == one process on the union, replicas bit-identical, no wait timed out.
+    "small": 8 x 512 environments, three updates of 2 x 4 optimizer steps.  "configs2": the EXACT shapes of BASELINE configs[2] -
+    32 768 environments as 8 x 4096, 4 epochs x 32 minibatches of 1280 rows per rank (every rank launches what it would launch on a GPU of
+    its own: the 256-tile weight-gradient launch with the eight-way slice masks, nA pieces per slice of the 250 140-float gradient) - two
+    updates = 256 exchanges against one process that trains on all 32 768 environments with minibatches of 10 240 rows."""
+    world, per_proc = 8, 2
+    updates = 3 if shape == "small" else 2
     port = _free_port()
-    ovr = ["training.num_envs=4096", "training.num_minibatches=4", "training.update_epochs=2", "training.total_timesteps=100000000"]
+    ovr = (["training.num_envs=4096", "training.num_minibatches=4", "training.update_epochs=2", "training.total_timesteps=100000000"] if shape == "small" else
+           ["training.num_envs=32768", "training.total_timesteps=2000000000"])
     env = _gpu_env()
     env.pop("MPPO_PEER_MODE", None)
     nproc = world // per_proc
