@@ -49,12 +49,27 @@ __global__ void __launch_bounds__(kStatsThreads) rollout_stats_kernel(int T, int
   for (int n = threadIdx.x; n < N; n += kStatsThreads) {
     float ret = ret_in[n];
     int len = len_in[n];
-    for (int t = 0; t < T; ++t) {
-      const float r = reward[(size_t)t * N + n];
-      const bool d = done[(size_t)t * N + n] != 0;
-      ret += r; len += 1;                       // new_episode_return / new_episode_length (env.py:183-184)
-      sr += (double)r;
-      if (d) { sd += 1.0; sret += (double)ret; slen += (double)len; ret = 0.f; len = 0; }  // env.py:187-190
+    // the T steps in chunks of eight whose loads are all requested before the first is consumed (the bookkeeping is a dependent chain, the
+    // loads are not: one trip to memory per chunk instead of one per step - 16 -> see DESIGN.md 3.6)
+    for (int t0 = 0; t0 < T; t0 += 8) {
+      float r8[8];
+      unsigned char d8[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int t = t0 + u < T ? t0 + u : T - 1;
+        r8[u] = reward[(size_t)t * N + n];
+        d8[u] = done[(size_t)t * N + n];
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        if (t0 + u < T) {
+          const float r = r8[u];
+          const bool d = d8[u] != 0;
+          ret += r; len += 1;                       // new_episode_return / new_episode_length (env.py:183-184)
+          sr += (double)r;
+          if (d) { sd += 1.0; sret += (double)ret; slen += (double)len; ret = 0.f; len = 0; }  // env.py:187-190
+        }
+      }
     }
   }
   sr = wave_sum_f64(sr); sd = wave_sum_f64(sd); sret = wave_sum_f64(sret); slen = wave_sum_f64(slen);
@@ -397,6 +412,7 @@ extern "C" int32_t mppo_engine_reset(mppo_engine_t* e, void* stream) {
   MPPO_CHECK_HIP(hipMemsetAsync(e->adam_m, 0, (size_t)e->P * 4, s));
   MPPO_CHECK_HIP(hipMemsetAsync(e->adam_v, 0, (size_t)e->P * 4, s));
   MPPO_CHECK_HIP(hipMemsetAsync(e->obs, 0, (size_t)(e->T + 1) * e->N * e->OP * 4, s));
+  MPPO_TRY(permutation_batch_prepare(e->B, e->E, e->perm_ws, e->perm_ws_bytes, s));
   MPPO_TRY(mppo_env_reset(e->model, e->N, e->state, e->reset_rec, e->obs, e->OP, nullptr, nullptr, &e->met, s));  // train.py:142-144
   e->was_reset = true;
   return MPPO_OK;

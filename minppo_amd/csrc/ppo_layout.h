@@ -204,6 +204,7 @@ int32_t permutation_ctr(unsigned long long seed, unsigned long long stream_id, c
 // E permutations (streams stream_id0 .. stream_id0 + E - 1) into idx[E][B] with one sort; same results as E calls of permutation_ctr
 int32_t perm_fill_keys_batch(unsigned long long seed, unsigned long long stream_id0, const int* ctr, int B, int E, unsigned long long* keys, int* vals, hipStream_t stream);
 size_t permutation_batch_ws_bytes(int B, int E);
+int32_t permutation_batch_prepare(int B, int E, void* ws, size_t ws_bytes, hipStream_t stream);  // zeroes the two-launch form's counters
 int32_t permutation_batch_ctr(unsigned long long seed, unsigned long long stream_id0, const int* ctr, int B, int E, int* idx, void* ws, size_t ws_bytes, hipStream_t stream);
 // k_rng.hip / k_perm.hip: jax.random-compatible streams (threefry2x32)
 int32_t threefry_normal(const unsigned* key2, size_t n, float* out, hipStream_t s);

@@ -369,3 +369,37 @@ def test_rccl_path_at_world_size_one_is_the_identity(monkeypatch):
     # measured on MI355X: 3 % of the elements differ, by at most 6e-5 (one Adam step is 3e-4): rounding-level drift
     np.testing.assert_allclose(res[0], res[1], rtol=1e-3, atol=3e-4)
 
+
+
+@pytest.mark.gpu
+def test_two_launch_permutations_equal_the_sort_at_full_size():
+    """The engine's permutations at BASELINE size (B = 40 960 samples, E = 4 epochs): two launches - scatter of (key, index) values into 256
+    buckets, one LDS bitonic sort per bucket (csrc/k_perm.hip) - instead of one key launch + nine rocPRIM launches.  The first update's
+    permutations equal `mppo_permutation` (rocPRIM's stable sort of the same Philox keys) epoch by epoch, bit for bit; the following
+    updates (the double-buffered bucket counters of both parities, replayed from the hipGraph) stay bijective and differ from update to update."""
+    from backends import get_backend
+
+    be = get_backend("hip")
+    cfg = _cfg("training.num_envs=4096")
+    tr = be.trainer(cfg, use_graph=True)
+    tr.reset()
+    E, B = tr.E, tr.T * tr.N
+    assert (E, B) == (4, 40960)
+    seen = []
+    for u in range(4):
+        tr.update()
+        tr._sync()
+        perm = be.host(tr.region("perm", (E, B))).copy()
+        for e in range(E):
+            assert (np.sort(perm[e]) == np.arange(B)).all(), (u, e)
+        seen.append(perm)
+        if u == 0:
+            wsb = be.lib.permutation_ws_bytes(B)
+            pws, one = be.zeros((wsb // 4 + 1,)), be.zeros((B,), np.int32)
+            for e in range(E):
+                be.lib.permutation(tr.seed, (0x5045524D << 24) + e, B, be.ptr(one), be.ptr(pws), wsb, be.stream)
+                np.testing.assert_array_equal(perm[e], be.host(one), err_msg=f"epoch {e}")
+    assert tr.graph_active()
+    for u in range(1, 4):
+        assert (seen[u] != seen[u - 1]).mean() > 0.99
+    tr.close()
