@@ -48,13 +48,15 @@ static size_t sort_temp_bytes64(size_t n, int end_bit) {
   return bytes;
 }
 // ---- all E permutations of an update in TWO launches (round 4; the sort above is one key launch + nine rocPRIM launches at the launch
-// floor, 70 us of every update).  A permutation of B <= 65536 samples is the order of the 48-bit values (key << 16 | index): exactly what the
+// floor, 70 us of every update).  A permutation of B <= 131072 samples is the order of the 52-bit values (key << 20 | index): exactly what the
 // stable sort of (key, index) pairs yields.  Launch 1 draws the Philox keys and scatters the values into 256 buckets by the key's top byte
 // (one atomic counter per bucket: the order INSIDE a bucket does not matter, it is sorted next); launch 2, one workgroup per bucket, sorts
 // its ~B/256 values in LDS (bitonic), finds its place by summing the counters of the buckets before it, and writes the indices.  Counters are
 // double-buffered by the parity of the update index and zeroed for the update after next by the workgroups that read them.
 constexpr int kPermBuckets = 256;
-constexpr int kPermCap = 1024;  // slots per bucket: the mean is B / 256 <= 256, the standard deviation <= 16
+constexpr int kPermCap = 1024;  // slots per bucket: the mean is B / 256 <= 512, the standard deviation <= 23
+constexpr int kPermIdxBits = 20;  // the index part of a value
+constexpr int kPermMaxB = 131072;
 
 static size_t perm_fast_bytes(int E) { return align_up((size_t)(2 * E * kPermBuckets + 64) * 4, 256) + (size_t)E * kPermBuckets * kPermCap * 8; }
 
@@ -89,8 +91,8 @@ __global__ void __launch_bounds__(kScatterThreads) perm_scatter_kernel(unsigned 
       const int i = 4 * q + k;
       if (i < B) {
         const int b = (int)(z[k] >> 24), pos = s_base[b] + rank[k];
-        if (pos < kPermCap) slots[((size_t)e * kPermBuckets + b) * kPermCap + pos] = ((unsigned long long)z[k] << 16) | (unsigned long long)i;
-        else cnt_base[2 * E * kPermBuckets] = 1;  // (cannot happen for B <= 65536 short of a 48-sigma event; recorded all the same)
+        if (pos < kPermCap) slots[((size_t)e * kPermBuckets + b) * kPermCap + pos] = ((unsigned long long)z[k] << kPermIdxBits) | (unsigned long long)i;
+        else cnt_base[2 * E * kPermBuckets] = 1;  // (cannot happen for B <= 131072 short of a 22-sigma event; recorded all the same)
       }
     }
   }
@@ -111,7 +113,7 @@ __global__ void __launch_bounds__(256) perm_bucket_kernel(const int* __restrict_
   const int n = n_all < kPermCap ? n_all : kPermCap;
   const unsigned long long* src = slots + ((size_t)e * kPermBuckets + b) * kPermCap;
   if (n <= 256) {
-    // the usual case (B / 256 values, at most 256 up to B = 65 536 but for the tail of the distribution): every thread holds one value and
+    // the usual case (B / 256 values per bucket on average; more go through the bitonic sort below): every thread holds one value and
     // counts the smaller ones - its place in the bucket.  The values are distinct (the index is part of them): the ranks are a permutation.
     const unsigned long long v = t < n ? src[t] : ~0ull;
     s[t] = v;
@@ -120,7 +122,7 @@ __global__ void __launch_bounds__(256) perm_bucket_kernel(const int* __restrict_
     int rk = 0;
 #pragma unroll 8
     for (int j = 0; j < n; ++j) rk += (int)(s[j] < v);
-    if (t < n) idx[(size_t)e * B + off + rk] = (int)(v & 0xFFFFull);
+    if (t < n) idx[(size_t)e * B + off + rk] = (int)(v & ((1ull << kPermIdxBits) - 1));
   } else {
     int m2 = 2;
     while (m2 < n) m2 <<= 1;  // elements sorted: the next power of two (uniform)
@@ -139,7 +141,7 @@ __global__ void __launch_bounds__(256) perm_bucket_kernel(const int* __restrict_
         }
         __syncthreads();
       }
-    for (int k = t; k < n; k += 256) idx[(size_t)e * B + off + k] = (int)(s[k] & 0xFFFFull);
+    for (int k = t; k < n; k += 256) idx[(size_t)e * B + off + k] = (int)(s[k] & ((1ull << kPermIdxBits) - 1));
   }
   if (t == 0) cnt_base[((par ^ 1) * E + e) * kPermBuckets + b] = 0;  // the other parity's counter: next used by the update after this one
 }
@@ -148,21 +150,21 @@ size_t permutation_batch_ws_bytes(int B, int E) {
   if (B < 1 || E < 1) return 0;
   const size_t n = (size_t)B * E;  // keys_in, keys_out (64-bit), vals_in + rocPRIM temporary storage
   const size_t sort_bytes = 2 * align_up(n * 8, 256) + align_up(n * 4, 256) + align_up(sort_temp_bytes64(n, 32 + bits_for(E)), 256);
-  return B <= 65536 && perm_fast_bytes(E) > sort_bytes ? perm_fast_bytes(E) : sort_bytes;
+  return B <= kPermMaxB && perm_fast_bytes(E) > sort_bytes ? perm_fast_bytes(E) : sort_bytes;
 }
 // the counters of the two-launch form must be zero before its first use (mppo_engine_reset)
 int32_t permutation_batch_prepare(int B, int E, void* ws, size_t ws_bytes, hipStream_t s) {
-  if (B <= 65536 && ws && ws_bytes >= perm_fast_bytes(E)) MPPO_CHECK_HIP(hipMemsetAsync(ws, 0, (size_t)(2 * E * kPermBuckets + 64) * 4, s));
+  if (B <= kPermMaxB && ws && ws_bytes >= perm_fast_bytes(E)) MPPO_CHECK_HIP(hipMemsetAsync(ws, 0, (size_t)(2 * E * kPermBuckets + 64) * 4, s));
   return MPPO_OK;
 }
-// All E epoch permutations of an update: block e of the result is exactly what permutation_ctr(stream_id0 + e) produces.  B <= 65536 and a
+// All E epoch permutations of an update: block e of the result is exactly what permutation_ctr(stream_id0 + e) produces.  B <= kPermMaxB and a
 // device counter: the two launches above; otherwise ONE sort of the pairs (epoch << 32 | key, index) of all epochs - the sort is stable and
 // the epoch is the most significant part of the key.
 int32_t permutation_batch_ctr(unsigned long long seed, unsigned long long stream_id0, const int* ctr, int B, int E, int* idx, void* ws, size_t ws_bytes,
                               hipStream_t s) {
   MPPO_REQUIRE(B >= 1 && E >= 1 && idx && ws, "permutation_batch: bad argument");
   if (ws_bytes < permutation_batch_ws_bytes(B, E)) return fail(MPPO_ENOMEM, "permutation_batch: workspace %zu < %zu bytes", ws_bytes, permutation_batch_ws_bytes(B, E));
-  if (B <= 65536 && ctr && ws_bytes >= perm_fast_bytes(E)) {
+  if (B <= kPermMaxB && ctr && ws_bytes >= perm_fast_bytes(E)) {
     int* cnt = static_cast<int*>(ws);
     unsigned long long* slots = reinterpret_cast<unsigned long long*>(static_cast<unsigned char*>(ws) + align_up((size_t)(2 * E * kPermBuckets + 64) * 4, 256));
     hipLaunchKernelGGL(perm_scatter_kernel, dim3(cdiv(cdiv(B, 4), kScatterThreads), E), dim3(kScatterThreads), 0, s, seed, stream_id0, ctr, B, cnt, slots);

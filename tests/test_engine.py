@@ -372,19 +372,22 @@ def test_rccl_path_at_world_size_one_is_the_identity(monkeypatch):
 
 
 @pytest.mark.gpu
-def test_two_launch_permutations_equal_the_sort_at_full_size():
-    """The engine's permutations at BASELINE size (B = 40 960 samples, E = 4 epochs): two launches - scatter of (key, index) values into 256
+@pytest.mark.parametrize("config,envs", [("stompy_pro", 4096), ("stompy_full", 8192)])
+def test_two_launch_permutations_equal_the_sort_at_full_size(config, envs):
+    """The engine's permutations at BASELINE sizes (configs[1]: B = 40 960 samples, configs[4]: B = 81 920 - more than 16 index bits; E = 4 epochs): two launches - scatter of (key, index) values into 256
     buckets, one LDS bitonic sort per bucket (csrc/k_perm.hip) - instead of one key launch + nine rocPRIM launches.  The first update's
     permutations equal `mppo_permutation` (rocPRIM's stable sort of the same Philox keys) epoch by epoch, bit for bit; the following
     updates (the double-buffered bucket counters of both parities, replayed from the hipGraph) stay bijective and differ from update to update."""
     from backends import get_backend
 
     be = get_backend("hip")
-    cfg = _cfg("training.num_envs=4096")
+    from minppo_amd.config import load_config_from_cli
+
+    cfg = load_config_from_cli([config, f"training.num_envs={envs}"])
     tr = be.trainer(cfg, use_graph=True)
     tr.reset()
     E, B = tr.E, tr.T * tr.N
-    assert (E, B) == (4, 40960)
+    assert (E, B) == (4, 10 * envs)
     seen = []
     for u in range(4):
         tr.update()
