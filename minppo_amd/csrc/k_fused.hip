@@ -30,8 +30,10 @@ namespace mppo {
 #ifdef MPPO_FUSED_TIMERS
 __device__ unsigned long long g_fused_t[24 + 64];
 #define FT(k) do { if (!ROLLOUT && blockIdx.x == 40 && blockIdx.y == 0 && threadIdx.x == 0) g_fused_t[k] = __builtin_amdgcn_s_memtime(); } while (0)
+#define FTW(k) do { if (!ROLLOUT && blockIdx.x == 40 && blockIdx.y == 0 && (threadIdx.x & 63) == 0) g_fused_t[(k) + (threadIdx.x >> 6)] = __builtin_amdgcn_s_memtime(); } while (0)
 #else
 #define FT(k) do { } while (0)
+#define FTW(k) do { } while (0)
 #endif
 
 constexpr float kLog2PiF = 1.8378770664093453f;
@@ -328,6 +330,7 @@ template <bool BF16, bool ROLLOUT, int OT, bool W2T = false, bool PRE = false>
 __global__ void __launch_bounds__(512, ROLLOUT ? MPPO_ROLLOUT_WAVES : MPPO_TRAIN_WAVES) fused_mlp_kernel(FusedArgs a) {
   constexpr int SD = 16 * OT;  // row stride of the per-row output-space tiles
   FT(0);
+  FTW(56);
   // The role is decided from the launch geometry alone (grid rows 0, 1: the two networks; rows 2, 3: gather), not from a kernel
   // argument: a scalar load ahead of this branch would put one more (cold) trip to the argument segment in front of every row tile.
   // <ROLLOUT, PRE> together name the gather-ONLY launch (fused_gather_rows): every workgroup gathers.
@@ -481,6 +484,7 @@ __global__ void __launch_bounds__(512, ROLLOUT ? MPPO_ROLLOUT_WAVES : MPPO_TRAIN
   }
 
   FT(2);
+  FTW(64);
   // ---- P0: gathered observation rows -> LDS (zero-padded to KP columns) ----
   if (PRE) {
     // a k-quad element is one column of four consecutive rows: four LDS words a row stride apart (consecutive lanes hold consecutive columns)
@@ -506,8 +510,10 @@ __global__ void __launch_bounds__(512, ROLLOUT ? MPPO_ROLLOUT_WAVES : MPPO_TRAIN
     if (c4 < OP) q = *reinterpret_cast<const float4*>(a.b.obs + row * a.b.obs_ld + c4);
     *reinterpret_cast<float4*>(xt + r * XS + c4) = q;
   }
+  FTW(72);
   __syncthreads();
   FT(3);
+  FTW(80);
   // ---- P1 / P2: hidden layers ----
   typename PipeSel<FRAG, false>::type pipe2;
   typename PipeSel<FRAG, !W2T>::type pipe5;

@@ -13,8 +13,9 @@ cfg = load_config_from_cli(["stompy_pro", "training.num_envs=4096"])
 tr = Trainer(cfg, use_graph=False)
 tr.reset(); tr.update(); tr._sync()
 dll = C.CDLL(str(nat.HIP_LIB_PATH))
-names = {0: "entry -> args", 1: "weights prefetch, biases, head weights", 2: "index -> rows chain (issue)", 3: "x tile to LDS + barrier + xmb copy", 4: "L1 GEMM",
-         5: "L1 epilogue + stores + barrier", 6: "L2 GEMM", 7: "L2 epilogue + stores + barrier", 8: "head GEMM + partials + barrier", 9: "head sums + loss + dOut",
+# interval i ends at stamp FT(i + 1) of csrc/k_fused.hip
+names = {0: "entry -> arguments; weights / biases / head weights requested", 1: "index -> rows chain (index wait, dependent loads issued)", 2: "x tile to LDS + barrier", 3: "L1 GEMM (this wave)",
+         4: "L1 epilogue + stores + barrier (waits for the SIMD's second wave)", 5: "L2 GEMM (this wave)", 6: "L2 epilogue + stores + barrier", 7: "(two stamps in a row)", 8: "head GEMM + partials + barrier", 9: "head sums + loss + dOut",
          10: "barrier + loss partials", 11: "dZ2 + stores + barrier", 12: "dZ1 GEMM", 13: "dZ1 epilogue + stores"}
 acc = {}
 for k in range(10):
@@ -24,6 +25,8 @@ for k in range(10):
     for i in range(14):
         acc.setdefault(i, []).append(float(t[i + 1] - t[i]))
     if k == 9:
+        print("per wave, ticks after wave 0 entered the kernel: entry", [int(t[56 + w] - t[0]) for w in range(8)], "| loads issued", [int(t[64 + w] - t[0]) for w in range(8)],
+              "| x tile written, at the barrier", [int(t[72 + w] - t[0]) for w in range(8)], "| past the barrier", [int(t[80 + w] - t[0]) for w in range(8)])
         for layer in (0, 1):
             print(f'layer {layer + 1} GEMM per wave (start, end) in ticks after wave 0 entered the layer loop:', [(int(t[24 + 16 * layer + w] - t[3]), int(t[24 + 16 * layer + 8 + w] - t[3])) for w in range(8)])
 tot = sum(float(np.median(v)) for v in acc.values())
