@@ -372,6 +372,40 @@ def test_rccl_path_at_world_size_one_is_the_identity(monkeypatch):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("envs,steps,minibatches,epochs", [(6, 3, 2, 2), (64, 10, 32, 4), (1000, 7, 4, 3), (13107, 10, 2, 1)])
+def test_two_launch_permutations_equal_the_sort_at_odd_sizes(envs, steps, minibatches, epochs):
+    """The same at batch sizes that fill the 256 buckets unevenly or hardly at all (B = 18: most buckets empty; B = 640: BASELINE configs[0];
+    B = 7 000: not a multiple of the scatter launch's 4 096 values per workgroup; B = 131 070: the largest batches the two launches take,
+    512 values per bucket on average = the LDS bitonic sort instead of the rank sort)."""
+    from backends import get_backend
+
+    be = get_backend("hip")
+    cfg = _cfg(f"training.num_envs={envs}", f"training.num_steps={steps}", f"rl.num_env_steps={steps}", f"training.num_minibatches={minibatches}",
+               f"training.update_epochs={epochs}", "training.total_timesteps=1000000000")
+    tr = be.trainer(cfg, use_graph=False)
+    tr.reset()
+    E, B = tr.E, tr.T * tr.N
+    assert (E, B) == (epochs, envs * steps)
+    prev = None
+    for u in range(3):
+        tr.update()
+        tr._sync()
+        perm = be.host(tr.region("perm", (E, B))).copy()
+        for e in range(E):
+            assert (np.sort(perm[e]) == np.arange(B)).all(), (u, e)
+        if u == 0:
+            wsb = be.lib.permutation_ws_bytes(B)
+            pws, one = be.zeros((wsb // 4 + 1,)), be.zeros((B,), np.int32)
+            for e in range(E):
+                be.lib.permutation(tr.seed, (0x5045524D << 24) + e, B, be.ptr(one), be.ptr(pws), wsb, be.stream)
+                np.testing.assert_array_equal(perm[e], be.host(one), err_msg=f"epoch {e}")
+        else:
+            assert (perm != prev).mean() > 0.8
+        prev = perm
+    tr.close()
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("config,envs", [("stompy_pro", 4096), ("stompy_full", 8192)])
 def test_two_launch_permutations_equal_the_sort_at_full_size(config, envs):
     """The engine's permutations at BASELINE sizes (configs[1]: B = 40 960 samples, configs[4]: B = 81 920 - more than 16 index bits; E = 4 epochs): two launches - scatter of (key, index) values into 256
