@@ -51,8 +51,9 @@ static size_t sort_temp_bytes64(size_t n, int end_bit) {
 // floor, 70 us of every update).  A permutation of B <= 131072 samples is the order of the 52-bit values (key << 20 | index): exactly what the
 // stable sort of (key, index) pairs yields.  Launch 1 draws the Philox keys and scatters the values into 256 buckets by the key's top byte
 // (one atomic counter per bucket: the order INSIDE a bucket does not matter, it is sorted next); launch 2, one workgroup per bucket, sorts
-// its ~B/256 values in LDS (bitonic), finds its place by summing the counters of the buckets before it, and writes the indices.  Counters are
-// double-buffered by the parity of the update index and zeroed for the update after next by the workgroups that read them.
+// its ~B/256 values in LDS (rank sort, bitonic above 256 values), finds its place by summing the counters of the buckets before it, and writes
+// the indices.  The last of an epoch's 256 bucket workgroups to finish takes that epoch's counters back to zero: they are zero between
+// launches whatever the caller does to the update index (a restored checkpoint, a repeated update).
 constexpr int kPermBuckets = 256;
 constexpr int kPermCap = 1024;  // slots per bucket: the mean is B / 256 <= 512, the standard deviation <= 23
 constexpr int kPermIdxBits = 20;  // the index part of a value
@@ -68,8 +69,7 @@ __global__ void __launch_bounds__(kScatterThreads) perm_scatter_kernel(unsigned 
   // form took 22 us at B = 40 960: 160 contended atomics per counter)
   __shared__ int s_cnt[kPermBuckets], s_base[kPermBuckets];
   const int t = threadIdx.x, q = blockIdx.x * kScatterThreads + t, e = blockIdx.y, E = gridDim.y;
-  const int par = ctr[0] & 1;
-  int* cnt = cnt_base + (par * E + e) * kPermBuckets;
+  int* cnt = cnt_base + e * kPermBuckets;
   if (t < kPermBuckets) s_cnt[t] = 0;
   __syncthreads();
   const unsigned long long stream_id = stream_id0 + (unsigned long long)e;
@@ -92,18 +92,17 @@ __global__ void __launch_bounds__(kScatterThreads) perm_scatter_kernel(unsigned 
       if (i < B) {
         const int b = (int)(z[k] >> 24), pos = s_base[b] + rank[k];
         if (pos < kPermCap) slots[((size_t)e * kPermBuckets + b) * kPermCap + pos] = ((unsigned long long)z[k] << kPermIdxBits) | (unsigned long long)i;
-        else cnt_base[2 * E * kPermBuckets] = 1;  // (cannot happen for B <= 131072 short of a 22-sigma event; recorded all the same)
+        else cnt_base[E * kPermBuckets] = 1;  // (cannot happen for B <= 131072 short of a 22-sigma event; recorded all the same)
       }
     }
   }
 }
 
-__global__ void __launch_bounds__(256) perm_bucket_kernel(const int* __restrict__ ctr, int B, int* __restrict__ cnt_base, const unsigned long long* __restrict__ slots, int* __restrict__ idx) {
+__global__ void __launch_bounds__(256) perm_bucket_kernel(int B, int* __restrict__ cnt_base, const unsigned long long* __restrict__ slots, int* __restrict__ idx) {
   __shared__ unsigned long long s[kPermCap];
-  __shared__ int s_part[4];
+  __shared__ int s_part[4], s_last;
   const int b = blockIdx.x, e = blockIdx.y, E = gridDim.y, t = threadIdx.x;
-  const int par = ctr[0] & 1;
-  int* cnt = cnt_base + (par * E + e) * kPermBuckets;
+  int* cnt = cnt_base + e * kPermBuckets;
   const int mine = cnt[t];  // thread t holds bucket t's count (256 threads = 256 buckets)
   // this bucket's count (a uniform read) and its offset: the counts of the buckets before it
   const int n_all = cnt[b];
@@ -143,7 +142,14 @@ __global__ void __launch_bounds__(256) perm_bucket_kernel(const int* __restrict_
       }
     for (int k = t; k < n; k += 256) idx[(size_t)e * B + off + k] = (int)(s[k] & ((1ull << kPermIdxBits) - 1));
   }
-  if (t == 0) cnt_base[((par ^ 1) * E + e) * kPermBuckets + b] = 0;  // the other parity's counter: next used by the update after this one
+  // every workgroup of the epoch has read the counters once its index stores are out (their addresses depend on the counts): the last
+  // one to say so zeroes them for the next launch
+  if (t == 0) s_last = atomicAdd(&cnt_base[E * kPermBuckets + 64 + e], 1) == kPermBuckets - 1;
+  __syncthreads();
+  if (s_last) {
+    cnt[t] = 0;
+    if (t == 0) cnt_base[E * kPermBuckets + 64 + e] = 0;
+  }
 }
 
 size_t permutation_batch_ws_bytes(int B, int E) {
@@ -169,7 +175,7 @@ int32_t permutation_batch_ctr(unsigned long long seed, unsigned long long stream
     unsigned long long* slots = reinterpret_cast<unsigned long long*>(static_cast<unsigned char*>(ws) + align_up((size_t)(2 * E * kPermBuckets + 64) * 4, 256));
     hipLaunchKernelGGL(perm_scatter_kernel, dim3(cdiv(cdiv(B, 4), kScatterThreads), E), dim3(kScatterThreads), 0, s, seed, stream_id0, ctr, B, cnt, slots);
     MPPO_CHECK_LAUNCH("perm_scatter_kernel");
-    hipLaunchKernelGGL(perm_bucket_kernel, dim3(kPermBuckets, E), dim3(256), 0, s, ctr, B, cnt, slots, idx);
+    hipLaunchKernelGGL(perm_bucket_kernel, dim3(kPermBuckets, E), dim3(256), 0, s, B, cnt, slots, idx);
     MPPO_CHECK_LAUNCH("perm_bucket_kernel");
     return MPPO_OK;
   }

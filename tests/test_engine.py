@@ -406,6 +406,39 @@ def test_two_launch_permutations_equal_the_sort_at_odd_sizes(envs, steps, miniba
 
 
 @pytest.mark.gpu
+def test_two_launch_permutations_survive_a_rewound_update_index():
+    """The bucket counters of the two-launch permutation are taken back to zero by the launch that read them, so they do not depend on the
+    history of the update index: an update repeated with the index written back through the arena (what a C-ABI caller restoring its own
+    snapshot of the `count` region does, without mppo_engine_reset) draws the very same permutations again."""
+    from backends import get_backend
+
+    be = get_backend("hip")
+    cfg = _cfg("training.num_envs=1024", "training.total_timesteps=1000000000")
+    tr = be.trainer(cfg, use_graph=True)
+    tr.reset()
+    E, B = tr.E, tr.T * tr.N
+    tr.update(); tr.update()
+    tr._sync()
+    count = be.host(tr.region("count")).copy()
+    tr.update()
+    tr._sync()
+    first = be.host(tr.region("perm", (E, B))).copy()
+    be.put(tr.region("count"), count)  # same update index (and Adam step) again: same parity as the launch before
+    tr.update()
+    tr._sync()
+    again = be.host(tr.region("perm", (E, B))).copy()
+    np.testing.assert_array_equal(first, again)
+    for e in range(E):
+        assert (np.sort(again[e]) == np.arange(B)).all()
+    tr.update()
+    tr._sync()
+    nxt = be.host(tr.region("perm", (E, B)))
+    for e in range(E):
+        assert (np.sort(nxt[e]) == np.arange(B)).all()
+    tr.close()
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("config,envs", [("stompy_pro", 4096), ("stompy_full", 8192)])
 def test_two_launch_permutations_equal_the_sort_at_full_size(config, envs):
     """The engine's permutations at BASELINE sizes (configs[1]: B = 40 960 samples, configs[4]: B = 81 920 - more than 16 index bits; E = 4 epochs): two launches - scatter of (key, index) values into 256
