@@ -238,6 +238,8 @@ int32_t mppo_clip_adam_shadow(const mppo_net_t* net, int32_t mb, void* grad_ws, 
  * the parameters, so the row pass of optimizer step s gathers the rows of step s + 1 on extra workgroups of its own launch into
  * the other of two k-quad buffers of the gradient workspace (`parity` 0 / 1 names the buffer that holds the CURRENT step's rows);
  * step s + 1 then starts from a contiguous tile instead of the index -> row chain (reference train.py:261-265, the gather).
+ * The same workgroups gather the rows' scalars of the loss (action, old log_prob, advantage, old value, target) behind the observation
+ * rows of the buffer, four rows of a column per float4: the next row pass reads them without an index -> row chain either.
  *   mppo_gather_rows               rows idx[0 .. mb) -> buffer `parity` (the first step of an update)
  *   mppo_minibatch_rowpass_pre     = mppo_minibatch_rowpass_shadow reading buffer `parity` and gathering idx_next (may be NULL: the
  *                                    last step) into the other buffer

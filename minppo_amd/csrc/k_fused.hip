@@ -318,6 +318,23 @@ __device__ __forceinline__ void gather_rows_tile(const FusedArgs& a, int tile, i
     }
     store_quad<BF16>(a.xnext, quad_index(row0 + 4 * qd, c, OP), v);
   }
+  // the same rows' scalars of the loss, behind the observation quads (ppo_layout.h xquad_floats): float4 = one column of four rows
+  if (a.b.action) {
+    const int A = a.A, SC = A + 4;
+    float* sq = a.xnext + xquad_obs_floats(OP, a.mb);
+    for (int e = threadIdx.x; e < 2 * SC; e += blockDim.x) {
+      const int qd = 2 * half + e / SC, c = e % SC;
+      float v[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int r = row0 + 4 * qd + j;
+        const long ix = a.idx_next[r < a.mb ? r : a.mb - 1];
+        const float x = c < A ? a.b.action[ix * a.b.act_ld + c] : c == A ? a.b.log_prob[ix] : c == A + 1 ? a.b.adv[ix] : c == A + 2 ? a.b.value[ix] : a.b.target[ix];
+        v[j] = r < a.mb ? x : 0.f;
+      }
+      *reinterpret_cast<float4*>(sq + ((size_t)((row0 >> 2) + qd) * SC + c) * 4) = make_float4(v[0], v[1], v[2], v[3]);
+    }
+  }
 }
 
 // rollout launches have 2 x N/16 workgroups (512 at N = 4096): two per CU must be co-resident = 4 waves per SIMD (the second
@@ -432,7 +449,7 @@ __global__ void __launch_bounds__(512, ROLLOUT ? MPPO_ROLLOUT_WAVES : MPPO_TRAIN
     const int i = row0 + 4 * rq + r;
     pon[r] = i < a.mb;
     const int ic = pon[r] ? i : a.mb - 1;
-    prow[r] = gather ? (long)a.idx[ic] : (long)ic;
+    prow[r] = (gather && !PRE) ? (long)a.idx[ic] : (long)ic;  // (PRE: the loss scalars come pre-gathered, nothing here is addressed by index)
   }
   if (gather && !PRE) { xrow0 = a.idx[gi0]; xrow1 = a.idx[gi1]; }
   // dependent batch: the observation chunks (needed first), then the per-row scalars of the loss (needed four phases later)
@@ -463,6 +480,26 @@ __global__ void __launch_bounds__(512, ROLLOUT ? MPPO_ROLLOUT_WAVES : MPPO_TRAIN
           const float v = a.noise[(size_t)prow[r] * A + (o < A ? o : A - 1)];
           pf0[ot][r] = (pon[r] && o < A) ? v : 0.f;
         }
+    }
+  } else if (PRE) {
+    // pre-gathered by the previous launch (gather_rows_tile): the lane's four rows of a column are ONE float4 of the scalar quads behind
+    // the observation quads - contiguous per row tile, no index, no dependent trip (rows past the minibatch read as 0; every use is masked)
+    const int SC = A + 4;
+    const float* sq = a.xpre + xquad_obs_floats(OP, a.mb) + ((size_t)((row0 >> 2) + rq) * SC) * 4;
+    if (net == 0) {
+#pragma unroll
+      for (int ot = 0; ot < OT; ++ot) {
+        const int o = cj + 16 * ot;
+        const float4 q = *reinterpret_cast<const float4*>(sq + 4 * (o < A ? o : A - 1));
+        pf0[ot][0] = q.x; pf0[ot][1] = q.y; pf0[ot][2] = q.z; pf0[ot][3] = q.w;
+      }
+      const float4 q1 = *reinterpret_cast<const float4*>(sq + 4 * A), q2 = *reinterpret_cast<const float4*>(sq + 4 * (A + 1));
+      pf1[0] = q1.x; pf1[1] = q1.y; pf1[2] = q1.z; pf1[3] = q1.w;
+      pf2[0] = q2.x; pf2[1] = q2.y; pf2[2] = q2.z; pf2[3] = q2.w;
+    } else {
+      const float4 q0 = *reinterpret_cast<const float4*>(sq + 4 * (A + 2)), q1 = *reinterpret_cast<const float4*>(sq + 4 * (A + 3));
+      pf0[0][0] = q0.x; pf0[0][1] = q0.y; pf0[0][2] = q0.z; pf0[0][3] = q0.w;
+      pf1[0] = q1.x; pf1[1] = q1.y; pf1[2] = q1.z; pf1[3] = q1.w;
     }
   } else if (net == 0) {
 #pragma unroll
@@ -891,7 +928,7 @@ int32_t fused_forward_backward(const mppo_net_t& net, const float* params, const
 int32_t fused_gather_rows(const mppo_net_t& net, const mppo_batch_t& batch, const int* idx, int mb, float* dst, hipStream_t stream) {
   MPPO_REQUIRE(idx && dst && batch.obs, "fused_gather_rows: null argument");
   FusedArgs a{};
-  a.mb = mb; a.O = net.O; a.OP = net.OP; a.H = net.H; a.b = batch; a.idx_next = idx; a.xnext = dst;
+  a.mb = mb; a.O = net.O; a.OP = net.OP; a.A = net.A; a.H = net.H; a.b = batch; a.idx_next = idx; a.xnext = dst;
   if (net.bf16) hipLaunchKernelGGL((fused_mlp_kernel<true, true, 1, true, true>), dim3(cdiv(mb, FRT), 2), dim3(256), 0, stream, a);  // (bf16 quads)
   else hipLaunchKernelGGL((fused_mlp_kernel<false, true, 1, true, true>), dim3(cdiv(mb, FRT), 2), dim3(256), 0, stream, a);
   MPPO_CHECK_LAUNCH("fused_mlp_kernel<gather>");

@@ -48,13 +48,13 @@ inline ParamLayout param_layout(int O, int A, int H, int nl = 2) {
 }
 inline ParamLayout param_layout(const mppo_net_t& n) { return param_layout(n.O, n.A, n.H, net_layers(n)); }
 
-inline size_t pad4(size_t n) { return (n + 3) & ~(size_t)3; }
+__host__ __device__ inline size_t pad4(size_t n) { return (n + 3) & ~(size_t)3; }
 
 // K-QUAD layout of a [rows][cols] operand of the weight-gradient product (contraction over rows): [rows/4][cols][4], i.e. the
 // four consecutive rows of a column are one float4.  The fused row pass (k_fused.hip) writes h1, h2, dZ1, dZ2, dOut and the
 // gathered observations this way and k_wgrad.hip reads them; rows are padded to the row pass's 16-row tiles with zeros.
 __host__ __device__ inline size_t quad_index(size_t row, size_t col, size_t cols) { return ((row >> 2) * cols + col) * 4 + (row & 3); }
-inline size_t pad16(size_t n) { return (n + 15) & ~(size_t)15; }
+__host__ __device__ inline size_t pad16(size_t n) { return (n + 15) & ~(size_t)15; }
 
 // activations of one forward pass over n rows
 struct FwdBufs {
@@ -115,12 +115,17 @@ struct GradBufs {
   int ksplit;
   size_t slab_stride;
 };
+// one pre-gathered minibatch (xmb / xmb2): the observation rows in k-quad layout [mbp / 4][OP][4], and behind them the per-row scalars of the
+// loss in the same layout, [mbp / 4][A + 4][4]: columns 0 .. A - 1 the action, A old log_prob, A + 1 advantage, A + 2 old value, A + 3 target
+// (k_fused.hip: gathered by the same workgroups as the rows, read by the next step's row tiles as whole float4s - no index -> row chain)
+__host__ __device__ inline size_t xquad_obs_floats(int OP, int mb) { return pad4(pad16((size_t)mb) * OP); }
+inline size_t xquad_floats(const mppo_net_t& net, int mb) { return xquad_obs_floats(net.OP, mb) + pad4(pad16((size_t)mb) * (net.A + 4)); }
 inline size_t grad_bufs_floats(const mppo_net_t& net, int mb) {
   const size_t mbp = pad16((size_t)mb);  // the quad-layout operands are written in whole 16-row tiles
   const size_t AP = pad4((size_t)net.A), nh = pad4(mbp * net.H);
   const size_t P = pad4((size_t)param_layout(net).total);
   const size_t nblk = (size_t)(mb + 3) / 4;  // head kernel: 8 rows per workgroup, 4 with more than 31 action dimensions (fused kernel: 16)
-  return fwd_bufs_floats(net, (int)mbp) + pad4(mbp * (AP + 4)) + 2 * (size_t)net_layers(net) * nh + pad4(nblk * (4 + AP)) + (size_t)kGradKSplitMax * P + 2 * pad4(mbp * net.OP) + 2 * pad4((size_t)net.H * net.H) +  // (xmb, xmb2)
+  return fwd_bufs_floats(net, (int)mbp) + pad4(mbp * (AP + 4)) + 2 * (size_t)net_layers(net) * nh + pad4(nblk * (4 + AP)) + (size_t)kGradKSplitMax * P + 2 * xquad_floats(net, mb) + 2 * pad4((size_t)net.H * net.H) +  // (xmb, xmb2)
          (net.bf16 ? pad4((size_t)(((net.O + 31) & ~31) + 2 * net.H) * net.H) : 0);  // bf16 fragments: 2 networks x (KP + 2H) x H halves = that many floats
 }
 inline GradBufs carve_grad(const mppo_net_t& net, int mb, float* ws) {
@@ -138,8 +143,8 @@ inline GradBufs carve_grad(const mppo_net_t& net, int mb, float* ws) {
   g.partial = ws; ws += pad4(nblk * (4 + AP));
   g.slabs = ws;
   g.xmb = ws + (size_t)kGradKSplitMax * pad4((size_t)param_layout(net).total);
-  g.xmb2 = g.xmb + pad4(mbp * net.OP);
-  g.w2t = g.xmb2 + pad4(mbp * net.OP);  // (the shadow copies stay the LAST region of the workspace)
+  g.xmb2 = g.xmb + xquad_floats(net, mb);
+  g.w2t = g.xmb2 + xquad_floats(net, mb);  // (the shadow copies stay the LAST region of the workspace)
   g.w2t_valid = false;
   g.frag = net.bf16 ? reinterpret_cast<unsigned short*>(g.w2t + 2 * pad4((size_t)net.H * net.H)) : nullptr;
   g.frag_net_stride = (size_t)(((net.O + 31) & ~31) + 2 * net.H) * net.H;
