@@ -29,8 +29,11 @@
 namespace mppo {
 const ModelView& model_view(const mppo_model* m);
 
-__global__ void advance_counters_kernel(int* count, int opt_steps) {
+// end of an update: the Adam step index and the update index move on; `zero` (optional): words another kernel of the update wants back
+// at zero before its next use (the bucket counters of the two-launch permutation, k_perm.hip)
+__global__ void advance_counters_kernel(int* count, int opt_steps, int* zero = nullptr, int nzero = 0) {
   if (threadIdx.x == 0 && blockIdx.x == 0 && opt_steps > 0) { count[0] += opt_steps; count[1] += 1; }
+  for (int i = threadIdx.x; i < nzero; i += blockDim.x) zero[i] = 0;
 }
 
 // Per-update rollout statistics: the device-side reduction of what the reference returns as the full [T,N] history of
@@ -328,12 +331,15 @@ static int32_t do_learn(mppo_engine* e, hipStream_t s) {
       MPPO_TRY(clip_adam((size_t)e->P, e->params, e->adam_m, e->adam_v, e->grad, e->count, st, ac, e->adam_ws, single, s, use_shadow ? &shadow : nullptr));  // train.py:248
 #ifdef MPPO_EXPERIMENTS
       static const int extra = [] { const char* v = getenv("MPPO_EXTRA_LAUNCHES"); return v ? atoi(v) : 0; }();  // timing experiment: what does ONE more trivial launch cost here?
-      for (int x = 0; x < extra; ++x) hipLaunchKernelGGL(advance_counters_kernel, dim3(1), dim3(64), 0, s, e->count, 0);
+      for (int x = 0; x < extra; ++x) hipLaunchKernelGGL(advance_counters_kernel, dim3(1), dim3(64), 0, s, e->count, 0, (int*)nullptr, 0);
 #endif
     }
   }
   if (use_peer) MPPO_TRY(peer_advance(e->peer, EM, s));
-  hipLaunchKernelGGL(advance_counters_kernel, dim3(1), dim3(64), 0, s, e->count, EM);
+  int* perm_cnt = nullptr;
+  int perm_ncnt = 0;
+  if (!c.external_random && c.rng_impl != 1) permutation_batch_counters(e->B, e->E, e->perm_ws, e->perm_ws_bytes, &perm_cnt, &perm_ncnt);
+  hipLaunchKernelGGL(advance_counters_kernel, dim3(1), dim3(256), 0, s, e->count, EM, perm_cnt, perm_ncnt);
   MPPO_CHECK_LAUNCH("advance_counters_kernel");
   // carry last_obs into slot 0 of the next rollout (RunnerState.last_obs, train.py:174,279)
   MPPO_CHECK_HIP(hipMemcpyAsync(e->obs, e->obs + (size_t)e->T * e->N * e->OP, (size_t)e->N * e->OP * 4, hipMemcpyDeviceToDevice, s));

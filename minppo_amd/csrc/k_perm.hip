@@ -52,8 +52,9 @@ static size_t sort_temp_bytes64(size_t n, int end_bit) {
 // stable sort of (key, index) pairs yields.  Launch 1 draws the Philox keys and scatters the values into 256 buckets by the key's top byte
 // (one atomic counter per bucket: the order INSIDE a bucket does not matter, it is sorted next); launch 2, one workgroup per bucket, sorts
 // its ~B/256 values in LDS (rank sort, bitonic above 256 values), finds its place by summing the counters of the buckets before it, and writes
-// the indices.  The last of an epoch's 256 bucket workgroups to finish takes that epoch's counters back to zero: they are zero between
-// launches whatever the caller does to the update index (a restored checkpoint, a repeated update).
+// the indices.  The counters are zeroed again by the caller's next launch (permutation_batch_counters: the engine's end-of-update kernel does
+// it; a counter that every bucket workgroup decrements through one atomic costs 10 us of contention): they are zero between updates
+// whatever the caller does to the update index (a restored checkpoint, a repeated update).
 constexpr int kPermBuckets = 256;
 constexpr int kPermCap = 1024;  // slots per bucket: the mean is B / 256 <= 512, the standard deviation <= 23
 constexpr int kPermIdxBits = 20;  // the index part of a value
@@ -100,8 +101,8 @@ __global__ void __launch_bounds__(kScatterThreads) perm_scatter_kernel(unsigned 
 
 __global__ void __launch_bounds__(256) perm_bucket_kernel(int B, int* __restrict__ cnt_base, const unsigned long long* __restrict__ slots, int* __restrict__ idx) {
   __shared__ unsigned long long s[kPermCap];
-  __shared__ int s_part[4], s_last;
-  const int b = blockIdx.x, e = blockIdx.y, E = gridDim.y, t = threadIdx.x;
+  __shared__ int s_part[4];
+  const int b = blockIdx.x, e = blockIdx.y, t = threadIdx.x;
   int* cnt = cnt_base + e * kPermBuckets;
   const int mine = cnt[t];  // thread t holds bucket t's count (256 threads = 256 buckets)
   // this bucket's count (a uniform read) and its offset: the counts of the buckets before it
@@ -142,14 +143,6 @@ __global__ void __launch_bounds__(256) perm_bucket_kernel(int B, int* __restrict
       }
     for (int k = t; k < n; k += 256) idx[(size_t)e * B + off + k] = (int)(s[k] & ((1ull << kPermIdxBits) - 1));
   }
-  // every workgroup of the epoch has read the counters once its index stores are out (their addresses depend on the counts): the last
-  // one to say so zeroes them for the next launch
-  if (t == 0) s_last = atomicAdd(&cnt_base[E * kPermBuckets + 64 + e], 1) == kPermBuckets - 1;
-  __syncthreads();
-  if (s_last) {
-    cnt[t] = 0;
-    if (t == 0) cnt_base[E * kPermBuckets + 64 + e] = 0;
-  }
 }
 
 size_t permutation_batch_ws_bytes(int B, int E) {
@@ -157,6 +150,13 @@ size_t permutation_batch_ws_bytes(int B, int E) {
   const size_t n = (size_t)B * E;  // keys_in, keys_out (64-bit), vals_in + rocPRIM temporary storage
   const size_t sort_bytes = 2 * align_up(n * 8, 256) + align_up(n * 4, 256) + align_up(sort_temp_bytes64(n, 32 + bits_for(E)), 256);
   return B <= kPermMaxB && perm_fast_bytes(E) > sort_bytes ? perm_fast_bytes(E) : sort_bytes;
+}
+// where the bucket counters of the two-launch form live (nullptr / 0 when that form is not in use for this shape): the caller zeroes them
+// after every use
+void permutation_batch_counters(int B, int E, void* ws, size_t ws_bytes, int** ptr, int* n) {
+  const bool fast = B <= kPermMaxB && ws && ws_bytes >= perm_fast_bytes(E);
+  *ptr = fast ? static_cast<int*>(ws) : nullptr;
+  *n = fast ? E * kPermBuckets + 1 : 0;  // (+ the overflow word)
 }
 // the counters of the two-launch form must be zero before its first use (mppo_engine_reset)
 int32_t permutation_batch_prepare(int B, int E, void* ws, size_t ws_bytes, hipStream_t s) {

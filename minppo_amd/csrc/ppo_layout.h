@@ -210,6 +210,7 @@ int32_t permutation_ctr(unsigned long long seed, unsigned long long stream_id, c
 int32_t perm_fill_keys_batch(unsigned long long seed, unsigned long long stream_id0, const int* ctr, int B, int E, unsigned long long* keys, int* vals, hipStream_t stream);
 size_t permutation_batch_ws_bytes(int B, int E);
 int32_t permutation_batch_prepare(int B, int E, void* ws, size_t ws_bytes, hipStream_t stream);  // zeroes the two-launch form's counters
+void permutation_batch_counters(int B, int E, void* ws, size_t ws_bytes, int** ptr, int* n);  // the words the caller zeroes after every use (nullptr / 0: none)
 int32_t permutation_batch_ctr(unsigned long long seed, unsigned long long stream_id0, const int* ctr, int B, int E, int* idx, void* ws, size_t ws_bytes, hipStream_t stream);
 // k_rng.hip / k_perm.hip: jax.random-compatible streams (threefry2x32)
 int32_t threefry_normal(const unsigned* key2, size_t n, float* out, hipStream_t s);

@@ -92,6 +92,7 @@ int32_t permutation_ctr(unsigned long long seed, unsigned long long stream_id, c
 
 size_t permutation_batch_ws_bytes(int B, int E) { return (B < 1 || E < 1) ? 0 : (size_t)B * E * 12; }
 int32_t permutation_batch_prepare(int, int, void*, size_t, hipStream_t) { return MPPO_OK; }
+void permutation_batch_counters(int, int, void*, size_t, int** ptr, int* n) { *ptr = nullptr; *n = 0; }
 int32_t permutation_batch_ctr(unsigned long long seed, unsigned long long stream_id0, const int* ctr, int B, int E, int* idx, void* ws, size_t ws_bytes,
                               hipStream_t stream) {
   MPPO_REQUIRE(B >= 1 && E >= 1 && idx && ws, "permutation_batch: bad argument");
