@@ -15,7 +15,8 @@ The line also carries
   roofline     : the dominant kernel (`fused_mlp_kernel`, the row-local forward + backward of one minibatch on the
                  f32 matrix cores) timed live with HIP events on a hipGraph replay of 50 launches, algorithmic
                  FLOPs per launch / average duration against the dense f32 MFMA peak (157.3 TFLOP/s,
-                 MI355X_MICROARCH.md)
+                 MI355X_MICROARCH.md); `in_situ`: the same kernel inside the update, from the newest committed
+                 `rocprofv3 --kernel-trace --stats` summary of this command (profiles/)
   cpu_baseline : the CPU restatement SURVEY.md 8(d) specifies (a "port": the JAX reference cannot run here) timed on this
                  box's host cores on a bounded sample of the same workload (whole updates at 4096 envs): the environment
                  step by a C++17 / OpenMP float32 twin, one environment per thread on all cores (oracle/cpu_twin/), the
@@ -525,6 +526,19 @@ def main() -> None:
             if name in kk and "mfma_busy_frac" in kk[name]:
                 mfma_busy = kk[name]["mfma_busy_frac"]
                 mfma_src = f"profiles/{pfs[-1].name} (SQ_VALU_MFMA_BUSY_CYCLES over 1024 SIMD pipes x the launch's duration under the counter pass x 2.4 GHz)"
+        # the same kernel INSIDE the update, from the newest committed `rocprofv3 --kernel-trace --stats` summary of this command (the probe above
+        # replays the row pass back to back; in the update it follows an Adam launch and runs ~1 us longer): reported beside the probe's figure
+        in_situ = None
+        ks = sorted((ROOT / "profiles").glob("r*_kernel_stats_config3_bf16.csv" if bf16 else "r*_kernel_stats.csv"))
+        if ks and args.config == "stompy_pro" and args.envs_per_gpu == 4096:
+            import csv
+            want = "fused_mlp_kernel<true, false, 1, true, true>" if bf16 else "fused_mlp_kernel<false, false, 1, true, true>"
+            for row in csv.DictReader(ks[-1].open()):
+                if want in row.get("Name", ""):
+                    us = float(row["AverageNs"]) * 1e-3
+                    in_situ = {"us_per_launch": us, "achieved": flops / (us * 1e-6) / 1e12, "frac": flops / (us * 1e-6) / 1e12 / peak, "launches": int(row["Calls"]),
+                               "source": f"profiles/{ks[-1].name} (rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline)"}
+                    break
         out = {
             "metric": ("env-steps/sec (whole node), stompy_pro 4096 envs, 1/2/4/8 MI355X" if args.config == "stompy_pro" and args.envs_per_gpu == 4096
                        else f"env-steps/sec (whole node), {args.config} {args.envs_per_gpu} envs per GPU, {world} MI355X"),
@@ -547,7 +561,7 @@ def main() -> None:
                        "hipgraph": bool(tr.graph_active()),
                        "pre_warm": f"{pre_warm_s:.1f} s of unrelated device work before the {args.warmup} warm-up steps (one-time start-up stall of the device, see bench.py)"},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
-                         "traffic": traffic, "traffic_unit": "bytes/launch", "traffic_source": traffic_src, "mfma_busy_frac": mfma_busy, "mfma_busy_source": mfma_src, "kernel": desc, "us_per_launch": sec * 1e6,
+                         "traffic": traffic, "traffic_unit": "bytes/launch", "traffic_source": traffic_src, "mfma_busy_frac": mfma_busy, "mfma_busy_source": mfma_src, "kernel": desc, "us_per_launch": sec * 1e6, "in_situ": in_situ,
                          "whole_update_mlp_tflops": (26.0 * (2 * tr.O * tr.H + 2 * tr.H * tr.H + tr.H * (tr.A + 1)) + 0.2 * (tr.O * tr.H + tr.H * tr.H + tr.H)) * steps_total / world / dt / 1e12},
             "sanity": {"mean_reward": stats["mean_reward"], "done_fraction": stats["done_fraction"], "mean_total_loss": float(lossm[0])},
         }
