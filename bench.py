@@ -47,6 +47,41 @@ PEAK_F32_MFMA_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md: "Peak FP
 PEAK_BF16_MFMA_TFLOPS = 2500.0  # same guide: dense bf16 MFMA ~2.5 PFLOP/s (no sparsity)
 
 
+def kernel_sources_sha() -> str:
+    """Identity of the kernels a measurement describes: sha256 over the text of everything the shipped library is compiled from
+    (minppo_amd/csrc/*.hip|*.h|*.inc, include/minppo_hip.h, the flags in minppo_amd/build.py).  Profile summaries under profiles/ record it
+    (tools/profile_meta.py writes `<summary>.meta.json` next to each one, on the GPU box, where there is no .git); this file quotes a
+    committed summary only if its recorded hash equals the hash of the tree it runs from."""
+    import hashlib
+
+    h = hashlib.sha256()
+    files = sorted((ROOT / "minppo_amd" / "csrc").glob("*.hip")) + sorted((ROOT / "minppo_amd" / "csrc").glob("*.h")) + sorted((ROOT / "minppo_amd" / "csrc").glob("*.inc"))
+    files += [ROOT / "include" / "minppo_hip.h", ROOT / "minppo_amd" / "build.py"]
+    for f in files:
+        h.update(f.name.encode() + b"\0" + f.read_bytes() + b"\0")
+    return h.hexdigest()[:16]
+
+
+def committed_summary(pattern: str):
+    """The newest committed profile summary matching `pattern` whose sidecar (`<name>.meta.json`, tools/profile_meta.py) says it was
+    taken on THESE kernel sources; (path, meta) or (None, why).  A summary without a sidecar, or with another tree's hash, describes
+    other kernels and is not quoted (round-4 review: the line carried counters of a kernel that had changed since)."""
+    here = kernel_sources_sha()
+    cands = sorted((ROOT / "profiles").glob(pattern))
+    why = f"no profiles/{pattern}"
+    for f in reversed(cands):
+        side = f.with_name(f.name + ".meta.json")
+        if not side.exists():
+            why = f"profiles/{f.name} has no .meta.json (taken before summaries recorded their tree): not quoted"
+            continue
+        meta = json.loads(side.read_text())
+        if meta.get("kernel_sources_sha") != here:
+            why = f"profiles/{f.name} was taken on kernel sources {meta.get('kernel_sources_sha')} (commit {meta.get('git_head')}), this tree is {here}: stale, not quoted"
+            continue
+        return f, meta
+    return None, why
+
+
 def parse() -> argparse.Namespace:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -57,6 +92,8 @@ def parse() -> argparse.Namespace:
     ap.add_argument("--set", action="append", default=[], metavar="KEY=VALUE", help="config override (dot-list), e.g. training.mlp_dtype=bf16")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-probe", action="store_true", help="do not run the stand-alone row-pass probe (profiling runs: the rocprofv3 summary of the "
+                    "update then contains the update's launches of the kernel only; the line's `roofline` is null)")
     ap.add_argument("--cpu-baseline-envs", type=int, default=4096)
     return ap.parse_args()
 
@@ -118,6 +155,11 @@ def rowpass_probe(tr, launches: int = 64, replays: int = 4):
     macs_row = (2 * O * H + 2 * H * H + H * (A + 1)) + (2 * H * H + H * (A + 1))  # forward (both nets) + dZ2, dZ1 (both nets)
     flops = 2.0 * macs_row * mb
     return sec, flops, f"fused_mlp_kernel: row pass of one minibatch (mb={mb}, O={O}, H={H}, A={A}, actor+critic; {'bf16 MFMA 16x16x16, f32 accumulate' if tr.net.bf16 else 'f32 MFMA 16x16x4'})"
+
+
+def rowpass_kernel_name(bf16: bool) -> str:
+    """Name (as rocprofv3 prints it) of the training row pass the engine launches for the headline geometry."""
+    return "fused_mlp_kernel<true, false, 1, true, true>" if bf16 else "fused_mlp_kernel<false, false, 1, true, true>"
 
 
 def _usable_cores() -> int:
@@ -226,6 +268,42 @@ def cpu_baseline(config_name: str, overrides, n_envs: int):
             "host_cores": int(w["host_cores"]), "usable_cores": int(w["usable_cores"]), "sanity": {"mean_reward": w["mean_reward"], "finite": w["finite"]}}
 
 
+def _attempt_limits():
+    """Time limits of a multi-rank run, chosen so that a hung first attempt + teardown + the RCCL repeat fit the driver's 600 s command
+    limit with room to spare (<= 540 s): every rank process reports `started` once it has imported torch, loaded the library and
+    touched its GPU (a fresh box pages the image in first: that is not the transport's fault and gets its own limit, `start`), and
+    from the moment ALL ranks have started an attempt may take `peer` seconds (attempt 0: rendezvous, hipIpc mapping, the <= 10 s
+    self-test, hipGraph capture, W + K updates: well under 30 s when healthy) or `rccl` seconds (the repeat).  Worst case
+    start + peer + teardown + start' + rccl = 90 + 90 + ~5 + ~15 (warm page cache) + 300 < 540.  $MPPO_BENCH_RANK_TIMEOUT overrides
+    `peer`, $MPPO_BENCH_RETRY_TIMEOUT `rccl`, $MPPO_BENCH_START_TIMEOUT `start`."""
+    return {"start": float(os.environ.get("MPPO_BENCH_START_TIMEOUT", "90")), "peer": float(os.environ.get("MPPO_BENCH_RANK_TIMEOUT", "90")),
+            "rccl": float(os.environ.get("MPPO_BENCH_RETRY_TIMEOUT", "300"))}
+
+
+def _started_file(d, attempt: int, r: int) -> Path:
+    return Path(d) / f"attempt{attempt}.started.rank{r}"
+
+
+class _AttemptClock:
+    """Deadline of one attempt as the supervisors see it: `start` seconds until every rank has reported `started`, then `run` seconds."""
+
+    def __init__(self, d, attempt: int, world: int, start_s: float, run_s: float):
+        self.d, self.attempt, self.world, self.run_s = d, attempt, world, run_s
+        self.t_start_deadline = time.monotonic() + start_s
+        self.t_run_deadline = None
+
+    def expired(self) -> str:
+        """'' while the attempt may go on, else the reason it may not."""
+        now = time.monotonic()
+        if self.t_run_deadline is None:
+            if all(_started_file(self.d, self.attempt, r).exists() for r in range(self.world)):
+                self.t_run_deadline = now + self.run_s
+            elif now > self.t_start_deadline:
+                return "a rank did not start (import torch, load the library, touch its GPU) within its limit"
+            return ""
+        return f"the ranks did not finish within {self.run_s:.0f} s of having started" if now > self.t_run_deadline else ""
+
+
 def spawn_ranks(args: argparse.Namespace) -> int:
     """`python bench.py --gpus N` with N > 1 and no launcher around it: this process becomes a supervisor that starts
     one fresh child per GPU (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in the environment, exactly what
@@ -253,38 +331,55 @@ def spawn_ranks(args: argparse.Namespace) -> int:
         s.close()
         return p
 
-    def attempt(extra_env: dict, limit_s: float):
+    import shutil
+    import tempfile
+
+    lim = _attempt_limits()
+    sdir = Path(tempfile.mkdtemp(prefix="mppo_bench_"))
+
+    def attempt(no: int, extra_env: dict, run_s: float):
         port = free_port()
         procs = []
         for r in range(args.gpus):
             env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(0 if share else r), WORLD_SIZE=str(args.gpus), LOCAL_WORLD_SIZE=str(args.gpus),
                        MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"),
-                       MPPO_BENCH_WORKER="1", **extra_env)  # the children measure; this process is already their supervisor
+                       MPPO_BENCH_WORKER="1", MPPO_BENCH_MILESTONE_DIR=str(sdir), MPPO_BENCH_ATTEMPT=str(no), **extra_env)  # the children measure; this process is already their supervisor
             procs.append(subprocess.Popen([sys.executable, os.environ.get("MPPO_BENCH_WORKER_SCRIPT", str(Path(__file__).resolve())), *sys.argv[1:]], env=env,
                                           stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, stderr=None))
-        deadline = time.monotonic() + limit_s
-        line, ok = b"", True
-        try:
-            out0, _ = procs[0].communicate(timeout=limit_s)
-            line = out0
-            for p in procs[1:]:
-                p.wait(timeout=max(1.0, deadline - time.monotonic()))
-        except subprocess.TimeoutExpired:
-            ok = False
+        clock = _AttemptClock(sdir, no, args.gpus, lim["start"], run_s)
+        line, why, got0 = b"", "", False
+        while True:
+            if got0:
+                time.sleep(0.2)
+            else:
+                try:
+                    line, _ = procs[0].communicate(timeout=0.5)  # (may be called again after a TimeoutExpired: nothing read so far is lost)
+                    got0 = True
+                except subprocess.TimeoutExpired:
+                    pass
+            if all(p.poll() is not None for p in procs):
+                break
+            dead = [r for r, p in enumerate(procs) if p.poll() is not None and p.returncode != 0]
+            why = f"rank {dead[0]} exited with status {procs[dead[0]].returncode}" if dead else clock.expired()
+            if why:
+                break
         for p in procs:  # exactly the PIDs started above, never a pattern
             if p.poll() is None:
                 p.kill()
                 p.wait()
-        ok = ok and all(p.returncode == 0 for p in procs)
-        return ok, line
+        if not why and not all(p.returncode == 0 for p in procs):
+            why = "a rank exited with a non-zero status"
+        return (not why), line, why
 
-    limit = float(os.environ.get("MPPO_BENCH_RANK_TIMEOUT", "420"))
-    ok, line = attempt({}, limit)
-    if not ok and os.environ.get("MPPO_ALLREDUCE", "peer") != "rccl" and not share:
-        sys.stderr.write("bench.py: ranks failed with the peer-to-peer exchange; repeating with eager RCCL all-reduces (MPPO_ALLREDUCE=rccl)\n")
-        ok, line = attempt({"MPPO_ALLREDUCE": "rccl", "MPPO_GRAPH_COMM": "0"}, limit)
+    try:
+        ok, line, why = attempt(0, {}, lim["peer"])
+        if not ok and os.environ.get("MPPO_ALLREDUCE", "peer") != "rccl" and not share:
+            sys.stderr.write(f"bench.py: the first attempt (peer-to-peer exchange) failed: {why}; repeating with eager RCCL all-reduces (MPPO_ALLREDUCE=rccl)\n")
+            ok, line, why = attempt(1, {"MPPO_ALLREDUCE": "rccl", "MPPO_GRAPH_COMM": "0"}, lim["rccl"])
+    finally:
+        shutil.rmtree(sdir, ignore_errors=True)
     if not ok:
-        sys.stderr.write("bench.py: a rank failed or timed out\n")
+        sys.stderr.write(f"bench.py: a rank failed or timed out: {why}\n")
         return 1
     js = [l for l in line.decode(errors="replace").splitlines() if l.startswith("{")]
     if not js:
@@ -312,7 +407,7 @@ def supervise_rank(args: argparse.Namespace) -> int:
     job = "mppo_bench_%s_%s" % (os.environ.get("MASTER_PORT", "0"), os.environ.get("MPPO_BENCH_JOB", str(os.getppid())))
     d = Path(os.environ.get("MPPO_BENCH_STATUS_DIR", tempfile.gettempdir())) / job
     d.mkdir(parents=True, exist_ok=True)
-    limit = float(os.environ.get("MPPO_BENCH_RANK_TIMEOUT", "300"))
+    lim = _attempt_limits()
     child_argv = [sys.executable, os.environ.get("MPPO_BENCH_WORKER_SCRIPT", str(Path(__file__).resolve())), *sys.argv[1:]]
     state = {"proc": None}
 
@@ -328,40 +423,46 @@ def supervise_rank(args: argparse.Namespace) -> int:
     def status_file(attempt: int, r: int) -> Path:
         return d / f"attempt{attempt}.rank{r}"
 
-    def run_attempt(attempt: int, extra_env: dict):
-        env = dict(os.environ, MPPO_BENCH_WORKER="1", HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"), **extra_env)
+    def run_attempt(attempt: int, extra_env: dict, run_s: float):
+        env = dict(os.environ, MPPO_BENCH_WORKER="1", HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"),
+                   MPPO_BENCH_MILESTONE_DIR=str(d), MPPO_BENCH_ATTEMPT=str(attempt), **extra_env)
         p = subprocess.Popen(child_argv, env=env, stdout=subprocess.PIPE if rank == 0 else subprocess.DEVNULL, stderr=None)
         state["proc"] = p
-        deadline = time.monotonic() + limit
-        ok, out = True, b""
+        clock = _AttemptClock(d, attempt, world, lim["start"], run_s)
+        ok, out, why = True, b"", ""
         while True:
             try:
-                o, _ = p.communicate(timeout=1.0)
+                o, _ = p.communicate(timeout=0.5)
                 out = o or b""
                 ok = p.returncode == 0
+                why = "" if ok else f"rank {rank}'s worker exited with status {p.returncode}"
                 break
             except subprocess.TimeoutExpired:
-                peer_failed = any(status_file(attempt, r).exists() and status_file(attempt, r).read_text().strip() != "ok" for r in range(world))
-                if peer_failed or time.monotonic() > deadline:
+                failed = [r for r in range(world) if status_file(attempt, r).exists() and status_file(attempt, r).read_text().strip() != "ok"]
+                why = f"rank {failed[0]} reported a failure" if failed else clock.expired()
+                if why:
                     p.kill()
                     o, _ = p.communicate()
                     ok = False
                     break
         state["proc"] = None
+        if not ok:
+            sys.stderr.write(f"bench.py: rank {rank}: attempt {attempt} ended: {why}\n")
         tmp = status_file(attempt, rank).with_suffix(f".rank{rank}.tmp")
         tmp.write_text("ok" if ok else "fail")
         tmp.rename(status_file(attempt, rank))
-        # everybody's verdict (a rank that never reports counts as failed)
-        wait_until = time.monotonic() + limit + 60
+        # everybody's verdict: the other supervisors watch the same clock and the same files, so they report within moments of this one
+        # (a supervisor that never reports counts as failed)
+        wait_until = time.monotonic() + 20.0 + (0.0 if not ok else lim["start"] + run_s)
         while time.monotonic() < wait_until and not all(status_file(attempt, r).exists() for r in range(world)):
             time.sleep(0.2)
         all_ok = all(status_file(attempt, r).exists() and status_file(attempt, r).read_text().strip() == "ok" for r in range(world))
-        return all_ok, out
+        return all_ok, out, why
 
-    ok, out = run_attempt(0, {})
+    ok, out, why = run_attempt(0, {}, lim["peer"])
     if not ok and os.environ.get("MPPO_ALLREDUCE", "peer") != "rccl":
         if rank == 0:
-            sys.stderr.write("bench.py: ranks failed with the peer-to-peer exchange; repeating with eager RCCL all-reduces (MPPO_ALLREDUCE=rccl)\n")
+            sys.stderr.write(f"bench.py: the first attempt (peer-to-peer exchange) failed ({why or 'another rank reported a failure'}); repeating with eager RCCL all-reduces (MPPO_ALLREDUCE=rccl)\n")
             s = socket.socket()
             s.bind(("127.0.0.1", 0))
             port = s.getsockname()[1]
@@ -369,12 +470,12 @@ def supervise_rank(args: argparse.Namespace) -> int:
             tmp = d / "retry_port.tmp"
             tmp.write_text(str(port))
             tmp.rename(d / "retry_port")
-        wait_until = time.monotonic() + 120
+        wait_until = time.monotonic() + 30
         while time.monotonic() < wait_until and not (d / "retry_port").exists():
             time.sleep(0.2)
         if (d / "retry_port").exists():
             port = (d / "retry_port").read_text().strip()
-            ok, out = run_attempt(1, {"MPPO_ALLREDUCE": "rccl", "MPPO_GRAPH_COMM": "0", "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": port, "TORCHELASTIC_USE_AGENT_STORE": "False"})
+            ok, out, why = run_attempt(1, {"MPPO_ALLREDUCE": "rccl", "MPPO_GRAPH_COMM": "0", "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": port, "TORCHELASTIC_USE_AGENT_STORE": "False"}, lim["rccl"])
     # leave nothing behind: every rank has read every verdict by now (run_attempt returns after all status files exist or the wait
     # expired); rank 0 removes the directory a moment later, whatever is still in it
     if rank == 0:
@@ -382,7 +483,7 @@ def supervise_rank(args: argparse.Namespace) -> int:
         time.sleep(1.0)
         shutil.rmtree(d, ignore_errors=True)
     if not ok:
-        sys.stderr.write(f"bench.py: rank {rank}: the run failed or timed out\n")
+        sys.stderr.write(f"bench.py: rank {rank}: the run failed or timed out ({why or 'another rank reported a failure'})\n")
         return 1
     if rank == 0:
         js = [l for l in out.decode(errors="replace").splitlines() if l.startswith("{")]
@@ -421,6 +522,12 @@ def main() -> None:
         raise SystemExit(f"rank {rank}: LOCAL_RANK {local_rank} but only {torch.cuda.device_count()} GPU(s) are visible")
     torch.cuda.set_device(local_rank)
     if world > 1:
+        from minppo_amd import _native as _nat
+
+        _nat.load()  # the library (and RCCL behind it) paged in
+        torch.zeros(1, device=f"cuda:{local_rank}").add_(1).item()  # the GPU touched: this rank has STARTED (see _attempt_limits)
+        if os.environ.get("MPPO_BENCH_MILESTONE_DIR"):
+            _started_file(os.environ["MPPO_BENCH_MILESTONE_DIR"], int(os.environ.get("MPPO_BENCH_ATTEMPT", "0")), rank).write_text("started")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if share:
             dist.init_process_group("gloo", rank=rank, world_size=world)  # RCCL refuses two ranks on one device
@@ -442,6 +549,8 @@ def main() -> None:
         cfg = load_config_from_cli([args.config, f"training.num_envs={n_global}", *args.set])
         tr = Trainer(cfg, device=f"cuda:{local_rank}", rank=rank, world_size=world, use_graph=not args.no_graph)
         transport = tr.init_comm()  # "peer" (default; csrc/peer.h) or "rccl" ($MPPO_ALLREDUCE), "none" for one rank
+        if world > 1 and rank == 0:
+            sys.stderr.write(f"bench.py: gradient transport: {transport}" + (f" ({tr.peer_form()})" if transport == "peer" else "") + f" - {tr.comm_note}\n")
     tr.reset()
     # A fresh process stalls ONCE for 70-90 ms some 30-40 ms after its first GPU work (measured per update by
     # tools/ramp_probe.py, graph replay and eager launches alike: profiles/r02_g_ramp.txt); with W = 3 warm-up updates
@@ -495,50 +604,72 @@ def main() -> None:
 
     out = None
     if rank == 0:
-        sec, flops, desc = rowpass_probe(tr)
-        achieved = flops / sec / 1e12
-        # HBM-side bytes per launch of the roofline kernel: PMC counters need rocprofv3 around the process, so they are
-        # collected by tools/gpu_traffic.sh (separate FETCH_SIZE / WRITE_SIZE passes, gfx950 x2 fetch correction) and
-        # the committed summary is read here; null when the workload is not the one the summary was taken on.
-        baseline_cfg = {"stompy_pro": "BASELINE configs[1]; configs[2] at 8 GPUs", "stompy_full": "BASELINE configs[4]"}.get(args.config, "not a BASELINE config")
         bf16 = cfg.training.mlp_dtype == "bf16"
+        peak = PEAK_BF16_MFMA_TFLOPS if bf16 else PEAK_F32_MFMA_TFLOPS
+        baseline_cfg = {"stompy_pro": "BASELINE configs[1]; configs[2] at 8 GPUs", "stompy_full": "BASELINE configs[4]"}.get(args.config, "not a BASELINE config")
         if bf16:
             baseline_cfg = "BASELINE configs[3]" if args.config == "stompy_pro" else baseline_cfg + ", bf16 MFMA"
-        peak = PEAK_BF16_MFMA_TFLOPS if bf16 else PEAK_F32_MFMA_TFLOPS
-        traffic, traffic_src = None, None
-        tfs = sorted((ROOT / "profiles").glob("r*_hbm_traffic.json"))  # the newest committed counter summary
-        if tfs and args.config == "stompy_pro" and args.envs_per_gpu == 4096 and not bf16:
-            k = json.loads(tfs[-1].read_text())["kernels"]
-            # the training row pass of a float network: <BF16 = false, ROLLOUT = false, OT = 1, W2T shadow = true> (the engine's choice)
-            key = next((n for n in k if n.endswith("fused_mlp_kernel<false, false, 1, true, true>")), None) or \
-                next((n for n in k if n.endswith("fused_mlp_kernel<false, false, 1, true>")), None) or \
-                next((n for n in k if n.endswith("fused_mlp_kernel<false, false, 1>")), None)
-            if key:
-                traffic = k[key]["hbm_bytes_per_launch"]
-                traffic_src = f"profiles/{tfs[-1].name} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, gfx950 corrections)"
-        # matrix-core utilisation of the same kernel from SQ counters (tools/pmc_mlp.sh: rocprofv3 --pmc passes of their own): the newest
-        # committed summary; MFMA-busy cycles / (1024 SIMD pipes x launch duration x 2.4 GHz)
-        mfma_busy, mfma_src = None, None
-        pfs = sorted((ROOT / "profiles").glob("r*_mlp_pmc_bf16.json" if bf16 else "r*_mlp_pmc.json"))
-        if pfs and args.config == "stompy_pro" and args.envs_per_gpu == 4096:
-            kk = json.loads(pfs[-1].read_text())["kernels"]
-            name = "fused_mlp_kernel<true, false, 1, true, true>" if bf16 else "fused_mlp_kernel<false, false, 1, true, true>"
-            if name in kk and "mfma_busy_frac" in kk[name]:
-                mfma_busy = kk[name]["mfma_busy_frac"]
-                mfma_src = f"profiles/{pfs[-1].name} (SQ_VALU_MFMA_BUSY_CYCLES over 1024 SIMD pipes x the launch's duration under the counter pass x 2.4 GHz)"
-        # the same kernel INSIDE the update, from the newest committed `rocprofv3 --kernel-trace --stats` summary of this command (the probe above
-        # replays the row pass back to back; in the update it follows an Adam launch and runs ~1 us longer): reported beside the probe's figure
-        in_situ = None
-        ks = sorted((ROOT / "profiles").glob("r*_kernel_stats_config3_bf16.csv" if bf16 else "r*_kernel_stats.csv"))
-        if ks and args.config == "stompy_pro" and args.envs_per_gpu == 4096:
-            import csv
-            want = "fused_mlp_kernel<true, false, 1, true, true>" if bf16 else "fused_mlp_kernel<false, false, 1, true, true>"
-            for row in csv.DictReader(ks[-1].open()):
-                if want in row.get("Name", ""):
-                    us = float(row["AverageNs"]) * 1e-3
-                    in_situ = {"us_per_launch": us, "achieved": flops / (us * 1e-6) / 1e12, "frac": flops / (us * 1e-6) / 1e12 / peak, "launches": int(row["Calls"]),
-                               "source": f"profiles/{ks[-1].name} (rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline)"}
-                    break
+        headline_shape = args.config == "stompy_pro" and args.envs_per_gpu == 4096
+        roofline = None
+        if not args.no_probe:
+            sec, flops, desc = rowpass_probe(tr)
+            achieved = flops / sec / 1e12
+            here = kernel_sources_sha()
+            # the training row pass the engine launches for this network: <BF16, ROLLOUT = false, OT = 1, W2T shadow = true, PRE = true>
+            kname = rowpass_kernel_name(bf16)
+            # HBM-side bytes per launch of the roofline kernel: PMC counters need rocprofv3 around the process, so they are collected by
+            # tools/profiles.sh (separate FETCH_SIZE / WRITE_SIZE passes, gfx950 x2 fetch correction) and the committed summary is read
+            # here - ONLY a summary taken on these very kernel sources (committed_summary); null otherwise, with the reason
+            traffic, traffic_src = None, None
+            if headline_shape:
+                f, meta = committed_summary("r*_hbm_traffic_bf16.json" if bf16 else "r*_hbm_traffic.json")
+                if f is None:
+                    traffic_src = meta
+                else:
+                    k = json.loads(f.read_text())["kernels"]
+                    key = next((n for n in k if n.endswith(kname)), None)
+                    if key:
+                        traffic = k[key]["hbm_bytes_per_launch"]
+                        traffic_src = f"profiles/{f.name} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, gfx950 corrections; commit {meta.get('git_head')}, kernel sources {here})"
+            # matrix-core utilisation of the same kernel from SQ counters (tools/pmc_mlp.sh: rocprofv3 --pmc passes of their own):
+            # MFMA-busy cycles / (1024 SIMD pipes x launch duration x 2.4 GHz)
+            mfma_busy, mfma_src = None, None
+            if headline_shape:
+                f, meta = committed_summary("r*_mlp_pmc_bf16.json" if bf16 else "r*_mlp_pmc.json")
+                if f is None:
+                    mfma_src = meta
+                else:
+                    kk = json.loads(f.read_text())["kernels"]
+                    key = next((n for n in kk if n.endswith(kname)), None)
+                    if key and "mfma_busy_frac" in kk[key]:
+                        mfma_busy = kk[key]["mfma_busy_frac"]
+                        mfma_src = (f"profiles/{f.name} (SQ_VALU_MFMA_BUSY_CYCLES over 1024 SIMD pipes x the launch's duration under the counter pass x 2.4 GHz; "
+                                    f"commit {meta.get('git_head')}, kernel sources {here})")
+            # the same kernel INSIDE the update: the committed `rocprofv3 --kernel-trace --stats` summary of `bench.py --no-probe` (no
+            # stand-alone probe launches in the profiled process: Calls must be a whole number of updates x E x M launches), taken on these
+            # kernel sources; the probe above replays the row pass back to back, in the update it follows an Adam launch
+            in_situ = None
+            if headline_shape:
+                f, meta = committed_summary("r*_kernel_stats_config3_bf16.csv" if bf16 else "r*_kernel_stats.csv")
+                if f is None:
+                    in_situ = {"us_per_launch": None, "why": meta}
+                else:
+                    import csv
+                    for row in csv.DictReader(f.open()):
+                        if kname in row.get("Name", ""):
+                            us, calls = float(row["AverageNs"]) * 1e-3, int(row["Calls"])
+                            if calls % (tr.E * tr.M) != 0:
+                                in_situ = {"us_per_launch": None, "why": f"profiles/{f.name}: {calls} launches of the row pass is not a whole number of updates x {tr.E * tr.M}: "
+                                                                            "the profiled process launched it outside the update as well; not quoted"}
+                            else:
+                                in_situ = {"us_per_launch": us, "achieved": flops / (us * 1e-6) / 1e12, "frac": flops / (us * 1e-6) / 1e12 / peak, "launches": calls,
+                                           "updates": calls // (tr.E * tr.M), "git_head": meta.get("git_head"), "kernel_sources_sha": here,
+                                           "source": f"profiles/{f.name} ({meta.get('command', 'rocprofv3 --kernel-trace --stats -- python3 bench.py --no-probe')})"}
+                            break
+            roofline = {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
+                        "traffic": traffic, "traffic_unit": "bytes/launch", "traffic_source": traffic_src, "mfma_busy_frac": mfma_busy, "mfma_busy_source": mfma_src, "kernel": desc,
+                        "us_per_launch": sec * 1e6, "in_situ": in_situ, "kernel_sources_sha": here,
+                        "whole_update_mlp_tflops": (26.0 * (2 * tr.O * tr.H + 2 * tr.H * tr.H + tr.H * (tr.A + 1)) + 0.2 * (tr.O * tr.H + tr.H * tr.H + tr.H)) * steps_total / world / dt / 1e12}
         out = {
             "metric": ("env-steps/sec (whole node), stompy_pro 4096 envs, 1/2/4/8 MI355X" if args.config == "stompy_pro" and args.envs_per_gpu == 4096
                        else f"env-steps/sec (whole node), {args.config} {args.envs_per_gpu} envs per GPU, {world} MI355X"),
@@ -560,9 +691,7 @@ def main() -> None:
                        "allreduce": transport + (f" ({tr.peer_form()})" if transport == "peer" else ""), "replicas_identical": replicas_identical,
                        "hipgraph": bool(tr.graph_active()),
                        "pre_warm": f"{pre_warm_s:.1f} s of unrelated device work before the {args.warmup} warm-up steps (one-time start-up stall of the device, see bench.py)"},
-            "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
-                         "traffic": traffic, "traffic_unit": "bytes/launch", "traffic_source": traffic_src, "mfma_busy_frac": mfma_busy, "mfma_busy_source": mfma_src, "kernel": desc, "us_per_launch": sec * 1e6, "in_situ": in_situ,
-                         "whole_update_mlp_tflops": (26.0 * (2 * tr.O * tr.H + 2 * tr.H * tr.H + tr.H * (tr.A + 1)) + 0.2 * (tr.O * tr.H + tr.H * tr.H + tr.H)) * steps_total / world / dt / 1e12},
+            "roofline": roofline,
             "sanity": {"mean_reward": stats["mean_reward"], "done_fraction": stats["done_fraction"], "mean_total_loss": float(lossm[0])},
         }
         if not args.no_cpu_baseline and world == 1:

@@ -125,6 +125,10 @@ class TrainingConfig:
     # Extension (absent upstream): full-state checkpoints.  `checkpoint_path` is written every
     # `checkpoint_every` updates (0 = only at the end, "" = never); `resume_from` restores parameters, Adam moments,
     # step counters (LR schedule + RNG stream position), environment states and episode metrics before training.
+    # Extension: `TrainOutput.metrics` in the REFERENCE's shape (train.py:283,287-289: the six `EnvMetrics` fields of every step of
+    # every update, [num_updates, T, N] each) instead of the per-update device-side reductions.  Small runs only: every update then
+    # synchronises and copies its [T, N] reward / done arrays out; refused above 1 GiB of history.
+    keep_metrics_history: bool = field(default=False)
     checkpoint_path: str = field(default="")
     checkpoint_every: int = field(default=0)
     resume_from: str = field(default="")

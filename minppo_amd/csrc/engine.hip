@@ -30,9 +30,16 @@ namespace mppo {
 const ModelView& model_view(const mppo_model* m);
 
 // end of an update: the Adam step index and the update index move on; `zero` (optional): words another kernel of the update wants back
-// at zero before its next use (the bucket counters of the two-launch permutation, k_perm.hip)
+// at zero before its next use (the bucket counters of the two-launch permutation, k_perm.hip).  The LAST of those words is that form's
+// overflow mark (a bucket received more values than it has slots: the epoch's index array is then not a permutation); before it is zeroed
+// it is made sticky in count[3], which the host reads at its next synchronisation (Trainer.check_status): an update that trained on a
+// spoilt permutation never passes silently (round-4 advisor; unreachable short of a 22-sigma event for B <= 131072, but no longer unguarded)
 __global__ void advance_counters_kernel(int* count, int opt_steps, int* zero = nullptr, int nzero = 0) {
-  if (threadIdx.x == 0 && blockIdx.x == 0 && opt_steps > 0) { count[0] += opt_steps; count[1] += 1; }
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    if (opt_steps > 0) { count[0] += opt_steps; count[1] += 1; }
+    if (nzero > 0 && zero[nzero - 1] != 0) count[3] = 1;
+  }
+  __syncthreads();
   for (int i = threadIdx.x; i < nzero; i += blockDim.x) zero[i] = 0;
 }
 
@@ -543,6 +550,14 @@ static inline float selftest_pattern(size_t i) { return (float)((int)(((unsigned
 extern "C" int32_t mppo_engine_peer_selftest(mppo_engine_t* e, void* stream, int32_t* ok) {
   MPPO_REQUIRE(e && ok && peer_connected(e->peer), "mppo_engine_peer_selftest: no connected exchange");
   MPPO_REQUIRE(!e->graph, "mppo_engine_peer_selftest: the update has been captured already");
+#ifndef MPPO_EMU
+  // Engines of ONE process wait for each other inside this call (every rank's self-test kernels poll the peers' flags): on the legacy
+  // default stream - which synchronises with every other blocking stream of the process - the ranks would serialise, every wait would
+  // run into its limit and the job would fall back to RCCL without anybody having said why (round-4 advisor).  Refused instead.
+  MPPO_REQUIRE(!peer_has_local(e->peer) || (stream != nullptr && stream != static_cast<void*>(hipStreamLegacy)),
+               "mppo_engine_peer_selftest: a peer engine lives in this process - every engine needs a stream of its own (not the default stream), "
+               "and its self-test a thread of its own");
+#endif
   *ok = 0;
   const int G = e->cfg.world_size;
   const size_t P = (size_t)e->P;
@@ -589,6 +604,10 @@ extern "C" int32_t mppo_engine_peer_selftest(mppo_engine_t* e, void* stream, int
   if (he != hipSuccess) return fail(MPPO_EHIP, "mppo_engine_peer_selftest: %s", hipGetErrorString(he));
   if (rc != MPPO_OK) return rc;
   bool good = !timed_out;
+  if (timed_out)  // say WHY the job is about to continue on RCCL: a wait ran into the self-test's limit, as opposed to a wrong value
+    fprintf(stderr, "[minppo_amd] warning: rank %d: the peer exchange's connect-time self-test timed out (%d wait(s) gave up after %llu ms) - a peer did not "
+                    "answer in time (a rank that started late, ranks serialised on a shared stream, or a mapping that carries no stores); the caller falls back to RCCL\n",
+            e->cfg.rank, (int)timed_out, (unsigned long long)(limit_ms > 10000ull ? 10000ull : limit_ms));
   for (double x : host) good = good && x == 0.5 * G * (G + 1);
   const float tri = 0.5f * (float)G * (float)(G + 1);
   double ss = 0.0, ss_dev = 0.0;

@@ -178,6 +178,12 @@ int32_t peer_connect(PeerComm* c, const void* handles, int shared_device) {
 }
 
 bool peer_connected(const PeerComm* c) { return c && c->connected; }
+bool peer_has_local(const PeerComm* c) {
+  if (!c) return false;
+  for (int q = 0; q < c->world; ++q)
+    if (q != c->rank && c->local[q]) return true;
+  return false;
+}
 
 void peer_destroy(PeerComm* c) {
   if (!c) return;

@@ -245,6 +245,7 @@ int32_t peer_wait_launch(const PeerStep& ps, int kind, hipStream_t s);  // one w
 int32_t peer_create(int rank, int world, size_t P, size_t adv_doubles, PeerComm** out, void* handle64);
 int32_t peer_connect(PeerComm* c, const void* handles, int shared_device);  // world x 64 bytes, rank order; shared_device: several ranks on one GPU
 bool peer_connected(const PeerComm* c);
+bool peer_has_local(const PeerComm* c);  // some peer's buffer belongs to an engine of THIS process (found in the registry, not opened through hipIpc)
 void peer_destroy(PeerComm* c);
 PeerStep peer_step(const PeerComm* c, int step);
 int peer_mode(const PeerComm* c);

@@ -12,8 +12,9 @@ multi-GPU) the rendezvous used to hand the RCCL id around.
 Deviations from the reference, all deliberate and documented in DESIGN.md:
   * `rng` is an integer seed (or a 2-word key whose words are folded into one); the random streams
     are the engine's Philox streams, not JAX threefry.
-  * `TrainOutput.metrics` holds per-update device-side reductions, not the full
-    `[num_updates, T, N]` history of six fields the reference returns (`train.py:283,287`).
+  * `TrainOutput.metrics` holds per-update device-side reductions by default; `training.keep_metrics_history=true`
+    (small runs) returns what the reference returns: an `EnvMetrics` of six `[num_updates, T, N]` arrays
+    (`train.py:283,287-289`).
 """
 
 from __future__ import annotations
@@ -267,6 +268,8 @@ class Trainer:
         self.P = int(self.lib.param_count(C.byref(self.net)))
         self.updates_done = 0
         self._prepared = False
+        self._keep_hist, self._hist_carry, self._hist_last = False, None, None
+        self.comm_note = "single rank"  # why init_comm chose the transport it returned (drivers print it)
         self.set_params_flat(init_flat_params(self.seed, self.O, self.A, self.H, self.L))
 
     @staticmethod
@@ -377,6 +380,7 @@ class Trainer:
                 self._write_region(self.region(name), z[name])
             self._write_region(self.region("obs", (self.T + 1, self.N, self.OP))[0], z["last_obs"])
         self.updates_done = int(meta["updates_done"])
+        self._hist_carry = None
 
     def _write_region(self, dst, src: np.ndarray) -> None:
         if tuple(dst.shape) != tuple(src.shape):
@@ -412,10 +416,13 @@ class Trainer:
                 self.lib.comm_unique_id(host.ctypes.data)
                 with self.torch.cuda.device(self.device):
                     self.lib.engine_comm_init(self._engine, host.ctypes.data)
+                self.comm_note = "MPPO_FORCE_COMM=1: single-rank RCCL communicator"
                 return "rccl"
             return "none"
         import torch
         import torch.distributed as dist
+
+        self.comm_note = "requested (mode / MPPO_ALLREDUCE=rccl)"
 
         on_gpu = self.xp == "torch" and dist.get_backend() == "nccl"
 
@@ -464,12 +471,14 @@ class Trainer:
                     except nat.NativeError as exc:
                         err = exc
                     if all_ok(err is None and ok.value == 1):
+                        self.comm_note = "hipIpc buffers mapped on every rank, connect-time self-test exact on every rank"
                         return "peer"
                     err = err or "the self-test all-reduce timed out or returned a wrong sum"
                 with device_ctx():
                     self.lib.engine_peer_disable(self._engine)
                 dist.barrier()  # nobody unmaps while a peer still reads
             logger.warning("peer-to-peer exchange unavailable on some rank (%s); falling back to RCCL", err)
+            self.comm_note = f"fallback: peer-to-peer exchange unavailable on some rank ({err or 'this rank was fine'})"
         host = np.zeros(128, np.uint8)
         if self.rank == 0:
             self.lib.comm_unique_id(host.ctypes.data)
@@ -517,11 +526,15 @@ class Trainer:
             import torch
             import torch.distributed as dist
 
-            t = torch.tensor([int(out.value), self.rank if out.value else -1], dtype=torch.int64)
-            if self.xp == "torch" and dist.get_backend() == "nccl":
+            # ONE packed value (count << 16 | rank): the maximum then names the rank that holds the largest count, not the largest rank id
+            # among all ranks that gave up (round-4 advisor)
+            t = torch.tensor([(min(int(out.value), (1 << 40) - 1) << 16) | (self.rank & 0xFFFF) if out.value else 0], dtype=torch.int64)
+            if dist.get_backend() == "nccl":  # (an nccl group reduces device tensors only)
+                if self.xp != "torch":
+                    raise RuntimeError("check_peers: an nccl process group needs device tensors, but this Trainer holds NumPy memory (xp != 'torch'); pass collective=False")
                 t = t.to(self.device)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            worst, where = int(t[0].item()), int(t[1].item())
+            worst, where = int(t[0].item()) >> 16, int(t[0].item()) & 0xFFFF
         if out.value:
             kind = {1: "the local gradient of rank", 2: "the reduced piece", 3: "the advantage sums of rank"}.get(info[0], "?")
             raise RuntimeError(f"rank {self.rank}: a wait for {kind} {info[1]} timed out (epoch {info[2]}, flag read {info[3]}; this rank: {info[4]} optimizer steps, "
@@ -529,6 +542,15 @@ class Trainer:
         if worst:
             raise RuntimeError(f"rank {self.rank}: a wait for a peer timed out on rank {where} ({worst} waits gave up there); the gradients it contributed "
                                f"to are invalid on every rank, this run's results are invalid")
+
+    def check_status(self) -> None:
+        """Synchronises and raises if the engine recorded a condition that invalidates the run: today one - a bucket of the two-launch
+        permutation (csrc/k_perm.hip) overflowed, i.e. an epoch's index array was not a permutation (`count[3]`, made sticky by the
+        end-of-update kernel; short of a 22-sigma event unreachable for num_envs * num_steps <= 131072, and guarded all the same)."""
+        self._sync()
+        if int(self._to_host(self.region("count"))[3]) != 0:
+            raise RuntimeError(f"rank {self.rank}: a bucket of the permutation kernel overflowed during an update (csrc/k_perm.hip); an epoch trained on an index "
+                               "array that was not a permutation - this run's results are invalid")
 
     @staticmethod
     def _dist_ready() -> bool:
@@ -548,6 +570,7 @@ class Trainer:
 
     # -- stepping ----------------------------------------------------------------
     def reset(self) -> None:
+        self._hist_carry = None  # (the metric words change under the history's feet: re-read before the next update)
         self.lib.engine_reset(self._engine, self._stream_ptr)
         if self.ecfg.rng_impl == 1:
             self._sync()
@@ -556,8 +579,67 @@ class Trainer:
     def update(self) -> None:
         if self.world_size > 1 and not self._prepared:
             self.prepare()
+        if self._keep_hist and self._hist_carry is None:
+            self._hist_carry = self._metric_words()  # the environments' metric words as they stand BEFORE this rollout
         self.lib.engine_update(self._engine, self._stream_ptr)
         self.updates_done += 1
+        if self._keep_hist:
+            self._hist_last = self._replay_metrics()
+
+    # -- the reference's per-step metrics (opt-in; `training.keep_metrics_history`) --------------------------------------------
+    _METRIC_FIELDS = (("episode_returns", np.float32), ("episode_lengths", np.int32), ("returned_episode_returns", np.float32),
+                      ("returned_episode_lengths", np.int32), ("timestep", np.int32), ("returned_episode", np.uint8))
+
+    def keep_metrics_history(self, on: bool = True) -> None:
+        """From the next `update()` on, every update also produces `metrics_history()`: the six `EnvMetrics` fields (`env.py:53-59`) of
+        every step of its rollout, `[T, N]` each - what the reference stores as `Memory.info` (`train.py:170,172`) and returns stacked
+        over the updates (`train.py:283,287-289`).  The engine keeps only the LATEST metric words per environment on the device (and
+        their per-update reductions, `rollout_stats`), so the `[T, N]` history is the bookkeeping of `env.py:183-194` replayed on the host
+        from the rollout's own `reward` / `done` arrays and the words as they stood before the rollout - the same float32 operations in
+        the same order as `env_kernel`'s epilogue, and the replay's last step must EQUAL the device's words (checked on every update).
+        Each update then synchronises: for small runs / reference-shaped callers, not for throughput."""
+        self._keep_hist, self._hist_carry, self._hist_last = bool(on), None, None
+
+    def _metric_words(self) -> Dict[str, np.ndarray]:
+        self._sync()
+        return {k: self._to_host(self.region(k)).astype(dt).copy() for k, dt in self._METRIC_FIELDS}
+
+    def _replay_metrics(self) -> Dict[str, np.ndarray]:
+        T, N = self.T, self.N
+        self._sync()
+        reward = self._to_host(self.region("reward", (T, N))).astype(np.float32)
+        done = self._to_host(self.region("done", (T, N))).astype(np.uint8)
+        c = self._hist_carry
+        ret, ln, rret, rln, ts = (c["episode_returns"].copy(), c["episode_lengths"].copy(), c["returned_episode_returns"].copy(),
+                                  c["returned_episode_lengths"].copy(), c["timestep"].copy())
+        h = {k: np.zeros((T, N), dt) for k, dt in self._METRIC_FIELDS}
+        for t in range(T):  # env.py:183-194, float32 like the kernel (csrc/k_physics.hip epilogue)
+            d = done[t] != 0
+            nd, ndi = np.where(d, np.float32(0), np.float32(1)), np.where(d, 0, 1).astype(np.int32)
+            new_ret, new_len = ret + reward[t], ln + 1
+            ret, ln = new_ret * nd, new_len * ndi
+            rret = rret * nd + new_ret * np.where(d, np.float32(1), np.float32(0))
+            rln = rln * ndi + new_len * np.where(d, 1, 0).astype(np.int32)
+            ts = ts + 1
+            for k, v in (("episode_returns", ret), ("episode_lengths", ln), ("returned_episode_returns", rret), ("returned_episode_lengths", rln),
+                         ("timestep", ts), ("returned_episode", d.astype(np.uint8))):
+                h[k][t] = v
+        now = self._metric_words()
+        for k, _ in self._METRIC_FIELDS:
+            if not np.array_equal(h[k][T - 1], now[k]):
+                bad = int(np.flatnonzero(h[k][T - 1] != now[k])[0])
+                raise RuntimeError(f"metrics history: the replayed `{k}` of environment {bad} after the rollout ({h[k][T - 1][bad]!r}) is not the device's word "
+                                   f"({now[k][bad]!r}); the history of this update is not what the engine computed")
+        self._hist_carry = now
+        return h
+
+    def metrics_history(self):
+        """`EnvMetrics` of `[T, N]` arrays: the last update's rollout (needs `keep_metrics_history()` before that update)."""
+        from minppo_amd.env import EnvMetrics  # (env.py imports this module)
+
+        if not self._keep_hist or self._hist_last is None:
+            raise RuntimeError("metrics_history(): call keep_metrics_history() before the update (training.keep_metrics_history=true)")
+        return EnvMetrics(**self._hist_last)
 
     def prepare(self) -> None:
         """Several ranks, before the first update: capture the update (hipGraph) on every rank, then meet at a barrier, so that the
@@ -692,6 +774,9 @@ def _seed_from_rng(rng: Any) -> int:
     return s
 
 
+_METRICS_HISTORY_MAX_BYTES = 1 << 30  # training.keep_metrics_history: refuse more than 1 GiB of [num_updates, T, N] history
+
+
 def make_train(config: Config, **trainer_kwargs: Any) -> Callable[[Any], TrainOutput]:
     """`make_train(config) -> train(rng)` (`minppo/train.py:92-291`)."""
     num_updates = config.training.total_timesteps // config.training.num_steps // config.training.num_envs
@@ -699,9 +784,18 @@ def make_train(config: Config, **trainer_kwargs: Any) -> Callable[[Any], TrainOu
     if minibatch_size * config.training.num_minibatches != config.training.num_steps * config.training.num_envs:
         raise ValueError("`batch_size` must be equal to `num_steps * num_envs`")
 
+    keep_hist = bool(config.training.keep_metrics_history)
+    hist_bytes_per_update = config.training.num_steps * config.training.num_envs * (4 * 5 + 1)
+    if keep_hist and num_updates * hist_bytes_per_update > _METRICS_HISTORY_MAX_BYTES:
+        raise ValueError(f"training.keep_metrics_history: {num_updates} updates x [{config.training.num_steps}, {config.training.num_envs}] x 6 fields = "
+                         f"{num_updates * hist_bytes_per_update / 2**30:.1f} GiB of history (limit {_METRICS_HISTORY_MAX_BYTES / 2**30:.0f} GiB): the reference-shaped "
+                         "metrics are for small runs; the default returns per-update reductions")
+
     def train(rng: Any, max_updates: Optional[int] = None, log_every: int = 0) -> TrainOutput:
         tr = Trainer(config, seed=_seed_from_rng(rng), **trainer_kwargs)
         tr.init_comm()
+        tr.keep_metrics_history(keep_hist)
+        hist: list = []
         tc = config.training
         ckpt = (tc.checkpoint_path + (f".rank{tr.rank}" if tr.world_size > 1 else "")) if tc.checkpoint_path else ""
         if tc.resume_from:
@@ -717,9 +811,12 @@ def make_train(config: Config, **trainer_kwargs: Any) -> Callable[[Any], TrainOu
         peers = tr.world_size > 1 and tr.comm_mode() == "peer"
         for u in range(first, n):
             tr.update()
+            if keep_hist:
+                hist.append(tr.metrics_history())
             if ckpt and tc.checkpoint_every > 0 and (u + 1) % tc.checkpoint_every == 0 and u + 1 < n:
                 if peers:
                     tr.check_peers()  # collective: never checkpoint parameters that ANY rank updated with a timed-out exchange
+                tr.check_status()
                 tr.save_checkpoint(ckpt)
                 tr.barrier()  # the ranks' files take different times to write: nobody starts the next exchange seconds ahead of a peer
             if log_every and ((u + 1) % log_every == 0 or u + 1 == n):
@@ -735,6 +832,7 @@ def make_train(config: Config, **trainer_kwargs: Any) -> Callable[[Any], TrainOu
                             st["done_fraction"], st["mean_episode_return"], st["mean_episode_length"], lo[0], sps)
         if peers:
             tr.check_peers()
+        tr.check_status()
         if ckpt:
             tr.save_checkpoint(ckpt)
             tr.barrier()
@@ -744,7 +842,15 @@ def make_train(config: Config, **trainer_kwargs: Any) -> Callable[[Any], TrainOu
                                                                    "nu": flat_to_tree(tr._to_host(tr.region("adam_v")), tr.O, tr.A, tr.H, tr.L), "count": count})
         last_obs = tr._to_host(tr.region("obs", (tr.T + 1, tr.N, tr.OP))[0, :, :tr.O])
         rs = RunnerState(train_state=state, env_state=tr._to_host(tr.region("state", (tr.N, tr.dims.rec_dim))), last_obs=last_obs, rng=rng)
-        out = TrainOutput(runner_state=rs, metrics={k: np.asarray(v) for k, v in metrics.items()})
+        if keep_hist:
+            # the reference's `metric` (train.py:283,287-289): EnvMetrics of [num_updates, T, N] arrays (this rank's environments: with several
+            # ranks N is the rank's share); the per-update reductions are then not returned
+            from minppo_amd.env import EnvMetrics
+
+            stacked = EnvMetrics(*(np.stack([getattr(h, f) for h in hist]) if hist else np.zeros((0, tr.T, tr.N), dt) for f, dt in Trainer._METRIC_FIELDS))
+            out = TrainOutput(runner_state=rs, metrics=stacked)
+        else:
+            out = TrainOutput(runner_state=rs, metrics={k: np.asarray(v) for k, v in metrics.items()})
         tr.close()
         return out
 

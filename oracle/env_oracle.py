@@ -126,20 +126,26 @@ class EnvOracle:
             else:
                 new_state[k] = v
         obs = np.where(done[:, None], obs_reset, obs_state)
-        m = es["metrics"]
-        nd_f = (1 - done.astype(np.int32)).astype(self.dtype)
-        nd_i = 1 - done.astype(np.int32)
-        new_ret = m["episode_returns"] + reward
-        new_len = m["episode_lengths"] + 1
-        metrics = dict(
-            episode_returns=new_ret * nd_f,
-            episode_lengths=new_len * nd_i,
-            returned_episode_returns=m["returned_episode_returns"] * nd_f + new_ret * done,
-            returned_episode_lengths=m["returned_episode_lengths"] * nd_i + new_len * done,
-            timestep=m["timestep"] + 1,
-            returned_episode=done,
-        )
+        metrics = metrics_step(es["metrics"], reward, done, self.dtype)
         return dict(pipeline_state=new_state, obs=obs, reward=reward, done=done, metrics=metrics)
+
+
+def metrics_step(m: dict, reward, done, dtype) -> dict:
+    """The episode bookkeeping of one environment step, env.py:183-194 (`EnvMetrics`), in `dtype` arithmetic."""
+    done = np.asarray(done).astype(bool)
+    reward = np.asarray(reward, dtype)
+    nd_f = (1 - done.astype(np.int32)).astype(dtype)
+    nd_i = 1 - done.astype(np.int32)
+    new_ret = np.asarray(m["episode_returns"], dtype) + reward
+    new_len = m["episode_lengths"] + 1
+    return dict(
+        episode_returns=new_ret * nd_f,
+        episode_lengths=new_len * nd_i,
+        returned_episode_returns=np.asarray(m["returned_episode_returns"], dtype) * nd_f + new_ret * done.astype(dtype),
+        returned_episode_lengths=m["returned_episode_lengths"] * nd_i + new_len * done,
+        timestep=m["timestep"] + 1,
+        returned_episode=done,
+    )
 
 
 # ---------------------------------------------------------------------------

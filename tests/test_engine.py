@@ -155,6 +155,69 @@ def test_rollout_statistics_match_the_env_metrics_history(be):
     tr.close()
 
 
+def test_a_permutation_bucket_overflow_is_surfaced(be):
+    """Round-4 advisor: the two-launch permutation (csrc/k_perm.hip) records a bucket overflow in a word that the end-of-update kernel zeroes
+    again; nothing read it.  Now that kernel makes it sticky in count[3] first and `Trainer.check_status()` raises.  The overflow itself is
+    unreachable (22 sigma at B <= 131072), so the mark is planted by hand where the scatter kernel would set it.  (The emulator build
+    replaces the two-launch form by a host sort - tests/emu/emu_stubs.cpp - so this is a hardware test.)"""
+    if be.name != "hip":
+        pytest.skip("the two-launch permutation exists in the HIP build only")
+    cfg = _cfg(*_small(be))
+    tr = be.trainer(cfg, use_graph=False)
+    tr.reset()
+    tr.update()
+    tr.check_status()  # a healthy update: nothing recorded
+    assert int(be.host(tr.region("count"))[3]) == 0
+    ws = tr.region("perm_ws")
+    words = ws.view(np.int32) if be.name == "emu" else ws.view(__import__("torch").int32)
+    mark = tr.E * 256  # the word behind the E x 256 bucket counters
+    assert int(be.host(words[:mark + 1]).sum()) == 0  # the counters are back at zero between updates
+    one = np.ones(1, np.int32)
+    be.put(words[mark:mark + 1], one)
+    tr.update()  # (this update's scatter finds the mark already set; its own buckets are fine)
+    assert int(be.host(tr.region("count"))[3]) == 1 and int(be.host(words[mark:mark + 1])[0]) == 0
+    with pytest.raises(RuntimeError, match="permutation"):
+        tr.check_status()
+    tr.reset()
+    tr.check_status()  # a reset run starts clean
+    tr.close()
+
+
+def test_reference_shaped_metrics_history(be):
+    """`training.keep_metrics_history` / `Trainer.keep_metrics_history()`: the six `EnvMetrics` fields of EVERY step of a rollout, [T, N] each -
+    what the reference keeps as `Memory.info` (train.py:170,172) and returns as `TrainOutput.metrics` (train.py:283,287-289).  Against the
+    oracle's bookkeeping (oracle/env_oracle.py:metrics_step = env.py:183-194) applied in float32 to the engine's own reward / done arrays,
+    over three updates with episodes ending inside the rollouts (carry-over across the update boundary): every field of every step
+    exactly; and the history's last step is what the kernel left in the per-environment metric words."""
+    from oracle.env_oracle import metrics_step
+
+    cfg = _cfg(*_small(be), "reward.height_max_z=1.0101")
+    tr = be.trainer(cfg, external_random=True, use_graph=False)
+    tr.reset()
+    tr.keep_metrics_history()
+    N, T, A, E = tr.N, tr.T, tr.A, tr.E
+    rng = np.random.default_rng(3)
+    m = dict(episode_returns=np.zeros(N, np.float32), episode_lengths=np.zeros(N, np.int32), returned_episode_returns=np.zeros(N, np.float32),
+             returned_episode_lengths=np.zeros(N, np.int32), timestep=np.zeros(N, np.int32), returned_episode=np.zeros(N, bool))
+    total_done = 0
+    for u in range(3):
+        be.put(tr.region("noise", (T, N, A)), (3.0 * rng.standard_normal((T, N, A))).astype(np.float32))
+        be.put(tr.region("perm", (E, N * T)), np.stack([rng.permutation(N * T) for _ in range(E)]).astype(np.int32))
+        tr.update()
+        h = tr.metrics_history()
+        rew, done = be.host(tr.region("reward", (T, N))).copy(), be.host(tr.region("done", (T, N))).astype(bool)
+        total_done += int(done.sum())
+        for t in range(T):
+            m = metrics_step(m, rew[t], done[t], np.float32)
+            for k in m:
+                np.testing.assert_array_equal(np.asarray(getattr(h, k)[t]), np.asarray(m[k]).astype(getattr(h, k).dtype), err_msg=f"update {u} step {t} {k}")
+        assert h.timestep.shape == (T, N) and (h.timestep[T - 1] == (u + 1) * T).all()
+        for k in ("episode_returns", "episode_lengths", "returned_episode_returns", "returned_episode_lengths", "timestep", "returned_episode"):
+            np.testing.assert_array_equal(np.asarray(getattr(h, k)[T - 1]), be.host(tr.region(k)).astype(getattr(h, k).dtype), err_msg=k)
+    assert total_done >= 2, "the test must see episodes end"
+    tr.close()
+
+
 def test_update_bf16_mlp_tracks_the_bf16_oracle(be):
     """BASELINE configs[3] through the whole engine: training.mlp_dtype = "bf16" (bf16-in / f32-accumulate MFMA in the MLP
     products; GAE, loss, clip and Adam in f32).  The PPO half of one update against the oracle run with the same operand

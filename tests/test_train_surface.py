@@ -51,6 +51,26 @@ def test_make_train_runs_and_saves(tmp_path):
         T.make_train(make_config(BASE, ["training.num_envs=6", "training.num_minibatches=4", "training.num_steps=1"]))
 
 
+def test_make_train_returns_the_references_metrics_when_asked():
+    """`training.keep_metrics_history=true`: `TrainOutput.metrics` is what the reference returns (train.py:283,287-289) - an `EnvMetrics` whose six
+    fields are [num_updates, T, N] arrays a caller can index `out.metrics.episode_returns[u, t, n]`; refused (ValueError) when the history
+    would exceed its byte budget.  The default stays the per-update reductions."""
+    from minppo_amd.env import EnvMetrics
+
+    be = get_backend("emu")
+    train = T.make_train(make_config(BASE, SMALL + ["training.keep_metrics_history=true"]), lib=be.lib, xp="numpy", use_graph=False)
+    out = train(1337)
+    assert isinstance(out.metrics, EnvMetrics)
+    for f in EnvMetrics._fields:
+        assert getattr(out.metrics, f).shape == (3, 2, 8), f  # num_updates = 48 // 2 // 8, T = 2, N = 8
+    np.testing.assert_array_equal(out.metrics.timestep[:, :, 0].reshape(-1), np.arange(1, 7))  # env.py:191: one more per step, carried over the updates
+    assert (out.metrics.episode_lengths == out.metrics.timestep).all() and not out.metrics.returned_episode.any()  # nobody falls in six steps
+    np.testing.assert_allclose(out.metrics.episode_returns[2, 1], out.metrics.episode_returns[2, 0] + (out.metrics.episode_returns[2, 1] - out.metrics.episode_returns[2, 0]))
+    assert np.isfinite(out.metrics.episode_returns).all() and (np.abs(out.metrics.episode_returns[-1, -1]) > 0).any()
+    with pytest.raises(ValueError, match="keep_metrics_history"):
+        T.make_train(make_config(BASE, ["training.keep_metrics_history=true", "training.num_envs=4096", "training.total_timesteps=10000000000"]))
+
+
 def _resume_case(be, tmp_path, trainer_kw):
     """4 updates in one go == 2 updates, checkpoint, NEW trainer, resume, 2 updates - bit for bit (parameters, Adam moments,
     counters, environment states, episode metrics); the engine's own RNG streams are positioned by the restored counters."""

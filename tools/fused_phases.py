@@ -1,6 +1,6 @@
 """Where does fused_mlp_kernel's time go: phase breakdown of one wave (wave 0 of row tile 40, actor network; s_memtime stamps in
 shader-clock ticks) from a -DMPPO_FUSED_TIMERS build (tools/build_variant.sh ftimers k_fused.hip -DMPPO_FUSED_TIMERS).
-usage: python tools/fused_phases.py tools/_variants/libminppo_ftimers.so"""
+usage: python tools/fused_phases.py tools/_variants/libminppo_ftimers.so [config overrides, e.g. training.mlp_dtype=bf16]"""
 import ctypes as C, sys
 from pathlib import Path
 import numpy as np, torch
@@ -9,7 +9,7 @@ from minppo_amd import _native as nat
 nat.HIP_LIB_PATH = Path(sys.argv[1]).resolve()
 from minppo_amd.config import load_config_from_cli
 from minppo_amd.train import Trainer
-cfg = load_config_from_cli(["stompy_pro", "training.num_envs=4096"])
+cfg = load_config_from_cli(["stompy_pro", "training.num_envs=4096", *sys.argv[2:]])
 tr = Trainer(cfg, use_graph=False)
 tr.reset(); tr.update(); tr._sync()
 dll = C.CDLL(str(nat.HIP_LIB_PATH))

@@ -75,3 +75,4 @@ json.dump({'_how': 'tools/pmc_mlp.sh: rocprofv3 --kernel-trace --pmc, three sepa
            'kernels': res}, open(out + '/mlp_pmc.json', 'w'), indent=1)
 print(open(out + '/mlp_pmc.txt').read())
 PY
+python3 tools/profile_meta.py "$OUT/mlp_pmc.json" "$OUT/mlp_pmc.txt" --command "tools/pmc_mlp.sh $TAG $ARGS"

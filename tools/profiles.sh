@@ -1,7 +1,7 @@
 #!/bin/bash
 # tools/profiles.sh <tag> [parts] - the evidence run of a round on the GPU box:  gpurun -- 'bash tools/profiles.sh r03_a'
 # parts (default "tests bench stats traffic"): tests = pytest -m gpu | bench = the three BASELINE bench lines (configs[1], [3], [4]) |
-# stats = rocprofv3 --kernel-trace --stats of the default bench command | traffic = FETCH_SIZE / WRITE_SIZE / RDREQ in SEPARATE
+# stats = rocprofv3 --kernel-trace --stats of the default bench command with --no-probe | traffic (trafficbf16: the bf16 network) = FETCH_SIZE / WRITE_SIZE / RDREQ in SEPARATE
 # --pmc passes over tools/kernel_probe.py (never combined with other trace domains) | bf16stats = kernel stats of the bf16 bench.
 # Everything lands under gpurun_out/<tag>/ ; copy what is judged into profiles/ (named <tag>_*).
 TAG=${1:-r00}
@@ -20,25 +20,28 @@ if has bench; then
   for f in bench_default bench_config3_bf16 bench_config5_stompy_full_8192; do python3 -c "import json;d=json.loads(open('$OUT/$f.json').read().strip().splitlines()[-1]);print('$f', round(d['value']/1e6,3),'M', round(d['ms_per_step'],3),'ms', round(d['roofline']['us_per_launch'],2),'us', round(d['roofline']['frac'],4))"; done
 fi
 if has stats; then
-  echo "=== rocprof kernel stats"; cd /tmp && step 900 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof" -- python3 "$ROOT/bench.py" --steps 5 --warmup 2 --no-cpu-baseline > "$OUT/bench_prof.json" 2>/dev/null
+  echo "=== rocprof kernel stats"; cd /tmp && step 900 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof" -- python3 "$ROOT/bench.py" --steps 5 --warmup 2 --no-cpu-baseline --no-probe > "$OUT/bench_prof.json" 2>/dev/null
   cd "$ROOT"; cp "$(ls $OUT/prof/*/*kernel_stats.csv | head -1)" "$OUT/kernel_stats.csv"; head -12 "$OUT/kernel_stats.csv" | cut -c1-150
+  python3 tools/profile_meta.py "$OUT/kernel_stats.csv" --command "rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-probe"
 fi
 if has bf16stats; then
-  cd /tmp && step 900 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof_bf16" -- python3 "$ROOT/bench.py" --steps 5 --warmup 2 --no-cpu-baseline --set training.mlp_dtype=bf16 > "$OUT/bench_prof_bf16.json" 2>/dev/null
-  cd "$ROOT"; cp "$(ls $OUT/prof_bf16/*/*kernel_stats.csv | head -1)" "$OUT/kernel_stats_config3_bf16.csv"
+  cd /tmp && step 900 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof_bf16" -- python3 "$ROOT/bench.py" --steps 5 --warmup 2 --no-cpu-baseline --no-probe --set training.mlp_dtype=bf16 > "$OUT/bench_prof_bf16.json" 2>/dev/null
+  cd "$ROOT"; cp "$(ls $OUT/prof_bf16/*/*kernel_stats.csv | head -1)" "$OUT/kernel_stats_config3_bf16.csv"; head -8 "$OUT/kernel_stats_config3_bf16.csv" | cut -c1-150
+  python3 tools/profile_meta.py "$OUT/kernel_stats_config3_bf16.csv" --command "rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-probe --set training.mlp_dtype=bf16"
 fi
-if has traffic; then
-  echo "=== traffic"; cd /tmp
+for TV in traffic trafficbf16; do if has $TV; then
+  if [ $TV = trafficbf16 ]; then SUF=_bf16; XARG="training.mlp_dtype=bf16"; else SUF=; XARG=; fi
+  echo "=== $TV"; cd /tmp
   for set in "FETCH_SIZE" "WRITE_SIZE" "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum"; do
     tag=$(echo $set | cut -d' ' -f1)
-    step 300 rocprofv3 --kernel-trace --pmc $set --output-format csv -d "$OUT/traffic/$tag" -- python3 "$ROOT/tools/kernel_probe.py" all 8 > "$OUT/traffic_$tag.log" 2>&1
+    step 300 rocprofv3 --kernel-trace --pmc $set --output-format csv -d "$OUT/traffic$SUF/$tag" -- python3 "$ROOT/tools/kernel_probe.py" all 8 $XARG > "$OUT/traffic${SUF}_$tag.log" 2>&1
   done
   cd "$ROOT"
-  python3 - "$OUT" <<'PY'
+  python3 - "$OUT" "$SUF" <<'PY'
 import csv, glob, collections, json, sys
-out = sys.argv[1]
+out = sys.argv[1]; suf = sys.argv[2] if len(sys.argv) > 2 else ''
 agg = collections.defaultdict(lambda: collections.defaultdict(list))
-for f in glob.glob(out + '/traffic/*/*/*counter_collection.csv'):
+for f in glob.glob(out + '/traffic' + suf + '/*/*/*counter_collection.csv'):
     for r in csv.DictReader(open(f)):
         k = r['Kernel_Name'].split('(')[0].replace('void ', '').replace('mppo::', '')[:80]
         agg[k][r['Counter_Name']].append(float(r['Counter_Value']))
@@ -51,9 +54,10 @@ for k, d in sorted(agg.items()):
     r32 = sum(d.get('TCC_EA0_RDREQ_32B_sum', [0])) / max(1, len(d.get('TCC_EA0_RDREQ_32B_sum', [0])))
     res[k] = {"launches": len(d['FETCH_SIZE']), "fetch_size_raw_bytes": round(fetch_raw), "fetch_bytes_corrected": round(2 * fetch_raw), "write_bytes": round(write),
               "hbm_bytes_per_launch": round(2 * fetch_raw + write), "rdreq_32B_per_launch": r32}
-json.dump({"_how": "rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE | TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum (separate passes, tools/profiles.sh) -- python3 tools/kernel_probe.py all 8; means per launch. FETCH_SIZE / WRITE_SIZE are KiB; gfx950 correction per MI355X_MICROARCH.md: FETCH_SIZE x2 (128-byte requests tallied at 64 B; valid while TCC_EA0_RDREQ_32B = 0), WRITE_SIZE exact. Workload: stompy_pro, 4096 envs, minibatch 1280 rows.",
-           "kernels": res}, open(out + '/hbm_traffic.json', 'w'), indent=1)
+json.dump({"_how": "rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE | TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum (separate passes, tools/profiles.sh) -- python3 tools/kernel_probe.py all 8; means per launch. FETCH_SIZE / WRITE_SIZE are KiB; gfx950 correction per MI355X_MICROARCH.md: FETCH_SIZE x2 (128-byte requests tallied at 64 B; valid while TCC_EA0_RDREQ_32B = 0), WRITE_SIZE exact. Workload: stompy_pro, 4096 envs, minibatch 1280 rows" + (", training.mlp_dtype=bf16" if suf else "") + ".",
+           "kernels": res}, open(out + '/hbm_traffic' + suf + '.json', 'w'), indent=1)
 for k, v in res.items():
     print('%-46s n=%4d  fetch %8.2f MB  write %8.2f MB  total %8.2f MB' % (k, v['launches'], v['fetch_bytes_corrected'] / 1e6, v['write_bytes'] / 1e6, v['hbm_bytes_per_launch'] / 1e6))
 PY
-fi
+  python3 tools/profile_meta.py "$OUT/hbm_traffic$SUF.json" --command "tools/profiles.sh $TAG $TV"
+fi; done
