@@ -154,12 +154,12 @@ def rowpass_probe(tr, launches: int = 64, replays: int = 4):
     O, A, H = tr.O, tr.A, tr.H
     macs_row = (2 * O * H + 2 * H * H + H * (A + 1)) + (2 * H * H + H * (A + 1))  # forward (both nets) + dZ2, dZ1 (both nets)
     flops = 2.0 * macs_row * mb
-    return sec, flops, f"fused_mlp_kernel: row pass of one minibatch (mb={mb}, O={O}, H={H}, A={A}, actor+critic; {'bf16 MFMA 16x16x16, f32 accumulate' if tr.net.bf16 else 'f32 MFMA 16x16x4'})"
+    return sec, flops, f"{'bf16_rowpass_kernel' if tr.net.bf16 else 'fused_mlp_kernel'}: row pass of one minibatch (mb={mb}, O={O}, H={H}, A={A}, actor+critic; {'bf16 MFMA 16x16x16, f32 accumulate' if tr.net.bf16 else 'f32 MFMA 16x16x4'})"
 
 
 def rowpass_kernel_name(bf16: bool) -> str:
     """Name (as rocprofv3 prints it) of the training row pass the engine launches for the headline geometry."""
-    return "fused_mlp_kernel<true, false, 1, true, true>" if bf16 else "fused_mlp_kernel<false, false, 1, true, true>"
+    return "bf16_rowpass_kernel<1, 8, true>" if bf16 else "fused_mlp_kernel<false, false, 1, true, true>"
 
 
 def _usable_cores() -> int:

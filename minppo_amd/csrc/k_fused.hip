@@ -191,14 +191,14 @@ struct GemmPipe {
 };
 
 // The same ring for a bf16 network with shadow copies: the B operand comes from the fragment-order bf16 copy of the weight
-// (ppo_layout.h frag_index): a lane's sixteen values of a stage are 32 contiguous bytes (two 16-byte buffer loads instead of eight
+// (ppo_layout.h frag_index): a lane's eight values of a column tile and stage are 16 contiguous bytes (two 16-byte buffer loads instead of eight
 // 8-byte ones, half the bytes, and no float -> bf16 conversion of weights in the loop).  `W` = fragment base of the matrix.
 struct FragStage {
   float4 q0, q1;  // raw bits: q0 = tile 0 (k 0..3 of group 0 | group 1), q1 = tile 1
   __device__ __forceinline__ void load(const BufView& wb, int S, int nwaves, int wave, int lane) {
     const int uni = ((S * nwaves + wave) * 64) * 32;  // bytes: (stage, wave slab) block of 2 KB
-    q0 = buf_load_f4(wb, lane * 32, uni);
-    q1 = buf_load_f4(wb, lane * 32 + 16, uni);
+    q0 = buf_load_f4(wb, lane * (2 * kFragLaneElems), uni);
+    q1 = buf_load_f4(wb, lane * (2 * kFragLaneElems) + 2 * kFragTileElems, uni);
   }
 };
 __device__ __forceinline__ void frag_mfma(const float* arow, int S, const FragStage& b, f32x4& acc0, f32x4& acc1) {
@@ -847,6 +847,8 @@ extern "C" int32_t mppo_debug_fused_timers(unsigned long long* out24) {
 namespace mppo {
 #endif
 
+#include "fused_bf16.h"  // bf16_rowpass_kernel: the training row pass of a bf16 network (BASELINE configs[3])
+
 size_t fused_smem_bytes(int O, int A, int H) {
   const int KP = (O + 31) & ~31, XS = KP + 4, HS = H + 4, OT = A > 16 ? 2 : 1;
   const size_t R0 = (size_t)FRT * (XS > HS ? XS : HS);
@@ -910,6 +912,22 @@ int32_t fused_forward_backward(const mppo_net_t& net, const float* params, const
   MPPO_REQUIRE(!pre || (w2t && idx), "fused_forward_backward: pre-gathered rows need the shadow copies and a permutation");
   if (pre) { a.xpre = pre->cur; a.xnext = pre->next; a.idx_next = pre->idx_next; }
   const dim3 grid(cdiv(mb, FRT), pre && pre->idx_next ? 4 : 2), block(2 * net.H);
+  if (pre && g.frag && bf16_rowpass_supported(net)) {  // the engine's minibatch loop of a bf16 network: the kernel designed for it (fused_bf16.h)
+    const size_t sb = bf16_rowpass_smem_bytes(net.O, net.A, net.H);
+#ifdef MPPO_TRACE_BF16
+    fprintf(stderr, "[trace] bf16_rowpass_kernel mb=%d\n", mb);
+#endif
+    const bool exact = ((net.O + 31) & ~31) == 32 * kBf16RowpassNS1 && net.H == 256;  // the registers are filled exactly: no zero stages, no selects
+    if (net.A > 16) {
+      if (exact) hipLaunchKernelGGL((bf16_rowpass_kernel<2, kBf16RowpassNS1, true>), grid, block, sb, stream, a);
+      else hipLaunchKernelGGL((bf16_rowpass_kernel<2, kBf16RowpassNS1, false>), grid, block, sb, stream, a);
+    } else {
+      if (exact) hipLaunchKernelGGL((bf16_rowpass_kernel<1, kBf16RowpassNS1, true>), grid, block, sb, stream, a);
+      else hipLaunchKernelGGL((bf16_rowpass_kernel<1, kBf16RowpassNS1, false>), grid, block, sb, stream, a);
+    }
+    MPPO_CHECK_LAUNCH("bf16_rowpass_kernel");
+    return MPPO_OK;
+  }
 #define MPPO_FUSED_GO(B, T) do { if (pre) hipLaunchKernelGGL((fused_mlp_kernel<B, false, T, true, true>), grid, block, smem, stream, a); \
                                 else if (w2t) hipLaunchKernelGGL((fused_mlp_kernel<B, false, T, true>), grid, block, smem, stream, a); \
                                 else hipLaunchKernelGGL((fused_mlp_kernel<B, false, T, false>), grid, block, smem, stream, a); } while (0)

@@ -370,13 +370,13 @@ __device__ __forceinline__ void shadow_write_tile(const ShadowRef& sh, const flo
     {
       const bf16x4 v = pack_bf16x4(tile[16 * gg + 4 * kq][2 * j + tau], tile[16 * gg + 4 * kq + 1][2 * j + tau], tile[16 * gg + 4 * kq + 2][2 * j + tau],
                                    tile[16 * gg + 4 * kq + 3][2 * j + tau]);
-      *reinterpret_cast<bf16x4*>(F + (((size_t)(k0 >> 5) * tn + (n0 >> 5)) * 64 + lane) * 16 + 8 * tau + 4 * gg) = v;
+      *reinterpret_cast<bf16x4*>(F + ((size_t)(k0 >> 5) * tn + (n0 >> 5)) * 1024 + (size_t)lane * kFragLaneElems + (size_t)tau * kFragTileElems + 4 * gg) = v;
     }
     if (!is_w1) {  // the transposed matrix B'(k', n') = W2[n'][k']: block (S = n0 / 32, w = k0 / 32), element from tile[n' - k0][k' - n0]
       unsigned short* FT_ = F + (size_t)sh.H * sh.H;
       const bf16x4 v = pack_bf16x4(tile[2 * j + tau][16 * gg + 4 * kq], tile[2 * j + tau][16 * gg + 4 * kq + 1], tile[2 * j + tau][16 * gg + 4 * kq + 2],
                                    tile[2 * j + tau][16 * gg + 4 * kq + 3]);
-      *reinterpret_cast<bf16x4*>(FT_ + (((size_t)(n0 >> 5) * tn + (k0 >> 5)) * 64 + lane) * 16 + 8 * tau + 4 * gg) = v;
+      *reinterpret_cast<bf16x4*>(FT_ + ((size_t)(n0 >> 5) * tn + (k0 >> 5)) * 1024 + (size_t)lane * kFragLaneElems + (size_t)tau * kFragTileElems + 4 * gg) = v;
     }
   }
 }

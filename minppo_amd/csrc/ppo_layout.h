@@ -107,7 +107,7 @@ struct GradBufs {
   float* w2t;
   bool w2t_valid;
   // bf16 networks only: the hidden-layer weights once more, rounded to bf16 and stored in the order the MFMA pipe consumes them
-  // (fragment order: [k stage of 32][32-column wave slab][lane][16 values], see frag_index): per network W1 (K padded to 32 with
+  // (fragment order: [k stage of 32][32-column wave slab][column tile][lane][8 values], see frag_index): per network W1 (K padded to 32 with
   // zeros), W2 and W2^T.  A lane's operands of a stage are 32 contiguous bytes, a wave's 2 KB: half the bytes of the float
   // weights, no conversion in the GEMM loop.  Same validity as w2t.
   unsigned short* frag;     // nullptr unless net.bf16
@@ -174,12 +174,20 @@ struct ShadowRef {
   // filled in by clip_adam: the flat workgroups skip the ranges that tile workgroups own (sorted, in float4 units)
   int flat_blocks, nskip; unsigned skip_start4[4], skip_len4[4];
 };
-// Position (in bf16 elements) of B(k, n) of a [K][N] weight inside its fragment-order copy: stage S = k / 32, wave slab w = n / 32,
-// lane = 16 kq + j, element e = 8 tau + 4 g + c with k = 32 S + 16 g + 4 kq + c and n = 32 w + 2 j + tau.
+// Position (in bf16 elements) of B(k, n) of a [K][N] weight inside its fragment-order copy: stage S = k / 32, wave slab w = n / 32 - a
+// block of 1024 elements (2 KB) per (S, w) - and inside the block TILE-MAJOR: column tile tau (n = 32 w + 2 j + tau) is 512 contiguous
+// elements, lane = 16 kq + j holds 8 of them, element 4 g + c with k = 32 S + 16 g + 4 kq + c.  One 16-byte load per lane and tile
+// therefore reads 1 KB of CONTIGUOUS memory across the wave (eight whole 128-byte lines).  MPPO_FRAG_LANE_MAJOR (A/B builds): round 3's
+// order, a lane's sixteen values of both tiles side by side - each of the two loads then touches half of sixteen lines.
+#ifdef MPPO_FRAG_LANE_MAJOR
+constexpr int kFragLaneElems = 16, kFragTileElems = 8;  // element strides between lanes / between the two tiles of a lane
+#else
+constexpr int kFragLaneElems = 8, kFragTileElems = 512;
+#endif
 __host__ __device__ inline size_t frag_index(int k, int n, int N) {
   const int S = k >> 5, kk = k & 31, g = kk >> 4, kq = (kk >> 2) & 3, c = kk & 3;
   const int w = n >> 5, nn = n & 31, j = nn >> 1, tau = nn & 1;
-  return (((size_t)S * (N >> 5) + w) * 64 + 16 * kq + j) * 16 + 8 * tau + 4 * g + c;
+  return ((size_t)S * (N >> 5) + w) * 1024 + (size_t)(16 * kq + j) * kFragLaneElems + (size_t)tau * kFragTileElems + 4 * g + c;
 }
 // peer (optional): `grad` / `ws` are the reduced gradient and its sums of squares in the exchange buffer; the launch reduces this rank's slice first (peer.h)
 int32_t clip_adam(size_t P, float* params, float* m, float* v, const float* grad, const int* count_base, int step_offset, const mppo_adam_cfg_t& cfg, float* ws,

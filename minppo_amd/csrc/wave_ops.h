@@ -58,6 +58,17 @@ __device__ __forceinline__ void mfma_bf16_16x16x16(bf16x4 a, bf16x4 b, f32x4& ac
   acc = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a, b, acc, 0, 0, 0);
 }
 
+// D(16x16) += A(16x32) * B(32x16): lane l supplies A[i = l&15][k = 8*(l>>4) + c] and B[k = 8*(l>>4) + c][j = l&15], c = 0..7, as the raw
+// bits of eight bf16 in a 16-byte register; acc as mfma_bf16_16x16x16  (v_mfma_f32_16x16x32_bf16, gfx950: twice the k of 16x16x16 per
+// instruction at ~16 cycles per SIMD - MI355X_MICROARCH.md, cycle constants)
+__device__ __forceinline__ void mfma_bf16_16x16x32(const float4& a_bits, const float4& b_bits, f32x4& acc) {
+  typedef __bf16 bf16x8_native __attribute__((ext_vector_type(8)));
+  typedef float f32x4_bits __attribute__((ext_vector_type(4)));
+  const bf16x8_native A = __builtin_bit_cast(bf16x8_native, f32x4_bits{a_bits.x, a_bits.y, a_bits.z, a_bits.w});
+  const bf16x8_native B = __builtin_bit_cast(bf16x8_native, f32x4_bits{b_bits.x, b_bits.y, b_bits.z, b_bits.w});
+  acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A, B, acc, 0, 0, 0);
+}
+
 // D(32x32) += A(32x8) * B(8x32): lane l supplies A[i = l&31][k = 4*(l>>5) + c] and B[k = 4*(l>>5) + c][j = l&31];
 // acc layout as mfma_f32_32x32x2  (v_mfma_f32_32x32x8_bf16)
 __device__ __forceinline__ void mfma_bf16_32x32x8(bf16x4 a, bf16x4 b, f32x16& acc) {
@@ -192,6 +203,10 @@ __device__ __forceinline__ void agent_acquire_fence() { __builtin_amdgcn_fence(_
 // compiler cannot prove that by itself and would otherwise wrap every buffer load whose scalar offset depends on it in a
 // waterfall loop (measured on k_wgrad.hip: 21 us -> 14 us)
 __device__ __forceinline__ int wave_uniform(int x) { return __builtin_amdgcn_readfirstlane(x); }
+
+// wave-level synchronisation point for LDS words that ONE wavefront writes and reads back (its LDS instructions execute in program order:
+// all that is needed is that the compiler keeps that order; the emulator, whose lanes are fibers, yields here instead - tests/emu/wave_ops.h)
+#define MPPO_WAVE_SYNC() __builtin_amdgcn_wave_barrier()
 
 // nothing is scheduled across this point (compiler-only; no instruction is emitted)
 #define MPPO_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)

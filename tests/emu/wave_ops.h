@@ -84,6 +84,25 @@ inline void mfma_bf16_16x16x16(bf16x4 a, bf16x4 b, f32x4& acc) {
   }
   __syncthreads();
 }
+// lane l supplies A[i = l&15][k = 8*(l>>4) + c], B[k][j = l&15], c = 0..7 (raw bits of eight bf16); acc[r] = D[4*(l>>4) + r][l&15]
+inline void mfma_bf16_16x16x32(const float4& a_bits, const float4& b_bits, f32x4& acc) {
+  const int t = emu::tid(), lane = t & 63, wave = t >> 6;
+  float* A = reinterpret_cast<float*>(emu::g_xchg) + wave * 1024;  // [k][i]
+  float* B = A + 512;                                              // [k][j]
+  const int i = lane & 15, q = lane >> 4;
+  short av[8], bv[8];
+  __builtin_memcpy(av, &a_bits, 16);
+  __builtin_memcpy(bv, &b_bits, 16);
+  for (int c = 0; c < 8; ++c) { A[(8 * q + c) * 16 + i] = emu_bf16_to_f32(av[c]); B[(8 * q + c) * 16 + i] = emu_bf16_to_f32(bv[c]); }
+  __syncthreads();
+  for (int r = 0; r < 4; ++r) {
+    const int row = 4 * q + r;
+    float c = acc[r];
+    for (int k = 0; k < 32; ++k) c = fmaf(A[k * 16 + row], B[k * 16 + i], c);
+    acc[r] = c;
+  }
+  __syncthreads();
+}
 // lane l supplies A[i = l&31][k = 4*(l>>5) + c], B[k][j = l&31]; acc layout as mfma_f32_32x32x2
 inline void mfma_bf16_32x32x8(bf16x4 a, bf16x4 b, f32x16& acc) {
   const int t = emu::tid(), lane = t & 63, wave = t >> 6;
@@ -169,6 +188,7 @@ inline float __shfl_xor(float x, int mask) {
 }
 
 #define MPPO_SCHED_FENCE()
+#define MPPO_WAVE_SYNC() __syncthreads()  // (every thread of the workgroup reaches the same point: the kernels use it workgroup-uniformly)
 inline void stream_store(float* p, float v) { *p = v; }
 inline void stream_store(float* p, float2 v) { *reinterpret_cast<float2*>(p) = v; }
 inline void stream_store(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }

@@ -479,7 +479,7 @@ def test_shadow_copies_change_nothing_but_the_layout_of_one_operand(be, bf16):
             g_, kq, c = kk >> 4, (kk >> 2) & 3, kk & 3
             w, nn = n >> 5, n & 31
             j, tau = nn >> 1, nn & 1
-            return ((S * (N >> 5) + w) * 64 + 16 * kq + j) * 16 + 8 * tau + 4 * g_ + c
+            return (S * (N >> 5) + w) * 1024 + tau * 512 + (16 * kq + j) * 8 + 4 * g_ + c  # tile-major inside a (stage, wave slab) block
 
         o1 = sl["c_w1"][0]
         W1c = newp[o1:o1 + O * H].reshape(O, H)

@@ -14,7 +14,7 @@ tr = Trainer(cfg, use_graph=False)
 tr.reset(); tr.update(); tr._sync()
 dll = C.CDLL(str(nat.HIP_LIB_PATH))
 # interval i ends at stamp FT(i + 1) of csrc/k_fused.hip
-names = {0: "entry -> arguments; weights / biases / head weights requested", 1: "index -> rows chain (index wait, dependent loads issued)", 2: "x tile to LDS + barrier", 3: "L1 GEMM (this wave)",
+names = {0: "entry -> arguments; weights / biases / head weights requested (bf16 row pass: x, W1, biases)", 1: "index -> rows chain (index wait, dependent loads issued; bf16 row pass: head weights / loss scalars requested)", 2: "x tile to LDS + barrier", 3: "L1 GEMM (this wave)",
          4: "L1 epilogue + stores + barrier (waits for the SIMD's second wave)", 5: "L2 GEMM (this wave)", 6: "L2 epilogue + stores + barrier", 7: "(two stamps in a row)", 8: "head GEMM + partials + barrier", 9: "head sums + loss + dOut",
          10: "barrier + loss partials", 11: "dZ2 + stores + barrier", 12: "dZ1 GEMM", 13: "dZ1 epilogue + stores"}
 acc = {}
