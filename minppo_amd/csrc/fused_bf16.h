@@ -81,7 +81,8 @@ __global__ void __launch_bounds__(512, 2) bf16_rowpass_kernel(FusedArgs a) {
   const int net = blockIdx.y;  // 0 actor, 1 critic
   const int KP = (O + 31) & ~31;
   const int XSB = KP + 8, HSB = H + 8, HS = H + 4;  // bf16 row strides (elements): 4 (mod 64) dwords; float row stride of h2
-  const int t = threadIdx.x, nthr = blockDim.x, lane = t & 63, wave = t >> 6, nw = nthr >> 6;
+  const int t = threadIdx.x, nthr = blockDim.x, lane = t & 63, nw = nthr >> 6;
+  const int wave = wave_uniform(t >> 6);  // (in a scalar register: a buffer load whose scalar offset the compiler cannot prove uniform is wrapped in a waterfall loop)
   unsigned short* xb = reinterpret_cast<unsigned short*>(smem_raw);  // [16][XSB] bf16   x tile
   unsigned short* h1b = xb + FRT * XSB;                             // [16][HSB] bf16   h1
   unsigned short* dzb = h1b + FRT * HSB;                            // [16][HSB] bf16   dZ2
@@ -104,15 +105,22 @@ __global__ void __launch_bounds__(512, 2) bf16_rowpass_kernel(FusedArgs a) {
   // L2: 3.8 us), so the stream must run from the first microsecond to the last GEMM WITHOUT the waves standing in the issue queue while
   // they could compute: a vector-memory instruction issues only when the CU's address path has room, and with eight waves requesting
   // 1 KB per instruction that is one instruction per ~130 cycles and wave.  W1 (needed first) is requested here, all of it; the 16
-  // loads of W2 are PACED through P0, layer 1's product and its epilogue, those of W2^T through layer 2, its epilogue, the heads and the
-  // loss - one or two at a time between blocks of other work (WL below), each a phase or two ahead of its use: a wave that asks for one
-  // load per ~150 cycles of its own work finds room in the queue, a wave that asks for sixteen in a row stands there for 1.4 us
-  // (profiles/r05_c_fused_phases_bf16.txt: layer 1's product took 3.4 k cycles with W2 requested between its stages, 0.6 k without).  Every load is unconditional on a clamped address (a conditional load is a basic block of its own, and the
+  // loads of W2 are requested at the start of P0 (4) and P1 (12), those of W2^T at the start of P2 (12) and P3 (4) - each a phase or two
+  // ahead of its use, in front of the phase's own work, which then runs while they are served.  (Measured and dropped, DESIGN.md 9: the same
+  // loads one at a time between blocks of work; the two waves of a SIMD requesting at opposite ends of a phase - 9.5 us either way.)  Every load is unconditional on a clamped address (a conditional load is a basic block of its own, and the
   // s_waitcnt insertion then assumes the worse of two histories at the join: the wait for the x tile waited for W1 as well).
   const int nxq = 4 * OP;
   const float* xtile = a.xpre + (size_t)(row0 >> 2) * OP * 2;  // this step's rows: a contiguous block of 8-byte bf16 quads (store_quad<true>)
-  const float2 xr0 = *reinterpret_cast<const float2*>(xtile + 2 * (t < nxq ? t : nxq - 1));
-  const float2 xr1 = *reinterpret_cast<const float2*>(xtile + 2 * (t + nthr < nxq ? t + nthr : nxq - 1));
+  // brought in by the FIRST HALF of the waves, four quads per lane: the address path serves the older wave of every SIMD first, so waves
+  // nw/2 .. get through their requests ~2 k cycles after waves 0 .. nw/2 - 1 (stamps: profiles/r05_j_fused_phases_bf16.txt) - by the time
+  // they would write their share of the tile to LDS the first half has written all of it, and the barrier behind P0 waits for nobody
+  const int nwx = (nw + 1) >> 1, nthx = 64 * nwx;
+  const bool xw = wave < nwx;
+  float2 xr0 = make_float2(0.f, 0.f), xr1 = xr0, xr2 = xr0, xr3 = xr0;
+  if (xw) {
+    auto xl = [&](int e) { return *reinterpret_cast<const float2*>(xtile + 2 * (e < nxq ? e : nxq - 1)); };
+    xr0 = xl(t); xr1 = xl(t + nthx); xr2 = xl(t + 2 * nthx); xr3 = xl(t + 3 * nthx);
+  }
   const unsigned short* fr = a.frag[net];
   FragSlab<NS1> w1;
   w1.open(fr, KP, H, wave, lane);
@@ -134,6 +142,20 @@ __global__ void __launch_bounds__(512, 2) bf16_rowpass_kernel(FusedArgs a) {
   const float4 w3r0 = w3_load(0), w3r1 = w3_load(1), w3r2 = NW3 > 2 ? w3_load(2) : w3r0, w3r3 = NW3 > 2 ? w3_load(3) : w3r0;  // (named: an array went to scratch)
   const float adv_mean = a.adv_stat[0], adv_rstd = a.adv_stat[1];
   float ls[OT], b3v[OT], w3p[OT][8], w3q[4 * OT][2], pf0[OT][4], pf1[4], pf2[4];
+#ifdef MPPO_EMU
+  constexpr bool kLossAllWaves = true;  // (the emulator's cross-lane shims are workgroup-wide barriers: every wave runs the loss block)
+#else
+  constexpr bool kLossAllWaves = false;  // on the GPU only wave 0 runs the loss block (see there) - and only it requests the block's inputs
+#endif
+#pragma unroll
+  for (int ot = 0; ot < OT; ++ot) {
+    ls[ot] = b3v[ot] = 0.f;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) pf0[ot][r] = 0.f;
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) pf1[r] = pf2[r] = 0.f;
+  if (kLossAllWaves || wave == 0) {
 #pragma unroll
   for (int ot = 0; ot < OT; ++ot) {
     const int o = cj + 16 * ot;
@@ -153,6 +175,7 @@ __global__ void __launch_bounds__(512, 2) bf16_rowpass_kernel(FusedArgs a) {
     pf1[0] = q1.x; pf1[1] = q1.y; pf1[2] = q1.z; pf1[3] = q1.w;
     pf2[0] = q2.x; pf2[1] = q2.y; pf2[2] = q2.z; pf2[3] = q2.w;
   }
+  }
   MPPO_SCHED_FENCE();
   FT(2);
   FTW(64);
@@ -168,15 +191,16 @@ __global__ void __launch_bounds__(512, 2) bf16_rowpass_kernel(FusedArgs a) {
       unsigned short* d = xb + (4 * qd) * XSB + c;
       d[0] = (unsigned short)(lo & 0xFFFFu); d[XSB] = (unsigned short)(lo >> 16); d[2 * XSB] = (unsigned short)(hi & 0xFFFFu); d[3 * XSB] = (unsigned short)(hi >> 16);
     };
-    if (t < nxq) put(t, xr0);
-    WL(w2, 0, 0);
-    if (t + nthr < nxq) put(t + nthr, xr1);
-    WL(w2, 0, 1);
-    for (int e = t + 2 * nthr; e < nxq; e += nthr) put(e, *reinterpret_cast<const float2*>(xtile + 2 * e));  // (fewer than nxq / 2 threads only)
+    WL(w2, 0, 0); WL(w2, 0, 1); WL(w2, 1, 0); WL(w2, 1, 1);
+    if (xw) {
+      if (t < nxq) put(t, xr0);
+      if (t + nthx < nxq) put(t + nthx, xr1);
+      if (t + 2 * nthx < nxq) put(t + 2 * nthx, xr2);
+      if (t + 3 * nthx < nxq) put(t + 3 * nthx, xr3);
+      for (int e = t + 4 * nthx; e < nxq; e += nthx) put(e, *reinterpret_cast<const float2*>(xtile + 2 * e));  // (small workgroups only)
+    }
     for (int r = t >> 5; r < FRT; r += nthr >> 5)  // K padding of the first layer: fewer than 32 columns per row, one lane each
       if (OP + (t & 31) < KP) xb[r * XSB + OP + (t & 31)] = 0;
-    WL(w2, 1, 0);
-    WL(w2, 1, 1);
   }
   FTW(72);
   __syncthreads();
@@ -192,13 +216,13 @@ __global__ void __launch_bounds__(512, 2) bf16_rowpass_kernel(FusedArgs a) {
     if (blockIdx.x == 40 && blockIdx.y == 0 && lane == 0) g_fused_t[24 + wave] = __builtin_amdgcn_s_memtime();
 #endif
     {
+#pragma unroll
+      for (int S = 2; S < NSH; ++S) { WL(w2, S, 0); WL(w2, S, 1); }
       const auto At = w1.template read_a<EXACT>(xb + cj * XSB + 4 * rq, nst1);
       MPPO_SCHED_FENCE();
 #pragma unroll
-      for (int S = 0; S < (NS1 > NSH ? NS1 : NSH); ++S) {
-        if (S < NS1) w1.mfma_stage(S, At, acc);
-        if (S < 8) WL(w2, 2 + (S >> 1), S & 1);
-      }
+      for (int S = 0; S < NS1; ++S) w1.mfma_stage(S, At, acc);
+      MPPO_SCHED_FENCE();
     }
     for (int r = 0; r < 4; ++r) { acc0[r] = acc[0][0][r] + acc[1][0][r]; acc1[r] = acc[0][1][r] + acc[1][1][r]; }
     MPPO_SCHED_FENCE();
@@ -211,7 +235,6 @@ __global__ void __launch_bounds__(512, 2) bf16_rowpass_kernel(FusedArgs a) {
       if (lane + 64 < nq4) *reinterpret_cast<float4*>(wsc + 4 * (lane + 64)) = w3r1;
       if (NW3 > 2 && lane + 128 < nq4) *reinterpret_cast<float4*>(wsc + 4 * (lane + 128)) = w3r2;
       if (NW3 > 2 && lane + 192 < nq4) *reinterpret_cast<float4*>(wsc + 4 * (lane + 192)) = w3r3;
-      WL(w2, 6, 0);
       MPPO_WAVE_SYNC();
 #pragma unroll
       for (int ot = 0; ot < OT; ++ot)
@@ -227,7 +250,7 @@ __global__ void __launch_bounds__(512, 2) bf16_rowpass_kernel(FusedArgs a) {
         w3q[m][1] = wsc[(2 * cj + 1) * nout + ac];
       }
     }
-    WL(w2, 6, 1);
+    MPPO_SCHED_FENCE();
 #ifdef MPPO_FUSED_TIMERS
     if (blockIdx.x == 40 && blockIdx.y == 0 && lane == 0) g_fused_t[24 + 8 + wave] = __builtin_amdgcn_s_memtime();
 #endif
@@ -243,11 +266,9 @@ __global__ void __launch_bounds__(512, 2) bf16_rowpass_kernel(FusedArgs a) {
       const bool on = row0 + rr < a.mb;
       q0[r] = on ? v0 : 0.f; q1[r] = on ? v1 : 0.f;
     }
-    WL(w2, 7, 0);
     size_t qi, qi2;
     pair_index<true>(row0 + 4 * rq, c0, H, qi, qi2);
     store_quad2<true>(a.h1[net], qi, qi2, q0, q1);
-    WL(w2, 7, 1);
   }
   __syncthreads();
   FT(5);
@@ -259,13 +280,13 @@ __global__ void __launch_bounds__(512, 2) bf16_rowpass_kernel(FusedArgs a) {
     if (blockIdx.x == 40 && blockIdx.y == 0 && lane == 0) g_fused_t[24 + 16 + wave] = __builtin_amdgcn_s_memtime();
 #endif
     {
+#pragma unroll
+      for (int S = 0; S < 6; ++S) { WL(w5, S, 0); WL(w5, S, 1); }
       const auto At = w2.template read_a<EXACT>(h1b + cj * HSB + 4 * rq, nsth);
       MPPO_SCHED_FENCE();
 #pragma unroll
-      for (int S = 0; S < NSH; ++S) {
-        w2.mfma_stage(S, At, acc);
-        WL(w5, S >> 1, S & 1);
-      }
+      for (int S = 0; S < NSH; ++S) w2.mfma_stage(S, At, acc);
+      MPPO_SCHED_FENCE();
     }
     for (int r = 0; r < 4; ++r) { acc0[r] = acc[0][0][r] + acc[1][0][r]; acc1[r] = acc[0][1][r] + acc[1][1][r]; }
 #ifdef MPPO_FUSED_TIMERS
@@ -283,19 +304,16 @@ __global__ void __launch_bounds__(512, 2) bf16_rowpass_kernel(FusedArgs a) {
       const bool on = row0 + rr < a.mb;
       q0[r] = on ? v0 : 0.f; q1[r] = on ? v1 : 0.f;
     }
-    WL(w5, 4, 0);
-    WL(w5, 4, 1);
     size_t qi, qi2;
     pair_index<true>(row0 + 4 * rq, c0, H, qi, qi2);
     store_quad2<true>(a.h2[net], qi, qi2, q0, q1);
-    WL(w5, 5, 0);
-    WL(w5, 5, 1);
   }
   __syncthreads();
   FT(7);
   FT(8);
   // ---- P3: output layer, exact float: OT 16x16 tiles (rows x outputs), K = H split over the waves, partial tiles summed through LDS ----
   {
+    WL(w5, 6, 0); WL(w5, 6, 1); WL(w5, 7, 0); WL(w5, 7, 1);
     f32x4 hp[OT];
 #pragma unroll
     for (int ot = 0; ot < OT; ++ot)
@@ -313,13 +331,14 @@ __global__ void __launch_bounds__(512, 2) bf16_rowpass_kernel(FusedArgs a) {
 #pragma unroll
     for (int ot = 0; ot < OT; ++ot)
       *reinterpret_cast<float4*>(s_hp + ((wave * OT + ot) * 64 + lane) * 4) = make_float4(hp[ot][0], hp[ot][1], hp[ot][2], hp[ot][3]);
-    WL(w5, 6, 0);
-    WL(w5, 6, 1);
   }
   __syncthreads();
   FT(9);
-  // ---- loss terms and d(loss)/d(outputs): the float kernel's arithmetic, statement for statement (k_fused.hip) ----
-  {
+  // ---- loss terms and d(loss)/d(outputs): the float kernel's arithmetic, statement for statement (k_fused.hip).  One wave's lanes cover
+  // all 16 rows x 16 OT outputs, and only wave 0's results are stored: on the GPU only wave 0 runs this block - its SIMD's second wave
+  // (wave 4) waits at the barrier instead of taking every other issue slot for a copy of the same arithmetic.  (The emulator's cross-lane
+  // shims are workgroup-wide barriers: there every wave takes part, as in fused_mlp_kernel.)
+  if (kLossAllWaves || wave == 0) {
     float out[OT][4];
 #pragma unroll
     for (int ot = 0; ot < OT; ++ot) {
@@ -331,8 +350,6 @@ __global__ void __launch_bounds__(512, 2) bf16_rowpass_kernel(FusedArgs a) {
       for (int w = 0; w < 8; ++w)
         if (EXACT || w < nw) { out[ot][0] += hq[w].x; out[ot][1] += hq[w].y; out[ot][2] += hq[w].z; out[ot][3] += hq[w].w; }
     }
-    WL(w5, 7, 0);
-    WL(w5, 7, 1);
     const bool st = wave == 0;
     float sum_ls_l = 0.f;
 #pragma unroll

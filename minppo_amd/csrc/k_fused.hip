@@ -196,7 +196,7 @@ struct GemmPipe {
 struct FragStage {
   float4 q0, q1;  // raw bits: q0 = tile 0 (k 0..3 of group 0 | group 1), q1 = tile 1
   __device__ __forceinline__ void load(const BufView& wb, int S, int nwaves, int wave, int lane) {
-    const int uni = ((S * nwaves + wave) * 64) * 32;  // bytes: (stage, wave slab) block of 2 KB
+    const int uni = ((S * nwaves + wave_uniform(wave)) * 64) * 32;  // bytes: (stage, wave slab) block of 2 KB; the wave index in a scalar register (else: a waterfall loop around every load)
     q0 = buf_load_f4(wb, lane * (2 * kFragLaneElems), uni);
     q1 = buf_load_f4(wb, lane * (2 * kFragLaneElems) + 2 * kFragTileElems, uni);
   }
