@@ -226,7 +226,7 @@ def _cpu_baseline_worker(config_name: str, overrides, n_envs: int, updates: int)
         noise = torch.randn(T, N, A, generator=gen)
         perms = torch.stack([torch.randperm(N * T, generator=gen) for _ in range(E)])
         t0 = time.perf_counter()
-        last_obs, mean_reward = pt.one_update(tw, p, opt, last_obs, noise, perms, M, hp, bool(cfg.model.use_tanh))
+        last_obs, mean_reward, _ = pt.one_update(tw, p, opt, last_obs, noise, perms, M, hp, bool(cfg.model.use_tanh))
         times.append(time.perf_counter() - t0)
     # the environment step alone (same states, fresh actions): how the update's time splits
     acts = [np.random.default_rng(5).standard_normal((N, A)).astype(np.float32) for _ in range(3)]

@@ -116,7 +116,7 @@ def update_epochs(p, opt: Adam, traj, adv, tgt, perms, num_minibatches: int, hp:
 def one_update(twin, p: Dict[str, torch.Tensor], opt: Adam, last_obs: torch.Tensor, noise: torch.Tensor, perms: torch.Tensor, num_minibatches: int, hp: dict,
                use_tanh: bool = True):
     """One `_update_step` (train.py:146-283) on the CPU: rollout through the C++ / OpenMP environment twin, then the update above.
-    Returns (last_obs, mean reward)."""
+    Returns (last_obs, mean reward, losses [E * M, 4] = total / value / actor / entropy of every minibatch step)."""
     T, N = noise.shape[0], noise.shape[1]
     O = twin.obs_dim
     obs_l, act_l, val_l, rew_l, lp_l, done_l = [], [], [], [], [], []
@@ -133,5 +133,5 @@ def one_update(twin, p: Dict[str, torch.Tensor], opt: Adam, last_obs: torch.Tens
         traj = dict(obs=torch.stack(obs_l), action=torch.stack(act_l), value=torch.stack(val_l), log_prob=torch.stack(lp_l))
         reward, done = torch.stack(rew_l), torch.stack(done_l)
         adv, tgt = gae(done, traj["value"], reward, last_val, hp["gamma"], hp["gae_lambda"])
-    update_epochs(p, opt, traj, adv, tgt, perms, num_minibatches, hp, use_tanh)
-    return last_obs, float(reward.mean())
+    losses = update_epochs(p, opt, traj, adv, tgt, perms, num_minibatches, hp, use_tanh)
+    return last_obs, float(reward.mean()), losses
