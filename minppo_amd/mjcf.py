@@ -297,8 +297,64 @@ def convex_hull_vertices(points: np.ndarray, what: str = "mesh") -> np.ndarray:
 # ---------------------------------------------------------------------------
 
 
+def _expand_includes(el: ET.Element, cur_dir: Optional[Path], main_dir: Optional[Path], seen: List[Path]) -> None:
+    """Replaces every `<include file=...>` below `el`, at any depth, by the children of the included file's root (`<mujoco>` or
+    `<mujocoinclude>`), recursively.  MuJoCo resolves the file name against the directory of the MAIN model file; exports that keep
+    their parts in sub-directories and include from there are accepted as well (the including file's own directory is tried second).
+    The reference copies the robot's whole directory next to the model for exactly this reason (env.py:35-37).  A file may be included
+    once (MuJoCo's rule): a second inclusion - a cycle among them - is an error."""
+    i = 0
+    while i < len(el):
+        ch = el[i]
+        if ch.tag != "include":
+            _expand_includes(ch, cur_dir, main_dir, seen)
+            i += 1
+            continue
+        fname = ch.get("file")
+        if not fname:
+            raise ValueError("<include> needs a file attribute")
+        if main_dir is None:
+            raise ValueError(f"<include file={fname!r}> needs the MJCF's directory (load it with load_mjcf / pass base_dir)")
+        cands = [Path(main_dir) / fname] + ([Path(cur_dir) / fname] if cur_dir is not None and Path(cur_dir) != Path(main_dir) else [])
+        path = next((c for c in cands if c.is_file()), None)
+        if path is None:
+            raise ValueError(f"<include file={fname!r}>: not found (tried {', '.join(str(c) for c in cands)})")
+        path = path.resolve()
+        if path in seen:
+            raise ValueError(f"<include file={fname!r}>: {path.name} is included more than once")
+        seen.append(path)
+        inc = ET.fromstring(path.read_text())
+        if inc.tag not in ("mujoco", "mujocoinclude"):
+            raise ValueError(f"<include file={fname!r}>: root element <{inc.tag}> (mujoco or mujocoinclude expected)")
+        _expand_includes(inc, path.parent, main_dir, seen)
+        el.remove(ch)
+        for k, sub in enumerate(list(inc)):
+            el.insert(i + k, sub)
+        i += len(inc)
+
+
+def _merged(root: ET.Element, tag: str) -> Optional[ET.Element]:
+    """MJCF sections may repeat (an included file usually brings its own <compiler>, <option>, <actuator> ...): MuJoCo merges them, later
+    attributes overriding earlier ones and children accumulating.  Returns one element carrying the merge (None if the section is absent)."""
+    els = root.findall(tag)
+    if not els:
+        return None
+    if len(els) == 1:
+        return els[0]
+    out = ET.Element(tag)
+    for e in els:
+        out.attrib.update(e.attrib)
+        for ch in e:
+            if tag == "option" and ch.tag == "flag" and out.find("flag") is not None:
+                out.find("flag").attrib.update(ch.attrib)
+            else:
+                out.append(ch)
+    return out
+
+
 def parse_mjcf(xml: str, name: str = "mjcf", base_dir: Optional[Path] = None) -> ModelSpec:
     root = ET.fromstring(xml)
+    _expand_includes(root, base_dir, base_dir, [])
     if root.tag != "mujoco":
         raise ValueError(f"not an MJCF document: root element <{root.tag}>")
     for ch in root:
@@ -306,12 +362,11 @@ def parse_mjcf(xml: str, name: str = "mjcf", base_dir: Optional[Path] = None) ->
             raise ValueError(f"<{ch.tag}> is outside the supported MJCF subset")
         if ch.tag not in _IGNORED_TOP | {"compiler", "option", "default", "worldbody", "actuator", "contact", "include"}:
             raise ValueError(f"<{ch.tag}> is outside the supported MJCF subset")
-        if ch.tag == "include":
-            raise ValueError("<include> is not resolved: flatten the MJCF first")
-    comp = _Compiler(root.find("compiler"))
+    comp_el = _merged(root, "compiler")
+    comp = _Compiler(comp_el)
     dfl = _Defaults(root)
     spec_kw: Dict[str, object] = {}
-    opt = root.find("option")
+    opt = _merged(root, "option")
     if opt is not None:
         for k, v in opt.attrib.items():
             if k == "timestep":
@@ -344,8 +399,8 @@ def parse_mjcf(xml: str, name: str = "mjcf", base_dir: Optional[Path] = None) ->
     # collision meshes (everything else under <asset> is visual)
     meshes: Dict[str, np.ndarray] = {}
     meshdir = ""
-    if root.find("compiler") is not None:
-        meshdir = root.find("compiler").get("meshdir", root.find("compiler").get("assetdir", ""))
+    if comp_el is not None:
+        meshdir = comp_el.get("meshdir", comp_el.get("assetdir", ""))
     for asset in root.findall("asset"):
         for me in asset.findall("mesh"):
             mname = me.get("name") or (Path(me.get("file", "")).stem if me.get("file") else None)
@@ -367,7 +422,7 @@ def parse_mjcf(xml: str, name: str = "mjcf", base_dir: Optional[Path] = None) ->
                 raise ValueError(f"mesh {mname}: refpos / refquat are not supported")
             meshes[mname] = pts * scale[None, :]
 
-    world = root.find("worldbody")
+    world = _merged(root, "worldbody")
     if world is None:
         raise ValueError("MJCF has no <worldbody>")
     bodies: List[BodySpec] = []
@@ -478,10 +533,14 @@ def parse_mjcf(xml: str, name: str = "mjcf", base_dir: Optional[Path] = None) ->
                 if ch.tag == "freejoint":
                     joints.append(JointSpec(ch.get("name", f"{bname}_free"), JNT_FREE))
                     continue
-                if "frictionloss" in ch.attrib and float(ch.attrib["frictionloss"]) != 0:
-                    raise ValueError(f"{what}: joint-level frictionloss is not supported (the reference only strips it from <default><joint>, "
-                                     f"env.py:41-45, and Brax would reject it)")
                 a = dfl.resolve("joint", ch, cc)
+                if "frictionloss" in ch.attrib and float(ch.attrib["frictionloss"]) != 0:
+                    # The reference deletes `frictionloss` from <default><joint> before MuJoCo sees the file, because Brax / MJX reject a model
+                    # with dry joint friction (env.py:41-45); an export that carries it on the joints themselves would stop it at
+                    # `mjcf.load_model`.  The same treatment here - stripped, said once per joint - so that such a file trains at all: the
+                    # physics then has NO dry friction in that joint (MuJoCo would add a friction-loss constraint row).
+                    logger.warning("%s: frictionloss=%s is dropped (the engine, like MJX behind the reference, models no dry joint friction; "
+                                   "the reference strips the attribute from <default><joint>, env.py:41-45)", what, ch.attrib["frictionloss"])
                 a.pop("frictionloss", None)
                 jt = {"free": JNT_FREE, "hinge": JNT_HINGE, "slide": JNT_SLIDE}.get(a.get("type", "hinge"))
                 if jt is None:
@@ -564,7 +623,7 @@ def parse_mjcf(xml: str, name: str = "mjcf", base_dir: Optional[Path] = None) ->
 
     joint_names = {j.name for b in bodies for j in b.joints}
     acts: List[ActuatorSpec] = []
-    act_el = root.find("actuator")
+    act_el = _merged(root, "actuator")
     for ch in (act_el if act_el is not None else []):
         what = f"<actuator><{ch.tag}>"
         if ch.tag not in ("position", "motor"):

@@ -80,11 +80,15 @@ def _walk(cm, N, steps, seed, scale=0.3):
 
 MJCF_ROBOT = str(Path(__file__).parent / "golden" / "hand_leg.xml")  # goes through minppo_amd/mjcf.py
 MJCF_MESH = str(Path(__file__).parent / "golden" / "mesh_foot.xml")   # a foot that collides as the convex hull of an inline <mesh vertex=...>
+# a 28-body biped laid out like an onshape / URDF export: <include> files in sub-directories, nested default classes, meshdir with .obj / .stl
+# files, joint-level frictionloss (tests/golden/make_export_biped.py); 33 dofs: the run-time-sized kernel
+MJCF_EXPORT = str(Path(__file__).parent / "golden" / "export_biped" / "robot.xml")
 
 
 @pytest.mark.parametrize("model,N", [("synth_stompy_pro", 33), ("synth_stompy_full", 17), ("synth_pendulum", 3), ("synth_ball", 2), (MJCF_ROBOT, 4),
                                      ("synth_brick", 6),              # a free box: eight corner contacts against the ground (box geoms)
-                                     ("synth_wedge", 6), (MJCF_MESH, 5)])  # mesh geoms: MJX's plane_convex, four slots per geom, vertices chosen every step
+                                     ("synth_wedge", 6), (MJCF_MESH, 5),   # mesh geoms: MJX's plane_convex, four slots per geom, vertices chosen every step
+                                     (MJCF_EXPORT, 12)])
 def test_forward_matches_oracle(be, model, N):
     cm = load_model(model)
     h, dims, _keep = be.model(cm)
@@ -616,6 +620,52 @@ def test_env_step_matches_env_oracle(be, model, n_frames, c_vals):
     # qvel' - qvel = h x (the solver's float32 envelope, module docstring), per frame
     dv = np.concatenate(dv_all)
     assert dv.max() <= 1.0 * n_frames and np.mean(dv > 0.15 * n_frames) <= 0.05 and np.median(dv) <= 0.02 * n_frames, (dv.max(), np.mean(dv > 0.15 * n_frames), np.median(dv))
+    be.lib.model_close(h)
+
+
+def test_export_style_biped_compiles_steps_and_follows_the_oracle(be):
+    """SURVEY 8(f1) towards the file a stompy_pro user actually has (reference env.py:27-50): a 28-body biped laid out like an onshape / URDF
+    export (tests/golden/export_biped/, written by tests/golden/make_export_biped.py) - includes in sub-directories, nested default classes,
+    meshdir with .obj / .stl files, joint-level frictionloss - goes through minppo_amd/mjcf.py and the run-time-sized kernel (33 dofs, 87
+    constraint rows): 12 steps against the environment oracle re-seeded before every step (observation, reward, done, stepped pose), then
+    100 free-running steps under random actions that stay finite, the pelvis neither sinking through the ground nor taking off."""
+    cm = load_model(MJCF_EXPORT)
+    assert (cm.nv, cm.nu, int(cm.t["nbody"]), int(cm.t["ncvx"]), int(cm.t["npair"])) == (33, 20, 29, 2, 1)
+    h, dims, _keep = be.model(cm)
+    flag = C.c_int32(-1)
+    be.lib.model_is_specialized(h, C.byref(flag))
+    assert flag.value == 0 and dims.lds_bytes <= 160 * 1024
+    N, O, OP, R, nv, nu = 5, dims.obs_dim, dims.obs_pad, dims.rec_dim, cm.nv, cm.nu
+    rcfg = RewardCfg()
+    env = EnvOracle(cm.t, rcfg)
+    state, reset_rec, obs = be.zeros((N, R)), be.zeros((R,)), be.full((N, OP), np.nan)
+    rew, done = be.zeros((N,)), be.zeros((N,), np.uint8)
+    be.lib.env_reset(h, N, be.ptr(state), be.ptr(reset_rec), be.ptr(obs), OP, be.ptr(rew), be.ptr(done), None, be.stream)
+    es = env.reset(N)
+    np.testing.assert_allclose(be.host(obs)[:, :O], es["obs"], atol=1e-5)
+    rc = nat.RewardCfg(rcfg.height_min_z, rcfg.height_max_z, 2.0, 0.2, 0.5, 0.1, 4.0, 1.0, 1.25)
+    rng = np.random.default_rng(4)
+    for t in range(12):
+        a = (0.5 * rng.standard_normal((N, nu))).astype(f32)
+        be.put(state, _pack(env, es["pipeline_state"], dims, nv))
+        be.lib.env_step(h, N, 1, C.byref(rc), be.ptr(state), be.ptr(reset_rec), be.ptr(be.arr(a)), nu, be.ptr(obs), OP, be.ptr(rew), be.ptr(done), None, be.stream)
+        es = env.step(es, a.astype(np.float64))
+        assert (be.host(done).astype(bool) == es["done"]).all(), t
+        np.testing.assert_allclose(be.host(obs)[:, :O], es["obs"], atol=1e-4)
+        np.testing.assert_allclose(be.host(rew), es["reward"], atol=2e-2)
+        # the stepped pose: the root within the usual 2e-3; the joints inside the float32 envelope of the unconverged solver, which is wide for this
+        # robot's light end bodies (a 0.12 kg toe: one unit of acceleration error is 2e-3 rad per frame) - nine in ten within 2e-3, none beyond 1.2e-2
+        dq = np.abs(be.host(state)[:, :cm.nq] - es["pipeline_state"].qpos)
+        assert dq[:, :7].max() <= 2e-3 and np.mean(dq[:, 7:] > 2e-3) <= 0.10 and dq.max() <= 1.2e-2, (t, dq[:, :7].max(), np.mean(dq[:, 7:] > 2e-3), dq.max())
+    z = []
+    for t in range(100):  # free running
+        a = (0.5 * rng.standard_normal((N, nu))).astype(f32)
+        be.lib.env_step(h, N, 1, C.byref(rc), be.ptr(state), be.ptr(reset_rec), be.ptr(be.arr(a)), nu, be.ptr(obs), OP, be.ptr(rew), be.ptr(done), None, be.stream)
+        st = be.host(state)
+        assert np.isfinite(st).all() and np.isfinite(be.host(rew)).all() and np.isfinite(be.host(obs)[:, :O]).all(), t
+        z.append(st[:, 2].copy())
+    z = np.asarray(z)
+    assert (z > 0.3).all() and (z < 1.0).all(), (z[-1], z.min(), z.max())  # on its feet or on its way down - neither through the ground nor off into the sky
     be.lib.model_close(h)
 
 

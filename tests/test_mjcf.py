@@ -1,6 +1,8 @@
 """MJCF subset compiler (`minppo_amd/mjcf.py`; stands where reference env.py:27-50 loads the robot file)."""
 import math
 
+from pathlib import Path
+
 import numpy as np
 import pytest
 
@@ -101,11 +103,21 @@ def test_hand_written_mjcf_defaults_units_and_inertia():
     assert (cm.nq, cm.nv, cm.nu) == (9, 8, 2)
 
 
-def test_frictionloss_is_stripped_only_where_the_reference_strips_it():
-    mjcf.parse_mjcf(HAND)  # <default><joint frictionloss> is deleted (reference env.py:41-45): no error
-    bad = HAND.replace('<joint name="knee" axis="0 1 0"/>', '<joint name="knee" axis="0 1 0" frictionloss="0.2"/>')
-    with pytest.raises(ValueError, match="frictionloss"):
-        mjcf.parse_mjcf(bad)
+def test_frictionloss_is_stripped_like_the_reference_strips_it(caplog):
+    """<default><joint frictionloss> is deleted silently (reference env.py:41-45); on a joint itself - where the reference would let Brax
+    refuse the model - it is dropped with a warning that names the joint: same compiled model either way."""
+    import logging
+
+    base = mjcf.parse_mjcf(HAND)
+    with caplog.at_level(logging.WARNING, logger="minppo_amd.mjcf"):
+        caplog.clear()
+        mjcf.parse_mjcf(HAND)
+        assert not [r for r in caplog.records if "frictionloss" in r.getMessage()]
+        worn = mjcf.parse_mjcf(HAND.replace('<joint name="knee" axis="0 1 0"/>', '<joint name="knee" axis="0 1 0" frictionloss="0.2"/>'))
+        msgs = [r.getMessage() for r in caplog.records if "frictionloss" in r.getMessage()]
+    assert len(msgs) == 1 and "shin" in msgs[0] and "0.2" in msgs[0]
+    a, b = compile_model(base), compile_model(worn)
+    assert a.to_blob(True) == b.to_blob(True)
 
 
 @pytest.mark.parametrize("old,new,msg", [
@@ -263,3 +275,60 @@ def test_mesh_geom_collides_as_its_convex_hull(tmp_path):
 def test_mesh_geoms_outside_the_subset_are_loud_errors(asset, gattr, extra, msg):
     with pytest.raises(ValueError, match=msg):
         compile_model(mjcf.parse_mjcf(MESH_XML.format(asset=asset, gattr=gattr, extra=extra)))
+
+
+EXPORT = Path(__file__).parent / "golden" / "export_biped"
+
+
+def test_export_style_layout_includes_defaults_meshdir(caplog):
+    """The way an onshape / URDF export lays a robot out (tests/golden/export_biped, written by tests/golden/make_export_biped.py): the model
+    split over <include> files - resolved against the MAIN file's directory, some inside a <body>, some in sub-directories - repeated
+    top-level sections that merge, nested default classes + childclass, meshdir with an .obj collision mesh and a binary .stl visual mesh."""
+    import logging
+
+    with caplog.at_level(logging.WARNING, logger="minppo_amd.mjcf"):
+        s = mjcf.load_mjcf(str(EXPORT / "robot.xml"))
+    names = [b.name for b in s.bodies]
+    assert len(names) == 28 and names[0] == "pelvis" and {"l_toe", "r_toe", "l_hand", "r_hand", "head", "torso"} <= set(names)
+    by = {b.name: b for b in s.bodies}
+    assert by["l_hip_yaw"].parent == "pelvis" and by["l_shoulder"].parent == "torso" and by["r_toe"].parent == "r_foot"  # includes spliced in place
+    # nested defaults: leg -> knee / ankle; childclass="leg" on the hip reaches the toe's joint; class on an element beats childclass
+    knee, ankle, toe, waist = by["l_shin"].joints[0], by["l_ankle"].joints[0], by["l_toe"].joints[0], by["torso"].joints[0]
+    assert (knee.damping, knee.armature, knee.range) == (1.2, 0.03, (0.0, 2.2))
+    assert (ankle.damping, ankle.armature, ankle.range) == (0.3, 0.01, (-0.6, 0.6))
+    assert (toe.damping, toe.armature, toe.stiffness) == (0.05, 0.03, 2.0)
+    assert (waist.damping, waist.armature) == (2.0, 0.05)
+    assert by["l_forearm"].joints[0].damping == 0.2 and by["l_hand"].joints[0].range == (-0.7, 0.7)
+    # both <actuator> sections arrived, in file order, with the <default><position> attributes
+    assert [a.joint for a in s.actuators][:3] == ["l_hip_yaw", "l_hip_roll", "l_hip_pitch"] and len(s.actuators) == 20
+    assert s.actuators[0].ctrlrange == (-1.0, 1.0) and s.actuators[0].forcerange == (-80.0, 80.0) and s.actuators[-1].kp == 4.0
+    # colliders: two mesh feet (hull of foot.obj: the two interior points are gone), toes, hands, shins; the visual geoms collide with nothing
+    feet = [g for n in ("l_foot", "r_foot") for g in by[n].geoms]
+    assert len(feet) == 2 and all(g.type == mjcf.GEOM_MESH and len(g.vertices) == 12 for g in feet)
+    assert not by["pelvis"].geoms and not by["l_thigh"].geoms and len(by["l_shin"].geoms) == 1 and by["l_shin"].geoms[0].contype == 2
+    # dry joint friction: silently gone from the defaults, dropped with a warning from the two joints that carry it themselves
+    msgs = [r.getMessage() for r in caplog.records if "frictionloss" in r.getMessage()]
+    assert len(msgs) == 2 and any("l_shin" in m for m in msgs) and any("r_forearm" in m for m in msgs)
+    # fullinertia -> principal moments (descending) + a rotation
+    w = np.linalg.eigvalsh(np.array([[0.045, 0.0008, -0.0004], [0.0008, 0.038, 0.0011], [-0.0004, 0.0011, 0.052]]))[::-1]
+    np.testing.assert_allclose(by["pelvis"].inertia, w, rtol=1e-12)
+    cm = compile_model(s)
+    assert (cm.nq, cm.nv, cm.nu) == (34, 33, 20) and int(cm.t["npair"]) == 1  # the shins' pair; feet / toes / hands meet the ground only
+
+
+def test_include_errors_are_loud(tmp_path):
+    main = tmp_path / "m.xml"
+    main.write_text('<mujoco><include file="a.xml"/><worldbody><body name="b"><freejoint/><inertial pos="0 0 0" mass="1" diaginertia="1 1 1"/></body></worldbody></mujoco>')
+    with pytest.raises(ValueError, match="not found"):
+        mjcf.load_mjcf(str(main))
+    (tmp_path / "a.xml").write_text('<mujocoinclude><include file="b.xml"/></mujocoinclude>')
+    (tmp_path / "b.xml").write_text('<mujocoinclude><include file="a.xml"/></mujocoinclude>')
+    with pytest.raises(ValueError, match="more than once"):
+        mjcf.load_mjcf(str(main))
+    (tmp_path / "a.xml").write_text('<robot/>')
+    with pytest.raises(ValueError, match="mujocoinclude"):
+        mjcf.load_mjcf(str(main))
+    with pytest.raises(ValueError, match="needs the MJCF's directory"):
+        mjcf.parse_mjcf(main.read_text())
+    (tmp_path / "a.xml").write_text('<mujocoinclude><option timestep="0.004"/><compiler angle="radian"/></mujocoinclude>')
+    assert mjcf.load_mjcf(str(main)).timestep == 0.004  # a section brought in by an include counts like one written in place
