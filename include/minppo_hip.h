@@ -183,6 +183,10 @@ typedef struct mppo_loss_cfg { float clip_eps, vf_coef, ent_coef; } mppo_loss_cf
 /* *fused = 1 if mppo_minibatch_grad takes the fused row pass + single-launch weight gradients for this geometry
  * (H a multiple of 32 up to 256, A <= 32, 16-byte aligned observation rows), 0 if it runs the layer-wise kernels. */
 int32_t mppo_minibatch_path(const mppo_net_t* net, const mppo_batch_t* batch, int32_t* fused);
+/* *rows = minibatch rows per workgroup of the fused row pass for a minibatch of mb rows: 16, or 32 where the engine's minibatch loop
+ * (pre_gathered = 1) runs a float network's row pass on two 16-row tiles per workgroup because the 16-row tiling would need more
+ * workgroups than the chip has CUs (BASELINE configs[4]: 2560-row minibatches).  One row of loss partials is written per workgroup. */
+int32_t mppo_minibatch_rows_per_workgroup(const mppo_net_t* net, int32_t mb, int32_t pre_gathered, int32_t* rows);
 size_t mppo_grad_ws_bytes(const mppo_net_t* net, int32_t mb);
 int32_t mppo_minibatch_grad(const mppo_net_t* net, const float* params, const mppo_batch_t* batch, const int32_t* idx,
                             int32_t mb, const float* adv_stat, float inv_count, const mppo_loss_cfg_t* lc, float* grad,

@@ -104,6 +104,7 @@ SIGNATURES = {
     "mppo_gae": (c_i32, [c_i32, c_i32, c_f, c_f, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "mppo_grad_ws_bytes": (c_sz, [P(Net), c_i32]),
     "mppo_minibatch_path": (c_i32, [P(Net), P(Batch), P(c_i32)]),
+    "mppo_minibatch_rows_per_workgroup": (c_i32, [P(Net), c_i32, c_i32, P(c_i32)]),
     "mppo_minibatch_grad": (c_i32, [P(Net), c_vp, P(Batch), c_vp, c_i32, c_vp, c_f, P(LossCfg), c_vp, c_vp, c_vp, c_sz,
                                     c_vp]),
     "mppo_minibatch_rowpass": (c_i32, [P(Net), c_vp, P(Batch), c_vp, c_i32, c_vp, c_f, P(LossCfg), c_vp, c_sz, c_vp]),

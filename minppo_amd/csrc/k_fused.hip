@@ -188,6 +188,35 @@ struct GemmPipe {
     if (S < nst) stage_mfma<BF16>(arow, S, b0.x0, b0.x1, acc0, acc1);
     if (S + 1 < nst) stage_mfma<BF16>(arow, S + 1, b1.x0, b1.x1, acc0, acc1);
   }
+  // Two 16-row tiles per workgroup (RT = 2: rows j and j + 16 of a 32-row activation tile): every weight stage is fetched ONCE and
+  // multiplied into both tiles - twice the MFMAs per byte streamed, the same ring otherwise.
+  __device__ __forceinline__ void run2(const float* At, int AS, int K, const float* W, int H, int n0, int lane, f32x4 (&acc)[2][2]) {
+    const int j = lane & 15, kq = lane >> 4;
+    const float* arow = At + j * AS + 4 * kq;
+    const float* arow2 = arow + 16 * AS;
+    const int nst = K / 32, last = nst - 1;
+    BStage<NT> b2;
+    int S = 0;
+    for (; S + 2 < nst; S += 3) {
+      b2.load(W, wb, H, K, S + 2, n0, j, kq);
+      MPPO_SCHED_FENCE();
+      stage_mfma<false>(arow, S, b0.x0, b0.x1, acc[0][0], acc[0][1]);
+      stage_mfma<false>(arow2, S, b0.x0, b0.x1, acc[1][0], acc[1][1]);
+      MPPO_SCHED_FENCE();
+      b0.load(W, wb, H, K, S + 3 < last ? S + 3 : last, n0, j, kq);
+      MPPO_SCHED_FENCE();
+      stage_mfma<false>(arow, S + 1, b1.x0, b1.x1, acc[0][0], acc[0][1]);
+      stage_mfma<false>(arow2, S + 1, b1.x0, b1.x1, acc[1][0], acc[1][1]);
+      MPPO_SCHED_FENCE();
+      b1.load(W, wb, H, K, S + 4 < last ? S + 4 : last, n0, j, kq);
+      MPPO_SCHED_FENCE();
+      stage_mfma<false>(arow, S + 2, b2.x0, b2.x1, acc[0][0], acc[0][1]);
+      stage_mfma<false>(arow2, S + 2, b2.x0, b2.x1, acc[1][0], acc[1][1]);
+      MPPO_SCHED_FENCE();
+    }
+    if (S < nst) { stage_mfma<false>(arow, S, b0.x0, b0.x1, acc[0][0], acc[0][1]); stage_mfma<false>(arow2, S, b0.x0, b0.x1, acc[1][0], acc[1][1]); }
+    if (S + 1 < nst) { stage_mfma<false>(arow, S + 1, b1.x0, b1.x1, acc[0][0], acc[0][1]); stage_mfma<false>(arow2, S + 1, b1.x0, b1.x1, acc[1][0], acc[1][1]); }
+  }
 };
 
 // The same ring for a bf16 network with shadow copies: the B operand comes from the fragment-order bf16 copy of the weight
@@ -248,6 +277,7 @@ struct FragPipe {
     if (S < nst) frag_mfma(arow, S, b0, acc0, acc1);
     if (S + 1 < nst) frag_mfma(arow, S + 1, b1, acc0, acc1);
   }
+  __device__ __forceinline__ void run2(const float*, int, int, const float*, int, int, int, f32x4 (&)[2][2]) {}  // (32-row tiles are a float-network form)
 };
 template <bool FRAG, bool NT> struct PipeSel { typedef GemmPipe<NT> type; };
 template <bool NT> struct PipeSel<true, NT> { typedef FragPipe type; };
@@ -343,15 +373,25 @@ __device__ __forceinline__ void gather_rows_tile(const FusedArgs& a, int tile, i
 // W2T: the backward product reads the transposed shadow copy of W2 (GradBufs::w2t) through the forward-style pipe: 23.9 -> 21.9 us
 // PRE: engine minibatch loop - the x tile comes from the pre-gathered k-quad buffer (one trip to memory instead of index -> row), the
 // gathered rows are not written again, and grid rows 2 and 3 gather the next step's rows
-template <bool BF16, bool ROLLOUT, int OT, bool W2T = false, bool PRE = false>
+// RT: 16-row tiles per workgroup.  2 = a 32-row tile whose two halves share every weight stage (GemmPipe::run2): for minibatches whose
+// 16-row tiling has more workgroups than the chip has CUs (BASELINE configs[4]: 2 x 160 = 320 on 256 - two rounds, the second one a
+// quarter full); 2 x 80 workgroups of 32 rows are ONE round.  Float networks on the engine's pre-gathered path only.
+template <bool BF16, bool ROLLOUT, int OT, bool W2T = false, bool PRE = false, int RT = 1>
 __global__ void __launch_bounds__(512, ROLLOUT ? MPPO_ROLLOUT_WAVES : MPPO_TRAIN_WAVES) fused_mlp_kernel(FusedArgs a) {
+  static_assert(RT == 1 || (RT == 2 && PRE && !BF16 && !ROLLOUT), "32-row tiles: float training row pass on pre-gathered rows");
   constexpr int SD = 16 * OT;  // row stride of the per-row output-space tiles
+  constexpr int ROWS = FRT * RT;
   FT(0);
   FTW(56);
   // The role is decided from the launch geometry alone (grid rows 0, 1: the two networks; rows 2, 3: gather), not from a kernel
   // argument: a scalar load ahead of this branch would put one more (cold) trip to the argument segment in front of every row tile.
   // <ROLLOUT, PRE> together name the gather-ONLY launch (fused_gather_rows): every workgroup gathers.
   if (PRE && (ROLLOUT || blockIdx.y >= 2)) {  // uniform per workgroup
+    if (RT == 2) {  // grid row 2 / 3: the first / second 16-row tile of this 32-row block, both halves
+      gather_rows_tile<BF16>(a, 2 * (int)blockIdx.x + (int)blockIdx.y - 2, 0);
+      gather_rows_tile<BF16>(a, 2 * (int)blockIdx.x + (int)blockIdx.y - 2, 1);
+      return;
+    }
     gather_rows_tile<BF16>(a, (int)blockIdx.x, ROLLOUT ? (int)blockIdx.y : (int)blockIdx.y - 2);
     return;
   }
@@ -361,16 +401,16 @@ __global__ void __launch_bounds__(512, ROLLOUT ? MPPO_ROLLOUT_WAVES : MPPO_TRAIN
   const int net = blockIdx.y + (ROLLOUT ? a.net0 : 0);  // 0 actor, 1 critic
   const int KP = (O + 31) & ~31;  // first-layer K padded to whole 32-k stages (x tile zero-padded)
   const int XS = KP + 4, HS = H + 4;
-  const int R0 = FRT * (XS > HS ? XS : HS);
-  float* xt = sm;            // [16][XS]  then dZ2 tile [16][HS]
-  float* h1t = sm + R0;      // [16][HS]
-  float* h2t = h1t + FRT * HS;
-  float* s_do = h2t + FRT * HS;         // [16][SD]  d mean (cols < A, zero beyond) | critic: col 0 = d value
-  float* s_red = s_do + FRT * SD;       // [16][SD]  d log_std terms
-  float* s_l = s_red + FRT * SD;        // [16]      per-row loss term
-  float* s_hp = xt;                     // [H/32 waves][OT][64 lanes][4]  partial head tiles: over the x tile, dead between layer 1 and dZ2
+  const int R0 = ROWS * (XS > HS ? XS : HS);
+  float* xt = sm;            // [ROWS][XS]  then dZ2 tile [ROWS][HS]
+  float* h1t = sm + R0;      // [ROWS][HS]
+  float* h2t = h1t + ROWS * HS;
+  float* s_do = h2t + ROWS * HS;        // [ROWS][SD]  d mean (cols < A, zero beyond) | critic: col 0 = d value
+  float* s_red = s_do + ROWS * SD;      // [ROWS][SD]  d log_std terms
+  float* s_l = s_red + ROWS * SD;       // [ROWS]      per-row loss term
+  float* s_hp = xt;                     // [H/32 waves][RT][OT][64 lanes][4]  partial head tiles: over the x tile, dead between layer 1 and dZ2
   const int t = threadIdx.x, nthr = blockDim.x, lane = t & 63, wave = t >> 6;
-  const int row0 = blockIdx.x * FRT;
+  const int row0 = blockIdx.x * ROWS;
   const bool tanh_act = net == 0 && a.use_tanh;
   const float* W1 = a.params + (net ? a.L.c_w1 : a.L.a_w1);
   const float* B1 = a.params + (net ? a.L.c_b1 : a.L.a_b1);
@@ -385,15 +425,22 @@ __global__ void __launch_bounds__(512, ROLLOUT ? MPPO_ROLLOUT_WAVES : MPPO_TRAIN
   // PRE: this step's observation tile is a contiguous block of the pre-gathered buffer: it depends on nothing but the kernel arguments and
   // is the longest chain in front of the first MFMA (memory -> registers -> LDS -> barrier), so it is requested before anything else
   float4 xq0 = make_float4(0.f, 0.f, 0.f, 0.f), xq1 = xq0;
-  const int nxq = 4 * OP;  // float4 elements of the k-quad tile, element e = (quad e / OP, column e % OP); contiguous in memory
+  const int nxq = 4 * RT * OP;  // float4 elements of the k-quad tile, element e = (quad e / OP, column e % OP); contiguous in memory
   const float* xtile = PRE ? a.xpre + (size_t)(row0 >> 2) * OP * (BF16 ? 2 : 4) : nullptr;  // (bf16 network: 8-byte quads, see store_quad)
   auto load_xq = [&](int e) {
     if (BF16) { const float2 b = *reinterpret_cast<const float2*>(xtile + 2 * e); return bf16x4_unpack(b.x, b.y); }
     return *reinterpret_cast<const float4*>(xtile + 4 * e);
   };
+  // (32-row tiles: up to eight elements per thread, all requested here - a loop of load-then-store pays one memory latency per element)
+  constexpr int NXE = RT == 2 ? 6 : 1;
+  float4 xqe[NXE];
   if (PRE) {
     if (t < nxq) xq0 = load_xq(t);
     if (t + nthr < nxq) xq1 = load_xq(t + nthr);
+    if (RT == 2) {
+#pragma unroll
+      for (int k = 0; k < NXE; ++k) xqe[k] = load_xq(t + (2 + k) * nthr < nxq ? t + (2 + k) * nthr : nxq - 1);
+    }
   }
   // ---- everything that depends on nothing computed here is requested now and consumed phases later: the first two
   // weight stages of layer 1, the biases, and the per-row scalars of the loss (index -> action / log_prob / advantage /
@@ -461,13 +508,15 @@ __global__ void __launch_bounds__(512, ROLLOUT ? MPPO_ROLLOUT_WAVES : MPPO_TRAIN
   // masking here: every use below is guarded by the same row / column conditions.  (A select on the loaded value in this place makes
   // it the value's first use, and the s_waitcnt goes where the first use is: with the network branch inside the row loop that was one
   // wait per row and array, eight memory latencies in series in front of the first MFMA - read off the ISA.)
-  float pf0[OT][4], pf1[4], pf2[4];
+  float pf0[RT][OT][4], pf1[RT][4], pf2[RT][4];  // (per 16-row tile of the workgroup)
 #pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    pf1[r] = pf2[r] = 0.f;
+  for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
-    for (int ot = 0; ot < OT; ++ot) pf0[ot][r] = 0.f;
-  }
+    for (int r = 0; r < 4; ++r) {
+      pf1[rt][r] = pf2[rt][r] = 0.f;
+#pragma unroll
+      for (int ot = 0; ot < OT; ++ot) pf0[rt][ot][r] = 0.f;
+    }
   if (ROLLOUT) {
     // (the rollout launch - four waves per SIMD, two workgroups per CU - measures 2 us FASTER with the masking select here, i.e. with the
     // wait for its noise in the prologue: 24.5 against 26.6 us; it keeps the masked form)
@@ -478,28 +527,31 @@ __global__ void __launch_bounds__(512, ROLLOUT ? MPPO_ROLLOUT_WAVES : MPPO_TRAIN
         for (int ot = 0; ot < OT; ++ot) {
           const int o = cj + 16 * ot;
           const float v = a.noise[(size_t)prow[r] * A + (o < A ? o : A - 1)];
-          pf0[ot][r] = (pon[r] && o < A) ? v : 0.f;
+          pf0[0][ot][r] = (pon[r] && o < A) ? v : 0.f;
         }
     }
   } else if (PRE) {
     // pre-gathered by the previous launch (gather_rows_tile): the lane's four rows of a column are ONE float4 of the scalar quads behind
     // the observation quads - contiguous per row tile, no index, no dependent trip (rows past the minibatch read as 0; every use is masked)
     const int SC = A + 4;
-    const float* sq = a.xpre + xquad_obs_floats(OP, a.mb) + ((size_t)((row0 >> 2) + rq) * SC) * 4;
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) {
+    const float* sq = a.xpre + xquad_obs_floats(OP, a.mb) + ((size_t)((row0 >> 2) + 4 * rt + rq) * SC) * 4;
     if (net == 0) {
 #pragma unroll
       for (int ot = 0; ot < OT; ++ot) {
         const int o = cj + 16 * ot;
         const float4 q = *reinterpret_cast<const float4*>(sq + 4 * (o < A ? o : A - 1));
-        pf0[ot][0] = q.x; pf0[ot][1] = q.y; pf0[ot][2] = q.z; pf0[ot][3] = q.w;
+        pf0[rt][ot][0] = q.x; pf0[rt][ot][1] = q.y; pf0[rt][ot][2] = q.z; pf0[rt][ot][3] = q.w;
       }
       const float4 q1 = *reinterpret_cast<const float4*>(sq + 4 * A), q2 = *reinterpret_cast<const float4*>(sq + 4 * (A + 1));
-      pf1[0] = q1.x; pf1[1] = q1.y; pf1[2] = q1.z; pf1[3] = q1.w;
-      pf2[0] = q2.x; pf2[1] = q2.y; pf2[2] = q2.z; pf2[3] = q2.w;
+      pf1[rt][0] = q1.x; pf1[rt][1] = q1.y; pf1[rt][2] = q1.z; pf1[rt][3] = q1.w;
+      pf2[rt][0] = q2.x; pf2[rt][1] = q2.y; pf2[rt][2] = q2.z; pf2[rt][3] = q2.w;
     } else {
       const float4 q0 = *reinterpret_cast<const float4*>(sq + 4 * (A + 2)), q1 = *reinterpret_cast<const float4*>(sq + 4 * (A + 3));
-      pf0[0][0] = q0.x; pf0[0][1] = q0.y; pf0[0][2] = q0.z; pf0[0][3] = q0.w;
-      pf1[0] = q1.x; pf1[1] = q1.y; pf1[2] = q1.z; pf1[3] = q1.w;
+      pf0[rt][0][0] = q0.x; pf0[rt][0][1] = q0.y; pf0[rt][0][2] = q0.z; pf0[rt][0][3] = q0.w;
+      pf1[rt][0] = q1.x; pf1[rt][1] = q1.y; pf1[rt][2] = q1.z; pf1[rt][3] = q1.w;
+    }
     }
   } else if (net == 0) {
 #pragma unroll
@@ -507,16 +559,16 @@ __global__ void __launch_bounds__(512, ROLLOUT ? MPPO_ROLLOUT_WAVES : MPPO_TRAIN
 #pragma unroll
       for (int ot = 0; ot < OT; ++ot) {
         const int o = cj + 16 * ot;
-        pf0[ot][r] = a.b.action[prow[r] * a.b.act_ld + (o < A ? o : A - 1)];
+        pf0[0][ot][r] = a.b.action[prow[r] * a.b.act_ld + (o < A ? o : A - 1)];
       }
-      pf1[r] = a.b.log_prob[prow[r]];
-      pf2[r] = a.b.adv[prow[r]];
+      pf1[0][r] = a.b.log_prob[prow[r]];
+      pf2[0][r] = a.b.adv[prow[r]];
     }
   } else {
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      pf0[0][r] = a.b.value[prow[r]];
-      pf1[r] = a.b.target[prow[r]];
+      pf0[0][0][r] = a.b.value[prow[r]];
+      pf1[0][r] = a.b.target[prow[r]];
     }
   }
 
@@ -526,14 +578,21 @@ __global__ void __launch_bounds__(512, ROLLOUT ? MPPO_ROLLOUT_WAVES : MPPO_TRAIN
   if (PRE) {
     // a k-quad element is one column of four consecutive rows: four LDS words a row stride apart (consecutive lanes hold consecutive columns)
     auto put = [&](int e, const float4& q) {
-      const int qd = (int)(e >= OP) + (int)(e >= 2 * OP) + (int)(e >= 3 * OP), c = e - qd * OP;  // e / OP for e < 4 OP, without the division
+      int qd = (int)(e >= OP) + (int)(e >= 2 * OP) + (int)(e >= 3 * OP);  // e / OP for e < 4 RT OP, without the division
+      if (RT == 2) qd += (int)(e >= 4 * OP) + (int)(e >= 5 * OP) + (int)(e >= 6 * OP) + (int)(e >= 7 * OP);
+      const int c = e - qd * OP;
       float* d = xt + (4 * qd) * XS + c;
       d[0] = q.x; d[XS] = q.y; d[2 * XS] = q.z; d[3 * XS] = q.w;
     };
     if (e0 < nxq) put(e0, xq0);
     if (e1 < nxq) put(e1, xq1);
-    for (int e = t + 2 * nthr; e < nxq; e += nthr) put(e, load_xq(e));
-    for (int r = t >> 5; r < FRT; r += nthr >> 5)  // K padding of the first layer: fewer than 32 columns per row, one lane each
+    if (RT == 2) {
+#pragma unroll
+      for (int k = 0; k < NXE; ++k)
+        if (t + (2 + k) * nthr < nxq) put(t + (2 + k) * nthr, xqe[k]);
+    }
+    for (int e = t + (RT == 2 ? 2 + NXE : 2) * nthr; e < nxq; e += nthr) put(e, load_xq(e));
+    for (int r = t >> 5; r < ROWS; r += nthr >> 5)  // K padding of the first layer: fewer than 32 columns per row, one lane each
       if (OP + (t & 31) < KP) xt[r * XS + OP + (t & 31)] = 0.f;
   } else {
   if (e0 < nx) *reinterpret_cast<float4*>(xt + xr0 * XS + xc0) = xq0;
@@ -557,17 +616,20 @@ __global__ void __launch_bounds__(512, ROLLOUT ? MPPO_ROLLOUT_WAVES : MPPO_TRAIN
   const float* W2back = FRAG ? reinterpret_cast<const float*>(a.frag[net] + (size_t)KP * H + (size_t)H * H) : W2T ? a.w2t[net] : W2;
   for (int layer = 0; layer < 2; ++layer) {
     f32x4 acc0, acc1;
-    for (int r = 0; r < 4; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
+    f32x4 accr[2][2];  // (RT = 2: [row tile][column tile])
+    for (int r = 0; r < 4; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; accr[0][0][r] = accr[0][1][r] = accr[1][0][r] = accr[1][1][r] = 0.f; }
 #ifdef MPPO_FUSED_TIMERS
     if (!ROLLOUT && blockIdx.x == 40 && blockIdx.y == 0 && lane == 0) g_fused_t[24 + 16 * layer + wave] = __builtin_amdgcn_s_memtime();
 #endif
     if (layer == 0) {
-      if (!(a.skip & 1)) pipe1.template run<BF16>(xt, XS, KP, F1, H, n0, lane, acc0, acc1);
+      if (RT == 2) pipe1.run2(xt, XS, KP, F1, H, n0, lane, accr);
+      else if (!(a.skip & 1)) pipe1.template run<BF16>(xt, XS, KP, F1, H, n0, lane, acc0, acc1);
       if (!ROLLOUT) pipe2.prefetch(H, H, F2, H, n0, lane);  // arrives during the epilogue + barrier below
     } else {
       // rollout: 4 waves per SIMD hide the fill latency, and the 128-VGPR budget has no room for a cross-phase prefetch
       if (ROLLOUT) pipe2.prefetch(H, H, F2, H, n0, lane);
-      if (!(a.skip & 2)) pipe2.template run<BF16>(h1t, HS, H, F2, H, n0, lane, acc0, acc1);
+      if (RT == 2) pipe2.run2(h1t, HS, H, F2, H, n0, lane, accr);
+      else if (!(a.skip & 2)) pipe2.template run<BF16>(h1t, HS, H, F2, H, n0, lane, acc0, acc1);
       if (!ROLLOUT) pipe5.prefetch(H, H, W2back, H, n0, lane);  // W2^T fragments of the backward product: hidden under heads / loss / dZ2
     }
     FT(4 + 2 * layer);
@@ -590,11 +652,13 @@ __global__ void __launch_bounds__(512, ROLLOUT ? MPPO_ROLLOUT_WAVES : MPPO_TRAIN
     float* hg = layer == 0 ? a.h1[net] : a.h2[net];
     const int c0 = n0 + 2 * cj;  // the wave's two interleaved column tiles: c0, c0 + 1
     const float2 bz = layer == 0 ? bz1 : bz2;
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) {
     float q0[4], q1[4];  // the lane's 4 rows x 2 columns: one k-quad of column c0 and one of column c0 + 1
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const int rr = 4 * rq + r;
-      float v0 = acc0[r] + bz.x, v1 = acc1[r] + bz.y;
+      const int rr = 16 * rt + 4 * rq + r;
+      float v0 = (RT == 2 ? accr[rt][0][r] : acc0[r]) + bz.x, v1 = (RT == 2 ? accr[rt][1][r] : acc1[r]) + bz.y;
       if (tanh_act) { v0 = fused_tanh(v0); v1 = fused_tanh(v1); } else { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); }
       *reinterpret_cast<float2*>(ht + rr * HS + c0) = make_float2(v0, v1);
       const bool on = row0 + rr < a.mb;  // rows past the minibatch are zero in the quad buffers (they are contracted over)
@@ -602,8 +666,9 @@ __global__ void __launch_bounds__(512, ROLLOUT ? MPPO_ROLLOUT_WAVES : MPPO_TRAIN
     }
     if (!ROLLOUT && !(a.skip & 32)) {  // two adjacent columns: 32 bytes per lane (bf16: 16)
       size_t qi, qi2;
-      pair_index<BF16>(row0 + 4 * rq, c0, H, qi, qi2);
+      pair_index<BF16>(row0 + 16 * rt + 4 * rq, c0, H, qi, qi2);
       store_quad2<BF16>(hg, qi, qi2, q0, q1);
+    }
     }
     __syncthreads();
     FT(5 + 2 * layer);
@@ -612,13 +677,14 @@ __global__ void __launch_bounds__(512, ROLLOUT ? MPPO_ROLLOUT_WAVES : MPPO_TRAIN
   FT(8);
   // ---- P3: output layer on the matrix cores: OT 16x16 tiles (rows x outputs), K = H split over the waves ----
   // wave w multiplies h2[:, 32w .. 32w+32) by W3[32w .. 32w+32, :]; the H/32 partial tiles are summed through LDS.
-  {
+#pragma unroll
+  for (int rt = 0; rt < RT; ++rt) {
     f32x4 hp[OT];
 #pragma unroll
     for (int ot = 0; ot < OT; ++ot)
       for (int r = 0; r < 4; ++r) hp[ot][r] = 0.f;
     if (!(a.skip & 4)) {
-      const float* arow = h2t + cj * HS + 4 * rq + 32 * wave;
+      const float* arow = h2t + (cj + 16 * rt) * HS + 4 * rq + 32 * wave;
 #pragma unroll
       for (int g = 0; g < 2; ++g) {
         const float4 av = *reinterpret_cast<const float4*>(arow + 16 * g);
@@ -631,11 +697,12 @@ __global__ void __launch_bounds__(512, ROLLOUT ? MPPO_ROLLOUT_WAVES : MPPO_TRAIN
     }
 #pragma unroll
     for (int ot = 0; ot < OT; ++ot)
-      *reinterpret_cast<float4*>(s_hp + ((wave * OT + ot) * 64 + lane) * 4) = make_float4(hp[ot][0], hp[ot][1], hp[ot][2], hp[ot][3]);
+      *reinterpret_cast<float4*>(s_hp + (((wave * RT + rt) * OT + ot) * 64 + lane) * 4) = make_float4(hp[ot][0], hp[ot][1], hp[ot][2], hp[ot][3]);
   }
   __syncthreads();
   FT(9);
-  {
+#pragma unroll
+  for (int rt = 0; rt < RT; ++rt) {
     // every wave adds the partial tiles (same order: identical values everywhere); lane (cj = lane&15, q = lane>>4) holds
     // out[ot][r] = output cj + 16*ot of row 4q + r.  A DPP row of 16 lanes therefore spans all outputs of a row: row
     // reductions are group16 sums (of the per-lane sum over ot), one per accumulator register.  Only wave 0 stores.
@@ -645,7 +712,7 @@ __global__ void __launch_bounds__(512, ROLLOUT ? MPPO_ROLLOUT_WAVES : MPPO_TRAIN
     for (int ot = 0; ot < OT; ++ot) {
       out[ot][0] = out[ot][1] = out[ot][2] = out[ot][3] = 0.f;
       for (int w = 0; w < nw; ++w) {
-        const float4 q = *reinterpret_cast<const float4*>(s_hp + ((w * OT + ot) * 64 + lane) * 4);
+        const float4 q = *reinterpret_cast<const float4*>(s_hp + (((w * RT + rt) * OT + ot) * 64 + lane) * 4);
         out[ot][0] += q.x; out[ot][1] += q.y; out[ot][2] += q.z; out[ot][3] += q.w;
       }
     }
@@ -667,7 +734,7 @@ __global__ void __launch_bounds__(512, ROLLOUT ? MPPO_ROLLOUT_WAVES : MPPO_TRAIN
             const int o = cj + 16 * ot;
             if (on && o < A) {
               const float mean = out[ot][r] + b3v[ot];
-              const float act = mean + __expf(ls[ot]) * pf0[ot][r];
+              const float act = mean + __expf(ls[ot]) * pf0[0][ot][r];
               const float z = (act - mean) * __expf(-ls[ot]);
               z2 += z * z;
               if (st) {
@@ -695,21 +762,21 @@ __global__ void __launch_bounds__(512, ROLLOUT ? MPPO_ROLLOUT_WAVES : MPPO_TRAIN
       float dmq[OT][4];
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int rr = 4 * rq + r, i = row0 + rr;
+        const int rr = 16 * rt + 4 * rq + r, i = row0 + rr;
         const bool on = i < a.mb;
         float z[OT], zz = 0.f;
 #pragma unroll
         for (int ot = 0; ot < OT; ++ot) {
           z[ot] = 0.f;
-          if (on && cj + 16 * ot < A) z[ot] = (pf0[ot][r] - (out[ot][r] + b3v[ot])) * __expf(-ls[ot]);
+          if (on && cj + 16 * ot < A) z[ot] = (pf0[rt][ot][r] - (out[ot][r] + b3v[ot])) * __expf(-ls[ot]);
           zz += z[ot] * z[ot];
         }
         const float ss = group16_sum(zz);
         float la = 0.f, dlogp = 0.f;
         if (on) {
           const float logp = -0.5f * ss - sum_ls - 0.5f * (float)A * kLog2PiF;
-          const float ratio = __expf(logp - pf1[r]);
-          const float g = (pf2[r] - adv_mean) * adv_rstd;
+          const float ratio = __expf(logp - pf1[rt][r]);
+          const float g = (pf2[rt][r] - adv_mean) * adv_rstd;
           const float la1 = ratio * g;
           const float la2 = fminf(fmaxf(ratio, 1.f - a.lc.clip_eps), 1.f + a.lc.clip_eps) * g;
           la = -fminf(la1, la2) * a.inv_count;
@@ -732,7 +799,7 @@ __global__ void __launch_bounds__(512, ROLLOUT ? MPPO_ROLLOUT_WAVES : MPPO_TRAIN
 #pragma unroll
         for (int ot = 0; ot < OT; ++ot) {
           const int o = cj + 16 * ot;
-          if (o < AP) store_quad<BF16>(a.dout, quad_index(row0 + 4 * rq, o, a.DP), dmq[ot]);
+          if (o < AP) store_quad<BF16>(a.dout, quad_index(row0 + 16 * rt + 4 * rq, o, a.DP), dmq[ot]);
         }
       }
     } else {
@@ -740,12 +807,12 @@ __global__ void __launch_bounds__(512, ROLLOUT ? MPPO_ROLLOUT_WAVES : MPPO_TRAIN
       float dvq[4];
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int rr = 4 * rq + r, i = row0 + rr;
+        const int rr = 16 * rt + 4 * rq + r, i = row0 + rr;
         const bool on = i < a.mb;
         const float vnew = group16_sum(cj == 0 ? out[0][r] : 0.f) + b3c;
         float lv = 0.f, dv = 0.f;
         if (on) {
-          const float ov = pf0[0][r], tg = pf1[r];
+          const float ov = pf0[rt][0][r], tg = pf1[rt][r];
           const float vc = ov + fminf(fmaxf(vnew - ov, -a.lc.clip_eps), a.lc.clip_eps);
           const float vl1 = (vnew - tg) * (vnew - tg), vl2 = (vc - tg) * (vc - tg);
           lv = 0.5f * fmaxf(vl1, vl2) * a.inv_count;
@@ -762,7 +829,7 @@ __global__ void __launch_bounds__(512, ROLLOUT ? MPPO_ROLLOUT_WAVES : MPPO_TRAIN
       // d value in column AP of dOut (k-quad layout), columns AP+1 .. AP+3 zero
       if (st && cj < 4) {
         const float zq[4] = {cj == 0 ? dvq[0] : 0.f, cj == 0 ? dvq[1] : 0.f, cj == 0 ? dvq[2] : 0.f, cj == 0 ? dvq[3] : 0.f};
-        store_quad<BF16>(a.dout, quad_index(row0 + 4 * rq, AP + cj, a.DP), zq);
+        store_quad<BF16>(a.dout, quad_index(row0 + 16 * rt + 4 * rq, AP + cj, a.DP), zq);
       }
     }
   }
@@ -772,16 +839,17 @@ __global__ void __launch_bounds__(512, ROLLOUT ? MPPO_ROLLOUT_WAVES : MPPO_TRAIN
   {
     float* prow_out = a.partial + (size_t)blockIdx.x * (4 + AP);
     if (net == 0) {
-      if (t == 0) { float s = 0.f; for (int r = 0; r < FRT; ++r) s += s_l[r]; prow_out[0] = s; }
-      if (t >= 4 && t < 4 + AP) { float s = 0.f; if (t - 4 < A) for (int r = 0; r < FRT; ++r) s += s_red[r * SD + (t - 4)]; prow_out[t] = s; }
+      if (t == 0) { float s = 0.f; for (int r = 0; r < ROWS; ++r) s += s_l[r]; prow_out[0] = s; }
+      if (t >= 4 && t < 4 + AP) { float s = 0.f; if (t - 4 < A) for (int r = 0; r < ROWS; ++r) s += s_red[r * SD + (t - 4)]; prow_out[t] = s; }
     } else if (t == 0) {
-      float s = 0.f; for (int r = 0; r < FRT; ++r) s += s_l[r]; prow_out[1] = s;
+      float s = 0.f; for (int r = 0; r < ROWS; ++r) s += s_l[r]; prow_out[1] = s;
     }
   }
   FT(11);
   // ---- P4: dZ2 = (dOut . W3^T) * act'(h2) on the matrix cores (K = outputs padded to 16*OT) -> LDS (over the dead x tile) + global ----
   float* dzt = xt;
-  {
+#pragma unroll
+  for (int rt = 0; rt < RT; ++rt) {
     f32x4 d0, d1;
     for (int r = 0; r < 4; ++r) { d0[r] = 0.f; d1[r] = 0.f; }
     const int c0 = n0 + 2 * cj;
@@ -789,14 +857,14 @@ __global__ void __launch_bounds__(512, ROLLOUT ? MPPO_ROLLOUT_WAVES : MPPO_TRAIN
 #pragma unroll
       for (int m = 0; m < 4 * OT; ++m) {
         const int ai = 4 * m + rq;  // output index contracted over
-        const float av = s_do[cj * SD + ai];
+        const float av = s_do[(cj + 16 * rt) * SD + ai];
         mfma_f32_16x16x4(av, w3q[m][0], d0); mfma_f32_16x16x4(av, w3q[m][1], d1);
       }
     }
     float q0[4], q1[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const int rr = 4 * rq + r;
+      const int rr = 16 * rt + 4 * rq + r;
       const float2 hv = *reinterpret_cast<const float2*>(h2t + rr * HS + c0);
       const float z0 = tanh_act ? d0[r] * (1.f - hv.x * hv.x) : (hv.x > 0.f ? d0[r] : 0.f);
       const float z1 = tanh_act ? d1[r] * (1.f - hv.y * hv.y) : (hv.y > 0.f ? d1[r] : 0.f);
@@ -806,7 +874,7 @@ __global__ void __launch_bounds__(512, ROLLOUT ? MPPO_ROLLOUT_WAVES : MPPO_TRAIN
     }
     if (!(a.skip & 32)) {
       size_t qi, qi2;
-      pair_index<BF16>(row0 + 4 * rq, c0, H, qi, qi2);
+      pair_index<BF16>(row0 + 16 * rt + 4 * rq, c0, H, qi, qi2);
       store_quad2<BF16>(a.dz2[net], qi, qi2, q0, q1);
     }
   }
@@ -815,24 +883,30 @@ __global__ void __launch_bounds__(512, ROLLOUT ? MPPO_ROLLOUT_WAVES : MPPO_TRAIN
   // ---- P5: dZ1 = (dZ2 . W2^T) * act'(h1) ----
   {
     f32x4 acc0, acc1;
-    for (int r = 0; r < 4; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
-    if (!(a.skip & 16)) pipe5.template run<BF16>(dzt, HS, H, W2back, H, n0, lane, acc0, acc1);
+    f32x4 accr[2][2];
+    for (int r = 0; r < 4; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; accr[0][0][r] = accr[0][1][r] = accr[1][0][r] = accr[1][1][r] = 0.f; }
+    if (RT == 2) pipe5.run2(dzt, HS, H, W2back, H, n0, lane, accr);
+    else if (!(a.skip & 16)) pipe5.template run<BF16>(dzt, HS, H, W2back, H, n0, lane, acc0, acc1);
     FT(13);
     const int c0 = n0 + 2 * cj;
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) {
     float q0[4], q1[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const int rr = 4 * rq + r;
+      const int rr = 16 * rt + 4 * rq + r;
       const bool on = row0 + rr < a.mb;
       const float2 gq = *reinterpret_cast<const float2*>(h1t + rr * HS + c0);
-      const float d0 = tanh_act ? acc0[r] * (1.f - gq.x * gq.x) : (gq.x > 0.f ? acc0[r] : 0.f);
-      const float d1 = tanh_act ? acc1[r] * (1.f - gq.y * gq.y) : (gq.y > 0.f ? acc1[r] : 0.f);
+      const float a0 = RT == 2 ? accr[rt][0][r] : acc0[r], a1 = RT == 2 ? accr[rt][1][r] : acc1[r];
+      const float d0 = tanh_act ? a0 * (1.f - gq.x * gq.x) : (gq.x > 0.f ? a0 : 0.f);
+      const float d1 = tanh_act ? a1 * (1.f - gq.y * gq.y) : (gq.y > 0.f ? a1 : 0.f);
       q0[r] = on ? d0 : 0.f; q1[r] = on ? d1 : 0.f;
     }
     {
       size_t qi, qi2;
-      pair_index<BF16>(row0 + 4 * rq, c0, H, qi, qi2);
+      pair_index<BF16>(row0 + 16 * rt + 4 * rq, c0, H, qi, qi2);
       store_quad2<BF16>(a.dz1[net], qi, qi2, q0, q1);
+    }
     }
   }
   FT(14);
@@ -849,11 +923,29 @@ namespace mppo {
 
 #include "fused_bf16.h"  // bf16_rowpass_kernel: the training row pass of a bf16 network (BASELINE configs[3])
 
-size_t fused_smem_bytes(int O, int A, int H) {
+size_t fused_smem_bytes(int O, int A, int H, int RT) {
   const int KP = (O + 31) & ~31, XS = KP + 4, HS = H + 4, OT = A > 16 ? 2 : 1;
-  const size_t R0 = (size_t)FRT * (XS > HS ? XS : HS);
+  const size_t rows = (size_t)FRT * RT, R0 = rows * (XS > HS ? XS : HS);
   // x tile (later: partial head tiles, then the dZ2 tile) | h1 | h2 | dOut, d log_std terms | per-row loss
-  return sizeof(float) * (R0 + 2 * (size_t)FRT * HS + 2 * FRT * 16 * OT + FRT);
+  return sizeof(float) * (R0 + 2 * rows * HS + 2 * rows * 16 * OT + rows);
+}
+size_t fused_smem_bytes(int O, int A, int H) { return fused_smem_bytes(O, A, H, 1); }
+
+// Rows per workgroup of the training row pass for this launch: 32 (two 16-row tiles sharing every weight stage) when the 16-row tiling
+// would need more workgroups than the chip has CUs - a second, mostly empty round - and the 32-row one fits in one; 16 otherwise.
+// Float networks on the engine's pre-gathered path, whole 32-row tiles (the quad buffers are sized in 16-row tiles), H = 256.
+#ifdef MPPO_EMU
+constexpr int kFusedCUs = 4;  // (the emulator's parity tests reach the 32-row form with 64-row minibatches of small networks)
+constexpr bool kFusedRt2AnyH = true;
+#else
+constexpr int kFusedCUs = 256;  // MI355X; one 512-thread workgroup per CU at H = 256
+constexpr bool kFusedRt2AnyH = false;
+#endif
+int fused_rows_per_workgroup(const mppo_net_t& net, int mb, bool pre) {
+  const int t16 = cdiv(mb, FRT);
+  if (!pre || net.bf16 || (net.H != 256 && !kFusedRt2AnyH) || (t16 & 1) || 2 * t16 <= kFusedCUs) return FRT;
+  if (fused_smem_bytes(net.O, net.A, net.H, 2) > 160 * 1024) return FRT;
+  return 2 * FRT;
 }
 
 bool fused_supported(const mppo_net_t& net, const mppo_batch_t& b) {
@@ -882,6 +974,8 @@ static int32_t fused_set_smem(size_t smem) {
   MPPO_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(fused_mlp_kernel<B, false, T, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem))
   MPPO_FUSED_ATTR(false, 1); MPPO_FUSED_ATTR(true, 1); MPPO_FUSED_ATTR(false, 2); MPPO_FUSED_ATTR(true, 2);
 #undef MPPO_FUSED_ATTR
+  MPPO_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(fused_mlp_kernel<false, false, 1, true, true, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  MPPO_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(fused_mlp_kernel<false, false, 2, true, true, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   MPPO_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(fused_mlp_kernel<true, true, 1, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
   MPPO_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(fused_mlp_kernel<true, true, 2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
   return MPPO_OK;
@@ -911,6 +1005,15 @@ int32_t fused_forward_backward(const mppo_net_t& net, const float* params, const
   }
   MPPO_REQUIRE(!pre || (w2t && idx), "fused_forward_backward: pre-gathered rows need the shadow copies and a permutation");
   if (pre) { a.xpre = pre->cur; a.xnext = pre->next; a.idx_next = pre->idx_next; }
+  if (fused_rows_per_workgroup(net, mb, pre != nullptr) == 2 * FRT) {  // 32-row tiles: one round of workgroups instead of two
+    const size_t smem2 = fused_smem_bytes(net.O, net.A, net.H, 2);
+    if (attr_for < smem) { MPPO_TRY(fused_set_smem(smem)); attr_for = smem; }  // (sets the 32-row instantiations' limit too)
+    const dim3 grid2(cdiv(mb, 2 * FRT), pre->idx_next ? 4 : 2), block2(2 * net.H);
+    if (net.A > 16) hipLaunchKernelGGL((fused_mlp_kernel<false, false, 2, true, true, 2>), grid2, block2, smem2, stream, a);
+    else hipLaunchKernelGGL((fused_mlp_kernel<false, false, 1, true, true, 2>), grid2, block2, smem2, stream, a);
+    MPPO_CHECK_LAUNCH("fused_mlp_kernel<32 rows>");
+    return MPPO_OK;
+  }
   const dim3 grid(cdiv(mb, FRT), pre && pre->idx_next ? 4 : 2), block(2 * net.H);
   if (pre && g.frag && bf16_rowpass_supported(net)) {  // the engine's minibatch loop of a bf16 network: the kernel designed for it (fused_bf16.h)
     const size_t sb = bf16_rowpass_smem_bytes(net.O, net.A, net.H);

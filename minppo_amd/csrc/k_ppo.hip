@@ -627,7 +627,7 @@ int32_t minibatch_rowpass(const mppo_net_t& net, const float* params, const mppo
   if (fused_out) *fused_out = fused;
   if (fused) {
     MPPO_TRY(fused_forward_backward(net, params, batch, idx, mb, adv_stat, inv_count, lc, gbuf, stream, pre));
-    *nblk_out = cdiv(mb, 16);
+    *nblk_out = cdiv(mb, fused_rows_per_workgroup(net, mb, pre != nullptr));  // one row of loss partials per row-pass workgroup
     return MPPO_OK;
   }
   MPPO_TRY(mlp_hidden_forward(net, params, mb, batch.obs, batch.obs_ld, idx, gbuf.f, gbuf.xmb, stream));
@@ -853,6 +853,12 @@ extern "C" int32_t mppo_gae(int32_t T, int32_t N, float gamma, float lam, const 
                             const float* last_val, float* adv, float* target, void* stream) {
   MPPO_REQUIRE(T >= 1 && N >= 1 && reward && value && done && last_val && adv && target, "mppo_gae: bad argument");
   return gae_launch(T, N, gamma, lam, reward, value, done, last_val, adv, target, static_cast<hipStream_t>(stream));
+}
+
+extern "C" int32_t mppo_minibatch_rows_per_workgroup(const mppo_net_t* net, int32_t mb, int32_t pre_gathered, int32_t* rows) {
+  MPPO_REQUIRE(net && rows && mb >= 1, "mppo_minibatch_rows_per_workgroup: null argument or mb < 1");
+  *rows = mppo::fused_rows_per_workgroup(*net, mb, pre_gathered != 0);
+  return MPPO_OK;
 }
 
 extern "C" int32_t mppo_minibatch_path(const mppo_net_t* net, const mppo_batch_t* batch, int32_t* fused) {

@@ -204,6 +204,7 @@ int32_t gae_launch(int T, int N, float gamma, float lam, const float* reward, co
                    float* target, hipStream_t stream);
 // k_fused.hip: row-local forward + backward of one minibatch in a single launch (falls back to the layer-wise path when unsupported)
 bool fused_supported(const mppo_net_t& net, const mppo_batch_t& b);
+int fused_rows_per_workgroup(const mppo_net_t& net, int mb, bool pre);  // 16, or 32 where that turns two rounds of workgroups into one (k_fused.hip)
 bool fused_rollout_supported(const mppo_net_t& net, const float* obs, int obs_ld);
 int32_t fused_policy_forward(const mppo_net_t& net, const float* params, int n, const float* obs, int obs_ld, const float* noise, float* action, float* log_prob,
                              float* value, float* mean_out, int AP, hipStream_t stream, const unsigned short* frag = nullptr, size_t frag_net_stride = 0);

@@ -92,7 +92,8 @@ def test_twin_follows_the_oracle_on_the_other_collider_kinds():
 
     here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
     for name, steps, amp in (("synth_stompy_pro_sc", 8, 0.6), ("synth_tumblers", 20, 0.0), (os.path.join(here, "hand_leg.xml"), 25, 0.3),
-                             (os.path.join(here, "mesh_foot.xml"), 40, 0.3)):
+                             (os.path.join(here, "mesh_foot.xml"), 40, 0.3),
+                             (os.path.join(here, "export_biped", "robot.xml"), 12, 0.3)):  # 28 bodies, 33 dofs, export-style multi-file MJCF
         cm = load_model(name)
         tw = Twin(cm)
         env = EnvOracle(cm.t, RewardCfg())
@@ -115,5 +116,5 @@ def test_twin_follows_the_oracle_on_the_other_collider_kinds():
             assert (done.astype(bool) == es["done"]).all(), (name, t)
             np.testing.assert_allclose(rew, es["reward"], atol=2e-2, err_msg=f"{name} step {t}")
             worst = max(worst, float(np.abs(tw.state[:, :cm.nq] - es["pipeline_state"].qpos).max()))
-        assert worst < 2e-3, (name, worst)
+        assert worst < (1.2e-2 if "export_biped" in name else 2e-3), (name, worst)  # (the biped's light end bodies: tests/test_kernels_physics.py)
         tw.close()

@@ -25,7 +25,7 @@ def _small(be):
     return ["training.num_envs=256", "training.num_minibatches=8", "training.update_epochs=2", "training.total_timesteps=100000000"]
 
 
-@pytest.mark.parametrize("robot", ["stompy_pro", "stompy_full", "stompy_pro_no_c_vals", "stompy_pro_1_layer", "stompy_pro_3_layers", "stompy_pro_ragged"])
+@pytest.mark.parametrize("robot", ["stompy_pro", "stompy_full", "stompy_pro_no_c_vals", "stompy_pro_1_layer", "stompy_pro_3_layers", "stompy_pro_ragged", "row_tiles_32"])
 def test_update_matches_oracle_stage_by_stage(be, robot):
     """Both BASELINE robots: configs[1] (synth_stompy_pro, O = 225, A = 10) and configs[4] (synth_stompy_full, O = 415, A = 20);
     the short observation of `environment.include_c_vals=false` (qpos, qvel, qfrc_actuator: O = 49; reference env.py:254-259);
@@ -35,8 +35,18 @@ def test_update_matches_oracle_stage_by_stage(be, robot):
                *(["model.num_layers=1"] if robot == "stompy_pro_1_layer" else []), *(["model.num_layers=3"] if robot == "stompy_pro_3_layers" else []),
                # minibatches of 9 rows (emulator) / 190 rows (GPU): not a multiple of the 4-row quads nor of the 16-row tiles - the pre-gathered
                # row buffers and the weight-gradient operands end in zero rows, and a minibatch starts in the middle of a quad of the permutation
-               *((["training.num_envs=6", "training.num_steps=3", "rl.num_env_steps=3"] if be.name == "emu" else ["training.num_envs=152"]) if robot == "stompy_pro_ragged" else []))
+               *((["training.num_envs=6", "training.num_steps=3", "rl.num_env_steps=3"] if be.name == "emu" else ["training.num_envs=152"]) if robot == "stompy_pro_ragged" else []),
+               # the 32-row form of the float row pass (two 16-row tiles per workgroup share every weight stage; taken when the 16-row tiling has more
+               # workgroups than the chip has CUs): on the GPU BASELINE configs[4]'s minibatch shape - 2560 rows of the 20-actuator robot, 2 x 160
+               # workgroups of 16 rows -> 2 x 80 of 32; on the emulator (threshold 4 workgroups) 64-row minibatches
+               *((["training.num_envs=32"] if be.name == "emu" else ["environment.model=synth_stompy_full", "training.num_envs=2048"]) if robot == "row_tiles_32" else []))
     tr = be.trainer(cfg, external_random=True, use_graph=False)
+    if robot == "row_tiles_32":
+        import ctypes as C_
+
+        rows = C_.c_int32(0)
+        be.lib.minibatch_rows_per_workgroup(C_.byref(tr.net), tr.N * tr.T // tr.M, 1, C_.byref(rows))
+        assert rows.value == 32, rows.value
     tr.reset()
     N, T, A, H, O, OP, E, M = tr.N, tr.T, tr.A, tr.H, tr.O, tr.OP, tr.E, tr.M
     rng = np.random.default_rng(0)

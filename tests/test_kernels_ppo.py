@@ -532,6 +532,13 @@ def test_pregathered_rows_change_nothing(be, bf16, mb):
         got[k] = (be.host(g).copy(), be.host(l).copy())
     for k in ("idx0", "idx1"):
         assert not np.isnan(got[k][0]).any()
+        if bf16:
+            # a bf16 network's pre-gathered step runs the row pass written for bf16 (csrc/fused_bf16.h: v_mfma_f32_16x16x32_bf16, four accumulation
+            # chains, loss partials summed by a DPP tree) where the stand-alone entry point runs fused_mlp_kernel<bf16>: the same roundings of the
+            # operands, another order of the float32 sums - equal to float32 rounding, not bit for bit
+            np.testing.assert_allclose(got[k][0], ref[k][0], rtol=0, atol=2e-6 * np.abs(ref[k][0]).max())
+            np.testing.assert_allclose(got[k][1], ref[k][1], rtol=2e-6, atol=1e-7)
+            continue
         assert np.array_equal(ref[k][0], got[k][0]), k
         assert np.array_equal(ref[k][1], got[k][1]), k
     assert not np.array_equal(ref["idx0"][0], ref["idx1"][0])
