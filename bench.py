@@ -159,7 +159,7 @@ def rowpass_probe(tr, launches: int = 64, replays: int = 4):
 
 def rowpass_kernel_name(bf16: bool) -> str:
     """Name (as rocprofv3 prints it) of the training row pass the engine launches for the headline geometry."""
-    return "bf16_rowpass_kernel<1, 8, true>" if bf16 else "fused_mlp_kernel<false, false, 1, true, true>"
+    return "bf16_rowpass_kernel<1, 8, true>" if bf16 else "fused_mlp_kernel<false, false, 1, true, true, 1>"  # (<BF16, ROLLOUT, OT, W2T, PRE, RT>)
 
 
 def _usable_cores() -> int:

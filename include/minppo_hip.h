@@ -45,7 +45,7 @@ extern "C" {
 #define MPPO_ENCCL (-5)    /* an RCCL call failed                                         */
 #define MPPO_ENOMEM (-6)   /* caller-provided workspace too small                         */
 
-#define MPPO_ABI_VERSION 4  /* 4: mppo_engine_peer_selftest runs on the caller's stream */
+#define MPPO_ABI_VERSION 5  /* 5: mppo_minibatch_rows_per_workgroup; a bf16 network's fragment copies are tile-major (4: mppo_engine_peer_selftest runs on the caller's stream) */
 
 const char* mppo_last_error(void);
 int32_t mppo_abi_version(void);

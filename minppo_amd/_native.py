@@ -83,7 +83,7 @@ class EngineCfg(C.Structure):
 
 
 P = C.POINTER
-ABI_VERSION = 4  # include/minppo_hip.h: MPPO_ABI_VERSION
+ABI_VERSION = 5  # include/minppo_hip.h: MPPO_ABI_VERSION
 
 # name -> (restype, argtypes); restype c_i32 functions are checked and raise NativeError
 SIGNATURES = {
