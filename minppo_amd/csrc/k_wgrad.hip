@@ -74,10 +74,17 @@ __global__ void __launch_bounds__(WTHREADS, RING <= 2 ? 4 : 2) wgrad_kernel(Wgra
   const BufView bufA = make_buf(p.A, (unsigned)a.Kq * (unsigned)p.lda * (unsigned)QB);
   const BufView bufB = make_buf(p.B, (unsigned)a.Kq * (unsigned)p.ldb * (unsigned)QB);
   constexpr int kOutOfRange = 0x40000000;
-  const int ca = m0 + i, cb = n0 + i;  // this lane's columns; their position inside the quad row (WgradProb::a_split)
-  const int pa = p.a_split ? (ca >> 1) + (ca & 1) * (p.lda >> 1) : ca, pb = p.b_split ? (cb >> 1) + (cb & 1) * (p.ldb >> 1) : cb;
-  const int offa = ca < p.acols ? (h * p.lda + pa) * QB : kOutOfRange;
-  const int offb = cb < p.bcols ? (h * p.ldb + pb) * QB : kOutOfRange;
+  // bf16 network (round 5): a lane takes a column PAIR of one quad - 16 contiguous bytes (the quad rows are in plain column order, 8 bytes per
+  // column) - instead of one 8-byte quad: half the vector-memory instructions for the same bytes (every such instruction costs the CU's
+  // address path ~16 cycles whatever it carries: 40 per wave were 2.1 us of an 8.2 us launch).  Lane (p16 = lane & 15,
+  // qg = lane >> 4) holds columns 2 p16, 2 p16 + 1 of quad qg of a group of four; that is the operand layout of v_mfma_f32_16x16x16_bf16
+  // (lane (i, kq) supplies k = 4 kq + c of row / column i), so the 32 x 32 tile is computed as 2 x 2 interleaved 16 x 16 sub-tiles:
+  // sub-tile (ea, eb) = rows 2 m + ea, columns 2 n + eb.
+  const int p16 = lane & 15, qg = lane >> 4;
+  const int ca = BF16 ? m0 + 2 * p16 : m0 + i, cb = BF16 ? n0 + 2 * p16 : n0 + i;  // this lane's column (bf16: the even one of its pair)
+  const int pa = p.a_split ? (ca >> 1) + (ca & 1) * (p.lda >> 1) : ca, pb = p.b_split ? (cb >> 1) + (cb & 1) * (p.ldb >> 1) : cb;  // (float networks: WgradProb::a_split)
+  const int offa = ca < p.acols ? ((BF16 ? qg : h) * p.lda + pa) * QB : kOutOfRange;
+  const int offb = cb < p.bcols ? ((BF16 ? qg : h) * p.ldb + pb) * QB : kOutOfRange;
   auto ldq = [&](const BufView& b, int lane_off, int uni_off) {  // one quad; bf16: raw bits in .x, .y
     if (BF16) { const float2 r = buf_load_f2(b, lane_off, uni_off); return make_float4(r.x, r.y, 0.f, 0.f); }
     return buf_load_f4(b, lane_off, uni_off);
@@ -98,14 +105,16 @@ __global__ void __launch_bounds__(WTHREADS, RING <= 2 ? 4 : 2) wgrad_kernel(Wgra
   if (tile == 0 && t == 0) for (int k = 0; k < a.A; ++k) sum_log_std += a.log_std[k];
   f32x16 acc;
   for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-  float colsum = 0.f;  // bias gradient: sum over k of B(k, n); tiles of the first row band only
+  f32x4 acc16[2][2];  // bf16 network: [ea][eb] sub-tiles
+  for (int r = 0; r < 4; ++r) acc16[0][0][r] = acc16[0][1][r] = acc16[1][0][r] = acc16[1][1][r] = 0.f;
+  float colsum = 0.f, colsum1 = 0.f;  // bias gradient: sum over k of B(k, n); tiles of the first row band only (bf16: the lane's even / odd column)
   const bool do_colsum = p.off_b >= 0 && mt == 0;
   // (RING = 5: measured - a ring of 4 costs 3 us at the headline shape)
   float4 ra[RING][4], rb[RING][4];
   // a thin band's own operand (its <= 4 rows of A over all K) is tiny: staged in LDS once, read as broadcasts
   __shared__ float4 sx[kThinQuads];
   const bool do_thin = mt == 0 && p.thin_rows > 0;  // uniform
-  float tacc[4] = {0.f, 0.f, 0.f, 0.f};
+  float tacc[4] = {0.f, 0.f, 0.f, 0.f}, tacc1[4] = {0.f, 0.f, 0.f, 0.f};  // (tacc1: a bf16 network's odd column)
   constexpr int kThinPerThread = (kThinQuads + WTHREADS - 1) / WTHREADS;
   float4 sxr[kThinPerThread];
   if (do_thin) {  // requested first, stored to LDS after the prologue's loads have been requested too (one latency, not two)
@@ -116,7 +125,16 @@ __global__ void __launch_bounds__(WTHREADS, RING <= 2 ? 4 : 2) wgrad_kernel(Wgra
       if (BF16) sxr[j] = bf16x4_unpack(sxr[j].x, sxr[j].y);
     }
   }
-  auto load = [&](int slot, int s) {  // stage s: quads q0 + 8 s + 2 c + h, c = 0..3
+  auto load = [&](int slot, int s) {  // stage s: quads q0 + 8 s + 2 c + h, c = 0..3  (bf16: q0 + 8 s + 4 c + qg, c = 0, 1: a column pair each)
+    if (BF16) {
+#pragma unroll
+      for (int c = 0; c < 2; ++c) {
+        const int qu = q0 + WSTAGE * s + 4 * c;  // uniform
+        ra[slot][c] = buf_load_f4(bufA, offa, qu * p.lda * QB);
+        rb[slot][c] = buf_load_f4(bufB, offb, qu * p.ldb * QB);
+      }
+      return;
+    }
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
       const int qu = q0 + WSTAGE * s + 2 * c;  // uniform
@@ -125,6 +143,29 @@ __global__ void __launch_bounds__(WTHREADS, RING <= 2 ? 4 : 2) wgrad_kernel(Wgra
     }
   };
   auto mm = [&](int slot, int s) {
+    if (BF16) {
+#pragma unroll
+      for (int c = 0; c < 2; ++c) {
+        const float4 x = ra[slot][c], yraw = rb[slot][c];  // .xy: the even column's quad, .zw: the odd column's (raw bf16 bits)
+        const float4 y0 = bf16x4_unpack(yraw.x, yraw.y), y1 = bf16x4_unpack(yraw.z, yraw.w);
+        colsum += (y0.x + y0.y) + (y0.z + y0.w);
+        colsum1 += (y1.x + y1.y) + (y1.z + y1.w);
+        if (do_thin) {
+          const int qd = q0 + WSTAGE * s + 4 * c + qg;  // this lane's quad (past the last quad: y is 0, the index is clamped)
+#pragma unroll
+          for (int rr = 0; rr < 4; ++rr)
+            if (rr < p.thin_rows) {
+              const float4 z = sx[rr * a.Kq + (qd < a.Kq ? qd : a.Kq - 1)];
+              tacc[rr] += (z.x * y0.x + z.y * y0.y) + (z.z * y0.z + z.w * y0.w);
+              tacc1[rr] += (z.x * y1.x + z.y * y1.y) + (z.z * y1.z + z.w * y1.w);
+            }
+        }
+        const bf16x4 a0 = bf16x4_from_bits(x.x, x.y), a1 = bf16x4_from_bits(x.z, x.w), b0 = bf16x4_from_bits(yraw.x, yraw.y), b1 = bf16x4_from_bits(yraw.z, yraw.w);
+        mfma_bf16_16x16x16(a0, b0, acc16[0][0]); mfma_bf16_16x16x16(a0, b1, acc16[0][1]);
+        mfma_bf16_16x16x16(a1, b0, acc16[1][0]); mfma_bf16_16x16x16(a1, b1, acc16[1][1]);
+      }
+      return;
+    }
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
       const float4 x = ra[slot][c], yraw = rb[slot][c];
@@ -166,15 +207,33 @@ __global__ void __launch_bounds__(WTHREADS, RING <= 2 ? 4 : 2) wgrad_kernel(Wgra
   if (do_thin) {
 #pragma unroll
     for (int rr = 0; rr < 4; ++rr) {
-      tacc[rr] += __shfl_xor(tacc[rr], 32);
-      if (h == 0) tred[g][rr][i] = tacc[rr];
+      if (BF16) {  // the four 16-lane groups hold different quads of the same column pair
+        tacc[rr] += __shfl_xor(tacc[rr], 16); tacc[rr] += __shfl_xor(tacc[rr], 32);
+        tacc1[rr] += __shfl_xor(tacc1[rr], 16); tacc1[rr] += __shfl_xor(tacc1[rr], 32);
+        if (qg == 0) { tred[g][rr][2 * p16] = tacc[rr]; tred[g][rr][2 * p16 + 1] = tacc1[rr]; }
+      } else {
+        tacc[rr] += __shfl_xor(tacc[rr], 32);
+        if (h == 0) tred[g][rr][i] = tacc[rr];
+      }
     }
   }
   // ---- sum the eight K ranges in wave order ----
+  if (BF16) {
+#pragma unroll
+    for (int ea = 0; ea < 2; ++ea)
+#pragma unroll
+      for (int eb = 0; eb < 2; ++eb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) red[g][(2 * (4 * qg + r) + ea) * (WTILE + 1) + 2 * p16 + eb] = acc16[ea][eb][r];
+    colsum += __shfl_xor(colsum, 16); colsum += __shfl_xor(colsum, 32);
+    colsum1 += __shfl_xor(colsum1, 16); colsum1 += __shfl_xor(colsum1, 32);
+    if (qg == 0) { cred[g][2 * p16] = colsum; cred[g][2 * p16 + 1] = colsum1; }
+  } else {
 #pragma unroll
   for (int r = 0; r < 16; ++r) red[g][((r & 3) + 8 * (r >> 2) + 4 * h) * (WTILE + 1) + i] = acc[r];
   colsum += __shfl_xor(colsum, 32);  // the two lane halves hold different quads
   if (h == 0) cred[g][i] = colsum;
+  }
   __syncthreads();
   float sq = 0.f;
   if (PEER && (p.N & 3) == 0 && (p.off_w & 3) == 0) {
