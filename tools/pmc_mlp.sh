@@ -30,7 +30,7 @@ for f in glob.glob(out + '/pmc*/*/*counter_collection.csv'):
         if 'mppo::' not in k:
             continue
         k = k.split('(')[0].replace('void mppo::', '')
-        if not any(s in k for s in ('fused_mlp_kernel', 'wgrad_kernel', 'adam_kernel', 'env_kernel', 'gae_kernel')):
+        if not any(s in k for s in ('fused_mlp_kernel', 'bf16_rowpass_kernel', 'wgrad_kernel', 'adam_kernel', 'env_kernel', 'gae_kernel')):
             continue
         agg[k][r['Counter_Name']].append(float(r['Counter_Value']))
 for f in glob.glob(out + '/pmc1/*/*kernel_trace.csv'):
