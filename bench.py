@@ -524,8 +524,8 @@ def main() -> None:
     if world > 1:
         from minppo_amd import _native as _nat
 
-        _nat.load()  # the library (and RCCL behind it) paged in
-        torch.zeros(1, device=f"cuda:{local_rank}").add_(1).item()  # the GPU touched: this rank has STARTED (see _attempt_limits)
+        torch.zeros(1, device=f"cuda:{local_rank}").add_(1).item()  # the GPU touched (torch's own HIP runtime first, as everywhere else in this file)
+        _nat.load()  # the library (and RCCL behind it) paged in: this rank has STARTED (see _attempt_limits)
         if os.environ.get("MPPO_BENCH_MILESTONE_DIR"):
             _started_file(os.environ["MPPO_BENCH_MILESTONE_DIR"], int(os.environ.get("MPPO_BENCH_ATTEMPT", "0")), rank).write_text("started")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")

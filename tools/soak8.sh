@@ -1,14 +1,14 @@
 #!/bin/bash
-# tools/soak8.sh <updates> <log> [envs] - world = 8 on ONE MI355X: four processes of two ranks each (the GPU box allows six GPU processes), 512
+# tools/soak8.sh <updates> <log> [envs] [config overrides...] - world = 8 on ONE MI355X: four processes of two ranks each (the GPU box allows six GPU processes), 512
 # environments per rank (4096 in all), the peer exchange inside every rank's hipGraph, the engine's own random streams; at the end every
 # rank's parameters must be bit-identical and no wait may have timed out (tests/dist_worker.py run_process_of_ranks).
 cd "${GRAFT_REPO_ROOT:-$(dirname "$0")/..}" || exit 1
-UPD=${1:-500}; LOG=${2:-gpurun_out/soak8.log}; ENVS=${3:-4096}   # ENVS = environments in all (32768 = BASELINE configs[2]: 8 x 4096)
+UPD=${1:-500}; LOG=${2:-gpurun_out/soak8.log}; ENVS=${3:-4096}; EXTRA="${@:4}"   # ENVS = environments in all (32768 = BASELINE configs[2]: 8 x 4096)
 TMP=$(mktemp -d); PORT=$((20000 + RANDOM % 20000))
 export MPPO_TEST_SOAK=1 MPPO_ALLREDUCE=peer HSA_ENABLE_IPC_MODE_LEGACY=${HSA_ENABLE_IPC_MODE_LEGACY:-0}
 pids=()
 for p in 0 1 2 3; do
-  python tests/dist_worker.py procs $p 4 2 $PORT $UPD $TMP/r training.num_envs=$ENVS training.total_timesteps=2000000000 > $TMP/p$p.log 2>&1 &
+  python tests/dist_worker.py procs $p 4 2 $PORT $UPD $TMP/r training.num_envs=$ENVS training.total_timesteps=2000000000 $EXTRA > $TMP/p$p.log 2>&1 &
   pids+=($!)
 done
 rc=0
