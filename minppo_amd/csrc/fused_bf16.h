@@ -5,18 +5,22 @@
 // Same decomposition as fused_mlp_kernel - one workgroup = 16 minibatch rows of ONE network, H / 32 waves, wave w owns hidden columns
 // [32 w, 32 w + 32) as two interleaved 16-column tiles - and the same arithmetic, rounding point for rounding point (oracle:
 // oracle/ppo_oracle.py loss_and_grad(bf16=True): bf16 operands in x.W1, h1.W2 and dZ2.W2^T, exact float output layer and dOut.W3^T,
-// activation derivatives from the float activations).  What differs is where the time went (profiles/r05_a_fused_phases_bf16.txt: the
-// float kernel's structure spends 4.2 of its 11.1 us in-kernel streaming three 128 KB weight slabs through a three-stage ring, phase
-// after phase, with < 1 us of matrix work):
-//   * A wave's slab of a WHOLE layer is 16 KB of bf16 fragments = 64 VGPRs (k_ppo.hip keeps the fragment-order copies current).  W1 and
-//     W2 are requested at kernel entry, before anything else but the x tile, W2^T as soon as layer 1 has consumed W1's registers: the
-//     384 KB a workgroup needs are in flight from the first microsecond and arrive while the prologue / the previous phase runs.  No ring,
-//     no per-stage waits: a GEMM phase is 16 LDS reads and 32 MFMAs per wave.
+// activation derivatives from the float activations).  What differs is where the time went (profiles/r05_a_fused_phases_bf16_before.txt:
+// the float kernel's structure spends 4.2 of its 11.1 us in-kernel streaming three 128 KB weight slabs through a three-stage ring, phase
+// after phase, with < 1 us of matrix work; DESIGN.md 3.1b has the measurements this file is built on):
+//   * A wave's slab of a WHOLE layer is 16 KB of bf16 fragments = 64 VGPRs (k_ppo.hip keeps the fragment-order copies current).  W1 is
+//     requested at kernel entry, W2 at the start of P0 / layer 1, W2^T at the start of layer 2 / the heads - each in front of the
+//     phase's own work, a phase or two ahead of its use.  No ring, no clamped re-loads, no per-stage waits: a GEMM phase is 16 LDS reads
+//     (all of them first) and 16 v_mfma_f32_16x16x32_bf16 per wave on four accumulation chains.
 //   * The 16-row activation tiles that feed the matrix cores (x, h1, dZ2) live in LDS ALREADY ROUNDED to bf16 (what the float kernel's
 //     pack at every read produced): 8-byte ds_read_b64 per four k instead of 16-byte reads + four conversions, row stride 4 (mod 64)
 //     dwords = conflict-free.  h2 stays float in LDS (A operand of the exact head product); the activations a lane needs again for its
 //     derivative (its own 4 rows x 2 columns of h1, h2) stay in its registers.
-//   * The per-workgroup loss partials (16-row sums) are 16-lane DPP sums by every wave instead of one thread's serial loop behind a barrier.
+//   * A wave's 32 rows of W3 arrive as two coalesced loads and are re-arranged through a wave-local LDS scratch (every vector-memory
+//     instruction costs the CU's address path ~16 cycles whatever it carries: sixteen 4-byte gathers per lane cost as much as 16 KB of
+//     fragments); the wave index lives in a scalar register (else: a waterfall loop around every fragment load).
+//   * The loss block runs on wave 0 only (the emulator: every wave), its 16-row partial sums are 16-lane DPP sums instead of one
+//     thread's serial loop behind a barrier, and the x tile is brought in by the first half of the waves.
 #pragma once
 
 // two floats -> the bits of two bf16 (round to nearest even) in one dword
@@ -107,12 +111,14 @@ __global__ void __launch_bounds__(512, 2) bf16_rowpass_kernel(FusedArgs a) {
   // 1 KB per instruction that is one instruction per ~130 cycles and wave.  W1 (needed first) is requested here, all of it; the 16
   // loads of W2 are requested at the start of P0 (4) and P1 (12), those of W2^T at the start of P2 (12) and P3 (4) - each a phase or two
   // ahead of its use, in front of the phase's own work, which then runs while they are served.  (Measured and dropped, DESIGN.md 9: the same
-  // loads one at a time between blocks of work; the two waves of a SIMD requesting at opposite ends of a phase - 9.5 us either way.)  Every load is unconditional on a clamped address (a conditional load is a basic block of its own, and the
-  // s_waitcnt insertion then assumes the worse of two histories at the join: the wait for the x tile waited for W1 as well).
+  // loads one at a time between blocks of work; the two waves of a SIMD requesting at opposite ends of a phase - 9.5 us either way.)  
+  // Every load of the common path is unconditional on a clamped address (a conditional load is a basic block of its own, and the s_waitcnt
+  // insertion then assumes the worse of two histories at the join: the wait for the x tile waited for W1 as well); the two wave-uniform
+  // exceptions - the x tile's loads (first half of the waves) and the loss block's inputs (wave 0) - sit in front of / behind W1's loads.
   const int nxq = 4 * OP;
   const float* xtile = a.xpre + (size_t)(row0 >> 2) * OP * 2;  // this step's rows: a contiguous block of 8-byte bf16 quads (store_quad<true>)
   // brought in by the FIRST HALF of the waves, four quads per lane: the address path serves the older wave of every SIMD first, so waves
-  // nw/2 .. get through their requests ~2 k cycles after waves 0 .. nw/2 - 1 (stamps: profiles/r05_j_fused_phases_bf16.txt) - by the time
+  // nw/2 .. get through their requests ~2 k cycles after waves 0 .. nw/2 - 1 (stamps: profiles/r05_k_fused_phases_bf16.txt) - by the time
   // they would write their share of the tile to LDS the first half has written all of it, and the barrier behind P0 waits for nobody
   const int nwx = (nw + 1) >> 1, nthx = 64 * nwx;
   const bool xw = wave < nwx;
