@@ -557,16 +557,16 @@ def parse_mjcf(xml: str, name: str = "mjcf", base_dir: Optional[Path] = None) ->
                 for k in ("solreflimit", "solimplimit"):
                     if k in a:
                         solrefs["limit"].add((k, tuple(_floats(a[k]))))
-                if float(a.get("springref", "0")) != 0 or float(a.get("margin", "0")) != 0:
-                    raise ValueError(f"{what}: springref / margin are not supported")
+                if float(a.get("margin", "0")) != 0:
+                    raise ValueError(f"{what}: joint margin is not supported")
                 for k in a:
                     if k not in ("name", "type", "pos", "axis", "range", "limited", "ref", "damping", "armature", "stiffness", "solreflimit", "solimplimit",
                                  "springref", "margin", "group", "user", "actuatorfrcrange", "actuatorfrclimited"):
                         raise ValueError(f"{what}: attribute {k!r} is outside the supported MJCF subset")
-                ref = float(a.get("ref", "0"))
+                ref, sref = float(a.get("ref", "0")), float(a.get("springref", "0"))  # MuJoCo: qpos0 = ref, qpos_spring = springref (both default 0)
                 joints.append(JointSpec(jn, jt, pos=tuple(_floats(a.get("pos", "0 0 0"), 3, what)), axis=tuple(_floats(a.get("axis", "0 0 1"), 3, what)), range=rng,
                                         damping=float(a.get("damping", "0")), armature=float(a.get("armature", "0")), stiffness=float(a.get("stiffness", "0")),
-                                        ref=comp.ang(ref) if jt == JNT_HINGE else ref))
+                                        ref=comp.ang(ref) if jt == JNT_HINGE else ref, springref=comp.ang(sref) if jt == JNT_HINGE else sref))
             elif ch.tag == "geom":
                 kind, gs, part = geom_spec(dfl.resolve("geom", ch, cc), what)
                 if kind == "plane":
@@ -722,7 +722,8 @@ def to_mjcf(spec: ModelSpec) -> str:
                 ET.SubElement(e, "freejoint", name=j.name)
                 continue
             a = dict(name=j.name, type="hinge" if j.type == JNT_HINGE else "slide", pos=_fmt(j.pos), axis=_fmt(j.axis), damping=repr(float(j.damping)),
-                     armature=repr(float(j.armature)), stiffness=repr(float(j.stiffness)), ref=repr(float(j.ref)))
+                     armature=repr(float(j.armature)), stiffness=repr(float(j.stiffness)), ref=repr(float(j.ref)),
+                     springref=repr(float(j.ref if j.springref is None else j.springref)))
             if j.range is not None:
                 a["range"] = _fmt(j.range)
             ET.SubElement(e, "joint", **a)

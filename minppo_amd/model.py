@@ -57,6 +57,7 @@ class JointSpec:
     armature: float = 0.0
     stiffness: float = 0.0
     ref: float = 0.0  # qpos0 for hinge/slide
+    springref: Optional[float] = None  # position at which the joint spring (stiffness) is at rest: MuJoCo's qpos_spring; None = at `ref` (the built-in robots)
 
 
 @dataclass
@@ -259,6 +260,7 @@ def compile_model(spec: ModelSpec) -> CompiledModel:
     joint_names: List[str] = []
     dof_bodyid, dof_jntid, dof_armature, dof_damping = [], [], [], []
     qpos0: List[float] = []
+    qpos_spring: List[float] = []
     geoms = []  # (type, bodyid, pos, quat, size, friction, contype, conaffinity)
 
     nq = nv = 0
@@ -296,6 +298,7 @@ def compile_model(spec: ModelSpec) -> CompiledModel:
                     raise ValueError("free joint only on a top-level body, alone")
                 # the first free body stands at free_root_z (the robot's root); further free bodies keep their own height
                 qpos0 += [b.pos[0], b.pos[1], spec.free_root_z if not seen_free else b.pos[2], *body_quat[bi]]
+                qpos_spring += qpos0[-7:]  # (a free joint has no spring)
                 seen_free = True
                 nq += 7
                 for _ in range(6):
@@ -306,6 +309,7 @@ def compile_model(spec: ModelSpec) -> CompiledModel:
                 nv += 6
             elif j.type in (JNT_HINGE, JNT_SLIDE):
                 qpos0.append(j.ref)
+                qpos_spring.append(j.ref if j.springref is None else j.springref)
                 nq += 1
                 dof_bodyid.append(bi)
                 dof_jntid.append(jid)
@@ -560,7 +564,7 @@ def compile_model(spec: ModelSpec) -> CompiledModel:
     put("dof_armature", dof_armature)
     put("dof_damping", dof_damping)
     put("qpos0", qpos0)
-    put("qpos_spring", qpos0)
+    put("qpos_spring", qpos_spring)
     put("act_dofid", act_dofid, np.int32)
     put("act_qposadr", act_qposadr, np.int32)
     put("act_gear", act_gear)

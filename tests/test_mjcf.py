@@ -120,6 +120,33 @@ def test_frictionloss_is_stripped_like_the_reference_strips_it(caplog):
     assert a.to_blob(True) == b.to_blob(True)
 
 
+def test_springref_is_the_springs_rest_position_not_ref():
+    """MuJoCo: qpos0 = ref, qpos_spring = springref (both default 0) - the reference's own robot sets neither, an export may set both.  The
+    spring term of the passive force (oracle passive(), the twin and the kernel read the same table) pulls towards springref."""
+    from oracle.physics_oracle import Physics
+
+    knee = '<joint name="knee" axis="0 1 0"/>'
+    plain = compile_model(mjcf.parse_mjcf(HAND.replace(knee, '<joint name="knee" axis="0 1 0" stiffness="5" ref="-10"/>')))
+    sprung = mjcf.parse_mjcf(HAND.replace(knee, '<joint name="knee" axis="0 1 0" stiffness="5" ref="-10" springref="-40"/>'))
+    cm = compile_model(sprung)
+    qa = cm.nq - 1
+    assert cm.t["qpos0"][qa] == pytest.approx(math.radians(-10)) and plain.t["qpos0"][qa] == pytest.approx(math.radians(-10))
+    assert cm.t["qpos_spring"][qa] == pytest.approx(math.radians(-40)) and plain.t["qpos_spring"][qa] == 0.0   # (springref's default is 0, not ref)
+    np.testing.assert_array_equal(np.delete(cm.t["qpos_spring"], qa), np.delete(cm.t["qpos0"], qa))
+    # the writer keeps it: text -> spec -> text -> spec compiles to the same bytes
+    again = compile_model(mjcf.parse_mjcf(mjcf.to_mjcf(sprung)))
+    assert again.to_blob(True) == cm.to_blob(True)
+    ph = Physics(cm.t, np.float64)
+    d = ph.pipeline_init(np.asarray(cm.t["qpos0"], np.float64)[None], np.zeros((1, cm.nv)))
+    ph.passive(d)
+    assert d["qfrc_passive"][0, cm.nv - 1] == pytest.approx(-5 * math.radians(30)) and not d["qfrc_passive"][0, :-1].any()
+    # a programmatic spec without springref keeps its spring at ref (the built-in robots' tables, and the golden fixtures made from them)
+    from minppo_amd.model import BUILTIN_MODELS
+    for name in BUILTIN_MODELS:
+        t = load_model(name).t
+        np.testing.assert_array_equal(t["qpos_spring"], t["qpos0"])
+
+
 @pytest.mark.parametrize("old,new,msg", [
     ('<actuator>', '<equality/><actuator>', "equality"),
     ('type="sphere" size="0.1"', 'type="cylinder" size="0.1 0.1"', "only sphere, capsule and box geoms can collide"),
