@@ -162,6 +162,138 @@ __device__ __forceinline__ Q4 axis_angle(V3 axis, float angle) {
   sincosf(0.5f * angle, &s, &c);
   return {c, axis.x * s, axis.y * s, axis.z * s};
 }
+// ---- a sphere / capsule of one body against a convex hull (box, mesh) of another: MJX collision_convex._sphere_convex / _capsule_convex.
+// The 16 lanes of an environment work on ONE pair together: lanes stride over the hull's faces (support) and edges (closest approach),
+// the winners are found with DPP row reductions (the first index among equal values, as argmax / argmin give it), the winning face's
+// polygon - a handful of vertices - is walked by every lane alike.  Tables come from the hull section in global memory (HullView).
+struct HullTabs {
+  const int* face_adr; const int* fidx; const int* edge;
+  const float* vert; const float* fnormal; const float* enormal;
+};
+// first index whose value equals the row's maximum (value `v` is this lane's best over its own indices, `i` its index; a lane without
+// candidates passes -inf)
+__device__ __forceinline__ int group16_argmax(float v, int i) {
+  const float m = group16_max(v);
+  return (int)-group16_max(v == m ? -(float)i : -INFINITY);
+}
+// MJX _clip_edge_to_planes for the side planes of one face (plane k: through p0[k] = the polygon's previous vertex, normal (p1 - p0) x n):
+// an end in front of a plane moves to the line's intersection with it, the candidate most along the edge wins; both ends in front of one
+// plane, or ends that crossed: the edge is kept and masked out
+__device__ __forceinline__ bool clip_segment_to_face(const HullTabs& T, int a0, int a1, V3 n, V3& e0, V3& e1) {
+  const V3 dir = sub3(e1, e0), rdir = sub3(e0, e1);
+  V3 n0 = e0, n1 = e1;
+  float d0 = 0.f, d1 = 0.f;  // (argmax over candidates that start as "p itself, dot 0" at plane 0)
+  bool first = true, both = false;
+  V3 prev = ld3(T.vert + 3 * T.fidx[a1 - 1]);
+  for (int i = a0; i < a1; ++i) {
+    const V3 cur = ld3(T.vert + 3 * T.fidx[i]);
+    const V3 en = cross3(sub3(cur, prev), n);
+    const float s0 = dot3(sub3(e0, prev), en), s1 = dot3(sub3(e1, prev), en);
+    const bool in0 = s0 > 1e-6f, in1 = s1 > 1e-6f;
+    const float denom = dot3(dir, en);
+    const float tt = dot3(sub3(prev, e0), en) / (denom + (denom == 0.f ? 1e-6f : 0.f));
+    const V3 cand = add3(e0, mul3(dir, tt));
+    const V3 c0 = in0 ? cand : e0, c1 = in1 ? cand : e1;
+    const float x0 = dot3(sub3(c0, e0), dir), x1 = dot3(sub3(c1, e1), rdir);
+    if (first || x0 > d0) { d0 = x0; n0 = c0; }
+    if (first || x1 > d1) { d1 = x1; n1 = c1; }
+    first = false;
+    both = both || (in0 && in1);
+    prev = cur;
+  }
+  bool mask = !both;
+  if (!mask) { n0 = e0; n1 = e1; }
+  if (dot3(rdir, sub3(n0, n1)) < 0.f) mask = false;
+  e0 = n0; e1 = n1;
+  return mask;
+}
+// -> dist[2], pos[2], nrm[2] in the hull's frame (normal from the sphere / capsule into the hull); a sphere fills slot 0 only
+__device__ __forceinline__ void hull_pair_contacts(const HullTabs& T, int f0, int f1, int ed0, int ed1, bool capsule, V3 cp, V3 half, float r, int g,
+                                                   float* dist, V3* pos, V3* nrm) {
+  const V3 c0 = sub3(cp, half), c1 = add3(cp, half);
+  // the face with the least penetration among those the geom's lowest point is behind
+  float best = -INFINITY;
+  int bi = 0;
+  bool allneg = true;
+  for (int f = f0 + g; f < f1; f += kGroupLanes) {
+    const V3 n = ld3(T.fnormal + 3 * f), v0 = ld3(T.vert + 3 * T.fidx[T.face_adr[f]]);
+    float sup = fminf(dot3(sub3(c0, v0), n), dot3(sub3(c1, v0), n)) - r;
+    allneg = allneg && sup < 0.f;
+    if (sup >= 0.f) sup = -1e12f;
+    if (sup > best) { best = sup; bi = f; }
+  }
+  const int fb = group16_argmax(best, bi);
+  const bool has_support = !group16_any(!allneg);
+  const V3 n = ld3(T.fnormal + 3 * fb);
+  const int a0 = T.face_adr[fb], a1 = T.face_adr[fb + 1];
+  const V3 v0 = ld3(T.vert + 3 * T.fidx[a0]);
+  if (!capsule) {
+    // the centre projected on the face's plane; outside the polygon: on the nearest edge it is in front of
+    V3 pt = sub3(cp, mul3(n, dot3(sub3(cp, v0), n)));
+    bool inside = true;
+    float emin = INFINITY;
+    V3 ea = v0, eb = v0;
+    bool any = false;
+    V3 prev = ld3(T.vert + 3 * T.fidx[a1 - 1]);
+    for (int i = a0; i < a1; ++i) {
+      const V3 cur = ld3(T.vert + 3 * T.fidx[i]);
+      const V3 en = cross3(sub3(cur, prev), n);
+      float ed = dot3(sub3(pt, prev), en);
+      inside = inside && ed <= 0.f;
+      if (ed < 0.f || (en.x == 0.f && en.y == 0.f && en.z == 0.f)) ed = 1e12f;
+      if (!any || ed < emin) { emin = ed; ea = prev; eb = cur; any = true; }
+      prev = cur;
+    }
+    if (!inside) pt = closest_segment_point(ea, eb, pt);
+    float d;
+    const V3 nc = normalize_norm(sub3(pt, cp), d);
+    dist[0] = d - r;
+    pos[0] = mul3(add3(pt, add3(cp, mul3(nc, r))), 0.5f);
+    nrm[0] = nc;
+    dist[1] = 1.f; pos[1] = pos[0]; nrm[1] = nc;
+    return;
+  }
+  // the capsule's segment clipped to the face's side planes: each clipped end is a contact against the face
+  V3 q0 = c0, q1 = c1;
+  const bool mask = clip_segment_to_face(T, a0, a1, n, q0, q1);
+  float fpen[2];
+  {
+    const V3 qs[2] = {sub3(q0, mul3(n, r)), sub3(q1, mul3(n, r))};
+    for (int j = 0; j < 2; ++j) {
+      const V3 fp = sub3(qs[j], mul3(n, dot3(sub3(qs[j], v0), n)));
+      pos[j] = mul3(add3(qs[j], fp), 0.5f);
+      fpen[j] = (mask && has_support) ? dot3(sub3(fp, qs[j]), n) : -1.f;
+    }
+  }
+  // the hull edge that comes closest to the segment: a shallow edge contact replaces slot 0
+  float dbest = INFINITY;
+  int eb_i = ed0;
+  for (int e = ed0 + g; e < ed1; e += kGroupLanes) {
+    V3 pe, pc;
+    closest_segment_points(ld3(T.vert + 3 * T.edge[2 * e]), ld3(T.vert + 3 * T.edge[2 * e + 1]), c0, c1, pe, pc);
+    const V3 dlt = sub3(pe, pc);
+    const float dd = sqrtf(dot3(dlt, dlt));
+    if (dd < dbest) { dbest = dd; eb_i = e; }
+  }
+  const int ew = group16_argmax(-dbest, eb_i);
+  V3 pe, pc;
+  closest_segment_points(ld3(T.vert + 3 * T.edge[2 * ew]), ld3(T.vert + 3 * T.edge[2 * ew + 1]), c0, c1, pe, pc);
+  const V3 edir = sub3(pe, pc);
+  const bool degenerate = dot3(edir, edir) < 1e-6f;
+  float edist;
+  const V3 eaxis = normalize_norm(edir, edist);
+  const bool front = dot3(ld3(T.enormal + 6 * ew), eaxis) < 0.f && dot3(ld3(T.enormal + 6 * ew + 3), eaxis) < 0.f;
+  const float epen = (!degenerate && front) ? r - edist : -1.f;
+  const bool parallel = fabsf(dot3(eaxis, n)) > 0.99f && !degenerate;
+  const float minf = fminf(fpen[0], fpen[1]);
+  const bool has_edge = epen > 0.f && (minf > 0.f ? epen < minf : true) && !parallel;
+  const V3 nn = {-n.x, -n.y, -n.z};
+  if (has_edge) pos[0] = mul3(add3(pe, add3(pc, mul3(eaxis, r))), 0.5f);
+  nrm[0] = has_edge ? eaxis : nn;
+  nrm[1] = nn;
+  dist[0] = -(has_edge ? epen : fpen[0]);
+  dist[1] = -(has_edge ? -1.f : fpen[1]);
+}
 // cinert (10) x spatial motion (6) -> spatial force (6)      (mju_mulInertVec)
 __device__ __forceinline__ void inert_mul(const float* i, const float* v, float* r) {
   r[0] = i[0] * v[0] + i[3] * v[1] + i[4] * v[2] - i[8] * v[4] + i[7] * v[5];
@@ -454,10 +586,10 @@ __global__ void __launch_bounds__(64 * kMaxWavesPerBlock) env_kernel(ModelView m
     PT(2);
     // ---- com_pos: centre of mass of every kinematic tree; contact candidates --------------------
     for (int r = 0; r < nroot; ++r) {
-      const u64 mask = TU(body_subtree_mask)[TI(root_body)[r]];
+      const u64 mask = TU(body_subtree_mask)[TI(root_body)[r]], mask_hi = nb > 64 ? TU(body_subtree_mask)[nb + TI(root_body)[r]] : 0ull;
       float sx = 0.f, sy = 0.f, sz = 0.f, sm = 0.f;
       FOR_G(b, nb) {
-        if ((mask >> b) & 1ull) {
+        if (((b < 64 ? mask : mask_hi) >> (b & 63)) & 1ull) {
           const float m = TF(body_mass)[b];
           sx += m * xipos[3 * b]; sy += m * xipos[3 * b + 1]; sz += m * xipos[3 * b + 2]; sm += m;
         }
@@ -531,6 +663,7 @@ __global__ void __launch_bounds__(64 * kMaxWavesPerBlock) env_kernel(ModelView m
       const int c = nplane + k;
       const int b1 = TI(pair_body)[2 * k], b2 = TI(pair_body)[2 * k + 1];
       const float* gp = TF(pair_geom) + 16 * k;
+      if (!kDims && gp[7] != 0.f) continue;  // geom 2 is a convex hull: below
       const Q4 q1 = ld4(xquat + 4 * b1), q2 = ld4(xquat + 4 * b2);
       const V3 c1 = add3(ld3(xpos + 3 * b1), qrot(q1, ld3(gp))), h1 = qrot(q1, ld3(gp + 3));
       const V3 c2 = add3(ld3(xpos + 3 * b2), qrot(q2, ld3(gp + 8))), h2 = qrot(q2, ld3(gp + 11));
@@ -544,6 +677,39 @@ __global__ void __launch_bounds__(64 * kMaxWavesPerBlock) env_kernel(ModelView m
       st3(conpos + 3 * c, add3(p1, mul3(n, gp[6] + 0.5f * dist)));
       st3(confr + 6 * c, n);
       st3(confr + 6 * c + 3, frame_tangent(n));
+    }
+    if (!kDims && mv.hull_words > 0) {
+      // sphere / capsule against a box or a mesh hull of another body (pair rows tagged with a hull; run-time-sized kernel only): one
+      // pair at a time, the environment's 16 lanes together.  Geometry in the frame of the hull's body, results back in the world.
+      const int* hs = mv.blob + mv.blob_words;
+      const HullView hv = hull_view(hs[0], hs[1], hs[2], hs[3], hs[4]);
+      const float* hf = reinterpret_cast<const float*>(hs);
+      const HullTabs T{hs + hv.face_adr, hs + hv.fidx, hs + hv.edge, hf + hv.vert, hf + hv.fnormal, hf + hv.enormal};
+      for (int k = 0; k < npair; ++k) {
+        const float* gp = TF(pair_geom) + 16 * k;
+        const int hid = (int)gp[7] - 1;
+        if (hid < 0 || gp[15] != 0.f) continue;  // (a capsule pair's second slot is filled with its first)
+        const int c = nplane + k;
+        const int b1 = TI(pair_body)[2 * k], b2 = TI(pair_body)[2 * k + 1];
+        const Q4 q1 = ld4(xquat + 4 * b1);
+        float R[9];
+        qmat(ld4(xquat + 4 * b2), R);
+        const V3 x2 = ld3(xpos + 3 * b2);
+        auto to_hull = [&](V3 v) { return V3{R[0] * v.x + R[3] * v.y + R[6] * v.z, R[1] * v.x + R[4] * v.y + R[7] * v.z, R[2] * v.x + R[5] * v.y + R[8] * v.z}; };
+        auto to_world = [&](V3 v) { return V3{R[0] * v.x + R[1] * v.y + R[2] * v.z, R[3] * v.x + R[4] * v.y + R[5] * v.z, R[6] * v.x + R[7] * v.y + R[8] * v.z}; };
+        const bool capsule = gp[3] != 0.f || gp[4] != 0.f || gp[5] != 0.f;
+        const V3 cp = to_hull(sub3(add3(ld3(xpos + 3 * b1), qrot(q1, ld3(gp))), x2)), half = to_hull(qrot(q1, ld3(gp + 3)));
+        float dist2[2];
+        V3 pos2[2], nrm2[2];
+        hull_pair_contacts(T, hs[hv.fadr + hid], hs[hv.fadr + hid + 1], hs[hv.eadr + hid], hs[hv.eadr + hid + 1], capsule, cp, half, gp[6], g, dist2, pos2, nrm2);
+        if (g < (capsule ? 2 : 1)) {  // (selected, not indexed: a lane-indexed register array would live in scratch)
+          const V3 nw = to_world(g == 0 ? nrm2[0] : nrm2[1]);
+          condist[c + g] = g == 0 ? dist2[0] : dist2[1];
+          st3(conpos + 3 * (c + g), add3(x2, to_world(g == 0 ? pos2[0] : pos2[1])));
+          st3(confr + 6 * (c + g), nw);
+          st3(confr + 6 * (c + g) + 3, frame_tangent(nw));
+        }
+      }
     }
     SYNC();
     PT(3);
@@ -602,13 +768,15 @@ __global__ void __launch_bounds__(64 * kMaxWavesPerBlock) env_kernel(ModelView m
     // ---- crb: composite inertia over the subtree mask, dense M ------------------------------------
     FOR_G(i, nv) {
       const int bi = TI(dof_bodyid)[i];
-      u64 mask = TU(body_subtree_mask)[bi];
       float crb[10];
       for (int k = 0; k < 10; ++k) crb[k] = 0.f;
-      while (mask) {
-        const int c = __ffsll((long long)mask) - 1;
-        mask &= mask - 1;
-        for (int k = 0; k < 10; ++k) crb[k] += cinert[10 * c + k];
+      for (int w = 0; w < (nb > 64 ? 2 : 1); ++w) {  // (a second word of the subtree set beyond 64 bodies: run-time-sized kernel only)
+        u64 mask = TU(body_subtree_mask)[w * nb + bi];
+        while (mask) {
+          const int c = 64 * w + __ffsll((long long)mask) - 1;
+          mask &= mask - 1;
+          for (int k = 0; k < 10; ++k) crb[k] += cinert[10 * c + k];
+        }
       }
       float buf[6];
       inert_mul(crb, cdof + 6 * i, buf);
@@ -837,11 +1005,13 @@ __global__ void __launch_bounds__(64 * kMaxWavesPerBlock) env_kernel(ModelView m
     // ---- qfrc_bias, passive, actuation -> qfrc_smooth -------------------------------------------------
     FOR_G(d, nv) {
       float f[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-      u64 mask = TU(body_subtree_mask)[TI(dof_bodyid)[d]];
-      while (mask) {
-        const int c = __ffsll((long long)mask) - 1;
-        mask &= mask - 1;
-        for (int k = 0; k < 6; ++k) f[k] += cfrc[6 * c + k];
+      for (int w = 0; w < (nb > 64 ? 2 : 1); ++w) {
+        u64 mask = TU(body_subtree_mask)[w * nb + TI(dof_bodyid)[d]];
+        while (mask) {
+          const int c = 64 * w + __ffsll((long long)mask) - 1;
+          mask &= mask - 1;
+          for (int k = 0; k < 6; ++k) f[k] += cfrc[6 * c + k];
+        }
       }
       const float* cd = cdof + 6 * d;
       const float bias = cd[0] * f[0] + cd[1] * f[1] + cd[2] * f[2] + cd[3] * f[3] + cd[4] * f[4] + cd[5] * f[5];
@@ -1401,8 +1571,8 @@ extern "C" int32_t mppo_model_open(const void* host_blob, size_t nbytes, const v
   const float* wf = static_cast<const float*>(host_blob);
   if (w[0] != kBlobMagic) return fail(MPPO_EMODEL, "bad model blob magic 0x%08x", w[0]);
   if (w[1] != kBlobVersion) return fail(MPPO_EMODEL, "unsupported model blob version %u", w[1]);
-  const size_t total = w[2];
-  if (total * 4 != nbytes) return fail(MPPO_EMODEL, "model blob size mismatch: header says %zu words, got %zu bytes", total, nbytes);
+  const size_t total = w[2], hull_words = w[35];  // table part + hull section
+  if ((total + hull_words) * 4 != nbytes) return fail(MPPO_EMODEL, "model blob size mismatch: header says %zu + %zu words, got %zu bytes", total, hull_words, nbytes);
   if (wi[32] != BLOB_ARRAY_COUNT) return fail(MPPO_EMODEL, "model blob has %d arrays, engine expects %d", wi[32], (int)BLOB_ARRAY_COUNT);
   mppo_model* m = new mppo_model();
   ModelView& v = m->mv;
@@ -1412,10 +1582,10 @@ extern "C" int32_t mppo_model_open(const void* host_blob, size_t nbytes, const v
   v.nefc = v.nlimit + 4 * v.ncon;
   v.timestep = wf[16]; v.tolerance = wf[17]; v.ls_tolerance = wf[18]; v.impratio = wf[19]; v.plane_z = wf[20]; v.meaninertia = wf[21];
   auto bad = [&](const char* what) { delete m; return fail(MPPO_EMODEL, "model blob: %s", what); };
-  if (v.nq < 1 || v.nv < 1 || v.nbody < 2 || v.nbody > 64 || v.nv > 64 || v.nq > 128 || v.nu < 0 || v.nu > v.nv || v.njnt < 1 ||
+  if (v.nq < 1 || v.nv < 1 || v.nbody < 2 || v.nbody > 128 || v.nv > 64 || v.nq > 128 || v.nu < 0 || v.nu > v.nv || v.njnt < 1 ||
       v.ncon < 0 || v.npair < 0 || v.npair > v.ncon || v.nlimit < 0 || v.nroot < 1 || v.nlevel < 1 || v.iterations < 0 || v.ls_iterations < 0 ||
       v.ncvx < 0 || 4 * v.ncvx > v.ncon - v.npair || v.ncvxvert < 4 * v.ncvx || v.ncvxvert > 64 * 64)
-    return bad("dimension out of the supported range (nbody<=64, nv<=64)");
+    return bad("dimension out of the supported range (nbody<=128, nv<=64)");
   if (!(v.timestep > 0.f) || !(v.meaninertia > 0.f) || !(v.impratio > 0.f)) return bad("non-positive timestep / meaninertia / impratio");
   const int32_t* dir = wi + kBlobHeaderWords;
   const BlobDims bd{v.nq, v.nv, v.nu, v.nbody, v.njnt, v.ncon, v.nlimit, v.npair, v.nlevel, v.nroot, v.ncvx, v.ncvxvert};
@@ -1449,6 +1619,36 @@ extern "C" int32_t mppo_model_open(const void* host_blob, size_t nbytes, const v
     if (v.ncvx > 0 && (va[0] != 0 || va[v.ncvx] != v.ncvxvert)) return bad("cvx_vadr does not cover the vertex table");
   }
   {
+    // the hull section: every index the kernel follows from a pair row to a hull, its faces, their vertex lists and its edges
+    v.hull_words = (int)hull_words;
+    const int32_t* hs = wi + total;
+    HullView hv{};
+    if (hull_words > 0) {
+      if (hull_words < 8 || (hull_words & 3)) return bad("hull section too short");
+      if (hs[0] < 1 || hs[1] < 4 || hs[2] < 4 || hs[3] < 12 || hs[4] < 6 || hs[0] > 64 || hs[1] > 64 * 64 || hs[2] > 128 * 64 || hs[3] > 6 * 128 * 64 || hs[4] > 192 * 64)
+        return bad("hull section: dimension out of range");
+      hv = hull_view(hs[0], hs[1], hs[2], hs[3], hs[4]);
+      if ((size_t)hv.words != hull_words) return bad("hull section: length does not follow from its dimensions");
+      const int32_t *va = hs + hv.vadr, *fa = hs + hv.fadr, *ea = hs + hv.eadr, *pa = hs + hv.face_adr, *fi = hs + hv.fidx, *ed = hs + hv.edge;
+      if (va[0] != 0 || fa[0] != 0 || ea[0] != 0 || pa[0] != 0 || va[hv.nhull] != hv.nvert || fa[hv.nhull] != hv.nface || ea[hv.nhull] != hv.nedge || pa[hv.nface] != hv.nfidx)
+        return bad("hull section: address tables do not cover their arrays");
+      for (int h = 0; h < hv.nhull; ++h) {
+        if (va[h + 1] < va[h] + 4 || va[h + 1] - va[h] > 64 || fa[h + 1] < fa[h] + 4 || ea[h + 1] < ea[h] + 6) return bad("a hull needs 4 .. 64 vertices, at least 4 faces and 6 edges");
+        for (int f = fa[h]; f < fa[h + 1]; ++f) {
+          if (pa[f + 1] < pa[f] + 3 || pa[f + 1] - pa[f] > 64) return bad("a hull face needs 3 .. 64 vertices");
+          for (int i = pa[f]; i < pa[f + 1]; ++i) if (fi[i] < va[h] || fi[i] >= va[h + 1]) return bad("hull face vertex out of its hull's range");
+        }
+        for (int e = 2 * ea[h]; e < 2 * ea[h + 1]; ++e) if (ed[e] < va[h] || ed[e] >= va[h + 1]) return bad("hull edge vertex out of its hull's range");
+      }
+    }
+    const float* pg = wf + dir[2 * BF_pair_geom];
+    for (int k = 0; k < v.npair; ++k) {
+      const float hid = pg[16 * k + 7], slot = pg[16 * k + 15];
+      if (hid != (float)(int)hid || hid < 0.f || hid > (float)hv.nhull || (slot != 0.f && slot != 1.f)) return bad("pair row: hull / slot tag out of range");
+      if (slot == 1.f && (hid == 0.f || k == 0 || pg[16 * (k - 1) + 7] != hid || pg[16 * (k - 1) + 15] != 0.f)) return bad("pair row: a second slot must follow its pair's first");
+    }
+  }
+  {
     const int32_t *jt = HI(BI_jnt_type), *qa = HI(BI_jnt_qposadr), *da = HI(BI_jnt_dofadr), *jn = HI(BI_body_jntnum), *ja = HI(BI_body_jntadr),
                   *par = HI(BI_body_parent), *dp = HI(BI_dof_parentid), *la = HI(BI_level_adr);
     for (int j = 0; j < v.njnt; ++j) {
@@ -1470,7 +1670,7 @@ extern "C" int32_t mppo_model_open(const void* host_blob, size_t nbytes, const v
   v.obs_dim = v.nq + 2 * v.nv + (v.include_c ? 16 * (v.nbody - 1) : 0);  // env.py:246-259
   v.obs_pad = (v.obs_dim + 3) & ~3;
   v.rec_dim = v.obs_pad + ((v.nv + 2 + 3) & ~3);
-  m->spec = find_spec(bd);
+  m->spec = v.hull_words > 0 ? -1 : find_spec(bd);  // (hull pairs: the run-time-sized kernel)
   // (a model-specialised kernel of up to 32 dofs keeps the inverse Cholesky factor in registers: no LL square in its layout)
   m->lds = make_phys_lds(v.nq, v.nv, v.nu, v.nbody, v.njnt, v.ncon, v.nefc, v.nroot, v.ncvx, m->spec >= 0 && v.nv <= 2 * kGroupLanes);
   // waves per workgroup: whatever puts the most waves on a CU (160 KB of LDS; every workgroup holds one copy of the model tables and

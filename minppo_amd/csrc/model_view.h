@@ -31,7 +31,7 @@ enum BlobF32 {
 };
 
 constexpr uint32_t kBlobMagic = 0x4D50504F;
-constexpr uint32_t kBlobVersion = 4;
+constexpr uint32_t kBlobVersion = 5;
 constexpr int kBlobHeaderWords = 64;
 constexpr int JNT_FREE = 0, JNT_HINGE = 2, JNT_SLIDE = 3;
 constexpr float MJ_MINVAL = 1e-15f, MJ_MINIMP = 0.0001f, MJ_MAXIMP = 0.9999f;
@@ -48,7 +48,8 @@ struct ModelView {
   int include_c;  // observation = qpos, qvel, cinert[1:], cvel[1:], qfrc_actuator (1) or qpos, qvel, qfrc_actuator (0): env.py:246-259
   float timestep, tolerance, ls_tolerance, impratio, plane_z, meaninertia;
   const int* blob;   // device copy of the whole blob (16-byte aligned)
-  int blob_words;    // multiple of 4
+  int blob_words;    // multiple of 4: the TABLE part (what the kernel copies into LDS)
+  int hull_words;    // the hull section behind it (0: the model has no convex geom in a geom-geom pair); read from global memory
   int o[BLOB_ARRAY_COUNT];
 };
 
@@ -73,7 +74,8 @@ __host__ __device__ constexpr inline int blob_array_len(const BlobDims& d, int k
     case BI_level_adr: return d.nlevel + 1;
     case BI_level_body: return d.nbody - 1;
     case BI_root_body: return d.nroot;
-    case BI_body_subtree_mask: case BI_body_ancdof_mask: case BF_body_invweight0: return 2 * d.nbody;
+    case BI_body_subtree_mask: return (d.nbody > 64 ? 4 : 2) * d.nbody;  // a 64-bit word per body: bodies 0..63 of its subtree; beyond 64 bodies a second block of words: bodies 64..127
+    case BI_body_ancdof_mask: case BF_body_invweight0: return 2 * d.nbody;
     case BI_dof_velmask: return 2 * d.nv;
     case BF_gravity: return 3;
     case BF_body_pos: case BF_body_ipos: case BF_body_inertia: return 3 * d.nbody;
@@ -99,6 +101,26 @@ __host__ __device__ constexpr inline BlobOffsets blob_offsets(const BlobDims& d)
   }
   b.words = cur;
   return b;
+}
+
+// The hull section (model.py _hull_section): the convex geoms (boxes, mesh hulls) that meet spheres / capsules of other bodies, as MJX's
+// sphere_convex / capsule_convex want them - per hull a range of vertices, of polygon faces (vertex index lists, counter-clockwise seen
+// from outside; outward unit normals) and of edges (vertex pair + the normals of the two faces beside it), everything in the frame of the
+// body the geom is fixed to.  Eight header words (nhull, nvert, nface, nfidx, nedge, 0, 0, 0), then the arrays in this order, each padded
+// to 4 words; offsets below are in words from the section's start.
+struct HullView {
+  int nhull, nvert, nface, nfidx, nedge;
+  int vadr, fadr, eadr, face_adr, fidx, edge, vert, fnormal, enormal;
+  int words;
+};
+__host__ __device__ constexpr inline HullView hull_view(int nhull, int nvert, int nface, int nfidx, int nedge) {
+  HullView h{nhull, nvert, nface, nfidx, nedge, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  int cur = 8;
+  auto take = [&](int n) { const int o = cur; cur += (n + 3) & ~3; return o; };
+  h.vadr = take(nhull + 1); h.fadr = take(nhull + 1); h.eadr = take(nhull + 1); h.face_adr = take(nface + 1); h.fidx = take(nfidx);
+  h.edge = take(2 * nedge); h.vert = take(3 * nvert); h.fnormal = take(3 * nface); h.enormal = take(6 * nedge);
+  h.words = cur;
+  return h;
 }
 
 // Per-environment LDS layout (offsets in floats).  What is alive from one end of a step to the other sits in front; region "A" is

@@ -25,6 +25,7 @@ spatial vectors are [rotational(3), translational(3)].
 
 from __future__ import annotations
 
+import math
 import struct
 from dataclasses import dataclass, field
 from typing import Dict, List, Optional, Sequence, Tuple
@@ -36,9 +37,10 @@ GEOM_SPHERE, GEOM_CAPSULE, GEOM_BOX, GEOM_MESH = 2, 3, 6, 7  # MuJoCo's mjtGeom 
 
 MJ_MINVAL = 1e-15
 MAX_CONVEX_VERTS = 64  # hull vertices of one mesh collider (the kernel scans them five times per step)
+MAX_BODIES = 128  # subtree sets are two 64-bit words per body (one up to 64 bodies); dofs: one word, 64
 
 BLOB_MAGIC = 0x4D50504F  # "MPPO"
-BLOB_VERSION = 4  # 2: header word include_c_vals; 3: geom-geom pairs (npair, pair_body, pair_geom) and con_axis; 4: convex (mesh) geoms against the plane
+BLOB_VERSION = 5  # 2: header word include_c_vals; 3: geom-geom pairs (npair, pair_body, pair_geom) and con_axis; 4: convex (mesh) geoms against the plane; 5: hull section (sphere / capsule against box / mesh)
 
 
 # ---------------------------------------------------------------------------
@@ -73,7 +75,7 @@ class GeomSpec:
     contype: int = 0
     conaffinity: int = 1
     # GEOM_MESH: the vertices of the mesh's CONVEX HULL in the geom's own frame ([V, 3]; `size` is unused).  A mesh collides as its
-    # convex hull, like in MuJoCo / MJX, and only with the ground plane here.
+    # convex hull, like in MuJoCo / MJX: with the ground plane, and with the spheres and capsules of other bodies (not with boxes / meshes).
     vertices: Optional[Sequence[Sequence[float]]] = None
 
 
@@ -236,6 +238,62 @@ class CompiledModel:
         return _to_blob(self, include_c_vals)
 
 
+def hull_topology(verts: np.ndarray) -> Tuple[List[List[int]], np.ndarray, np.ndarray, np.ndarray]:
+    """Faces, outward unit normals, edges and the two face normals beside every edge of the convex hull of `verts` ([V, 3], every one
+    of them a hull vertex) - what MJX keeps of a convex geom for sphere_convex / capsule_convex (its mesh.py: the hull's triangles,
+    coplanar ones merged into polygons; a box is the six quads this gives for its corners).  A face lists its vertices counter-clockwise
+    seen from outside.  Returns (faces, normals [F, 3], edges [E, 2] with i < j, edge_normals [E, 2, 3])."""
+    from scipy.spatial import ConvexHull
+
+    v = np.asarray(verts, np.float64).reshape(-1, 3)
+    hull = ConvexHull(v)
+    tris = [tuple(int(i) for i in tri) for tri in hull.simplices]
+    nrm = hull.equations[:, :3] / np.linalg.norm(hull.equations[:, :3], axis=1, keepdims=True)
+    parent = list(range(len(tris)))
+
+    def find(i):
+        while parent[i] != i:
+            parent[i] = parent[parent[i]]
+            i = parent[i]
+        return i
+
+    by_edge: Dict[Tuple[int, int], List[int]] = {}
+    for ti, tri in enumerate(tris):
+        for a, b in ((tri[0], tri[1]), (tri[1], tri[2]), (tri[2], tri[0])):
+            by_edge.setdefault((min(a, b), max(a, b)), []).append(ti)
+    for ts in by_edge.values():
+        for other in ts[1:]:
+            if np.dot(nrm[ts[0]], nrm[other]) > 1.0 - 1e-9:  # coplanar neighbours: one polygon
+                parent[find(other)] = find(ts[0])
+    groups: Dict[int, List[int]] = {}
+    for ti in range(len(tris)):
+        groups.setdefault(find(ti), []).append(ti)
+    faces: List[List[int]] = []
+    normals: List[np.ndarray] = []
+    for members in sorted(groups.values(), key=lambda m: min(min(tris[ti]) for ti in m) * len(v) * len(v) + min(m)):
+        n = nrm[members].mean(0)
+        n /= np.linalg.norm(n)
+        idx = sorted({i for ti in members for i in tris[ti]})
+        c = v[idx].mean(0)
+        u = v[idx[0]] - c
+        u -= n * np.dot(u, n)
+        u /= np.linalg.norm(u)
+        w = np.cross(n, u)  # (u, w, n) right-handed: increasing angle = counter-clockwise seen from outside
+        ang = [math.atan2(np.dot(v[i] - c, w), np.dot(v[i] - c, u)) for i in idx]
+        order = [i for _, i in sorted(zip(ang, idx))]
+        k0 = order.index(min(order))
+        faces.append(order[k0:] + order[:k0])
+        normals.append(n)
+    edge_faces: Dict[Tuple[int, int], List[int]] = {}
+    for fi, f in enumerate(faces):
+        for a, b in zip(f, f[1:] + f[:1]):
+            edge_faces.setdefault((min(a, b), max(a, b)), []).append(fi)
+    edges = sorted(edge_faces)
+    if any(len(edge_faces[e]) != 2 for e in edges):
+        raise ValueError("convex hull: an edge that does not separate exactly two faces (degenerate mesh)")
+    return faces, np.asarray(normals), np.asarray(edges, np.int32).reshape(-1, 2), np.asarray([[normals[edge_faces[e][0]], normals[edge_faces[e][1]]] for e in edges]).reshape(-1, 2, 3)
+
+
 def compile_model(spec: ModelSpec) -> CompiledModel:
     """Flattens a ModelSpec and derives the constants MuJoCo's compiler would
     (`mj_setConst`: `dof_invweight0`, `body_invweight0`, `stat.meaninertia`)."""
@@ -347,8 +405,9 @@ def compile_model(spec: ModelSpec) -> CompiledModel:
     for bi in range(1, nbody):
         depth[bi] = depth[body_parent[bi]] + 1
 
-    if nbody > 64 or nv > 64:
-        raise ValueError("the physics kernel supports at most 64 bodies and 64 dofs (bitmask topology tables)")
+    if nbody > MAX_BODIES or nv > 64:
+        raise ValueError(f"the physics kernel supports at most {MAX_BODIES} bodies (the world included) and 64 dofs (bitmask topology tables); "
+                         f"this model has {nbody} bodies and {nv} dofs")
     # bodies grouped by depth (level-synchronous kinematics)
     nlevel = int(depth.max()) if nbody > 1 else 0
     level_adr = np.zeros(nlevel + 1, np.int32)
@@ -360,9 +419,9 @@ def compile_model(spec: ModelSpec) -> CompiledModel:
     root_body = [b for b in range(1, nbody) if body_parent[b] == 0]
     # bitmask topology: subtree(b) as a set of bodies; ancestor-or-own dofs of body b;
     # dofs whose motion precedes dof j in mj_comVel (used for cdof_dot)
-    subtree = np.zeros(nbody, np.uint64)
+    subtree = [0] * nbody  # (Python integers: up to 128 bits)
     for b in range(nbody - 1, 0, -1):
-        subtree[b] |= np.uint64(1) << np.uint64(b)
+        subtree[b] |= 1 << b
         subtree[body_parent[b]] |= subtree[b]
     ancdof = np.zeros(nbody, np.uint64)
     for b in range(1, nbody):
@@ -470,10 +529,11 @@ def compile_model(spec: ModelSpec) -> CompiledModel:
             con_axis.append(list(axis_l))
             con_cvx.append(-1)
     nplane = len(con_bodyid)
-    # ... then geom-geom pairs between different bodies (sphere / capsule only), filtered as MuJoCo filters them: same weld
-    # group and parent-child weld groups are skipped (mj_filterBodyPair), then the contype / conaffinity masks.  geom1 is the
-    # one with the smaller type id (sphere before capsule); groups are ordered (sphere, sphere), (sphere, capsule),
-    # (capsule, capsule) like MJX's collision-function table.
+    # ... then geom-geom pairs between different bodies, filtered as MuJoCo filters them: same weld group and parent-child weld
+    # groups are skipped (mj_filterBodyPair), then the contype / conaffinity masks.  geom1 is the one with the smaller type id
+    # (sphere < capsule < box < mesh); groups are ordered (sphere, sphere), (sphere, capsule), (sphere, box), (sphere, mesh),
+    # (capsule, capsule), (capsule, box), (capsule, mesh) like MJX's collision-function table.  A box or a mesh meets a sphere / capsule
+    # as a convex hull (MJX sphere_convex: one contact; capsule_convex: two); box / mesh against box / mesh is not built.
     weld = np.arange(nbody)
     for b in range(1, nbody):
         if body_jntnum[b] == 0:
@@ -491,17 +551,49 @@ def compile_model(spec: ModelSpec) -> CompiledModel:
                 continue
             if not _masks_match(gi[6], gi[7], gj[6], gj[7]):
                 continue
-            if GEOM_BOX in (gi[0], gj[0]) or GEOM_MESH in (gi[0], gj[0]):
-                kind = "box" if GEOM_BOX in (gi[0], gj[0]) else "mesh"
-                raise ValueError(f"a {kind} geom can only collide with the ground plane: exclude it from geom-geom pairs with contype / conaffinity")
-            pair_rows.append(((gi[0], gj[0]), gi, gj))
-    pair_rows.sort(key=lambda r: r[0])  # stable: geom order inside a group
+            if gi[0] in (GEOM_BOX, GEOM_MESH):
+                names_ = {GEOM_BOX: "box", GEOM_MESH: "mesh"}
+                raise ValueError(f"a {names_[gi[0]]} geom cannot collide with a {names_[gj[0]]} geom (convex-convex pairs are not built): "
+                                 "exclude the pair with contype / conaffinity")
+            pair_rows.append(((gi[0], gj[0]), gi, gj, 0))
+            if gj[0] in (GEOM_BOX, GEOM_MESH) and gi[0] == GEOM_CAPSULE:
+                pair_rows.append(((gi[0], gj[0]), gi, gj, 1))  # capsule_convex fills two contact slots
+    pair_rows.sort(key=lambda r: r[0])  # stable: geom order inside a group, a pair's two slots next to each other
     pair_body, pair_geom = [], []
-    for _, gi, gj in pair_rows:
+    # hull section: the convex geoms that take part in a pair, vertices / normals in the BODY frame
+    hull_of: Dict[int, int] = {}
+    hull_body: List[int] = []
+    hull_vadr, hull_fadr, hull_eadr, hull_face_adr = [0], [0], [0], [0]
+    hull_vert: List[List[float]] = []
+    hull_fidx: List[int] = []
+    hull_fnormal: List[List[float]] = []
+    hull_edge: List[List[int]] = []
+    hull_enormal: List[List[float]] = []
+    for _, gi, gj, slot in pair_rows:
         pair_body += [gi[1], gj[1]]
-        for g_ in (gi, gj):
+        hid = -1
+        if gj[0] in (GEOM_BOX, GEOM_MESH):
+            if id(gj) not in hull_of:
+                if gj[0] == GEOM_BOX:
+                    local = np.asarray([[sx * gj[4][0], sy * gj[4][1], sz * gj[4][2]] for sx in (-1.0, 1.0) for sy in (-1.0, 1.0) for sz in (-1.0, 1.0)])
+                else:
+                    local = gj[8]
+                faces_, fn_, edges_, en_ = hull_topology(local)
+                v0 = len(hull_vert)
+                hull_of[id(gj)] = len(hull_body)
+                hull_body.append(gj[1])
+                hull_vert += [list(np.asarray(gj[2]) + _qrot(gj[3], v)) for v in local]
+                for f_, n_ in zip(faces_, fn_):
+                    hull_fidx += [v0 + i for i in f_]
+                    hull_face_adr.append(len(hull_fidx))
+                    hull_fnormal.append(list(_qrot(gj[3], n_)))
+                hull_edge += [[v0 + int(a), v0 + int(b)] for a, b in edges_]
+                hull_enormal += [[*_qrot(gj[3], n2[0]), *_qrot(gj[3], n2[1])] for n2 in en_]
+                hull_vadr.append(len(hull_vert)); hull_fadr.append(len(hull_fnormal)); hull_eadr.append(len(hull_edge))
+            hid = hull_of[id(gj)]
+        for g_, tag in ((gi, float(hid + 1)), (gj, float(slot))):
             half = _qrot(g_[3], [0, 0, 1.0]) * g_[4][1] if g_[0] == GEOM_CAPSULE else np.zeros(3)
-            pair_geom += [*g_[2], *half, g_[4][0], 0.0]
+            pair_geom += [*g_[2], *half, g_[4][0] if g_[0] in (GEOM_SPHERE, GEOM_CAPSULE) else 0.0, tag]  # [7]: hull + 1 (0: none), [15]: slot of a two-contact pair
         con_bodyid.append(gj[1])
         con_lpos.append([0.0, 0.0, 0.0])
         con_radius.append(0.0)
@@ -535,7 +627,9 @@ def compile_model(spec: ModelSpec) -> CompiledModel:
     put("level_adr", level_adr, np.int32)
     put("level_body", level_body, np.int32)
     put("root_body", root_body, np.int32)
-    put("body_subtree_mask", _m64(subtree), np.int32)
+    # bodies 0 .. 63 of every body's subtree, then (models with more than 64 bodies only) bodies 64 .. 127 of every body's subtree
+    lo64 = (1 << 64) - 1
+    put("body_subtree_mask", np.concatenate([_m64([m & lo64 for m in subtree])] + ([_m64([m >> 64 for m in subtree])] if nbody > 64 else [])), np.int32)
     put("body_ancdof_mask", _m64(ancdof), np.int32)
     put("dof_velmask", _m64(velmask), np.int32)
     put("dof_qposadr", dof_qposadr, np.int32)
@@ -585,6 +679,17 @@ def compile_model(spec: ModelSpec) -> CompiledModel:
     put("cvx_vert", np.reshape(cvx_vert, (ncvxvert, 3)))
     put("pair_body", np.reshape(pair_body, (npair, 2)), np.int32)
     put("pair_geom", np.reshape(pair_geom, (npair, 16)))
+    put("nhull", len(hull_body), np.int32)
+    put("hull_body", hull_body, np.int32)
+    put("hull_vadr", hull_vadr, np.int32)
+    put("hull_fadr", hull_fadr, np.int32)
+    put("hull_eadr", hull_eadr, np.int32)
+    put("hull_face_adr", hull_face_adr, np.int32)
+    put("hull_fidx", hull_fidx, np.int32)
+    put("hull_edge", np.reshape(hull_edge, (len(hull_edge), 2)), np.int32)
+    put("hull_vert", np.reshape(hull_vert, (len(hull_vert), 3)))
+    put("hull_fnormal", np.reshape(hull_fnormal, (len(hull_fnormal), 3)))
+    put("hull_enormal", np.reshape(hull_enormal, (len(hull_enormal), 6)))
     put("lim_jntid", lim_jnt, np.int32)
     put("contact_solref", spec.contact_solref)
     put("contact_solimp", spec.contact_solimp)
@@ -747,18 +852,20 @@ _BLOB_F32 = [
 ]
 _HDR_INT = ["nq", "nv", "nu", "nbody", "njnt", "ncon", "nlimit", "iterations", "ls_iterations", "nlevel", "nroot", "include_c_vals", "npair"]
 _HDR_F32 = ["timestep", "tolerance", "ls_tolerance", "impratio", "plane_z", "meaninertia"]
-_HDR_INT2 = ["ncvx", "ncvxvert"]  # words 33..: dims that arrived after the first header block was full
+_HDR_INT2 = ["ncvx", "ncvxvert", "hull_words"]  # words 33..: dims that arrived after the first header block was full (hull_words: length of the hull section behind the table part)
 BLOB_HEADER_WORDS = 64  # fixed-size header; array directory follows
 
 
 def _to_blob(cm: CompiledModel, include_c_vals: bool = True) -> bytes:
     """Packs the model into one little-endian blob of 4-byte words.
 
-    word 0: magic, 1: version, 2: total words, 3..: header ints (see _HDR_INT),
-    words 16..: header floats (see _HDR_F32), words 32..63: reserved.
+    word 0: magic, 1: version, 2: total words of the TABLE part, 3..: header ints (see _HDR_INT),
+    words 16..: header floats (see _HDR_F32), word 32: number of arrays, 33..: _HDR_INT2, the rest reserved.
     Then a directory of (offset_words, count) pairs for every array in
-    _BLOB_INT + _BLOB_F32 order, then the arrays (each padded to 4 words).
-    The C side (csrc/model_blob.h) mirrors this layout.
+    _BLOB_INT + _BLOB_F32 order, then the arrays (each padded to 4 words) - the table part: what the environment kernel copies
+    into LDS.  Behind it, if the model has convex geoms in geom-geom pairs, the HULL SECTION (header word `hull_words`; read from
+    global memory, a few lines per step): eight words (nhull, nvert, nface, nfidx, nedge, 0, 0, 0), then the arrays of
+    _HULL_ARRAYS in that order, each padded to 4 words.  The C side (csrc/model_view.h) mirrors this layout.
     """
     t = cm.t
     names = _BLOB_INT + _BLOB_F32
@@ -788,15 +895,31 @@ def _to_blob(cm: CompiledModel, include_c_vals: bool = True) -> bytes:
     for i, k in enumerate(_HDR_F32):
         struct.pack_into("<f", hdr, 4 * (16 + i), float(t[k]))
     struct.pack_into("<i", hdr, 4 * 32, ndir)
+    hull = _hull_section(t)
     for i, k in enumerate(_HDR_INT2):
-        struct.pack_into("<i", hdr, 4 * (33 + i), int(t[k]))
+        struct.pack_into("<i", hdr, 4 * (33 + i), len(hull) // 4 if k == "hull_words" else int(t[k]))
     d = bytearray()
     for off, n in dir_entries:
         d += struct.pack("<2i", off, n)
     d += b"\0" * (4 * (base - BLOB_HEADER_WORDS - 2 * ndir))
     blob = bytes(hdr) + bytes(d) + bytes(payload)
     assert len(blob) == 4 * total, (len(blob), total)
-    return blob
+    return blob + hull
+
+
+_HULL_ARRAYS = [("hull_vadr", "<i4"), ("hull_fadr", "<i4"), ("hull_eadr", "<i4"), ("hull_face_adr", "<i4"), ("hull_fidx", "<i4"), ("hull_edge", "<i4"),
+                ("hull_vert", "<f4"), ("hull_fnormal", "<f4"), ("hull_enormal", "<f4")]
+
+
+def _hull_section(t: Dict[str, np.ndarray]) -> bytes:
+    nh = int(t["nhull"]) if "nhull" in t else 0
+    if nh == 0:
+        return b""
+    out = bytearray(struct.pack("<8i", nh, len(t["hull_vert"]), len(t["hull_fnormal"]), len(t["hull_fidx"]), len(t["hull_edge"]), 0, 0, 0))
+    for k, dt in _HULL_ARRAYS:
+        raw = np.ascontiguousarray(t[k]).reshape(-1).astype(dt).tobytes()
+        out += raw + b"\0" * ((-len(raw)) % 16)
+    return bytes(out)
 
 
 # ---------------------------------------------------------------------------
@@ -887,6 +1010,43 @@ def synth_stompy_pro_sc() -> ModelSpec:
     return _humanoid("synth_stompy_pro_sc", arms=False, self_collide=True)
 
 
+def synth_stompy_frames() -> ModelSpec:
+    """synth_stompy_full the way an export leaves a robot: every link carries three jointless frames (sensor / fastener / cover bodies with a
+    little mass, which MuJoCo keeps as bodies of their own), and each hand two two-link fingers behind them - 93 bodies with the world, 34
+    dofs: beyond the 64 bodies one mask word covers (the run-time-sized kernel's two-word subtree sets; bodies and dofs past index 64)."""
+    spec = _humanoid("synth_stompy_frames", arms=True)
+    links = list(spec.bodies)
+    frames = []
+    for bi, b in enumerate(links):
+        for k in range(3):
+            off = (0.02 * (k - 1), 0.015 * ((bi + k) % 3 - 1), -0.03 * k)
+            frames.append(BodySpec(f"{b.name}_frame{k}", b.name, pos=off, quat=_normalize((1.0, 0.1 * k, 0.05 * bi % 0.3, 0.0)), mass=0.02 + 0.01 * k,
+                                   inertia=(2e-5, 3e-5, 4e-5), ipos=(0.0, 0.005, 0.0)))
+    fingers = []
+    for side in ("left", "right"):
+        for f in range(2):
+            y = 0.015 * (2 * f - 1)
+            fingers.append(BodySpec(f"{side}_finger{f}_a", f"{side}_hand", pos=(0.0, y, -0.09), mass=0.05, inertia=(2e-5, 2e-5, 1e-5), ipos=(0.0, 0.0, -0.02),
+                                    joints=[JointSpec(f"{side}_finger{f}_a", JNT_HINGE, axis=(0, 1, 0), range=(-0.2, 1.2), damping=0.05, armature=0.002)]))
+            fingers.append(BodySpec(f"{side}_finger{f}_b", f"{side}_finger{f}_a", pos=(0.0, 0.0, -0.04), mass=0.03, inertia=(1e-5, 1e-5, 5e-6), ipos=(0.0, 0.0, -0.015),
+                                    joints=[JointSpec(f"{side}_finger{f}_b", JNT_HINGE, axis=(0, 1, 0), range=(-0.2, 1.2), damping=0.05, armature=0.002)],
+                                    geoms=[GeomSpec(GEOM_SPHERE, (0.012,), pos=(0.0, 0.0, -0.03))]))
+    # in document order (depth first), as MuJoCo numbers the bodies of an MJCF: a link, its frames, then the next link of the chain
+    everything = links + frames + fingers
+    ordered: List[BodySpec] = []
+
+    def visit(parent: str) -> None:
+        for b in everything:
+            if b.parent == parent:
+                ordered.append(b)
+                visit(b.name)
+
+    visit("world")
+    spec.bodies = ordered
+    spec.actuators = spec.actuators + [ActuatorSpec(b.joints[0].name, kp=2.0, ctrlrange=(-1.0, 1.0), forcerange=(-2.0, 2.0)) for b in fingers]
+    return spec
+
+
 def synth_tumblers() -> ModelSpec:
     """Three free bodies (sphere, two capsules) that collide with each other and with the ground: all three pair routines,
     several kinematic trees."""
@@ -958,6 +1118,7 @@ BUILTIN_MODELS = {
     "synth_stompy_pro": synth_stompy_pro,
     "synth_stompy_full": synth_stompy_full,
     "synth_stompy_pro_sc": synth_stompy_pro_sc,
+    "synth_stompy_frames": synth_stompy_frames,
     "synth_tumblers": synth_tumblers,
     "synth_pendulum": synth_pendulum,
     "synth_ball": synth_ball,

@@ -90,6 +90,116 @@ inline void closest_segment_points(V3 a0, V3 a1, V3 b0, V3 b1, V3& best_a, V3& b
   const V3 e1 = sub3(new_a, best_b), e2 = sub3(new_b, best_a);
   if (dot3(e1, e1) < dot3(e2, e2)) best_a = new_a; else best_b = new_b;
 }
+// ---- sphere / capsule against a convex hull (MJX collision_convex._sphere_convex / _capsule_convex), everything in the hull's frame.
+// Written out the way the NumPy oracle states it: per-plane candidate arrays, then the argmax / argmin over them.
+struct HullRef {
+  const int* face_adr; const int* fidx; const int* edge; const float* vert; const float* fnormal; const float* enormal;
+  int f0, f1, e0, e1;
+};
+inline int best_face(const HullRef& H, V3 c0, V3 c1, float r, bool& has_support) {
+  std::vector<float> sup(H.f1 - H.f0);
+  has_support = true;
+  for (int f = H.f0; f < H.f1; ++f) {
+    const V3 n = ld3(H.fnormal + 3 * f), v0 = ld3(H.vert + 3 * H.fidx[H.face_adr[f]]);
+    const float a = dot3(sub3(c0, v0), n) - r, b = dot3(sub3(c1, v0), n) - r;
+    const float sp = std::min(a, b);
+    if (!(sp < 0.f)) has_support = false;
+    sup[f - H.f0] = sp >= 0.f ? -1e12f : sp;
+  }
+  return H.f0 + (int)(std::max_element(sup.begin(), sup.end()) - sup.begin());  // (the first maximum)
+}
+inline void sphere_convex(const HullRef& H, V3 sp, float r, float& dist, V3& pos, V3& nrm) {
+  bool hs;
+  const int f = best_face(H, sp, sp, r, hs);
+  const V3 n = ld3(H.fnormal + 3 * f);
+  const int a0 = H.face_adr[f], m = H.face_adr[f + 1] - a0;
+  auto P = [&](int i) { return ld3(H.vert + 3 * H.fidx[a0 + ((i % m) + m) % m]); };
+  V3 pt = sub3(sp, mul3(n, dot3(sub3(sp, P(0)), n)));
+  std::vector<float> ed(m);
+  bool inside = true;
+  for (int i = 0; i < m; ++i) {
+    const V3 p0 = P(i - 1), p1 = P(i), en = cross3(sub3(p1, p0), n);
+    const float d = dot3(sub3(pt, p0), en);
+    if (d > 0.f) inside = false;
+    const bool degenerate = en.x == 0.f && en.y == 0.f && en.z == 0.f;
+    ed[i] = (degenerate || d < 0.f) ? 1e12f : d;
+  }
+  if (!inside) {
+    const int i = (int)(std::min_element(ed.begin(), ed.end()) - ed.begin());
+    pt = closest_segment_point(P(i - 1), P(i), pt);
+  }
+  float d;
+  nrm = normalize_norm(sub3(pt, sp), d);
+  dist = d - r;
+  pos = mul3(add3(pt, add3(sp, mul3(nrm, r))), 0.5f);
+}
+inline void capsule_convex(const HullRef& H, V3 cp, V3 half, float r, float* dist, V3* pos, V3* nrm) {
+  const V3 c0 = sub3(cp, half), c1 = add3(cp, half);
+  bool has_support;
+  const int f = best_face(H, c0, c1, r, has_support);
+  const V3 n = ld3(H.fnormal + 3 * f), nn = mul3(n, -1.f);
+  const int a0 = H.face_adr[f], m = H.face_adr[f + 1] - a0;
+  auto P = [&](int i) { return ld3(H.vert + 3 * H.fidx[a0 + ((i % m) + m) % m]); };
+  // clip the segment against the face's side planes
+  std::vector<V3> cand(m);
+  std::vector<char> in0(m), in1(m);
+  const V3 dir = sub3(c1, c0);
+  bool both = false;
+  for (int i = 0; i < m; ++i) {
+    const V3 p0 = P(i - 1), en = cross3(sub3(P(i), p0), n);
+    in0[i] = dot3(sub3(c0, p0), en) > 1e-6f;
+    in1[i] = dot3(sub3(c1, p0), en) > 1e-6f;
+    both = both || (in0[i] && in1[i]);
+    const float denom = dot3(dir, en);
+    cand[i] = add3(c0, mul3(dir, dot3(sub3(p0, c0), en) / (denom + (denom == 0.f ? 1e-6f : 0.f))));
+  }
+  auto clip_point = [&](V3 p0, V3 p1, const std::vector<char>& in_front) {
+    int bi = 0;
+    float bd = 0.f;
+    for (int i = 0; i < m; ++i) {
+      const float d = dot3(sub3(in_front[i] ? cand[i] : p0, p0), sub3(p1, p0));
+      if (i == 0 || d > bd) { bd = d; bi = i; }
+    }
+    return in_front[bi] ? cand[bi] : p0;
+  };
+  V3 q0 = clip_point(c0, c1, in0), q1 = clip_point(c1, c0, in1);
+  bool mask = !both;
+  if (!mask) { q0 = c0; q1 = c1; }
+  if (dot3(sub3(c0, c1), sub3(q0, q1)) < 0.f) mask = false;
+  float fpen[2];
+  const V3 q[2] = {sub3(q0, mul3(n, r)), sub3(q1, mul3(n, r))};
+  for (int j = 0; j < 2; ++j) {
+    const V3 fp = sub3(q[j], mul3(n, dot3(sub3(q[j], P(0)), n)));
+    pos[j] = mul3(add3(q[j], fp), 0.5f);
+    fpen[j] = (mask && has_support) ? dot3(sub3(fp, q[j]), n) : -1.f;
+  }
+  // nearest hull edge
+  int ew = H.e0;
+  float dmin = 0.f;
+  for (int e = H.e0; e < H.e1; ++e) {
+    V3 pe, pc;
+    closest_segment_points(ld3(H.vert + 3 * H.edge[2 * e]), ld3(H.vert + 3 * H.edge[2 * e + 1]), c0, c1, pe, pc);
+    const V3 dl = sub3(pe, pc);
+    const float d = std::sqrt(dot3(dl, dl));
+    if (e == H.e0 || d < dmin) { dmin = d; ew = e; }
+  }
+  V3 pe, pc;
+  closest_segment_points(ld3(H.vert + 3 * H.edge[2 * ew]), ld3(H.vert + 3 * H.edge[2 * ew + 1]), c0, c1, pe, pc);
+  const V3 edir = sub3(pe, pc);
+  const bool degenerate = dot3(edir, edir) < 1e-6f;
+  float edist;
+  const V3 eaxis = normalize_norm(edir, edist);
+  const bool front = dot3(ld3(H.enormal + 6 * ew), eaxis) < 0.f && dot3(ld3(H.enormal + 6 * ew + 3), eaxis) < 0.f;
+  const float epen = (!degenerate && front) ? r - edist : -1.f;
+  const bool parallel = std::fabs(dot3(eaxis, n)) > 0.99f && !degenerate;
+  const float minf = std::min(fpen[0], fpen[1]);
+  const bool has_edge = epen > 0.f && (minf > 0.f ? epen < minf : true) && !parallel;
+  if (has_edge) pos[0] = mul3(add3(pe, add3(pc, mul3(eaxis, r))), 0.5f);
+  nrm[0] = has_edge ? eaxis : nn;
+  nrm[1] = nn;
+  dist[0] = -(has_edge ? epen : fpen[0]);
+  dist[1] = -(has_edge ? -1.f : fpen[1]);
+}
 inline V3 frame_tangent(V3 n) {  // second row of MJX math.make_frame for a unit n
   V3 b = (n.y > -0.5f && n.y < 0.5f) ? V3{0.f, 1.f, 0.f} : V3{0.f, 0.f, 1.f};
   b = sub3(b, mul3(n, dot3(n, b)));
@@ -125,6 +235,10 @@ struct Model {
   int obs_dim, obs_pad, rec_dim;
   float timestep, tolerance, ls_tolerance, impratio, plane_z, meaninertia;
   int off[BLOB_ARRAY_COUNT];
+  int hull_base = 0;  // word offset of the hull section (0: none)
+  mppo::HullView hv{};
+  const int* HI(int o) const { return blob.data() + hull_base + o; }
+  const float* HF(int o) const { return reinterpret_cast<const float*>(blob.data()) + hull_base + o; }
   const int* I(int k) const { return blob.data() + off[k]; }
   const float* F(int k) const { return reinterpret_cast<const float*>(blob.data()) + off[k]; }
 };
@@ -352,6 +466,27 @@ float forward(const Model& m, Work& w, const float* qpos, const float* qvel, con
     const float* gp = m.F(BF_pair_geom) + 16 * k;
     const Q4 q1 = ld4(&w.xquat[4 * b1]), q2 = ld4(&w.xquat[4 * b2]);
     const V3 c1 = add3(ld3(&w.xpos[3 * b1]), qrot(q1, ld3(gp))), h1 = qrot(q1, ld3(gp + 3));
+    if (gp[7] != 0.f) {  // geom 2 is a convex hull fixed to b2: in b2's frame, then back
+      if (gp[15] != 0.f) continue;  // (second slot of a capsule's pair: filled with the first)
+      const int hid = (int)gp[7] - 1;
+      const HullRef H{m.HI(m.hv.face_adr), m.HI(m.hv.fidx), m.HI(m.hv.edge), m.HF(m.hv.vert), m.HF(m.hv.fnormal), m.HF(m.hv.enormal),
+                      m.HI(m.hv.fadr)[hid], m.HI(m.hv.fadr)[hid + 1], m.HI(m.hv.eadr)[hid], m.HI(m.hv.eadr)[hid + 1]};
+      const Q4 q2i = {q2.w, -q2.x, -q2.y, -q2.z};
+      const V3 x2 = ld3(&w.xpos[3 * b2]);
+      const V3 cp = qrot(q2i, sub3(c1, x2)), hh = qrot(q2i, h1);
+      float dist[2];
+      V3 pos[2], nrm[2];
+      int cnt = 1;
+      if (gp[3] != 0.f || gp[4] != 0.f || gp[5] != 0.f) { capsule_convex(H, cp, hh, gp[6], dist, pos, nrm); cnt = 2; }
+      else sphere_convex(H, cp, gp[6], dist[0], pos[0], nrm[0]);
+      for (int j = 0; j < cnt; ++j) {
+        const V3 n = qrot(q2, nrm[j]), t1 = frame_tangent(n);
+        w.condist[c + j] = dist[j];
+        st3(&w.conpos[3 * (c + j)], add3(x2, qrot(q2, pos[j])));
+        st3(&w.confr[9 * (c + j)], n); st3(&w.confr[9 * (c + j) + 3], t1); st3(&w.confr[9 * (c + j) + 6], cross3(n, t1));
+      }
+      continue;
+    }
     const V3 c2 = add3(ld3(&w.xpos[3 * b2]), qrot(q2, ld3(gp + 8))), h2 = qrot(q2, ld3(gp + 11));
     V3 p1, p2;
     closest_segment_points(sub3(c1, h1), add3(c1, h1), sub3(c2, h2), add3(c2, h2), p1, p2);
@@ -574,8 +709,14 @@ void* twin_model_open(const void* host_blob, size_t nbytes) {
   const int32_t* wi = static_cast<const int32_t*>(host_blob);
   const uint32_t* wu = static_cast<const uint32_t*>(host_blob);
   const float* wf = static_cast<const float*>(host_blob);
-  if (nbytes < 4 * (size_t)kBlobHeaderWords || wu[0] != kBlobMagic || wu[1] != kBlobVersion || wi[32] != BLOB_ARRAY_COUNT || (size_t)wu[2] * 4 != nbytes) return nullptr;
+  if (nbytes < 4 * (size_t)kBlobHeaderWords || wu[0] != kBlobMagic || wu[1] != kBlobVersion || wi[32] != BLOB_ARRAY_COUNT || ((size_t)wu[2] + (size_t)wu[35]) * 4 != nbytes) return nullptr;
   Model* m = new Model();
+  if (wu[35] > 0) {
+    m->hull_base = (int)wu[2];
+    const int32_t* hs = wi + wu[2];
+    m->hv = hull_view(hs[0], hs[1], hs[2], hs[3], hs[4]);
+    if ((uint32_t)m->hv.words != wu[35]) { delete m; return nullptr; }
+  }
   m->blob.assign(wi, wi + nbytes / 4);
   m->nq = wi[3]; m->nv = wi[4]; m->nu = wi[5]; m->nb = wi[6]; m->njnt = wi[7]; m->ncon = wi[8]; m->nlim = wi[9]; m->iterations = wi[10]; m->ls_iterations = wi[11];
   m->nroot = wi[13]; m->include_c = wi[14] ? 1 : 0; m->npair = wi[15]; m->ncvx = wi[33];

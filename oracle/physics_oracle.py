@@ -202,6 +202,134 @@ def sphere_sphere(pos1, r1, pos2, r2):
     return dist, pos1 + n * (r1 + 0.5 * dist)[..., None], n
 
 
+class Hull:
+    """One convex geom as sphere_convex / capsule_convex see it (MJX ConvexInfo): vertices, polygon faces (vertex lists,
+    counter-clockwise seen from outside), outward face normals, edges and the two face normals beside each edge - all in the frame
+    of the BODY the geom is fixed to (MJX works in the geom's frame; the geom's pose in its body is folded into the tables)."""
+
+    def __init__(self, t, h, dtype):
+        v0 = int(t["hull_vadr"][h])
+        self.vert = np.asarray(t["hull_vert"][v0:int(t["hull_vadr"][h + 1])], dtype)
+        f0, f1 = int(t["hull_fadr"][h]), int(t["hull_fadr"][h + 1])
+        self.faces = [np.asarray(t["hull_fidx"][int(t["hull_face_adr"][f]):int(t["hull_face_adr"][f + 1])]) - v0 for f in range(f0, f1)]
+        self.fnormal = np.asarray(t["hull_fnormal"][f0:f1], dtype)
+        e0, e1 = int(t["hull_eadr"][h]), int(t["hull_eadr"][h + 1])
+        self.edge = np.asarray(t["hull_edge"][e0:e1]) - v0
+        self.enormal = np.asarray(t["hull_enormal"][e0:e1], dtype).reshape(-1, 2, 3)
+
+
+def _face_support(hull, pts, r):
+    """min over the points `pts` [N, P, 3] of (p - n r - face[0]) . n for every face -> [N, F] (MJX get_support)."""
+    v0 = np.stack([hull.vert[f[0]] for f in hull.faces])                              # [F, 3]
+    return np.min(np.einsum("npfk,fk->npf", pts[:, :, None, :] - v0[None, None], hull.fnormal) - r, axis=1)
+
+
+def sphere_convex(sp, r, hull):
+    """MJX collision_convex._sphere_convex ([3P-recall]: MuJoCo 3.1 / 3.2; not present under /root/reference), batched: sphere
+    centre `sp` [N, 3] in the hull's frame.  The face with the least penetration among those the sphere's lowest point is behind
+    (argmax of the support, faces with support >= 0 masked to -1e12); the sphere centre projected on that face's plane and, if it
+    falls outside the polygon, on the nearest edge it is in front of.  -> dist [N], pos [N, 3], normal [N, 3] (sphere -> hull)."""
+    dt = sp.dtype
+    N = sp.shape[0]
+    support = _face_support(hull, sp[:, None, :], r)
+    support = np.where(support >= 0, dt.type(-1e12), support)
+    best = np.argmax(support, axis=1)
+    pt_out = np.zeros((N, 3), dt)
+    for f in np.unique(best):
+        sel = best == f
+        poly, n = hull.vert[hull.faces[f]], hull.fnormal[f]
+        c = sp[sel]
+        pt = c - ((c - poly[0]) @ n)[:, None] * n
+        p0, p1 = np.roll(poly, 1, axis=0), poly
+        en = np.cross(p1 - p0, n)                                                      # [m, 3] outward in the face's plane
+        ed = np.einsum("nmk,mk->nm", pt[:, None, :] - p0[None], en)
+        inside = np.all(ed <= 0, axis=1)
+        degenerate = np.all(en == 0, axis=1)
+        ed = np.where(degenerate[None] | (ed < 0), dt.type(1e12), ed)
+        idx = np.argmin(ed, axis=1)
+        edge_pt = closest_segment_point(p0[idx], p1[idx], pt)
+        pt_out[sel] = np.where(inside[:, None], pt, edge_pt)
+    n, d = _normalize_with_norm(pt_out - sp)
+    spt = sp + n * r
+    return d - r, (pt_out + spt) * dt.type(0.5), n
+
+
+def _clip_edge_to_planes(e0, e1, plane_pts, plane_normals):
+    """MJX / Brax clip_edge_to_planes, batched over the edge ([N, 3] ends) for one set of planes [m, 3]: an end in front of a
+    plane moves to the line's intersection with it (the candidate most along the edge wins); an edge with both ends in front of one
+    plane is kept as it is and masked out, and so is an edge whose ends crossed."""
+    dt = e0.dtype
+    in0 = np.einsum("nmk,mk->nm", e0[:, None, :] - plane_pts[None], plane_normals) > 1e-6
+    in1 = np.einsum("nmk,mk->nm", e1[:, None, :] - plane_pts[None], plane_normals) > 1e-6
+    dirn = e1 - e0
+    denom = dirn @ plane_normals.T                                                       # [N, m]
+    tt = np.einsum("nmk,mk->nm", plane_pts[None] - e0[:, None, :], plane_normals) / (denom + dt.type(1e-6) * (denom == 0))
+    cand = e0[:, None, :] + tt[..., None] * dirn[:, None, :]                             # [N, m, 3]
+    rows = np.arange(e0.shape[0])
+
+    def clip_point(p0, p1, in_front):
+        new = np.where(in_front[..., None], cand, p0[:, None, :])
+        dots = np.einsum("nmk,nk->nm", new - p0[:, None, :], p1 - p0)
+        return new[rows, np.argmax(dots, axis=1)]
+
+    n0, n1 = clip_point(e0, e1, in0), clip_point(e1, e0, in1)
+    mask = ~np.any(in0 & in1, axis=1)
+    n0 = np.where(mask[:, None], n0, e0)
+    n1 = np.where(mask[:, None], n1, e1)
+    mask = np.where(np.sum((e0 - e1) * (n0 - n1), -1) < 0, False, mask)
+    return n0, n1, mask
+
+
+def capsule_convex(cp, half, r, hull):
+    """MJX collision_convex._capsule_convex ([3P-recall], as above), batched: capsule centre `cp` and half-axis vector `half`
+    [N, 3] in the hull's frame.  Two slots: the capsule's segment clipped to the side planes of the best face (as in sphere_convex,
+    support = the lower of the two ends), each clipped end a contact against the face; slot 0 is replaced by an edge contact when the
+    hull edge nearest to the segment is in the segment's Voronoi region, penetrates by less than both face contacts and is not
+    parallel to the face normal.  -> dist [N, 2], pos [N, 2, 3], normal [N, 2, 3] (capsule -> hull); an unused slot has dist = 1."""
+    dt = cp.dtype
+    N = cp.shape[0]
+    c0, c1 = cp - half, cp + half
+    support = _face_support(hull, np.stack([c0, c1], axis=1), r)
+    has_support = np.all(support < 0, axis=1)
+    support = np.where(support >= 0, dt.type(-1e12), support)
+    best = np.argmax(support, axis=1)
+    pos = np.zeros((N, 2, 3), dt)
+    fpen = np.zeros((N, 2), dt)
+    normal = hull.fnormal[best]                                                          # [N, 3]
+    for f in np.unique(best):
+        sel = best == f
+        poly, n = hull.vert[hull.faces[f]], hull.fnormal[f]
+        p0, p1 = np.roll(poly, 1, axis=0), poly
+        en = np.cross(p1 - p0, n)
+        q0, q1, mask = _clip_edge_to_planes(c0[sel], c1[sel], p0, en)
+        for j, q in enumerate((q0, q1)):
+            q = q - n * r
+            fp = q - ((q - poly[0]) @ n)[:, None] * n
+            pos[sel, j] = (q + fp) * dt.type(0.5)
+            fpen[sel, j] = np.where(mask & has_support[sel], (fp - q) @ n, dt.type(-1))
+    # the shallow edge contact
+    ea, eb = hull.vert[hull.edge[:, 0]], hull.vert[hull.edge[:, 1]]                        # [E, 3]
+    E = ea.shape[0]
+    ep, cq = closest_segment_to_segment_points(np.broadcast_to(ea[None], (N, E, 3)), np.broadcast_to(eb[None], (N, E, 3)),
+                                                np.broadcast_to(c0[:, None, :], (N, E, 3)), np.broadcast_to(c1[:, None, :], (N, E, 3)))
+    edir = ep - cq
+    eaxis, edist = _normalize_with_norm(edir)
+    k = np.argmin(np.abs(edist), axis=1)
+    rows = np.arange(N)
+    eaxis, edist, ep, cq = eaxis[rows, k], edist[rows, k], ep[rows, k], cq[rows, k]
+    degenerate = np.sum(edir[rows, k] ** 2, -1) < 1e-6
+    front = np.all(np.einsum("njk,nk->nj", hull.enormal[k], eaxis) < 0, axis=1)
+    epen = np.where(~degenerate & front, r - edist, dt.type(-1))
+    epos = (ep + cq + eaxis * r) * dt.type(0.5)
+    parallel = (np.abs(np.sum(eaxis * normal, -1)) > 0.99) & ~degenerate
+    minf = fpen.min(axis=1)
+    has_edge = (epen > 0) & np.where(minf > 0, epen < minf, True) & ~parallel
+    pos[:, 0] = np.where(has_edge[:, None], epos, pos[:, 0])
+    nrm = np.stack([np.where(has_edge[:, None], eaxis, -normal), -normal], axis=1)
+    pen = np.stack([np.where(has_edge, epen, fpen[:, 0]), np.where(has_edge, dt.type(-1), fpen[:, 1])], axis=1)
+    return -pen, pos, nrm
+
+
 # ---------------------------------------------------------------------------
 # data container
 # ---------------------------------------------------------------------------
@@ -415,6 +543,25 @@ class Physics:
             c2 = d.xpos[:, b2] + qrot(d.xquat[:, b2], p2)
             a1 = qrot(d.xquat[:, b1], np.broadcast_to(h1, (N, 3)).astype(dt))
             a2 = qrot(d.xquat[:, b2], np.broadcast_to(h2, (N, 3)).astype(dt))
+            hid, slot = int(g[7]) - 1, int(g[15])
+            if hid >= 0:
+                # geom 2 is a convex hull (box / mesh) fixed to b2: work in b2's frame, come back to the world (MJX sphere_convex /
+                # capsule_convex); a capsule's pair owns two consecutive slots and is computed at the first
+                if slot == 1:
+                    continue
+                R2 = qmat(d.xquat[:, b2])
+                to_hull = lambda v: np.einsum("nji,nj->ni", R2, v)
+                hull = Hull(t, hid, dt)
+                if np.any(h1 != 0):
+                    dd, pp, nn = capsule_convex(to_hull(c1 - d.xpos[:, b2]), to_hull(a1), dt.type(r1), hull)
+                else:
+                    dd, pp, nn = sphere_convex(to_hull(c1 - d.xpos[:, b2]), dt.type(r1), hull)
+                    dd, pp, nn = dd[:, None], pp[:, None], nn[:, None]
+                for j in range(dd.shape[1]):
+                    dist[:, c + j] = dd[:, j]
+                    cpos[:, c + j] = d.xpos[:, b2] + np.einsum("nij,nj->ni", R2, pp[:, j])
+                    frame[:, c + j] = make_frame(np.einsum("nij,nj->ni", R2, nn[:, j]))
+                continue
             q1, q2 = closest_segment_to_segment_points(c1 - a1, c1 + a1, c2 - a2, c2 + a2)
             dist[:, c], cpos[:, c], nn = sphere_sphere(q1, r1, q2, r2)
             frame[:, c] = make_frame(nn)

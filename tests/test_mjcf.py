@@ -206,7 +206,7 @@ def test_box_geom_collides_through_its_eight_corners(tmp_path):
 def test_collision_masks_generate_the_pairs_mujoco_would_test(tmp_path):
     """SURVEY 8(f1) body-body pairs.  With MuJoCo's default masks (contype = conaffinity = 1) every sphere / capsule pair on
     different bodies is a candidate except parent-child pairs and bodies welded together; contype / conaffinity remove pairs;
-    geom 1 of a mixed pair is the sphere.  A box that would have to meet another geom is an error."""
+    geom 1 of a mixed pair is the sphere.  A box meets the round geoms of other bodies as a convex hull."""
     import numpy as np
 
     from minppo_amd import mjcf
@@ -243,9 +243,11 @@ def test_collision_masks_generate_the_pairs_mujoco_would_test(tmp_path):
     # plane contype 1 & d conaffinity 0 = 0) neither the plane nor anybody
     cm2, pb2 = pairs(xml(extra_d='contype="2" conaffinity="0"'))
     assert set(pb2) == {(1, 4)} and cm2.ncon == (2 + 1 + 1 + 2) + 1
-    # a box may stand on the ground, but not be paired with another geom
-    with pytest.raises(ValueError, match="box geom can only collide with the ground"):
-        pairs(xml(dtype="box", dsize="0.04 0.04 0.04"))
+    # a box meets spheres and capsules of other bodies as a convex hull (round 5; tests/test_convex_pairs.py): one slot per sphere, two per
+    # capsule, after the groups of the round geoms among themselves - (sphere, box) < (capsule, capsule) < (capsule, box) by MuJoCo's type ids
+    cmb, pbb = pairs(xml(dtype="box", dsize="0.04 0.04 0.04"))
+    assert pbb == [(2, 5), (3, 5), (1, 4), (4, 5), (4, 5)] and int(cmb.t["nhull"]) == 1 and cmb.ncon == (2 + 1 + 1 + 2 + 8) + 5
+    assert np.asarray(cmb.t["pair_geom"])[:, 7].tolist() == [1, 1, 0, 1, 1] and np.asarray(cmb.t["pair_geom"])[:, 15].tolist() == [0, 0, 0, 0, 1]
     cm3, pb3 = pairs(xml(dtype="box", dsize="0.04 0.04 0.04", extra_d='contype="0" conaffinity="1"').replace('name="ga" type="capsule"', 'name="ga" contype="0" type="capsule"')
                      .replace('name="gb" type="sphere"', 'name="gb" contype="0" type="sphere"').replace('name="gw" type="sphere"', 'name="gw" contype="0" type="sphere"')
                      .replace('name="gc" type="capsule"', 'name="gc" contype="0" type="capsule"'))
@@ -295,8 +297,8 @@ def test_mesh_geom_collides_as_its_convex_hull(tmp_path):
     ('<mesh name="rock" vertex="0 0 0 1 0 0 0 1 0"/>', 'contype="0"', "", "at least four vertices"),
     ('<mesh name="rock" vertex="0 0 0 1 0 0 0 1 0 1 1 0 0.5 0.5 0"/>', 'contype="0"', "", "degenerate mesh"),
     (f'<mesh name="rock" vertex="{CUBE_PLUS}"/>', "", '<body name="b2" pos="0 0 0.2"><joint name="j" axis="0 1 0"/><inertial pos="0 0 0" mass="1" diaginertia="1 1 1"/>'
-     '<body name="b3" pos="0 0 0.2"><joint name="j3" axis="0 1 0"/><inertial pos="0 0 0" mass="1" diaginertia="1 1 1"/><geom type="sphere" size="0.05"/></body></body>',
-     "can only collide with the ground plane"),
+     '<body name="b3" pos="0 0 0.2"><joint name="j3" axis="0 1 0"/><inertial pos="0 0 0" mass="1" diaginertia="1 1 1"/><geom type="box" size="0.05 0.05 0.05"/></body></body>',
+     "convex-convex pairs are not built"),
     ('<mesh name="rock" vertex="' + " ".join(f"{np.cos(a):.6f} {np.sin(a):.6f} {0.3 * np.cos(5 * a):.6f}" for a in np.linspace(0, 6.2, 80)) + '"/>', 'contype="0"', "", "decimate the collision mesh"),
 ])
 def test_mesh_geoms_outside_the_subset_are_loud_errors(asset, gattr, extra, msg):
