@@ -26,8 +26,11 @@ Subset
   <asset><mesh name vertex="x y z ..." | file="*.obj|*.stl" scale>: the collision geometry of mesh geoms (files relative to the MJCF,
             honouring <compiler meshdir>); everything else under <asset> is visual and ignored
   <actuator>: <position joint kp kv gear ctrlrange forcerange>, <motor joint gear ctrlrange forcerange>
-Contacts: geom-vs-ground-plane, and sphere / capsule geom pairs between bodies that MuJoCo would test (contype / conaffinity
-masks, same-body and parent-child pairs filtered); a box or mesh that the masks pair with another geom is an error (`compile_model`).
+  <contact><exclude body1 body2/>: no contacts between the geoms of these two bodies (<contact><pair> is an error)
+Contacts: geom-vs-ground-plane, and the geom pairs between bodies that MuJoCo would test (contype / conaffinity masks, same-body and
+parent-child pairs filtered, <exclude>d body pairs dropped): sphere / capsule among themselves, and a sphere or capsule against a box
+or a mesh hull of another body (MJX sphere_convex / capsule_convex); a box or mesh that the masks pair with another box or mesh is an
+error (`compile_model`).
 """
 
 from __future__ import annotations
@@ -673,6 +676,20 @@ def parse_mjcf(xml: str, name: str = "mjcf", base_dir: Optional[Path] = None) ->
     else:
         spec_kw["has_plane"] = False
         logger.warning("MJCF has no ground plane: only geom-geom contacts will be generated")
+    # <contact>: <exclude body1 body2/> removes every geom pair between two bodies (what exports use where neighbouring collision shapes overlap
+    # at rest); explicit <pair geom1 geom2 ...> elements carry contact parameters of their own and are not supported
+    known = {b.name for b in bodies}
+    excludes: List[Tuple[str, str]] = []
+    for sec in root.findall("contact"):
+        for el in sec:
+            if el.tag != "exclude":
+                raise ValueError(f"<contact><{el.tag}> is outside the supported MJCF subset (only <exclude body1 body2/>)")
+            b1, b2 = el.get("body1"), el.get("body2")
+            if b1 not in known or b2 not in known:
+                raise ValueError(f"<contact><exclude body1={b1!r} body2={b2!r}>: unknown body")
+            excludes.append((b1, b2))
+    if excludes:
+        spec_kw["contact_excludes"] = excludes
     return ModelSpec(name=name, bodies=bodies, actuators=acts, free_root_z=free_root_z, **spec_kw)
 
 
@@ -745,5 +762,9 @@ def to_mjcf(spec: ModelSpec) -> str:
             ET.SubElement(act, "position", kp=repr(float(a.kp)), kv=repr(float(a.kv)), **kw)
         else:
             ET.SubElement(act, "motor", **kw)
+    if spec.contact_excludes:
+        con = ET.SubElement(root, "contact")
+        for b1, b2 in spec.contact_excludes:
+            ET.SubElement(con, "exclude", body1=b1, body2=b2)
     ET.indent(root)
     return ET.tostring(root, encoding="unicode")

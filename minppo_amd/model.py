@@ -126,6 +126,7 @@ class ModelSpec:
     plane_conaffinity: int = 1
     has_plane: bool = True
     free_root_z: float = 1.0  # qpos0[2] of the (first) free joint
+    contact_excludes: List[Tuple[str, str]] = field(default_factory=list)  # MJCF <contact><exclude body1 body2/>: no geom pairs between these bodies
 
 
 # ---------------------------------------------------------------------------
@@ -539,13 +540,18 @@ def compile_model(spec: ModelSpec) -> CompiledModel:
         if body_jntnum[b] == 0:
             weld[b] = weld[body_parent[b]]
     pair_rows = []
+    excluded = set()
+    for n1, n2 in spec.contact_excludes:
+        if n1 not in names or n2 not in names:
+            raise ValueError(f"contact exclude ({n1!r}, {n2!r}): unknown body")
+        excluded.add(frozenset((names.index(n1), names.index(n2))))
     for i in range(len(geoms)):
         for j in range(i + 1, len(geoms)):
             gi, gj = geoms[i], geoms[j]
             if gi[0] > gj[0]:
                 gi, gj = gj, gi
             w1, w2 = weld[gi[1]], weld[gj[1]]
-            if w1 == w2:
+            if w1 == w2 or frozenset((gi[1], gj[1])) in excluded:
                 continue
             if w1 != 0 and w2 != 0 and (w1 == weld[body_parent[w2]] or w2 == weld[body_parent[w1]]):
                 continue

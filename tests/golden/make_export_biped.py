@@ -5,7 +5,9 @@ exercises in minppo_amd/mjcf.py: the model split over `<include file=...>` files
 sub-directories, one of them inside a `<body>`), repeated top-level sections that must merge (`<actuator>`, `<asset>`, `<default>`),
 nested `<default class>` trees with `childclass`, `meshdir` (an .obj collision mesh and a binary .stl visual mesh in millimetres),
 per-body `<inertial>` (some as `fullinertia`), dry joint friction on the defaults AND on two joints (stripped, env.py:41-45), collision
-filtering by contype / conaffinity (feet, toes and hands meet the ground only; the two shins meet each other).
+filtering by contype / conaffinity (toes and hands meet the ground only; the two shins meet each other; a FOOT MESH meets the ground and
+the shin capsule of the other leg - MJX capsule_convex, two slots per pair) and a `<contact><exclude>` file that takes out each leg's own
+shin / foot pair, whose shapes overlap at the ankle.
 
     python tests/golden/make_export_biped.py
 """
@@ -39,6 +41,7 @@ ROBOT = """<!-- authored for this repository's tests (not a reference file): see
       </body>
     </body>
   </worldbody>
+  <include file="contacts.xml"/>
   <include file="actuators_legs.xml"/>
   <include file="actuators_arms.xml"/>
 </mujoco>
@@ -58,6 +61,7 @@ DEFAULTS = """<mujocoinclude>
         <default class="knee"><joint range="0 2.2" damping="1.2"/></default>
         <default class="ankle"><joint range="-0.6 0.6" damping="0.3" armature="0.01"/></default>
         <default class="shin_collision"><geom contype="2" conaffinity="2" group="3"/></default>
+        <default class="foot_collision"><geom contype="1" conaffinity="2" group="3"/></default>
       </default>
       <default class="arm">
         <joint damping="0.2" range="-1.5 1.5"/>
@@ -102,7 +106,7 @@ def leg(side: str, sy: int) -> str:
             <body name="{side}_foot" pos="0 0 -0.03">
               <inertial pos="0.03 0 -0.02" mass="0.7" diaginertia="0.0008 0.0024 0.0028"/>
               <joint name="{side}_ankle_roll" axis="1 0 0" class="ankle" range="-0.35 0.35"/>
-              <geom type="mesh" mesh="foot" pos="0.02 0 -0.03" class="collision"/>
+              <geom type="mesh" mesh="foot" pos="0.02 0 -0.03" class="foot_collision"/>
               <body name="{side}_toe" pos="0.12 0 -0.035">
                 <inertial pos="0.02 0 0" mass="0.12" diaginertia="0.00004 0.00008 0.0001"/>
                 <joint name="{side}_toe" axis="0 1 0" range="-0.3 0.6" damping="0.05" stiffness="2.0"/>
@@ -174,6 +178,7 @@ def main() -> None:
     (OUT / "robot.xml").write_text(ROBOT)
     (OUT / "defaults.xml").write_text(DEFAULTS)
     (OUT / "assets.xml").write_text(ASSETS)
+    (OUT / "contacts.xml").write_text("<mujocoinclude>\n  <contact>\n" + "".join(f'    <exclude body1="{s}_shin" body2="{s}_foot"/>\n' for s in "lr") + "  </contact>\n</mujocoinclude>\n")
     (OUT / "parts" / "leg_left.xml").write_text(leg("l", 1))
     (OUT / "parts" / "leg_right.xml").write_text(leg("r", -1))
     (OUT / "parts" / "upper_body.xml").write_text("<mujocoinclude>\n" + arm("l", 1) + arm("r", -1) + HEAD + "</mujocoinclude>\n")

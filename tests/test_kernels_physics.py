@@ -637,7 +637,7 @@ def test_export_style_biped_compiles_steps_and_follows_the_oracle(be, model):
     The same for synth_stompy_frames: the arm-and-leg stand-in with three jointless frames on every link and fingers behind them - 93
     bodies, past the 64 one mask word covers (round 5: two-word subtree sets), an observation of 1575 values."""
     cm = load_model(MJCF_EXPORT if model == "export_biped" else model)
-    assert (cm.nv, cm.nu, int(cm.t["nbody"]), int(cm.t["ncvx"]), int(cm.t["npair"])) == ((33, 20, 29, 2, 1) if model == "export_biped" else (34, 28, 93, 0, 0))
+    assert (cm.nv, cm.nu, int(cm.t["nbody"]), int(cm.t["ncvx"]), int(cm.t["npair"])) == ((33, 20, 29, 2, 5) if model == "export_biped" else (34, 28, 93, 0, 0))
     h, dims, _keep = be.model(cm)
     flag = C.c_int32(-1)
     be.lib.model_is_specialized(h, C.byref(flag))

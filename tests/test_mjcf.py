@@ -342,7 +342,20 @@ def test_export_style_layout_includes_defaults_meshdir(caplog):
     w = np.linalg.eigvalsh(np.array([[0.045, 0.0008, -0.0004], [0.0008, 0.038, 0.0011], [-0.0004, 0.0011, 0.052]]))[::-1]
     np.testing.assert_allclose(by["pelvis"].inertia, w, rtol=1e-12)
     cm = compile_model(s)
-    assert (cm.nq, cm.nv, cm.nu) == (34, 33, 20) and int(cm.t["npair"]) == 1  # the shins' pair; feet / toes / hands meet the ground only
+    # pairs: the two shins; each shin capsule against the OTHER leg's foot mesh (capsule_convex: two slots each).  A leg's own shin / foot pair
+    # is a candidate by the masks too (the ankle body sits between them) and is taken out by contacts.xml's <exclude>; toes / hands: ground only
+    assert s.contact_excludes == [("l_shin", "l_foot"), ("r_shin", "r_foot")]
+    assert (cm.nq, cm.nv, cm.nu) == (34, 33, 20) and int(cm.t["npair"]) == 5 and int(cm.t["nhull"]) == 2
+    assert cm.t["pair_body"].tolist() == [[5, 12], [5, 14], [5, 14], [12, 7], [12, 7]]
+    s.contact_excludes = []
+    assert int(compile_model(s).t["npair"]) == 9
+    # the writer keeps the excludes; anything else under <contact> is an error
+    s.contact_excludes = [("l_shin", "l_foot"), ("r_shin", "r_foot")]
+    assert compile_model(mjcf.parse_mjcf(mjcf.to_mjcf(s))).t["pair_body"].tolist() == cm.t["pair_body"].tolist()
+    with pytest.raises(ValueError, match="only <exclude"):
+        mjcf.parse_mjcf(HAND.replace("<actuator>", '<contact><pair geom1="a" geom2="b"/></contact><actuator>'))
+    with pytest.raises(ValueError, match="unknown body"):
+        mjcf.parse_mjcf(HAND.replace("<actuator>", '<contact><exclude body1="base" body2="nobody"/></contact><actuator>'))
 
 
 def test_include_errors_are_loud(tmp_path):
