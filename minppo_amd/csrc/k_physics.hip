@@ -645,6 +645,38 @@ __global__ void __launch_bounds__(64 * kMaxWavesPerBlock) env_kernel(ModelView m
     FOR_G(c, nplane) {  // ground contacts (MJX plane_sphere / plane_capsule; a box corner is a sphere of radius 0; a convex geom's chosen vertices)
       const int b = TI(con_bodyid)[c];
       const Q4 q = ld4(xquat + 4 * b);
+      if (!kDims && mv.ncyl > 0 && TI(con_cvx)[c] <= -2) {
+        // a cylinder against the plane, MJX collision_primitive.plane_cylinder: three slots, placed by the lane that owns the first - the
+        // point of the lower rim nearest to the plane and two more of that rim 120 degrees to either side; lying on its side
+        // (|axis . n| half < 1e-3): the nearest point of the other rim in slot 1
+        if (TI(con_cvx)[c] != -2) continue;
+        const V3 ctr = add3(ld3(xpos + 3 * b), qrot(q, ld3(TF(con_lpos) + 3 * c)));
+        const V3 hv = ld3(TF(con_axis) + 3 * c);
+        const float half = sqrtf(dot3(hv, hv)), r = TF(con_radius)[c], height = ctr.z - mv.plane_z;
+        V3 axis = qrot(q, mul3(hv, 1.f / half));
+        const V3 xaxis = qrot(q, ld3(TF(con_axis) + 3 * (c + 1)));
+        float prjaxis = axis.z;
+        const float sign = prjaxis < 0.f ? 1.f : -1.f;  // the axis turned towards the plane
+        axis = mul3(axis, sign); prjaxis *= sign;
+        V3 vec = sub3(mul3(axis, prjaxis), V3{0.f, 0.f, 1.f});
+        const float len = sqrtf(dot3(vec, vec));
+        vec = len < 1e-12f ? mul3(xaxis, r) : mul3(vec, r / len);
+        const float prjvec = vec.z;
+        axis = mul3(axis, half); prjaxis *= half;
+        float nrm;
+        const V3 vec1 = mul3(normalize_norm(cross3(vec, axis), nrm), r * 0.8660254037844386f);
+        const float d1 = height + prjaxis + prjvec, d2 = height + prjaxis - 0.5f * prjvec, d3 = height - prjaxis + prjvec;
+        const bool side = fabsf(prjaxis) < 1e-3f;
+        const V3 hvv = mul3(vec, 0.5f);
+        const V3 r0 = add3(axis, vec), r1 = side ? sub3(vec, axis) : sub3(add3(axis, vec1), hvv), r2 = sub3(sub3(axis, vec1), hvv);
+        const float dd1 = side ? d3 : d2;
+        condist[c] = d1; condist[c + 1] = dd1; condist[c + 2] = d2;
+        st3(conpos + 3 * c, {ctr.x + r0.x, ctr.y + r0.y, ctr.z + r0.z - 0.5f * d1});
+        st3(conpos + 3 * (c + 1), {ctr.x + r1.x, ctr.y + r1.y, ctr.z + r1.z - 0.5f * dd1});
+        st3(conpos + 3 * (c + 2), {ctr.x + r2.x, ctr.y + r2.y, ctr.z + r2.z - 0.5f * d2});
+        for (int j = 0; j < 3; ++j) { st3(confr + 6 * (c + j), {0.f, 0.f, 1.f}); st3(confr + 6 * (c + j) + 3, {0.f, 1.f, 0.f}); }
+        continue;
+      }
       const int cs = ncvx > 0 ? TI(con_cvx)[c] : -1;
       const V3 centre = add3(ld3(xpos + 3 * b), qrot(q, cs >= 0 ? ld3(cvxsel + 3 * cs) : ld3(TF(con_lpos) + 3 * c)));
       const float rad = TF(con_radius)[c];
@@ -1611,12 +1643,27 @@ extern "C" int32_t mppo_model_open(const void* host_blob, size_t nbytes, const v
       !in_range(BI_act_dofid, 0, v.nv) || !in_range(BI_act_qposadr, 0, v.nq) || !in_range(BI_con_bodyid, 1, v.nbody) || !in_range(BI_pair_body, 1, v.nbody) ||
       !in_range(BI_lim_jntid, 0, v.njnt) || !in_range(BI_level_adr, 0, v.nbody) || !in_range(BI_level_body, 1, v.nbody) ||
       !in_range(BI_root_body, 1, v.nbody) || !in_range(BI_body_jntnum, 0, v.njnt + 1) || !in_range(BI_body_jntadr, -1, v.njnt) ||
-      !in_range(BI_con_cvx, -1, 4 * v.ncvx) || !in_range(BI_cvx_body, 1, v.nbody) || !in_range(BI_cvx_vadr, 0, v.ncvxvert + 1))
+      !in_range(BI_con_cvx, -4, 4 * v.ncvx) || !in_range(BI_cvx_body, 1, v.nbody) || !in_range(BI_cvx_vadr, 0, v.ncvxvert + 1))
     return bad("index table entry out of range");
   {
     const int32_t* va = HI(BI_cvx_vadr);
     for (int k = 0; k < v.ncvx; ++k) if (va[k + 1] < va[k] + 4 || va[k + 1] - va[k] > 64) return bad("a convex geom needs 4 .. 64 hull vertices");
     if (v.ncvx > 0 && (va[0] != 0 || va[v.ncvx] != v.ncvxvert)) return bad("cvx_vadr does not cover the vertex table");
+    // cylinders: slots -2, -3, -4 in a row among the ground contacts, a half-axis vector of non-zero length in the first
+    const int32_t* kind = HI(BI_con_cvx);
+    const float* cax = wf + dir[2 * BF_con_axis];
+    int ncyl = 0;
+    for (int c = 0; c < v.ncon; ++c) {
+      if (kind[c] > -2) continue;
+      if (c >= v.ncon - v.npair) return bad("a cylinder slot among the pair contacts");
+      if (kind[c] == -2) {
+        if (c + 2 >= v.ncon - v.npair || kind[c + 1] != -3 || kind[c + 2] != -4) return bad("a cylinder needs three consecutive ground-contact slots");
+        if (!(cax[3 * c] * cax[3 * c] + cax[3 * c + 1] * cax[3 * c + 1] + cax[3 * c + 2] * cax[3 * c + 2] > 0.f)) return bad("a cylinder with a zero half-axis");
+        ++ncyl;
+      } else if (c == 0 || kind[c - 1] != kind[c] + 1) return bad("a cylinder's second / third slot without its first");
+    }
+    if (ncyl != wi[36]) return bad("header ncyl does not match the contact table");
+    v.ncyl = ncyl;
   }
   {
     // the hull section: every index the kernel follows from a pair row to a hull, its faces, their vertex lists and its edges
@@ -1670,7 +1717,7 @@ extern "C" int32_t mppo_model_open(const void* host_blob, size_t nbytes, const v
   v.obs_dim = v.nq + 2 * v.nv + (v.include_c ? 16 * (v.nbody - 1) : 0);  // env.py:246-259
   v.obs_pad = (v.obs_dim + 3) & ~3;
   v.rec_dim = v.obs_pad + ((v.nv + 2 + 3) & ~3);
-  m->spec = v.hull_words > 0 ? -1 : find_spec(bd);  // (hull pairs: the run-time-sized kernel)
+  m->spec = v.hull_words > 0 || v.ncyl > 0 ? -1 : find_spec(bd);  // (hull pairs, cylinders: the run-time-sized kernel)
   // (a model-specialised kernel of up to 32 dofs keeps the inverse Cholesky factor in registers: no LL square in its layout)
   m->lds = make_phys_lds(v.nq, v.nv, v.nu, v.nbody, v.njnt, v.ncon, v.nefc, v.nroot, v.ncvx, m->spec >= 0 && v.nv <= 2 * kGroupLanes);
   // waves per workgroup: whatever puts the most waves on a CU (160 KB of LDS; every workgroup holds one copy of the model tables and

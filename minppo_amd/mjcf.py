@@ -18,11 +18,12 @@ Subset
   <worldbody>: one <geom type="plane"> (the ground), <body name pos quat|euler|axisangle|xyaxes|zaxis childclass>
       <inertial pos quat|euler mass diaginertia|fullinertia>
       <freejoint/> | <joint type="free|hinge|slide" name pos axis range limited ref damping armature stiffness>
-      <geom type="sphere|capsule|box|mesh" size pos quat|euler fromto friction mass density contype conaffinity mesh>
+      <geom type="sphere|capsule|cylinder|box|mesh" size pos quat|euler fromto friction mass density contype conaffinity mesh>
             (a box collides with the ground through its eight corners; a mesh collides with the ground as its CONVEX HULL, as in
-             MuJoCo / MJX - up to four contacts per step, MJX's plane_convex; type="cylinder|ellipsoid" geoms are accepted ONLY with
-             contype="0" conaffinity="0", i.e. visual or inertia-only, and then still contribute to inertiafromgeom; a mesh never
-             contributes an inertia: its body needs an <inertial>)
+             MuJoCo / MJX - up to four contacts per step, MJX's plane_convex; a cylinder meets the ground with three contacts per step,
+             MJX's plane_cylinder, and nothing else; type="ellipsoid" geoms are accepted ONLY with contype="0" conaffinity="0", i.e.
+             visual or inertia-only, and then still contribute to inertiafromgeom; a mesh never contributes an inertia: its body needs
+             an <inertial>)
   <asset><mesh name vertex="x y z ..." | file="*.obj|*.stl" scale>: the collision geometry of mesh geoms (files relative to the MJCF,
             honouring <compiler meshdir>); everything else under <asset> is visual and ignored
   <actuator>: <position joint kp kv gear ctrlrange forcerange>, <motor joint gear ctrlrange forcerange>
@@ -43,7 +44,7 @@ from typing import Dict, List, Optional, Sequence, Tuple
 
 import numpy as np
 
-from minppo_amd.model import (GEOM_BOX, GEOM_CAPSULE, GEOM_MESH, GEOM_SPHERE, JNT_FREE, JNT_HINGE, JNT_SLIDE, MAX_CONVEX_VERTS, ActuatorSpec, BodySpec, GeomSpec, JointSpec,
+from minppo_amd.model import (GEOM_BOX, GEOM_CAPSULE, GEOM_CYLINDER, GEOM_MESH, GEOM_SPHERE, JNT_FREE, JNT_HINGE, JNT_SLIDE, MAX_CONVEX_VERTS, ActuatorSpec, BodySpec, GeomSpec, JointSpec,
                               ModelSpec, _normalize, _qmat, _qmul)
 
 logger = logging.getLogger(__name__)
@@ -482,8 +483,8 @@ def parse_mjcf(xml: str, name: str = "mjcf", base_dir: Optional[Path] = None) ->
         part = (m, diag, pos, quat)
         if not collides:
             return "inert", None, part
-        if gtype not in ("sphere", "capsule", "box"):
-            raise ValueError(f"{what}: only sphere, capsule and box geoms can collide (a colliding {gtype} needs contype='0' conaffinity='0' or a capsule approximation)")
+        if gtype not in ("sphere", "capsule", "cylinder", "box"):
+            raise ValueError(f"{what}: only sphere, capsule, cylinder and box geoms can collide (a colliding {gtype} needs contype='0' conaffinity='0' or a capsule approximation)")
         for k in ("solref", "solimp"):
             if k in a:
                 solrefs["contact"].add((k, tuple(_floats(a[k]))))
@@ -492,7 +493,7 @@ def parse_mjcf(xml: str, name: str = "mjcf", base_dir: Optional[Path] = None) ->
         if int(a.get("condim", "3")) != 3:
             raise ValueError(f"{what}: condim {a['condim']} (only 3: pyramidal sliding friction)")
         fr = tuple((_floats(a["friction"]) + [0.005, 0.0001])[:3]) if "friction" in a else (1.0, 0.005, 0.0001)
-        gs = GeomSpec({"sphere": GEOM_SPHERE, "capsule": GEOM_CAPSULE, "box": GEOM_BOX}[gtype], tuple(size[:need]), pos=tuple(pos), quat=tuple(quat), friction=fr,
+        gs = GeomSpec({"sphere": GEOM_SPHERE, "capsule": GEOM_CAPSULE, "cylinder": GEOM_CYLINDER, "box": GEOM_BOX}[gtype], tuple(size[:need]), pos=tuple(pos), quat=tuple(quat), friction=fr,
                       contype=contype, conaffinity=conaff)
         return "collide", gs, part
 
@@ -749,7 +750,7 @@ def to_mjcf(spec: ModelSpec) -> str:
                 ET.SubElement(e, "geom", type="mesh", mesh=f"{b.name}_mesh{gi}", pos=_fmt(g.pos), quat=_fmt(g.quat), friction=_fmt(g.friction), contype=str(g.contype),
                               conaffinity=str(g.conaffinity))
                 continue
-            ET.SubElement(e, "geom", type={GEOM_SPHERE: "sphere", GEOM_CAPSULE: "capsule", GEOM_BOX: "box"}[g.type], size=_fmt(g.size), pos=_fmt(g.pos), quat=_fmt(g.quat), friction=_fmt(g.friction),
+            ET.SubElement(e, "geom", type={GEOM_SPHERE: "sphere", GEOM_CAPSULE: "capsule", GEOM_CYLINDER: "cylinder", GEOM_BOX: "box"}[g.type], size=_fmt(g.size), pos=_fmt(g.pos), quat=_fmt(g.quat), friction=_fmt(g.friction),
                           contype=str(g.contype), conaffinity=str(g.conaffinity))
     act = ET.SubElement(root, "actuator")
     for a in spec.actuators:

@@ -33,7 +33,7 @@ from typing import Dict, List, Optional, Sequence, Tuple
 import numpy as np
 
 JNT_FREE, JNT_HINGE, JNT_SLIDE = 0, 2, 3  # (ball=1 unsupported)
-GEOM_SPHERE, GEOM_CAPSULE, GEOM_BOX, GEOM_MESH = 2, 3, 6, 7  # MuJoCo's mjtGeom numbering
+GEOM_SPHERE, GEOM_CAPSULE, GEOM_CYLINDER, GEOM_BOX, GEOM_MESH = 2, 3, 5, 6, 7  # MuJoCo's mjtGeom numbering
 
 MJ_MINVAL = 1e-15
 MAX_CONVEX_VERTS = 64  # hull vertices of one mesh collider (the kernel scans them five times per step)
@@ -65,7 +65,7 @@ class JointSpec:
 @dataclass
 class GeomSpec:
     type: int
-    size: Sequence[float]  # sphere: (r,), capsule: (r, half_length) along local z
+    size: Sequence[float]  # sphere: (r,), capsule / cylinder: (r, half_length) along local z, box: the three half sizes
     pos: Sequence[float] = (0.0, 0.0, 0.0)
     quat: Sequence[float] = (1.0, 0.0, 0.0, 0.0)
     friction: Sequence[float] = (1.0, 0.005, 0.0001)
@@ -493,7 +493,7 @@ def compile_model(spec: ModelSpec) -> CompiledModel:
     con_bodyid, con_lpos, con_radius, con_friction, con_axis, con_cvx = [], [], [], [], [], []
     cvx_body, cvx_vadr, cvx_vert = [], [0], []
     for (gt, bi, gpos, gquat, gsize, gfri, gct, gca, gverts) in geoms:
-        if gt not in (GEOM_SPHERE, GEOM_CAPSULE, GEOM_BOX, GEOM_MESH):
+        if gt not in (GEOM_SPHERE, GEOM_CAPSULE, GEOM_CYLINDER, GEOM_BOX, GEOM_MESH):
             raise ValueError(f"unsupported geom type {gt}")
         if not spec.has_plane or not _masks_match(spec.plane_contype, spec.plane_conaffinity, gct, gca):
             continue
@@ -510,6 +510,16 @@ def compile_model(spec: ModelSpec) -> CompiledModel:
             for j in range(4):
                 con_bodyid.append(bi); con_lpos.append([0.0, 0.0, 0.0]); con_radius.append(0.0); con_friction.append(list(fri)); con_axis.append([0.0, 0.0, 0.0])
                 con_cvx.append(4 * k + j)
+            continue
+        if gt == GEOM_CYLINDER:
+            # a cylinder against the plane, MJX collision_primitive.plane_cylinder: THREE slots per geom, placed every step - the rim point
+            # nearest to the plane and two more on the same rim (a triangle), or, lying on its side, the nearest points of both rims.
+            # con_cvx = -2 marks the first slot (it computes all three), -3 / -4 the others; con_axis carries the half-axis vector (first
+            # slot) and the geom's x axis (second slot: the direction MJX picks when the disk is parallel to the plane), body frame
+            for j in range(3):
+                con_bodyid.append(bi); con_lpos.append(list(gpos)); con_radius.append(gsize[0]); con_friction.append(list(fri))
+                con_axis.append(list(_qrot(gquat, [0, 0, 1.0]) * gsize[1]) if j == 0 else list(_qrot(gquat, [1.0, 0, 0])) if j == 1 else [0.0, 0.0, 0.0])
+                con_cvx.append(-2 - j)
             continue
         if gt == GEOM_SPHERE:
             ends = [np.asarray(gpos, dtype=np.float64)]
@@ -557,6 +567,9 @@ def compile_model(spec: ModelSpec) -> CompiledModel:
                 continue
             if not _masks_match(gi[6], gi[7], gj[6], gj[7]):
                 continue
+            if GEOM_CYLINDER in (gi[0], gj[0]):
+                raise ValueError("a cylinder geom can only collide with the ground plane (MJX pairs it through signed-distance functions: not built): "
+                                 "exclude it from geom-geom pairs with contype / conaffinity")
             if gi[0] in (GEOM_BOX, GEOM_MESH):
                 names_ = {GEOM_BOX: "box", GEOM_MESH: "mesh"}
                 raise ValueError(f"a {names_[gi[0]]} geom cannot collide with a {names_[gj[0]]} geom (convex-convex pairs are not built): "
@@ -608,6 +621,7 @@ def compile_model(spec: ModelSpec) -> CompiledModel:
         con_cvx.append(-1)
     npair = len(pair_rows)
     ncvx, ncvxvert = len(cvx_body), len(cvx_vert)
+    ncyl = sum(1 for k in con_cvx if k == -2)
     ncon = len(con_bodyid)
 
     lim_jnt = [j for j in range(njnt) if jnt_limited[j] and jnt_type[j] != JNT_FREE]
@@ -685,6 +699,7 @@ def compile_model(spec: ModelSpec) -> CompiledModel:
     put("cvx_vert", np.reshape(cvx_vert, (ncvxvert, 3)))
     put("pair_body", np.reshape(pair_body, (npair, 2)), np.int32)
     put("pair_geom", np.reshape(pair_geom, (npair, 16)))
+    put("ncyl", ncyl, np.int32)
     put("nhull", len(hull_body), np.int32)
     put("hull_body", hull_body, np.int32)
     put("hull_vadr", hull_vadr, np.int32)
@@ -858,7 +873,7 @@ _BLOB_F32 = [
 ]
 _HDR_INT = ["nq", "nv", "nu", "nbody", "njnt", "ncon", "nlimit", "iterations", "ls_iterations", "nlevel", "nroot", "include_c_vals", "npair"]
 _HDR_F32 = ["timestep", "tolerance", "ls_tolerance", "impratio", "plane_z", "meaninertia"]
-_HDR_INT2 = ["ncvx", "ncvxvert", "hull_words"]  # words 33..: dims that arrived after the first header block was full (hull_words: length of the hull section behind the table part)
+_HDR_INT2 = ["ncvx", "ncvxvert", "hull_words", "ncyl"]  # words 33..: dims that arrived after the first header block was full (hull_words: length of the hull section behind the table part)
 BLOB_HEADER_WORDS = 64  # fixed-size header; array directory follows
 
 
@@ -1097,6 +1112,20 @@ def synth_brick() -> ModelSpec:
     return ModelSpec(name="synth_brick", bodies=bodies, actuators=[], free_root_z=0.12)
 
 
+def synth_can() -> ModelSpec:
+    """A free cylinder above the plane, tilted, with a small hinged cylinder (a lid that swings about the can's x axis) on top: the cylinder
+    collider of SURVEY 8(f1) - MJX collision_primitive.plane_cylinder, three slots per geom (what a URDF-derived export uses for wheels and
+    feet; URDF has no capsule)."""
+    bodies = [
+        BodySpec("can", "world", quat=(0.9537, 0.2132, 0.2132, 0.0), mass=0.8, inertia=(0.0029, 0.0029, 0.0014), joints=[JointSpec("root", JNT_FREE)],
+                 geoms=[GeomSpec(GEOM_CYLINDER, (0.06, 0.09), pos=(0.0, 0.005, 0.01), friction=(0.9, 0.005, 0.0001))]),
+        BodySpec("lid", "can", pos=(0.0, 0.0, 0.13), mass=0.1, inertia=(0.00004, 0.00004, 0.00006),
+                 joints=[JointSpec("lid", JNT_HINGE, axis=(1, 0, 0), range=(-0.8, 0.8), damping=0.02, armature=0.001)],
+                 geoms=[GeomSpec(GEOM_CYLINDER, (0.035, 0.012), quat=(0.9961947, 0.0, 0.0871557, 0.0))]),
+    ]
+    return ModelSpec(name="synth_can", bodies=bodies, actuators=[ActuatorSpec("lid", kp=1.0, ctrlrange=(-1.0, 1.0))], free_root_z=0.14)
+
+
 # hull vertices of an irregular "foot" (no two edges parallel, no symmetric pairs: the argmax steps of plane_convex have no exact ties)
 WEDGE_VERTS = ((0.11, 0.045, -0.021), (0.12, -0.04, -0.019), (-0.09, -0.052, -0.02), (-0.10, 0.038, -0.018), (0.07, 0.03, 0.028), (0.06, -0.025, 0.03),
                (-0.05, -0.03, 0.035), (-0.06, 0.02, 0.04), (0.0, 0.0, 0.055))
@@ -1129,6 +1158,7 @@ BUILTIN_MODELS = {
     "synth_pendulum": synth_pendulum,
     "synth_ball": synth_ball,
     "synth_brick": synth_brick,
+    "synth_can": synth_can,
     "synth_wedge": synth_wedge,
 }
 

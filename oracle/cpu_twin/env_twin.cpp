@@ -449,7 +449,39 @@ float forward(const Model& m, Work& w, const float* qpos, const float* qvel, con
   for (int c = 0; c < nplane; ++c) {
     const int b = m.I(BI_con_bodyid)[c];
     const Q4 q = ld4(&w.xquat[4 * b]);
-    const int cs = m.ncvx > 0 ? m.I(BI_con_cvx)[c] : -1;
+    const int kind = m.I(BI_con_cvx)[c];
+    if (kind <= -2) {
+      // a cylinder against the plane (MJX plane_cylinder): three slots, all of them placed when the first comes up
+      if (kind != -2) continue;
+      const V3 ctr = add3(ld3(&w.xpos[3 * b]), qrot(q, ld3(m.F(BF_con_lpos) + 3 * c)));
+      const V3 hv = ld3(m.F(BF_con_axis) + 3 * c);
+      const float half = std::sqrt(dot3(hv, hv)), r = m.F(BF_con_radius)[c], height = ctr.z - m.plane_z;
+      V3 axis = qrot(q, mul3(hv, 1.f / half));
+      const V3 xaxis = qrot(q, ld3(m.F(BF_con_axis) + 3 * (c + 1))), up = {0, 0, 1};
+      float prjaxis = axis.z;
+      const float sign = prjaxis < 0.f ? 1.f : -1.f;  // turned towards the plane
+      axis = mul3(axis, sign); prjaxis *= sign;
+      V3 vec = sub3(mul3(axis, prjaxis), up);
+      const float len = std::sqrt(dot3(vec, vec));
+      vec = len < 1e-12f ? mul3(xaxis, r) : mul3(vec, r / len);
+      const float prjvec = vec.z;
+      axis = mul3(axis, half); prjaxis *= half;
+      float nrm;
+      const V3 vec1 = mul3(normalize_norm(cross3(vec, axis), nrm), r * std::sqrt(3.f) * 0.5f);
+      const float d1 = height + prjaxis + prjvec, d2 = height + prjaxis - 0.5f * prjvec, d3 = height - prjaxis + prjvec;
+      const bool side = std::fabs(prjaxis) < 1e-3f;
+      const float dist[3] = {d1, side ? d3 : d2, d2};
+      const V3 hvv = mul3(vec, 0.5f);
+      const V3 rel[3] = {add3(axis, vec), side ? sub3(vec, axis) : sub3(add3(axis, vec1), hvv), sub3(sub3(axis, vec1), hvv)};
+      for (int j = 0; j < 3; ++j) {
+        w.condist[c + j] = dist[j];
+        const V3 p = add3(ctr, rel[j]);
+        st3(&w.conpos[3 * (c + j)], {p.x, p.y, p.z - 0.5f * dist[j]});
+        st3(&w.confr[9 * (c + j)], up); st3(&w.confr[9 * (c + j) + 3], {0, 1, 0}); st3(&w.confr[9 * (c + j) + 6], {-1, 0, 0});
+      }
+      continue;
+    }
+    const int cs = m.ncvx > 0 ? kind : -1;
     const V3 centre = add3(ld3(&w.xpos[3 * b]), qrot(q, cs >= 0 ? ld3(&w.cvxsel[3 * cs]) : ld3(m.F(BF_con_lpos) + 3 * c)));
     const float rad = m.F(BF_con_radius)[c];
     float dist = centre.z - m.plane_z - rad;

@@ -28,6 +28,7 @@ All arrays are batched over environments: shape [N, ...].  dtype-generic
 
 from __future__ import annotations
 
+import math
 from typing import Dict, NamedTuple
 
 import numpy as np
@@ -200,6 +201,36 @@ def sphere_sphere(pos1, r1, pos2, r2):
     n = np.where((dist == 0)[..., None], np.array([1.0, 0.0, 0.0], n.dtype), n)
     dist = dist - (r1 + r2)
     return dist, pos1 + n * (r1 + 0.5 * dist)[..., None], n
+
+
+def plane_cylinder(height, axis, xaxis, r, half):
+    """MJX collision_primitive.plane_cylinder ([3P-recall]: MuJoCo 3.1 / 3.2, the three-contact form of the C engine's mjc_PlaneCylinder;
+    not present under /root/reference) for the plane z = const with normal +z, batched: `height` [N] of the cylinder's centre above the
+    plane, unit `axis` and the geom's `xaxis` [N, 3] in the world.  Slot 0: the point of the lower rim nearest to the plane; slots 1, 2: two
+    more points of that rim, 120 degrees to either side; when the cylinder lies on its side (|axis . n| half < 1e-3) slot 1 is the
+    nearest point of the OTHER rim instead.  -> dist [N, 3], pos - centre [N, 3, 3]."""
+    dt = axis.dtype
+    n = np.array([0.0, 0.0, 1.0], dt)
+    prjaxis = axis @ n
+    sign = -np.where(prjaxis < 0, dt.type(-1), dt.type(1))  # (the axis is turned towards the plane)
+    axis, prjaxis = axis * sign[:, None], prjaxis * sign
+    vec = axis * prjaxis[:, None] - n
+    ln = np.linalg.norm(vec, axis=-1)
+    vec = np.where((ln < 1e-12)[:, None], xaxis * r, vec / (ln + dt.type(1e-15) * (ln == 0))[:, None] * r)
+    prjvec = vec @ n
+    axis, prjaxis = axis * half, prjaxis * half
+    prjvec1 = -prjvec * dt.type(0.5)
+    vec1 = _normalize_with_norm(np.cross(vec, axis))[0] * (r * dt.type(math.sqrt(3.0)) * dt.type(0.5))
+    d1 = height + prjaxis + prjvec
+    d2 = height + prjaxis + prjvec1
+    d3 = height - prjaxis + prjvec
+    side = np.abs(prjaxis) < 1e-3
+    dist = np.stack([d1, np.where(side, d3, d2), d2], axis=1)
+    half_v = vec * dt.type(0.5)
+    p0 = axis + vec - n * (d1 * dt.type(0.5))[:, None]
+    p1 = np.where(side[:, None], vec - axis - n * (d3 * dt.type(0.5))[:, None], axis + vec1 - half_v - n * (d2 * dt.type(0.5))[:, None])
+    p2 = axis - vec1 - half_v - n * (d2 * dt.type(0.5))[:, None]
+    return dist, np.stack([p0, p1, p2], axis=1)
 
 
 class Hull:
@@ -518,7 +549,22 @@ class Physics:
                 sel_ok[:, 4 * k + j] = ~np.any(idx[:, :j] == idx[:, j:j + 1], axis=1)      # unique = first occurrence of the vertex
         for c in range(nc - npair):
             b = t["con_bodyid"][c]
-            cs = int(t["con_cvx"][c]) if ncvx else -1
+            kind = int(t["con_cvx"][c]) if "con_cvx" in t else -1
+            if kind <= -2:
+                # a cylinder's three slots (MJX plane_cylinder), computed at the first
+                if kind == -2:
+                    centre = d.xpos[:, b] + qrot(d.xquat[:, b], np.broadcast_to(np.asarray(t["con_lpos"][c], dt), (N, 3)))
+                    hv = np.asarray(t["con_axis"][c], dt)
+                    half = dt.type(np.linalg.norm(t["con_axis"][c]))
+                    axis = qrot(d.xquat[:, b], np.broadcast_to(hv / half, (N, 3)))
+                    xaxis = qrot(d.xquat[:, b], np.broadcast_to(np.asarray(t["con_axis"][c + 1], dt), (N, 3)))
+                    dd, pp = plane_cylinder(centre[:, 2] - dt.type(t["plane_z"]), axis, xaxis, dt.type(t["con_radius"][c]), half)
+                    for j in range(3):
+                        dist[:, c + j] = dd[:, j]
+                        cpos[:, c + j] = centre + pp[:, j]
+                        frame[:, c + j] = make_frame(np.broadcast_to(n, (N, 3)))
+                continue
+            cs = kind if ncvx else -1
             lpos = sel_pos[:, cs] if cs >= 0 else np.broadcast_to(np.asarray(t["con_lpos"][c], dt), (N, 3))
             centre = d.xpos[:, b] + qrot(d.xquat[:, b], lpos)
             r = t["con_radius"][c]

@@ -87,6 +87,7 @@ MJCF_EXPORT = str(Path(__file__).parent / "golden" / "export_biped" / "robot.xml
 
 @pytest.mark.parametrize("model,N", [("synth_stompy_pro", 33), ("synth_stompy_full", 17), ("synth_pendulum", 3), ("synth_ball", 2), (MJCF_ROBOT, 4),
                                      ("synth_brick", 6),              # a free box: eight corner contacts against the ground (box geoms)
+                                     ("synth_can", 6),                # cylinders: MJX's plane_cylinder, three slots per geom (tests/test_cylinder.py)
                                      ("synth_wedge", 6), (MJCF_MESH, 5),   # mesh geoms: MJX's plane_convex, four slots per geom, vertices chosen every step
                                      (MJCF_EXPORT, 12),
                                      ("synth_stompy_frames", 8)])     # 93 bodies: subtree sets of two 64-bit words, bodies and dofs beyond index 64

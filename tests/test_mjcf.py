@@ -149,7 +149,7 @@ def test_springref_is_the_springs_rest_position_not_ref():
 
 @pytest.mark.parametrize("old,new,msg", [
     ('<actuator>', '<equality/><actuator>', "equality"),
-    ('type="sphere" size="0.1"', 'type="cylinder" size="0.1 0.1"', "only sphere, capsule and box geoms can collide"),
+    ('type="sphere" size="0.1"', 'type="ellipsoid" size="0.1 0.1 0.2"', "only sphere, capsule, cylinder and box geoms can collide"),
     ('<joint name="knee" axis="0 1 0"/>', '<joint name="knee" type="ball"/>', "joint type"),
     ('<position joint="hip"/>', '<position tendon="t"/>', "joint transmissions"),
     ('<position joint="hip"/>', '<position joint="nope"/>', "unknown joint"),
