@@ -68,18 +68,18 @@ def committed_summary(pattern: str):
     other kernels and is not quoted (round-4 review: the line carried counters of a kernel that had changed since)."""
     here = kernel_sources_sha()
     cands = sorted((ROOT / "profiles").glob(pattern))
-    why = f"no profiles/{pattern}"
+    why = None  # (the reason the NEWEST candidate is not quoted: that is the one a reader would look for)
     for f in reversed(cands):
         side = f.with_name(f.name + ".meta.json")
         if not side.exists():
-            why = f"profiles/{f.name} has no .meta.json (taken before summaries recorded their tree): not quoted"
+            why = why or f"profiles/{f.name} has no .meta.json (taken before summaries recorded their tree): not quoted"
             continue
         meta = json.loads(side.read_text())
         if meta.get("kernel_sources_sha") != here:
-            why = f"profiles/{f.name} was taken on kernel sources {meta.get('kernel_sources_sha')} (commit {meta.get('git_head')}), this tree is {here}: stale, not quoted"
+            why = why or f"profiles/{f.name} was taken on kernel sources {meta.get('kernel_sources_sha')} (commit {meta.get('git_head')}), this tree is {here}: stale, not quoted"
             continue
         return f, meta
-    return None, why
+    return None, why or f"no profiles/{pattern}"
 
 
 def parse() -> argparse.Namespace:
