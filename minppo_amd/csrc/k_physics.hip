@@ -20,6 +20,7 @@
 #include "mppo_common.h"
 #include <wave_ops.h>
 
+#include <initializer_list>
 #include <type_traits>
 #include <utility>
 
@@ -1611,6 +1612,10 @@ extern "C" int32_t mppo_model_open(const void* host_blob, size_t nbytes, const v
   v.nq = wi[3]; v.nv = wi[4]; v.nu = wi[5]; v.nbody = wi[6]; v.njnt = wi[7]; v.ncon = wi[8]; v.nlimit = wi[9];
   v.iterations = wi[10]; v.ls_iterations = wi[11]; v.nlevel = wi[12]; v.nroot = wi[13]; v.include_c = wi[14] ? 1 : 0; v.npair = wi[15];
   v.ncvx = wi[33]; v.ncvxvert = wi[34];
+  // every header dimension inside a bound that keeps the size arithmetic below (and in blob_offsets) far from overflow, BEFORE any of it
+  // is computed (tests/test_blob_fuzz.py under UBSan: a dimension of INT_MAX overflowed `4 * ncon` here)
+  for (int d : {v.nq, v.nv, v.nu, v.nbody, v.njnt, v.ncon, v.nlimit, v.iterations, v.ls_iterations, v.nlevel, v.nroot, v.npair, v.ncvx, v.ncvxvert, wi[36]})
+    if (d < 0 || d > (1 << 16)) { delete m; return fail(MPPO_EMODEL, "model blob: header dimension %d out of range", d); }
   v.nefc = v.nlimit + 4 * v.ncon;
   v.timestep = wf[16]; v.tolerance = wf[17]; v.ls_tolerance = wf[18]; v.impratio = wf[19]; v.plane_z = wf[20]; v.meaninertia = wf[21];
   auto bad = [&](const char* what) { delete m; return fail(MPPO_EMODEL, "model blob: %s", what); };

@@ -1126,6 +1126,33 @@ def synth_can() -> ModelSpec:
     return ModelSpec(name="synth_can", bodies=bodies, actuators=[ActuatorSpec("lid", kp=1.0, ctrlrange=(-1.0, 1.0))], free_root_z=0.14)
 
 
+def synth_pile() -> ModelSpec:
+    """Every contact routine of SURVEY 8(f1) in one scene, at rest under gravity: a box and a 20-vertex mesh rock on the ground (corner
+    contacts, plane_convex), a ball on the box (sphere_convex), a rod across the rock (capsule_convex), a can standing beside them
+    (plane_cylinder) - each starting 2 - 3 mm inside what it rests on, so that the contacts act from the first step (what an external MJX
+    fixture of ten steps records: tools/make_mjx_fixtures.py).  Masks: the plane types 1 | 4 and is affine to nothing; box and rock are
+    affine to 1, ball and rod type 1 and are affine to 4, the can is affine to 4 only - no box-rock and no cylinder pair arises."""
+    rng = np.random.default_rng(5)
+    v = rng.normal(size=(20, 3))
+    v = v / np.linalg.norm(v, axis=1, keepdims=True) * [0.3, 0.25, 0.2]
+    top = v[np.argmax(v[:, 2])]
+    rock_z = -float(v[:, 2].min()) - 0.003
+    free = lambda n: [JointSpec(n, JNT_FREE)]
+    bodies = [
+        BodySpec("box", "world", pos=(0.0, 0.0, 0.1), mass=2.0, inertia=(0.033, 0.067, 0.087), joints=free("box"),
+                 geoms=[GeomSpec(GEOM_BOX, (0.3, 0.2, 0.1), contype=0, conaffinity=1, friction=(0.9, 0.005, 0.0001))]),
+        BodySpec("rock", "world", pos=(1.0, 0.0, rock_z), mass=1.5, inertia=(0.02, 0.025, 0.03), joints=free("rock"),
+                 geoms=[GeomSpec(GEOM_MESH, (), vertices=tuple(map(tuple, v)), contype=0, conaffinity=1)]),
+        BodySpec("ball", "world", pos=(0.05, 0.03, 0.2 + 0.08 - 0.003), mass=0.5, inertia=(0.0013, 0.0013, 0.0013), joints=free("ball"),
+                 geoms=[GeomSpec(GEOM_SPHERE, (0.08,), contype=1, conaffinity=4)]),
+        BodySpec("rod", "world", pos=(1.0 + float(top[0]), float(top[1]), rock_z + float(top[2]) + 0.05 - 0.002), quat=(0.70710678, 0.0, 0.70710678, 0.0),
+                 mass=0.4, inertia=(0.0032, 0.0032, 0.0005), joints=free("rod"), geoms=[GeomSpec(GEOM_CAPSULE, (0.05, 0.15), contype=1, conaffinity=4)]),
+        BodySpec("can", "world", pos=(0.0, 1.0, 0.09 - 0.002), mass=0.8, inertia=(0.0029, 0.0029, 0.0014), joints=free("can"),
+                 geoms=[GeomSpec(GEOM_CYLINDER, (0.06, 0.09), contype=0, conaffinity=4)]),
+    ]
+    return ModelSpec(name="synth_pile", bodies=bodies, actuators=[], free_root_z=0.1 - 0.002, plane_contype=5, plane_conaffinity=0)
+
+
 # hull vertices of an irregular "foot" (no two edges parallel, no symmetric pairs: the argmax steps of plane_convex have no exact ties)
 WEDGE_VERTS = ((0.11, 0.045, -0.021), (0.12, -0.04, -0.019), (-0.09, -0.052, -0.02), (-0.10, 0.038, -0.018), (0.07, 0.03, 0.028), (0.06, -0.025, 0.03),
                (-0.05, -0.03, 0.035), (-0.06, 0.02, 0.04), (0.0, 0.0, 0.055))
@@ -1159,6 +1186,7 @@ BUILTIN_MODELS = {
     "synth_ball": synth_ball,
     "synth_brick": synth_brick,
     "synth_can": synth_can,
+    "synth_pile": synth_pile,
     "synth_wedge": synth_wedge,
 }
 

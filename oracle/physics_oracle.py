@@ -896,10 +896,12 @@ class Physics:
     def euler(self, d: PhysState) -> None:
         t = self.t
         h = self.dtype.type(self.timestep)
-        qacc = d.qacc
-        if np.any(t["dof_damping"] > 0):
-            dh = d.qM + h * np.eye(self.nv, dtype=self.dtype)[None] * t["dof_damping"][None, :, None]
-            qacc = np.linalg.solve(dh, (d.qfrc_smooth + d.qfrc_constraint)[..., None])[..., 0]
+        # MJX forward.euler integrates (M + h D)^-1 (qfrc_smooth + qfrc_constraint) ALWAYS - it has no "is any dof damped" test (the C engine's
+        # mj_Euler skips the solve for an undamped model and integrates the solver's qacc; MJX cannot branch on an array).  The two differ
+        # wherever the solver has not converged (six CG iterations), damped or not: round 5 found the oracle on the C engine's side of
+        # this for undamped models while kernel and twin were on MJX's (synth_pile: 24 contact slots at rest).
+        dh = d.qM + h * np.eye(self.nv, dtype=self.dtype)[None] * t["dof_damping"][None, :, None]
+        qacc = np.linalg.solve(dh, (d.qfrc_smooth + d.qfrc_constraint)[..., None])[..., 0]
         qvel = d.qvel + qacc * h
         qpos = d.qpos.copy()
         for j in range(self.njnt):

@@ -91,7 +91,7 @@ def test_twin_follows_the_oracle_on_the_other_collider_kinds():
     import os
 
     here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
-    for name, steps, amp in (("synth_stompy_pro_sc", 8, 0.6), ("synth_tumblers", 20, 0.0), ("synth_can", 60, 0.3), ("synth_stompy_frames", 6, 0.4), (os.path.join(here, "hand_leg.xml"), 25, 0.3),
+    for name, steps, amp in (("synth_stompy_pro_sc", 8, 0.6), ("synth_tumblers", 20, 0.0), ("synth_can", 60, 0.3), ("synth_pile", 30, 0.0), ("synth_stompy_frames", 6, 0.4), (os.path.join(here, "hand_leg.xml"), 25, 0.3),
                              (os.path.join(here, "mesh_foot.xml"), 40, 0.3),
                              (os.path.join(here, "export_biped", "robot.xml"), 12, 0.3)):  # 28 bodies, 33 dofs, export-style multi-file MJCF
         cm = load_model(name)

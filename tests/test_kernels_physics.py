@@ -61,10 +61,8 @@ def _cost(ref, qacc):
 
 def _euler_acc(cm, ref):
     """the acceleration the integrator applies (MJX euler with implicit joint damping):
-    (M + h diag(damping))^-1 (qfrc_smooth + qfrc_constraint), or qacc itself for an undamped model"""
+    (M + h diag(damping))^-1 (qfrc_smooth + qfrc_constraint) - for an undamped model too (MJX has no test for that; physics_oracle.euler)"""
     damp = np.asarray(cm.t["dof_damping"], np.float64)
-    if not np.any(damp > 0):
-        return ref.qacc
     dh = ref.qM + float(cm.t["timestep"]) * np.eye(cm.nv)[None] * damp[None, :, None]
     return np.linalg.solve(dh, (ref.qfrc_smooth + ref.qfrc_constraint)[..., None])[..., 0]
 
@@ -87,6 +85,7 @@ MJCF_EXPORT = str(Path(__file__).parent / "golden" / "export_biped" / "robot.xml
 
 @pytest.mark.parametrize("model,N", [("synth_stompy_pro", 33), ("synth_stompy_full", 17), ("synth_pendulum", 3), ("synth_ball", 2), (MJCF_ROBOT, 4),
                                      ("synth_brick", 6),              # a free box: eight corner contacts against the ground (box geoms)
+                                     ("synth_pile", 3),               # every contact routine at rest in one scene: corners, plane_convex, sphere_convex, capsule_convex, plane_cylinder
                                      ("synth_can", 6),                # cylinders: MJX's plane_cylinder, three slots per geom (tests/test_cylinder.py)
                                      ("synth_wedge", 6), (MJCF_MESH, 5),   # mesh geoms: MJX's plane_convex, four slots per geom, vertices chosen every step
                                      (MJCF_EXPORT, 12),

@@ -344,3 +344,22 @@ def test_plane_convex_picks_the_deepest_vertices_like_mjx():
     assert (dist[1] < 0).sum() == 2 and np.isclose(dist[1], 1.0).sum() == 2                                    # the edge's two vertices, two duplicates
     assert np.allclose(np.sort(pos[1][dist[1] < 0][:, 0]), [-0.1, 0.1], atol=0.021)
     assert (dist[2] > 0).all()
+
+
+def test_euler_integrates_the_constraint_forces_not_the_solver_iterate():
+    """MJX forward.euler: qvel' = qvel + h (M + h D)^-1 (qfrc_smooth + qfrc_constraint) - also when no dof is damped (the C engine would then
+    integrate the solver's qacc; MJX has no such test).  The two differ wherever six CG iterations have not converged: synth_pile (undamped,
+    24 contact slots at rest) is such a case, and the oracle must be on MJX's side of it, where the kernel and the C++ twin are."""
+    cm = load_model("synth_pile")
+    assert not np.any(cm.t["dof_damping"] > 0)
+    ph = Physics(cm.t)
+    d = ph.pipeline_init(np.tile(cm.t["qpos0"], (1, 1)), np.zeros((1, cm.nv)))
+    for _ in range(6):
+        d = ph.pipeline_step(d, np.zeros((1, 0)))
+    before = d.copy()
+    ph.forward(before)
+    implied = np.linalg.solve(before.qM, (before.qfrc_smooth + before.qfrc_constraint)[..., None])[..., 0]
+    assert np.abs(implied - before.qacc).max() > 0.1                      # the solver's iterate is NOT the acceleration its forces produce here
+    after = ph.pipeline_step(d, np.zeros((1, 0)))
+    h = float(cm.t["timestep"])
+    np.testing.assert_allclose(after.qvel, before.qvel + h * implied, atol=1e-12)

@@ -5,7 +5,7 @@ This script cannot run in the build container or on the GPU box: it needs `mujoc
 installed there and cannot be (no network).  Run it on any machine that has them (pip install mujoco mujoco-mjx "jax[cpu]"),
 from the repository root, and commit the files it writes:
 
-    python tools/make_mjx_fixtures.py [synth_stompy_pro synth_stompy_full ...]      ->  tests/golden/mjx_<model>.npz
+    python tools/make_mjx_fixtures.py [synth_stompy_pro synth_stompy_full synth_pile ...]      ->  tests/golden/mjx_<model>.npz
 
 tests/test_mjx_fixtures.py consumes those files when they exist (and skips otherwise): it feeds the recorded (qpos, qvel, ctrl,
 qacc_warmstart) to the float64 oracle and - through `mppo_physics_forward` - to the kernel, and compares every intermediate with
@@ -76,4 +76,6 @@ def main(names):
 
 
 if __name__ == "__main__":
-    main(sys.argv[1:] or ["synth_stompy_pro", "synth_stompy_full"])
+    # the two BASELINE robots, then one model per contact routine (pairs of round geoms, box corners, plane_convex, plane_cylinder) and the
+    # scene that has them all plus sphere_convex / capsule_convex at rest (synth_pile)
+    main(sys.argv[1:] or ["synth_stompy_pro", "synth_stompy_full", "synth_stompy_pro_sc", "synth_brick", "synth_wedge", "synth_can", "synth_pile"])
