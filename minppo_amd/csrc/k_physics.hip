@@ -1066,6 +1066,12 @@ __global__ void __launch_bounds__(64 * kMaxWavesPerBlock) env_kernel(ModelView m
           act += fo * gear;
         }
       }
+      // MJCF <joint actuatorfrcrange>: the joint's total actuator force is clamped (MJX fwd_actuation; -FLT_MAX / FLT_MAX when the joint has none);
+      // comparisons, not fmin / fmax: a NaN must stay a NaN for the guard below
+      {
+        const float lo = TF(dof_actfrcrange)[2 * d], hi = TF(dof_actfrcrange)[2 * d + 1];
+        act = act < lo ? lo : (act > hi ? hi : act);
+      }
       qfs[d] = passive - bias + act;
       // qfrc_actuator is part of the new record / observation (env.py:252) and of the NaN guard, not of the solver: it leaves here
       badi |= (int)isnan(act);

@@ -26,12 +26,12 @@ enum BlobF32 {
   BF_act_gear, BF_act_gain, BF_act_bias, BF_act_ctrlrange, BF_act_forcerange,
   BF_con_lpos, BF_con_radius, BF_con_friction, BF_con_axis, BF_pair_geom,
   BF_contact_solref, BF_contact_solimp, BF_limit_solref, BF_limit_solimp,
-  BF_cvx_vert,
+  BF_cvx_vert, BF_dof_actfrcrange,
   BLOB_ARRAY_COUNT
 };
 
 constexpr uint32_t kBlobMagic = 0x4D50504F;
-constexpr uint32_t kBlobVersion = 5;
+constexpr uint32_t kBlobVersion = 6;
 constexpr int kBlobHeaderWords = 64;
 constexpr int JNT_FREE = 0, JNT_HINGE = 2, JNT_SLIDE = 3;
 constexpr float MJ_MINVAL = 1e-15f, MJ_MINIMP = 0.0001f, MJ_MAXIMP = 0.9999f;
@@ -77,7 +77,7 @@ __host__ __device__ constexpr inline int blob_array_len(const BlobDims& d, int k
     case BI_root_body: return d.nroot;
     case BI_body_subtree_mask: return (d.nbody > 64 ? 4 : 2) * d.nbody;  // a 64-bit word per body: bodies 0..63 of its subtree; beyond 64 bodies a second block of words: bodies 64..127
     case BI_body_ancdof_mask: case BF_body_invweight0: return 2 * d.nbody;
-    case BI_dof_velmask: return 2 * d.nv;
+    case BI_dof_velmask: case BF_dof_actfrcrange: return 2 * d.nv;
     case BF_gravity: return 3;
     case BF_body_pos: case BF_body_ipos: case BF_body_inertia: return 3 * d.nbody;
     case BF_body_quat: case BF_body_iquat: return 4 * d.nbody;

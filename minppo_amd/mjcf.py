@@ -17,7 +17,7 @@ Subset
             `childclass` on <body>, `class` on elements
   <worldbody>: one <geom type="plane"> (the ground), <body name pos quat|euler|axisangle|xyaxes|zaxis childclass>
       <inertial pos quat|euler mass diaginertia|fullinertia>
-      <freejoint/> | <joint type="free|hinge|slide" name pos axis range limited ref damping armature stiffness>
+      <freejoint/> | <joint type="free|hinge|slide" name pos axis range limited ref springref damping armature stiffness actuatorfrcrange>
       <geom type="sphere|capsule|cylinder|box|mesh" size pos quat|euler fromto friction mass density contype conaffinity mesh>
             (a box collides with the ground through its eight corners; a mesh collides with the ground as its CONVEX HULL, as in
              MuJoCo / MJX - up to four contacts per step, MJX's plane_convex; a cylinder meets the ground with three contacts per step,
@@ -26,7 +26,8 @@ Subset
              an <inertial>)
   <asset><mesh name vertex="x y z ..." | file="*.obj|*.stl" scale>: the collision geometry of mesh geoms (files relative to the MJCF,
             honouring <compiler meshdir>); everything else under <asset> is visual and ignored
-  <actuator>: <position joint kp kv gear ctrlrange forcerange>, <motor joint gear ctrlrange forcerange>
+  <actuator>: <position joint kp kv gear ctrlrange forcerange>, <motor joint gear ctrlrange forcerange>, <velocity joint kv ...>,
+            <general joint gainprm biastype="none|affine" biasprm ...> (dyntype none, gaintype fixed)
   <contact><exclude body1 body2/>: no contacts between the geoms of these two bodies (<contact><pair> is an error)
 Contacts: geom-vs-ground-plane, and the geom pairs between bodies that MuJoCo would test (contype / conaffinity masks, same-body and
 parent-child pairs filtered, <exclude>d body pairs dropped): sphere / capsule among themselves, and a sphere or capsule against a box
@@ -568,9 +569,19 @@ def parse_mjcf(xml: str, name: str = "mjcf", base_dir: Optional[Path] = None) ->
                                  "springref", "margin", "group", "user", "actuatorfrcrange", "actuatorfrclimited"):
                         raise ValueError(f"{what}: attribute {k!r} is outside the supported MJCF subset")
                 ref, sref = float(a.get("ref", "0")), float(a.get("springref", "0"))  # MuJoCo: qpos0 = ref, qpos_spring = springref (both default 0)
+                # actuatorfrcrange: the joint's total actuator force is clamped (what URDF-derived exports make of an <effort> limit)
+                frc = None
+                if "actuatorfrcrange" in a:
+                    lim = a.get("actuatorfrclimited", "auto")
+                    if lim == "true" or (lim == "auto" and comp.autolimits):
+                        if jt == JNT_FREE:
+                            raise ValueError(f"{what}: actuatorfrcrange on a free joint")
+                        frc = tuple(_floats(a["actuatorfrcrange"], 2, what))
+                elif a.get("actuatorfrclimited") == "true":
+                    raise ValueError(f"{what}: actuatorfrclimited='true' without actuatorfrcrange")
                 joints.append(JointSpec(jn, jt, pos=tuple(_floats(a.get("pos", "0 0 0"), 3, what)), axis=tuple(_floats(a.get("axis", "0 0 1"), 3, what)), range=rng,
                                         damping=float(a.get("damping", "0")), armature=float(a.get("armature", "0")), stiffness=float(a.get("stiffness", "0")),
-                                        ref=comp.ang(ref) if jt == JNT_HINGE else ref, springref=comp.ang(sref) if jt == JNT_HINGE else sref))
+                                        ref=comp.ang(ref) if jt == JNT_HINGE else ref, springref=comp.ang(sref) if jt == JNT_HINGE else sref, actuatorfrcrange=frc))
             elif ch.tag == "geom":
                 kind, gs, part = geom_spec(dfl.resolve("geom", ch, cc), what)
                 if kind == "plane":
@@ -630,8 +641,8 @@ def parse_mjcf(xml: str, name: str = "mjcf", base_dir: Optional[Path] = None) ->
     act_el = _merged(root, "actuator")
     for ch in (act_el if act_el is not None else []):
         what = f"<actuator><{ch.tag}>"
-        if ch.tag not in ("position", "motor"):
-            raise ValueError(f"{what} is outside the supported MJCF subset (position, motor)")
+        if ch.tag not in ("position", "motor", "velocity", "general"):
+            raise ValueError(f"{what} is outside the supported MJCF subset (position, motor, velocity, general)")
         a = dfl.resolve(ch.tag, ch, None)
         if "joint" not in a:
             raise ValueError(f"{what}: only joint transmissions are supported")
@@ -650,11 +661,23 @@ def parse_mjcf(xml: str, name: str = "mjcf", base_dir: Optional[Path] = None) ->
                 return (r[0], r[1])
             return None
 
+        own = {"position": ("kp", "kv"), "motor": (), "velocity": ("kv",), "general": ("gaintype", "biastype", "dyntype", "gainprm", "biasprm")}[ch.tag]
         for k in a:
-            if k not in ("name", "joint", "gear", "kp", "kv", "ctrlrange", "ctrllimited", "forcerange", "forcelimited", "group", "user"):
+            if k not in ("name", "joint", "gear", "ctrlrange", "ctrllimited", "forcerange", "forcelimited", "group", "user") + own:
                 raise ValueError(f"{what}: attribute {k!r} is outside the supported MJCF subset")
-        acts.append(ActuatorSpec(a["joint"], gear=gear, kp=float(a.get("kp", "1")) if ch.tag == "position" else 0.0, kv=float(a.get("kv", "0")) if ch.tag == "position" else 0.0,
-                                 ctrlrange=rng("ctrlrange", "ctrllimited"), forcerange=rng("forcerange", "forcelimited")))
+        kw = dict(gear=gear, ctrlrange=rng("ctrlrange", "ctrllimited"), forcerange=rng("forcerange", "forcelimited"))
+        if ch.tag == "position":
+            kw.update(kp=float(a.get("kp", "1")), kv=float(a.get("kv", "0")))
+        elif ch.tag == "velocity":      # force = kv * (ctrl - velocity)
+            kv = float(a.get("kv", "1"))
+            kw.update(gain=kv, bias=(0.0, 0.0, -kv))
+        elif ch.tag == "general":       # force = gainprm[0] * ctrl + biasprm[0] + biasprm[1] * length + biasprm[2] * velocity
+            if a.get("dyntype", "none") != "none" or a.get("gaintype", "fixed") != "fixed" or a.get("biastype", "none") not in ("none", "affine"):
+                raise ValueError(f"{what}: only dyntype='none', gaintype='fixed', biastype='none' | 'affine' are supported")
+            gp = (_floats(a.get("gainprm", "1")) + [0.0])[0]
+            bp = (_floats(a.get("biasprm", "0 0 0")) + [0.0, 0.0, 0.0])[:3] if a.get("biastype", "none") == "affine" else [0.0, 0.0, 0.0]
+            kw.update(gain=gp, bias=tuple(bp))
+        acts.append(ActuatorSpec(a["joint"], **kw))
 
     for kind, key_ref, key_imp, field_ref, field_imp in (("limit", "solreflimit", "solimplimit", "limit_solref", "limit_solimp"),
                                                          ("contact", "solref", "solimp", "contact_solref", "contact_solimp")):
@@ -742,6 +765,8 @@ def to_mjcf(spec: ModelSpec) -> str:
             a = dict(name=j.name, type="hinge" if j.type == JNT_HINGE else "slide", pos=_fmt(j.pos), axis=_fmt(j.axis), damping=repr(float(j.damping)),
                      armature=repr(float(j.armature)), stiffness=repr(float(j.stiffness)), ref=repr(float(j.ref)),
                      springref=repr(float(j.ref if j.springref is None else j.springref)))
+            if j.actuatorfrcrange is not None:
+                a.update(actuatorfrcrange=_fmt(j.actuatorfrcrange), actuatorfrclimited="true")
             if j.range is not None:
                 a["range"] = _fmt(j.range)
             ET.SubElement(e, "joint", **a)
@@ -759,7 +784,9 @@ def to_mjcf(spec: ModelSpec) -> str:
             kw["ctrlrange"] = _fmt(a.ctrlrange)
         if a.forcerange is not None:
             kw["forcerange"] = _fmt(a.forcerange)
-        if a.kp != 0:
+        if a.gain is not None:
+            ET.SubElement(act, "general", gainprm=repr(float(a.gain)), biastype="affine", biasprm=_fmt(a.bias), **kw)
+        elif a.kp != 0:
             ET.SubElement(act, "position", kp=repr(float(a.kp)), kv=repr(float(a.kv)), **kw)
         else:
             ET.SubElement(act, "motor", **kw)

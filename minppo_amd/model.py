@@ -40,7 +40,7 @@ MAX_CONVEX_VERTS = 64  # hull vertices of one mesh collider (the kernel scans th
 MAX_BODIES = 128  # subtree sets are two 64-bit words per body (one up to 64 bodies); dofs: one word, 64
 
 BLOB_MAGIC = 0x4D50504F  # "MPPO"
-BLOB_VERSION = 5  # 2: header word include_c_vals; 3: geom-geom pairs (npair, pair_body, pair_geom) and con_axis; 4: convex (mesh) geoms against the plane; 5: hull section (sphere / capsule against box / mesh)
+BLOB_VERSION = 6  # 6: dof_actfrcrange (joint actuatorfrcrange); 2: header word include_c_vals; 3: geom-geom pairs (npair, pair_body, pair_geom) and con_axis; 4: convex (mesh) geoms against the plane; 5: hull section (sphere / capsule against box / mesh)
 
 
 # ---------------------------------------------------------------------------
@@ -59,6 +59,7 @@ class JointSpec:
     armature: float = 0.0
     stiffness: float = 0.0
     ref: float = 0.0  # qpos0 for hinge/slide
+    actuatorfrcrange: Optional[Tuple[float, float]] = None  # MJCF actuatorfrcrange: the total actuator force on this (hinge / slide) joint is clamped to it
     springref: Optional[float] = None  # position at which the joint spring (stiffness) is at rest: MuJoCo's qpos_spring; None = at `ref` (the built-in robots)
 
 
@@ -99,6 +100,10 @@ class ActuatorSpec:
     gear: float = 1.0
     kp: float = 0.0  # position servo: force = kp*(ctrl - length) - kv*velocity ; kp=0 -> motor (gain 1)
     kv: float = 0.0
+    # MJCF <general gaintype="fixed" biastype="affine"> / <velocity>: force = gain * ctrl + bias[0] + bias[1] * length + bias[2] * velocity; when
+    # `gain` is given it replaces what kp / kv would produce
+    gain: Optional[float] = None
+    bias: Sequence[float] = (0.0, 0.0, 0.0)
     ctrlrange: Optional[Tuple[float, float]] = None
     forcerange: Optional[Tuple[float, float]] = None
 
@@ -318,6 +323,8 @@ def compile_model(spec: ModelSpec) -> CompiledModel:
     jnt_pos, jnt_axis, jnt_range, jnt_limited, jnt_stiffness = [], [], [], [], []
     joint_names: List[str] = []
     dof_bodyid, dof_jntid, dof_armature, dof_damping = [], [], [], []
+    dof_actfrcrange: List[List[float]] = []
+    F32_MAX = float(np.finfo(np.float32).max)
     qpos0: List[float] = []
     qpos_spring: List[float] = []
     geoms = []  # (type, bodyid, pos, quat, size, friction, contype, conaffinity)
@@ -365,6 +372,7 @@ def compile_model(spec: ModelSpec) -> CompiledModel:
                     dof_jntid.append(jid)
                     dof_armature.append(j.armature)
                     dof_damping.append(j.damping)
+                    dof_actfrcrange.append([-F32_MAX, F32_MAX])
                 nv += 6
             elif j.type in (JNT_HINGE, JNT_SLIDE):
                 qpos0.append(j.ref)
@@ -374,6 +382,9 @@ def compile_model(spec: ModelSpec) -> CompiledModel:
                 dof_jntid.append(jid)
                 dof_armature.append(j.armature)
                 dof_damping.append(j.damping)
+                if j.actuatorfrcrange is not None and not (j.actuatorfrcrange[0] < j.actuatorfrcrange[1]):
+                    raise ValueError(f"joint {j.name}: actuatorfrcrange {tuple(j.actuatorfrcrange)} is empty")
+                dof_actfrcrange.append([-F32_MAX, F32_MAX] if j.actuatorfrcrange is None else [float(j.actuatorfrcrange[0]), float(j.actuatorfrcrange[1])])
                 nv += 1
             else:
                 raise ValueError(f"unsupported joint type {j.type}")
@@ -474,7 +485,10 @@ def compile_model(spec: ModelSpec) -> CompiledModel:
         act_dofid[ai] = jnt_dofadr[jid]
         act_qposadr[ai] = jnt_qposadr[jid]
         act_gear[ai] = a.gear
-        if a.kp > 0:
+        if a.gain is not None:
+            act_gain[ai] = a.gain
+            act_bias[ai] = list(a.bias)
+        elif a.kp > 0:
             act_gain[ai] = a.kp
             act_bias[ai] = [0.0, -a.kp, -a.kv]
         else:
@@ -679,6 +693,7 @@ def compile_model(spec: ModelSpec) -> CompiledModel:
     put("dof_damping", dof_damping)
     put("qpos0", qpos0)
     put("qpos_spring", qpos_spring)
+    put("dof_actfrcrange", np.reshape(dof_actfrcrange, (nv, 2)))
     put("act_dofid", act_dofid, np.int32)
     put("act_qposadr", act_qposadr, np.int32)
     put("act_gear", act_gear)
@@ -869,7 +884,7 @@ _BLOB_F32 = [
     "act_gear", "act_gain", "act_bias", "act_ctrlrange", "act_forcerange",
     "con_lpos", "con_radius", "con_friction", "con_axis", "pair_geom",
     "contact_solref", "contact_solimp", "limit_solref", "limit_solimp",
-    "cvx_vert",
+    "cvx_vert", "dof_actfrcrange",
 ]
 _HDR_INT = ["nq", "nv", "nu", "nbody", "njnt", "ncon", "nlimit", "iterations", "ls_iterations", "nlevel", "nroot", "include_c_vals", "npair"]
 _HDR_F32 = ["timestep", "tolerance", "ls_tolerance", "impratio", "plane_z", "meaninertia"]
@@ -1139,7 +1154,7 @@ def synth_pile() -> ModelSpec:
     rock_z = -float(v[:, 2].min()) - 0.003
     free = lambda n: [JointSpec(n, JNT_FREE)]
     bodies = [
-        BodySpec("box", "world", pos=(0.0, 0.0, 0.1), mass=2.0, inertia=(0.033, 0.067, 0.087), joints=free("box"),
+        BodySpec("box", "world", pos=(0.0, 0.0, 0.0), mass=2.0, inertia=(0.033, 0.067, 0.087), joints=free("box"),
                  geoms=[GeomSpec(GEOM_BOX, (0.3, 0.2, 0.1), contype=0, conaffinity=1, friction=(0.9, 0.005, 0.0001))]),
         BodySpec("rock", "world", pos=(1.0, 0.0, rock_z), mass=1.5, inertia=(0.02, 0.025, 0.03), joints=free("rock"),
                  geoms=[GeomSpec(GEOM_MESH, (), vertices=tuple(map(tuple, v)), contype=0, conaffinity=1)]),

@@ -626,6 +626,10 @@ float forward(const Model& m, Work& w, const float* qpos, const float* qvel, con
     if (m.I(BI_act_forcelimited)[u]) fo = std::min(std::max(fo, m.F(BF_act_forcerange)[2 * u]), m.F(BF_act_forcerange)[2 * u + 1]);
     w.qact[d] += fo * gear;
   }
+  for (int d = 0; d < nv; ++d) {  // <joint actuatorfrcrange>: the joint's total actuator force, clamped
+    const float lo = m.F(BF_dof_actfrcrange)[2 * d], hi = m.F(BF_dof_actfrcrange)[2 * d + 1];
+    if (w.qact[d] < lo) w.qact[d] = lo; else if (w.qact[d] > hi) w.qact[d] = hi;
+  }
   for (int d = 0; d < nv; ++d) {
     const float* cd = &w.cdof[6 * d];
     const float* f = &w.cfrc[6 * dof_bodyid[d]];

@@ -758,6 +758,9 @@ class Physics:
             force = np.where(flim[None], np.clip(force, t["act_forcerange"][:, 0], t["act_forcerange"][:, 1]), force)
             np.add.at(qfrc, (slice(None), t["act_dofid"]), force * t["act_gear"][None])
             d["actuator_force"] = force
+        # MJX fwd_actuation: qfrc_actuator clipped to the joint's actuatorfrcrange where it has one (the table holds -FLT_MAX / FLT_MAX elsewhere)
+        rng_ = np.asarray(t["dof_actfrcrange"], self.dtype)
+        qfrc = np.where(qfrc < rng_[None, :, 0], rng_[None, :, 0], np.where(qfrc > rng_[None, :, 1], rng_[None, :, 1], qfrc))
         d["qfrc_actuator"] = qfrc.astype(self.dtype)
 
     def fwd_acceleration(self, d: PhysState) -> None:

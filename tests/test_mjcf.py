@@ -120,6 +120,41 @@ def test_frictionloss_is_stripped_like_the_reference_strips_it(caplog):
     assert a.to_blob(True) == b.to_blob(True)
 
 
+def test_joint_force_limits_and_the_other_actuator_kinds():
+    """<joint actuatorfrcrange> (what URDF-derived exports make of an effort limit) clamps the joint's TOTAL actuator force - MJX fwd_actuation;
+    <velocity> and <general biastype="affine"> actuators are gain / bias rows like <position>.  Known answers through the oracle."""
+    from oracle.physics_oracle import Physics
+
+    xml = HAND.replace('<joint name="knee" axis="0 1 0"/>', '<joint name="knee" axis="0 1 0" actuatorfrcrange="-3 2"/>') \
+              .replace('<position joint="knee" kp="40" forcerange="-30 30"/>', '<position joint="knee" kp="40" forcerange="-30 30"/><velocity joint="knee" kv="0.5" ctrlrange="-10 10"/>'
+                       '<general joint="hip" gainprm="2" biastype="affine" biasprm="0.25 -1 -0.1" ctrlrange="-3 3" gear="1.5"/>')
+    assert xml != HAND
+    spec = mjcf.parse_mjcf(xml)
+    assert [b for b in spec.bodies if b.name == "shin"][0].joints[0].actuatorfrcrange == (-3.0, 2.0)
+    cm = compile_model(spec)
+    nv, t = cm.nv, cm.t
+    assert t["dof_actfrcrange"][nv - 1].tolist() == [-3.0, 2.0] and t["dof_actfrcrange"][0, 1] == np.finfo(np.float32).max
+    assert t["act_gain"].tolist() == [25.0, 40.0, 0.5, 2.0] and t["act_bias"][2].tolist() == [0.0, 0.0, -0.5] and t["act_bias"][3].tolist() == [0.25, -1.0, -0.1]
+    # the writer keeps all of it
+    assert compile_model(mjcf.parse_mjcf(mjcf.to_mjcf(spec))).to_blob(True) == cm.to_blob(True)
+    ph = Physics(t, np.float64)
+    q = np.asarray(t["qpos0"], np.float64)[None].copy()
+    v = np.zeros((1, nv))
+    q[0, -2], q[0, -1], v[0, -2], v[0, -1] = 0.1, -0.2, 0.3, -0.4      # hip, knee
+    d = ph.pipeline_init(q, v)
+    d["ctrl"] = np.array([[0.0, 0.0, 1.0, 0.5]])
+    ph.fwd_actuation(d)
+    hip_pos = 25.0 * (0.0 - 0.1)
+    hip_gen = 2.0 * 0.5 + 0.25 - 1.0 * (1.5 * 0.1) - 0.1 * (1.5 * 0.3)      # length and velocity carry the gear
+    assert d["qfrc_actuator"][0, -2] == pytest.approx(hip_pos + 1.5 * hip_gen)
+    knee = 40.0 * (0.0 + 0.2) + 0.5 * (1.0 + 0.4)                          # position servo 8.0 (inside its forcerange) + velocity servo 0.7
+    assert knee == pytest.approx(8.7) and d["qfrc_actuator"][0, -1] == 2.0   # ... clamped by the joint's actuatorfrcrange
+    with pytest.raises(ValueError, match="actuatorfrclimited='true' without"):
+        mjcf.parse_mjcf(HAND.replace('<joint name="knee" axis="0 1 0"/>', '<joint name="knee" axis="0 1 0" actuatorfrclimited="true"/>'))
+    with pytest.raises(ValueError, match="only dyntype='none'"):
+        mjcf.parse_mjcf(HAND.replace('<position joint="hip"/>', '<general joint="hip" dyntype="integrator"/>'))
+
+
 def test_springref_is_the_springs_rest_position_not_ref():
     """MuJoCo: qpos0 = ref, qpos_spring = springref (both default 0) - the reference's own robot sets neither, an export may set both.  The
     spring term of the passive force (oracle passive(), the twin and the kernel read the same table) pulls towards springref."""

@@ -55,7 +55,8 @@ def random_model(seed: int) -> ModelSpec:
         ref = float(rng.uniform(-0.3, 0.3)) if rng.random() < 0.3 else 0.0
         return JointSpec(name, jt, pos=tuple(0.05 * rng.normal(size=3)), axis=tuple(_unit(rng)), range=lim, damping=float(rng.uniform(0.0, 1.5)) if rng.random() < 0.7 else 0.0,
                          armature=float(rng.uniform(0.0, 0.05)), stiffness=float(rng.uniform(1.0, 20.0)) if rng.random() < 0.3 else 0.0, ref=ref,
-                         springref=float(rng.uniform(-0.3, 0.3)) if rng.random() < 0.3 else None)
+                         springref=float(rng.uniform(-0.3, 0.3)) if rng.random() < 0.3 else None,
+                         actuatorfrcrange=(-float(rng.uniform(0.5, 8.0)), float(rng.uniform(0.5, 8.0))) if rng.random() < 0.3 else None)
 
     for b in range(nb):
         m, inert, ipos, iquat = inertial()
@@ -76,9 +77,15 @@ def random_model(seed: int) -> ModelSpec:
         for j in bodies[-1].joints:
             if j.type != JNT_FREE and rng.random() < 0.6:
                 fr = (-float(rng.uniform(2, 30)),) if rng.random() < 0.5 else None
-                if rng.random() < 0.6:
+                u = rng.random()
+                if u < 0.5:
                     acts.append(ActuatorSpec(j.name, gear=float(rng.uniform(0.5, 3.0)), kp=float(rng.uniform(2, 40)), kv=float(rng.uniform(0, 1.0)) if rng.random() < 0.3 else 0.0,
                                              ctrlrange=(-1.0, 1.0) if rng.random() < 0.7 else None, forcerange=(fr[0], -fr[0]) if fr else None))
+                elif u < 0.65:   # <velocity kv> / <general biastype="affine">
+                    kv = float(rng.uniform(0.1, 2.0))
+                    acts.append(ActuatorSpec(j.name, gear=float(rng.uniform(0.5, 2.0)), gain=kv, bias=(0.0, 0.0, -kv), ctrlrange=(-2.0, 2.0)))
+                elif u < 0.75:
+                    acts.append(ActuatorSpec(j.name, gear=float(rng.uniform(0.5, 2.0)), gain=float(rng.uniform(1, 10)), bias=tuple(rng.uniform(-2, 2, 3)), forcerange=(fr[0], -fr[0]) if fr else None))
                 else:
                     acts.append(ActuatorSpec(j.name, gear=float(rng.uniform(0.5, 30.0)), ctrlrange=(-1.0, 1.0), forcerange=(fr[0], -fr[0]) if fr else None))
     return ModelSpec(f"random_{seed}", bodies, acts, timestep=0.002, free_root_z=float(rng.uniform(0.15, 0.6)), plane_contype=5, plane_conaffinity=0,
