@@ -440,6 +440,8 @@ def parse_mjcf(xml: str, name: str = "mjcf", base_dir: Optional[Path] = None) ->
         gtype = a.get("type", "sphere")
         contype, conaff = int(a.get("contype", "1")), int(a.get("conaffinity", "1"))
         collides = (contype | conaff) != 0
+        if collides and int(a.get("priority", "0")) != 0:
+            raise ValueError(f"{what}: geom priority is not supported (a pair's friction is the larger of the two geoms', MuJoCo's rule for equal priorities)")
         quat = comp.orientation(a, what)
         pos = np.array(_floats(a.get("pos", "0 0 0"), 3, what))
         size = _floats(a["size"]) if "size" in a else []
