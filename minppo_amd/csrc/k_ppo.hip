@@ -630,6 +630,8 @@ int32_t minibatch_rowpass(const mppo_net_t& net, const float* params, const mppo
     *nblk_out = cdiv(mb, fused_rows_per_workgroup(net, mb, pre != nullptr));  // one row of loss partials per row-pass workgroup
     return MPPO_OK;
   }
+  MPPO_REQUIRE(!net.bf16, "minibatch_grad: bf16 products need the fused kernels and this geometry (O=%d A=%d H=%d: e.g. an observation too wide for the weight-gradient "
+               "tile table) runs the layer-wise path, which is float only", net.O, net.A, net.H);
   MPPO_TRY(mlp_hidden_forward(net, params, mb, batch.obs, batch.obs_ld, idx, gbuf.f, gbuf.xmb, stream));
   HeadArgs ha = head_args(net, params, mb, gbuf.f);
   ha.idx = idx; ha.b = batch; ha.adv_stat = adv_stat; ha.inv_count = inv_count; ha.lc = lc;
@@ -830,6 +832,10 @@ static int32_t check_net(const mppo_net_t* net) {
                net->O, net->A, net->H);
   MPPO_REQUIRE(net->OP >= net->O && (net->OP % 4) == 0, "OP=%d must be a multiple of 4 and >= O=%d", net->OP, net->O);
   MPPO_REQUIRE(net->num_layers >= 0 && net->num_layers <= kMaxHidden, "num_layers=%d: 1 .. %d hidden layers (0 = 2)", net->num_layers, kMaxHidden);
+  // (the engine says the same when it is created; a stand-alone call used to get as far as "gemm_launch: no bf16 variant ..." - tests/test_ppo_fuzz.py)
+  MPPO_REQUIRE(!net->bf16 || ((net->num_layers == 0 || net->num_layers == 2) && net->H % 32 == 0 && net->H <= 256 && net->A <= 32),
+               "bf16 products need the fused kernels (two hidden layers, hidden size a multiple of 32 up to 256, at most 32 actuators); O=%d A=%d H=%d layers=%d runs the "
+               "layer-wise path, which is float only", net->O, net->A, net->H, net->num_layers);
   return MPPO_OK;
 }
 
