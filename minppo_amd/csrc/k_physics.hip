@@ -20,6 +20,7 @@
 #include "mppo_common.h"
 #include <wave_ops.h>
 
+#include <algorithm>
 #include <initializer_list>
 #include <type_traits>
 #include <utility>
@@ -434,8 +435,10 @@ __global__ void __launch_bounds__(64 * kMaxWavesPerBlock) env_kernel(ModelView m
   const int tid = threadIdx.x;
   const int g = tid & (kGroupLanes - 1);
   const int row = (tid & 63) / kGroupLanes;                 // DPP row inside the wave
-  const int el = (tid >> 6) * kEnvsPerWave + row;          // environment inside the workgroup
-  int env = blockIdx.x * ((int)(blockDim.x >> 6) * kEnvsPerWave) + el;  // the launch chooses the waves per workgroup (launch_env)
+  // environments per wave: four; a run-time-sized kernel carries two or one when the robot's working set is too large for four (mppo_model_open)
+  const int epw = kDims ? kEnvsPerWave : mv.epw;
+  const int el = (tid >> 6) * epw + row;          // environment inside the workgroup
+  int env = blockIdx.x * ((int)(blockDim.x >> 6) * epw) + el;  // the launch chooses the waves per workgroup (launch_env)
   const bool valid = env < a.N;
   if (!valid) env = a.N - 1;  // surplus groups shadow the last environment and never store
   // model tables: one coalesced copy of the blob into LDS per workgroup, then every table read is a ds_read
@@ -447,7 +450,7 @@ __global__ void __launch_bounds__(64 * kMaxWavesPerBlock) env_kernel(ModelView m
     for (int i = tid; i < mv.blob_words / 4; i += (int)blockDim.x) dst[i] = src[i];
   }
   __syncthreads();  // the only workgroup-wide barrier: model tables are shared by the waves of the block
-  if (row >= kEnvsPerWave) return;  // rows without an environment
+  if (row >= epw) return;  // rows without an environment
   float* S = reinterpret_cast<float*>(smem_raw) + mv.blob_words + (size_t)el * P.total;
 
   const int nq = kDims ? kSD.nq : mv.nq, nv = kDims ? kSD.nv : mv.nv, nu = kDims ? kSD.nu : mv.nu, nb = kDims ? kSD.nbody : mv.nbody, njnt = kDims ? kSD.njnt : mv.njnt,
@@ -1592,7 +1595,7 @@ struct mppo_model {
   mppo::ModelView mv;
   mppo::PhysLds lds;
   int lds_bytes;
-  int waves;  // wavefronts per workgroup (4 environments each; one copy of the model tables per workgroup)
+  int waves;  // wavefronts per workgroup (mv.epw environments each: 4, fewer for a very large robot; one copy of the model tables per workgroup)
   int spec;  // index into the table of model-specialised kernels (spec_dims.inc), -1: the run-time-sized kernel
 };
 
@@ -1733,7 +1736,11 @@ extern "C" int32_t mppo_model_open(const void* host_blob, size_t nbytes, const v
   m->lds = make_phys_lds(v.nq, v.nv, v.nu, v.nbody, v.njnt, v.ncon, v.nefc, v.nroot, v.ncvx, m->spec >= 0 && v.nv <= 2 * kGroupLanes);
   // waves per workgroup: whatever puts the most waves on a CU (160 KB of LDS; every workgroup holds one copy of the model tables and
   // waves x 4 environments), the smaller workgroup on a tie.  MPPO_ENV_WAVES=1..4 overrides (measurements).
-  auto lds_of = [&](int w) { return (v.blob_words + m->lds.total * kEnvsPerWave * w) * 4; };
+  // A robot too large for four environments per wave (many contact slots: the Jacobian rows dominate) runs two or one per wave on the
+  // run-time-sized kernel - three quarters of the lanes idle, but it runs (round 5; before, it was refused).
+  v.epw = kEnvsPerWave;
+  auto lds_of = [&](int w) { return (int)std::min<long long>(((long long)v.blob_words + (long long)m->lds.total * v.epw * w) * 4, 1 << 30); };
+  while (lds_of(1) > 160 * 1024 && m->spec < 0 && v.epw > 1) v.epw /= 2;
   int best = 1, best_per_cu = 0;
   for (int w = 1; w <= kMaxWavesPerBlock; ++w) {
     const int per_cu = lds_of(w) <= 160 * 1024 ? (160 * 1024 / lds_of(w)) * w : 0;
@@ -1742,7 +1749,7 @@ extern "C" int32_t mppo_model_open(const void* host_blob, size_t nbytes, const v
   if (const char* e = getenv("MPPO_ENV_WAVES")) { const int w = atoi(e); if (w >= 1 && w <= kMaxWavesPerBlock) best = w; }
   m->waves = best;
   m->lds_bytes = lds_of(best);
-  if (m->lds_bytes > 160 * 1024) { delete m; return fail(MPPO_EMODEL, "model needs %d bytes of LDS per workgroup (limit 163840)", m->lds_bytes); }
+  if (m->lds_bytes > 160 * 1024) { delete m; return fail(MPPO_EMODEL, "model needs %d bytes of LDS per workgroup for ONE environment (limit 163840)", m->lds_bytes); }
   *out = m;
   return MPPO_OK;
 }
@@ -1769,7 +1776,7 @@ extern "C" int32_t mppo_model_get_dims(const mppo_model_t* m, mppo_model_dims_t*
 
 namespace mppo {
 static int32_t launch_env(const mppo_model_t* m, const EnvArgs& a, hipStream_t stream) {
-  const int blocks = cdiv(a.N, kEnvsPerWave * m->waves);
+  const int blocks = cdiv(a.N, m->mv.epw * m->waves);
   return (m->spec >= 0 ? kSpecs[m->spec].launch : &launch_env_t<RuntimeModel>)(m->mv, a, m->lds, m->lds_bytes, blocks, m->waves, stream);
 }
 }  // namespace mppo

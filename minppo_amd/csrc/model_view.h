@@ -49,6 +49,7 @@ struct ModelView {
   float timestep, tolerance, ls_tolerance, impratio, plane_z, meaninertia;
   const int* blob;   // device copy of the whole blob (16-byte aligned)
   int blob_words;    // multiple of 4: the TABLE part (what the kernel copies into LDS)
+  int epw;           // environments per wave of the run-time-sized kernel: 4, or 2 / 1 for a robot whose working set would not fit LDS four at a time
   int ncyl;          // cylinders against the plane: three contact slots each (con_cvx = -2, -3, -4); run-time-sized kernel only
   int hull_words;    // the hull section behind it (0: the model has no convex geom in a geom-geom pair); read from global memory
   int o[BLOB_ARRAY_COUNT];

@@ -125,22 +125,19 @@ def _states(cm, N, rng):
     return q, 0.5 * rng.normal(size=(N, cm.nv)), rng.uniform(-1.3, 1.3, size=(N, cm.nu))
 
 
-SEEDS = list(range(12))
+SEEDS = list(range(12)) + [17]
 
 
 @pytest.mark.parametrize("seed", SEEDS)
 def test_kernel_follows_the_oracle_on_a_random_robot(be, seed):
     from test_kernels_physics import _probe
 
-    from minppo_amd import _native as nat
-
     cm = compile_model(random_model(seed))
-    try:
-        h, dims, _keep = be.model(cm)
-    except nat.NativeError as e:   # a robot with very many contact candidates does not fit the kernel's LDS-resident layout: a loud error, by design
-        assert "bytes of LDS" in str(e)
-        pytest.skip(str(e))
-    N = 8
+    # (a robot with very many contact candidates - seed 17: 130 slots, 527 constraint rows - does not fit LDS four environments to a wave: the
+    # run-time-sized kernel then carries two or one per wave; until round 5 such a robot was refused)
+    h, dims, _keep = be.model(cm)
+    assert dims.lds_bytes <= 160 * 1024
+    N = 8 if seed % 2 == 0 else 7   # (7: the last workgroup is ragged whatever the environments per wave)
     rng = np.random.default_rng(seed)
     qpos, qvel, ctrl = _states(cm, N, rng)
     q32 = [x.astype(f32) for x in (qpos, qvel, ctrl if cm.nu else np.zeros((N, 1)), np.zeros((N, cm.nv)))]
