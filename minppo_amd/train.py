@@ -186,6 +186,10 @@ def reward_cfg(config: Config) -> nat.RewardCfg:
 
 
 def resolve_model(config: Config) -> CompiledModel:
+    # `environment.backend` goes to brax's PipelineEnv in the reference (env.py:102: "mjx", or one of brax's own pipelines); the engine is a
+    # restatement of the MJX pipeline and nothing else - any other value used to be read and ignored
+    if config.environment.backend != "mjx":
+        raise ValueError(f"environment.backend={config.environment.backend!r}: only the MJX pipeline ('mjx', the reference's default) exists in this engine")
     name = config.environment.model or require(config.kscale_id, "kscale_id")
     return load_model(name)
 

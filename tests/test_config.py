@@ -41,3 +41,16 @@ def test_errors_follow_the_reference():
         make_config({}, ["training.num_envs=abc"])
     with pytest.raises(MissingMandatoryValue):
         require(Config().kscale_id, "kscale_id")
+
+
+def test_a_backend_other_than_mjx_is_refused():
+    """`environment.backend` selects brax's pipeline in the reference (env.py:102); only the MJX one is restated here - another value is an
+    error, not something read and ignored."""
+    import pytest
+
+    from minppo_amd.config import make_config
+    from minppo_amd.train import resolve_model
+
+    assert resolve_model(make_config({"kscale_id": "synth_stompy_pro"})).name == "synth_stompy_pro"
+    with pytest.raises(ValueError, match="only the MJX pipeline"):
+        resolve_model(make_config({"kscale_id": "synth_stompy_pro", "environment": {"backend": "positional"}}))
