@@ -61,9 +61,11 @@ def test_minibatch_step_on_a_random_shape(be, seed):
                               g, btgt[idx].astype(np.float64), 0.2, 0.5, ent, bool(tanh), bf16=bf16)
     got, g64 = be.host(grad), po.named_to_flat(gr, O, A, H)
     assert not np.isnan(got).any(), (O, A, H, mb, bf16)
-    np.testing.assert_allclose(be.host(loss4), lo, rtol=2e-4 if bf16 else 1e-5, atol=2e-5 if bf16 else 1e-6, err_msg=str((O, A, H, mb, bf16)))
+    # (bf16: the tolerances of test_bf16_mfma_path - operands rounded on both sides, only boundary flips of single operands remain; float: a
+    # three-row minibatch's loss sums carry a few 1e-6 of cancellation)
+    np.testing.assert_allclose(be.host(loss4), lo, rtol=2e-3 if bf16 else 5e-5, atol=1e-5 if bf16 else 5e-6, err_msg=str((O, A, H, mb, bf16)))
     for k, (o, s) in po.param_slices(O, A, H).items():
         sz = int(np.prod(s))
-        tol = (2e-3 if bf16 else 1e-4) * np.abs(g64[o:o + sz]).max() + 1e-7
+        tol = (5e-3 if bf16 else 1e-4) * np.abs(g64[o:o + sz]).max() + 1e-7
         np.testing.assert_allclose(got[o:o + sz], g64[o:o + sz], rtol=0, atol=tol, err_msg=f"{k} at {(O, A, H, mb, bf16)}")
 
