@@ -25,12 +25,38 @@ def _small(be):
     return ["training.num_envs=256", "training.num_minibatches=8", "training.update_epochs=2", "training.total_timesteps=100000000"]
 
 
-@pytest.mark.parametrize("robot", ["stompy_pro", "stompy_full", "stompy_pro_no_c_vals", "stompy_pro_1_layer", "stompy_pro_3_layers", "stompy_pro_ragged", "row_tiles_32"])
+def _random_engine_config(seed, emu):
+    """A random configuration of the whole engine (tests of the hand-picked ones sit on known edges): environments, rollout length, minibatch
+    count (a divisor of the batch), epochs, hidden width, depth, robot, observation kind (float products, tanh, one frame per step: what the
+    oracle side of the test below is written for)."""
+    rng = np.random.default_rng(4000 + seed)
+    T = int(rng.integers(1, 5 if emu else 12))
+    N = int(rng.integers(6, 16 if emu else 700))   # (the free-running physics comparison below is a statistic over environments)
+    div = [m for m in range(1, 17) if (T * N) % m == 0]
+    M = int(rng.choice(div))
+    layers = int(rng.choice([1, 2, 2, 2, 3]))
+    H = int(rng.choice([32, 64] if emu else [32, 64, 96, 128, 160, 256, 40, 200]))
+    over = [f"training.num_envs={N}", f"training.num_steps={T}", f"rl.num_env_steps={T}", f"training.num_minibatches={M}", f"training.update_epochs={int(rng.integers(1, 4))}",
+            f"model.hidden_size={H}", f"model.num_layers={layers}", "training.total_timesteps=100000000"]
+    if rng.random() < 0.3:
+        over.append("environment.model=synth_stompy_full")
+    if rng.random() < 0.25:
+        over.append("environment.include_c_vals=false")
+    return over
+
+
+import os
+
+_FUZZ = [f"fuzz{k}" for k in range(int(os.environ.get("MPPO_FUZZ_ENGINES", "3")))]   # (MPPO_FUZZ_ENGINES=60 on the GPU: DESIGN.md section 5)
+
+
+@pytest.mark.parametrize("robot", ["stompy_pro", "stompy_full", "stompy_pro_no_c_vals", "stompy_pro_1_layer", "stompy_pro_3_layers", "stompy_pro_ragged", "row_tiles_32"] + _FUZZ)
 def test_update_matches_oracle_stage_by_stage(be, robot):
     """Both BASELINE robots: configs[1] (synth_stompy_pro, O = 225, A = 10) and configs[4] (synth_stompy_full, O = 415, A = 20);
     the short observation of `environment.include_c_vals=false` (qpos, qvel, qfrc_actuator: O = 49; reference env.py:254-259);
     and `model.num_layers` = 1 / 3 (reference config.py:53, train.py:79,82; the layer-wise kernels)."""
-    cfg = _cfg(*_small(be), *(["environment.model=synth_stompy_full"] if robot == "stompy_full" else []),
+    cfg = _cfg(*(_small(be) if not robot.startswith("fuzz") else _random_engine_config(int(robot[4:]), be.name == "emu")),
+               *(["environment.model=synth_stompy_full"] if robot == "stompy_full" else []),
                *(["environment.include_c_vals=false"] if robot == "stompy_pro_no_c_vals" else []),
                *(["model.num_layers=1"] if robot == "stompy_pro_1_layer" else []), *(["model.num_layers=3"] if robot == "stompy_pro_3_layers" else []),
                # minibatches of 9 rows (emulator) / 190 rows (GPU): not a multiple of the 4-row quads nor of the 16-row tiles - the pre-gathered
