@@ -18,7 +18,13 @@ if os.environ.get("MPPO_ENV_TIME_CASES"):  # e.g. "synth_stompy_pro:8192,synth_s
 for model, N in cases:
     if only and model != only:
         continue
-    cm = load_model(model)
+    if model.startswith("random"):  # random<seed>: a robot of tests/test_model_fuzz.py (e.g. random17: 130 contact slots, one environment per wave)
+        sys.path.insert(0, str(Path(__file__).resolve().parents[1] / "tests"))
+        from test_model_fuzz import random_model
+        from minppo_amd.model import compile_model
+        cm = compile_model(random_model(int(model[6:])))
+    else:
+        cm = load_model(model)
     blob = np.frombuffer(cm.to_blob(), np.uint8)
     dblob = torch.from_numpy(blob.copy()).cuda()
     h = C.c_void_p()
@@ -43,5 +49,5 @@ for model, N in cases:
     e0.record()
     for k in range(30): step(k)
     e1.record(); torch.cuda.synchronize()
-    print(f"{model} N={N}: {e0.elapsed_time(e1) / 30 * 1e3:.1f} us per env_step launch; state checksum {float(state.double().sum()):.6f} done {int(done.sum())}")
+    print(f"{model} (nv {cm.nv}, {cm.ncon} contact slots, {cm.nefc} constraint rows, {dims.lds_bytes} bytes of LDS per workgroup) N={N}: {e0.elapsed_time(e1) / 30 * 1e3:.1f} us per env_step launch; state checksum {float(state.double().sum()):.6f} done {int(done.sum())}")
     lib.model_close(h)
