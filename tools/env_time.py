@@ -38,11 +38,11 @@ for model, N in cases:
     met = nat.EnvMetrics(*[t.data_ptr() for t in met_keep])  # (the tensors must outlive the launches: the kernel writes the episode metrics through these pointers)
     lib.env_reset(h, N, state.data_ptr(), reset.data_ptr(), obs.data_ptr(), dims.obs_pad, 0, 0, C.byref(met), s)
     g = torch.Generator(device="cuda"); g.manual_seed(0)
-    acts = [torch.randn(N, dims.nu, device="cuda", generator=g) for _ in range(10)]
+    acts = [torch.randn(N, max(dims.nu, 1), device="cuda", generator=g) for _ in range(10)]  # (a robot without actuators still passes a pointer)
     rew = torch.zeros(N, device="cuda"); done = torch.zeros(N, dtype=torch.uint8, device="cuda")
     rc = nat.RewardCfg(-0.2, 2.0, 2.0, 0.2, 0.5, 0.1, 4.0, 1.0, 1.25)
     def step(k):
-        lib.env_step(h, N, 1, C.byref(rc), state.data_ptr(), reset.data_ptr(), acts[k % 10].data_ptr(), dims.nu, obs.data_ptr(), dims.obs_pad, rew.data_ptr(), done.data_ptr(), C.byref(met), s)
+        lib.env_step(h, N, 1, C.byref(rc), state.data_ptr(), reset.data_ptr(), acts[k % 10].data_ptr(), max(dims.nu, 1), obs.data_ptr(), dims.obs_pad, rew.data_ptr(), done.data_ptr(), C.byref(met), s)
     for k in range(10): step(k)
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
