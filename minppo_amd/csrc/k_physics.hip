@@ -414,10 +414,10 @@ struct RuntimeModel {
   static constexpr bool kStatic = false;
   static constexpr BlobDims dims() { return BlobDims{}; }
 };
-template <int NQ, int NV, int NU, int NBODY, int NJNT, int NCON, int NLIMIT, int NPAIR, int NLEVEL, int NROOT, int NCVX = 0, int NCVXVERT = 0>
+template <int NQ, int NV, int NU, int NBODY, int NJNT, int NCON, int NLIMIT, int NPAIR, int NLEVEL, int NROOT, int NCVX = 0, int NCVXVERT = 0, int HULL = 0, int NCYL = 0>
 struct StaticModel {
   static constexpr bool kStatic = true;
-  static constexpr BlobDims dims() { return BlobDims{NQ, NV, NU, NBODY, NJNT, NCON, NLIMIT, NPAIR, NLEVEL, NROOT, NCVX, NCVXVERT}; }
+  static constexpr BlobDims dims() { return BlobDims{NQ, NV, NU, NBODY, NJNT, NCON, NLIMIT, NPAIR, NLEVEL, NROOT, NCVX, NCVXVERT, HULL, NCYL}; }
 };
 // MODE (EnvArgs::mode) is a template parameter too: the step kernel carries neither the probe's 17 output pointers nor its stores.
 template <class SD, int MODE>
@@ -470,6 +470,8 @@ __global__ void __launch_bounds__(64 * kMaxWavesPerBlock) env_kernel(ModelView m
   float* eD = S + P.D; float* earef = S + P.aref; float* jaref = S + P.jaref; float* jv = S + P.jv; float* force = S + P.force;
   float* conpos = S + P.conpos; float* condist = S + P.condist; float* confr = S + P.confr;
   const int npair = kDims ? kSD.npair : mv.npair, nplane = ncon - npair, ncvx = kDims ? kSD.ncvx : mv.ncvx;
+  // (features that select code: constants in a model-specialised kernel - a robot without hull pairs / cylinders carries none of it)
+  const bool has_hull = kDims ? kSD.hull != 0 : mv.hull_words > 0, has_cyl = kDims ? kSD.ncyl > 0 : mv.ncyl > 0;
   float* cvxsel = S + P.cvxsel; float* cvxok = S + P.cvxok;
   float* xanchor = S + P.xanchor; float* xaxis = S + P.xaxis;
   float* Cw = S + P.C; float* cdofdot = S + P.cdofdot; float* cfrc = S + P.cfrc; float* J = (float*)__builtin_assume_aligned(S + P.J, 16);
@@ -649,7 +651,7 @@ __global__ void __launch_bounds__(64 * kMaxWavesPerBlock) env_kernel(ModelView m
     FOR_G(c, nplane) {  // ground contacts (MJX plane_sphere / plane_capsule; a box corner is a sphere of radius 0; a convex geom's chosen vertices)
       const int b = TI(con_bodyid)[c];
       const Q4 q = ld4(xquat + 4 * b);
-      if (!kDims && mv.ncyl > 0 && TI(con_cvx)[c] <= -2) {
+      if (has_cyl && TI(con_cvx)[c] <= -2) {
         // a cylinder against the plane, MJX collision_primitive.plane_cylinder: three slots, placed by the lane that owns the first - the
         // point of the lower rim nearest to the plane and two more of that rim 120 degrees to either side; lying on its side
         // (|axis . n| half < 1e-3): the nearest point of the other rim in slot 1
@@ -699,7 +701,7 @@ __global__ void __launch_bounds__(64 * kMaxWavesPerBlock) env_kernel(ModelView m
       const int c = nplane + k;
       const int b1 = TI(pair_body)[2 * k], b2 = TI(pair_body)[2 * k + 1];
       const float* gp = TF(pair_geom) + 16 * k;
-      if (!kDims && gp[7] != 0.f) continue;  // geom 2 is a convex hull: below
+      if (has_hull && gp[7] != 0.f) continue;  // geom 2 is a convex hull: below
       const Q4 q1 = ld4(xquat + 4 * b1), q2 = ld4(xquat + 4 * b2);
       const V3 c1 = add3(ld3(xpos + 3 * b1), qrot(q1, ld3(gp))), h1 = qrot(q1, ld3(gp + 3));
       const V3 c2 = add3(ld3(xpos + 3 * b2), qrot(q2, ld3(gp + 8))), h2 = qrot(q2, ld3(gp + 11));
@@ -714,7 +716,7 @@ __global__ void __launch_bounds__(64 * kMaxWavesPerBlock) env_kernel(ModelView m
       st3(confr + 6 * c, n);
       st3(confr + 6 * c + 3, frame_tangent(n));
     }
-    if (!kDims && mv.hull_words > 0) {
+    if (has_hull) {
       // sphere / capsule against a box or a mesh hull of another body (pair rows tagged with a hull; run-time-sized kernel only): one
       // pair at a time, the environment's 16 lanes together.  Geometry in the frame of the hull's body, results back in the world.
       const int* hs = mv.blob + mv.blob_words;
@@ -1584,7 +1586,7 @@ static int find_spec(const BlobDims& d) {
   for (int i = 0; kSpecs[i].launch; ++i) {
     const BlobDims& s = kSpecs[i].d;
     if (s.nq == d.nq && s.nv == d.nv && s.nu == d.nu && s.nbody == d.nbody && s.njnt == d.njnt && s.ncon == d.ncon && s.nlimit == d.nlimit &&
-        s.npair == d.npair && s.nlevel == d.nlevel && s.nroot == d.nroot && s.ncvx == d.ncvx && s.ncvxvert == d.ncvxvert)
+        s.npair == d.npair && s.nlevel == d.nlevel && s.nroot == d.nroot && s.ncvx == d.ncvx && s.ncvxvert == d.ncvxvert && s.hull == d.hull && s.ncyl == d.ncyl)
       return i;
   }
   return -1;
@@ -1634,7 +1636,7 @@ extern "C" int32_t mppo_model_open(const void* host_blob, size_t nbytes, const v
     return bad("dimension out of the supported range (nbody<=128, nv<=64)");
   if (!(v.timestep > 0.f) || !(v.meaninertia > 0.f) || !(v.impratio > 0.f)) return bad("non-positive timestep / meaninertia / impratio");
   const int32_t* dir = wi + kBlobHeaderWords;
-  const BlobDims bd{v.nq, v.nv, v.nu, v.nbody, v.njnt, v.ncon, v.nlimit, v.npair, v.nlevel, v.nroot, v.ncvx, v.ncvxvert};
+  BlobDims bd{v.nq, v.nv, v.nu, v.nbody, v.njnt, v.ncon, v.nlimit, v.npair, v.nlevel, v.nroot, v.ncvx, v.ncvxvert, 0, 0};
   const BlobOffsets canon = blob_offsets(bd);
   const size_t dir_end = kBlobHeaderWords + 2 * (size_t)BLOB_ARRAY_COUNT;
   if (dir_end > total) return bad("directory past the end");
@@ -1731,7 +1733,8 @@ extern "C" int32_t mppo_model_open(const void* host_blob, size_t nbytes, const v
   v.obs_dim = v.nq + 2 * v.nv + (v.include_c ? 16 * (v.nbody - 1) : 0);  // env.py:246-259
   v.obs_pad = (v.obs_dim + 3) & ~3;
   v.rec_dim = v.obs_pad + ((v.nv + 2 + 3) & ~3);
-  m->spec = v.hull_words > 0 || v.ncyl > 0 ? -1 : find_spec(bd);  // (hull pairs, cylinders: the run-time-sized kernel)
+  bd.hull = v.hull_words > 0 ? 1 : 0; bd.ncyl = v.ncyl;
+  m->spec = find_spec(bd);
   // (a model-specialised kernel of up to 32 dofs keeps the inverse Cholesky factor in registers: no LL square in its layout)
   m->lds = make_phys_lds(v.nq, v.nv, v.nu, v.nbody, v.njnt, v.ncon, v.nefc, v.nroot, v.ncvx, m->spec >= 0 && v.nv <= 2 * kGroupLanes);
   // waves per workgroup: whatever puts the most waves on a CU (160 KB of LDS; every workgroup holds one copy of the model tables and
@@ -1739,6 +1742,11 @@ extern "C" int32_t mppo_model_open(const void* host_blob, size_t nbytes, const v
   // A robot too large for four environments per wave (many contact slots: the Jacobian rows dominate) runs two or one per wave on the
   // run-time-sized kernel - three quarters of the lanes idle, but it runs (round 5; before, it was refused).
   v.epw = kEnvsPerWave;
+  if (m->spec >= 0 && ((long long)v.blob_words + (long long)m->lds.total * kEnvsPerWave) * 4 > 160 * 1024) {
+    // (a specialised kernel carries four environments per wave; a robot too large for that runs the run-time-sized kernel with fewer)
+    m->spec = -1;
+    m->lds = make_phys_lds(v.nq, v.nv, v.nu, v.nbody, v.njnt, v.ncon, v.nefc, v.nroot, v.ncvx, false);
+  }
   auto lds_of = [&](int w) { return (int)std::min<long long>(((long long)v.blob_words + (long long)m->lds.total * v.epw * w) * 4, 1 << 30); };
   while (lds_of(1) > 160 * 1024 && m->spec < 0 && v.epw > 1) v.epw /= 2;
   int best = 1, best_per_cu = 0;

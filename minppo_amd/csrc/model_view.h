@@ -58,7 +58,8 @@ struct ModelView {
 // The dims every array length follows from, and the canonical placement of the arrays (model.py _to_blob: directory order, each
 // array padded to 4 words, first array right after the directory).  mppo_model_open refuses a blob laid out differently, so a
 // kernel compiled for fixed dims may take the offsets as constants.
-struct BlobDims { int nq, nv, nu, nbody, njnt, ncon, nlimit, npair, nlevel, nroot, ncvx, ncvxvert; };
+struct BlobDims { int nq, nv, nu, nbody, njnt, ncon, nlimit, npair, nlevel, nroot, ncvx, ncvxvert;
+                  int hull, ncyl; };  // (hull: 1 if the model has a hull section; ncyl: its cylinders - they select code, not table sizes)
 struct BlobOffsets { int o[BLOB_ARRAY_COUNT]; int words; };
 __host__ __device__ constexpr inline int blob_array_len(const BlobDims& d, int k) {
   switch (k) {

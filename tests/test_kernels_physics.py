@@ -485,11 +485,12 @@ def test_specialised_kernel_equals_the_runtime_sized_kernel(be, monkeypatch):
     """The BASELINE robots run an env_kernel instantiation compiled for their dimensions (csrc/spec_dims.inc); every other
     model - and these two under MPPO_ENV_GENERIC=1 - runs the run-time-sized instantiation of the same source.  Same
     arithmetic in the same order: the forward probe and a stretch of env steps agree bit for bit."""
-    for model in ("synth_stompy_pro", "synth_stompy_full"):
+    # (synth_pile: hull pairs, a cylinder and plane_convex in one robot - those code paths specialise too since round 5)
+    for model in ("synth_stompy_pro", "synth_stompy_full", "synth_pile"):
         cm = load_model(model)
         N = 9
         ph, d, rng = _walk(cm, N, 5, 8)
-        ctrl = 0.4 * rng.standard_normal((N, cm.nu))
+        ctrl = 0.4 * rng.standard_normal((N, max(cm.nu, 1)))
         q32 = [x.astype(f32) for x in (d.qpos, d.qvel, ctrl, d.qacc_warmstart)]
         res = []
         for generic in (False, True):
@@ -506,11 +507,11 @@ def test_specialised_kernel_equals_the_runtime_sized_kernel(be, monkeypatch):
             state, reset_rec, obs = be.zeros((N, R)), be.zeros((R,)), be.zeros((N, OP))
             rew, done = be.zeros((N,)), be.zeros((N,), np.uint8)
             be.lib.env_reset(h, N, be.ptr(state), be.ptr(reset_rec), be.ptr(obs), OP, be.ptr(rew), be.ptr(done), None, be.stream)
-            rc = nat.RewardCfg(0.95, 2.0, 2.0, 0.2, 0.5, 0.1, 4.0, 1.0, 1.25)
+            rc = nat.RewardCfg(0.95 if model != "synth_pile" else -1.0, 2.0, 2.0, 0.2, 0.5, 0.1, 4.0, 1.0, 1.25)
             r2 = np.random.default_rng(3)
             for _ in range(6):
-                act = be.arr((0.8 * r2.standard_normal((N, cm.nu))).astype(f32))
-                be.lib.env_step(h, N, 2, C.byref(rc), be.ptr(state), be.ptr(reset_rec), be.ptr(act), cm.nu, be.ptr(obs), OP, be.ptr(rew), be.ptr(done), None, be.stream)
+                act = be.arr((0.8 * r2.standard_normal((N, max(cm.nu, 1)))).astype(f32))
+                be.lib.env_step(h, N, 2, C.byref(rc), be.ptr(state), be.ptr(reset_rec), be.ptr(act), max(cm.nu, 1), be.ptr(obs), OP, be.ptr(rew), be.ptr(done), None, be.stream)
                 be.sync()  # the launch is asynchronous on the backend's stream: `act` must outlive it
             got.update(state=be.host(state).copy(), obs=be.host(obs).copy(), rew=be.host(rew).copy(), done=be.host(done).copy())
             res.append(got)
