@@ -648,7 +648,7 @@ __global__ void __launch_bounds__(64 * kMaxWavesPerBlock) env_kernel(ModelView m
       }
       SYNC();
     }
-    FOR_G(c, nplane) {  // ground contacts (MJX plane_sphere / plane_capsule; a box corner is a sphere of radius 0; a convex geom's chosen vertices)
+    FOR_G(c, nplane) {  // ground contacts (MJX plane_sphere / plane_capsule; a box's or a mesh's chosen hull vertices: plane_convex)
       const int b = TI(con_bodyid)[c];
       const Q4 q = ld4(xquat + 4 * b);
       if (has_cyl && TI(con_cvx)[c] <= -2) {

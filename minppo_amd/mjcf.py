@@ -19,7 +19,7 @@ Subset
       <inertial pos quat|euler mass diaginertia|fullinertia>
       <freejoint/> | <joint type="free|hinge|slide" name pos axis range limited ref springref damping armature stiffness actuatorfrcrange>
       <geom type="sphere|capsule|cylinder|box|mesh" size pos quat|euler fromto friction mass density contype conaffinity mesh>
-            (a box collides with the ground through its eight corners; a mesh collides with the ground as its CONVEX HULL, as in
+            (a box - the convex mesh of its eight corners - and a mesh collide with the ground as a CONVEX HULL, as in
              MuJoCo / MJX - up to four contacts per step, MJX's plane_convex; a cylinder meets the ground with three contacts per step,
              MJX's plane_cylinder, and nothing else; type="ellipsoid" geoms are accepted ONLY with contype="0" conaffinity="0", i.e.
              visual or inertia-only, and then still contribute to inertiafromgeom; a mesh never contributes an inertia: its body needs

@@ -500,7 +500,7 @@ def compile_model(spec: ModelSpec) -> CompiledModel:
             act_forcerange[ai] = a.forcerange
             act_forcelimited[ai] = 1
 
-    # collision candidates, MJX-style static slots.  First every sphere / capsule end / box corner against the ground plane ...
+    # collision candidates, MJX-style static slots.  First every sphere / capsule end / hull (box, mesh) / cylinder against the ground plane ...
     def _masks_match(ct1, ca1, ct2, ca2):
         return bool((ct1 & ca2) | (ct2 & ca1))
 
@@ -513,9 +513,14 @@ def compile_model(spec: ModelSpec) -> CompiledModel:
             continue
         fri = np.maximum(np.asarray(gfri), np.asarray(spec.plane_friction))
         axis_l = np.zeros(3)
-        if gt == GEOM_MESH:
+        if gt in (GEOM_MESH, GEOM_BOX):
             # a convex hull against the plane, MJX collision_convex.plane_convex: FOUR slots per geom; which hull vertices fill them
-            # is decided every step (the deepest ones, spread out: _manifold_points), duplicates are switched off
+            # is decided every step (the deepest ones, spread out: _manifold_points), duplicates are switched off.  A BOX takes the same
+            # route in MJX (its collision table sends (plane, box) to plane_convex: the box is a convex mesh of its eight corners, in the
+            # order of mesh.box - x outermost, z innermost) - NOT the C engine's mjc_PlaneBox: only corners within 1 mm of the deepest one
+            # are candidates.  Until the end of round 5 a box was eight independent corner contacts here (the C engine's behaviour).
+            if gt == GEOM_BOX:
+                gverts = np.asarray([[sx * gsize[0], sy * gsize[1], sz * gsize[2]] for sx in (-1.0, 1.0) for sy in (-1.0, 1.0) for sz in (-1.0, 1.0)])
             k = len(cvx_body)
             cvx_body.append(bi)
             for v in gverts:
@@ -537,19 +542,14 @@ def compile_model(spec: ModelSpec) -> CompiledModel:
             continue
         if gt == GEOM_SPHERE:
             ends = [np.asarray(gpos, dtype=np.float64)]
-        elif gt == GEOM_CAPSULE:
+        else:
             axis_l = _qrot(gquat, [0, 0, 1.0])  # the two end contacts share a frame whose first tangent follows this axis
             axis = axis_l * gsize[1]
             ends = [np.asarray(gpos) + axis, np.asarray(gpos) - axis]
-        else:
-            # a box against the ground plane touches with its corners: eight point contacts (radius 0).  MuJoCo's plane-box
-            # routine reports at most four of them per step - the same set whenever no more than four corners penetrate,
-            # which is every pose of a box that is not sunk to its middle.
-            ends = [np.asarray(gpos) + _qrot(gquat, [sx * gsize[0], sy * gsize[1], sz * gsize[2]]) for sx in (-1.0, 1.0) for sy in (-1.0, 1.0) for sz in (-1.0, 1.0)]
         for e in ends:
             con_bodyid.append(bi)
             con_lpos.append(list(e))
-            con_radius.append(0.0 if gt == GEOM_BOX else gsize[0])
+            con_radius.append(gsize[0])
             con_friction.append(list(fri))
             con_axis.append(list(axis_l))
             con_cvx.append(-1)
@@ -1119,7 +1119,7 @@ def synth_ball() -> ModelSpec:
 
 
 def synth_brick() -> ModelSpec:
-    """A free box above the plane, tilted: the box collider's corner contacts (landing on one corner, then an edge, then a face)."""
+    """A free box above the plane, tilted: the box collider (plane_convex on its eight corners; landing on one corner, then an edge, then a face)."""
     bodies = [
         BodySpec("brick", "world", quat=(0.9659258, 0.1830127, 0.1830127, 0.0), mass=1.2, inertia=(0.0013, 0.0044, 0.0055),
                  joints=[JointSpec("root", JNT_FREE)], geoms=[GeomSpec(GEOM_BOX, (0.10, 0.05, 0.02))]),

@@ -411,7 +411,7 @@ float forward(const Model& m, Work& w, const float* qpos, const float* qvel, con
     }
   }
   cholesky(w.M.data(), w.L.data(), nv);
-  // ---- collision: ground contacts (plane-sphere / plane-capsule end / box corner / chosen hull vertices), geom-geom pairs
+  // ---- collision: ground contacts (plane-sphere / plane-capsule end / a box's or a mesh's chosen hull vertices / cylinder rims), geom-geom pairs
   for (int k = 0; k < m.ncvx; ++k) {  // MJX collision_convex.plane_convex + _manifold_points
     const int b = m.I(BI_cvx_body)[k], v0 = m.I(BI_cvx_vadr)[k], v1 = m.I(BI_cvx_vadr)[k + 1];
     float R[9];

@@ -523,7 +523,7 @@ class Physics:
 
     def collision(self, d: PhysState) -> None:
         """Every candidate keeps a slot (MJX static shapes).  The first ncon - npair slots are ground contacts (MJX
-        collision_primitive.plane_sphere / plane_capsule; a box corner is a sphere of radius 0), the last npair are geom-geom
+        collision_primitive.plane_sphere / plane_capsule, plane_cylinder, collision_convex.plane_convex for boxes and meshes), the last npair are geom-geom
         pairs (sphere_sphere / sphere_capsule / capsule_capsule: one contact each)."""
         t = self.t
         N = d.qpos.shape[0]

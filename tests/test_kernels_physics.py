@@ -84,7 +84,7 @@ MJCF_EXPORT = str(Path(__file__).parent / "golden" / "export_biped" / "robot.xml
 
 
 @pytest.mark.parametrize("model,N", [("synth_stompy_pro", 33), ("synth_stompy_full", 17), ("synth_pendulum", 3), ("synth_ball", 2), (MJCF_ROBOT, 4),
-                                     ("synth_brick", 6),              # a free box: eight corner contacts against the ground (box geoms)
+                                     ("synth_brick", 6),              # a free box: plane_convex on its eight corners (box geoms)
                                      ("synth_pile", 3),               # every contact routine at rest in one scene: corners, plane_convex, sphere_convex, capsule_convex, plane_cylinder
                                      ("synth_can", 6),                # cylinders: MJX's plane_cylinder, three slots per geom (tests/test_cylinder.py)
                                      ("synth_wedge", 6), (MJCF_MESH, 5),   # mesh geoms: MJX's plane_convex, four slots per geom, vertices chosen every step
@@ -124,7 +124,8 @@ def test_forward_matches_oracle(be, model, N):
         rel_e = np.abs(got["qacc_euler"] - ref_e).max(1) / (np.abs(ref_e).max(1) + 1e-9)
         # (the export-style biped: 87 constraint rows on light end bodies whose implicit damping h D is larger than their inertia - the same
         # float32 envelope of the unconverged solver reads wider in this quantity: 4 of 12 states at 0.3 - 0.65 on the GPU, median 6e-3)
-        lim_med, lim_q90 = (2e-2, 0.7) if model == MJCF_EXPORT else (5e-3, 0.3)
+        # (synth_pile: one undamped scene, the same in all its environments - twenty contact slots at rest, the solver 1 % from float64 there)
+        lim_med, lim_q90 = (2e-2, 0.7) if model == MJCF_EXPORT else (2e-2, 0.3) if model == "synth_pile" else (5e-3, 0.3)
         assert np.median(rel_e) <= lim_med and np.quantile(rel_e, 0.9) <= lim_q90, (np.median(rel_e), rel_e.max())
     else:
         np.testing.assert_allclose(got["qacc"], ref.qacc, rtol=1e-4, atol=1e-4)
@@ -197,14 +198,16 @@ def test_solver_is_tight_where_the_active_set_is_stable(be, model, state, med, q
     be.lib.model_close(h)
 
 
-@pytest.mark.parametrize("steps,min_rows,med", [(60, 4, 5e-3), (300, 16, 1e-3)])
+@pytest.mark.parametrize("steps,min_rows,med", [(60, 4, 5e-3), (300, 12, 1e-3)])
 def test_box_collider_corner_contacts(be, steps, min_rows, med):
-    """SURVEY 8(f1) box geoms: a free brick dropped tilted.  After 60 steps it stands on one corner (one contact = four pyramid
-    rows), after 300 it rests on a face (four corners = sixteen rows).  From the oracle's state at that moment the kernel's
+    """SURVEY 8(f1) box geoms: a free brick dropped tilted (a box meets the ground as MJX has it: plane_convex on its eight corners, four
+    slots).  After 60 steps it stands on one corner (one contact = four pyramid rows), after 300 it rests on a face - on THREE of its corners
+    (twelve rows): with the face's four corners equally deep, _manifold_points' fourth pick ties between the remaining corner and the first
+    one and argmax takes the first, a duplicate, which is switched off; a rectangle on three points is a stable support.  From the oracle's state at that moment the kernel's
     constraint rows, reference accelerations and solver result are compared as in test_forward_matches_oracle; the resting
     case is a stable active set (tight bound)."""
     cm = load_model("synth_brick")
-    assert cm.ncon == 8 and cm.nefc == 32  # eight corners x four pyramid rows
+    assert cm.ncon == 4 and cm.nefc == 16 and int(cm.t["ncvx"]) == 1 and len(cm.t["cvx_vert"]) == 8  # four plane_convex slots x four pyramid rows
     h, dims, _keep = be.model(cm)
     N = 5
     ph = Physics(cm.t)

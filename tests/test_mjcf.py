@@ -214,8 +214,8 @@ def test_load_model_accepts_an_xml_path_and_the_oracle_can_step_it(tmp_path):
 
 
 def test_box_geom_collides_through_its_eight_corners(tmp_path):
-    """box geoms.  A colliding <geom type="box"> becomes eight point contacts (its corners, in the body frame,
-    geom pose applied) against the ground plane; it survives the writer / parser round trip."""
+    """box geoms.  A colliding <geom type="box"> meets the ground as MJX has it - plane_convex on the convex mesh of its eight
+    corners (in the body frame, geom pose applied; mesh.box's vertex order), four contact slots; it survives the writer / parser round trip."""
     import numpy as np
 
     from minppo_amd import mjcf
@@ -228,10 +228,10 @@ def test_box_geom_collides_through_its_eight_corners(tmp_path):
     p.write_text(xml)
     spec = mjcf.load_mjcf(str(p))
     cm = compile_model(spec)
-    assert cm.ncon == 8 and cm.nefc == 32 and (np.asarray(cm.t["con_radius"]) == 0).all()
-    corners = np.asarray(cm.t["con_lpos"]).reshape(8, 3)
-    want = {(0.01 + sx * 0.10, sy * 0.05, sz * 0.02) for sx in (-1, 1) for sy in (-1, 1) for sz in (-1, 1)}
-    assert {tuple(np.round(c, 9)) for c in corners} == {tuple(np.round(w, 9)) for w in want}
+    assert cm.ncon == 4 and cm.nefc == 16 and (np.asarray(cm.t["con_radius"]) == 0).all() and cm.t["con_cvx"].tolist() == [0, 1, 2, 3]
+    corners = np.asarray(cm.t["cvx_vert"]).reshape(8, 3)
+    want = [(0.01 + sx * 0.10, sy * 0.05, sz * 0.02) for sx in (-1, 1) for sy in (-1, 1) for sz in (-1, 1)]
+    np.testing.assert_allclose(corners, want, atol=1e-12)
     p2 = tmp_path / "brick2.xml"
     p2.write_text(mjcf.to_mjcf(spec))
     cm2 = compile_model(mjcf.load_mjcf(str(p2)))
@@ -281,12 +281,12 @@ def test_collision_masks_generate_the_pairs_mujoco_would_test(tmp_path):
     # a box meets spheres and capsules of other bodies as a convex hull (round 5; tests/test_convex_pairs.py): one slot per sphere, two per
     # capsule, after the groups of the round geoms among themselves - (sphere, box) < (capsule, capsule) < (capsule, box) by MuJoCo's type ids
     cmb, pbb = pairs(xml(dtype="box", dsize="0.04 0.04 0.04"))
-    assert pbb == [(2, 5), (3, 5), (1, 4), (4, 5), (4, 5)] and int(cmb.t["nhull"]) == 1 and cmb.ncon == (2 + 1 + 1 + 2 + 8) + 5
+    assert pbb == [(2, 5), (3, 5), (1, 4), (4, 5), (4, 5)] and int(cmb.t["nhull"]) == 1 and cmb.ncon == (2 + 1 + 1 + 2 + 4) + 5
     assert np.asarray(cmb.t["pair_geom"])[:, 7].tolist() == [1, 1, 0, 1, 1] and np.asarray(cmb.t["pair_geom"])[:, 15].tolist() == [0, 0, 0, 0, 1]
     cm3, pb3 = pairs(xml(dtype="box", dsize="0.04 0.04 0.04", extra_d='contype="0" conaffinity="1"').replace('name="ga" type="capsule"', 'name="ga" contype="0" type="capsule"')
                      .replace('name="gb" type="sphere"', 'name="gb" contype="0" type="sphere"').replace('name="gw" type="sphere"', 'name="gw" contype="0" type="sphere"')
                      .replace('name="gc" type="capsule"', 'name="gc" contype="0" type="capsule"'))
-    assert pb3 == [] and cm3.ncon == 2 + 1 + 1 + 2 + 8  # everything still meets the ground (plane contype 1 & conaffinity 1)
+    assert pb3 == [] and cm3.ncon == 2 + 1 + 1 + 2 + 4  # everything still meets the ground (plane contype 1 & conaffinity 1)
 
 
 MESH_XML = """<mujoco model="meshy"><compiler angle="radian" meshdir="assets"/><option timestep="0.002"/>
