@@ -135,7 +135,7 @@ def test_kernel_follows_the_oracle_on_a_random_robot(be, seed):
     from test_kernels_physics import _probe
 
     cm = compile_model(random_model(seed))
-    # (a robot with very many contact candidates - seed 17: 130 slots, 527 constraint rows - does not fit LDS four environments to a wave: the
+    # (a robot with very many contact candidates - seed 17: 114 slots, 463 constraint rows - does not fit LDS four environments to a wave: the
     # run-time-sized kernel then carries two or one per wave; until round 5 such a robot was refused)
     h, dims, _keep = be.model(cm)
     assert dims.lds_bytes <= 160 * 1024
