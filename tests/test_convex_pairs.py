@@ -65,10 +65,15 @@ def test_hull_topology_of_a_box_and_of_a_random_hull():
     faces, normals, edges, enormals = hull_topology(c)
     assert sorted(len(f) for f in faces) == [4] * 6 and len(edges) == 12                     # the twelve triangles merged into six quads
     assert sorted(map(tuple, np.round(normals).astype(int).tolist())) == sorted([(0, 0, -1), (0, 0, 1), (0, -1, 0), (0, 1, 0), (-1, 0, 0), (1, 0, 0)])
+    # a hexagonal prism: the four triangles of each hexagon merge into ONE six-sided face
+    ang = np.arange(6) * np.pi / 3
+    prism = np.array([[np.cos(a), np.sin(a), z] for z in (-0.3, 0.4) for a in ang]) * [0.2, 0.25, 1.0]
+    faces, normals, edges, enormals = hull_topology(prism)
+    assert sorted(len(f) for f in faces) == [4] * 6 + [6, 6] and len(edges) == 18
     rng = np.random.default_rng(0)
     v = rng.normal(size=(30, 3))
     v /= np.linalg.norm(v, axis=1, keepdims=True)
-    for verts in (c, v):
+    for verts in (c, v, prism):
         faces, normals, edges, enormals = hull_topology(verts)
         assert len(verts) - len(edges) + len(faces) == 2                                       # Euler
         for f, n in zip(faces, normals):
