@@ -11,7 +11,8 @@ or attribute - nothing is silently dropped except purely visual / bookkeeping co
 `<keyframe>`, `<statistic>`, `<size>`, `<custom>`, materials, rgba, names of geoms ...).
 
 Subset
-  <compiler angle="degree|radian" eulerseq autolimits inertiafromgeom="auto|true|false">
+  <compiler angle="degree|radian" eulerseq autolimits inertiafromgeom="auto|true|false" meshdir strippath boundmass boundinertia settotalmass
+            balanceinertia> (fusestatic="true" is refused when the model has a jointless body: fusing would renumber the bodies)
   <option timestep gravity impratio>            solver / iterations / ls_iterations are OVERRIDDEN (CG, 6, 6: env.py:95-97)
   <default> with nested <default class="...">: <joint>, <geom>, <position>, <motor>, <general> attribute inheritance;
             `childclass` on <body>, `class` on elements
@@ -123,6 +124,12 @@ class _Compiler:
                 raise ValueError(f"<compiler {k}=...> is outside the supported MJCF subset")
         if a.get("coordinate", "local") != "local":
             raise ValueError("<compiler coordinate='global'> is not supported")
+        # mass / inertia post-processing of MuJoCo's compiler (until round 5 these five were accepted and ignored)
+        self.boundmass, self.boundinertia = float(a.get("boundmass", "0")), float(a.get("boundinertia", "0"))
+        self.settotalmass = float(a.get("settotalmass", "-1"))
+        self.balanceinertia = a.get("balanceinertia", "false") == "true"
+        self.strippath = a.get("strippath", "false") == "true"
+        self.fusestatic = a.get("fusestatic", "false") == "true"
 
     def ang(self, x: float) -> float:
         return math.radians(x) if self.deg else x
@@ -420,7 +427,7 @@ def parse_mjcf(xml: str, name: str = "mjcf", base_dir: Optional[Path] = None) ->
             elif "file" in me.attrib:
                 if base_dir is None:
                     raise ValueError(f"mesh {mname}: file={me.get('file')!r} needs the MJCF's directory (load it with load_mjcf / pass base_dir)")
-                pts = _read_mesh_file(Path(base_dir) / meshdir / me.get("file"))
+                pts = _read_mesh_file(Path(base_dir) / meshdir / (Path(me.get("file")).name if comp.strippath else me.get("file")))
             else:
                 raise ValueError(f"mesh {mname}: neither vertex nor file")
             if any(k in me.attrib for k in ("refpos", "refquat")):
@@ -610,6 +617,15 @@ def parse_mjcf(xml: str, name: str = "mjcf", base_dir: Optional[Path] = None) ->
             free_z.append(pos[2])
             if len(free_z) == 1:  # ModelSpec keeps the height of the first free root separately (qpos0[2] = free_root_z)
                 pos = (pos[0], pos[1], 0.0)
+        if comp.fusestatic and not joints:
+            raise ValueError(f"body {bname} has no joint and <compiler fusestatic='true'> would merge it into its parent (renumbering the bodies the observation "
+                             "lists): not supported - set fusestatic='false' (MJCF's default) or merge the body by hand")
+        mass_, inertia_ = float(inertial[0]), [float(x) for x in inertial[3]]
+        if comp.balanceinertia and (inertia_[0] + inertia_[1] < inertia_[2] or inertia_[0] + inertia_[2] < inertia_[1] or inertia_[1] + inertia_[2] < inertia_[0]):
+            inertia_ = [sum(inertia_) / 3.0] * 3   # MuJoCo: an inertia that violates A + B >= C gets three equal moments
+        mass_ = max(mass_, comp.boundmass)
+        inertia_ = [max(x, comp.boundinertia) for x in inertia_]
+        inertial = (mass_, inertial[1], inertial[2], tuple(inertia_))
         bodies.append(BodySpec(bname, parent, pos=pos, quat=tuple(quat), mass=inertial[0], inertia=inertial[3], ipos=inertial[1], iquat=inertial[2],
                                joints=joints, geoms=geoms))
         for ch in el.findall("body"):
@@ -637,6 +653,10 @@ def parse_mjcf(xml: str, name: str = "mjcf", base_dir: Optional[Path] = None) ->
         raise ValueError("MJCF has no bodies")
 
     free_root_z = float(free_z[0]) if free_z else 1.0
+    if comp.settotalmass > 0:   # every mass and inertia scaled so that the robot weighs this much
+        scale = comp.settotalmass / sum(b.mass for b in bodies)
+        for b in bodies:
+            b.mass, b.inertia = b.mass * scale, tuple(x * scale for x in b.inertia)
 
     joint_names = {j.name for b in bodies for j in b.joints}
     acts: List[ActuatorSpec] = []

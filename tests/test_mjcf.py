@@ -409,3 +409,25 @@ def test_include_errors_are_loud(tmp_path):
         mjcf.parse_mjcf(main.read_text())
     (tmp_path / "a.xml").write_text('<mujocoinclude><option timestep="0.004"/><compiler angle="radian"/></mujocoinclude>')
     assert mjcf.load_mjcf(str(main)).timestep == 0.004  # a section brought in by an include counts like one written in place
+
+
+def test_compiler_mass_post_processing_and_fusestatic():
+    """<compiler boundmass boundinertia settotalmass balanceinertia> change masses and inertias (MuJoCo's compiler applies them in this order:
+    balance, bounds, total mass); fusestatic='true' would renumber the bodies - an error when the model has a jointless body, nothing otherwise."""
+    base = mjcf.parse_mjcf(HAND)
+    total = sum(b.mass for b in base.bodies)
+    s = mjcf.parse_mjcf(HAND.replace('<compiler angle="degree" eulerseq="xyz"/>', '<compiler angle="degree" eulerseq="xyz" settotalmass="10" fusestatic="true"/>'))
+    assert sum(b.mass for b in s.bodies) == pytest.approx(10.0)
+    for b0, b1 in zip(base.bodies, s.bodies):
+        assert b1.mass == pytest.approx(b0.mass * 10.0 / total) and b1.inertia == pytest.approx(tuple(x * 10.0 / total for x in b0.inertia))
+    s = mjcf.parse_mjcf(HAND.replace('<compiler angle="degree" eulerseq="xyz"/>', '<compiler angle="degree" eulerseq="xyz" boundmass="1.0" boundinertia="0.025"/>'))
+    assert [b.mass for b in s.bodies] == pytest.approx([max(b.mass, 1.0) for b in base.bodies]) and min(min(b.inertia) for b in s.bodies) == pytest.approx(0.025)
+    bad = '<inertial pos="0 0 -0.15" mass="2.0" fullinertia="0.02 0.03 0.01 0.001 0 0"/>'
+    assert bad in HAND
+    lop = HAND.replace(bad, '<inertial pos="0 0 -0.15" mass="2.0" diaginertia="0.05 0.01 0.01"/>')
+    assert mjcf.parse_mjcf(lop).bodies[1].inertia == (0.05, 0.01, 0.01)
+    s = mjcf.parse_mjcf(lop.replace('<compiler angle="degree" eulerseq="xyz"/>', '<compiler angle="degree" eulerseq="xyz" balanceinertia="true"/>'))
+    assert s.bodies[1].inertia == pytest.approx((0.07 / 3,) * 3)
+    with pytest.raises(ValueError, match="fusestatic"):
+        mjcf.parse_mjcf(HAND.replace('<compiler angle="degree" eulerseq="xyz"/>', '<compiler angle="degree" eulerseq="xyz" fusestatic="true"/>')
+                        .replace('<body name="shin" pos="0 0 -0.3">', '<body name="bracket" pos="0 0 -0.1"><inertial pos="0 0 0" mass="0.1" diaginertia="1e-4 1e-4 1e-4"/></body><body name="shin" pos="0 0 -0.3">'))
