@@ -653,6 +653,9 @@ def parse_mjcf(xml: str, name: str = "mjcf", base_dir: Optional[Path] = None) ->
         raise ValueError("MJCF has no bodies")
 
     free_root_z = float(free_z[0]) if free_z else 1.0
+    for st in root.findall("statistic"):   # (extent, center, meansize, meanmass only scale the visualisation; meaninertia scales the solver's tolerance)
+        if "meaninertia" in st.attrib:
+            spec_kw["meaninertia"] = float(st.get("meaninertia"))
     if comp.settotalmass > 0:   # every mass and inertia scaled so that the robot weighs this much
         scale = comp.settotalmass / sum(b.mass for b in bodies)
         for b in bodies:
@@ -758,6 +761,8 @@ def to_mjcf(spec: ModelSpec) -> str:
     ET.SubElement(root, "compiler", angle="radian", autolimits="true", inertiafromgeom="false")
     ET.SubElement(root, "option", timestep=repr(float(spec.timestep)), gravity=_fmt(spec.gravity), impratio=repr(float(spec.impratio)), solver="CG",
                   iterations=str(spec.iterations), ls_iterations=str(spec.ls_iterations), tolerance=repr(float(spec.tolerance)), ls_tolerance=repr(float(spec.ls_tolerance)))
+    if spec.meaninertia is not None:
+        ET.SubElement(root, "statistic", meaninertia=repr(float(spec.meaninertia)))
     d = ET.SubElement(ET.SubElement(root, "default"), "joint", solreflimit=_fmt(spec.limit_solref), solimplimit=_fmt(spec.limit_solimp))
     del d
     ET.SubElement(root.find("default"), "geom", solref=_fmt(spec.contact_solref), solimp=_fmt(spec.contact_solimp), condim="3")

@@ -131,6 +131,7 @@ class ModelSpec:
     plane_conaffinity: int = 1
     has_plane: bool = True
     free_root_z: float = 1.0  # qpos0[2] of the (first) free joint
+    meaninertia: Optional[float] = None  # MJCF <statistic meaninertia>: overrides the value derived from M(qpos0) (it scales the solver's tolerance)
     contact_excludes: List[Tuple[str, str]] = field(default_factory=list)  # MJCF <contact><exclude body1 body2/>: no geom pairs between these bodies
 
 
@@ -184,6 +185,7 @@ class CompiledModel:
     t: Dict[str, np.ndarray]  # tables (float64 / int32); scalars stored as 0-d arrays
     body_names: List[str]
     joint_names: List[str]
+    meaninertia_override: Optional[float] = None
 
     # -- dims -------------------------------------------------------------
     @property
@@ -732,7 +734,7 @@ def compile_model(spec: ModelSpec) -> CompiledModel:
     put("limit_solref", spec.limit_solref)
     put("limit_solimp", spec.limit_solimp)
 
-    cm = CompiledModel(spec.name, t, names, joint_names)
+    cm = CompiledModel(spec.name, t, names, joint_names, spec.meaninertia)
     _set_const(cm)
     return cm
 
@@ -833,7 +835,7 @@ def _set_const(cm: CompiledModel) -> None:
     f = _forward_position0(cm)
     M = f["M"]
     Minv = np.linalg.inv(M)
-    t["meaninertia"] = np.asarray(np.trace(M) / max(nv, 1))
+    t["meaninertia"] = np.asarray(np.trace(M) / max(nv, 1)) if cm.meaninertia_override is None else np.asarray(float(cm.meaninertia_override))
     dof_inv = np.diag(Minv).copy()
     for j in range(cm.njnt):
         if t["jnt_type"][j] == JNT_FREE:

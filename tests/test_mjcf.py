@@ -431,3 +431,12 @@ def test_compiler_mass_post_processing_and_fusestatic():
     with pytest.raises(ValueError, match="fusestatic"):
         mjcf.parse_mjcf(HAND.replace('<compiler angle="degree" eulerseq="xyz"/>', '<compiler angle="degree" eulerseq="xyz" fusestatic="true"/>')
                         .replace('<body name="shin" pos="0 0 -0.3">', '<body name="bracket" pos="0 0 -0.1"><inertial pos="0 0 0" mass="0.1" diaginertia="1e-4 1e-4 1e-4"/></body><body name="shin" pos="0 0 -0.3">'))
+
+
+def test_statistic_meaninertia_overrides_the_derived_value():
+    """<statistic meaninertia> (it scales the solver's tolerance: MJX solver.solve) is honoured and written back; the other <statistic> fields are visual."""
+    derived = compile_model(mjcf.parse_mjcf(HAND))
+    s = mjcf.parse_mjcf(HAND.replace("<default>", '<statistic meaninertia="0.37" extent="2"/><default>', 1))
+    cm = compile_model(s)
+    assert float(cm.t["meaninertia"]) == 0.37 != float(derived.t["meaninertia"])
+    assert float(compile_model(mjcf.parse_mjcf(mjcf.to_mjcf(s))).t["meaninertia"]) == 0.37
