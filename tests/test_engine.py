@@ -254,11 +254,27 @@ def test_reference_shaped_metrics_history(be):
     tr.close()
 
 
-def test_update_bf16_mlp_tracks_the_bf16_oracle(be):
+def _random_bf16_config(seed, emu):
+    """Random engine configurations a bf16 network can have: two hidden layers, a width the fused kernels cover."""
+    rng = np.random.default_rng(4500 + seed)
+    T = int(rng.integers(1, 5 if emu else 12))
+    N = int(rng.integers(6, 16 if emu else 700))
+    M = int(rng.choice([m for m in range(1, 17) if (T * N) % m == 0]))
+    over = [f"training.num_envs={N}", f"training.num_steps={T}", f"rl.num_env_steps={T}", f"training.num_minibatches={M}", f"training.update_epochs={int(rng.integers(1, 4))}",
+            f"model.hidden_size={int(rng.choice([32, 64] if emu else [32, 64, 96, 128, 160, 192, 224, 256]))}", "training.total_timesteps=100000000"]
+    if rng.random() < 0.3:
+        over.append("environment.model=synth_stompy_full")
+    if rng.random() < 0.25:
+        over.append("environment.include_c_vals=false")
+    return over
+
+
+@pytest.mark.parametrize("case", ["configs3"] + [f"fuzz{k}" for k in range(int(os.environ.get("MPPO_FUZZ_ENGINES", "2")))])
+def test_update_bf16_mlp_tracks_the_bf16_oracle(be, case):
     """BASELINE configs[3] through the whole engine: training.mlp_dtype = "bf16" (bf16-in / f32-accumulate MFMA in the MLP
     products; GAE, loss, clip and Adam in f32).  The PPO half of one update against the oracle run with the same operand
-    rounding (hp["mlp_bf16"]), on the engine's own trajectory."""
-    cfg = _cfg(*_small(be), "training.mlp_dtype=bf16")
+    rounding (hp["mlp_bf16"]), on the engine's own trajectory.  Also on random configurations (MPPO_FUZZ_ENGINES widens)."""
+    cfg = _cfg(*(_small(be) if case == "configs3" else _random_bf16_config(int(case[4:]), be.name == "emu")), "training.mlp_dtype=bf16")
     tr = be.trainer(cfg, external_random=True, use_graph=False)
     tr.reset()
     N, T, A, H, O, E, M = tr.N, tr.T, tr.A, tr.H, tr.O, tr.E, tr.M
