@@ -82,6 +82,37 @@ __global__ void __launch_bounds__(512, 2) stream2_kernel(const unsigned char* w,
   if (acc == 12345.678f) sink[threadIdx.x] = acc;
 }
 
+// PRIVATE copies (round 5, last): one copy of both networks' fragments per XCD, written by workgroups of THAT XCD (workgroup id mod 8 = XCD: the
+// round-robin placement the engine's tile orders already rely on) with ordinary write-back stores, read only by workgroups of that XCD - is the
+// stream then as fast behind the rewrite as it is warm?  (what an optimizer that runs redundantly on every XCD would buy the row pass)
+template <int DEPTH>
+__global__ void __launch_bounds__(512, 2) stream_private_kernel(const unsigned char* w, float* sink, int empty) {
+  if (empty) return;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), xcd = blockIdx.x & 7, net = (blockIdx.x >> 3) & 1;
+  const i32x4n r = make_rsrc(w + ((size_t)xcd * 2 + net) * kNetBytes, kNetBytes);
+  f32x4n q[kStages][2];
+  float acc = 0.f;
+#pragma unroll
+  for (int S = 0; S < kStages + DEPTH; ++S) {
+    if (S < kStages) {
+      q[S][0] = raw_load_f32x4(r, lane * 16, (S * kWaves + wave) * 2048, 0);
+      q[S][1] = raw_load_f32x4(r, lane * 16 + 1024, (S * kWaves + wave) * 2048, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    if (S >= DEPTH) {
+      const int C = S - DEPTH;
+      acc += q[C][0].x + q[C][0].y + q[C][0].z + q[C][0].w + q[C][1].x + q[C][1].y + q[C][1].z + q[C][1].w;
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  if (acc == 12345.678f) sink[threadIdx.x] = acc;
+}
+// every XCD rewrites ITS copy (block b: XCD b & 7, chunk b >> 3); policy 0 = write-back into the XCD's own L2
+__global__ void __launch_bounds__(256) adam_private(unsigned char* w, int n16, float v) {
+  const int xcd = blockIdx.x & 7, i = (blockIdx.x >> 3) * 256 + threadIdx.x;
+  if (i < n16) raw_store_f32x4(f32x4n{v, v, v, v}, make_rsrc(w + (size_t)xcd * 2 * kNetBytes, 2 * kNetBytes), i * 16, 0, 0);
+}
+
 // the optimizer's stand-in: rewrites all weights with write-through stores (values stay finite)
 __global__ void __launch_bounds__(256) adam_like(unsigned char* w, int n16, float v) {
   const int i = blockIdx.x * 256 + threadIdx.x;
@@ -128,6 +159,36 @@ static void report(const char* what, unsigned char* w, float* sink, int grid, hi
   }
 }
 
+static double run_private(unsigned char* w8, float* sink, int cold, int empty, hipStream_t s) {
+  constexpr int LAUNCHES = 64;
+  const int n16 = 2 * kNetBytes / 16;
+  auto seq = [&] {
+    for (int k = 0; k < LAUNCHES; ++k) {
+      if (cold) hipLaunchKernelGGL(adam_private, dim3(8 * ((n16 + 255) / 256)), dim3(256), 0, s, w8, n16, 0.001f * (float)(k & 7));
+      hipLaunchKernelGGL((stream_private_kernel<8>), dim3(160), dim3(512), 0, s, w8, sink, empty);
+    }
+  };
+  seq();
+  CK(hipStreamSynchronize(s));
+  hipGraph_t g; hipGraphExec_t ge;
+  CK(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+  seq();
+  CK(hipStreamEndCapture(s, &g));
+  CK(hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
+  CK(hipGraphLaunch(ge, s));
+  CK(hipStreamSynchronize(s));
+  hipEvent_t e0, e1;
+  CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+  CK(hipEventRecord(e0, s));
+  for (int rep = 0; rep < 5; ++rep) CK(hipGraphLaunch(ge, s));
+  CK(hipEventRecord(e1, s));
+  CK(hipStreamSynchronize(s));
+  float ms = 0.f;
+  CK(hipEventElapsedTime(&ms, e0, e1));
+  CK(hipGraphExecDestroy(ge)); CK(hipGraphDestroy(g)); CK(hipEventDestroy(e0)); CK(hipEventDestroy(e1));
+  return 1e3 * ms / (5.0 * LAUNCHES);
+}
+
 static double run2(unsigned char* w, float* sink, int grid, int cold, int empty, hipStream_t s) {
   constexpr int LAUNCHES = 64;
   const int n16 = 2 * kNetBytes / 16;
@@ -162,6 +223,18 @@ int main() {
     const double b = run2(w, sink, 80, cold, 1, s), t = run2(w, sink, 80, cold, 0, s);
     printf("BOTH networks per workgroup (768 KB per CU), depth 4, grid  80 %s  %6.2f us per step (empty: %5.2f)  -> stream %5.2f us = %6.1f GB/s per CU\n",
            cold ? "after adam-like rewrite" : "warm                   ", t, b, t - b, 768.0 * 1024.0 / ((t - b) * 1e-6) / 1e9);
+  }
+  {
+    unsigned char* w8;
+    CK(hipMalloc(&w8, 16 * (size_t)kNetBytes));
+    CK(hipMemset(w8, 0, 16 * (size_t)kNetBytes));
+    for (int cold = 0; cold < 2; ++cold) {
+      const double b = run_private(w8, sink, cold, 1, s), t = run_private(w8, sink, cold, 0, s);
+      printf("PRIVATE copy per XCD, depth 8, grid 160 %s  %6.2f us per step (empty: %5.2f)  -> stream %5.2f us = %6.1f GB/s per CU\n",
+             cold ? "after a rewrite by the XCD's own workgroups (write-back)" : "warm                                                    ", t, b, t - b,
+             384.0 * 1024.0 / ((t - b) * 1e-6) / 1e9);
+    }
+    CK(hipFree(w8));
   }
   for (int grid : {160, 80, 256}) {
     report<1, 0>("depth 1, default", w, sink, grid, s);
