@@ -108,9 +108,10 @@ __global__ void __launch_bounds__(512, 2) stream_private_kernel(const unsigned c
   if (acc == 12345.678f) sink[threadIdx.x] = acc;
 }
 // every XCD rewrites ITS copy (block b: XCD b & 7, chunk b >> 3); policy 0 = write-back into the XCD's own L2
+template <int POLICY>
 __global__ void __launch_bounds__(256) adam_private(unsigned char* w, int n16, float v) {
   const int xcd = blockIdx.x & 7, i = (blockIdx.x >> 3) * 256 + threadIdx.x;
-  if (i < n16) raw_store_f32x4(f32x4n{v, v, v, v}, make_rsrc(w + (size_t)xcd * 2 * kNetBytes, 2 * kNetBytes), i * 16, 0, 0);
+  if (i < n16) raw_store_f32x4(f32x4n{v, v, v, v}, make_rsrc(w + (size_t)xcd * 2 * kNetBytes, 2 * kNetBytes), i * 16, 0, POLICY);
 }
 
 // the optimizer's stand-in: rewrites all weights with write-through stores (values stay finite)
@@ -159,12 +160,13 @@ static void report(const char* what, unsigned char* w, float* sink, int grid, hi
   }
 }
 
+template <int POLICY>
 static double run_private(unsigned char* w8, float* sink, int cold, int empty, hipStream_t s) {
   constexpr int LAUNCHES = 64;
   const int n16 = 2 * kNetBytes / 16;
   auto seq = [&] {
     for (int k = 0; k < LAUNCHES; ++k) {
-      if (cold) hipLaunchKernelGGL(adam_private, dim3(8 * ((n16 + 255) / 256)), dim3(256), 0, s, w8, n16, 0.001f * (float)(k & 7));
+      if (cold) hipLaunchKernelGGL(adam_private<POLICY>, dim3(8 * ((n16 + 255) / 256)), dim3(256), 0, s, w8, n16, 0.001f * (float)(k & 7));
       hipLaunchKernelGGL((stream_private_kernel<8>), dim3(160), dim3(512), 0, s, w8, sink, empty);
     }
   };
@@ -229,10 +231,15 @@ int main() {
     CK(hipMalloc(&w8, 16 * (size_t)kNetBytes));
     CK(hipMemset(w8, 0, 16 * (size_t)kNetBytes));
     for (int cold = 0; cold < 2; ++cold) {
-      const double b = run_private(w8, sink, cold, 1, s), t = run_private(w8, sink, cold, 0, s);
+      const double b = run_private<0>(w8, sink, cold, 1, s), t = run_private<0>(w8, sink, cold, 0, s);
       printf("PRIVATE copy per XCD, depth 8, grid 160 %s  %6.2f us per step (empty: %5.2f)  -> stream %5.2f us = %6.1f GB/s per CU\n",
              cold ? "after a rewrite by the XCD's own workgroups (write-back)" : "warm                                                    ", t, b, t - b,
              384.0 * 1024.0 / ((t - b) * 1e-6) / 1e9);
+    }
+    {  // the same with the engine's write-through stores (sc0 sc1): does the writer's L2 keep the line?
+      const double b = run_private<17>(w8, sink, 1, 1, s), t = run_private<17>(w8, sink, 1, 0, s);
+      printf("PRIVATE copy per XCD, depth 8, grid 160 after a rewrite by the XCD's own workgroups (write-through sc0 sc1)  %6.2f us per step (empty: %5.2f)  -> stream %5.2f us = %6.1f GB/s per CU\n",
+             t, b, t - b, 384.0 * 1024.0 / ((t - b) * 1e-6) / 1e9);
     }
     CK(hipFree(w8));
   }
