@@ -45,7 +45,7 @@ extern "C" {
 #define MPPO_ENCCL (-5)    /* an RCCL call failed                                         */
 #define MPPO_ENOMEM (-6)   /* caller-provided workspace too small                         */
 
-#define MPPO_ABI_VERSION 5  /* 5: mppo_minibatch_rows_per_workgroup; a bf16 network's fragment copies are tile-major (4: mppo_engine_peer_selftest runs on the caller's stream) */
+#define MPPO_ABI_VERSION 6  /* 6: mppo_model_scratch_bytes (a large robot's matrices in global memory); 5: mppo_minibatch_rows_per_workgroup; a bf16 network's fragment copies are tile-major (4: mppo_engine_peer_selftest runs on the caller's stream) */
 
 const char* mppo_last_error(void);
 int32_t mppo_abi_version(void);
@@ -74,6 +74,12 @@ int32_t mppo_model_get_dims(const mppo_model_t* m, mppo_model_dims_t* out);
  * (csrc/spec_dims.inc, written by `python -m minppo_amd.build`; MPPO_SPECIALIZE=robot.xml[,...] adds models), 0 when it runs the
  * run-time-sized kernel.  Same results either way; the fixed-size kernel is faster (env_kernel). */
 int32_t mppo_model_is_specialized(const mppo_model_t* m, int32_t* out);
+/* Bytes of global memory the environment kernel uses beside the state for N environments: 0 for a robot whose per-environment working set
+ * fits LDS four waves to a CU; a larger robot (about 30 dofs / 20 contact slots and up) keeps its mass matrix and contact Jacobian in
+ * per-environment records there (L2 / Infinity-Cache resident).  mppo_env_reset / mppo_env_step / mppo_physics_forward
+ * allocate them on demand inside the handle (hipMalloc, grown when N grows, freed by mppo_model_close; not during a stream capture, and
+ * one stream at a time may launch through such a handle); an engine takes them from its arena (mppo_engine_arena_bytes includes them). */
+int32_t mppo_model_scratch_bytes(const mppo_model_t* m, int32_t N, size_t* out);
 
 /* Reward / termination constants read by compute_reward and is_done (env.py:199-242,
  * config.py:36-48). */

@@ -28,6 +28,11 @@
 
 namespace mppo {
 const ModelView& model_view(const mppo_model* m);
+size_t model_scratch_bytes(const mppo_model* m, int N);
+int32_t env_step_ws(const mppo_model_t* m, int32_t N, int32_t n_frames, const mppo_reward_cfg_t* rc, float* state, const float* reset_rec, const float* action,
+                    int32_t act_ld, float* obs, int32_t obs_ld, float* reward, uint8_t* done, const mppo_env_metrics_t* metrics, float* ws, size_t ws_bytes, hipStream_t stream);
+int32_t env_reset_ws(const mppo_model_t* m, int32_t N, float* state, float* reset_rec, float* obs, int32_t obs_ld, const mppo_env_metrics_t* metrics, float* ws, size_t ws_bytes,
+                     hipStream_t stream);
 
 // end of an update: the Adam step index and the update index move on; `zero` (optional): words another kernel of the update wants back
 // at zero before its next use (the bucket counters of the two-launch permutation, k_perm.hip).  The LAST of those words is that form's
@@ -120,6 +125,8 @@ struct mppo_engine {
   int jax_rounds;
   void* perm_ws;
   size_t perm_ws_bytes;
+  float* env_ws;
+  size_t env_ws_bytes;
   mppo::Comm* comm;
   mppo::PeerComm* peer;  // the ranks' peer-to-peer exchange (peer.h); takes precedence over `comm` once connected
   mppo::GraphExec* graph;
@@ -180,6 +187,9 @@ static size_t layout(mppo_engine* e, bool assign) {
   e->perm_ws_bytes = mppo_permutation_ws_bytes((int)B);
   if (permutation_batch_ws_bytes((int)B, e->E) > e->perm_ws_bytes) e->perm_ws_bytes = permutation_batch_ws_bytes((int)B, e->E);  // all epochs in one sort
   e->perm_ws = take("perm_ws", e->perm_ws_bytes);
+  // a large robot's mass matrices and contact Jacobians, one record per environment (k_physics.hip; nothing for the robots whose working set fits LDS)
+  e->env_ws_bytes = model_scratch_bytes(e->model, (int)N);
+  e->env_ws = e->env_ws_bytes ? (float*)take("env_scratch", e->env_ws_bytes) : nullptr;
   return align_up(off, 256);
 }
 
@@ -255,8 +265,8 @@ static int32_t do_rollout(mppo_engine* e, hipStream_t s) {
     const float* obs_t = e->obs + (size_t)t * N * OP;
     MPPO_TRY(policy_forward(c.net, e->params, e->N, obs_t, e->OP, fb, e->noise + t * N * A, e->action + t * N * A, e->log_prob + t * N,
                             e->value + (size_t)t * N, nullptr, s));                                                   // train.py:157-160
-    MPPO_TRY(mppo_env_step(e->model, e->N, c.n_frames, &c.reward, e->state, e->reset_rec, e->action + t * N * A, e->A, e->obs + (size_t)(t + 1) * N * OP,
-                           e->OP, e->reward + t * N, e->done + t * N, &e->met, s));                                  // :165
+    MPPO_TRY(env_step_ws(e->model, e->N, c.n_frames, &c.reward, e->state, e->reset_rec, e->action + t * N * A, e->A, e->obs + (size_t)(t + 1) * N * OP,
+                         e->OP, e->reward + t * N, e->done + t * N, &e->met, e->env_ws, e->env_ws_bytes, static_cast<hipStream_t>(s)));                                  // :165
   }
   MPPO_TRY(policy_forward(c.net, e->params, e->N, e->obs + (size_t)e->T * N * OP, e->OP, fb, nullptr, nullptr, nullptr, e->last_val, nullptr, s));  // train.py:182
   MPPO_TRY(gae_launch(e->T, e->N, c.gamma, c.gae_lambda, e->reward, e->value, e->done, e->last_val, e->adv, e->target, s));
@@ -426,7 +436,7 @@ extern "C" int32_t mppo_engine_reset(mppo_engine_t* e, void* stream) {
   MPPO_CHECK_HIP(hipMemsetAsync(e->adam_v, 0, (size_t)e->P * 4, s));
   MPPO_CHECK_HIP(hipMemsetAsync(e->obs, 0, (size_t)(e->T + 1) * e->N * e->OP * 4, s));
   MPPO_TRY(permutation_batch_prepare(e->B, e->E, e->perm_ws, e->perm_ws_bytes, s));
-  MPPO_TRY(mppo_env_reset(e->model, e->N, e->state, e->reset_rec, e->obs, e->OP, nullptr, nullptr, &e->met, s));  // train.py:142-144
+  MPPO_TRY(env_reset_ws(e->model, e->N, e->state, e->reset_rec, e->obs, e->OP, &e->met, e->env_ws, e->env_ws_bytes, static_cast<hipStream_t>(s)));  // train.py:142-144
   e->was_reset = true;
   return MPPO_OK;
 }

@@ -50,6 +50,7 @@ struct EnvArgs {
   mppo_reward_cfg_t rc;
   const float *p_qpos, *p_qvel, *p_ctrl, *p_warm;
   mppo_forward_probe_t probe;
+  float* scratch;  // per-environment records in global memory for the matrices a large robot keeps out of LDS (PhysLds::gwords floats each; null if none)
 };
 
 // wave-level synchronisation point: an environment's LDS arrays are touched by ONE wavefront only, whose LDS instructions
@@ -58,6 +59,14 @@ struct EnvArgs {
 #define SYNC() __syncthreads()
 #else
 #define SYNC() __builtin_amdgcn_wave_barrier()
+#endif
+// ... and for the matrices a large robot keeps in global memory (PhysLds::spill): an environment's record is written and read by ONE
+// wavefront, whose vector-memory instructions reach the CU's L1 / the L2 in program order; the fence makes the compiler wait for the
+// stores (s_waitcnt) before anything that follows
+#ifdef MPPO_EMU
+#define GSYNC() __syncthreads()
+#else
+#define GSYNC() do { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); __builtin_amdgcn_wave_barrier(); } while (0)
 #endif
 #define FOR_G(i, n) for (int i = g; i < (n); i += kGroupLanes)
 #ifndef MPPO_DOT_UNROLL_RT
@@ -318,35 +327,41 @@ __device__ __forceinline__ void cross_force(const float* vel, const float* f, fl
   st3(r + 3, cross3(w, b));
 }
 
-// x = (L L^T)^-1 b from the packed inverse factors LL (leading dim ldm):
-//   EUL = false: L^-1 of M          , element [i][k] (k <= i) at LL[i*ldm + k]
-//   EUL = true : L^-1 of M + h*damp , element [i][k] (k <= i) at LL[k*ldm + i + 1]
-// `tmp` and `x` are nv-vectors in LDS; b may alias neither.  Contains two barriers.
-template <bool EUL, int NV>
-__device__ __forceinline__ void solve_linv(const float* LL, int ldm, int nv_rt, const float* b, float* tmp, float* x, int g) {
+// x = (L L^T)^-1 b from the inverse factor Li, a packed lower triangle (row i at i (i + 1) / 2: Li[i][k], k <= i) - the factor of M
+// during the step, of M + h*damp once the step's second factorisation has run.  `tmp` and `x` are nv-vectors in LDS; b may alias
+// neither.  Contains two synchronisation points.
+// Both triangular products run per 16-row pass over a lane-independent range of k (rows 16 q .. 16 q + 15: k < 16 (q + 1) for L^-1 b,
+// k >= 16 q for L^-T t) with the entries outside the triangle masked to 0: a uniform trip count lets the compiler request eight LDS
+// operands at a time and wait once, where a per-lane triangular loop waits for every single one (one wave per SIMD: nothing else
+// hides an LDS round trip).  The terms left out are exact zeros: the sums equal the full-length ones of the register-resident form
+// (solve_regs) bit for bit.
+template <int NV>
+__device__ __forceinline__ void solve_tri(const float* Li, int nv_rt, const float* b, float* tmp, float* x, int g) {
   const int nv = NV ? NV : nv_rt;
   constexpr int kDotU = dot_unroll(NV);
-  // Both triangular products run over the FULL row with the entries outside the triangle masked to 0 (LL packs two inverse
-  // factors in one square): a lane-independent trip count lets the compiler request eight LDS operands at a time and wait once,
-  // where the triangular loop waited for every single one (one wave per SIMD: nothing else hides an LDS round trip).
-  FOR_G(i, nv) {
+  for (int i0 = 0; i0 < nv; i0 += kGroupLanes) {
+    const int i = i0 + g, ic = i < nv ? i : nv - 1, ti = ic * (ic + 1) / 2;
+    const int kend = i0 + kGroupLanes < nv ? i0 + kGroupLanes : nv;
     float s = 0.f;
 DOT_UNROLL
-    for (int k = 0; k < nv; ++k) {
-      const float l = EUL ? LL[k * ldm + i + 1] : LL[i * ldm + k];
-      s += (k <= i ? l : 0.f) * b[k];
+    for (int k = 0; k < kend; ++k) {
+      const float l = Li[ti + (k <= ic ? k : ic)];
+      s += (k <= ic ? l : 0.f) * b[k];
     }
-    tmp[i] = s;
+    if (i < nv) tmp[i] = s;
   }
   SYNC();
-  FOR_G(i, nv) {
+  for (int i0 = 0; i0 < nv; i0 += kGroupLanes) {
+    const int i = i0 + g, ic = i < nv ? i : nv - 1;
     float s = 0.f;
+    int tk = i0 * (i0 + 1) / 2;  // row k of the triangle
 DOT_UNROLL
-    for (int k = 0; k < nv; ++k) {
-      const float l = EUL ? LL[i * ldm + k + 1] : LL[k * ldm + i];
-      s += (k >= i ? l : 0.f) * tmp[k];
+    for (int k = i0; k < nv; ++k) {
+      const float l = Li[tk + (k >= ic ? ic : k)];
+      s += (k >= ic ? l : 0.f) * tmp[k];
+      tk += k + 1;
     }
-    x[i] = s;
+    if (i < nv) x[i] = s;
   }
   SYNC();
 }
@@ -427,7 +442,8 @@ __global__ void __launch_bounds__(64 * kMaxWavesPerBlock) env_kernel(ModelView m
   constexpr bool kDims = SD::kStatic;
   // fixed-size kernel, up to 32 dofs: a lane's rows / columns of the Cholesky factors live in registers (see factor_m below)
   constexpr bool kRegChol = kDims && kSD.nv <= 2 * kGroupLanes;
-  constexpr PhysLds kSP = make_phys_lds(kSD.nq, kSD.nv, kSD.nu, kSD.nbody, kSD.njnt, kSD.ncon, kSD.nlimit + 4 * kSD.ncon, kSD.nroot, kSD.ncvx, kRegChol);
+  constexpr int kSpill = kDims ? spill_for(kSD.nq, kSD.nv, kSD.nu, kSD.nbody, kSD.njnt, kSD.ncon, kSD.nlimit + 4 * kSD.ncon, kSD.nroot, kSD.ncvx, kRegChol, kSO.words) : 0;
+  constexpr PhysLds kSP = make_phys_lds(kSD.nq, kSD.nv, kSD.nu, kSD.nbody, kSD.njnt, kSD.ncon, kSD.nlimit + 4 * kSD.ncon, kSD.nroot, kSD.ncvx, kRegChol, kSpill);
   const PhysLds P = SD::kStatic ? kSP : Prt;
   constexpr int NV = kDims ? kSD.nv : 0;
   constexpr int kDotU = dot_unroll(NV);
@@ -452,11 +468,16 @@ __global__ void __launch_bounds__(64 * kMaxWavesPerBlock) env_kernel(ModelView m
   __syncthreads();  // the only workgroup-wide barrier: model tables are shared by the waves of the block
   if (row >= epw) return;  // rows without an environment
   float* S = reinterpret_cast<float*>(smem_raw) + mv.blob_words + (size_t)el * P.total;
+  // matrices in global memory (large robots; model_view.h PhysLds::spill): this group's record - one per group of the GRID, so that a
+  // surplus group (which shadows the last environment) has a record of its own
+  const bool spJ = (P.spill & kSpillJ) != 0, spM = (P.spill & kSpillM) != 0;
+  float* G = P.gwords > 0 ? a.scratch + (size_t)(blockIdx.x * ((int)(blockDim.x >> 6) * epw) + el) * P.gwords : nullptr;
 
   const int nq = kDims ? kSD.nq : mv.nq, nv = kDims ? kSD.nv : mv.nv, nu = kDims ? kSD.nu : mv.nu, nb = kDims ? kSD.nbody : mv.nbody, njnt = kDims ? kSD.njnt : mv.njnt,
             ncon = kDims ? kSD.ncon : mv.ncon, nlim = kDims ? kSD.nlimit : mv.nlimit, nefc = kDims ? kSD.nlimit + 4 * kSD.ncon : mv.nefc;
   const int nlevel = kDims ? kSD.nlevel : mv.nlevel, nroot = kDims ? kSD.nroot : mv.nroot;
   const int ldm = P.ldm, ldj = P.ldj;
+  const int nvq = (nv + 3) >> 2;  // dof quads (the global-memory matrices hold four consecutive dofs per 16-byte word)
   const float h = mv.timestep;
   const int O = mv.obs_dim, OP = mv.obs_pad;
   float* qpos = S + P.qpos; float* qvel = (float*)__builtin_assume_aligned(S + P.qvel, 16); float* ctrl = S + P.ctrl; float* warm = S + P.warm;
@@ -476,6 +497,15 @@ __global__ void __launch_bounds__(64 * kMaxWavesPerBlock) env_kernel(ModelView m
   float* xanchor = S + P.xanchor; float* xaxis = S + P.xaxis;
   float* Cw = S + P.C; float* cdofdot = S + P.cdofdot; float* cfrc = S + P.cfrc; float* J = (float*)__builtin_assume_aligned(S + P.J, 16);
 
+  // M in global memory: Mq[k / 4][i][k % 4] - lane i reads four consecutive columns of its row as one 16-byte word, the lanes of an
+  // environment consecutive words.  (Entries k >= nv of the last quad are zeros.)
+  float4* Mq = reinterpret_cast<float4*>(G + (spM ? P.gM : 0));
+  auto Mset = [&](int i, int k, float v) {
+    if (spM) reinterpret_cast<float*>(Mq)[((k >> 2) * nv + i) * 4 + (k & 3)] = v; else M[i * ldm + k] = v;
+  };
+  auto Mget = [&](int i, int k) -> float {
+    return spM ? reinterpret_cast<const float*>(Mq)[((k >> 2) * nv + i) * 4 + (k & 3)] : M[i * ldm + k];
+  };
   const float* rec = a.state ? a.state + (size_t)env * mv.rec_dim : nullptr;
 
   PT(0);
@@ -800,8 +830,9 @@ __global__ void __launch_bounds__(64 * kMaxWavesPerBlock) env_kernel(ModelView m
         st3(cdof + 6 * da + 3, ld3(xaxis + 3 * j));
       }
     }
-    FOR_G(i, nv) for (int k = 0; k < nv; ++k) M[i * ldm + k] = 0.f;
-    SYNC();
+    if (spM) { for (int w = g; w < nvq * nv; w += kGroupLanes) Mq[w] = make_float4(0.f, 0.f, 0.f, 0.f); }
+    else FOR_G(i, nv) for (int k = 0; k < nv; ++k) M[i * ldm + k] = 0.f;
+    if (spM) GSYNC(); else SYNC();
     PT(4);
     // ---- crb: composite inertia over the subtree mask, dense M ------------------------------------
     FOR_G(i, nv) {
@@ -823,12 +854,12 @@ __global__ void __launch_bounds__(64 * kMaxWavesPerBlock) env_kernel(ModelView m
         const float* cj = cdof + 6 * j;
         float v = cj[0] * buf[0] + cj[1] * buf[1] + cj[2] * buf[2] + cj[3] * buf[3] + cj[4] * buf[4] + cj[5] * buf[5];
         if (j == i) v += TF(dof_armature)[i];
-        M[i * ldm + j] = v;
-        M[j * ldm + i] = v;
+        Mset(i, j, v);
+        Mset(j, i, v);
         j = TI(dof_parentid)[j];
       }
     }
-    SYNC();
+    if (spM) GSYNC(); else SYNC();
     PT(5);
     // ---- factor_m: Cholesky of M (now) and of M + h*diag(damping) (implicit joint damping: at the END of the step, Euler), and the
     // inverse factors.  The step is wrapped in a two-trip loop around ONE copy of the factorisation code: trip 0 factors M and runs
@@ -845,7 +876,7 @@ __global__ void __launch_bounds__(64 * kMaxWavesPerBlock) env_kernel(ModelView m
     int ir[RC];       // this lane's rows; a surplus slot shadows the last row and never publishes
     bool own[RC];
     _Pragma("unroll") for (int q = 0; q < RC; ++q) { const int i = g + kGroupLanes * q; own[q] = i < NVc; ir[q] = own[q] ? i : NVc - 1; }
-    // x = (L L^T)^-1 b with the factor in registers: the same two masked full-length products as solve_linv, the operand vector read
+    // x = (L L^T)^-1 b with the factor in registers: the two masked products of solve_tri (full-length: the extra terms are exact zeros), the operand vector read
     // once for all of a lane's rows
     auto solve_regs = [&](const float* bvec, float* tmp, float* x) {
       float br[NVc];
@@ -866,7 +897,7 @@ __global__ void __launch_bounds__(64 * kMaxWavesPerBlock) env_kernel(ModelView m
     };
     auto solveL = [&](auto eul_c, const float* bvec, float* tmp, float* x) {
       if constexpr (kRegChol) { (void)eul_c; solve_regs(bvec, tmp, x); }
-      else solve_linv<decltype(eul_c)::value, NV>(LL, ldm, nv, bvec, tmp, x, g);
+      else { (void)eul_c; solve_tri<NV>(LL, nv, bvec, tmp, x, g); }
     };
     _Pragma("unroll 1") for (int pass = 0; pass < 2; ++pass) {
     if (kRegChol) {
@@ -877,9 +908,17 @@ __global__ void __launch_bounds__(64 * kMaxWavesPerBlock) env_kernel(ModelView m
       _Pragma("unroll") for (int q = 0; q < RC; ++q) {
         const int i = ir[q];
         const float hd = eul ? h * TF(dof_damping)[i] : 0.f;
-        _Pragma("unroll") for (int k = 0; k < NVc; ++k) {
-          const float v = M[i * ldm + k];
-          c[q][k] = (eul && k == i) ? v + hd : v;
+        if (spM) {
+          _Pragma("unroll") for (int k4 = 0; k4 < (NVc + 3) / 4; ++k4) {
+            const float4 w = Mq[k4 * nv + i];
+            const float we[4] = {w.x, w.y, w.z, w.w};
+            _Pragma("unroll") for (int e = 0; e < 4; ++e) { const int k = 4 * k4 + e; if (k < NVc) c[q][k] = (eul && k == i) ? we[e] + hd : we[e]; }
+          }
+        } else {
+          _Pragma("unroll") for (int k = 0; k < NVc; ++k) {
+            const float v = M[i * ldm + k];
+            c[q][k] = (eul && k == i) ? v + hd : v;
+          }
         }
       }
       static_for<NVc>([&](auto kc) {
@@ -934,54 +973,70 @@ __global__ void __launch_bounds__(64 * kMaxWavesPerBlock) env_kernel(ModelView m
         }
       }
       SYNC();  // the work copy's storage goes to the velocity / RNE scratch (trip 0)
-    } else if (pass == 0) {
-      // run-time-sized kernel / more than 16 dofs: both matrices in the same column sweep (a column costs two synchronisation
-      // points, whichever the number of matrices), work copies stored as lower triangles (row i at i (i + 1) / 2) - the two
-      // squares would be the largest thing in region A.  The diagonal keeps L_kk^2 (never overwritten).
-      const int ntri = (nv * (nv + 1) / 2 + 3) & ~3;
-      float* C1 = Cw; float* C2 = Cw + ntri;
+    } else {
+      // run-time-sized kernel / more than 32 dofs: the same two trips with the matrices in LDS.  Work copy `Lp`: a packed lower
+      // triangle (row i at i (i + 1) / 2; region A2), factored column by column in LEFT-looking order - entry (i, k) starts as
+      // M[i][k] and loses L[i][j] L[k][j] for j = 0 .. k - 1, one after the other: the subtractions the right-looking elimination
+      // of the register-resident form applies to it, in the same order (bit-identical), but as a dot product of two rows that
+      // stores nothing inside its loop (round 6; the right-looking sweep re-wrote the trailing triangle once per column through
+      // LDS: a third of the step of a 33-dof robot).  The diagonal keeps L_kk^2.  Then the inverse factor `Li`, packed the same
+      // way, one column per lane by forward substitution.  One factor at a time (M now, M + h D at the end of the step): half
+      // the LDS of round 5's two squares.
+      const bool eul = pass == 1;
+      float* Lp = Cw; float* Li = LL;
       FOR_G(i, nv) {
         const int ti = i * (i + 1) / 2;
-        const float hd = h * TF(dof_damping)[i];
-        for (int k = 0; k <= i; ++k) {
-          const float v = M[i * ldm + k];
-          C1[ti + k] = v;
-          C2[ti + k] = (k == i) ? v + hd : v;
-        }
-      }
-      for (int k = 0; k < nv; ++k) {
-        SYNC();  // trailing update of column k-1 (or the copy) is complete
-        const int tk = k * (k + 1) / 2;
-        const float r1 = rsqrtf(fmaxf(C1[tk + k], MJ_MINVAL)), r2 = rsqrtf(fmaxf(C2[tk + k], MJ_MINVAL));
-        FOR_G(i, nv) if (i > k) { const int ti = i * (i + 1) / 2; C1[ti + k] *= r1; C2[ti + k] *= r2; }
-        SYNC();
-        FOR_G(i, nv) {
-          if (i > k) {
-            const int ti = i * (i + 1) / 2;
-            const float l1 = C1[ti + k], l2 = C2[ti + k];
-            int tj = tk + k + 1;  // row k + 1
-  #pragma unroll 4
-            for (int j = k + 1; j <= i; ++j) {
-              C1[ti + j] -= l1 * C1[tj + k];
-              C2[ti + j] -= l2 * C2[tj + k];
-              tj += j + 1;
-            }
+        const float hd = eul ? h * TF(dof_damping)[i] : 0.f;
+        if (spM) {
+          for (int k4 = 0; 4 * k4 <= i; ++k4) {
+            const float4 w = Mq[k4 * nv + i];
+            const float we[4] = {w.x, w.y, w.z, w.w};
+            _Pragma("unroll") for (int e = 0; e < 4; ++e) { const int k = 4 * k4 + e; if (k <= i) Lp[ti + k] = (eul && k == i) ? we[e] + hd : we[e]; }
+          }
+        } else {
+          for (int k = 0; k <= i; ++k) {
+            const float v = M[i * ldm + k];
+            Lp[ti + k] = (eul && k == i) ? v + hd : v;
           }
         }
       }
       SYNC();
-      // triangular inverses, one column per lane (no cross-lane dependency inside a column)
+      for (int k = 0; k < nv; ++k) {
+        const int tk = k * (k + 1) / 2;
+        float vv[4];  // this lane's rows g, g + 16, .. (at most 64 dofs)
+        _Pragma("unroll") for (int q = 0; q < 4; ++q) {
+          const int i = g + kGroupLanes * q;
+          vv[q] = 0.f;
+          if (i >= k && i < nv) {
+            const int ti = i * (i + 1) / 2;
+            float v = Lp[ti + k];
+  DOT_UNROLL
+            for (int j = 0; j < k; ++j) v -= Lp[ti + j] * Lp[tk + j];
+            vv[q] = v;
+            if (i == k) Lp[tk + k] = v;
+          }
+        }
+        SYNC();
+        const float r = rsqrtf(fmaxf(Lp[tk + k], MJ_MINVAL));
+        _Pragma("unroll") for (int q = 0; q < 4; ++q) {
+          const int i = g + kGroupLanes * q;
+          if (i > k && i < nv) Lp[i * (i + 1) / 2 + k] = vv[q] * r;
+        }
+        SYNC();
+      }
+      if (pass == 0) PT(6);
+      // triangular inverse, one column per lane (no cross-lane dependency inside a column)
       FOR_G(j, nv) {
-        const int tjj = j * (j + 1) / 2 + j;
-        LL[j * ldm + j] = rsqrtf(fmaxf(C1[tjj], MJ_MINVAL));      // Li[j][j]
-        LL[j * ldm + j + 1] = rsqrtf(fmaxf(C2[tjj], MJ_MINVAL));  // Le[j][j] (transposed slot)
+        const int tj = j * (j + 1) / 2;
+        Li[tj + j] = rsqrtf(fmaxf(Lp[tj + j], MJ_MINVAL));
+        int ti = tj + j + 1;  // row j + 1
         for (int i = j + 1; i < nv; ++i) {
-          const int ti = i * (i + 1) / 2;
-          float s1 = 0.f, s2 = 0.f;
+          float s1 = 0.f;
+          int tkj = tj + j;  // Li[k][j], k = j
   #pragma unroll 4
-          for (int k = j; k < i; ++k) { s1 += C1[ti + k] * LL[k * ldm + j]; s2 += C2[ti + k] * LL[j * ldm + k + 1]; }
-          LL[i * ldm + j] = -s1 * rsqrtf(fmaxf(C1[ti + i], MJ_MINVAL));      // Li[i][j]
-          LL[j * ldm + i + 1] = -s2 * rsqrtf(fmaxf(C2[ti + i], MJ_MINVAL));  // Le[i][j]
+          for (int k = j; k < i; ++k) { s1 += Lp[ti + k] * Li[tkj]; tkj += k + 1; }
+          Li[ti + j] = -s1 * rsqrtf(fmaxf(Lp[ti + i], MJ_MINVAL));
+          ti += i + 1;
         }
       }
     }
@@ -1119,8 +1174,20 @@ __global__ void __launch_bounds__(64 * kMaxWavesPerBlock) env_kernel(ModelView m
     // dof): it is kept as that sign (dsgn, per dof; 0 = no active limit) and its row index (drow), and only the contact rows are
     // a dense [4 ncon][nv] matrix in LDS.  Products with the limit rows are written out where they occur; they equal what the
     // dense row gave bit for bit (the other terms of that row's sum were exact zeros).
-    FOR_G(r, 4 * ncon) for (int k = 0; k < nv; ++k) J[r * ldj + k] = 0.f;
+    if (!spJ) FOR_G(r, 4 * ncon) for (int k = 0; k < nv; ++k) J[r * ldj + k] = 0.f;
     FOR_G(i, nv) dlim[i] = 0;
+    // Jacobian in global memory (large robots): per contact slot the set of dofs its rows touch - the ancestors of its one or two bodies -
+    // if the contact is active, else none; the rows are written and read through these sets only (every other entry is an exact zero)
+    u64* jmask = reinterpret_cast<u64*>(S + P.jmask);
+    float4* Jc = reinterpret_cast<float4*>(G + (spJ ? P.gJc : 0));  // [ncon][nv]: (rows 4 c .. 4 c + 3) of dof d
+    float4* Jq = reinterpret_cast<float4*>(G + (spJ ? P.gJq : 0));  // [nvq][4 ncon]: (dofs 4 q .. 4 q + 3) of row r
+    if (spJ) {
+      FOR_G(c, ncon) {
+        u64 m = TU(body_ancdof_mask)[TI(con_bodyid)[c]];
+        if (c >= nplane) m |= TU(body_ancdof_mask)[TI(pair_body)[2 * (c - nplane)]];
+        jmask[c] = condist[c] < 0.f ? m : 0ull;
+      }
+    }
     SYNC();
     FOR_G(r, nlim) {  // joint limits: one row each
       const int jid = TI(lim_jntid)[r];
@@ -1132,33 +1199,54 @@ __global__ void __launch_bounds__(64 * kMaxWavesPerBlock) env_kernel(ModelView m
       jv[r] = act ? pos : 0.f;               // pos, parked in jv until the row parameters are built
       jaref[r] = act ? TF(dof_invweight0)[da] : 0.f;  // invweight, parked in jaref
     }
+    // the four pyramid rows of contact c at dof d (false: the dof moves neither body - the entries are zeros)
+    auto contact_rows = [&](int c, int d, float* r4) -> bool {
+      // translational Jacobian of the contact point: body 2 minus body 1 (body 1 = world for a ground contact)
+      V3 jp = {0.f, 0.f, 0.f};
+      bool any = false;
+      for (int side = 0; side < 2; ++side) {
+        if (side == 1 && c < nplane) break;
+        const int b = side == 0 ? TI(con_bodyid)[c] : TI(pair_body)[2 * (c - nplane)];
+        if ((TU(body_ancdof_mask)[b] >> d) & 1ull) {
+          int ri = 0;
+          for (int r = 0; r < nroot; ++r) if (TI(root_body)[r] == TI(body_rootid)[b]) ri = r;
+          const V3 off = sub3(ld3(conpos + 3 * c), ld3(rootcom + 3 * ri));
+          const V3 jb = add3(ld3(cdof + 6 * d + 3), cross3(ld3(cdof + 6 * d), off));
+          jp = side == 0 ? add3(jp, jb) : sub3(jp, jb);
+          any = true;
+        }
+      }
+      if (any) {
+        const V3 n = ld3(confr + 6 * c), t1 = ld3(confr + 6 * c + 3), t2 = cross3(n, t1);
+        const float jn = dot3(n, jp), jt1 = dot3(t1, jp), jt2 = dot3(t2, jp);
+        const float mu = TF(con_friction)[3 * c];
+        r4[0] = jn + mu * jt1; r4[1] = jn - mu * jt1; r4[2] = jn + mu * jt2; r4[3] = jn - mu * jt2;
+      }
+      return any;
+    };
+    if (spJ) {
+      const int nv4 = 4 * nvq, R = 4 * ncon;
+      for (int item = g; item < ncon * nv4; item += kGroupLanes) {  // (contact, dof) per item, the last quad's padding included
+        const int c = item / nv4, d = item - c * nv4;
+        const u64 m = jmask[c];
+        if (!((m >> (d & ~3)) & 15ull)) continue;  // nobody reads this quad
+        float r4[4] = {0.f, 0.f, 0.f, 0.f};
+        const bool any = d < nv && ((m >> d) & 1ull) && contact_rows(c, d, r4);
+        if (any) Jc[c * nv + d] = make_float4(r4[0], r4[1], r4[2], r4[3]);
+        float* q = reinterpret_cast<float*>(Jq + ((d >> 2) * R + 4 * c)) + (d & 3);
+        q[0] = r4[0]; q[4] = r4[1]; q[8] = r4[2]; q[12] = r4[3];
+      }
+    } else
     for (int item = g; item < ncon * nv; item += kGroupLanes) {  // contacts: 4 pyramid rows, (contact, dof) per item
       const int c = item / nv, d = item - c * nv;
       if (condist[c] < 0.f) {
-        // translational Jacobian of the contact point: body 2 minus body 1 (body 1 = world for a ground contact)
-        V3 jp = {0.f, 0.f, 0.f};
-        bool any = false;
-        for (int side = 0; side < 2; ++side) {
-          if (side == 1 && c < nplane) break;
-          const int b = side == 0 ? TI(con_bodyid)[c] : TI(pair_body)[2 * (c - nplane)];
-          if ((TU(body_ancdof_mask)[b] >> d) & 1ull) {
-            int ri = 0;
-            for (int r = 0; r < nroot; ++r) if (TI(root_body)[r] == TI(body_rootid)[b]) ri = r;
-            const V3 off = sub3(ld3(conpos + 3 * c), ld3(rootcom + 3 * ri));
-            const V3 jb = add3(ld3(cdof + 6 * d + 3), cross3(ld3(cdof + 6 * d), off));
-            jp = side == 0 ? add3(jp, jb) : sub3(jp, jb);
-            any = true;
-          }
-        }
-        if (any) {
-          const V3 n = ld3(confr + 6 * c), t1 = ld3(confr + 6 * c + 3), t2 = cross3(n, t1);
-          const float jn = dot3(n, jp), jt1 = dot3(t1, jp), jt2 = dot3(t2, jp);
-          const float mu = TF(con_friction)[3 * c];
+        float r4[4];
+        if (contact_rows(c, d, r4)) {
           const int r0 = 4 * c;
-          J[(r0 + 0) * ldj + d] = jn + mu * jt1;
-          J[(r0 + 1) * ldj + d] = jn - mu * jt1;
-          J[(r0 + 2) * ldj + d] = jn + mu * jt2;
-          J[(r0 + 3) * ldj + d] = jn - mu * jt2;
+          J[(r0 + 0) * ldj + d] = r4[0];
+          J[(r0 + 1) * ldj + d] = r4[1];
+          J[(r0 + 2) * ldj + d] = r4[2];
+          J[(r0 + 3) * ldj + d] = r4[3];
         }
       }
     }
@@ -1173,27 +1261,68 @@ __global__ void __launch_bounds__(64 * kMaxWavesPerBlock) env_kernel(ModelView m
         jaref[nlim + 4 * c + k] = act ? iw : 0.f;
       }
     }
-    SYNC();
+    if (spJ) GSYNC(); else SYNC();
     float k_lim, b_lim, k_con, b_con;
     kb_params(TF(limit_solref), TF(limit_solimp), h, k_lim, b_lim);
     kb_params(TF(contact_solref), TF(contact_solimp), h, k_con, b_con);
     // row r of the constraint Jacobian times an nv-vector / column i times an nefc-vector
     auto jrow_dot = [&](int r, const float* x) {
       if (r < nlim) { const int da = TI(jnt_dofadr)[TI(lim_jntid)[r]]; return lim_sign(dlim[da]) * x[da]; }
-      const float* jr = J + (r - nlim) * ldj;
       float s = 0.f;
+      if (spJ) {
+        // the row's dof quads that hold anything, in ascending order: the dense sum's terms minus exact zeros
+        const int rc = r - nlim, R = 4 * ncon;
+        const u64 m = jmask[rc >> 2];
+  #pragma unroll 4
+        for (int k4 = 0; k4 < nvq; ++k4) {
+          if ((m >> (4 * k4)) & 15ull) {
+            const float4 w = Jq[k4 * R + rc];
+            const int k = 4 * k4;
+            s += w.x * x[k];
+            s += w.y * (k + 1 < nv ? x[k + 1] : 0.f);
+            s += w.z * (k + 2 < nv ? x[k + 2] : 0.f);
+            s += w.w * (k + 3 < nv ? x[k + 3] : 0.f);
+          }
+        }
+        return s;
+      }
+      const float* jr = J + (r - nlim) * ldj;
       DOT_UNROLL for (int k = 0; k < nv; ++k) s += jr[k] * x[k];
       return s;
     };
     auto jcol_dot = [&](int i, const float* f) {
       float s = 0.f;
       if (nlim > 0) { const int dl = dlim[i]; s = lim_sign(dl) * f[lim_row(dl)]; }
+      if (spJ) {
+  #pragma unroll 4
+        for (int c = 0; c < ncon; ++c) {
+          if ((jmask[c] >> i) & 1ull) {
+            const float4 w = Jc[c * nv + i];
+            const float* fc = f + nlim + 4 * c;
+            s += w.x * fc[0]; s += w.y * fc[1]; s += w.z * fc[2]; s += w.w * fc[3];
+          }
+        }
+        return s;
+      }
       const int nc4 = 4 * ncon;
       DOT_UNROLL for (int r = 0; r < nc4; ++r) s += J[r * ldj + i] * f[nlim + r];
       return s;
     };
     auto mrow_dot = [&](int i, const float* x) {
       float s = 0.f;
+      if (spM) {
+        // the same terms in the same order; a quad's entries beyond nv are zeros times a masked operand (x is padded to a quad in LDS)
+  #pragma unroll 4
+        for (int k4 = 0; k4 < nvq; ++k4) {
+          const float4 w = Mq[k4 * nv + i];
+          const int k = 4 * k4;
+          s += w.x * x[k];
+          s += w.y * (k + 1 < nv ? x[k + 1] : 0.f);
+          s += w.z * (k + 2 < nv ? x[k + 2] : 0.f);
+          s += w.w * (k + 3 < nv ? x[k + 3] : 0.f);
+        }
+        return s;
+      }
       DOT_UNROLL for (int k = 0; k < nv; ++k) s += M[i * ldm + k] * x[k];
       return s;
     };
@@ -1415,11 +1544,13 @@ __global__ void __launch_bounds__(64 * kMaxWavesPerBlock) env_kernel(ModelView m
     // ---- probe outputs (parity tests) ---------------------------------------------------------------------
     if (MODE == 2 && valid) {
       const mppo_forward_probe_t& pr = a.probe;
-      if (pr.qM) FOR_G(i, nv) for (int k = 0; k < nv; ++k) pr.qM[((size_t)env * nv + i) * nv + k] = M[i * ldm + k];
+      if (pr.qM) FOR_G(i, nv) for (int k = 0; k < nv; ++k) pr.qM[((size_t)env * nv + i) * nv + k] = Mget(i, k);
       if (pr.qacc_smooth) FOR_G(i, nv) pr.qacc_smooth[(size_t)env * nv + i] = qas[i];
       if (pr.qacc) FOR_G(i, nv) pr.qacc[(size_t)env * nv + i] = qacc[i];
       if (pr.efc_J) FOR_G(r, nefc) for (int k = 0; k < nv; ++k)
-        pr.efc_J[((size_t)env * nefc + r) * nv + k] = r >= nlim ? J[(r - nlim) * ldj + k] : (k == TI(jnt_dofadr)[TI(lim_jntid)[r]] ? lim_sign(dlim[k]) : 0.f);
+        pr.efc_J[((size_t)env * nefc + r) * nv + k] = r >= nlim ? (spJ ? (((jmask[(r - nlim) >> 2] >> k) & 1ull) ? reinterpret_cast<const float*>(Jc + ((r - nlim) >> 2) * nv + k)[(r - nlim) & 3] : 0.f)
+                                                                        : J[(r - nlim) * ldj + k])
+                                                            : (k == TI(jnt_dofadr)[TI(lim_jntid)[r]] ? lim_sign(dlim[k]) : 0.f);
       if (pr.efc_D) FOR_G(r, nefc) pr.efc_D[(size_t)env * nefc + r] = eD[r];
       if (pr.efc_aref) FOR_G(r, nefc) pr.efc_aref[(size_t)env * nefc + r] = earef[r];
       if (pr.subtree_com1 && g == 0) pr.subtree_com1[env] = new_comx;
@@ -1599,10 +1730,21 @@ struct mppo_model {
   int lds_bytes;
   int waves;  // wavefronts per workgroup (mv.epw environments each: 4, fewer for a very large robot; one copy of the model tables per workgroup)
   int spec;  // index into the table of model-specialised kernels (spec_dims.inc), -1: the run-time-sized kernel
+  // the records of the matrices a large robot keeps out of LDS (PhysLds::gwords floats per environment group of the grid), for launches
+  // through mppo_env_reset / _step / mppo_physics_forward: owned by the handle, grown on demand (the engine passes a region of its arena
+  // instead).  One stream at a time may launch through a handle that needs them.
+  mutable float* scratch = nullptr;
+  mutable size_t scratch_bytes = 0;
 };
 
 namespace mppo {
 const ModelView& model_view(const mppo_model* m) { return m->mv; }
+// bytes of global memory the environment kernel needs beside the state for N environments (0 for a robot whose matrices fit LDS)
+size_t model_scratch_bytes(const mppo_model* m, int N) {
+  if (m->lds.gwords <= 0) return 0;
+  const int per_block = m->mv.epw * m->waves;
+  return (size_t)cdiv(N, per_block) * per_block * (size_t)m->lds.gwords * sizeof(float);
+}
 }
 
 extern "C" int32_t mppo_model_open(const void* host_blob, size_t nbytes, const void* dev_blob, mppo_model_t** out) {
@@ -1735,8 +1877,13 @@ extern "C" int32_t mppo_model_open(const void* host_blob, size_t nbytes, const v
   v.rec_dim = v.obs_pad + ((v.nv + 2 + 3) & ~3);
   bd.hull = v.hull_words > 0 ? 1 : 0; bd.ncyl = v.ncyl;
   m->spec = find_spec(bd);
-  // (a model-specialised kernel of up to 32 dofs keeps the inverse Cholesky factor in registers: no LL square in its layout)
-  m->lds = make_phys_lds(v.nq, v.nv, v.nu, v.nbody, v.njnt, v.ncon, v.nefc, v.nroot, v.ncvx, m->spec >= 0 && v.nv <= 2 * kGroupLanes);
+  // (a model-specialised kernel of up to 32 dofs keeps the inverse Cholesky factor in registers: no LL square in its layout; the matrices
+  // that leave LDS for global memory - spill_for - are a function of the dims that the specialised kernel evaluated at compile time)
+  auto lds_for = [&](bool li_regs) {
+    return make_phys_lds(v.nq, v.nv, v.nu, v.nbody, v.njnt, v.ncon, v.nefc, v.nroot, v.ncvx, li_regs,
+                         spill_for(v.nq, v.nv, v.nu, v.nbody, v.njnt, v.ncon, v.nefc, v.nroot, v.ncvx, li_regs, canon.words));
+  };
+  m->lds = lds_for(m->spec >= 0 && v.nv <= 2 * kGroupLanes);
   // waves per workgroup: whatever puts the most waves on a CU (160 KB of LDS; every workgroup holds one copy of the model tables and
   // waves x 4 environments), the smaller workgroup on a tie.  MPPO_ENV_WAVES=1..4 overrides (measurements).
   // A robot too large for four environments per wave (many contact slots: the Jacobian rows dominate) runs two or one per wave on the
@@ -1745,7 +1892,7 @@ extern "C" int32_t mppo_model_open(const void* host_blob, size_t nbytes, const v
   if (m->spec >= 0 && ((long long)v.blob_words + (long long)m->lds.total * kEnvsPerWave) * 4 > 160 * 1024) {
     // (a specialised kernel carries four environments per wave; a robot too large for that runs the run-time-sized kernel with fewer)
     m->spec = -1;
-    m->lds = make_phys_lds(v.nq, v.nv, v.nu, v.nbody, v.njnt, v.ncon, v.nefc, v.nroot, v.ncvx, false);
+    m->lds = lds_for(false);
   }
   auto lds_of = [&](int w) { return (int)std::min<long long>(((long long)v.blob_words + (long long)m->lds.total * v.epw * w) * 4, 1 << 30); };
   while (lds_of(1) > 160 * 1024 && m->spec < 0 && v.epw > 1) v.epw /= 2;
@@ -1770,7 +1917,14 @@ extern "C" int32_t mppo_debug_phys_timers(unsigned long long* out40) {
 #endif
 
 extern "C" int32_t mppo_model_close(mppo_model_t* m) {
+  if (m && m->scratch) (void)hipFree(m->scratch);
   delete m;
+  return MPPO_OK;
+}
+
+extern "C" int32_t mppo_model_scratch_bytes(const mppo_model_t* m, int32_t N, size_t* out) {
+  if (!m || !out || N < 1) return mppo::fail(MPPO_EINVAL, "mppo_model_scratch_bytes: null argument or N < 1");
+  *out = mppo::model_scratch_bytes(m, N);
   return MPPO_OK;
 }
 
@@ -1783,9 +1937,43 @@ extern "C" int32_t mppo_model_get_dims(const mppo_model_t* m, mppo_model_dims_t*
 }
 
 namespace mppo {
-static int32_t launch_env(const mppo_model_t* m, const EnvArgs& a, hipStream_t stream) {
+// `ws`: the caller's region for the out-of-LDS matrices (the engine's arena), or null: the handle's own allocation, grown on demand
+static int32_t launch_env(const mppo_model_t* m, EnvArgs a, hipStream_t stream, float* ws = nullptr, size_t ws_bytes = 0) {
   const int blocks = cdiv(a.N, m->mv.epw * m->waves);
+  const size_t need = model_scratch_bytes(m, a.N);
+  if (need > 0) {
+    if (ws) {
+      if (ws_bytes < need) return fail(MPPO_EINVAL, "environment kernel: the caller's scratch region holds %zu bytes, %d environments need %zu", ws_bytes, a.N, need);
+      a.scratch = ws;
+    } else {
+      if (m->scratch_bytes < need) {
+        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+        if (stream && hipStreamIsCapturing(stream, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone)
+          return fail(MPPO_EINVAL, "environment kernel: this robot keeps %zu bytes of matrices in global memory for %d environments and the handle's allocation would have to grow inside a stream capture: launch once outside the capture first", need, a.N);
+        if (m->scratch) { MPPO_CHECK_HIP(hipDeviceSynchronize()); (void)hipFree(m->scratch); m->scratch = nullptr; m->scratch_bytes = 0; }
+        MPPO_CHECK_HIP(hipMalloc(reinterpret_cast<void**>(&m->scratch), need));
+        m->scratch_bytes = need;
+      }
+      a.scratch = m->scratch;
+    }
+  }
   return (m->spec >= 0 ? kSpecs[m->spec].launch : &launch_env_t<RuntimeModel>)(m->mv, a, m->lds, m->lds_bytes, blocks, m->waves, stream);
+}
+// the engine's entry: mppo_env_step with the out-of-LDS matrices in a region of the engine's arena (hipGraph capture: nothing is allocated)
+int32_t env_step_ws(const mppo_model_t* m, int32_t N, int32_t n_frames, const mppo_reward_cfg_t* rc, float* state, const float* reset_rec, const float* action,
+                    int32_t act_ld, float* obs, int32_t obs_ld, float* reward, uint8_t* done, const mppo_env_metrics_t* metrics, float* ws, size_t ws_bytes, hipStream_t stream) {
+  EnvArgs a{};
+  a.N = N; a.mode = 1; a.n_frames = n_frames; a.state = state; a.reset_in = reset_rec; a.action = action; a.act_ld = act_ld;
+  a.obs = obs; a.obs_ld = obs_ld; a.reward = reward; a.done = done; a.rc = *rc;
+  if (metrics) a.met = *metrics;
+  return launch_env(m, a, stream, ws, ws_bytes);
+}
+int32_t env_reset_ws(const mppo_model_t* m, int32_t N, float* state, float* reset_rec, float* obs, int32_t obs_ld, const mppo_env_metrics_t* metrics, float* ws, size_t ws_bytes,
+                     hipStream_t stream) {
+  EnvArgs a{};
+  a.N = N; a.mode = 0; a.n_frames = 1; a.state = state; a.reset_out = reset_rec; a.obs = obs; a.obs_ld = obs_ld;
+  if (metrics) a.met = *metrics;
+  return launch_env(m, a, stream, ws, ws_bytes);
 }
 }  // namespace mppo
 

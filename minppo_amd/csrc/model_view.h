@@ -131,7 +131,8 @@ __host__ __device__ constexpr inline HullView hull_view(int nhull, int nvert, in
 //   A1 kinematics: poses (xpos, xquat, xipos), joint anchors / axes (the rotation matrices of bodies and inertial frames are recomputed
 //      from the quaternions where they are used - the same arithmetic, nothing stored)          - until the contact frames are built
 //   A2 factorisation work copy: a [nv][ldc] square (<= 32 dofs, fixed-size kernel: rows in registers; also the square through which the
-//      inverse factor is transposed into the row owners' registers) or the lower triangles of M and M + h D (run-time-sized kernel)
+//      inverse factor is transposed into the row owners' registers) or one packed lower triangle (run-time-sized kernel: M, and at the
+//      end of the step M + h D)
 //   A3 velocity / RNE scratch: cdofdot, cfrc, cvel                                             - until qfrc_bias is done
 //   A4 the contact rows of the constraint Jacobian (joint-limit rows are a signed row number per dof: dlim, never a dense row)
 // A second time-shared region, B, holds cdof + contact geometry, then the solver's vectors.  cinert (computed after the kinematics, last
@@ -144,7 +145,8 @@ struct PhysLds {
   int qpos, qvel, ctrl, warm;  // ctrl shares t1's storage (dead before the solver; re-read from the action every frame)
   int rootcom, cdof;
   int ldc;         // row stride of the factorisation work copy in a fixed-size kernel: nv rounded up to 4 (rows are read as float4)
-  int M, LL, ldm;  // LL (run-time-sized kernel only) packs L^-1 of M (lower part, [i][k<=i]) and of M + h*D (stored transposed at [k][i+1])
+  int M, LL, ldm;  // LL (kernels that keep the factor in LDS): the inverse Cholesky factor as a packed lower triangle (row i at i (i + 1) / 2) - of M during the
+                   // step, of M + h*D once the second factorisation at the end of the step has run (round 6; round 5 kept both in one square)
   int qfs, qas, qacc, Ma, grad, Mgrad, search, mv, qfc, t0, t1;
   int dlim;        // per dof, an int: +-(row + 1) of its active joint-limit row, the sign being the row's single Jacobian entry (0: none)
   int D, aref, jaref, jv, force;  // force shares jv's storage (jv is dead once the step along the search direction is taken)
@@ -152,11 +154,20 @@ struct PhysLds {
   int cvxsel, cvxok;           // per convex geom: the four hull vertices chosen this step (body frame) and whether each slot is a first occurrence
   int A, xpos, xquat, xipos, xanchor, xaxis, C, cdofdot, cfrc, cvel, cinert, J, ldj;
   int total;
+  // Round 6 - matrices that leave LDS for a per-environment record in global memory (L2 / Infinity-Cache resident; `spill`, chosen per
+  // model by spill_for below so that a CU's 160 KB hold four waves): offsets in floats inside the record, -1 = the matrix is in LDS.
+  //   gJc  [ncon][nv][4]       the four pyramid rows of a contact side by side: lane = dof reads one float4 per contact   (J^T f)
+  //   gJq  [nvq][4 ncon][4]    four consecutive dofs of a row side by side: lane = row reads one float4 per dof quad      (J x)
+  //   gM   [nvq][nv][4]        four consecutive columns of a row side by side: lane = row reads one float4 per quad       (M x)
+  // (nvq = ceil(nv / 4); lanes of an environment read consecutive 16-byte words.)  jmask: per contact slot, in LDS, the dofs its rows
+  // touch (the ancestors of its one or two bodies) if the contact is active this step, else 0 - writers and readers skip the rest.
+  int spill, gJc, gJq, gM, gwords, jmask;
 };
+constexpr int kSpillJ = 1, kSpillM = 2;
 
 __host__ __device__ constexpr inline int imax_(int a, int b) { return a > b ? a : b; }
 
-__host__ __device__ constexpr inline PhysLds make_phys_lds(int nq, int nv, int nu, int nbody, int njnt, int ncon, int nefc, int nroot, int ncvx = 0, bool li_regs = false) {
+__host__ __device__ constexpr inline PhysLds make_phys_lds(int nq, int nv, int nu, int nbody, int njnt, int ncon, int nefc, int nroot, int ncvx = 0, bool li_regs = false, int spill = 0) {
   PhysLds p{};
   int o = 0;
   auto take = [&](int n) { int r = o; o += (n + 3) & ~3; return r; };
@@ -164,8 +175,10 @@ __host__ __device__ constexpr inline PhysLds make_phys_lds(int nq, int nv, int n
   p.qpos = take(nq); p.qvel = take(nv); p.warm = take(nv);
   p.rootcom = take(3 * (nroot > 0 ? nroot : 1));
   p.ldm = nv + 1;  // odd row stride: a column read by 16 lanes hits 16 different banks
-  p.M = take(nv * p.ldm);
-  p.LL = li_regs ? p.M : take(nv * p.ldm);  // (li_regs: never addressed)
+  p.spill = ncon > 0 ? spill : (spill & ~kSpillJ);
+  p.M = (p.spill & kSpillM) ? 0 : take(nv * p.ldm);
+  const int ntri = (nv * (nv + 1) / 2 + 3) & ~3;  // a packed lower triangle: row i at i (i + 1) / 2
+  p.LL = li_regs ? p.M : take(ntri);  // (li_regs: never addressed)
   p.qfs = take(nv); p.qas = take(nv); p.t0 = take(nv); p.t1 = take(nv);
   p.ctrl = p.t1;
   p.dlim = take(nv);
@@ -175,6 +188,7 @@ __host__ __device__ constexpr inline PhysLds make_phys_lds(int nq, int nv, int n
   const int rows1 = o;
   o = rows0; p.cinert = take(10 * nbody); o = imax_(o, rows1);
   p.cvxsel = take(12 * ncvx); p.cvxok = take(4 * ncvx);
+  p.jmask = (p.spill & kSpillJ) ? take(2 * ncon) : 0;
   // region B, two lifetimes: the dynamics' cdof and the contact geometry, dead once the Jacobian is built | the solver's nv-vectors,
   // born after that (qacc stays until the end of the step: it is the next step's warm start)
   const int B = o;
@@ -186,14 +200,49 @@ __host__ __device__ constexpr inline PhysLds make_phys_lds(int nq, int nv, int n
   p.xpos = take(3 * nbody); p.xquat = take(4 * nbody); p.xipos = take(3 * nbody); p.xanchor = take(3 * njnt); p.xaxis = take(3 * njnt);
   int end = o;
   p.ldc = (nv + 3) & ~3;
-  o = p.A; p.C = take(imax_(nv <= 32 ? nv * imax_(p.ldm, p.ldc) : 0, 2 * ((nv * (nv + 1) / 2 + 3) & ~3))); end = imax_(end, o);
+  o = p.A; p.C = take(li_regs ? imax_(nv * imax_(p.ldm, p.ldc), 2 * ntri) : ntri); end = imax_(end, o);
   o = p.A; p.cdofdot = take(6 * nv); p.cfrc = take(6 * nbody); p.cvel = take(6 * nbody); end = imax_(end, o);
   p.ldj = nv + 1;
-  o = p.A; p.J = take((ncon > 0 ? 4 * ncon : 1) * p.ldj); end = imax_(end, o);
+  o = p.A; p.J = (p.spill & kSpillJ) ? o : take((ncon > 0 ? 4 * ncon : 1) * p.ldj); end = imax_(end, o);
+  {
+    const int nvq = (nv + 3) / 4;
+    int go = 0;
+    auto gtake = [&](int n) { int r = go; go += (n + 63) & ~63; return r; };  // (256-byte aligned pieces)
+    p.gJc = (p.spill & kSpillJ) ? gtake(ncon * nv * 4) : -1;
+    p.gJq = (p.spill & kSpillJ) ? gtake(nvq * 4 * ncon * 4) : -1;
+    p.gM = (p.spill & kSpillM) ? gtake(nvq * nv * 4) : -1;
+    p.gwords = go;
+  }
   // an environment's arrays start 16 banks after its neighbour's (total = 16 mod 64 words): the four environments of a wave read the
   // same logical address at the same time, 16 consecutive words or 16 rows of odd stride each - disjoint sets of the 64 banks
   p.total = ((end + 47) & ~63) + 16;
   return p;
+}
+
+// Which matrices leave LDS (PhysLds::spill): the smallest set - none, the contact Jacobian, the Jacobian and M - with which a CU holds
+// the most waves, counted up to four (one wave per SIMD: 4096 environments of four per wave are then ONE round of the 256 CUs; a fifth
+// wave per CU does not shorten anything the matrices' longer way would not lengthen).  A pure function of the dims: the model-specialised
+// kernels evaluate it at compile time, mppo_model_open at run time.
+constexpr int kLdsPerCu = 160 * 1024;
+__host__ __device__ constexpr inline int waves_per_cu(long long blob_words, long long env_words, int epw) {
+  int best = 0;
+  for (int w = 1; w <= 4; ++w) {
+    const long long bytes = (blob_words + env_words * epw * w) * 4;
+    const int per_cu = bytes <= kLdsPerCu ? (int)(kLdsPerCu / bytes) * w : 0;
+    if (per_cu > best) best = per_cu;
+  }
+  return best;
+}
+__host__ __device__ constexpr inline int spill_for(int nq, int nv, int nu, int nbody, int njnt, int ncon, int nefc, int nroot, int ncvx, bool li_regs, int blob_words) {
+  int best = 0, best_w = -1;
+  const int opts[3] = {0, kSpillJ, kSpillJ | kSpillM};
+  for (int t = 0; t < 3; ++t) {
+    const int s = opts[t];
+    const int w = waves_per_cu(blob_words, make_phys_lds(nq, nv, nu, nbody, njnt, ncon, nefc, nroot, ncvx, li_regs, s).total, 4);
+    const int wc = w > 4 ? 4 : w;
+    if (wc > best_w) { best_w = wc; best = s; }
+  }
+  return best;
 }
 
 // Geometry of the environment kernel.  An environment is private to ONE wavefront (16 lanes = one DPP row), so everything

@@ -27,8 +27,8 @@ names = {0: "load state", 1: "kinematics", 2: "com + contacts", 3: "cinert, cdof
          18: "CG it 5", 20: "probe outputs", 21: "euler + integrate", 22: "epilogue"}
 acc = {}
 for k in range(12):
-    act = torch.randn(N, dims.nu, device="cuda", generator=g)
-    lib.env_step(h, N, 1, C.byref(rc), state.data_ptr(), reset.data_ptr(), act.data_ptr(), dims.nu, obs.data_ptr(), dims.obs_pad, rew.data_ptr(), done.data_ptr(), None, s)
+    act = torch.randn(N, max(dims.nu, 1), device="cuda", generator=g)
+    lib.env_step(h, N, 1, C.byref(rc), state.data_ptr(), reset.data_ptr(), act.data_ptr(), max(dims.nu, 1), obs.data_ptr(), dims.obs_pad, rew.data_ptr(), done.data_ptr(), None, s)
     torch.cuda.synchronize()
     t = (C.c_ulonglong * 40)()
     assert dll.mppo_debug_phys_timers(t) == 0
