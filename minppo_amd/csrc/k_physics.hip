@@ -441,7 +441,7 @@ __global__ void __launch_bounds__(64 * kMaxWavesPerBlock) env_kernel(ModelView m
   constexpr BlobOffsets kSO = blob_offsets(kSD);
   constexpr bool kDims = SD::kStatic;
   // fixed-size kernel, up to 32 dofs: a lane's rows / columns of the Cholesky factors live in registers (see factor_m below)
-  constexpr bool kRegChol = kDims && kSD.nv <= 2 * kGroupLanes;
+  constexpr bool kRegChol = kDims && kSD.nv <= kRegCholMaxNv;
   constexpr int kSpill = kDims ? spill_for(kSD.nq, kSD.nv, kSD.nu, kSD.nbody, kSD.njnt, kSD.ncon, kSD.nlimit + 4 * kSD.ncon, kSD.nroot, kSD.ncvx, kRegChol, kSO.words) : 0;
   constexpr PhysLds kSP = make_phys_lds(kSD.nq, kSD.nv, kSD.nu, kSD.nbody, kSD.njnt, kSD.ncon, kSD.nlimit + 4 * kSD.ncon, kSD.nroot, kSD.ncvx, kRegChol, kSpill);
   const PhysLds P = SD::kStatic ? kSP : Prt;
@@ -1710,10 +1710,18 @@ static const SpecEntry kSpecs[] = {
     {BlobDims{}, nullptr}};
 #undef MPPO_SPEC
 
-// MPPO_ENV_GENERIC=1 forces the run-time-sized kernel (A/B tests of the two instantiations)
+// MPPO_ENV_GENERIC=1 forces the run-time-sized kernel (A/B tests of the two instantiations); so does MPPO_ENV_SPILL, which only the
+// run-time-sized kernel can follow (a specialised kernel's choice is compiled in)
+static int env_spill_override() {
+  const char* e = getenv("MPPO_ENV_SPILL");
+  if (!e || !e[0]) return -1;
+  const int v = atoi(e);
+  return v == 0 ? 0 : v == 1 ? kSpillJ : (kSpillJ | kSpillM);
+}
 static int find_spec(const BlobDims& d) {
   const char* e = getenv("MPPO_ENV_GENERIC");
   if (e && e[0] == '1') return -1;
+  if (env_spill_override() >= 0) return -1;
   for (int i = 0; kSpecs[i].launch; ++i) {
     const BlobDims& s = kSpecs[i].d;
     if (s.nq == d.nq && s.nv == d.nv && s.nu == d.nu && s.nbody == d.nbody && s.njnt == d.njnt && s.ncon == d.ncon && s.nlimit == d.nlimit &&
@@ -1879,11 +1887,14 @@ extern "C" int32_t mppo_model_open(const void* host_blob, size_t nbytes, const v
   m->spec = find_spec(bd);
   // (a model-specialised kernel of up to 32 dofs keeps the inverse Cholesky factor in registers: no LL square in its layout; the matrices
   // that leave LDS for global memory - spill_for - are a function of the dims that the specialised kernel evaluated at compile time)
+  // (MPPO_ENV_SPILL=0|1|3 overrides the choice - nothing, the Jacobian, the Jacobian and M in global memory - for A/B measurements and
+  // for the test that holds the two placements bit-equal)
   auto lds_for = [&](bool li_regs) {
+    const int forced = env_spill_override();
     return make_phys_lds(v.nq, v.nv, v.nu, v.nbody, v.njnt, v.ncon, v.nefc, v.nroot, v.ncvx, li_regs,
-                         spill_for(v.nq, v.nv, v.nu, v.nbody, v.njnt, v.ncon, v.nefc, v.nroot, v.ncvx, li_regs, canon.words));
+                         forced >= 0 ? forced : spill_for(v.nq, v.nv, v.nu, v.nbody, v.njnt, v.ncon, v.nefc, v.nroot, v.ncvx, li_regs, canon.words));
   };
-  m->lds = lds_for(m->spec >= 0 && v.nv <= 2 * kGroupLanes);
+  m->lds = lds_for(m->spec >= 0 && v.nv <= kRegCholMaxNv);
   // waves per workgroup: whatever puts the most waves on a CU (160 KB of LDS; every workgroup holds one copy of the model tables and
   // waves x 4 environments), the smaller workgroup on a tie.  MPPO_ENV_WAVES=1..4 overrides (measurements).
   // A robot too large for four environments per wave (many contact slots: the Jacobian rows dominate) runs two or one per wave on the

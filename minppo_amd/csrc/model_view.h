@@ -256,6 +256,10 @@ __host__ __device__ constexpr inline int spill_for(int nq, int nv, int nu, int n
 #define MPPO_ENVS_PER_WAVE 4
 #endif
 constexpr int kGroupLanes = 16;                      // lanes that cooperate on one environment
+#ifndef MPPO_REGCHOL_MAX_NV
+#define MPPO_REGCHOL_MAX_NV 48
+#endif
+constexpr int kRegCholMaxNv = MPPO_REGCHOL_MAX_NV;   // model-specialised kernels up to this many dofs keep the Cholesky factors in registers (three rows per lane)
 constexpr int kEnvsPerWave = MPPO_ENVS_PER_WAVE;     // 1, 2 or 4
 constexpr int kMaxWavesPerBlock = 4;                 // the number of waves per workgroup is chosen per model (mppo_model_open): the most
                                                      // waves per CU that 160 KB of LDS hold, one copy of the model tables per workgroup

@@ -371,6 +371,39 @@ def test_engine_errors(be):
         be.trainer(_cfg(*_small(be), "model.num_layers=3", "training.mlp_dtype=bf16"))
 
 
+def test_engine_with_a_robots_matrices_in_global_memory(be, monkeypatch):
+    """Round 6: the export-style biped (33 dofs, 19 contact slots) keeps its contact Jacobian and M in per-environment records in global
+    memory (k_physics.hip).  An engine takes those records from its arena (region `env_scratch`: nothing is allocated
+    inside the hipGraph capture); whole updates equal those of an engine forced to keep everything in LDS (MPPO_ENV_SPILL=0: no such
+    region) bit for bit."""
+    from pathlib import Path
+
+    robot = str(Path(__file__).parent / "golden" / "export_biped" / "robot.xml")
+    over = (["training.num_envs=8", "training.num_steps=3", "rl.num_env_steps=3", "training.num_minibatches=2", "training.update_epochs=1", "model.hidden_size=32"]
+            if be.name == "emu" else ["training.num_envs=200", "training.num_minibatches=4", "training.update_epochs=1"])
+    cfg = _cfg(*over, "training.total_timesteps=100000000", f"environment.model={robot}")
+    res = []
+    for spill in (None, "0"):
+        if spill is None:
+            monkeypatch.delenv("MPPO_ENV_SPILL", raising=False)
+        else:
+            monkeypatch.setenv("MPPO_ENV_SPILL", spill)
+        tr = be.trainer(cfg) if be.name == "emu" else be.trainer(cfg, use_graph=True)
+        if spill is None:
+            assert tr.region("env_scratch").numel() > 0 if be.xp == "torch" else tr.region("env_scratch").size > 0
+        else:
+            with pytest.raises(nat.NativeError):
+                tr.region("env_scratch")
+        tr.reset()
+        for _ in range(2):
+            tr.update()
+        res.append((tr.params_flat(), be.host(tr.region("reward")).copy(), be.host(tr.region("state")).copy()))
+        tr.close()
+    monkeypatch.delenv("MPPO_ENV_SPILL", raising=False)
+    for a_, b_ in zip(res[0], res[1]):
+        np.testing.assert_array_equal(a_, b_)
+
+
 @pytest.mark.gpu
 def test_hipgraph_replay_equals_eager_launches():
     """The captured update replays the same launch sequence: parameters are bitwise equal to the eager run."""

@@ -530,6 +530,58 @@ def test_specialised_kernel_equals_the_runtime_sized_kernel(be, monkeypatch):
     be.lib.model_close(h)
 
 
+def test_matrices_in_global_memory_change_nothing(be, monkeypatch):
+    """Round 6: a robot whose per-environment working set does not fit LDS four waves to a CU keeps its contact Jacobian (and M) in
+    per-environment records in global memory (model_view.h spill_for; mppo_model_scratch_bytes says how much).  Where a matrix lives is
+    a placement, not arithmetic: the products skip only exact zeros.  The export-style biped (33 dofs, 19 contact slots: Jacobian and M
+    outside by default), forced to keep everything in LDS / only the Jacobian outside / both outside (MPPO_ENV_SPILL), must give the
+    same forward probe and the same env steps bit for bit - at an environment count that leaves the last workgroup partly empty (its
+    surplus groups have records of their own).  The BASELINE robots keep everything in LDS and need no scratch."""
+    for name in ("synth_stompy_pro", "synth_stompy_full"):
+        h, dims, _keep = be.model(load_model(name))
+        nb = C.c_size_t(1)
+        be.lib.model_scratch_bytes(h, 4096, C.byref(nb))
+        assert nb.value == 0, name
+        be.lib.model_close(h)
+    cm = load_model(MJCF_EXPORT)
+    N = 21
+    ph, d, rng = _walk(cm, N, 5, 8)
+    ctrl = 0.4 * rng.standard_normal((N, cm.nu))
+    q32 = [x.astype(f32) for x in (d.qpos, d.qvel, ctrl, d.qacc_warmstart)]
+    res, scratch, lds = [], [], []
+    for spill in (None, "0", "1", "3"):
+        if spill is None:
+            monkeypatch.delenv("MPPO_ENV_SPILL", raising=False)
+        else:
+            monkeypatch.setenv("MPPO_ENV_SPILL", spill)
+        h, dims, _keep = be.model(cm)
+        nb = C.c_size_t(0)
+        be.lib.model_scratch_bytes(h, N, C.byref(nb))
+        scratch.append(nb.value); lds.append(dims.lds_bytes)
+        got = _probe(be, h, cm, *q32)
+        OP, R = dims.obs_pad, dims.rec_dim
+        state, reset_rec, obs = be.zeros((N, R)), be.zeros((R,)), be.zeros((N, OP))
+        rew, done = be.zeros((N,)), be.zeros((N,), np.uint8)
+        be.lib.env_reset(h, N, be.ptr(state), be.ptr(reset_rec), be.ptr(obs), OP, be.ptr(rew), be.ptr(done), None, be.stream)
+        rc = nat.RewardCfg(0.3, 2.0, 2.0, 0.2, 0.5, 0.1, 4.0, 1.0, 1.25)
+        r2 = np.random.default_rng(5)
+        for _ in range(5):
+            act = be.arr((0.8 * r2.standard_normal((N, cm.nu))).astype(f32))
+            be.lib.env_step(h, N, 2, C.byref(rc), be.ptr(state), be.ptr(reset_rec), be.ptr(act), cm.nu, be.ptr(obs), OP, be.ptr(rew), be.ptr(done), None, be.stream)
+            be.sync()
+        got.update(state=be.host(state).copy(), obs=be.host(obs).copy(), rew=be.host(rew).copy(), done=be.host(done).copy())
+        res.append(got)
+        be.lib.model_close(h)
+    monkeypatch.delenv("MPPO_ENV_SPILL", raising=False)
+    assert scratch[1] == 0 and 0 < scratch[2] < scratch[3] == scratch[0], scratch  # the default for this robot: both matrices outside
+    assert lds[0] <= 160 * 1024 and lds[0] == lds[3], lds
+    for other in res[1:]:
+        for k in res[0]:
+            a_, b_ = np.asarray(res[0][k]), np.asarray(other[k])
+            neq = ~((a_ == b_) | (np.isnan(a_) & np.isnan(b_))) if a_.dtype.kind == "f" else a_ != b_
+            assert not neq.any(), (k, np.argwhere(neq)[:8].tolist(), a_[neq][:4], b_[neq][:4])
+
+
 def test_free_fall_is_exact_semi_implicit_euler(be):
     """Known answer through the kernel: a free sphere falls z_k = z0 - g h^2 k(k+1)/2 until it touches."""
     cm = load_model("synth_ball")
