@@ -21,6 +21,8 @@
 #include <wave_ops.h>
 
 #include <algorithm>
+#include <cstring>
+#include <vector>
 #include <initializer_list>
 #include <type_traits>
 #include <utility>
@@ -1703,12 +1705,16 @@ static int32_t launch_env_t(const ModelView& mv, const EnvArgs& a, const PhysLds
 struct SpecEntry {
   BlobDims d;
   int32_t (*launch)(const ModelView&, const EnvArgs&, const PhysLds&, int, int, int, hipStream_t);
+  bool extra;  // added by MPPO_SPECIALIZE for this build: not one of the instantiations the test suite holds bit-equal to the run-time-sized
+               // kernel on both backends - mppo_model_open checks it against that kernel on the device before trusting it (spec_self_check)
 };
-#define MPPO_SPEC(...) {BlobDims{__VA_ARGS__}, &launch_env_t<StaticModel<__VA_ARGS__>>},
+#define MPPO_SPEC(...) {BlobDims{__VA_ARGS__}, &launch_env_t<StaticModel<__VA_ARGS__>>, false},
+#define MPPO_SPEC_EXTRA(...) {BlobDims{__VA_ARGS__}, &launch_env_t<StaticModel<__VA_ARGS__>>, true},
 static const SpecEntry kSpecs[] = {
 #include "spec_dims.inc"
-    {BlobDims{}, nullptr}};
+    {BlobDims{}, nullptr, false}};
 #undef MPPO_SPEC
+#undef MPPO_SPEC_EXTRA
 
 // MPPO_ENV_GENERIC=1 forces the run-time-sized kernel (A/B tests of the two instantiations); so does MPPO_ENV_SPILL, which only the
 // run-time-sized kernel can follow (a specialised kernel's choice is compiled in)
@@ -1743,6 +1749,7 @@ struct mppo_model {
   // instead).  One stream at a time may launch through a handle that needs them.
   mutable float* scratch = nullptr;
   mutable size_t scratch_bytes = 0;
+  int canon_words = 0;  // the table part's length as it follows from the dims (what a specialised kernel's compile-time layout choice saw)
 };
 
 namespace mppo {
@@ -1754,6 +1761,106 @@ size_t model_scratch_bytes(const mppo_model* m, int N) {
   return (size_t)cdiv(N, per_block) * per_block * (size_t)m->lds.gwords * sizeof(float);
 }
 }
+
+namespace mppo {
+static int32_t launch_env(const mppo_model_t* m, EnvArgs a, hipStream_t stream, float* ws = nullptr, size_t ws_bytes = 0);
+
+// LDS layout, matrices in global memory, environments per wave and waves per workgroup of a model whose `spec` is decided
+static int32_t finalize_layout(mppo_model* m) {
+  ModelView& v = m->mv;
+  // (a model-specialised kernel of up to kRegCholMaxNv dofs keeps the inverse Cholesky factor in registers: no factor in its LDS layout; the
+  // matrices that leave LDS for global memory - spill_for - are a function of the dims that the specialised kernel evaluated at compile time)
+  // (MPPO_ENV_SPILL=0|1|3 overrides the choice - nothing, the Jacobian, the Jacobian and M in global memory - for A/B measurements and
+  // for the test that holds the two placements bit-equal)
+  auto lds_for = [&](bool li_regs) {
+    const int forced = env_spill_override();
+    return make_phys_lds(v.nq, v.nv, v.nu, v.nbody, v.njnt, v.ncon, v.nefc, v.nroot, v.ncvx, li_regs,
+                         forced >= 0 ? forced : spill_for(v.nq, v.nv, v.nu, v.nbody, v.njnt, v.ncon, v.nefc, v.nroot, v.ncvx, li_regs, m->canon_words));
+  };
+  m->lds = lds_for(m->spec >= 0 && v.nv <= kRegCholMaxNv);
+  // waves per workgroup: whatever puts the most waves on a CU (160 KB of LDS; every workgroup holds one copy of the model tables and
+  // waves x 4 environments), the smaller workgroup on a tie.  MPPO_ENV_WAVES=1..4 overrides (measurements).
+  // A robot too large for four environments per wave even with its matrices outside LDS runs two or one per wave on the
+  // run-time-sized kernel - three quarters of the lanes idle, but it runs (round 5; before, it was refused).
+  v.epw = kEnvsPerWave;
+  if (m->spec >= 0 && ((long long)v.blob_words + (long long)m->lds.total * kEnvsPerWave) * 4 > 160 * 1024) {
+    // (a specialised kernel carries four environments per wave; a robot too large for that runs the run-time-sized kernel with fewer)
+    m->spec = -1;
+    m->lds = lds_for(false);
+  }
+  auto lds_of = [&](int w) { return (int)std::min<long long>(((long long)v.blob_words + (long long)m->lds.total * v.epw * w) * 4, 1 << 30); };
+  while (lds_of(1) > 160 * 1024 && m->spec < 0 && v.epw > 1) v.epw /= 2;
+  int best = 1, best_per_cu = 0;
+  for (int w = 1; w <= kMaxWavesPerBlock; ++w) {
+    const int per_cu = lds_of(w) <= 160 * 1024 ? (160 * 1024 / lds_of(w)) * w : 0;
+    if (per_cu > best_per_cu) { best = w; best_per_cu = per_cu; }
+  }
+  if (const char* e = getenv("MPPO_ENV_WAVES")) { const int w = atoi(e); if (w >= 1 && w <= kMaxWavesPerBlock) best = w; }
+  m->waves = best;
+  m->lds_bytes = lds_of(best);
+  if (m->lds_bytes > 160 * 1024) return fail(MPPO_EMODEL, "model needs %d bytes of LDS per workgroup for ONE environment (limit 163840)", m->lds_bytes);
+  return MPPO_OK;
+}
+
+// A kernel instantiation that MPPO_SPECIALIZE added to this build has never been compared with anything: before it is trusted, a reset and
+// four steps of 24 environments under pseudo-random controls must equal the run-time-sized kernel's bit for bit ON THIS DEVICE.  If they do
+// not (round 6: a 34-dof / 93-body robot's instantiation, 250 spilled registers, ended every episode at its first step on the GPU while the
+// same source was right on the emulator - a code-generation problem under register pressure), the model runs the run-time-sized kernel and
+// says so on stderr.  A few milliseconds at mppo_model_open; the BASELINE instantiations are held to the same standard by the test suite.
+static int32_t spec_self_check(mppo_model* m) {
+  const ModelView& v = m->mv;
+  const int N = 24, steps = 4, nu = v.nu > 0 ? v.nu : 1;
+  const size_t nstate = (size_t)N * v.rec_dim, nobs = (size_t)N * v.obs_pad, nact = (size_t)N * nu;
+  const size_t words = nstate + v.rec_dim + nobs + (size_t)steps * nact + N + N;  // state, reset record, observation, controls, reward, done
+  float* dev = nullptr;
+  MPPO_CHECK_HIP(hipMalloc(reinterpret_cast<void**>(&dev), words * sizeof(float)));
+  std::vector<float> act((size_t)steps * nact), got[2];
+  unsigned lcg = 12345u;
+  for (float& x : act) { lcg = lcg * 1664525u + 1013904223u; x = ((lcg >> 8) & 0xffff) / 32768.f - 1.f; }
+  float *state = dev, *reset_rec = state + nstate, *obs = reset_rec + v.rec_dim, *actd = obs + nobs, *rew = actd + (size_t)steps * nact;
+  unsigned char* done = reinterpret_cast<unsigned char*>(rew + N);
+  mppo_reward_cfg_t rc{};
+  rc.height_min_z = -1e9f; rc.height_max_z = 1e9f;
+  mppo_model generic = *m;
+  generic.spec = -1; generic.scratch = nullptr; generic.scratch_bytes = 0;
+  int32_t st = finalize_layout(&generic);
+  for (int which = 0; which < 2 && st == MPPO_OK; ++which) {
+    const mppo_model* mm = which == 0 ? m : &generic;
+    hipError_t he = hipMemset(dev, 0, words * sizeof(float));
+    if (he == hipSuccess) he = hipMemcpy(actd, act.data(), act.size() * sizeof(float), hipMemcpyHostToDevice);
+    if (he != hipSuccess) { st = fail(MPPO_EHIP, "specialised-kernel self-check: %s", hipGetErrorString(he)); break; }
+    EnvArgs a{};
+    a.N = N; a.mode = 0; a.n_frames = 1; a.state = state; a.reset_out = reset_rec; a.obs = obs; a.obs_ld = v.obs_pad; a.reward = rew; a.done = done;
+    st = launch_env(mm, a, nullptr);
+    for (int t = 0; t < steps && st == MPPO_OK; ++t) {
+      EnvArgs b{};
+      b.N = N; b.mode = 1; b.n_frames = 1; b.state = state; b.reset_in = reset_rec; b.action = actd + (size_t)t * nact; b.act_ld = nu;
+      b.obs = obs; b.obs_ld = v.obs_pad; b.reward = rew; b.done = done; b.rc = rc;
+      st = launch_env(mm, b, nullptr);
+    }
+    if (st != MPPO_OK) break;
+    got[which].resize(words);
+    he = hipDeviceSynchronize();
+    if (he == hipSuccess) he = hipMemcpy(got[which].data(), dev, words * sizeof(float), hipMemcpyDeviceToHost);
+    if (he != hipSuccess) st = fail(MPPO_EHIP, "specialised-kernel self-check: %s", hipGetErrorString(he));
+  }
+  (void)hipFree(dev);
+  if (generic.scratch) (void)hipFree(generic.scratch);
+  if (st != MPPO_OK) return st;
+  // (the controls are the same bytes in both; everything else is the kernels' output)
+  if (memcmp(got[0].data(), got[1].data(), words * sizeof(float)) != 0) {
+    size_t bad = 0;
+    for (size_t i = 0; i < words; ++i) bad += memcmp(&got[0][i], &got[1][i], 4) != 0;
+    fprintf(stderr, "minppo_amd: the environment kernel specialised for this robot (nv %d, %d bodies, %d contact slots) differs from the run-time-sized kernel in %zu of %zu "
+                    "words after a reset and %d steps of %d environments on this device: NOT used - the run-time-sized kernel runs instead.  (Rebuild with "
+                    "MPPO_REGCHOL_MAX_NV=32 to keep the specialised kernel's factorisation out of registers.)\n", v.nv, v.nbody, v.ncon, bad, words, steps, N);
+    if (m->scratch) { (void)hipFree(m->scratch); m->scratch = nullptr; m->scratch_bytes = 0; }
+    m->spec = -1;
+    return finalize_layout(m);
+  }
+  return MPPO_OK;
+}
+}  // namespace mppo
 
 extern "C" int32_t mppo_model_open(const void* host_blob, size_t nbytes, const void* dev_blob, mppo_model_t** out) {
   using namespace mppo;
@@ -1885,37 +1992,11 @@ extern "C" int32_t mppo_model_open(const void* host_blob, size_t nbytes, const v
   v.rec_dim = v.obs_pad + ((v.nv + 2 + 3) & ~3);
   bd.hull = v.hull_words > 0 ? 1 : 0; bd.ncyl = v.ncyl;
   m->spec = find_spec(bd);
-  // (a model-specialised kernel of up to 32 dofs keeps the inverse Cholesky factor in registers: no LL square in its layout; the matrices
-  // that leave LDS for global memory - spill_for - are a function of the dims that the specialised kernel evaluated at compile time)
-  // (MPPO_ENV_SPILL=0|1|3 overrides the choice - nothing, the Jacobian, the Jacobian and M in global memory - for A/B measurements and
-  // for the test that holds the two placements bit-equal)
-  auto lds_for = [&](bool li_regs) {
-    const int forced = env_spill_override();
-    return make_phys_lds(v.nq, v.nv, v.nu, v.nbody, v.njnt, v.ncon, v.nefc, v.nroot, v.ncvx, li_regs,
-                         forced >= 0 ? forced : spill_for(v.nq, v.nv, v.nu, v.nbody, v.njnt, v.ncon, v.nefc, v.nroot, v.ncvx, li_regs, canon.words));
-  };
-  m->lds = lds_for(m->spec >= 0 && v.nv <= kRegCholMaxNv);
-  // waves per workgroup: whatever puts the most waves on a CU (160 KB of LDS; every workgroup holds one copy of the model tables and
-  // waves x 4 environments), the smaller workgroup on a tie.  MPPO_ENV_WAVES=1..4 overrides (measurements).
-  // A robot too large for four environments per wave (many contact slots: the Jacobian rows dominate) runs two or one per wave on the
-  // run-time-sized kernel - three quarters of the lanes idle, but it runs (round 5; before, it was refused).
-  v.epw = kEnvsPerWave;
-  if (m->spec >= 0 && ((long long)v.blob_words + (long long)m->lds.total * kEnvsPerWave) * 4 > 160 * 1024) {
-    // (a specialised kernel carries four environments per wave; a robot too large for that runs the run-time-sized kernel with fewer)
-    m->spec = -1;
-    m->lds = lds_for(false);
+  m->canon_words = canon.words;
+  if (int32_t rc = mppo::finalize_layout(m); rc != MPPO_OK) { delete m; return rc; }
+  if (m->spec >= 0 && kSpecs[m->spec].extra) {
+    if (int32_t rc = mppo::spec_self_check(m); rc != MPPO_OK) { if (m->scratch) (void)hipFree(m->scratch); delete m; return rc; }
   }
-  auto lds_of = [&](int w) { return (int)std::min<long long>(((long long)v.blob_words + (long long)m->lds.total * v.epw * w) * 4, 1 << 30); };
-  while (lds_of(1) > 160 * 1024 && m->spec < 0 && v.epw > 1) v.epw /= 2;
-  int best = 1, best_per_cu = 0;
-  for (int w = 1; w <= kMaxWavesPerBlock; ++w) {
-    const int per_cu = lds_of(w) <= 160 * 1024 ? (160 * 1024 / lds_of(w)) * w : 0;
-    if (per_cu > best_per_cu) { best = w; best_per_cu = per_cu; }
-  }
-  if (const char* e = getenv("MPPO_ENV_WAVES")) { const int w = atoi(e); if (w >= 1 && w <= kMaxWavesPerBlock) best = w; }
-  m->waves = best;
-  m->lds_bytes = lds_of(best);
-  if (m->lds_bytes > 160 * 1024) { delete m; return fail(MPPO_EMODEL, "model needs %d bytes of LDS per workgroup for ONE environment (limit 163840)", m->lds_bytes); }
   *out = m;
   return MPPO_OK;
 }
@@ -1949,7 +2030,7 @@ extern "C" int32_t mppo_model_get_dims(const mppo_model_t* m, mppo_model_dims_t*
 
 namespace mppo {
 // `ws`: the caller's region for the out-of-LDS matrices (the engine's arena), or null: the handle's own allocation, grown on demand
-static int32_t launch_env(const mppo_model_t* m, EnvArgs a, hipStream_t stream, float* ws = nullptr, size_t ws_bytes = 0) {
+static int32_t launch_env(const mppo_model_t* m, EnvArgs a, hipStream_t stream, float* ws, size_t ws_bytes) {
   const int blocks = cdiv(a.N, m->mv.epw * m->waves);
   const size_t need = model_scratch_bytes(m, a.N);
   if (need > 0) {
