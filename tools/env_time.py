@@ -49,5 +49,6 @@ for model, N in cases:
     e0.record()
     for k in range(30): step(k)
     e1.record(); torch.cuda.synchronize()
-    print(f"{model} (nv {cm.nv}, {cm.ncon} contact slots, {cm.nefc} constraint rows, {dims.lds_bytes} bytes of LDS per workgroup) N={N}: {e0.elapsed_time(e1) / 30 * 1e3:.1f} us per env_step launch; state checksum {float(state.double().sum()):.6f} done {int(done.sum())}")
+    nb = C.c_size_t(0); lib.model_scratch_bytes(h, N, C.byref(nb))
+    print(f"{model} (nv {cm.nv}, {cm.ncon} contact slots, {cm.nefc} constraint rows, {dims.lds_bytes} bytes of LDS per workgroup = {160 * 1024 // dims.lds_bytes} workgroup(s) per CU, {nb.value >> 10} KB of matrices in global memory) N={N}: {e0.elapsed_time(e1) / 30 * 1e3:.1f} us per env_step launch; state checksum {float(state.double().sum()):.6f} done {int(done.sum())}")
     lib.model_close(h)
