@@ -666,9 +666,27 @@ def main() -> None:
                                            "updates": calls // (tr.E * tr.M), "git_head": meta.get("git_head"), "kernel_sources_sha": here,
                                            "source": f"profiles/{f.name} ({meta.get('command', 'rocprofv3 --kernel-trace --stats -- python3 bench.py --no-probe')})"}
                             break
-            roofline = {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
+            # Headline figures of the object: the kernel INSIDE the update when a summary of this very tree is committed (it follows an Adam
+            # launch that has just rewritten the weights: every XCD's L2 fetches them again, the back-to-back replay never sees that), the
+            # live stand-alone replay otherwise - `measured` says which, the other one rides along under `standalone` / `in_situ`.
+            standalone = {"us_per_launch": sec * 1e6, "achieved": achieved, "frac": achieved / peak,
+                          "how": "64 launches of exactly this minibatch row pass replayed back to back from a hipGraph on the engine stream between HIP events, live in this run"}
+            use_situ = bool(in_situ and in_situ.get("us_per_launch"))
+            head = in_situ if use_situ else standalone
+            # a bf16 network's row pass is not bound by its matrix work (1 us of MFMA in a 10 us launch): what bounds it is the weight stream
+            # through the CUs' address paths and the latency-bound phases between - say so, and give the stream's rate
+            bound = "mfma"
+            stream = None
+            if bf16:
+                bound = "latency/address-path (the MFMA fraction is reported for the record: DESIGN.md 3.1b)"
+                wbytes = 2.0 * (tr.OP * tr.H + 2 * tr.H * tr.H)  # one network's bf16 fragments a workgroup streams per launch: W1, W2, W2^T
+                stream = {"weight_bytes_per_workgroup": wbytes, "GB_per_s_per_CU": wbytes / (head["us_per_launch"] * 1e-6) / 1e9,
+                          "note": "a CU's vector-memory path takes 64 B per clock = 150 - 180 GB/s warm, 100 - 120 GB/s behind an optimizer step (tools/wstream_probe.hip)"}
+            roofline = {"bound": bound, "achieved": head["achieved"], "peak": peak, "unit": "TFLOP/s", "frac": head["frac"],
+                        "measured": ("in situ: rocprofv3 --kernel-trace --stats of `bench.py --no-probe` on this tree's kernels, " + in_situ["source"]) if use_situ
+                                    else "stand-alone replay, live (no in-situ summary of this tree's kernels is committed: see in_situ.why)",
                         "traffic": traffic, "traffic_unit": "bytes/launch", "traffic_source": traffic_src, "mfma_busy_frac": mfma_busy, "mfma_busy_source": mfma_src, "kernel": desc,
-                        "us_per_launch": sec * 1e6, "in_situ": in_situ, "kernel_sources_sha": here,
+                        "us_per_launch": head["us_per_launch"], "standalone": standalone, "in_situ": in_situ, "weight_stream": stream, "kernel_sources_sha": here,
                         "whole_update_mlp_tflops": (26.0 * (2 * tr.O * tr.H + 2 * tr.H * tr.H + tr.H * (tr.A + 1)) + 0.2 * (tr.O * tr.H + tr.H * tr.H + tr.H)) * steps_total / world / dt / 1e12}
         out = {
             "metric": ("env-steps/sec (whole node), stompy_pro 4096 envs, 1/2/4/8 MI355X" if args.config == "stompy_pro" and args.envs_per_gpu == 4096
@@ -684,7 +702,7 @@ def main() -> None:
             "vs_baseline": None,
             "dtype": "bf16" if bf16 else "f32",
             "data": f"synthetic (stand-in robot {tr.cm.name}, random-init weights, Philox action noise)",
-            "config": {"workload": f"{args.config}: {args.envs_per_gpu} envs/GPU x T={tr.T} rollout + {tr.E}x{tr.M} minibatch PPO update, O={tr.O} A={tr.A} H={tr.H}, {'bf16-in/f32-acc MLP products, f32 elsewhere' if bf16 else 'fp32'} ({baseline_cfg})",
+            "config": {"workload": f"{args.config}{'' if not cfg.environment.model else ' with robot ' + str(cfg.environment.model)}: {args.envs_per_gpu} envs/GPU x T={tr.T} rollout + {tr.E}x{tr.M} minibatch PPO update, O={tr.O} A={tr.A} H={tr.H}, {'bf16-in/f32-acc MLP products, f32 elsewhere' if bf16 else 'fp32'} ({baseline_cfg})",
                        "global_envs": n_global, "parallelism": (f"env-sharded dp{world}, gradients summed per optimizer step: " +
                                                                            ("peer-to-peer exchange over hipIpc-mapped buffers fused into the weight-gradient and Adam launches (csrc/peer.h)" if transport == "peer"
                                                                             else "RCCL all-reduce") + (", all ranks on ONE GPU" if share else "")) if world > 1 else "single GPU",

@@ -157,11 +157,12 @@ static size_t layout(mppo_engine* e, bool assign) {
   e->reset_rec = (float*)take("reset_rec", (size_t)e->mv.rec_dim * 4);
   e->obs = (float*)take("obs", (T + 1) * N * OP * 4);
   e->action = (float*)take("action", T * N * A * 4);
-  e->value = (float*)take("value", B * 4);
+  e->value = (float*)take("value", (B + N) * 4);  // [T][N] + the bootstrap values behind them (region "last_val" below): one critic launch can write both
   e->reward = (float*)take("reward", B * 4);
   e->log_prob = (float*)take("log_prob", B * 4);
   e->done = (unsigned char*)take("done", B);
-  e->last_val = (float*)take("last_val", N * 4);
+  e->last_val = assign ? e->value + B : nullptr;
+  for (Region& r : e->regions) if (r.name == "value") { r.bytes = B * 4; e->regions.push_back({"last_val", r.off + B * 4, N * 4}); break; }  // (two names for the two parts)
   e->adv = (float*)take("adv", B * 4);
   e->target = (float*)take("target", B * 4);
   e->noise = (float*)take("noise", T * N * A * 4);
@@ -261,14 +262,20 @@ static int32_t do_rollout(mppo_engine* e, hipStream_t s) {
     MPPO_TRY(shadow_refresh(c.net, e->params, gb, s));
     fb.frag = gb.frag; fb.frag_net_stride = gb.frag_net_stride;
   }
+  // (measurement, -DMPPO_EXPERIMENTS: MPPO_DEFER_CRITIC=1 takes the critic off the rollout's launches - actor-only rollout forwards, one critic launch before GAE)
+  static const char* defer_env = MPPO_EXPERIMENT_ENV("MPPO_DEFER_CRITIC");
+  const bool defer_critic = defer_env && defer_env[0] == '1' && fused_rollout_supported(c.net, e->obs, e->OP);
   for (int t = 0; t < e->T; ++t) {
     const float* obs_t = e->obs + (size_t)t * N * OP;
     MPPO_TRY(policy_forward(c.net, e->params, e->N, obs_t, e->OP, fb, e->noise + t * N * A, e->action + t * N * A, e->log_prob + t * N,
-                            e->value + (size_t)t * N, nullptr, s));                                                   // train.py:157-160
+                            defer_critic ? nullptr : e->value + (size_t)t * N, nullptr, s));                          // train.py:157-160
     MPPO_TRY(env_step_ws(e->model, e->N, c.n_frames, &c.reward, e->state, e->reset_rec, e->action + t * N * A, e->A, e->obs + (size_t)(t + 1) * N * OP,
                          e->OP, e->reward + t * N, e->done + t * N, &e->met, e->env_ws, e->env_ws_bytes, static_cast<hipStream_t>(s)));                                  // :165
   }
-  MPPO_TRY(policy_forward(c.net, e->params, e->N, e->obs + (size_t)e->T * N * OP, e->OP, fb, nullptr, nullptr, nullptr, e->last_val, nullptr, s));  // train.py:182
+  if (defer_critic)  // value[t] of all T steps and the bootstrap value in ONE critic launch over the [T + 1][N] observation rows (nothing before GAE reads them)
+    MPPO_TRY(policy_forward(c.net, e->params, (e->T + 1) * e->N, e->obs, e->OP, fb, nullptr, nullptr, nullptr, e->value, nullptr, s));
+  else
+    MPPO_TRY(policy_forward(c.net, e->params, e->N, e->obs + (size_t)e->T * N * OP, e->OP, fb, nullptr, nullptr, nullptr, e->last_val, nullptr, s));  // train.py:182
   MPPO_TRY(gae_launch(e->T, e->N, c.gamma, c.gae_lambda, e->reward, e->value, e->done, e->last_val, e->adv, e->target, s));
   hipLaunchKernelGGL(rollout_stats_kernel, dim3(1), dim3(kStatsThreads), 0, s, e->T, e->N, e->reward, e->done, e->stat_ret_in, e->stat_len_in, e->stats);
   MPPO_CHECK_LAUNCH("rollout_stats_kernel");

@@ -1057,7 +1057,7 @@ int32_t fused_gather_rows(const mppo_net_t& net, const mppo_batch_t& batch, cons
 }
 
 // Rollout policy step on n rows in ONE launch: both hidden layers, the heads, sample + log-prob, value (train.py:157-160);
-// noise == nullptr: critic only (bootstrap value, train.py:182).  Replaces two layer GEMM launches + the head kernel.
+// noise == nullptr: critic only (bootstrap value, train.py:182); value == nullptr: actor only.  Replaces two layer GEMM launches + the head kernel.
 int32_t fused_policy_forward(const mppo_net_t& net, const float* params, int n, const float* obs, int obs_ld, const float* noise, float* action, float* log_prob,
                              float* value, float* mean_out, int AP, hipStream_t stream, const unsigned short* frag, size_t frag_net_stride) {
   FusedArgs a{};
@@ -1074,7 +1074,7 @@ int32_t fused_policy_forward(const mppo_net_t& net, const float* params, int n, 
     MPPO_TRY(fused_set_smem(smem));
     attr_for = smem;
   }
-  const dim3 grid(cdiv(n, FRT), noise ? 2 : 1);
+  const dim3 grid(cdiv(n, FRT), noise && value ? 2 : 1);  // (noise without value: the actor alone)
   const dim3 block(2 * net.H);
   if (net.A > 16) {
     if (use_frag) hipLaunchKernelGGL((fused_mlp_kernel<true, true, 2, true>), grid, block, smem, stream, a);
