@@ -54,6 +54,9 @@ __device__ __forceinline__ void gstore(float* p, float v) {
 // workgroup per CU - right when the launch has no more tiles than the chip has CUs (the headline shape: exactly 256).  2: 64 registers
 // of operands in flight, <= 128 registers in all, TWO workgroups per CU hide each other's latency - for launches with more tiles than
 // CUs (BASELINE configs[4]: 352 tiles were two rounds of one workgroup per CU).  Same products, same order: bit-identical results.
+#ifdef MPPO_EXPERIMENTS
+__device__ unsigned g_wgrad_barrier[2];  // arrivals, generation (MPPO_WGRAD_BARRIER; zero-initialised with the code object)
+#endif
 template <bool BF16, bool PEER = false, int RING = 5>
 __global__ void __launch_bounds__(WTHREADS, RING <= 2 ? 4 : 2) wgrad_kernel(WgradArgs a, PeerStep ps) {
   __shared__ float red[WWAVES][WTILE * (WTILE + 1)];
@@ -314,6 +317,26 @@ __global__ void __launch_bounds__(WTHREADS, RING <= 2 ? 4 : 2) wgrad_kernel(Wgra
     a.sq_partial[blockIdx.x] = s;
   }
   if (PEER) peer_publish_done(ps.v, ps.epoch[0] + ps.step + 1, desc >> 24, a.slice_need);  // every store of the gradient is above this line
+#ifdef MPPO_EXPERIMENTS
+  // measurement (MPPO_WGRAD_BARRIER=1): what a device-wide barrier costs at the END of this launch - where clip + Adam would continue if the two
+  // launches were one (every workgroup of the launch is resident: one per CU).  Arrive on one counter, the last one opens the next generation.
+  if (!PEER && ps.mode == -12345) {
+    __syncthreads();
+    if (t == 0) {
+      __threadfence();
+      const unsigned gen = __hip_atomic_load(&g_wgrad_barrier[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (__hip_atomic_fetch_add(&g_wgrad_barrier[0], 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1) {
+        __hip_atomic_store(&g_wgrad_barrier[0], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_fetch_add(&g_wgrad_barrier[1], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+      } else {
+        while (__hip_atomic_load(&g_wgrad_barrier[1], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) == gen) __builtin_amdgcn_s_sleep(1);
+      }
+    }
+    __syncthreads();
+    // (what would follow: every workgroup re-adds the partial sums of squares - one load of 512 floats - and updates its tile)
+    if (t < 64 && a.sq_partial) { float s = 0.f; for (int e = t; e < kSqSlots; e += 64) s += __hip_atomic_load(&a.sq_partial[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); if (s == -1.f) a.grad[0] = s; }
+  }
+#endif
 }
 
 bool wgrad_supported(const WgradArgs& a) {
@@ -451,8 +474,10 @@ int32_t wgrad_launch(const WgradArgs& a_in, bool bf16, hipStream_t stream, const
     MPPO_CHECK_LAUNCH("wgrad_kernel<peer>");
     return MPPO_OK;
   }
-  const PeerStep nops{};
+  PeerStep nops{};
 #ifdef MPPO_EXPERIMENTS
+  static const int bar_on = [] { const char* e = getenv("MPPO_WGRAD_BARRIER"); return e && e[0] == '1' ? 1 : 0; }();
+  if (bar_on) nops.mode = -12345;  // (the switch rides in a field the launch without a peer exchange does not read)
   static const int dbg = [] { const char* e = getenv("MPPO_WGRAD_DBG"); return e ? atoi(e) : 0; }();
 #else
   constexpr int dbg = 0;
