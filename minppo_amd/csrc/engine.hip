@@ -201,6 +201,7 @@ static int32_t validate_cfg(const mppo_model* m, const mppo_engine_cfg_t* c) {
   MPPO_REQUIRE(c->world_size >= 1 && c->rank >= 0 && c->rank < c->world_size, "engine: bad rank %d / world %d", c->rank, c->world_size);
   const long B = (long)c->num_envs * c->num_steps;
   // the reference raises ValueError here (train.py:253-255)
+  MPPO_REQUIRE(B <= permutation_max_samples(), "engine: %ld samples per rank and update (num_envs x num_steps); the minibatch permutations take at most %d", B, permutation_max_samples());
   MPPO_REQUIRE(B % c->num_minibatches == 0, "`batch_size` must be equal to `num_steps * num_envs` (num_envs*num_steps = %ld is not divisible by num_minibatches = %d)", B,
                c->num_minibatches);
   MPPO_REQUIRE(c->net.O == mv.obs_dim && c->net.OP == mv.obs_pad, "engine: net O/OP (%d/%d) do not match the model's observation (%d/%d)", c->net.O, c->net.OP,

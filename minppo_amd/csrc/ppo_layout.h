@@ -218,6 +218,7 @@ int32_t permutation_ctr(unsigned long long seed, unsigned long long stream_id, c
 // E permutations (streams stream_id0 .. stream_id0 + E - 1) into idx[E][B] with one sort; same results as E calls of permutation_ctr
 int32_t perm_fill_keys_batch(unsigned long long seed, unsigned long long stream_id0, const int* ctr, int B, int E, unsigned long long* keys, int* vals, hipStream_t stream);
 size_t permutation_batch_ws_bytes(int B, int E);
+int permutation_max_samples();  // the largest batch (samples per rank) the engine's two-launch sort takes
 int32_t permutation_batch_prepare(int B, int E, void* ws, size_t ws_bytes, hipStream_t stream);  // zeroes the two-launch form's counters
 void permutation_batch_counters(int B, int E, void* ws, size_t ws_bytes, int** ptr, int* n);  // the words the caller zeroes after every use (nullptr / 0: none)
 int32_t permutation_batch_ctr(unsigned long long seed, unsigned long long stream_id0, const int* ctr, int B, int E, int* idx, void* ws, size_t ws_bytes, hipStream_t stream);

@@ -74,57 +74,7 @@ hipError_t hipIpcOpenMemHandle(void** p, hipIpcMemHandle_t h, unsigned) {
 }
 hipError_t hipIpcCloseMemHandle(void* p) { return hipFree(p); }
 
-extern "C" size_t mppo_permutation_ws_bytes(int32_t B) { return B < 1 ? 0 : 2 * (size_t)B * 4; }
-
 namespace mppo {
-int32_t permutation_ctr(unsigned long long seed, unsigned long long stream_id, const int* ctr, int B, int* idx, void* ws, size_t ws_bytes, hipStream_t stream) {
-  MPPO_REQUIRE(B >= 1 && idx && ws, "mppo_permutation: bad argument");
-  if (ws_bytes < mppo_permutation_ws_bytes(B)) return fail(MPPO_ENOMEM, "mppo_permutation: workspace too small");
-  unsigned* keys = static_cast<unsigned*>(ws);
-  int* vals = reinterpret_cast<int*>(keys + B);
-  MPPO_TRY(perm_fill_keys(seed, stream_id, ctr, B, keys, vals, stream));
-  std::vector<int> order(B);
-  std::iota(order.begin(), order.end(), 0);
-  std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return keys[a] < keys[b]; });
-  for (int i = 0; i < B; ++i) idx[i] = vals[order[i]];
-  return MPPO_OK;
-}
-
-size_t permutation_batch_ws_bytes(int B, int E) { return (B < 1 || E < 1) ? 0 : (size_t)B * E * 12; }
-int32_t permutation_batch_prepare(int, int, void*, size_t, hipStream_t) { return MPPO_OK; }
-void permutation_batch_counters(int, int, void*, size_t, int** ptr, int* n) { *ptr = nullptr; *n = 0; }
-int32_t permutation_batch_ctr(unsigned long long seed, unsigned long long stream_id0, const int* ctr, int B, int E, int* idx, void* ws, size_t ws_bytes,
-                              hipStream_t stream) {
-  MPPO_REQUIRE(B >= 1 && E >= 1 && idx && ws, "permutation_batch: bad argument");
-  if (ws_bytes < permutation_batch_ws_bytes(B, E)) return fail(MPPO_ENOMEM, "permutation_batch: workspace too small");
-  const size_t n = (size_t)B * E;
-  unsigned long long* keys = static_cast<unsigned long long*>(ws);
-  int* vals = reinterpret_cast<int*>(keys + n);
-  MPPO_TRY(perm_fill_keys_batch(seed, stream_id0, ctr, B, E, keys, vals, stream));
-  std::vector<size_t> order(n);
-  std::iota(order.begin(), order.end(), (size_t)0);
-  std::stable_sort(order.begin(), order.end(), [&](size_t a, size_t b) { return keys[a] < keys[b]; });
-  for (size_t i = 0; i < n; ++i) idx[i] = vals[order[i]];
-  return MPPO_OK;
-}
-
-int32_t threefry_permutation(const unsigned* sort_keys, int rounds, int B, int* idx, void* ws, size_t ws_bytes, hipStream_t stream) {
-  MPPO_REQUIRE(B >= 1 && idx && ws && sort_keys && rounds >= 1, "threefry_permutation: bad argument");
-  if (ws_bytes < mppo_permutation_ws_bytes(B)) return fail(MPPO_ENOMEM, "threefry_permutation: workspace too small");
-  unsigned* keys = static_cast<unsigned*>(ws);
-  std::vector<int> cur(B), order(B), next(B);
-  std::iota(cur.begin(), cur.end(), 0);
-  for (int r = 0; r < rounds; ++r) {
-    MPPO_TRY(threefry_bits(sort_keys + 2 * r, (size_t)B, keys, nullptr, stream));
-    std::iota(order.begin(), order.end(), 0);
-    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return keys[a] < keys[b]; });
-    for (int i = 0; i < B; ++i) next[i] = cur[order[i]];
-    cur.swap(next);
-  }
-  for (int i = 0; i < B; ++i) idx[i] = cur[i];
-  return MPPO_OK;
-}
-
 // RCCL's place is taken by an all-reduce through POSIX shared memory between the rank PROCESSES of a CPU test
 // (tests/test_distributed.py): same call sites in engine.hip, same semantics (in-place sum, every rank gets the
 // identical result: slots are added in rank order).  The 128-byte "unique id" carries the segment name.
@@ -239,10 +189,4 @@ int32_t graph_launch(GraphExec*, hipStream_t) { return fail(MPPO_EHIP, "hipGraph
 void graph_destroy(GraphExec*) {}
 }  // namespace mppo
 
-extern "C" int32_t mppo_threefry_permutation(const uint32_t* sort_keys, int32_t rounds, int32_t B, int32_t* idx, void* ws, size_t ws_bytes, void* stream) {
-  return mppo::threefry_permutation(sort_keys, rounds, B, idx, ws, ws_bytes, static_cast<hipStream_t>(stream));
-}
 
-extern "C" int32_t mppo_permutation(uint64_t seed, uint64_t stream_id, int32_t B, int32_t* idx, void* ws, size_t ws_bytes, void* stream) {
-  return mppo::permutation_ctr(seed, stream_id, nullptr, B, idx, ws, ws_bytes, static_cast<hipStream_t>(stream));
-}

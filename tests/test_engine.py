@@ -10,6 +10,7 @@ from minppo_amd import _native as nat
 from minppo_amd.config import make_config
 from oracle import ppo_oracle as po
 from oracle.env_oracle import EnvOracle, RewardCfg, default_hp
+from test_kernels_ppo import _host_permutation
 
 BASE = {"kscale_id": "5eb3cb7f23232298", "visualization": {"camera_name": "track"}}
 
@@ -547,6 +548,7 @@ def test_two_launch_permutations_equal_the_sort_at_odd_sizes(envs, steps, miniba
             for e in range(E):
                 be.lib.permutation(tr.seed, (0x5045524D << 24) + e, B, be.ptr(one), be.ptr(pws), wsb, be.stream)
                 np.testing.assert_array_equal(perm[e], be.host(one), err_msg=f"epoch {e}")
+                np.testing.assert_array_equal(perm[e], _host_permutation(tr.seed, (0x5045524D << 24) + e, B), err_msg=f"epoch {e} against the host's stable argsort of the Philox keys")
         else:
             assert (perm != prev).mean() > 0.8
         prev = perm
@@ -587,11 +589,12 @@ def test_two_launch_permutations_survive_a_rewound_update_index():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("config,envs", [("stompy_pro", 4096), ("stompy_full", 8192)])
+@pytest.mark.parametrize("config,envs", [("stompy_pro", 4096), ("stompy_full", 8192), ("stompy_pro", 32768)])
 def test_two_launch_permutations_equal_the_sort_at_full_size(config, envs):
     """The engine's permutations at BASELINE sizes (configs[1]: B = 40 960 samples, configs[4]: B = 81 920 - more than 16 index bits; E = 4 epochs): two launches - scatter of (key, index) values into 256
-    buckets, one LDS bitonic sort per bucket (csrc/k_perm.hip) - instead of one key launch + nine rocPRIM launches.  The first update's
-    permutations equal `mppo_permutation` (rocPRIM's stable sort of the same Philox keys) epoch by epoch, bit for bit; the following
+    buckets, one LDS sort per bucket (csrc/k_perm.hip).  Round 6: also 32 768 environments on ONE rank (B = 327 680: 1 024 buckets - configs[2]'s
+    global batch without the sharding).  The first update's permutations equal `mppo_permutation` (the same two launches for one stream) and the
+    host's stable argsort of the same Philox keys (tests/test_kernels_ppo.py _host_permutation) epoch by epoch, bit for bit; the following
     updates (the double-buffered bucket counters of both parities, replayed from the hipGraph) stay bijective and differ from update to update."""
     from backends import get_backend
 
@@ -617,6 +620,7 @@ def test_two_launch_permutations_equal_the_sort_at_full_size(config, envs):
             for e in range(E):
                 be.lib.permutation(tr.seed, (0x5045524D << 24) + e, B, be.ptr(one), be.ptr(pws), wsb, be.stream)
                 np.testing.assert_array_equal(perm[e], be.host(one), err_msg=f"epoch {e}")
+                np.testing.assert_array_equal(perm[e], _host_permutation(tr.seed, (0x5045524D << 24) + e, B), err_msg=f"epoch {e} against the host's stable argsort of the Philox keys")
     assert tr.graph_active()
     for u in range(1, 4):
         assert (seen[u] != seen[u - 1]).mean() > 0.99

@@ -338,6 +338,45 @@ def test_clip_adam_and_schedule(be):
     assert (be.host(p)[2:] == 0).all()
 
 
+def _philox4x32(c0, c1, c2, c3, k0, k1):
+    """Philox4x32-10 (Salmon et al., SC'11) on NumPy arrays: the host restatement the engine's permutation keys are checked against
+    (the device code is csrc/philox.h; pinned by the golden prefix below and by the Random123 known answers in tests/test_jaxrng.py's sibling
+    generator)."""
+    c0, c1, c2, c3 = (np.asarray(x, np.uint64) for x in (c0, c1, c2, c3))
+    k0, k1 = np.uint64(k0), np.uint64(k1)
+    M32 = np.uint64(0xFFFFFFFF)
+    for _ in range(10):
+        p0, p1 = np.uint64(0xD2511F53) * c0, np.uint64(0xCD9E8D57) * c2
+        n0, n1, n2, n3 = (p1 >> np.uint64(32)) ^ c1 ^ k0, p1 & M32, (p0 >> np.uint64(32)) ^ c3 ^ k1, p0 & M32
+        c0, c1, c2, c3 = n0, n1, n2, n3
+        k0, k1 = (k0 + np.uint64(0x9E3779B9)) & M32, (k1 + np.uint64(0xBB67AE85)) & M32
+    return c0, c1, c2, c3
+
+
+def _host_permutation(seed, stream_id, B, ctr=0):
+    """What mppo_permutation must return: positions 0 .. B-1 in the stable order of their Philox keys (key i = word i & 3 of block i >> 2)."""
+    q = np.arange((B + 3) // 4, dtype=np.uint64)
+    z = np.stack(_philox4x32(q, np.full_like(q, ctr), np.full_like(q, stream_id & 0xFFFFFFFF), np.full_like(q, ((stream_id >> 32) ^ 0x5045524D) & 0xFFFFFFFF),
+                             seed & 0xFFFFFFFF, seed >> 32), 1).reshape(-1)[:B]
+    return np.argsort(z, kind="stable").astype(np.int32)
+
+
+@pytest.mark.parametrize("B", [1, 18, 777, 4096, 40960, 131072, 131073, 327680, 2097152])
+def test_permutation_is_the_stable_order_of_the_philox_keys(be, B):
+    """Round 6: every permutation path sorts with the engine's own two launches (csrc/k_perm.hip: scatter into buckets by the key's top
+    bits, one LDS sort per bucket) - no library sort.  mppo_permutation against a NumPy restatement: Philox keys, stable argsort.  Sizes: a
+    single sample; most buckets empty; a partial scatter workgroup; BASELINE configs[1]'s batch; the largest batch of 256 buckets (512 per
+    bucket: the LDS bitonic sort) and the first of 512 buckets; 32 768 environments x 10 steps on one rank (1 024 buckets); the largest batch the sort takes (4 096 buckets of 512)."""
+    if be.name == "emu" and B > 50000:
+        pytest.skip("the larger batches run on the GPU (one fiber per work-item on the emulator)")
+    idx = be.zeros((B,), np.int32)
+    wsb = be.lib.permutation_ws_bytes(B)
+    ws = be.zeros((wsb // 4 + 4,), np.int32)
+    for seed, stream in ((1337, 3), (0x123456789, (0x5045524D << 24) + 2)):
+        be.lib.permutation(seed, stream, B, be.ptr(idx), be.ptr(ws), wsb, be.stream)
+        np.testing.assert_array_equal(be.host(idx), _host_permutation(seed, stream, B), err_msg=f"seed {seed} stream {stream}")
+
+
 def test_philox_normal_and_permutation(be):
     n = 100003
     z = be.zeros((n,))
