@@ -545,12 +545,18 @@ def main() -> None:
         cfg = load_config_from_cli([args.config, f"training.num_envs={args.envs_per_gpu}", *args.set])
         tr = Trainer(cfg, device=f"cuda:{local_rank}", rank=0, world_size=1, seed=1337 + rank, use_graph=not args.no_graph)
         transport = "independent replicas (no exchange)"
-    else:
+    t_link = None
+    if not indep:
         cfg = load_config_from_cli([args.config, f"training.num_envs={n_global}", *args.set])
         tr = Trainer(cfg, device=f"cuda:{local_rank}", rank=rank, world_size=world, use_graph=not args.no_graph)
         transport = tr.init_comm()  # "peer" (default; csrc/peer.h) or "rccl" ($MPPO_ALLREDUCE), "none" for one rank
         if world > 1 and rank == 0:
             sys.stderr.write(f"bench.py: gradient transport: {transport}" + (f" ({tr.peer_form()})" if transport == "peer" else "") + f" - {tr.comm_note}\n")
+        # the measured one-way latency of a system-scope flag between rank 0 and every peer (collective; about 1 ms per peer): the t_link of the
+        # efficiency model in DESIGN.md 7.2, for the first run on distinct GPUs to put a number where the model has an assumption
+        t_link = tr.peer_latencies() if transport == "peer" else None
+        if t_link is not None and rank == 0:
+            sys.stderr.write("bench.py: one-way flag latency rank 0 <-> rank 1.." + str(world - 1) + " [us]: " + ", ".join(f"{x:.2f}" for x in t_link) + "\n")
     tr.reset()
     # A fresh process stalls ONCE for 70-90 ms some 30-40 ms after its first GPU work (measured per update by
     # tools/ramp_probe.py, graph replay and eager launches alike: profiles/r02_g_ramp.txt); with W = 3 warm-up updates
@@ -707,6 +713,7 @@ def main() -> None:
                                                                            ("peer-to-peer exchange over hipIpc-mapped buffers fused into the weight-gradient and Adam launches (csrc/peer.h)" if transport == "peer"
                                                                             else "RCCL all-reduce") + (", all ranks on ONE GPU" if share else "")) if world > 1 else "single GPU",
                        "allreduce": transport + (f" ({tr.peer_form()})" if transport == "peer" else ""), "replicas_identical": replicas_identical,
+                       "t_link_us": t_link,  # one-way latency of a system-scope flag, rank 0 <-> rank q (device-timed ping-pong through the exchange buffers; null: no peer exchange)
                        "hipgraph": bool(tr.graph_active()),
                        "pre_warm": f"{pre_warm_s:.1f} s of unrelated device work before the {args.warmup} warm-up steps (one-time start-up stall of the device, see bench.py)"},
             "roofline": roofline,

@@ -354,6 +354,11 @@ int32_t mppo_engine_peer_connect(mppo_engine_t* e, const void* handles, int32_t 
 int32_t mppo_engine_comm_mode(const mppo_engine_t* e, int32_t* out);
 int32_t mppo_engine_peer_status(const mppo_engine_t* e, int32_t* timed_out, int32_t* info8);
 int32_t mppo_engine_peer_selftest(mppo_engine_t* e, void* stream, int32_t* ok);
+/* One-way latency, in microseconds, of a system-scope flag between this rank and `other_rank`: `iters` round trips of one word through the two
+ * ranks' exchange buffers, timed on the device (100 MHz clock) - what one dependent trip of the fused exchange costs on this machine (on one GPU
+ * about 0.65 us; over an xGMI hop: the t_link of DESIGN.md 7.2).  BOTH ranks call it at the same time, one with initiator = 1; synchronises.
+ * `bench.py --gpus N` reports it per peer of rank 0 (config.t_link_us). */
+int32_t mppo_engine_peer_latency(mppo_engine_t* e, int32_t other_rank, int32_t iters, int32_t initiator, void* stream, double* one_way_us);
 int32_t mppo_engine_peer_disable(mppo_engine_t* e);
 /* env reset (train.py:142-144) */
 int32_t mppo_engine_reset(mppo_engine_t* e, void* stream);

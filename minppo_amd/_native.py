@@ -138,6 +138,7 @@ SIGNATURES = {
     "mppo_engine_comm_mode": (c_i32, [c_vp, P(c_i32)]),
     "mppo_engine_peer_status": (c_i32, [c_vp, P(c_i32), P(c_i32)]),
     "mppo_engine_peer_selftest": (c_i32, [c_vp, c_vp, P(c_i32)]),
+    "mppo_engine_peer_latency": (c_i32, [c_vp, c_i32, c_i32, c_i32, c_vp, P(C.c_double)]),
     "mppo_engine_peer_disable": (c_i32, [c_vp]),
     "mppo_engine_reset": (c_i32, [c_vp, c_vp]),
     "mppo_engine_update": (c_i32, [c_vp, c_vp]),

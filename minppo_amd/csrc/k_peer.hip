@@ -23,6 +23,7 @@ struct PeerComm {
   bool connected;
   int mode;  // PeerStep::mode
   PeerView view;
+  int probe_count[kPeerMaxRanks] = {};  // flags exchanged with rank q by the latency probe so far (peer_latency)
 };
 
 // Exchange buffers created in this process, by exported handle: hipIpcOpenMemHandle refuses a handle of the opening process, so several
@@ -217,6 +218,38 @@ int32_t peer_allreduce_f64(const PeerComm* c, double* buf, size_t n, hipStream_t
 int32_t peer_advance(const PeerComm* c, int steps, hipStream_t s) {
   hipLaunchKernelGGL(peer_advance_kernel, dim3(1), dim3(64), 0, s, c->view, steps);
   MPPO_CHECK_LAUNCH("peer_advance_kernel");
+  return MPPO_OK;
+}
+
+// latency probe: `iters` round trips of one flag between two ranks (the initiator stores first); one lane per rank, bounded waits
+__global__ void peer_probe_kernel(PeerView v, int other, int iters, int initiator, int base, unsigned long long* ticks_out) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  PeerHdr* me = peer_hdr(v, v.rank);
+  PeerHdr* peer = peer_hdr(v, other);
+  // base: the flags this pair has exchanged before (counted on the host by both sides: every probe is symmetric) - NOT read from the flag
+  // word, which the other side may have advanced already
+  const unsigned long long t0 = realtime_ticks();
+  for (int i = 1; i <= iters; ++i) {
+    if (initiator) sys_store_i32(&peer->probe[v.rank], base + i);
+    peer_wait(&me->probe[other], base + i, me, v.limit_ticks, 4, other);
+    if (!initiator) sys_store_i32(&peer->probe[v.rank], base + i);
+  }
+  *ticks_out = realtime_ticks() - t0;
+}
+
+int32_t peer_latency(PeerComm* c, int other, int iters, int initiator, hipStream_t s, double* one_way_us) {
+  MPPO_REQUIRE(c && c->connected && one_way_us && other >= 0 && other < c->world && other != c->rank && iters >= 1, "peer_latency: bad argument");
+  unsigned long long* dev = nullptr;
+  MPPO_CHECK_HIP(hipMalloc(reinterpret_cast<void**>(&dev), sizeof(unsigned long long)));
+  hipLaunchKernelGGL(peer_probe_kernel, dim3(1), dim3(64), 0, s, c->view, other, iters, initiator, c->probe_count[other], dev);
+  c->probe_count[other] += iters;
+  hipError_t he = hipGetLastError();
+  if (he == hipSuccess) he = hipStreamSynchronize(s);
+  unsigned long long ticks = 0;
+  if (he == hipSuccess) he = hipMemcpy(&ticks, dev, sizeof(ticks), hipMemcpyDeviceToHost);
+  (void)hipFree(dev);
+  if (he != hipSuccess) return fail(MPPO_EHIP, "peer_latency: %s", hipGetErrorString(he));
+  *one_way_us = (double)ticks / 100.0 / (double)iters / 2.0;  // 100 MHz ticks, two one-way trips per iteration
   return MPPO_OK;
 }
 

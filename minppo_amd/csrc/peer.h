@@ -51,7 +51,8 @@ struct PeerHdr {
   int error;                        // != 0: a wait ran into its time limit (the run is invalid)
   int epoch[2];                     // optimizer steps / updates completed since creation (peer_advance_kernel)
   int error_info[4];                // the first wait that timed out: kind (1 wg_done, 2 red_done, 3 adv_done), index, epoch waited for, value seen
-  int pad[41];
+  int probe[kPeerMaxRanks];         // [q]: the count of the latency probe's flags rank q has stored here (peer_latency: a ping-pong of one word between two ranks)
+  int pad[33];
 };
 static_assert(sizeof(PeerHdr) % 256 == 0, "the regions behind the header stay 256-byte aligned");
 
@@ -255,6 +256,9 @@ int32_t peer_publish(const PeerComm* c, const float* grad, size_t P, int step, h
 int32_t peer_allreduce_f64(const PeerComm* c, double* buf, size_t n, hipStream_t s);            // in-place sum over the ranks, once per update
 int32_t peer_advance(const PeerComm* c, int steps, hipStream_t s);                              // end of an update
 int32_t peer_status(const PeerComm* c, int32_t* timed_out, int32_t* info8);
+// one-way latency of a system-scope flag between this rank and `other` (both ranks call it at the same time, one as initiator): `iters` round
+// trips of one word through the two exchange buffers' headers, timed by the initiator's kernel on the 100 MHz clock; synchronises
+int32_t peer_latency(PeerComm* c, int other, int iters, int initiator, hipStream_t s, double* one_way_us);
 unsigned long long peer_set_limit_ms(PeerComm* c, double ms);  // time limit of a wait; returns the previous one in the same unit (ms <= 0: leave it, just return it)                      // synchronises the device; info8 (optional): what timed out + counters
 
 }  // namespace mppo

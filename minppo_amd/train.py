@@ -28,7 +28,7 @@ import pickle
 from pathlib import Path
 import sys
 import time
-from typing import Any, Callable, Dict, NamedTuple, Optional, Sequence
+from typing import Any, Callable, Dict, List, NamedTuple, Optional, Sequence
 
 import numpy as np
 
@@ -437,9 +437,7 @@ class Trainer:
             dist.all_reduce(t, op=dist.ReduceOp.MIN)
             return bool(int(t.item()))
 
-        def device_ctx():
-            import contextlib
-            return self.torch.cuda.device(self.device) if self.xp == "torch" else contextlib.nullcontext()
+        device_ctx = self._device_guard
 
         if mode == "peer":
             handle, err = np.zeros(64, np.uint8), None
@@ -475,7 +473,8 @@ class Trainer:
                     except nat.NativeError as exc:
                         err = exc
                     if all_ok(err is None and ok.value == 1):
-                        self.comm_note = "hipIpc buffers mapped on every rank, connect-time self-test exact on every rank"
+                        self.comm_note = ("hipIpc buffers mapped on every rank, connect-time self-test exact on every rank (one fully checked exchange + "
+                                          f"{os.environ.get('MPPO_PEER_SOAK', '2000')} more, every element compared on the device)")
                         return "peer"
                     err = err or "the self-test all-reduce timed out or returned a wrong sum"
                 with device_ctx():
@@ -494,6 +493,10 @@ class Trainer:
         with device_ctx():  # (emulator build: the "communicator" is a shared-memory segment between the rank processes, tests/emu)
             self.lib.engine_comm_init(self._engine, host.ctypes.data)
         return "rccl"
+
+    def _device_guard(self):
+        import contextlib
+        return self.torch.cuda.device(self.device) if self.xp == "torch" else contextlib.nullcontext()
 
     def _device_identity(self) -> str:
         if self.xp != "torch":
@@ -515,6 +518,50 @@ class Trainer:
         out = C.c_int32(0)
         self.lib.engine_comm_mode(self._engine, C.byref(out))
         return {2: "fused", 3: "split", 4: "shared"}.get(out.value, "")
+
+    def peer_latencies(self, iters: int = 2000) -> Optional[List[float]]:
+        """COLLECTIVE (peer transport, every rank): the one-way latency in microseconds of a system-scope flag between rank 0 and every other
+        rank - `iters` round trips of one word through the two ranks' exchange buffers, timed on the device (mppo_engine_peer_latency).  What
+        ONE dependent trip of the fused exchange costs on this machine: the `t_link` of the efficiency model, measured.
+        Returns the list on every rank (entry q - 1 = rank 0 <-> rank q), None without a connected exchange."""
+        if self.world_size < 2 or self.comm_mode() != "peer" or not self._dist_ready():
+            return None
+        import torch
+        import torch.distributed as dist
+
+        out = []
+        for q in range(1, self.world_size):
+            us = C.c_double(0.0)
+            if self.rank in (0, q):
+                with self._device_guard():
+                    self.lib.engine_peer_latency(self._engine, q if self.rank == 0 else 0, int(iters), int(self.rank == 0), self._stream_ptr, C.byref(us))
+            t = torch.tensor([us.value if self.rank == 0 else 0.0], dtype=torch.float64)
+            if dist.get_backend() == "nccl":
+                t = t.to(self.device)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)  # (also the barrier between the pairs)
+            out.append(float(t[0].item()))
+        return out
+
+    def check_replicas(self) -> None:
+        """COLLECTIVE (every rank): the replicas of a data-parallel run must hold bit-identical parameters after the same updates - a slice of
+        the gradient is reduced once, by its owner, and broadcast.  Compares a checksum of the parameter bits over the ranks and raises on
+        every rank if they differ (a torn or reordered store in the exchange that the tags did not catch would show here, within
+        `checkpoint_every` updates, and not only at the end of the run)."""
+        if self.world_size < 2 or not self._dist_ready():
+            return
+        import torch
+        import torch.distributed as dist
+
+        bits = self.params_flat().view(np.uint32).astype(np.uint64)
+        chk = torch.tensor([int(bits.sum() % (1 << 62)), int((bits * (np.arange(bits.size, dtype=np.uint64) % 65521 + 1)).sum() % (1 << 62))], dtype=torch.int64)
+        if dist.get_backend() == "nccl":
+            chk = chk.to(self.device)
+        lo, hi = chk.clone(), chk.clone()
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        if not bool((lo == hi).all().item()):
+            raise RuntimeError(f"rank {self.rank}: the ranks' parameter replicas differ (checksums {lo.tolist()} .. {hi.tolist()}): the gradient exchange delivered "
+                               "different bytes to different ranks - this run's results are invalid")
 
     def check_peers(self, collective: bool = True) -> None:
         """Synchronises the device and raises if a wait for a peer rank ran into its time limit (MPPO_PEER_TIMEOUT_MS): the kernels
@@ -820,6 +867,8 @@ def make_train(config: Config, **trainer_kwargs: Any) -> Callable[[Any], TrainOu
             if ckpt and tc.checkpoint_every > 0 and (u + 1) % tc.checkpoint_every == 0 and u + 1 < n:
                 if peers:
                     tr.check_peers()  # collective: never checkpoint parameters that ANY rank updated with a timed-out exchange
+                if tr.world_size > 1:
+                    tr.check_replicas()  # collective: the replicas hold the same bits (a corrupted exchange shows here, not only at the end of the run)
                 tr.check_status()
                 tr.save_checkpoint(ckpt)
                 tr.barrier()  # the ranks' files take different times to write: nobody starts the next exchange seconds ahead of a peer
@@ -836,6 +885,8 @@ def make_train(config: Config, **trainer_kwargs: Any) -> Callable[[Any], TrainOu
                             st["done_fraction"], st["mean_episode_return"], st["mean_episode_length"], lo[0], sps)
         if peers:
             tr.check_peers()
+        if tr.world_size > 1:
+            tr.check_replicas()
         tr.check_status()
         if ckpt:
             tr.save_checkpoint(ckpt)

@@ -67,6 +67,12 @@ def run_rank(rank, world, port, overrides, updates, out_path):
         assert got == want == tr.comm_mode(), (got, want, tr.comm_mode())
         want_form = os.environ.get("MPPO_TEST_PEER_FORM")
         assert not want_form or tr.peer_form() == want_form, (tr.peer_form(), want_form)
+        if os.environ.get("MPPO_TEST_LATENCY") == "1":  # the flag ping-pong between rank 0 and every peer (collective)
+            lat = tr.peer_latencies(iters=40)
+            assert (lat is None) == (got != "peer"), (lat, got)
+            if lat is not None:
+                assert len(lat) == world - 1 and all(0.0 < x < 1e6 for x in lat), lat
+                np.save(out_path + ".latency.npy", np.asarray(lat))
     tr.reset()
     N, Nl, T, A, E, M = cfg.training.num_envs, tr.N, tr.T, tr.A, tr.E, tr.M
 
@@ -88,6 +94,18 @@ def run_rank(rank, world, port, overrides, updates, out_path):
             else:
                 tr.learn()  # mppo_engine_learn: csrc/engine.hip do_learn, peer-to-peer or communicator branch
     tr.check_peers()
+    tr.check_replicas()  # (collective) bit-identical replicas
+    if os.environ.get("MPPO_TEST_REPLICA_MISMATCH") == "1":  # one rank's parameters disturbed by one ulp-sized step: EVERY rank must hear about it
+        if rank == world - 1:
+            p = be.host(tr.region("params")).copy()
+            p[7] = np.nextafter(p[7], np.float32(1e9))
+            be.put(tr.region("params"), p)
+        try:
+            tr.check_replicas()
+            raised = False
+        except RuntimeError as exc:
+            raised = "replicas differ" in str(exc)
+        assert raised, f"rank {rank}: check_replicas did not raise"
     _save(tr, be, out_path, T, Nl)
     dist.barrier()  # nobody unmaps an exchange buffer a peer might still read
     tr.close()

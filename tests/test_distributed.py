@@ -275,6 +275,20 @@ def test_eight_ranks_on_one_gpu(tmp_path, shape):
     tr.close()
 
 
+def test_replica_check_and_flag_latency(tmp_path):
+    """Round 6, first contact with a multi-GPU node hardened further: (1) the connect-time self-test is a soak (one fully checked exchange,
+    then MPPO_PEER_SOAK more with every element compared on the device: 6 on the emulator, 2 000 on hardware); (2) `Trainer.peer_latencies`
+    - the device-timed ping-pong of one flag between rank 0 and every peer that `bench.py --gpus N` reports as config.t_link_us - returns
+    one positive figure per peer; (3) `Trainer.check_replicas` (called by make_train before every checkpoint and at the end) passes on
+    bit-identical replicas and raises on EVERY rank when one rank's parameters differ by one ulp in one element."""
+    world, port = 3, _free_port()
+    env = dict(os.environ, MPPO_TEST_HOST_DRIVEN="0", MPPO_ALLREDUCE="peer", MPPO_TEST_LATENCY="1", MPPO_TEST_REPLICA_MISMATCH="1", MPPO_PEER_SOAK="5")
+    ovr = [o if not o.startswith("training.num_envs=") else "training.num_envs=12" for o in OVR]
+    _spawn(lambda r: [str(r), str(world), str(port), "2", str(tmp_path / f"r{r}.npz"), *ovr], world, env, 300)
+    lat = np.load(str(tmp_path / "r0.npz") + ".latency.npy")
+    assert lat.shape == (world - 1,) and (lat > 0).all()
+
+
 def test_make_train_with_two_ranks(tmp_path):
     """`make_train(config)(seed)` - the host loop a user runs (minppo_amd/train.py, reference train.py:92-291) - as two env-sharded ranks:
     the peer exchange is set up by `init_comm`, every second update a checkpoint is written behind the COLLECTIVE check of the exchange
