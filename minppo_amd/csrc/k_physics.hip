@@ -182,6 +182,7 @@ __device__ __forceinline__ Q4 axis_angle(V3 axis, float angle) {
 struct HullTabs {
   const int* face_adr; const int* fidx; const int* edge;
   const float* vert; const float* fnormal; const float* enormal;
+  const int* udadr; const float* udir;  // per hull: unit edge directions, parallel ones dropped (convex_convex)
 };
 // first index whose value equals the row's maximum (value `v` is this lane's best over its own indices, `i` its index; a lane without
 // candidates passes -inf)
@@ -306,6 +307,196 @@ __device__ __forceinline__ void hull_pair_contacts(const HullTabs& T, int f0, in
   nrm[1] = nn;
   dist[0] = -(has_edge ? epen : fpen[0]);
   dist[1] = -(has_edge ? -1.f : fpen[1]);
+}
+// a value pinned in a vector register (an empty asm the optimiser cannot look through): a select between pinned values stays a select -
+// without it the compiler folds `q == 0 ? a[0] : q == 1 ? a[1] : ..` into a load from a[q], and an array indexed by a run-time value lives in scratch
+#ifdef MPPO_EMU
+#define MPPO_REG_PIN(x) do { } while (0)
+#else
+#define MPPO_REG_PIN(x) asm volatile("" : "+v"(x))
+#endif
+// ---- a box / mesh hull against a box / mesh hull of another body (round 6): the form of MJX collision_convex._box_box, for every hull pair.
+// Everything in the frame of hull B's body; (R, tr) take hull A's body frame into it.  The environment's 16 lanes stride over the
+// separating axes (A's face normals, B's face normals, the cross products of the hulls' edge directions), over the faces (reference /
+// incident face) and over the clipped candidate points (four per lane, in registers); winners come from DPP row reductions that keep
+// argmax / argmin's "first index among equals", a winner's coordinates from a row shuffle.  No LDS.
+struct RigidT { float R[9]; V3 t; };
+__device__ __forceinline__ V3 rt_rot(const RigidT& X, V3 v) { return {X.R[0] * v.x + X.R[1] * v.y + X.R[2] * v.z, X.R[3] * v.x + X.R[4] * v.y + X.R[5] * v.z, X.R[6] * v.x + X.R[7] * v.y + X.R[8] * v.z}; }
+__device__ __forceinline__ V3 rt_rot_t(const RigidT& X, V3 v) { return {X.R[0] * v.x + X.R[3] * v.y + X.R[6] * v.z, X.R[1] * v.x + X.R[4] * v.y + X.R[7] * v.z, X.R[2] * v.x + X.R[5] * v.y + X.R[8] * v.z}; }
+// vertex i of a face (its index list starts at a0) of hull A (transformed) or hull B
+struct FacePoly { int a0, m; bool of_a; };
+__device__ __forceinline__ V3 poly_vert(const HullTabs& T, const RigidT& X, const FacePoly& P, int i) {
+  const V3 v = ld3(T.vert + 3 * T.fidx[P.a0 + i]);
+  return P.of_a ? add3(rt_rot(X, v), X.t) : v;
+}
+// MJX _clip_edge_to_planes: the segment e0-e1 against the side planes of polygon P (plane k through vertex k - 1, normal (v_k - v_{k-1}) x n)
+template <class GetV>
+__device__ __forceinline__ bool clip_edge_to_poly(GetV getv, int m, V3 n, V3& e0, V3& e1) {
+  const V3 dir = sub3(e1, e0), rdir = sub3(e0, e1);
+  V3 n0 = e0, n1 = e1;
+  float d0 = 0.f, d1 = 0.f;
+  bool first = true, both = false;
+  V3 prev = getv(m - 1);
+  for (int i = 0; i < m; ++i) {
+    const V3 cur = getv(i);
+    const V3 en = cross3(sub3(cur, prev), n);
+    const bool in0 = dot3(sub3(e0, prev), en) > 1e-6f, in1 = dot3(sub3(e1, prev), en) > 1e-6f;
+    const float denom = dot3(dir, en);
+    const float tt = dot3(sub3(prev, e0), en) / (denom + (denom == 0.f ? 1e-6f : 0.f));
+    const V3 cand = add3(e0, mul3(dir, tt));
+    const V3 c0 = in0 ? cand : e0, c1 = in1 ? cand : e1;
+    const float x0 = dot3(sub3(c0, e0), dir), x1 = dot3(sub3(c1, e1), rdir);
+    if (first || x0 > d0) { d0 = x0; n0 = c0; }
+    if (first || x1 > d1) { d1 = x1; n1 = c1; }
+    first = false;
+    both = both || (in0 && in1);
+    prev = cur;
+  }
+  bool mask = !both;
+  if (!mask) { n0 = e0; n1 = e1; }
+  if (dot3(rdir, sub3(n0, n1)) < 0.f) mask = false;
+  e0 = n0; e1 = n1;
+  return mask;
+}
+// -> dist[4] (1: slot unused), pos[4] (B's frame, on the reference face), nrm (from A to B, B's frame); identical in every lane of the row
+__device__ __forceinline__ void hull_hull_contacts(const HullTabs& T, const RigidT& X, int fa0, int fa1, int fb0, int fb1, int va0, int va1, int vb0, int vb1,
+                                                   int ua0, int ua1, int ub0, int ub1, int g, float* dist, V3* pos, V3& nrm) {
+  const int nfa = fa1 - fa0, nfb = fb1 - fb0, nea = ua1 - ua0, neb = ub1 - ub0, nax = nfa + nfb + nea * neb;
+  auto axis_of = [&](int k, bool& degenerate) -> V3 {
+    degenerate = false;
+    if (k < nfa) return rt_rot(X, ld3(T.fnormal + 3 * (fa0 + k)));
+    if (k < nfa + nfb) return ld3(T.fnormal + 3 * (fb0 + k - nfa));
+    const int e = k - nfa - nfb, j = e / nea, i = e - j * nea;
+    const V3 cr = cross3(rt_rot(X, ld3(T.udir + 3 * (ua0 + i))), ld3(T.udir + 3 * (ub0 + j)));
+    degenerate = dot3(cr, cr) < 1e-6f;
+    float nn;
+    return normalize_norm(cr, nn);
+  };
+  // per axis: the smaller of the two overlaps of the hulls' projections, and which way it points
+  auto overlap = [&](V3 ax, bool degenerate, float& sign) -> float {
+    const V3 axa = rt_rot_t(X, ax);
+    const float off = dot3(X.t, ax);
+    float amax = -INFINITY, amin = INFINITY, bmax = -INFINITY, bmin = INFINITY;
+    for (int v = va0; v < va1; ++v) { const float p = dot3(ld3(T.vert + 3 * v), axa) + off; amax = fmaxf(amax, p); amin = fminf(amin, p); }
+    for (int v = vb0; v < vb1; ++v) { const float p = dot3(ld3(T.vert + 3 * v), ax); bmax = fmaxf(bmax, p); bmin = fminf(bmin, p); }
+    const float d1 = amax - bmin, d2 = bmax - amin;
+    sign = d1 > d2 ? -1.f : 1.f;
+    return degenerate ? 1e6f : fminf(d1, d2);
+  };
+  float best = INFINITY;
+  int bk = 0;
+  for (int k = g; k < nax; k += kGroupLanes) {
+    bool dg;
+    float sg_;
+    const V3 ax = axis_of(k, dg);
+    const float d = overlap(ax, dg, sg_);
+    if (d < best) { best = d; bk = k; }
+  }
+  const int kbest = group16_argmax(-best, bk);
+  bool dgb;
+  float sg;
+  const V3 axis = axis_of(kbest, dgb);
+  (void)overlap(axis, dgb, sg);
+  // the reference / incident faces: A's face most aligned with sg * axis, B's face most aligned with - sg * axis
+  float va_ = -INFINITY, vb_ = -INFINITY;
+  int ia = 0, ib = 0;
+  for (int f = g; f < nfa; f += kGroupLanes) { const float x = dot3(rt_rot(X, ld3(T.fnormal + 3 * (fa0 + f))), axis) * sg; if (x > va_) { va_ = x; ia = f; } }
+  for (int f = g; f < nfb; f += kGroupLanes) { const float x = dot3(ld3(T.fnormal + 3 * (fb0 + f)), axis) * -sg; if (x > vb_) { vb_ = x; ib = f; } }
+  const int fa = fa0 + group16_argmax(va_, ia), fb = fb0 + group16_argmax(vb_, ib);
+  const V3 na = rt_rot(X, ld3(T.fnormal + 3 * fa)), nb = ld3(T.fnormal + 3 * fb);
+  const bool ref_a = fabsf(dot3(na, axis)) > fabsf(dot3(nb, axis));
+  const FacePoly PA{T.face_adr[fa], T.face_adr[fa + 1] - T.face_adr[fa], true}, PB{T.face_adr[fb], T.face_adr[fb + 1] - T.face_adr[fb], false};
+  const FacePoly ref = ref_a ? PA : PB, inc = ref_a ? PB : PA;
+  const V3 ref_n = ref_a ? na : nb, inc_n = ref_a ? nb : na;
+  const V3 ref0 = poly_vert(T, X, ref, 0), inc0 = poly_vert(T, X, inc, 0);
+  // MJX _clip: the incident face's edges against the reference face's side planes, then the reference face's edges - projected onto the
+  // incident plane along the reference normal - against the incident face's side planes: 2 ms + 2 mc candidate points, four per lane
+  const int ms = inc.m, mc = ref.m, ncand = 2 * (ms + mc);
+  const float pden = dot3(ref_n, inc_n), pd = dot3(inc0, inc_n);
+  auto onto_inc_plane = [&](V3 p) { const float tt = (pd - dot3(p, inc_n)) / (pden + (pden == 0.f ? 1e-6f : 0.f)); return add3(p, mul3(ref_n, tt)); };
+  V3 cp[4], cr_[4];     // candidate on the incident plane / projected onto the reference plane
+  bool cm[4];
+  float pen[4];
+  static_for<4>([&](auto qc) {  // (a compile-time loop: the unroll pragma gives up on a body with inner loops, and the arrays would live in scratch)
+    constexpr int q = decltype(qc)::value;
+    const int c = g + kGroupLanes * q;
+    cm[q] = false; cp[q] = ref0; cr_[q] = ref0; pen[q] = 0.f;
+    if (c < ncand) {
+      V3 e0, e1;
+      bool m;
+      bool second;
+      if (c < 2 * ms) {
+        const int i = c < ms ? c : c - ms;
+        second = c >= ms;
+        e0 = poly_vert(T, X, inc, i == 0 ? ms - 1 : i - 1); e1 = poly_vert(T, X, inc, i);
+        m = clip_edge_to_poly([&](int k) { return poly_vert(T, X, ref, k); }, mc, ref_n, e0, e1);
+      } else {
+        const int c2 = c - 2 * ms, i = c2 < mc ? c2 : c2 - mc;
+        second = c2 >= mc;
+        e0 = onto_inc_plane(poly_vert(T, X, ref, i == 0 ? mc - 1 : i - 1)); e1 = onto_inc_plane(poly_vert(T, X, ref, i));
+        m = clip_edge_to_poly([&](int k) { return poly_vert(T, X, inc, k); }, ms, inc_n, e0, e1);
+      }
+      const V3 p = second ? e1 : e0;
+      const float h = dot3(sub3(p, ref0), ref_n);
+      cp[q] = p;
+      cr_[q] = sub3(p, mul3(ref_n, h));
+      cm[q] = m && (-h > 1e-6f);
+      pen[q] = dot3(sub3(p, cr_[q]), V3{-ref_n.x, -ref_n.y, -ref_n.z});
+    }
+  });
+  // MJX _manifold_points over the candidates (values of non-candidates carry -1e6; argmax takes the first maximum in candidate order)
+  auto pick = [&](auto value, int& cidx) {
+    float bv = -INFINITY;
+    int bc = 0;
+    static_for<4>([&](auto qc) { constexpr int q = decltype(qc)::value; const int c = g + kGroupLanes * q; if (c < ncand) { const float x = value(qc); if (x > bv) { bv = x; bc = c; } } });
+    // (a lane's candidates ascend with q: `>` keeps its first maximum; the row reduction keeps the first index among equal maxima)
+    cidx = group16_argmax(bv, bc);
+  };
+  // (selects over a lane's four registers, never an indexed array: nothing of this lives in scratch)
+  V3 r0 = cr_[0], r1 = cr_[1], r2 = cr_[2], r3 = cr_[3];
+  MPPO_REG_PIN(r0.x); MPPO_REG_PIN(r0.y); MPPO_REG_PIN(r0.z); MPPO_REG_PIN(r1.x); MPPO_REG_PIN(r1.y); MPPO_REG_PIN(r1.z);
+  MPPO_REG_PIN(r2.x); MPPO_REG_PIN(r2.y); MPPO_REG_PIN(r2.z); MPPO_REG_PIN(r3.x); MPPO_REG_PIN(r3.y); MPPO_REG_PIN(r3.z);
+  auto fetch_pt = [&](int c) -> V3 {
+    const int q = c >> 4, src = c & 15;
+    const V3 mine = q == 0 ? r0 : q == 1 ? r1 : q == 2 ? r2 : r3;
+    return {group16_shfl(mine.x, src), group16_shfl(mine.y, src), group16_shfl(mine.z, src)};
+  };
+  float dm[4], cmf[4];
+  static_for<4>([&](auto qc) { constexpr int q = decltype(qc)::value; dm[q] = cm[q] ? 0.f : -1e6f; cmf[q] = cm[q] ? 1.f : 0.f; });
+  float m0 = cmf[0], m1 = cmf[1], m2 = cmf[2], m3 = cmf[3], e0_ = pen[0], e1_ = pen[1], e2_ = pen[2], e3_ = pen[3];
+  MPPO_REG_PIN(m0); MPPO_REG_PIN(m1); MPPO_REG_PIN(m2); MPPO_REG_PIN(m3); MPPO_REG_PIN(e0_); MPPO_REG_PIN(e1_); MPPO_REG_PIN(e2_); MPPO_REG_PIN(e3_);
+  auto fetch_mask = [&](int c) -> float { const int q = c >> 4; return group16_shfl(q == 0 ? m0 : q == 1 ? m1 : q == 2 ? m2 : m3, c & 15); };
+  auto fetch_pen = [&](int c) -> float { const int q = c >> 4; return group16_shfl(q == 0 ? e0_ : q == 1 ? e1_ : q == 2 ? e2_ : e3_, c & 15); };
+  int idx[4];
+  pick([&](auto qc) { return dm[decltype(qc)::value]; }, idx[0]);
+  const V3 A_ = fetch_pt(idx[0]);
+  pick([&](auto qc) { constexpr int q = decltype(qc)::value; const V3 e = sub3(A_, cr_[q]); return dot3(e, e) + dm[q]; }, idx[1]);
+  const V3 B_ = fetch_pt(idx[1]);
+  const V3 ab = cross3(ref_n, sub3(A_, B_));
+  pick([&](auto qc) { constexpr int q = decltype(qc)::value; return fabsf(dot3(sub3(A_, cr_[q]), ab)) + dm[q]; }, idx[2]);
+  const V3 C_ = fetch_pt(idx[2]);
+  const V3 ac = cross3(ref_n, sub3(A_, C_)), bc = cross3(ref_n, sub3(B_, C_));
+  {
+    // the fourth point: the first maximum of the list [|(B - p) . bc|, then |(A - p) . ac|] over the candidates
+    int i1, i2;
+    pick([&](auto qc) { constexpr int q = decltype(qc)::value; return fabsf(dot3(sub3(B_, cr_[q]), bc)) + dm[q]; }, i1);
+    pick([&](auto qc) { constexpr int q = decltype(qc)::value; return fabsf(dot3(sub3(A_, cr_[q]), ac)) + dm[q]; }, i2);
+    const V3 p1 = fetch_pt(i1), p2 = fetch_pt(i2);
+    const float v1 = fabsf(dot3(sub3(B_, p1), bc)) + (fetch_mask(i1) != 0.f ? 0.f : -1e6f), v2 = fabsf(dot3(sub3(A_, p2), ac)) + (fetch_mask(i2) != 0.f ? 0.f : -1e6f);
+    idx[3] = v2 > v1 ? i2 : i1;
+  }
+  static_for<4>([&](auto jc) {
+    constexpr int j = decltype(jc)::value;
+    pos[j] = fetch_pt(idx[j]);
+    dist[j] = fetch_mask(idx[j]) != 0.f ? -fetch_pen(idx[j]) : 1.f;
+  });
+  if (kbest >= nfa + nfb) {  // an edge-edge axis: the deepest point of the manifold alone (selects, not indexed: no scratch)
+    float dk = dist[0];
+    V3 pk = pos[0];
+    static_for<3>([&](auto jc) { constexpr int j = decltype(jc)::value + 1; if (dist[j] < dk) { dk = dist[j]; pk = pos[j]; } });
+    static_for<4>([&](auto jc) { constexpr int j = decltype(jc)::value; dist[j] = j == 0 ? dk : 1.f; pos[j] = pk; });
+  }
+  nrm = mul3(axis, sg);
 }
 // cinert (10) x spatial motion (6) -> spatial force (6)      (mju_mulInertVec)
 __device__ __forceinline__ void inert_mul(const float* i, const float* v, float* r) {
@@ -752,13 +943,13 @@ __global__ void __launch_bounds__(64 * kMaxWavesPerBlock) env_kernel(ModelView m
       // sphere / capsule against a box or a mesh hull of another body (pair rows tagged with a hull; run-time-sized kernel only): one
       // pair at a time, the environment's 16 lanes together.  Geometry in the frame of the hull's body, results back in the world.
       const int* hs = mv.blob + mv.blob_words;
-      const HullView hv = hull_view(hs[0], hs[1], hs[2], hs[3], hs[4]);
+      const HullView hv = hull_view(hs[0], hs[1], hs[2], hs[3], hs[4], hs[5]);
       const float* hf = reinterpret_cast<const float*>(hs);
-      const HullTabs T{hs + hv.face_adr, hs + hv.fidx, hs + hv.edge, hf + hv.vert, hf + hv.fnormal, hf + hv.enormal};
+      const HullTabs T{hs + hv.face_adr, hs + hv.fidx, hs + hv.edge, hf + hv.vert, hf + hv.fnormal, hf + hv.enormal, hs + hv.udadr, hf + hv.udir};
       for (int k = 0; k < npair; ++k) {
         const float* gp = TF(pair_geom) + 16 * k;
         const int hid = (int)gp[7] - 1;
-        if (hid < 0 || gp[15] != 0.f) continue;  // (a capsule pair's second slot is filled with its first)
+        if (hid < 0 || gp[15] != 0.f) continue;  // (the later slots of a pair with several contacts are filled with its first)
         const int c = nplane + k;
         const int b1 = TI(pair_body)[2 * k], b2 = TI(pair_body)[2 * k + 1];
         const Q4 q1 = ld4(xquat + 4 * b1);
@@ -767,6 +958,33 @@ __global__ void __launch_bounds__(64 * kMaxWavesPerBlock) env_kernel(ModelView m
         const V3 x2 = ld3(xpos + 3 * b2);
         auto to_hull = [&](V3 v) { return V3{R[0] * v.x + R[3] * v.y + R[6] * v.z, R[1] * v.x + R[4] * v.y + R[7] * v.z, R[2] * v.x + R[5] * v.y + R[8] * v.z}; };
         auto to_world = [&](V3 v) { return V3{R[0] * v.x + R[1] * v.y + R[2] * v.z, R[3] * v.x + R[4] * v.y + R[5] * v.z, R[6] * v.x + R[7] * v.y + R[8] * v.z}; };
+        if (gp[14] != 0.f && gp[3] == 0.f && gp[4] == 0.f && gp[5] == 0.f && gp[6] == 0.f) {
+          // geom 1 is a hull too: box / mesh against box / mesh (MJX convex_convex), four slots
+          const int hid1 = (int)gp[14] - 1;
+          float R1[9];
+          qmat(q1, R1);
+          RigidT X;  // body 1's frame -> body 2's: R2^T R1, R2^T (x1 - x2)
+          _Pragma("unroll") for (int i = 0; i < 3; ++i) _Pragma("unroll") for (int j = 0; j < 3; ++j) X.R[3 * i + j] = R[i] * R1[j] + R[3 + i] * R1[3 + j] + R[6 + i] * R1[6 + j];
+          X.t = to_hull(sub3(ld3(xpos + 3 * b1), x2));
+          float d4[4];
+          V3 p4[4], n4;
+          hull_hull_contacts(T, X, hs[hv.fadr + hid1], hs[hv.fadr + hid1 + 1], hs[hv.fadr + hid], hs[hv.fadr + hid + 1], hs[hv.vadr + hid1], hs[hv.vadr + hid1 + 1],
+                             hs[hv.vadr + hid], hs[hv.vadr + hid + 1], T.udadr[hid1], T.udadr[hid1 + 1], T.udadr[hid], T.udadr[hid + 1], g, d4, p4, n4);
+          V3 q0 = p4[0], q1_ = p4[1], q2 = p4[2], q3 = p4[3];
+          float e0 = d4[0], e1 = d4[1], e2 = d4[2], e3 = d4[3];
+          MPPO_REG_PIN(q0.x); MPPO_REG_PIN(q0.y); MPPO_REG_PIN(q0.z); MPPO_REG_PIN(q1_.x); MPPO_REG_PIN(q1_.y); MPPO_REG_PIN(q1_.z);
+          MPPO_REG_PIN(q2.x); MPPO_REG_PIN(q2.y); MPPO_REG_PIN(q2.z); MPPO_REG_PIN(q3.x); MPPO_REG_PIN(q3.y); MPPO_REG_PIN(q3.z);
+          MPPO_REG_PIN(e0); MPPO_REG_PIN(e1); MPPO_REG_PIN(e2); MPPO_REG_PIN(e3);
+          if (g < 4) {
+            const V3 nw = to_world(n4);
+            const V3 pw = g == 0 ? q0 : g == 1 ? q1_ : g == 2 ? q2 : q3;
+            condist[c + g] = g == 0 ? e0 : g == 1 ? e1 : g == 2 ? e2 : e3;
+            st3(conpos + 3 * (c + g), add3(x2, to_world(pw)));
+            st3(confr + 6 * (c + g), nw);
+            st3(confr + 6 * (c + g) + 3, frame_tangent(nw));
+          }
+          continue;
+        }
         const bool capsule = gp[3] != 0.f || gp[4] != 0.f || gp[5] != 0.f;
         const V3 cp = to_hull(sub3(add3(ld3(xpos + 3 * b1), qrot(q1, ld3(gp))), x2)), half = to_hull(qrot(q1, ld3(gp + 3)));
         float dist2[2];
@@ -1947,8 +2165,14 @@ extern "C" int32_t mppo_model_open(const void* host_blob, size_t nbytes, const v
       if (hull_words < 8 || (hull_words & 3)) return bad("hull section too short");
       if (hs[0] < 1 || hs[1] < 4 || hs[2] < 4 || hs[3] < 12 || hs[4] < 6 || hs[0] > 64 || hs[1] > 64 * 64 || hs[2] > 128 * 64 || hs[3] > 6 * 128 * 64 || hs[4] > 192 * 64)
         return bad("hull section: dimension out of range");
-      hv = hull_view(hs[0], hs[1], hs[2], hs[3], hs[4]);
+      if (hs[5] < 3 * hs[0] || hs[5] > hs[4]) return bad("hull section: number of edge directions out of range");
+      hv = hull_view(hs[0], hs[1], hs[2], hs[3], hs[4], hs[5]);
       if ((size_t)hv.words != hull_words) return bad("hull section: length does not follow from its dimensions");
+      {
+        const int32_t* ua = hs + hv.udadr;
+        if (ua[0] != 0 || ua[hv.nhull] != hv.nudir) return bad("hull section: edge-direction ranges do not cover their array");
+        for (int h = 0; h < hv.nhull; ++h) if (ua[h + 1] < ua[h] + 3) return bad("a hull needs at least three edge directions");
+      }
       const int32_t *va = hs + hv.vadr, *fa = hs + hv.fadr, *ea = hs + hv.eadr, *pa = hs + hv.face_adr, *fi = hs + hv.fidx, *ed = hs + hv.edge;
       if (va[0] != 0 || fa[0] != 0 || ea[0] != 0 || pa[0] != 0 || va[hv.nhull] != hv.nvert || fa[hv.nhull] != hv.nface || ea[hv.nhull] != hv.nedge || pa[hv.nface] != hv.nfidx)
         return bad("hull section: address tables do not cover their arrays");
@@ -1962,10 +2186,26 @@ extern "C" int32_t mppo_model_open(const void* host_blob, size_t nbytes, const v
       }
     }
     const float* pg = wf + dir[2 * BF_pair_geom];
+    auto v_pair_body = [&](int k) { const int32_t* pb = HI(BI_pair_body); return ((long long)pb[2 * k] << 32) | (long long)(unsigned)pb[2 * k + 1]; };
     for (int k = 0; k < v.npair; ++k) {
-      const float hid = pg[16 * k + 7], slot = pg[16 * k + 15];
-      if (hid != (float)(int)hid || hid < 0.f || hid > (float)hv.nhull || (slot != 0.f && slot != 1.f)) return bad("pair row: hull / slot tag out of range");
-      if (slot == 1.f && (hid == 0.f || k == 0 || pg[16 * (k - 1) + 7] != hid || pg[16 * (k - 1) + 15] != 0.f)) return bad("pair row: a second slot must follow its pair's first");
+      const float* row = pg + 16 * k;
+      const float hid = row[7], slot = row[15];
+      // a hull pair (box / mesh against box / mesh, four slots): geom 1 carries no shape of its own and geom 2's radius word names geom 1's hull
+      const bool hullpair = hid != 0.f && row[14] != 0.f && row[3] == 0.f && row[4] == 0.f && row[5] == 0.f && row[6] == 0.f;
+      if (hid != (float)(int)hid || hid < 0.f || hid > (float)hv.nhull || slot != (float)(int)slot || slot < 0.f || slot > (hullpair ? 3.f : 1.f))
+        return bad("pair row: hull / slot tag out of range");
+      if (hullpair) {
+        const float h1 = row[14];
+        if (h1 != (float)(int)h1 || h1 < 1.f || h1 > (float)hv.nhull || h1 == hid) return bad("pair row: a hull pair's first hull out of range");
+        if (slot == 0.f && k + 3 >= v.npair) return bad("pair row: a hull pair needs four consecutive slots");
+        // (the manifold's candidates are kept four to a lane: faces of at most 16 vertices on either side)
+        const int32_t *fa = wi + total + hv.fadr, *pa = wi + total + hv.face_adr;
+        for (int hh : {(int)h1 - 1, (int)hid - 1})
+          for (int f = fa[hh]; f < fa[hh + 1]; ++f) if (pa[f + 1] - pa[f] > 16) return bad("a hull in a hull pair has a face of more than 16 vertices");
+      }
+      if (slot >= 1.f && (hid == 0.f || k == 0 || pg[16 * (k - 1) + 7] != hid || pg[16 * (k - 1) + 15] != slot - 1.f || pg[16 * (k - 1) + 14] != row[14] ||
+                          v_pair_body(k) != v_pair_body(k - 1)))
+        return bad("pair row: a later slot must follow its pair's previous one");
     }
   }
   {

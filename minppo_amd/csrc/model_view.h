@@ -31,7 +31,7 @@ enum BlobF32 {
 };
 
 constexpr uint32_t kBlobMagic = 0x4D50504F;
-constexpr uint32_t kBlobVersion = 6;
+constexpr uint32_t kBlobVersion = 7;
 constexpr int kBlobHeaderWords = 64;
 constexpr int JNT_FREE = 0, JNT_HINGE = 2, JNT_SLIDE = 3;
 constexpr float MJ_MINVAL = 1e-15f, MJ_MINIMP = 0.0001f, MJ_MAXIMP = 0.9999f;
@@ -110,18 +110,20 @@ __host__ __device__ constexpr inline BlobOffsets blob_offsets(const BlobDims& d)
 // sphere_convex / capsule_convex want them - per hull a range of vertices, of polygon faces (vertex index lists, counter-clockwise seen
 // from outside; outward unit normals) and of edges (vertex pair + the normals of the two faces beside it), everything in the frame of the
 // body the geom is fixed to.  Eight header words (nhull, nvert, nface, nfidx, nedge, 0, 0, 0), then the arrays in this order, each padded
-// to 4 words; offsets below are in words from the section's start.
+// to 4 words; offsets below are in words from the section's start.  (Header word 5: the number of edge directions, blob version 7.)
 struct HullView {
   int nhull, nvert, nface, nfidx, nedge;
   int vadr, fadr, eadr, face_adr, fidx, edge, vert, fnormal, enormal;
   int words;
+  int nudir, udadr, udir;  // round 6 (blob 7): per hull a range of unit edge DIRECTIONS, the parallel ones dropped - the edge axes of convex_convex
 };
-__host__ __device__ constexpr inline HullView hull_view(int nhull, int nvert, int nface, int nfidx, int nedge) {
-  HullView h{nhull, nvert, nface, nfidx, nedge, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+__host__ __device__ constexpr inline HullView hull_view(int nhull, int nvert, int nface, int nfidx, int nedge, int nudir = 0) {
+  HullView h{nhull, nvert, nface, nfidx, nedge, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, nudir, 0, 0};
   int cur = 8;
   auto take = [&](int n) { const int o = cur; cur += (n + 3) & ~3; return o; };
   h.vadr = take(nhull + 1); h.fadr = take(nhull + 1); h.eadr = take(nhull + 1); h.face_adr = take(nface + 1); h.fidx = take(nfidx);
   h.edge = take(2 * nedge); h.vert = take(3 * nvert); h.fnormal = take(3 * nface); h.enormal = take(6 * nedge);
+  h.udadr = take(nhull + 1); h.udir = take(3 * nudir);
   h.words = cur;
   return h;
 }

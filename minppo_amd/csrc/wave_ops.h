@@ -95,6 +95,8 @@ __device__ __forceinline__ float group16_max(float x) {
   x = fmaxf(x, dpp_row<0x121>(x));
   return x;
 }
+// the value lane `src` (0 .. 15) of this lane's 16-lane row holds (ds_bpermute: the source may differ from row to row)
+__device__ __forceinline__ float group16_shfl(float x, int src) { return __shfl(x, (int)((threadIdx.x & 63) & ~15) | (src & 15), 64); }
 // true in every lane of the wave if pred holds in any lane of the wave
 __device__ __forceinline__ bool wave_any(bool pred) { return __any(pred); }
 // true in every lane of a 16-lane row if pred holds in any lane of that row

@@ -40,7 +40,7 @@ MAX_CONVEX_VERTS = 64  # hull vertices of one mesh collider (the kernel scans th
 MAX_BODIES = 128  # subtree sets are two 64-bit words per body (one up to 64 bodies); dofs: one word, 64
 
 BLOB_MAGIC = 0x4D50504F  # "MPPO"
-BLOB_VERSION = 6  # 6: dof_actfrcrange (joint actuatorfrcrange); 2: header word include_c_vals; 3: geom-geom pairs (npair, pair_body, pair_geom) and con_axis; 4: convex (mesh) geoms against the plane; 5: hull section (sphere / capsule against box / mesh)
+BLOB_VERSION = 7  # 7: hull section carries the hulls' edge directions (convex_convex: box / mesh against box / mesh); 6: dof_actfrcrange (joint actuatorfrcrange); 2: header word include_c_vals; 3: geom-geom pairs (npair, pair_body, pair_geom) and con_axis; 4: convex (mesh) geoms against the plane; 5: hull section (sphere / capsule against box / mesh)
 
 
 # ---------------------------------------------------------------------------
@@ -560,7 +560,7 @@ def compile_model(spec: ModelSpec) -> CompiledModel:
     # groups are skipped (mj_filterBodyPair), then the contype / conaffinity masks.  geom1 is the one with the smaller type id
     # (sphere < capsule < box < mesh); groups are ordered (sphere, sphere), (sphere, capsule), (sphere, box), (sphere, mesh),
     # (capsule, capsule), (capsule, box), (capsule, mesh) like MJX's collision-function table.  A box or a mesh meets a sphere / capsule
-    # as a convex hull (MJX sphere_convex: one contact; capsule_convex: two); box / mesh against box / mesh is not built.
+    # as a convex hull (MJX sphere_convex: one contact; capsule_convex: two); box / mesh against box / mesh: convex_convex, four (round 6).
     weld = np.arange(nbody)
     for b in range(1, nbody):
         if body_jntnum[b] == 0:
@@ -586,13 +586,12 @@ def compile_model(spec: ModelSpec) -> CompiledModel:
             if GEOM_CYLINDER in (gi[0], gj[0]):
                 raise ValueError("a cylinder geom can only collide with the ground plane (MJX pairs it through signed-distance functions: not built): "
                                  "exclude it from geom-geom pairs with contype / conaffinity")
-            if gi[0] in (GEOM_BOX, GEOM_MESH):
-                names_ = {GEOM_BOX: "box", GEOM_MESH: "mesh"}
-                raise ValueError(f"a {names_[gi[0]]} geom cannot collide with a {names_[gj[0]]} geom (convex-convex pairs are not built): "
-                                 "exclude the pair with contype / conaffinity")
             pair_rows.append(((gi[0], gj[0]), gi, gj, 0))
             if gj[0] in (GEOM_BOX, GEOM_MESH) and gi[0] == GEOM_CAPSULE:
                 pair_rows.append(((gi[0], gj[0]), gi, gj, 1))  # capsule_convex fills two contact slots
+            if gi[0] in (GEOM_BOX, GEOM_MESH):  # box / mesh against box / mesh (round 6; MJX convex_convex): a manifold of four contact slots
+                for slot_ in (1, 2, 3):
+                    pair_rows.append(((gi[0], gj[0]), gi, gj, slot_))
     pair_rows.sort(key=lambda r: r[0])  # stable: geom order inside a group, a pair's two slots next to each other
     pair_body, pair_geom = [], []
     # hull section: the convex geoms that take part in a pair, vertices / normals in the BODY frame
@@ -604,31 +603,45 @@ def compile_model(spec: ModelSpec) -> CompiledModel:
     hull_fnormal: List[List[float]] = []
     hull_edge: List[List[int]] = []
     hull_enormal: List[List[float]] = []
+    hull_udadr: List[int] = [0]      # per hull: its edge DIRECTIONS with parallel ones dropped (unit vectors, body frame): the edge axes of convex_convex
+    hull_udir: List[List[float]] = []
+
+    def hull_id(gx) -> int:
+        if id(gx) not in hull_of:
+            if gx[0] == GEOM_BOX:
+                local = np.asarray([[sx * gx[4][0], sy * gx[4][1], sz * gx[4][2]] for sx in (-1.0, 1.0) for sy in (-1.0, 1.0) for sz in (-1.0, 1.0)])
+            else:
+                local = gx[8]
+            faces_, fn_, edges_, en_ = hull_topology(local)
+            v0 = len(hull_vert)
+            hull_of[id(gx)] = len(hull_body)
+            hull_body.append(gx[1])
+            hull_vert.extend([list(np.asarray(gx[2]) + _qrot(gx[3], v)) for v in local])
+            for f_, n_ in zip(faces_, fn_):
+                hull_fidx.extend([v0 + i for i in f_])
+                hull_face_adr.append(len(hull_fidx))
+                hull_fnormal.append(list(_qrot(gx[3], n_)))
+            hull_edge.extend([[v0 + int(a), v0 + int(b)] for a, b in edges_])
+            hull_enormal.extend([[*_qrot(gx[3], n2[0]), *_qrot(gx[3], n2[1])] for n2 in en_])
+            kept: List[np.ndarray] = []
+            for a, b in edges_:
+                dvec = np.asarray(local[int(b)], np.float64) - np.asarray(local[int(a)], np.float64)
+                dvec = dvec / np.linalg.norm(dvec)
+                if all(np.sum(np.cross(dvec, k_) ** 2) >= 1e-6 for k_ in kept):
+                    kept.append(dvec)
+            hull_udir.extend([list(_qrot(gx[3], k_)) for k_ in kept])
+            hull_udadr.append(len(hull_udir))
+            hull_vadr.append(len(hull_vert)); hull_fadr.append(len(hull_fnormal)); hull_eadr.append(len(hull_edge))
+        return hull_of[id(gx)]
+
     for _, gi, gj, slot in pair_rows:
         pair_body += [gi[1], gj[1]]
-        hid = -1
-        if gj[0] in (GEOM_BOX, GEOM_MESH):
-            if id(gj) not in hull_of:
-                if gj[0] == GEOM_BOX:
-                    local = np.asarray([[sx * gj[4][0], sy * gj[4][1], sz * gj[4][2]] for sx in (-1.0, 1.0) for sy in (-1.0, 1.0) for sz in (-1.0, 1.0)])
-                else:
-                    local = gj[8]
-                faces_, fn_, edges_, en_ = hull_topology(local)
-                v0 = len(hull_vert)
-                hull_of[id(gj)] = len(hull_body)
-                hull_body.append(gj[1])
-                hull_vert += [list(np.asarray(gj[2]) + _qrot(gj[3], v)) for v in local]
-                for f_, n_ in zip(faces_, fn_):
-                    hull_fidx += [v0 + i for i in f_]
-                    hull_face_adr.append(len(hull_fidx))
-                    hull_fnormal.append(list(_qrot(gj[3], n_)))
-                hull_edge += [[v0 + int(a), v0 + int(b)] for a, b in edges_]
-                hull_enormal += [[*_qrot(gj[3], n2[0]), *_qrot(gj[3], n2[1])] for n2 in en_]
-                hull_vadr.append(len(hull_vert)); hull_fadr.append(len(hull_fnormal)); hull_eadr.append(len(hull_edge))
-            hid = hull_of[id(gj)]
-        for g_, tag in ((gi, float(hid + 1)), (gj, float(slot))):
+        hid = hull_id(gj) if gj[0] in (GEOM_BOX, GEOM_MESH) else -1
+        hid1 = hull_id(gi) if gi[0] in (GEOM_BOX, GEOM_MESH) else -1
+        for g_, r_, tag in ((gi, 0.0, float(hid + 1)), (gj, float(hid1 + 1), float(slot))):
             half = _qrot(g_[3], [0, 0, 1.0]) * g_[4][1] if g_[0] == GEOM_CAPSULE else np.zeros(3)
-            pair_geom += [*g_[2], *half, g_[4][0] if g_[0] in (GEOM_SPHERE, GEOM_CAPSULE) else 0.0, tag]  # [7]: hull + 1 (0: none), [15]: slot of a two-contact pair
+            # [7]: geom 2's hull + 1 (0: none), [14]: geom 1's hull + 1 (a hull pair; a round geom 2 carries its radius there), [15]: slot of a pair with several contacts
+            pair_geom += [*g_[2], *half, g_[4][0] if g_[0] in (GEOM_SPHERE, GEOM_CAPSULE) else r_, tag]
         con_bodyid.append(gj[1])
         con_lpos.append([0.0, 0.0, 0.0])
         con_radius.append(0.0)
@@ -728,6 +741,8 @@ def compile_model(spec: ModelSpec) -> CompiledModel:
     put("hull_vert", np.reshape(hull_vert, (len(hull_vert), 3)))
     put("hull_fnormal", np.reshape(hull_fnormal, (len(hull_fnormal), 3)))
     put("hull_enormal", np.reshape(hull_enormal, (len(hull_enormal), 6)))
+    put("hull_udadr", hull_udadr, np.int32)
+    put("hull_udir", np.reshape(hull_udir, (len(hull_udir), 3)))
     put("lim_jntid", lim_jnt, np.int32)
     put("contact_solref", spec.contact_solref)
     put("contact_solimp", spec.contact_solimp)
@@ -946,14 +961,14 @@ def _to_blob(cm: CompiledModel, include_c_vals: bool = True) -> bytes:
 
 
 _HULL_ARRAYS = [("hull_vadr", "<i4"), ("hull_fadr", "<i4"), ("hull_eadr", "<i4"), ("hull_face_adr", "<i4"), ("hull_fidx", "<i4"), ("hull_edge", "<i4"),
-                ("hull_vert", "<f4"), ("hull_fnormal", "<f4"), ("hull_enormal", "<f4")]
+                ("hull_vert", "<f4"), ("hull_fnormal", "<f4"), ("hull_enormal", "<f4"), ("hull_udadr", "<i4"), ("hull_udir", "<f4")]
 
 
 def _hull_section(t: Dict[str, np.ndarray]) -> bytes:
     nh = int(t["nhull"]) if "nhull" in t else 0
     if nh == 0:
         return b""
-    out = bytearray(struct.pack("<8i", nh, len(t["hull_vert"]), len(t["hull_fnormal"]), len(t["hull_fidx"]), len(t["hull_edge"]), 0, 0, 0))
+    out = bytearray(struct.pack("<8i", nh, len(t["hull_vert"]), len(t["hull_fnormal"]), len(t["hull_fidx"]), len(t["hull_edge"]), len(t["hull_udir"]), 0, 0))
     for k, dt in _HULL_ARRAYS:
         raw = np.ascontiguousarray(t[k]).reshape(-1).astype(dt).tobytes()
         out += raw + b"\0" * ((-len(raw)) % 16)

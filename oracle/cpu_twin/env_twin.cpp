@@ -200,6 +200,125 @@ inline void capsule_convex(const HullRef& H, V3 cp, V3 half, float r, float* dis
   dist[0] = -(has_edge ? epen : fpen[0]);
   dist[1] = -(has_edge ? -1.f : fpen[1]);
 }
+// ---- a box / mesh hull against a box / mesh hull of another body (round 6): the form of MJX collision_convex._box_box for every hull pair,
+// written out the way the NumPy oracle states it (oracle/physics_oracle.py convex_convex): A's vertices, normals and edge directions
+// taken into B's frame, per-axis overlap arrays, argmin / argmax over them, the clipped candidates as arrays, _manifold_points.
+struct HullFull {
+  const int* face_adr; const int* fidx; const float* vert; const float* fnormal; const float* udir;
+  int v0, v1, f0, f1, u0, u1;
+};
+inline bool clip_edge_to_planes(const std::vector<V3>& poly, V3 n, V3& e0, V3& e1) {  // MJX _clip_edge_to_planes against the polygon's side planes
+  const int m = (int)poly.size();
+  const V3 dir = sub3(e1, e0), rdir = sub3(e0, e1);
+  V3 n0 = e0, n1 = e1;
+  float d0 = 0.f, d1 = 0.f;
+  bool both = false;
+  for (int i = 0; i < m; ++i) {
+    const V3 p0 = poly[(i + m - 1) % m], en = cross3(sub3(poly[i], p0), n);
+    const bool in0 = dot3(sub3(e0, p0), en) > 1e-6f, in1 = dot3(sub3(e1, p0), en) > 1e-6f;
+    const float denom = dot3(dir, en);
+    const V3 cand = add3(e0, mul3(dir, dot3(sub3(p0, e0), en) / (denom + (denom == 0.f ? 1e-6f : 0.f))));
+    const V3 c0 = in0 ? cand : e0, c1 = in1 ? cand : e1;
+    const float x0 = dot3(sub3(c0, e0), dir), x1 = dot3(sub3(c1, e1), rdir);
+    if (i == 0 || x0 > d0) { d0 = x0; n0 = c0; }
+    if (i == 0 || x1 > d1) { d1 = x1; n1 = c1; }
+    both = both || (in0 && in1);
+  }
+  bool mask = !both;
+  if (!mask) { n0 = e0; n1 = e1; }
+  if (dot3(rdir, sub3(n0, n1)) < 0.f) mask = false;
+  e0 = n0; e1 = n1;
+  return mask;
+}
+inline void convex_convex(const HullFull& A, const HullFull& B, const float* R, V3 tr, float* dist, V3* pos, V3& nrm) {
+  auto rot = [&](V3 v) { return V3{R[0] * v.x + R[1] * v.y + R[2] * v.z, R[3] * v.x + R[4] * v.y + R[5] * v.z, R[6] * v.x + R[7] * v.y + R[8] * v.z}; };
+  std::vector<V3> va, vb, na, nb, ea, eb;
+  for (int v = A.v0; v < A.v1; ++v) va.push_back(add3(rot(ld3(A.vert + 3 * v)), tr));
+  for (int v = B.v0; v < B.v1; ++v) vb.push_back(ld3(B.vert + 3 * v));
+  for (int f = A.f0; f < A.f1; ++f) na.push_back(rot(ld3(A.fnormal + 3 * f)));
+  for (int f = B.f0; f < B.f1; ++f) nb.push_back(ld3(B.fnormal + 3 * f));
+  for (int u = A.u0; u < A.u1; ++u) ea.push_back(rot(ld3(A.udir + 3 * u)));
+  for (int u = B.u0; u < B.u1; ++u) eb.push_back(ld3(B.udir + 3 * u));
+  const int nfa = (int)na.size(), nfb = (int)nb.size();
+  std::vector<V3> axes(na);
+  axes.insert(axes.end(), nb.begin(), nb.end());
+  std::vector<char> degenerate(nfa + nfb, 0);
+  for (size_t j = 0; j < eb.size(); ++j)
+    for (size_t i = 0; i < ea.size(); ++i) {
+      const V3 cr = cross3(ea[i], eb[j]);
+      degenerate.push_back(dot3(cr, cr) < 1e-6f);
+      float nn;
+      axes.push_back(normalize_norm(cr, nn));
+    }
+  int best = 0;
+  float bsup = 0.f, bsign = 1.f;
+  for (size_t k = 0; k < axes.size(); ++k) {
+    float amax = -INFINITY, amin = INFINITY, bmax = -INFINITY, bmin = INFINITY;
+    for (const V3& v : va) { const float p = dot3(v, axes[k]); amax = std::max(amax, p); amin = std::min(amin, p); }
+    for (const V3& v : vb) { const float p = dot3(v, axes[k]); bmax = std::max(bmax, p); bmin = std::min(bmin, p); }
+    const float d1 = amax - bmin, d2 = bmax - amin;
+    const float sup = degenerate[k] ? 1e6f : std::min(d1, d2);
+    if (k == 0 || sup < bsup) { bsup = sup; best = (int)k; bsign = d1 > d2 ? -1.f : 1.f; }
+  }
+  const V3 axis = axes[best];
+  int fa = 0, fb = 0;
+  for (int f = 1; f < nfa; ++f) if (dot3(na[f], axis) * bsign > dot3(na[fa], axis) * bsign) fa = f;
+  for (int f = 1; f < nfb; ++f) if (dot3(nb[f], axis) * -bsign > dot3(nb[fb], axis) * -bsign) fb = f;
+  std::vector<V3> pa, pb;
+  for (int i = A.face_adr[A.f0 + fa]; i < A.face_adr[A.f0 + fa + 1]; ++i) pa.push_back(add3(rot(ld3(A.vert + 3 * A.fidx[i])), tr));
+  for (int i = B.face_adr[B.f0 + fb]; i < B.face_adr[B.f0 + fb + 1]; ++i) pb.push_back(ld3(B.vert + 3 * B.fidx[i]));
+  const bool ref_a = std::fabs(dot3(na[fa], axis)) > std::fabs(dot3(nb[fb], axis));
+  const std::vector<V3>& ref = ref_a ? pa : pb;
+  const std::vector<V3>& inc = ref_a ? pb : pa;
+  const V3 ref_n = ref_a ? na[fa] : nb[fb], inc_n = ref_a ? nb[fb] : na[fa];
+  const int ms = (int)inc.size(), mc = (int)ref.size();
+  std::vector<V3> cand(2 * (ms + mc));
+  std::vector<char> mask(2 * (ms + mc));
+  for (int i = 0; i < ms; ++i) {
+    V3 e0 = inc[(i + ms - 1) % ms], e1 = inc[i];
+    const bool m = clip_edge_to_planes(ref, ref_n, e0, e1);
+    cand[i] = e0; cand[ms + i] = e1; mask[i] = mask[ms + i] = m;
+  }
+  const float pden = dot3(ref_n, inc_n), pd = dot3(inc[0], inc_n);
+  auto onto = [&](V3 p) { return add3(p, mul3(ref_n, (pd - dot3(p, inc_n)) / (pden + (pden == 0.f ? 1e-6f : 0.f)))); };
+  for (int i = 0; i < mc; ++i) {
+    V3 e0 = onto(ref[(i + mc - 1) % mc]), e1 = onto(ref[i]);
+    const bool m = clip_edge_to_planes(inc, inc_n, e0, e1);
+    cand[2 * ms + i] = e0; cand[2 * ms + mc + i] = e1; mask[2 * ms + i] = mask[2 * ms + mc + i] = m;
+  }
+  const int nc = (int)cand.size();
+  std::vector<V3> on_ref(nc);
+  std::vector<float> dm(nc), pen(nc);
+  for (int c = 0; c < nc; ++c) {
+    const float h = dot3(sub3(cand[c], ref[0]), ref_n);
+    on_ref[c] = sub3(cand[c], mul3(ref_n, h));
+    mask[c] = mask[c] && (-h > 1e-6f);
+    dm[c] = mask[c] ? 0.f : -1e6f;
+    pen[c] = dot3(sub3(cand[c], on_ref[c]), mul3(ref_n, -1.f));
+  }
+  auto argmax = [&](auto value) { int bi = 0; float bv = value(0); for (int c = 1; c < nc; ++c) { const float x = value(c); if (x > bv) { bv = x; bi = c; } } return bi; };
+  int idx[4];
+  idx[0] = argmax([&](int c) { return dm[c]; });
+  const V3 a = on_ref[idx[0]];
+  idx[1] = argmax([&](int c) { const V3 e = sub3(a, on_ref[c]); return dot3(e, e) + dm[c]; });
+  const V3 b = on_ref[idx[1]];
+  const V3 ab = cross3(ref_n, sub3(a, b));
+  idx[2] = argmax([&](int c) { return std::fabs(dot3(sub3(a, on_ref[c]), ab)) + dm[c]; });
+  const V3 cpt = on_ref[idx[2]];
+  const V3 ac = cross3(ref_n, sub3(a, cpt)), bc = cross3(ref_n, sub3(b, cpt));
+  const int i1 = argmax([&](int c) { return std::fabs(dot3(sub3(b, on_ref[c]), bc)) + dm[c]; });
+  const int i2 = argmax([&](int c) { return std::fabs(dot3(sub3(a, on_ref[c]), ac)) + dm[c]; });
+  idx[3] = (std::fabs(dot3(sub3(a, on_ref[i2]), ac)) + dm[i2]) > (std::fabs(dot3(sub3(b, on_ref[i1]), bc)) + dm[i1]) ? i2 : i1;
+  for (int j = 0; j < 4; ++j) { pos[j] = on_ref[idx[j]]; dist[j] = mask[idx[j]] ? -pen[idx[j]] : 1.f; }
+  if (best >= nfa + nfb) {
+    int k = 0;
+    for (int j = 1; j < 4; ++j) if (dist[j] < dist[k]) k = j;
+    const float dk = dist[k];
+    const V3 pk = pos[k];
+    for (int j = 0; j < 4; ++j) { dist[j] = j == 0 ? dk : 1.f; pos[j] = pk; }
+  }
+  nrm = mul3(axis, bsign);
+}
 inline V3 frame_tangent(V3 n) {  // second row of MJX math.make_frame for a unit n
   V3 b = (n.y > -0.5f && n.y < 0.5f) ? V3{0.f, 1.f, 0.f} : V3{0.f, 0.f, 1.f};
   b = sub3(b, mul3(n, dot3(n, b)));
@@ -499,8 +618,30 @@ float forward(const Model& m, Work& w, const float* qpos, const float* qvel, con
     const Q4 q1 = ld4(&w.xquat[4 * b1]), q2 = ld4(&w.xquat[4 * b2]);
     const V3 c1 = add3(ld3(&w.xpos[3 * b1]), qrot(q1, ld3(gp))), h1 = qrot(q1, ld3(gp + 3));
     if (gp[7] != 0.f) {  // geom 2 is a convex hull fixed to b2: in b2's frame, then back
-      if (gp[15] != 0.f) continue;  // (second slot of a capsule's pair: filled with the first)
+      if (gp[15] != 0.f) continue;  // (a later slot of a pair with several contacts: filled with the first)
       const int hid = (int)gp[7] - 1;
+      if (gp[14] != 0.f && gp[3] == 0.f && gp[4] == 0.f && gp[5] == 0.f && gp[6] == 0.f) {  // geom 1 is a hull too: four slots
+        const int hid1 = (int)gp[14] - 1;
+        auto full = [&](int h) {
+          return HullFull{m.HI(m.hv.face_adr), m.HI(m.hv.fidx), m.HF(m.hv.vert), m.HF(m.hv.fnormal), m.HF(m.hv.udir), m.HI(m.hv.vadr)[h], m.HI(m.hv.vadr)[h + 1],
+                          m.HI(m.hv.fadr)[h], m.HI(m.hv.fadr)[h + 1], m.HI(m.hv.udadr)[h], m.HI(m.hv.udadr)[h + 1]};
+        };
+        float R1[9], R2[9], Rr[9];
+        qmat(q1, R1); qmat(q2, R2);
+        for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) Rr[3 * i + j] = R2[i] * R1[j] + R2[3 + i] * R1[3 + j] + R2[6 + i] * R1[6 + j];
+        const V3 x2 = ld3(&w.xpos[3 * b2]), dx = sub3(ld3(&w.xpos[3 * b1]), x2);
+        const V3 tr = {R2[0] * dx.x + R2[3] * dx.y + R2[6] * dx.z, R2[1] * dx.x + R2[4] * dx.y + R2[7] * dx.z, R2[2] * dx.x + R2[5] * dx.y + R2[8] * dx.z};
+        float d4[4];
+        V3 p4[4], n4;
+        convex_convex(full(hid1), full(hid), Rr, tr, d4, p4, n4);
+        const V3 n = qrot(q2, n4), t1 = frame_tangent(n);
+        for (int j = 0; j < 4; ++j) {
+          w.condist[c + j] = d4[j];
+          st3(&w.conpos[3 * (c + j)], add3(x2, qrot(q2, p4[j])));
+          st3(&w.confr[9 * (c + j)], n); st3(&w.confr[9 * (c + j) + 3], t1); st3(&w.confr[9 * (c + j) + 6], cross3(n, t1));
+        }
+        continue;
+      }
       const HullRef H{m.HI(m.hv.face_adr), m.HI(m.hv.fidx), m.HI(m.hv.edge), m.HF(m.hv.vert), m.HF(m.hv.fnormal), m.HF(m.hv.enormal),
                       m.HI(m.hv.fadr)[hid], m.HI(m.hv.fadr)[hid + 1], m.HI(m.hv.eadr)[hid], m.HI(m.hv.eadr)[hid + 1]};
       const Q4 q2i = {q2.w, -q2.x, -q2.y, -q2.z};
@@ -750,7 +891,7 @@ void* twin_model_open(const void* host_blob, size_t nbytes) {
   if (wu[35] > 0) {
     m->hull_base = (int)wu[2];
     const int32_t* hs = wi + wu[2];
-    m->hv = hull_view(hs[0], hs[1], hs[2], hs[3], hs[4]);
+    m->hv = hull_view(hs[0], hs[1], hs[2], hs[3], hs[4], hs[5]);
     if ((uint32_t)m->hv.words != wu[35]) { delete m; return nullptr; }
   }
   m->blob.assign(wi, wi + nbytes / 4);

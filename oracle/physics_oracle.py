@@ -247,6 +247,8 @@ class Hull:
         e0, e1 = int(t["hull_eadr"][h]), int(t["hull_eadr"][h + 1])
         self.edge = np.asarray(t["hull_edge"][e0:e1]) - v0
         self.enormal = np.asarray(t["hull_enormal"][e0:e1], dtype).reshape(-1, 2, 3)
+        if "hull_udadr" in t:  # the hull's edge directions with the parallel ones dropped (the axes of convex_convex's edge-edge tests)
+            self.udir = np.asarray(t["hull_udir"][int(t["hull_udadr"][h]):int(t["hull_udadr"][h + 1])], dtype).reshape(-1, 3)
 
 
 def _face_support(hull, pts, r):
@@ -309,6 +311,80 @@ def _clip_edge_to_planes(e0, e1, plane_pts, plane_normals):
     n1 = np.where(mask[:, None], n1, e1)
     mask = np.where(np.sum((e0 - e1) * (n0 - n1), -1) < 0, False, mask)
     return n0, n1, mask
+
+
+def _clip_polygons(clip_poly, subj_poly, clip_n, subj_n):
+    """MJX collision_convex._clip ([3P-recall]): the subject polygon's edges clipped against the side planes of the clipping polygon, and
+    the clipping polygon's edges - projected onto the subject's plane along the clipping normal - clipped against the subject's side
+    planes.  Polygons [m, 3] counter-clockwise seen from outside (side plane normals (p1 - p0) x n point away from the centre).
+    -> candidate points [2 ms + 2 mc, 3] on the subject's plane and their mask."""
+    dt = clip_poly.dtype
+    c0, c1 = np.roll(clip_poly, 1, axis=0), clip_poly
+    cn = np.cross(c1 - c0, clip_n)
+    s0, s1 = np.roll(subj_poly, 1, axis=0), subj_poly
+    sn = np.cross(s1 - s0, subj_n)
+    e0, e1, m = _clip_edge_to_planes(s0, s1, c0, cn)
+
+    def onto_subject_plane(poly):
+        denom = clip_n @ subj_n
+        tt = (subj_poly[0] @ subj_n - poly @ subj_n) / (denom + dt.type(1e-6) * (denom == 0))
+        return poly + tt[:, None] * clip_n
+
+    f0, f1, ms = _clip_edge_to_planes(onto_subject_plane(c0), onto_subject_plane(c1), s0, sn)
+    return np.concatenate([e0, e1, f0, f1]), np.concatenate([m, m, ms, ms])
+
+
+def convex_convex(A, B, R, tr):
+    """A box or a mesh hull against a box or a mesh hull of another body, the form of MJX collision_convex._box_box ([3P-recall]; MJX runs
+    this form for two boxes and - since 3.1.3 - a Gauss-map variant of it for meshes, which prunes the edge pairs and places an edge
+    contact at the two edges' closest points: here every hull pair takes the box form).  Everything in B's frame; R [N, 3, 3] / tr [N, 3]
+    take A's frame into it.  Separating-axis test over A's face normals, B's face normals and the cross products of the hulls' edge
+    directions (parallel pairs ignored): per axis the smaller of the two overlaps of the projections, the axis of the least overlap wins
+    (argmin: the first among equals - face axes before edge axes).  The reference face is the face most aligned with the axis on the hull
+    that is better aligned, the other hull's most anti-aligned face is clipped against its side planes (_clip), the candidates behind the
+    reference plane are projected onto it and four of them chosen (_manifold_points).  An edge-axis winner keeps the deepest point only.
+    -> dist [N, 4] (1 = slot unused), pos [N, 4, 3] on the reference face, normal [N, 3] from A to B."""
+    dt = B.vert.dtype
+    N = R.shape[0]
+    dist, pos, normal = np.ones((N, 4), dt), np.zeros((N, 4, 3), dt), np.zeros((N, 3), dt)
+    nfa, nfb = len(A.faces), len(B.faces)
+    for e in range(N):
+        va = A.vert @ R[e].T + tr[e]
+        na = A.fnormal @ R[e].T
+        ea = A.udir @ R[e].T
+        vb, nb, eb = B.vert, B.fnormal, B.udir
+        cr = np.cross(np.tile(ea, (len(eb), 1)), np.repeat(eb, len(ea), axis=0))      # index j * nEa + i
+        degenerate = (cr ** 2).sum(1) < 1e-6
+        nrm = np.linalg.norm(cr, axis=1)
+        cr = cr / (nrm + dt.type(1e-6) * (nrm == 0))[:, None]
+        axes = np.concatenate([na, nb, cr])
+        pa, pb = va @ axes.T, vb @ axes.T                                               # [V, naxes]
+        d1, d2 = pa.max(0) - pb.min(0), pb.max(0) - pa.min(0)
+        sign = np.where(d1 > d2, -1.0, 1.0).astype(dt)
+        sup = np.minimum(d1, d2)
+        sup[nfa + nfb:] = np.where(degenerate, dt.type(1e6), sup[nfa + nfb:])
+        best = int(np.argmin(sup))
+        axis, sg = axes[best], sign[best]
+        da, db = na @ axis, nb @ axis
+        fa, fb = int(np.argmax(da * sg)), int(np.argmax(db * -sg))
+        poly_a, poly_b = va[A.faces[fa]], vb[B.faces[fb]]
+        if abs(da[fa]) > abs(db[fb]):
+            ref, ref_n, inc, inc_n = poly_a, na[fa], poly_b, nb[fb]
+        else:
+            ref, ref_n, inc, inc_n = poly_b, nb[fb], poly_a, na[fa]
+        cand, mask = _clip_polygons(ref, inc, ref_n, inc_n)
+        on_ref = cand - ((cand - ref[0]) @ ref_n)[:, None] * ref_n
+        mask = mask & (((cand - ref[0]) @ -ref_n) > 1e-6)
+        idx = manifold_points(on_ref, mask[None], ref_n[None])[0]
+        pen = (cand[idx] - on_ref[idx]) @ -ref_n
+        dd = np.where(mask[idx], -pen, dt.type(1.0))
+        pp = on_ref[idx]
+        if best >= nfa + nfb:  # an edge-edge axis: the deepest point of the manifold alone
+            k = int(np.argmin(dd))
+            dd = np.array([dd[k], 1.0, 1.0, 1.0], dt)
+            pp = np.tile(pp[k], (4, 1))
+        dist[e], pos[e], normal[e] = dd, pp, sg * axis
+    return dist, pos, normal
 
 
 def capsule_convex(cp, half, r, hull):
@@ -590,6 +666,19 @@ class Physics:
             a1 = qrot(d.xquat[:, b1], np.broadcast_to(h1, (N, 3)).astype(dt))
             a2 = qrot(d.xquat[:, b2], np.broadcast_to(h2, (N, 3)).astype(dt))
             hid, slot = int(g[7]) - 1, int(g[15])
+            hid1 = int(g[14]) - 1  # geom 1 is a convex hull too (box / mesh against box / mesh): four slots, computed at the first
+            if hid >= 0 and hid1 >= 0:
+                if slot == 0:
+                    R1, R2 = qmat(d.xquat[:, b1]), qmat(d.xquat[:, b2])
+                    Rr = np.einsum("nji,njk->nik", R2, R1)                               # A's (body 1) frame -> B's (body 2) frame
+                    trr = np.einsum("nji,nj->ni", R2, d.xpos[:, b1] - d.xpos[:, b2])
+                    dd, pp, nn = convex_convex(Hull(t, hid1, dt), Hull(t, hid, dt), Rr, trr)
+                    fr = make_frame(np.einsum("nij,nj->ni", R2, nn))
+                    for j in range(4):
+                        dist[:, c + j] = dd[:, j]
+                        cpos[:, c + j] = d.xpos[:, b2] + np.einsum("nij,nj->ni", R2, pp[:, j])
+                        frame[:, c + j] = fr
+                continue
             if hid >= 0:
                 # geom 2 is a convex hull (box / mesh) fixed to b2: work in b2's frame, come back to the world (MJX sphere_convex /
                 # capsule_convex); a capsule's pair owns two consecutive slots and is computed at the first

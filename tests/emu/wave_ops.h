@@ -177,6 +177,16 @@ inline double wave_sum_f64(double x) {
   __syncthreads();
   return r;
 }
+// the value lane `src` (0 .. 15) of this lane's 16-lane row holds
+inline float group16_shfl(float x, int src) {
+  float* s = reinterpret_cast<float*>(emu::g_xchg);
+  const int t = emu::tid();
+  s[t] = x;
+  __syncthreads();
+  const float r = s[(t & ~15) | (src & 15)];
+  __syncthreads();
+  return r;
+}
 inline float __shfl_xor(float x, int mask) {
   float* s = reinterpret_cast<float*>(emu::g_xchg);
   const int t = emu::tid();

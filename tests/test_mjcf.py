@@ -331,14 +331,21 @@ def test_mesh_geom_collides_as_its_convex_hull(tmp_path):
     ('<mesh name="other" vertex="0 0 0 1 0 0 0 1 0 0 0 1"/>', 'contype="0"', "", "is not defined under <asset>"),
     ('<mesh name="rock" vertex="0 0 0 1 0 0 0 1 0"/>', 'contype="0"', "", "at least four vertices"),
     ('<mesh name="rock" vertex="0 0 0 1 0 0 0 1 0 1 1 0 0.5 0.5 0"/>', 'contype="0"', "", "degenerate mesh"),
-    (f'<mesh name="rock" vertex="{CUBE_PLUS}"/>', "", '<body name="b2" pos="0 0 0.2"><joint name="j" axis="0 1 0"/><inertial pos="0 0 0" mass="1" diaginertia="1 1 1"/>'
-     '<body name="b3" pos="0 0 0.2"><joint name="j3" axis="0 1 0"/><inertial pos="0 0 0" mass="1" diaginertia="1 1 1"/><geom type="box" size="0.05 0.05 0.05"/></body></body>',
-     "convex-convex pairs are not built"),
     ('<mesh name="rock" vertex="' + " ".join(f"{np.cos(a):.6f} {np.sin(a):.6f} {0.3 * np.cos(5 * a):.6f}" for a in np.linspace(0, 6.2, 80)) + '"/>', 'contype="0"', "", "decimate the collision mesh"),
 ])
 def test_mesh_geoms_outside_the_subset_are_loud_errors(asset, gattr, extra, msg):
     with pytest.raises(ValueError, match=msg):
         compile_model(mjcf.parse_mjcf(MESH_XML.format(asset=asset, gattr=gattr, extra=extra)))
+
+
+def test_a_mesh_against_a_box_of_another_body_is_a_pair_of_four_slots():
+    """Round 6 (it was a loud error until round 5): a mesh hull and a box on bodies that are neither welded nor parent and child collide as MJX's
+    convex_convex pairs them - four contact slots, both hulls in the blob's hull section."""
+    extra = ('<body name="b2" pos="0 0 0.2"><joint name="j" axis="0 1 0"/><inertial pos="0 0 0" mass="1" diaginertia="1 1 1"/>'
+             '<body name="b3" pos="0 0 0.2"><joint name="j3" axis="0 1 0"/><inertial pos="0 0 0" mass="1" diaginertia="1 1 1"/><geom type="box" size="0.05 0.05 0.05"/></body></body>')
+    cm = compile_model(mjcf.parse_mjcf(MESH_XML.format(asset=f'<mesh name="rock" vertex="{CUBE_PLUS}"/>', gattr="", extra=extra)))
+    assert cm.npair == 4 and int(cm.t["nhull"]) == 2 and cm.t["pair_geom"][:, 15].tolist() == [0, 1, 2, 3]
+    assert (cm.t["pair_geom"][:, 7] > 0).all() and (cm.t["pair_geom"][:, 14] > 0).all() and (cm.t["pair_geom"][:, 7] != cm.t["pair_geom"][:, 14]).all()
 
 
 EXPORT = Path(__file__).parent / "golden" / "export_biped"
