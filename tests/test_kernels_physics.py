@@ -161,18 +161,34 @@ def test_forward_matches_the_f64_oracle_at_full_size(model, N):
     ref = PhysState(qpos=q32[0].astype(np.float64), qvel=q32[1].astype(np.float64), ctrl=q32[2].astype(np.float64), qacc_warmstart=q32[3].astype(np.float64), time=np.zeros(N))
     Physics(cm.t).forward(ref)
     got = _probe(be, h, cm, *q32)
-    tol = dict(qM=1e-5, qfrc_bias=1e-4, qfrc_passive=1e-5, qfrc_actuator=1e-5, qacc_smooth=2e-4, efc_J=1e-5, efc_D=5e-4, efc_aref=5e-4, cinert=1e-5, cvel=1e-4, xpos=1e-5)
+    tol = dict(qM=1e-5, qfrc_bias=1e-4, qfrc_passive=1e-5, qfrc_actuator=1e-5, qacc_smooth=2e-4, cinert=1e-5, cvel=1e-4, xpos=1e-5)
     for k, t in tol.items():
         r = ref[k]
         scale = np.abs(r).max() + 1e-6
         assert np.abs(got[k].reshape(r.shape) - r).max() <= t * scale, (k, np.abs(got[k].reshape(r.shape) - r).max(), scale)
+    # The constraint rows, row by row where kernel and oracle agree that the row is active or not.  Among tens of thousands of rows some sit ON the
+    # threshold (a contact distance or a limit violation of +-1e-6 changes sign between float32 and float64): such a row may differ in being there, and
+    # only such a row - the oracle's signed distance of every row whose state differs must be within 1e-5 of zero, and they must be rare.
+    act_g, act_r = got["efc_D"].reshape(N, -1) > 0, ref.efc_D > 0
+    same = act_g == act_r
+    nlim = cm.nefc - 4 * cm.ncon
+    row_pos = np.concatenate([np.zeros((N, nlim)), np.repeat(ref.con_dist, 4, axis=1)], axis=1)   # (limit rows: their violation is not kept by the oracle; see below)
+    flips = ~same
+    assert flips.mean() <= 1e-3 and (np.abs(row_pos[flips & (np.arange(cm.nefc) >= nlim)[None]]) < 1e-5).all(), (flips.mean(), flips.sum())
+    for k, t in dict(efc_J=1e-5, efc_D=5e-4, efc_aref=5e-4).items():
+        r, g = ref[k], got[k].reshape(ref[k].shape)
+        scale = np.abs(r).max() + 1e-6
+        diff = np.abs(g - r).reshape(N, cm.nefc, -1).max(-1)
+        assert diff[same].max() <= t * scale, (k, diff[same].max(), scale)
+    ok = same.all(1)  # environments whose active sets agree: the solver saw the same problem
+    assert ok.mean() >= 0.99
     c_got, c_ref, c_smooth = _cost(ref, got["qacc"]), _cost(ref, ref.qacc), _cost(ref, ref.qacc_smooth)
-    np.testing.assert_allclose(c_got, c_ref, rtol=5e-2, atol=1e-3)
-    assert np.all(c_got <= c_smooth * (1 + 1e-5) + 1e-6) and np.all(got["niter"] <= 6)
-    rel = np.abs(got["qacc"] - ref.qacc).max(1) / (np.abs(ref.qacc).max(1) + 1e-9)
+    np.testing.assert_allclose(c_got[ok], c_ref[ok], rtol=5e-2, atol=1e-3)
+    assert np.all(c_got[ok] <= c_smooth[ok] * (1 + 1e-5) + 1e-6) and np.all(got["niter"] <= 6)
+    rel = (np.abs(got["qacc"] - ref.qacc).max(1) / (np.abs(ref.qacc).max(1) + 1e-9))[ok]
     assert np.median(rel) <= 5e-3 and np.quantile(rel, 0.999) <= 0.3, (np.median(rel), np.quantile(rel, 0.999), rel.max())
     ref_e = _euler_acc(cm, ref)
-    rel_e = np.abs(got["qacc_euler"] - ref_e).max(1) / (np.abs(ref_e).max(1) + 1e-9)
+    rel_e = (np.abs(got["qacc_euler"] - ref_e).max(1) / (np.abs(ref_e).max(1) + 1e-9))[ok]
     assert np.median(rel_e) <= 5e-3 and np.quantile(rel_e, 0.9) <= 0.3, (np.median(rel_e), np.quantile(rel_e, 0.9))
     be.lib.model_close(h)
 
