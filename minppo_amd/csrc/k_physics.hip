@@ -1458,15 +1458,33 @@ __global__ void __launch_bounds__(64 * kMaxWavesPerBlock) env_kernel(ModelView m
       }
     } else
     for (int item = g; item < ncon * nv; item += kGroupLanes) {  // contacts: 4 pyramid rows, (contact, dof) per item
+      // (the same arithmetic as contact_rows, written out as in rounds 2 - 5: the BASELINE robots' kernels keep their instruction stream)
       const int c = item / nv, d = item - c * nv;
       if (condist[c] < 0.f) {
-        float r4[4];
-        if (contact_rows(c, d, r4)) {
+        // translational Jacobian of the contact point: body 2 minus body 1 (body 1 = world for a ground contact)
+        V3 jp = {0.f, 0.f, 0.f};
+        bool any = false;
+        for (int side = 0; side < 2; ++side) {
+          if (side == 1 && c < nplane) break;
+          const int b = side == 0 ? TI(con_bodyid)[c] : TI(pair_body)[2 * (c - nplane)];
+          if ((TU(body_ancdof_mask)[b] >> d) & 1ull) {
+            int ri = 0;
+            for (int r = 0; r < nroot; ++r) if (TI(root_body)[r] == TI(body_rootid)[b]) ri = r;
+            const V3 off = sub3(ld3(conpos + 3 * c), ld3(rootcom + 3 * ri));
+            const V3 jb = add3(ld3(cdof + 6 * d + 3), cross3(ld3(cdof + 6 * d), off));
+            jp = side == 0 ? add3(jp, jb) : sub3(jp, jb);
+            any = true;
+          }
+        }
+        if (any) {
+          const V3 n = ld3(confr + 6 * c), t1 = ld3(confr + 6 * c + 3), t2 = cross3(n, t1);
+          const float jn = dot3(n, jp), jt1 = dot3(t1, jp), jt2 = dot3(t2, jp);
+          const float mu = TF(con_friction)[3 * c];
           const int r0 = 4 * c;
-          J[(r0 + 0) * ldj + d] = r4[0];
-          J[(r0 + 1) * ldj + d] = r4[1];
-          J[(r0 + 2) * ldj + d] = r4[2];
-          J[(r0 + 3) * ldj + d] = r4[3];
+          J[(r0 + 0) * ldj + d] = jn + mu * jt1;
+          J[(r0 + 1) * ldj + d] = jn - mu * jt1;
+          J[(r0 + 2) * ldj + d] = jn + mu * jt2;
+          J[(r0 + 3) * ldj + d] = jn - mu * jt2;
         }
       }
     }

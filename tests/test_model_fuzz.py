@@ -21,8 +21,11 @@ def _unit(rng, n=3):
     return x / np.linalg.norm(x)
 
 
-def random_model(seed: int) -> ModelSpec:
+def random_model(seed: int, hull_pairs: bool = False) -> ModelSpec:
+    """hull_pairs: boxes and meshes carry contype 1 as well, so that a hull meets the hulls of other bodies (MJX convex_convex, round 6) - the
+    same robot otherwise (no random number is drawn for it)."""
     rng = np.random.default_rng(1000 + seed)
+    hct = 1 if hull_pairs else 0
     nb = int(rng.integers(3, 13))
     bodies, acts = [], []
 
@@ -39,11 +42,11 @@ def random_model(seed: int) -> ModelSpec:
             elif kind == "cylinder":
                 out.append(GeomSpec(GEOM_CYLINDER, (float(rng.uniform(0.03, 0.07)), float(rng.uniform(0.02, 0.08))), pos=pos, quat=quat, friction=fr, contype=0, conaffinity=4))
             elif kind == "box":
-                out.append(GeomSpec(GEOM_BOX, tuple(rng.uniform(0.03, 0.1, 3)), pos=pos, quat=quat, friction=fr, contype=0, conaffinity=1))
+                out.append(GeomSpec(GEOM_BOX, tuple(rng.uniform(0.03, 0.1, 3)), pos=pos, quat=quat, friction=fr, contype=hct, conaffinity=1))
             else:
                 v = rng.normal(size=(int(rng.integers(6, 13)), 3))
                 v = v / np.linalg.norm(v, axis=1, keepdims=True) * rng.uniform(0.04, 0.1, 3)
-                out.append(GeomSpec(GEOM_MESH, (), pos=pos, quat=quat, friction=fr, contype=0, conaffinity=1, vertices=tuple(map(tuple, v))))
+                out.append(GeomSpec(GEOM_MESH, (), pos=pos, quat=quat, friction=fr, contype=hct, conaffinity=1, vertices=tuple(map(tuple, v))))
         return out
 
     def inertial():
@@ -166,6 +169,56 @@ def test_kernel_follows_the_oracle_on_a_random_robot(be, seed):
         for k, tol in dict(efc_D=1e-3, efc_aref=1e-3, efc_J=5e-4).items():
             r, g = ref[k], got[k].reshape(ref[k].shape)
             assert np.abs(g[good] - r[good]).max() <= tol * scale(k), (seed, k, np.abs(g[good] - r[good]).max() / scale(k))
+    be.lib.model_close(h)
+
+
+HULL_SEEDS = [s_ for s_ in range(40) if compile_model(random_model(s_, True)).npair > compile_model(random_model(s_)).npair][:int(os.environ.get("MPPO_FUZZ_HULL_ROBOTS", "5"))]
+
+
+@pytest.mark.parametrize("seed", HULL_SEEDS)
+def test_kernel_follows_the_oracle_on_a_random_robot_with_hull_pairs(be, seed):
+    """Round 6: the same random robots with their boxes and meshes allowed to meet each other (MJX convex_convex: four slots a pair, in the
+    links of an articulated robot this time, not in a scene of free bodies).  Constraint rows against the oracle on the well-conditioned poses; a
+    hull pair's fourth slot - an exact tie in _manifold_points between a duplicate of its first and of its second point - may be any of the
+    oracle's four rows of that pair (tests/test_convex_pairs.py)."""
+    from test_kernels_physics import _probe
+
+    cm = compile_model(random_model(seed, True))
+    pg = np.asarray(cm.t["pair_geom"]).reshape(-1, 16)
+    hull_first = [k for k in range(cm.npair) if pg[k, 7] != 0 and pg[k, 14] != 0 and not pg[k, 3:7].any() and pg[k, 15] == 0]
+    assert hull_first, seed
+    h, dims, _keep = be.model(cm)
+    N = 12
+    rng = np.random.default_rng(500 + seed)
+    qpos, qvel, ctrl = _states(cm, N, rng)
+    q32 = [x.astype(f32) for x in (qpos, qvel, ctrl if cm.nu else np.zeros((N, 1)), np.zeros((N, cm.nv)))]
+
+    def oracle(dtype):
+        d = PhysState(qpos=q32[0].astype(dtype), qvel=q32[1].astype(dtype), ctrl=q32[2].astype(dtype)[:, :cm.nu], qacc_warmstart=np.zeros((N, cm.nv), dtype), time=np.zeros(N, dtype))
+        Physics(cm.t, dtype).forward(d)
+        return d
+
+    ref, ref32 = oracle(f64), oracle(f32)
+    got = _probe(be, h, cm, *q32)
+    scale = lambda k: np.abs(ref[k]).max() + 1e-6
+    good = (np.abs(ref32.efc_J - ref.efc_J).reshape(N, -1).max(1) <= 2e-4 * scale("efc_J")) & (np.abs(ref32.efc_aref - ref.efc_aref).max(1) <= 5e-4 * scale("efc_aref")) & \
+           ((ref32.efc_D > 0) == (ref.efc_D > 0)).all(1)
+    assert good.sum() >= N // 3, (seed, good)
+    assert ((got["efc_D"].reshape(N, -1) > 0) == (ref.efc_D > 0))[good].all(), seed
+    nlim, nplane = cm.nefc - 4 * cm.ncon, cm.ncon - cm.npair
+    fourth = np.zeros(cm.nefc, bool)                       # the rows of every hull pair's fourth slot
+    for k in hull_first:
+        r0 = nlim + 4 * (nplane + k + 3)
+        fourth[r0:r0 + 4] = True
+    for k, tol in dict(efc_D=1e-3, efc_aref=1e-3, efc_J=5e-4).items():
+        r, g = ref[k], got[k].reshape(ref[k].shape)
+        d = np.abs(g - r).reshape(N, cm.nefc, -1).max(-1)
+        assert d[good][:, ~fourth].max() <= tol * scale(k), (seed, k, d[good][:, ~fourth].max() / scale(k))
+        for kk in hull_first:                              # the fourth slot: one of the oracle's four
+            r0 = nlim + 4 * (nplane + kk)
+            g4 = g.reshape(N, cm.nefc, -1)[good][:, r0 + 12:r0 + 16]
+            r4 = r.reshape(N, cm.nefc, -1)[good][:, r0:r0 + 16].reshape(-1, 4, 4, g4.shape[-1])
+            assert np.abs(g4[:, None] - r4).reshape(len(g4), 4, -1).max(-1).min(-1).max() <= tol * scale(k), (seed, k, "fourth slot of pair", kk)
     be.lib.model_close(h)
 
 
