@@ -687,7 +687,7 @@ def main() -> None:
                 bound = "latency/address-path (the MFMA fraction is reported for the record: DESIGN.md 3.1b)"
                 wbytes = 2.0 * (tr.OP * tr.H + 2 * tr.H * tr.H)  # one network's bf16 fragments a workgroup streams per launch: W1, W2, W2^T
                 stream = {"weight_bytes_per_workgroup": wbytes, "GB_per_s_per_CU": wbytes / (head["us_per_launch"] * 1e-6) / 1e9,
-                          "note": "a CU's vector-memory path takes 64 B per clock = 150 - 180 GB/s warm, 100 - 120 GB/s behind an optimizer step (tools/wstream_probe.hip)"}
+                          "note": "the weights a workgroup streams divided by the WHOLE launch (the stream is one of its phases: while it runs, a CU's vector-memory path takes 64 B per clock = 150 - 180 GB/s warm, 100 - 120 GB/s behind an optimizer step, tools/wstream_probe.hip)"}
             roofline = {"bound": bound, "achieved": head["achieved"], "peak": peak, "unit": "TFLOP/s", "frac": head["frac"],
                         "measured": ("in situ: rocprofv3 --kernel-trace --stats of `bench.py --no-probe` on this tree's kernels, " + in_situ["source"]) if use_situ
                                     else "stand-alone replay, live (no in-situ summary of this tree's kernels is committed: see in_situ.why)",
