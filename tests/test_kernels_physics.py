@@ -550,7 +550,8 @@ def test_specialised_kernel_equals_the_runtime_sized_kernel(be, monkeypatch):
     model - and these two under MPPO_ENV_GENERIC=1 - runs the run-time-sized instantiation of the same source.  Same
     arithmetic in the same order: the forward probe and a stretch of env steps agree bit for bit."""
     # (synth_pile: hull pairs, a cylinder and plane_convex in one robot - those code paths specialise too since round 5)
-    for model in ("synth_stompy_pro", "synth_stompy_full", "synth_pile"):
+    # (the export-style biped, round 6: 33 dofs - the register-resident Cholesky with THREE rows per lane - and the Jacobian and M in global memory)
+    for model in ("synth_stompy_pro", "synth_stompy_full", "synth_pile", MJCF_EXPORT):
         cm = load_model(model)
         N = 9
         ph, d, rng = _walk(cm, N, 5, 8)
@@ -571,7 +572,7 @@ def test_specialised_kernel_equals_the_runtime_sized_kernel(be, monkeypatch):
             state, reset_rec, obs = be.zeros((N, R)), be.zeros((R,)), be.zeros((N, OP))
             rew, done = be.zeros((N,)), be.zeros((N,), np.uint8)
             be.lib.env_reset(h, N, be.ptr(state), be.ptr(reset_rec), be.ptr(obs), OP, be.ptr(rew), be.ptr(done), None, be.stream)
-            rc = nat.RewardCfg(0.95 if model != "synth_pile" else -1.0, 2.0, 2.0, 0.2, 0.5, 0.1, 4.0, 1.0, 1.25)
+            rc = nat.RewardCfg(0.95 if model not in ("synth_pile", MJCF_EXPORT) else -1.0, 2.0, 2.0, 0.2, 0.5, 0.1, 4.0, 1.0, 1.25)
             r2 = np.random.default_rng(3)
             for _ in range(6):
                 act = be.arr((0.8 * r2.standard_normal((N, max(cm.nu, 1)))).astype(f32))
@@ -635,7 +636,7 @@ def test_matrices_in_global_memory_change_nothing(be, monkeypatch):
         be.lib.model_close(h)
     monkeypatch.delenv("MPPO_ENV_SPILL", raising=False)
     assert scratch[1] == 0 and 0 < scratch[2] < scratch[3] == scratch[0], scratch  # the default for this robot: both matrices outside
-    assert lds[0] <= 160 * 1024 and lds[0] == lds[3], lds
+    assert max(lds) <= 160 * 1024, lds  # (default: the specialised kernel's layout - no factor in LDS - since the biped is a default instantiation)
     for other in res[1:]:
         for k in res[0]:
             a_, b_ = np.asarray(res[0][k]), np.asarray(other[k])
@@ -758,7 +759,7 @@ def test_export_style_biped_compiles_steps_and_follows_the_oracle(be, model):
     h, dims, _keep = be.model(cm)
     flag = C.c_int32(-1)
     be.lib.model_is_specialized(h, C.byref(flag))
-    assert flag.value == 0 and dims.lds_bytes <= 160 * 1024
+    assert flag.value == (1 if model == "export_biped" else 0) and dims.lds_bytes <= 160 * 1024  # (the export biped is a default instantiation since round 6)
     N, O, OP, R, nv, nu = 5, dims.obs_dim, dims.obs_pad, dims.rec_dim, cm.nv, cm.nu
     rcfg = RewardCfg()
     env = EnvOracle(cm.t, rcfg)
