@@ -1,12 +1,12 @@
 #!/bin/bash
 # tools/refresh_evidence.sh <new label, e.g. r5_ac> <new profiles prefix, e.g. r05_ac> <old profiles prefix, e.g. r05_ab>
-# One GPU session (tests + three bench lines + in-situ kernel stats + HBM traffic + SQ counters, float and bf16) on the CURRENT tree, the
+# One GPU session (tests + in-situ kernel stats + HBM traffic + SQ counters, float and bf16, then the three bench lines - last, so that they quote this session's summaries) on the CURRENT tree, the
 # summaries copied into profiles/ under the new prefix, the old prefix's files removed and its name replaced in DESIGN.md / README.md /
 # profiles/README.md.  The NUMBERS quoted in those files are not touched: read the printed summary and edit them.  Needs a clean, built tree.
 cd "$(dirname "$0")/.." || exit 1
 L=$1; NEW=$2; OLD=$3
 [ -n "$L" ] && [ -n "$NEW" ] && [ -n "$OLD" ] || { echo "usage: $0 <label> <new prefix> <old prefix>"; exit 2; }
-printf '1500 bash tools/profiles.sh %s "tests bench stats bf16stats traffic trafficbf16"\n900 bash tools/pmc_mlp.sh %s_pmc all 4\n900 bash tools/pmc_mlp.sh %s_pmc_bf16 all 4 training.mlp_dtype=bf16\n' "$L" "$L" "$L" > tools/steps/$L.txt
+printf '1500 bash tools/profiles.sh %s "tests stats bf16stats traffic trafficbf16"\n900 bash tools/pmc_mlp.sh %s_pmc all 4\n900 bash tools/pmc_mlp.sh %s_pmc_bf16 all 4 training.mlp_dtype=bf16\n60 bash tools/collect_profiles.sh %s %s partial\n1500 bash tools/profiles.sh %s bench\n' "$L" "$L" "$L" "$L" "$NEW" "$L" > tools/steps/$L.txt
 tools/gpurun.sh --timeout 1200 -- "bash tools/gpu_run.sh $L < tools/steps/$L.txt" > /tmp/gpurun_$L.log 2>&1 || { tail -5 /tmp/gpurun_$L.log; exit 1; }
 grep "gpurun\] status\|left this round" /tmp/gpurun_$L.log
 tail -n 2 gpurun_out/$L/pytest_gpu.log
