@@ -714,7 +714,7 @@ def main() -> None:
                                                                             else "RCCL all-reduce") + (", all ranks on ONE GPU" if share else "")) if world > 1 else "single GPU",
                        "allreduce": transport + (f" ({tr.peer_form()})" if transport == "peer" else ""), "replicas_identical": replicas_identical,
                        "t_link_us": t_link,  # one-way latency of a system-scope flag, rank 0 <-> rank q (device-timed ping-pong through the exchange buffers; null: no peer exchange)
-                       "hipgraph": bool(tr.graph_active()),
+                       "hipgraph": bool(tr.graph_active()), "env_kernel": tr.env_kernel,
                        "pre_warm": f"{pre_warm_s:.1f} s of unrelated device work before the {args.warmup} warm-up steps (one-time start-up stall of the device, see bench.py)"},
             "roofline": roofline,
             "sanity": {"mean_reward": stats["mean_reward"], "done_fraction": stats["done_fraction"], "mean_total_loss": float(lossm[0])},

@@ -45,7 +45,7 @@ extern "C" {
 #define MPPO_ENCCL (-5)    /* an RCCL call failed                                         */
 #define MPPO_ENOMEM (-6)   /* caller-provided workspace too small                         */
 
-#define MPPO_ABI_VERSION 6  /* 6: mppo_model_scratch_bytes (a large robot's matrices in global memory); 5: mppo_minibatch_rows_per_workgroup; a bf16 network's fragment copies are tile-major (4: mppo_engine_peer_selftest runs on the caller's stream) */
+#define MPPO_ABI_VERSION 7  /* 7: mppo_model_attach_kernel (an environment kernel compiled for the robot at run time); 6: mppo_model_scratch_bytes (a large robot's matrices in global memory); 5: mppo_minibatch_rows_per_workgroup; a bf16 network's fragment copies are tile-major (4: mppo_engine_peer_selftest runs on the caller's stream) */
 
 const char* mppo_last_error(void);
 int32_t mppo_abi_version(void);
@@ -74,6 +74,19 @@ int32_t mppo_model_get_dims(const mppo_model_t* m, mppo_model_dims_t* out);
  * (csrc/spec_dims.inc, written by `python -m minppo_amd.build`; MPPO_SPECIALIZE=robot.xml[,...] adds models), 0 when it runs the
  * run-time-sized kernel.  Same results either way; the fixed-size kernel is faster (env_kernel). */
 int32_t mppo_model_is_specialized(const mppo_model_t* m, int32_t* out);
+/* Attaches a gfx950 code object that holds the environment kernel compiled for exactly this robot's dimensions - the build-time
+ * MPPO_SPECIALIZE at run time, for a robot the library was not built for (`minppo_amd/jit.py` makes one: hipcc, device side only, of
+ * csrc/k_physics.hip with a one-robot list, cached by the hash of the kernel sources and the dimensions).  What it replaces in the
+ * reference: `jax.jit` of the environment step (environment.py / train.py jit their step functions: XLA compiles them for the loaded
+ * robot's shapes at start-up).  `names[0..2]`: the symbols of the kernel's three modes (reset, step, probe) - their mangled names must
+ * spell this model's dimensions; `regchol_max_nv`: the MPPO_REGCHOL_MAX_NV the object was compiled with (48 by default: its LDS layout
+ * follows from it).  The object must carry the library's `mppo_env_kernel_tag` (argument-struct sizes, blob version).  Before it is
+ * used, a reset and four steps of 24 environments must equal the run-time-sized kernel's bit for bit on this device.  *used = 1: the
+ * model now runs the attached kernel (mppo_model_is_specialized reports 2); *used = 0 with MPPO_OK: it does not - the library has an
+ * instantiation for this robot already, MPPO_ENV_GENERIC / MPPO_ENV_SPILL are set, the robot is too large for four environments per
+ * wave, or the kernel failed the comparison (a message on stderr) - and the model is as it was.  Call before the model is handed to an
+ * engine (mppo_model_get_dims().lds_bytes and mppo_model_scratch_bytes change with the kernel). */
+int32_t mppo_model_attach_kernel(mppo_model_t* m, const void* image, size_t nbytes, const char* const* names, int32_t regchol_max_nv, int32_t* used);
 /* Bytes of global memory the environment kernel uses beside the state for N environments: 0 for a robot whose per-environment working set
  * fits LDS four waves to a CU; a larger robot (about 30 dofs / 20 contact slots and up) keeps its mass matrix and contact Jacobian in
  * per-environment records there (L2 / Infinity-Cache resident).  mppo_env_reset / mppo_env_step / mppo_physics_forward

@@ -83,7 +83,7 @@ class EngineCfg(C.Structure):
 
 
 P = C.POINTER
-ABI_VERSION = 6  # include/minppo_hip.h: MPPO_ABI_VERSION
+ABI_VERSION = 7  # include/minppo_hip.h: MPPO_ABI_VERSION
 
 # name -> (restype, argtypes); restype c_i32 functions are checked and raise NativeError
 SIGNATURES = {
@@ -94,6 +94,7 @@ SIGNATURES = {
     "mppo_model_get_dims": (c_i32, [c_vp, P(ModelDims)]),
     "mppo_model_is_specialized": (c_i32, [c_vp, P(c_i32)]),
     "mppo_model_scratch_bytes": (c_i32, [c_vp, c_i32, P(c_sz)]),
+    "mppo_model_attach_kernel": (c_i32, [c_vp, c_vp, c_sz, P(C.c_char_p), c_i32, P(c_i32)]),
     "mppo_env_reset": (c_i32, [c_vp, c_i32, c_vp, c_vp, c_vp, c_i32, c_vp, c_vp, P(EnvMetrics), c_vp]),
     "mppo_env_step": (c_i32, [c_vp, c_i32, c_i32, P(RewardCfg), c_vp, c_vp, c_vp, c_i32, c_vp, c_i32, c_vp, c_vp,
                               P(EnvMetrics), c_vp]),

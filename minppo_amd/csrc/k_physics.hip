@@ -1946,8 +1946,13 @@ struct SpecEntry {
 };
 #define MPPO_SPEC(...) {BlobDims{__VA_ARGS__}, &launch_env_t<StaticModel<__VA_ARGS__>>, false},
 #define MPPO_SPEC_EXTRA(...) {BlobDims{__VA_ARGS__}, &launch_env_t<StaticModel<__VA_ARGS__>>, true},
+// (MPPO_SPEC_INC: minppo_amd/jit.py compiles this file once more, device side only, with a list of ONE robot - the code object
+// mppo_model_attach_kernel takes)
+#ifndef MPPO_SPEC_INC
+#define MPPO_SPEC_INC "spec_dims.inc"
+#endif
 static const SpecEntry kSpecs[] = {
-#include "spec_dims.inc"
+#include MPPO_SPEC_INC
     {BlobDims{}, nullptr, false}};
 #undef MPPO_SPEC
 #undef MPPO_SPEC_EXTRA
@@ -1986,6 +1991,13 @@ struct mppo_model {
   mutable float* scratch = nullptr;
   mutable size_t scratch_bytes = 0;
   int canon_words = 0;  // the table part's length as it follows from the dims (what a specialised kernel's compile-time layout choice saw)
+  // a code object attached at run time (mppo_model_attach_kernel): the environment kernel compiled for exactly this robot's dimensions -
+  // what MPPO_SPECIALIZE does at build time, for a robot the library was not built for
+  bool jit = false;
+  int jit_regchol = 0;  // the MPPO_REGCHOL_MAX_NV the code object was compiled with (its LDS layout follows from it)
+  hipModule_t jit_module = nullptr;
+  hipFunction_t jit_fn[3] = {nullptr, nullptr, nullptr};
+  std::vector<char> jit_image;
 };
 
 namespace mppo {
@@ -2013,19 +2025,21 @@ static int32_t finalize_layout(mppo_model* m) {
     return make_phys_lds(v.nq, v.nv, v.nu, v.nbody, v.njnt, v.ncon, v.nefc, v.nroot, v.ncvx, li_regs,
                          forced >= 0 ? forced : spill_for(v.nq, v.nv, v.nu, v.nbody, v.njnt, v.ncon, v.nefc, v.nroot, v.ncvx, li_regs, m->canon_words));
   };
-  m->lds = lds_for(m->spec >= 0 && v.nv <= kRegCholMaxNv);
+  const bool fixed = m->spec >= 0 || m->jit;
+  m->lds = lds_for(fixed && v.nv <= (m->jit ? m->jit_regchol : kRegCholMaxNv));
   // waves per workgroup: whatever puts the most waves on a CU (160 KB of LDS; every workgroup holds one copy of the model tables and
   // waves x 4 environments), the smaller workgroup on a tie.  MPPO_ENV_WAVES=1..4 overrides (measurements).
   // A robot too large for four environments per wave even with its matrices outside LDS runs two or one per wave on the
   // run-time-sized kernel - three quarters of the lanes idle, but it runs (round 5; before, it was refused).
   v.epw = kEnvsPerWave;
-  if (m->spec >= 0 && ((long long)v.blob_words + (long long)m->lds.total * kEnvsPerWave) * 4 > 160 * 1024) {
+  if (fixed && ((long long)v.blob_words + (long long)m->lds.total * kEnvsPerWave) * 4 > 160 * 1024) {
     // (a specialised kernel carries four environments per wave; a robot too large for that runs the run-time-sized kernel with fewer)
     m->spec = -1;
+    m->jit = false;
     m->lds = lds_for(false);
   }
   auto lds_of = [&](int w) { return (int)std::min<long long>(((long long)v.blob_words + (long long)m->lds.total * v.epw * w) * 4, 1 << 30); };
-  while (lds_of(1) > 160 * 1024 && m->spec < 0 && v.epw > 1) v.epw /= 2;
+  while (lds_of(1) > 160 * 1024 && m->spec < 0 && !m->jit && v.epw > 1) v.epw /= 2;
   int best = 1, best_per_cu = 0;
   for (int w = 1; w <= kMaxWavesPerBlock; ++w) {
     const int per_cu = lds_of(w) <= 160 * 1024 ? (160 * 1024 / lds_of(w)) * w : 0;
@@ -2043,7 +2057,33 @@ static int32_t finalize_layout(mppo_model* m) {
 // not (round 6: a 34-dof / 93-body robot's instantiation, 250 spilled registers, ended every episode at its first step on the GPU while the
 // same source was right on the emulator - a code-generation problem under register pressure), the model runs the run-time-sized kernel and
 // says so on stderr.  A few milliseconds at mppo_model_open; the BASELINE instantiations are held to the same standard by the test suite.
+// Work on the device the model's tables are on, whatever the calling thread's current device is (restored on the way out)
+struct OnDeviceOf {
+  int cur = -1, dev = -1;
+  hipError_t err = hipSuccess;
+  explicit OnDeviceOf(const void* p) {
+#ifndef MPPO_EMU
+    hipPointerAttribute_t attr{};
+    err = hipGetDevice(&cur);
+    if (err == hipSuccess) err = hipPointerGetAttributes(&attr, p);
+    if (err == hipSuccess) { dev = attr.device; if (dev != cur) err = hipSetDevice(dev); }
+#else
+    (void)p;
+#endif
+  }
+  ~OnDeviceOf() {
+#ifndef MPPO_EMU
+    if (dev != cur && dev >= 0 && cur >= 0) (void)hipSetDevice(cur);
+#endif
+  }
+};
+static int32_t spec_self_check_on_device(mppo_model* m);
 static int32_t spec_self_check(mppo_model* m) {
+  OnDeviceOf where(m->mv.blob);
+  MPPO_CHECK_HIP(where.err);
+  return spec_self_check_on_device(m);
+}
+static int32_t spec_self_check_on_device(mppo_model* m) {
   const ModelView& v = m->mv;
   const int N = 24, steps = 4, nu = v.nu > 0 ? v.nu : 1;
   const size_t nstate = (size_t)N * v.rec_dim, nobs = (size_t)N * v.obs_pad, nact = (size_t)N * nu;
@@ -2058,7 +2098,7 @@ static int32_t spec_self_check(mppo_model* m) {
   mppo_reward_cfg_t rc{};
   rc.height_min_z = -1e9f; rc.height_max_z = 1e9f;
   mppo_model generic = *m;
-  generic.spec = -1; generic.scratch = nullptr; generic.scratch_bytes = 0;
+  generic.spec = -1; generic.jit = false; generic.scratch = nullptr; generic.scratch_bytes = 0;
   int32_t st = finalize_layout(&generic);
   for (int which = 0; which < 2 && st == MPPO_OK; ++which) {
     const mppo_model* mm = which == 0 ? m : &generic;
@@ -2092,6 +2132,7 @@ static int32_t spec_self_check(mppo_model* m) {
                     "minppo_amd/build.py names the build variable that keeps a specialised kernel's factorisation out of registers.)\n", v.nv, v.nbody, v.ncon, bad, words, steps, N);
     if (m->scratch) { (void)hipFree(m->scratch); m->scratch = nullptr; m->scratch_bytes = 0; }
     m->spec = -1;
+    m->jit = false;
     return finalize_layout(m);
   }
   return MPPO_OK;
@@ -2276,7 +2317,70 @@ extern "C" int32_t mppo_debug_phys_timers(unsigned long long* out40) {
 
 extern "C" int32_t mppo_model_close(mppo_model_t* m) {
   if (m && m->scratch) (void)hipFree(m->scratch);
+  if (m && m->jit_module) (void)hipModuleUnload(m->jit_module);
   delete m;
+  return MPPO_OK;
+}
+
+// The tag a code object of this file carries (`mppo_env_kernel_tag`): the sizes of the three kernel-argument structs and the blob version -
+// what has to agree between the library and a code object compiled apart from it for a launch to mean anything.
+namespace mppo {
+constexpr unsigned kEnvKernelTag = (unsigned)sizeof(ModelView) * 2654435761u ^ (unsigned)sizeof(EnvArgs) * 40503u ^ (unsigned)sizeof(PhysLds) * 2246822519u ^ kBlobVersion * 3266489917u ^
+                                   (unsigned)kEnvsPerWave;
+}
+extern "C" __device__ __attribute__((used)) const unsigned mppo_env_kernel_tag = mppo::kEnvKernelTag;
+
+extern "C" int32_t mppo_model_attach_kernel(mppo_model_t* m, const void* image, size_t nbytes, const char* const* names, int32_t regchol_max_nv, int32_t* used) {
+  using namespace mppo;
+  if (!m || !image || !nbytes || !names || !names[0] || !names[1] || !names[2] || !used) return fail(MPPO_EINVAL, "mppo_model_attach_kernel: null argument");
+  *used = 0;
+  if (m->jit) return fail(MPPO_EINVAL, "mppo_model_attach_kernel: a code object is attached to this model already");
+  if (regchol_max_nv < 0 || regchol_max_nv > 64) return fail(MPPO_EINVAL, "mppo_model_attach_kernel: regchol_max_nv %d", regchol_max_nv);
+  if (m->spec >= 0) return MPPO_OK;  // (the library holds this robot's kernel itself)
+  {
+    const char* e = getenv("MPPO_ENV_GENERIC");
+    if ((e && e[0] == '1') || env_spill_override() >= 0) return MPPO_OK;  // (the switches that force the run-time-sized kernel)
+  }
+  // the kernels' names spell the dimensions they were compiled for: StaticModel<nq, nv, nu, nbody, njnt, ncon, nlimit, npair, nlevel, nroot, ncvx, ncvxvert, hull, ncyl>, MODE
+  const ModelView& v = m->mv;
+  const int dims[14] = {v.nq, v.nv, v.nu, v.nbody, v.njnt, v.ncon, v.nlimit, v.npair, v.nlevel, v.nroot, v.ncvx, v.ncvxvert, v.hull_words > 0 ? 1 : 0, v.ncyl};
+  char want[256];
+  int o = snprintf(want, sizeof want, "StaticModelI");
+  for (int d : dims) o += snprintf(want + o, sizeof want - o, "Li%dE", d);
+  for (int k = 0; k < 3; ++k) {
+    char mode[320];
+    snprintf(mode, sizeof mode, "%sEELi%dEEEv", want, k);
+    if (!strstr(names[k], "env_kernel") || !strstr(names[k], mode))
+      return fail(MPPO_EINVAL, "mppo_model_attach_kernel: kernel %d is named %s - not the environment kernel of this robot's dimensions and mode (%s)", k, names[k], mode);
+  }
+  OnDeviceOf where(m->mv.blob);  // (a module belongs to the device it was loaded on)
+  MPPO_CHECK_HIP(where.err);
+  m->jit_image.assign(static_cast<const char*>(image), static_cast<const char*>(image) + nbytes);
+  hipModule_t mod = nullptr;
+  hipError_t he = hipModuleLoadData(&mod, m->jit_image.data());
+  if (he != hipSuccess) { m->jit_image.clear(); return fail(MPPO_EHIP, "mppo_model_attach_kernel: the code object does not load (%s)", hipGetErrorString(he)); }
+  auto drop = [&](int32_t rc) { (void)hipModuleUnload(mod); m->jit_module = nullptr; m->jit = false; m->jit_image.clear(); m->jit_image.shrink_to_fit(); return rc; };
+  hipDeviceptr_t tag_ptr = nullptr;
+  size_t tag_bytes = 0;
+  unsigned tag = 0;
+  he = hipModuleGetGlobal(&tag_ptr, &tag_bytes, mod, "mppo_env_kernel_tag");
+  if (he == hipSuccess && tag_bytes == sizeof tag) he = hipMemcpy(&tag, tag_ptr, sizeof tag, hipMemcpyDeviceToHost);
+  if (he != hipSuccess || tag_bytes != sizeof tag) return drop(fail(MPPO_EINVAL, "mppo_model_attach_kernel: the code object carries no mppo_env_kernel_tag (%s)", hipGetErrorString(he)));
+  if (tag != kEnvKernelTag) return drop(fail(MPPO_EINVAL, "mppo_model_attach_kernel: the code object was compiled from other kernel sources than this library (tag %08x, library %08x)", tag, kEnvKernelTag));
+  for (int k = 0; k < 3; ++k) {
+    he = hipModuleGetFunction(&m->jit_fn[k], mod, names[k]);
+    if (he != hipSuccess) return drop(fail(MPPO_EINVAL, "mppo_model_attach_kernel: no kernel %s in the code object (%s)", names[k], hipGetErrorString(he)));
+  }
+  // the layout the specialised kernel computed for itself at compile time; then the same proof a build-time instantiation gives
+  m->jit_module = mod;
+  m->jit = true;
+  m->jit_regchol = regchol_max_nv;
+  if (m->scratch) { MPPO_CHECK_HIP(hipDeviceSynchronize()); (void)hipFree(m->scratch); m->scratch = nullptr; m->scratch_bytes = 0; }
+  int32_t rc = finalize_layout(m);
+  if (rc == MPPO_OK && m->jit) rc = spec_self_check(m);
+  if (rc != MPPO_OK) { m->jit = false; (void)finalize_layout(m); return drop(rc); }
+  if (!m->jit) return drop(MPPO_OK);  // (too large for four environments per wave, or it failed the check: the run-time-sized kernel stays)
+  *used = 1;
   return MPPO_OK;
 }
 
@@ -2315,7 +2419,18 @@ static int32_t launch_env(const mppo_model_t* m, EnvArgs a, hipStream_t stream, 
       a.scratch = m->scratch;
     }
   }
+  if (m->jit) {
+    ModelView mv = m->mv;
+    PhysLds lds = m->lds;
+    void* params[] = {&mv, &a, &lds};
+    MPPO_CHECK_HIP(hipModuleLaunchKernel(m->jit_fn[a.mode], blocks, 1, 1, 64 * m->waves, 1, 1, m->lds_bytes, stream, params, nullptr));
+    return MPPO_OK;
+  }
+#ifdef MPPO_JIT_ONLY  // (the device-side compile of minppo_amd/jit.py: one robot's instantiation and nothing else)
+  return kSpecs[0].launch(m->mv, a, m->lds, m->lds_bytes, blocks, m->waves, stream);
+#else
   return (m->spec >= 0 ? kSpecs[m->spec].launch : &launch_env_t<RuntimeModel>)(m->mv, a, m->lds, m->lds_bytes, blocks, m->waves, stream);
+#endif
 }
 // the engine's entry: mppo_env_step with the out-of-LDS matrices in a region of the engine's arena (hipGraph capture: nothing is allocated)
 int32_t env_step_ws(const mppo_model_t* m, int32_t N, int32_t n_frames, const mppo_reward_cfg_t* rc, float* state, const float* reset_rec, const float* action,
@@ -2337,7 +2452,7 @@ int32_t env_reset_ws(const mppo_model_t* m, int32_t N, float* state, float* rese
 
 extern "C" int32_t mppo_model_is_specialized(const mppo_model_t* m, int32_t* out) {
   if (!m || !out) return mppo::fail(MPPO_EINVAL, "mppo_model_is_specialized: null argument");
-  *out = m->spec >= 0 ? 1 : 0;
+  *out = m->spec >= 0 ? 1 : m->jit ? 2 : 0;
   return MPPO_OK;
 }
 

@@ -68,7 +68,13 @@ class HumanoidEnv:
         self._blob_host = np.frombuffer(self.cm.to_blob(self._include_c_vals), np.uint8).copy()
         self._blob_dev = torch.from_numpy(self._blob_host.copy()).to(self.device)
         self._model = C.c_void_p()
-        self.lib.model_open(self._blob_host.ctypes.data, self._blob_host.size, self._blob_dev.data_ptr(), C.byref(self._model))
+        with torch.cuda.device(self.device):
+            self.lib.model_open(self._blob_host.ctypes.data, self._blob_host.size, self._blob_dev.data_ptr(), C.byref(self._model))
+        if config.environment.jit_kernel:
+            from minppo_amd import jit
+
+            with torch.cuda.device(self.device):
+                jit.specialize(self.lib, self._model, self.cm)
         self.dims = nat.ModelDims()
         self.lib.model_get_dims(self._model, C.byref(self.dims))
         self._action_size = self.cm.nu

@@ -243,7 +243,16 @@ class Trainer:
             self._blob_dev[:] = blob
             self.stream, self._stream_ptr = None, None
         self._model = C.c_void_p()
-        self.lib.model_open(self._blob_host.ctypes.data, self._blob_host.size, nat.ptr(self._blob_dev), C.byref(self._model))
+        with self._device_guard():  # (a specialised kernel is checked against the run-time-sized one on the device when the model is opened)
+            self.lib.model_open(self._blob_host.ctypes.data, self._blob_host.size, nat.ptr(self._blob_dev), C.byref(self._model))
+        if config.environment.jit_kernel and xp == "torch":  # (before the engine sizes its arena: the kernel's LDS / global-memory needs follow from it)
+            from minppo_amd import jit
+
+            with self._device_guard():
+                jit.specialize(self.lib, self._model, self.cm, verbose=rank == 0)
+        kind = C.c_int32(0)
+        self.lib.model_is_specialized(self._model, C.byref(kind))
+        self.env_kernel = ("run-time-sized", "library instantiation for this robot", "compiled for this robot at start-up")[kind.value]
         self.dims = nat.ModelDims()
         self.lib.model_get_dims(self._model, C.byref(self.dims))
         self.O, self.OP, self.A, self.H = self.dims.obs_dim, self.dims.obs_pad, self.dims.nu, config.model.hidden_size

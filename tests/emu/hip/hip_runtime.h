@@ -47,6 +47,16 @@ inline hipError_t hipDeviceSynchronize() { return hipSuccess; }
 enum hipStreamCaptureStatus { hipStreamCaptureStatusNone = 0, hipStreamCaptureStatusActive = 1 };
 inline hipError_t hipStreamIsCapturing(hipStream_t, hipStreamCaptureStatus* s) { *s = hipStreamCaptureStatusNone; return hipSuccess; }
 inline hipError_t hipMemcpy(void* d, const void* s, size_t n, hipMemcpyKind) { memmove(d, s, n); return hipSuccess; }
+// code objects (mppo_model_attach_kernel): there is no device code on the emulator - loading one fails, and the caller says so
+typedef struct emu_module* hipModule_t;
+typedef struct emu_function* hipFunction_t;
+typedef void* hipDeviceptr_t;
+constexpr hipError_t hipErrorNotSupported = 801;
+inline hipError_t hipModuleLoadData(hipModule_t*, const void*) { return hipErrorNotSupported; }
+inline hipError_t hipModuleUnload(hipModule_t) { return hipSuccess; }
+inline hipError_t hipModuleGetFunction(hipFunction_t*, hipModule_t, const char*) { return hipErrorNotSupported; }
+inline hipError_t hipModuleGetGlobal(hipDeviceptr_t*, size_t*, hipModule_t, const char*) { return hipErrorNotSupported; }
+inline hipError_t hipModuleLaunchKernel(hipFunction_t, unsigned, unsigned, unsigned, unsigned, unsigned, unsigned, unsigned, hipStream_t, void**, void**) { return hipErrorNotSupported; }
 inline hipError_t hipMemset(void* d, int v, size_t n) { memset(d, v, n); return hipSuccess; }
 // "device" allocations of the engine itself (the ranks' exchange buffers, csrc/k_peer.hip): POSIX shared memory, so that the rank
 // PROCESSES of a CPU test can map each other's buffers the way hipIpc maps a peer GPU's (emu_stubs.cpp)

@@ -29,6 +29,10 @@ for model, N in cases:
     dblob = torch.from_numpy(blob.copy()).cuda()
     h = C.c_void_p()
     lib.model_open(blob.ctypes.data, blob.size, dblob.data_ptr(), C.byref(h))
+    kind = C.c_int32(0); lib.model_is_specialized(h, C.byref(kind)); kind = kind.value
+    if os.environ.get("MPPO_ENV_TIME_JIT") == "1":  # a kernel compiled for this robot now (minppo_amd/jit.py), where the library has none
+        from minppo_amd import jit
+        kind = jit.specialize(lib, h, cm, verbose=True)
     dims = nat.ModelDims(); lib.model_get_dims(h, C.byref(dims))
     state = torch.zeros(N, dims.rec_dim, device="cuda"); reset = torch.zeros(dims.rec_dim, device="cuda")
     obs = torch.zeros(N, dims.obs_pad, device="cuda")
@@ -50,5 +54,5 @@ for model, N in cases:
     for k in range(30): step(k)
     e1.record(); torch.cuda.synchronize()
     nb = C.c_size_t(0); lib.model_scratch_bytes(h, N, C.byref(nb))
-    print(f"{model} (nv {cm.nv}, {cm.ncon} contact slots, {cm.nefc} constraint rows, {dims.lds_bytes} bytes of LDS per workgroup = {160 * 1024 // dims.lds_bytes} workgroup(s) per CU, {nb.value >> 10} KB of matrices in global memory) N={N}: {e0.elapsed_time(e1) / 30 * 1e3:.1f} us per env_step launch; state checksum {float(state.double().sum()):.6f} done {int(done.sum())}")
+    print(f"{model} [{('run-time-sized kernel', 'kernel of the library for this robot', 'kernel compiled at start-up')[kind]}] (nv {cm.nv}, {cm.ncon} contact slots, {cm.nefc} constraint rows, {dims.lds_bytes} bytes of LDS per workgroup = {160 * 1024 // dims.lds_bytes} workgroup(s) per CU, {nb.value >> 10} KB of matrices in global memory) N={N}: {e0.elapsed_time(e1) / 30 * 1e3:.1f} us per env_step launch; state checksum {float(state.double().sum()):.6f} done {int(done.sum())}")
     lib.model_close(h)
