@@ -31,6 +31,9 @@ def _emu_stale() -> bool:
     return any(s.stat().st_mtime > t for s in srcs)
 
 
+JIT_KINDS = []  # (MPPO_TEST_JIT=1: which kernel each opened robot ended up with - 0 run-time-sized, 1 the library's, 2 compiled at start-up)
+
+
 class Backend:
     name = "?"
 
@@ -40,6 +43,12 @@ class Backend:
         dev = self.arr(blob)
         h = C.c_void_p()
         self.lib.model_open(blob.ctypes.data, blob.size, self.ptr(dev), C.byref(h))
+        if os.environ.get("MPPO_TEST_JIT") == "1" and self.name == "hip":
+            # every robot of a GPU test run gets the kernel compiled for it at start-up (minppo_amd/jit.py): the parity tests then check THAT kernel
+            from minppo_amd import jit
+
+            kind = jit.specialize(self.lib, h, cm)
+            JIT_KINDS.append((tuple(jit.dims_of(cm)), kind))
         dims = nat.ModelDims()
         self.lib.model_get_dims(h, C.byref(dims))
         return h, dims, (blob, dev)

@@ -22,6 +22,7 @@ Tolerances (float32 kernel vs float64 oracle), stated per quantity:
 """
 
 import ctypes as C
+import os
 
 from pathlib import Path
 
@@ -34,6 +35,13 @@ from oracle.env_oracle import EnvOracle, RewardCfg
 from oracle.physics_oracle import Physics, PhysState
 
 f32 = np.float32
+
+
+
+def _NOT_IN_THE_LIBRARY(be):
+    """mppo_model_is_specialized of a robot the library has no instantiation for: 0 (run-time-sized kernel) - or 2 in a GPU run with
+    MPPO_TEST_JIT=1, where tests/backends.py gives every robot the kernel compiled for it at start-up (minppo_amd/jit.py)."""
+    return 2 if (os.environ.get("MPPO_TEST_JIT") == "1" and be.name == "hip") else 0
 
 
 def _probe(be, h, cm, qpos, qvel, ctrl, warm):
@@ -488,7 +496,7 @@ def test_forty_dof_robot_runs_the_runtime_sized_kernel(be):
     h, dims, _keep = be.model(cm)
     flag = C.c_int32(-1)
     be.lib.model_is_specialized(h, C.byref(flag))
-    assert flag.value == 0 and dims.lds_bytes <= 160 * 1024
+    assert flag.value == _NOT_IN_THE_LIBRARY(be) and dims.lds_bytes <= 160 * 1024
     N = 6
     ph, d, rng = _walk(cm, N, 5, 21)
     ctrl = 0.3 * rng.standard_normal((N, cm.nu))
@@ -588,7 +596,7 @@ def test_specialised_kernel_equals_the_runtime_sized_kernel(be, monkeypatch):
     h, dims, _keep = be.model(load_model("synth_stompy_pro_sc"))
     flag = C.c_int32(-1)
     be.lib.model_is_specialized(h, C.byref(flag))
-    assert flag.value == 0  # not in the list: run-time-sized kernel
+    assert flag.value == _NOT_IN_THE_LIBRARY(be)  # not in the list: run-time-sized kernel
     be.lib.model_close(h)
 
 
@@ -759,7 +767,7 @@ def test_export_style_biped_compiles_steps_and_follows_the_oracle(be, model):
     h, dims, _keep = be.model(cm)
     flag = C.c_int32(-1)
     be.lib.model_is_specialized(h, C.byref(flag))
-    assert flag.value == (1 if model == "export_biped" else 0) and dims.lds_bytes <= 160 * 1024  # (the export biped is a default instantiation since round 6)
+    assert flag.value == (1 if model == "export_biped" else _NOT_IN_THE_LIBRARY(be)) and dims.lds_bytes <= 160 * 1024  # (the export biped is a default instantiation since round 6)
     N, O, OP, R, nv, nu = 5, dims.obs_dim, dims.obs_pad, dims.rec_dim, cm.nv, cm.nu
     rcfg = RewardCfg()
     env = EnvOracle(cm.t, rcfg)
