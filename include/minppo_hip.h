@@ -77,8 +77,8 @@ int32_t mppo_model_is_specialized(const mppo_model_t* m, int32_t* out);
 /* Attaches a gfx950 code object that holds the environment kernel compiled for exactly this robot's dimensions - the build-time
  * MPPO_SPECIALIZE at run time, for a robot the library was not built for (`minppo_amd/jit.py` makes one: hipcc, device side only, of
  * csrc/k_physics.hip with a one-robot list, cached by the hash of the kernel sources and the dimensions).  What it replaces in the
- * reference: `jax.jit` of the environment step (environment.py / train.py jit their step functions: XLA compiles them for the loaded
- * robot's shapes at start-up).  `names[0..2]`: the symbols of the kernel's three modes (reset, step, probe) - their mangled names must
+ * reference: `jax.jit` of the environment step (env.py:123,147 `@partial(jax.jit, ...)` on reset / step, train.py:133,138,306: XLA
+ * compiles them for the loaded robot's shapes at start-up).  `names[0..2]`: the symbols of the kernel's three modes (reset, step, probe) - their mangled names must
  * spell this model's dimensions; `regchol_max_nv`: the MPPO_REGCHOL_MAX_NV the object was compiled with (48 by default: its LDS layout
  * follows from it).  The object must carry the library's `mppo_env_kernel_tag` (argument-struct sizes, blob version).  Before it is
  * used, a reset and four steps of 24 environments must equal the run-time-sized kernel's bit for bit on this device.  *used = 1: the

@@ -1,8 +1,9 @@
 """The environment kernel compiled for ONE robot at start-up: what `MPPO_SPECIALIZE=robot.xml python -m minppo_amd.build` does at build
 time, for a robot the library was not built for.
 
-What it stands in for: the reference `jax.jit`s its environment step (environment.py `step` / `reset`, train.py `_env_step`): XLA compiles
-them for the loaded robot's shapes when training starts.  Here the library carries a run-time-sized kernel that runs any robot, and kernels
+What it stands in for: the reference `jax.jit`s its environment step (env.py:123,147 `@partial(jax.jit, static_argnums=(0,))` on `reset` /
+`step`; train.py:133,138 the vmapped wrappers, :306 `jax.jit(make_train(config))`): XLA compiles them for the loaded robot's shapes when
+training starts.  Here the library carries a run-time-sized kernel that runs any robot, and kernels
 with fixed dimensions for the BASELINE robots (csrc/spec_dims.inc) - 1.2x - 1.6x faster, bit-identical results.  `specialize()` gives any
 other robot its own: `hipcc --cuda-device-only` of csrc/k_physics.hip with a one-robot list (about 20 s, once: the code object is cached
 under the hash of the kernel sources, the build flags and the dimensions), handed to the library through `mppo_model_attach_kernel`, which
@@ -115,7 +116,10 @@ def compile_kernel(dims: Tuple[int, ...], regchol: int, *, verbose: bool = False
                 flags = [f for f in _build.FILE_FLAGS.get("k_physics.hip", []) if not f.startswith("-DMPPO_REGCHOL_MAX_NV")]
                 cmd = [_build.HIPCC, *_build.FLAGS, *flags, f"-DMPPO_REGCHOL_MAX_NV={regchol}", "--cuda-device-only", "--no-gpu-bundle-output", "-DMPPO_JIT_ONLY",
                        f'-DMPPO_SPEC_INC="{inc}"', "-c", str(_build.CSRC / "k_physics.hip"), "-o", str(obj)]
-                r = subprocess.run(cmd, capture_output=True, text=True, timeout=1800)
+                try:
+                    r = subprocess.run(cmd, capture_output=True, text=True, timeout=1800)
+                except FileNotFoundError as e:
+                    raise RuntimeError(f"environment.jit_kernel needs hipcc ({_build.HIPCC}; set $HIPCC) to compile the environment kernel for this robot") from e
                 if r.returncode != 0:
                     raise RuntimeError(f"hipcc failed on the environment kernel for {dims}:\n{r.stderr[-4000:]}")
                 kernel_symbols(obj.read_bytes())  # (a code object without the three kernels is not cached)
