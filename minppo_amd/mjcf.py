@@ -25,8 +25,10 @@ Subset
              MJX's plane_cylinder, and nothing else; type="ellipsoid" geoms are accepted ONLY with contype="0" conaffinity="0", i.e.
              visual or inertia-only, and then still contribute to inertiafromgeom; a mesh never contributes an inertia: its body needs
              an <inertial>)
-  <asset><mesh name vertex="x y z ..." | file="*.obj|*.stl" scale>: the collision geometry of mesh geoms (files relative to the MJCF,
-            honouring <compiler meshdir>); everything else under <asset> is visual and ignored
+  <asset><mesh name vertex="x y z ..." | file="*.obj|*.stl" scale maxhullvert class>: the collision geometry of mesh geoms (files relative
+            to the MJCF, honouring <compiler meshdir>; <default><mesh scale maxhullvert> applies - where exports put the millimetre scale;
+            maxhullvert caps the hull as MuJoCo does, so a mesh of thousands of vertices loads with maxhullvert="64" instead of being
+            decimated by hand); everything else under <asset> is visual and ignored
   <actuator>: <position joint kp kv gear ctrlrange forcerange>, <motor joint gear ctrlrange forcerange>, <velocity joint kv ...>,
             <general joint gainprm biastype="none|affine" biasprm ...> (dyntype none, gaintype fixed)
   <contact><exclude body1 body2/>: no contacts between the geoms of these two bodies (<contact><pair> is an error)
@@ -166,7 +168,7 @@ class _Compiler:
 class _Defaults:
     """`<default>` tree: class name -> {element tag -> attributes}, children inherit from their parents."""
 
-    TAGS = ("joint", "geom", "position", "motor", "general", "velocity")
+    TAGS = ("joint", "geom", "position", "motor", "general", "velocity", "mesh")
 
     def __init__(self, root: ET.Element):
         self.classes: Dict[str, Dict[str, Dict[str, str]]] = {"main": {t: {} for t in self.TAGS}}
@@ -188,7 +190,7 @@ class _Defaults:
                     # the reference deletes exactly this attribute before MuJoCo sees the file (env.py:41-45)
                     del attrs["frictionloss"]
                 cur[ch.tag].update(attrs)
-            elif ch.tag in ("mesh", "material", "site", "camera", "light", "pair", "equality", "tendon"):
+            elif ch.tag in ("material", "site", "camera", "light", "pair", "equality", "tendon"):
                 if ch.tag in ("equality", "tendon", "pair"):
                     raise ValueError(f"<default><{ch.tag}> is outside the supported MJCF subset")
             else:
@@ -284,9 +286,12 @@ def _read_mesh_file(path: Path) -> np.ndarray:
     raise ValueError(f"{path}: mesh files must be .obj or .stl (or give the vertices inline: <mesh vertex=...>)")
 
 
-def convex_hull_vertices(points: np.ndarray, what: str = "mesh") -> np.ndarray:
+def convex_hull_vertices(points: np.ndarray, what: str = "mesh", maxhullvert: int = -1) -> np.ndarray:
     """The vertices of the convex hull of `points`, in the order they appear in `points` (what MuJoCo keeps of a mesh for
-    collision).  More than MAX_CONVEX_VERTS hull vertices is an error: collision meshes are expected to be decimated."""
+    collision).  More than MAX_CONVEX_VERTS hull vertices is an error: collision meshes are expected to be decimated - or to say
+    `maxhullvert` (MuJoCo >= 3.1.4, the setting its documentation recommends for MJX): the hull is then the one qhull has after
+    `maxhullvert - 4` points were added to its initial simplex (MuJoCo hands qhull the option `TA<maxhullvert - 4>`; [3P-recall] of
+    user_mesh.cc, like every MuJoCo detail here - scipy's ConvexHull is the same qhull)."""
     from scipy.spatial import ConvexHull, QhullError
 
     pts = np.asarray(points, np.float64).reshape(-1, 3)
@@ -294,13 +299,15 @@ def convex_hull_vertices(points: np.ndarray, what: str = "mesh") -> np.ndarray:
     pts = pts[np.sort(first)]  # duplicates dropped, the file's vertex order kept (the order decides ties in plane_convex)
     if len(pts) < 4:
         raise ValueError(f"{what}: a mesh needs at least four distinct vertices")
+    if maxhullvert != -1 and maxhullvert < 4:
+        raise ValueError(f"{what}: maxhullvert must be larger than 3")
     try:
-        hull = ConvexHull(pts)
+        hull = ConvexHull(pts) if maxhullvert == -1 else ConvexHull(pts, qhull_options=f"Qt TA{maxhullvert - 4}")
     except QhullError as exc:
         raise ValueError(f"{what}: degenerate mesh (flat or collinear): {str(exc).splitlines()[0]}") from exc
     keep = np.sort(hull.vertices)
     if len(keep) > MAX_CONVEX_VERTS:
-        raise ValueError(f"{what}: the convex hull has {len(keep)} vertices (limit {MAX_CONVEX_VERTS}); decimate the collision mesh")
+        raise ValueError(f"{what}: the convex hull has {len(keep)} vertices (limit {MAX_CONVEX_VERTS}); decimate the collision mesh or give the <mesh> maxhullvert=\"{MAX_CONVEX_VERTS}\"")
     return pts[keep]
 
 
@@ -410,6 +417,7 @@ def parse_mjcf(xml: str, name: str = "mjcf", base_dir: Optional[Path] = None) ->
 
     # collision meshes (everything else under <asset> is visual)
     meshes: Dict[str, np.ndarray] = {}
+    mesh_maxhull: Dict[str, int] = {}
     meshdir = ""
     if comp_el is not None:
         meshdir = comp_el.get("meshdir", comp_el.get("assetdir", ""))
@@ -418,7 +426,9 @@ def parse_mjcf(xml: str, name: str = "mjcf", base_dir: Optional[Path] = None) ->
             mname = me.get("name") or (Path(me.get("file", "")).stem if me.get("file") else None)
             if not mname:
                 raise ValueError("<asset><mesh> needs a name (or a file to take it from)")
-            scale = np.array(_floats(me.get("scale", "1 1 1"), 3, f"mesh {mname} scale"))
+            ma = dfl.resolve("mesh", me, None)  # (<default><mesh scale=... maxhullvert=...>: millimetre STL files are scaled there as a rule)
+            scale = np.array(_floats(ma.get("scale", "1 1 1"), 3, f"mesh {mname} scale"))
+            mesh_maxhull[mname] = int(ma.get("maxhullvert", "-1"))
             if "vertex" in me.attrib:
                 pts = np.asarray(_floats(me.get("vertex")), np.float64)
                 if pts.size % 3 or pts.size < 12:
@@ -430,7 +440,7 @@ def parse_mjcf(xml: str, name: str = "mjcf", base_dir: Optional[Path] = None) ->
                 pts = _read_mesh_file(Path(base_dir) / meshdir / (Path(me.get("file")).name if comp.strippath else me.get("file")))
             else:
                 raise ValueError(f"mesh {mname}: neither vertex nor file")
-            if any(k in me.attrib for k in ("refpos", "refquat")):
+            if any(k in ma for k in ("refpos", "refquat")):
                 raise ValueError(f"mesh {mname}: refpos / refquat are not supported")
             meshes[mname] = pts * scale[None, :]
 
@@ -480,7 +490,7 @@ def parse_mjcf(xml: str, name: str = "mjcf", base_dir: Optional[Path] = None) ->
             # MuJoCo re-centres a mesh on its centre of mass and principal axes and compensates in the geom's pose: the shape in the
             # body frame is unchanged, so the hull is kept in the file's own mesh frame under the geom's pos / quat as written
             gs = GeomSpec(GEOM_MESH, (), pos=tuple(pos), quat=tuple(quat), friction=fr, contype=contype, conaffinity=conaff,
-                          vertices=tuple(map(tuple, convex_hull_vertices(meshes[mname], f"mesh {mname}"))))
+                          vertices=tuple(map(tuple, convex_hull_vertices(meshes[mname], f"mesh {mname}", mesh_maxhull.get(mname, -1)))))
             return "collide", gs, None
         need = {"sphere": 1, "capsule": 2, "cylinder": 2, "box": 3, "ellipsoid": 3}.get(gtype)
         if need is None:

@@ -327,6 +327,37 @@ def test_mesh_geom_collides_as_its_convex_hull(tmp_path):
         np.testing.assert_allclose(cm1.t[k], cm2.t[k], atol=1e-12, err_msg=k)
 
 
+def test_mesh_defaults_and_maxhullvert(tmp_path):
+    """What a real export's collision meshes need: `<default><mesh scale=...>` (millimetre STL files are scaled there) and
+    `maxhullvert` - MuJoCo's cap on a mesh's hull, the setting its documentation recommends for MJX: a mesh whose hull has hundreds of
+    vertices is refused without it (the kernel scans 64 at most) and loads with it, as the hull qhull holds after maxhullvert - 4 added points."""
+    rng = np.random.default_rng(3)
+    pts = rng.normal(size=(400, 3))
+    pts = np.round(0.05 * pts / np.linalg.norm(pts, axis=1, keepdims=True) * [1.0, 0.7, 0.5], 7)  # an ellipsoid's surface: every point is a hull vertex
+    vtx = " ".join(f"{x:.7f}" for x in pts.ravel())
+    with pytest.raises(ValueError, match="maxhullvert"):
+        compile_model(mjcf.parse_mjcf(MESH_XML.format(asset=f'<mesh name="rock" vertex="{vtx}"/>', gattr='contype="0"', extra="")))
+    cm = compile_model(mjcf.parse_mjcf(MESH_XML.format(asset=f'<mesh name="rock" vertex="{vtx}" maxhullvert="40"/>', gattr='contype="0"', extra="")))
+    v = np.asarray(cm.t["cvx_vert"]) - [0.01, 0, 0]
+    assert cm.ncvx == 1 and len(v) == 40
+    def given(r):
+        return np.abs(pts - r).max(axis=1).min() < 1e-9
+
+    assert all(given(r) for r in v)  # vertices of the mesh, not new points
+    assert np.ptp(v, axis=0).min() > 0.03  # the capped hull still spans the ellipsoid (qhull adds the furthest points first)
+    with pytest.raises(ValueError, match="larger than 3"):
+        mjcf.parse_mjcf(MESH_XML.format(asset=f'<mesh name="rock" vertex="{vtx}" maxhullvert="3"/>', gattr='contype="0"', extra=""))
+    # the same through <default><mesh>, with the scale there too (class defaults included)
+    xml = MESH_XML.format(asset=f'<mesh name="rock" vertex="{vtx}"/>', gattr='contype="0"', extra="").replace(
+        "<asset>", '<default><mesh scale="2 2 2" maxhullvert="24"/><default class="big"><mesh maxhullvert="48"/></default></default><asset>')
+    cm2 = compile_model(mjcf.parse_mjcf(xml))
+    v2 = np.asarray(cm2.t["cvx_vert"]) - [0.01, 0, 0]
+    assert len(v2) == 24 and all(given(r / 2) for r in v2)
+    cm3 = compile_model(mjcf.parse_mjcf(xml.replace('<mesh name="rock"', '<mesh class="big" name="rock"')))
+    assert len(np.asarray(cm3.t["cvx_vert"])) == 48
+    assert cm.ncon == 4  # (four ground slots, like every hull)
+
+
 @pytest.mark.parametrize("asset,gattr,extra,msg", [
     ('<mesh name="other" vertex="0 0 0 1 0 0 0 1 0 0 0 1"/>', 'contype="0"', "", "is not defined under <asset>"),
     ('<mesh name="rock" vertex="0 0 0 1 0 0 0 1 0"/>', 'contype="0"', "", "at least four vertices"),
