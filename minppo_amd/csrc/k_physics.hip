@@ -735,7 +735,13 @@ __global__ void __launch_bounds__(64 * kMaxWavesPerBlock) env_kernel(ModelView m
   }
   float* recw = a.state ? a.state + (size_t)env * mv.rec_dim : nullptr;
   const int o_ci = nq + nv, o_cv = o_ci + (mv.include_c ? 10 * (nb - 1) : 0), o_qa = o_cv + (mv.include_c ? 6 * (nb - 1) : 0);  // the record's fields
-  int badi = 0;  // NaN anywhere in the stepped state (env.py:173-176), accumulated where the values are at hand
+  // NaN anywhere in the stepped state (env.py:173-176), accumulated where the values are at hand.  What is found in the middle of the step (qfrc_actuator,
+  // cinert, cvel) waits for the end of the step as the wave's BALLOT - one scalar value for the four environments - not as a per-lane register: a per-lane
+  // flag that only an any-reduction reads is live in all sixteen lanes across the second factorisation, and in a kernel that spills (three matrix rows per
+  // lane, 93 bodies: 250 spilled registers) the compiler saved and restored it inside divergent code - the lanes inactive there came back with garbage, every
+  // episode "ended" at its first step (round 6; only on hardware, only in that instantiation; found by mppo_model_open's comparison with the run-time-sized
+  // kernel).  A scalar is saved whole whatever lanes are active.
+  group16_flags_t bad_mid = group16_flags(false);
 
   float new_comx = 0.f;
   const int frames = MODE == 1 ? a.n_frames : 1;
@@ -1316,6 +1322,7 @@ __global__ void __launch_bounds__(64 * kMaxWavesPerBlock) env_kernel(ModelView m
     SYNC();
     PT(8);
     // ---- qfrc_bias, passive, actuation -> qfrc_smooth -------------------------------------------------
+    int badm = 0;  // this frame's NaN flags of qfrc_actuator, cinert, cvel (per lane; folded into bad_mid below)
     FOR_G(d, nv) {
       float f[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
       for (int w = 0; w < (nb > 64 ? 2 : 1); ++w) {
@@ -1354,7 +1361,7 @@ __global__ void __launch_bounds__(64 * kMaxWavesPerBlock) env_kernel(ModelView m
       }
       qfs[d] = passive - bias + act;
       // qfrc_actuator is part of the new record / observation (env.py:252) and of the NaN guard, not of the solver: it leaves here
-      badi |= (int)isnan(act);
+      badm |= (int)isnan(act);
       if (MODE != 2 && frame == frames - 1 && valid) {
         recw[o_qa + d] = act;
         if (MODE == 0) { if (env == 0 && a.reset_out) a.reset_out[o_qa + d] = act; if (a.obs) a.obs[(size_t)env * a.obs_ld + o_qa + d] = act; }
@@ -1367,8 +1374,9 @@ __global__ void __launch_bounds__(64 * kMaxWavesPerBlock) env_kernel(ModelView m
     }
     // cinert and cvel have done their work in the dynamics (RNE above was the last reader); what remains is their place in the
     // new state record / observation (env.py:246-259) and the NaN guard: both are served here, and their LDS goes to the Jacobian
-    FOR_G(i, 10 * nb) badi |= (int)isnan(cinert[i]);
-    FOR_G(i, 6 * nb) badi |= (int)isnan(cvel[i]);
+    FOR_G(i, 10 * nb) badm |= (int)isnan(cinert[i]);
+    FOR_G(i, 6 * nb) badm |= (int)isnan(cvel[i]);
+    bad_mid = group16_flags_or(bad_mid, group16_flags(badm != 0));
     if (MODE != 2 && frame == frames - 1 && mv.include_c && valid) {
       FOR_G(i, 10 * (nb - 1)) {
         const float v = cinert[10 + i];
@@ -1871,11 +1879,12 @@ __global__ void __launch_bounds__(64 * kMaxWavesPerBlock) env_kernel(ModelView m
   // cvel were checked when they left LDS)
   const float z = qpos[2];
   // (bitwise accumulation: a short-circuit || would put every load behind its own branch)
+  int badi = 0;
   FOR_G(i, nq) badi |= (int)isnan(qpos[i]);
   FOR_G(i, nv) badi |= (int)isnan(qvel[i]) | (int)isnan(warm[i]);  // (qfrc_actuator was checked when it left for the record)
   badi |= (int)isnan(new_comx);
   const bool bad = badi != 0;
-  const bool done = (bool)((int)!((rc.height_min_z < z) & (z < rc.height_max_z)) | (int)group16_any(bad));
+  const bool done = (bool)((int)!((rc.height_min_z < z) & (z < rc.height_max_z)) | (int)group16_any(bad) | (int)group16_flag_set(bad_mid));
   // The new record: qpos, qvel, the warm start, com_x and the time from LDS (cinert / cvel / qfrc_actuator are in place already) - or,
   // when the episode ended, the reset record, which is also the observation to emit (env.py:179-180).  Ended episodes are rare: the
   // reset record is not even loaded otherwise.
@@ -2055,7 +2064,7 @@ static int32_t finalize_layout(mppo_model* m) {
 // A kernel instantiation that MPPO_SPECIALIZE added to this build has never been compared with anything: before it is trusted, a reset and
 // four steps of 24 environments under pseudo-random controls must equal the run-time-sized kernel's bit for bit ON THIS DEVICE.  If they do
 // not (round 6: a 34-dof / 93-body robot's instantiation, 250 spilled registers, ended every episode at its first step on the GPU while the
-// same source was right on the emulator - a code-generation problem under register pressure), the model runs the run-time-sized kernel and
+// same source was right on the emulator - a per-lane flag spilled inside divergent code: `bad_mid` in env_kernel says how it ended), the model runs the run-time-sized kernel and
 // says so on stderr.  A few milliseconds at mppo_model_open; the BASELINE instantiations are held to the same standard by the test suite.
 // Work on the device the model's tables are on, whatever the calling thread's current device is (restored on the way out)
 struct OnDeviceOf {
@@ -2128,7 +2137,7 @@ static int32_t spec_self_check_on_device(mppo_model* m) {
     size_t bad = 0;
     for (size_t i = 0; i < words; ++i) bad += memcmp(&got[0][i], &got[1][i], 4) != 0;
     fprintf(stderr, "minppo_amd: the environment kernel specialised for this robot (nv %d, %d bodies, %d contact slots) differs from the run-time-sized kernel in %zu of %zu "
-                    "words after a reset and %d steps of %d environments on this device: NOT used - the run-time-sized kernel runs instead.  (A compiler problem: "
+                    "words after a reset and %d steps of %d environments on this device: NOT used - the run-time-sized kernel runs instead.  (DESIGN.md 3.3 has the one such kernel met so far; "
                     "minppo_amd/build.py names the build variable that keeps a specialised kernel's factorisation out of registers.)\n", v.nv, v.nbody, v.ncon, bad, words, steps, N);
     if (m->scratch) { (void)hipFree(m->scratch); m->scratch = nullptr; m->scratch_bytes = 0; }
     m->spec = -1;

@@ -105,6 +105,12 @@ __device__ __forceinline__ bool group16_any(bool pred) {
   const int row = (threadIdx.x & 63) >> 4;
   return ((m >> (16 * row)) & 0xffffull) != 0ull;
 }
+// A per-environment flag that has to survive a long, register-starved stretch of a kernel: the wave's ballot - ONE scalar value (an SGPR pair) for the four
+// 16-lane rows, not a register per lane (k_physics.hip says what happened to the per-lane form).
+typedef unsigned long long group16_flags_t;
+__device__ __forceinline__ group16_flags_t group16_flags(bool pred) { return __ballot(pred); }
+__device__ __forceinline__ group16_flags_t group16_flags_or(group16_flags_t a, group16_flags_t b) { return a | b; }
+__device__ __forceinline__ bool group16_flag_set(group16_flags_t m) { return ((m >> (16 * (int)((threadIdx.x & 63) >> 4))) & 0xffffull) != 0ull; }
 // full-wave sum, result in every lane
 __device__ __forceinline__ float wave_sum(float x) {
   x = group16_sum(x);

@@ -9,9 +9,9 @@ other robot its own: `hipcc --cuda-device-only` of csrc/k_physics.hip with a one
 under the hash of the kernel sources, the build flags and the dimensions), handed to the library through `mppo_model_attach_kernel`, which
 checks it against the run-time-sized kernel on the device (a reset and four steps of 24 environments, bit for bit) before it is used.
 
-A kernel that fails that check (round 6 saw one: a 34-dof / 93-body robot with its Cholesky factors in registers, miscompiled under
-register pressure) is compiled once more with the factors in LDS (`-DMPPO_REGCHOL_MAX_NV=32`); the failure is remembered beside the cache
-entry, so the next start goes to the working variant directly.
+A kernel that fails that check (round 6 saw one - a 34-dof / 93-body robot with its Cholesky factors in registers: a per-lane flag the
+compiler spilled inside divergent code, since carried as the wave's ballot) is compiled once more with the factors in LDS
+(`-DMPPO_REGCHOL_MAX_NV=32`); the failure is remembered beside the cache entry, so the next start goes to the working variant directly.
 
     from minppo_amd import jit
     used = jit.specialize(lib, model_handle, compiled_model)      # 0: run-time-sized kernel stays, 1: the library's own, 2: attached
@@ -97,9 +97,20 @@ def cache_dir() -> Path:
     return d
 
 
+def _extra_flags() -> List[str]:
+    # MPPO_JIT_EXTRA_FLAGS: more hipcc flags for the start-up compile (code-generation experiments; part of the cache key)
+    import shlex
+
+    return shlex.split(os.environ.get("MPPO_JIT_EXTRA_FLAGS", ""))
+
+
+def _key(dims: Tuple[int, ...], regchol: int) -> str:
+    return hashlib.sha256(f"{sources_key()}|{dims}|{regchol}|{' '.join(_extra_flags())}".encode()).hexdigest()[:24]
+
+
 def compile_kernel(dims: Tuple[int, ...], regchol: int, *, verbose: bool = False) -> Path:
     """The cached code object of the environment kernel for `dims`, compiled if it is not there (one process compiles, the others wait)."""
-    key = hashlib.sha256(f"{sources_key()}|{dims}|{regchol}".encode()).hexdigest()[:24]
+    key = _key(dims, regchol)
     out = cache_dir() / f"env_{key}.hsaco"
     if out.exists():
         return out
@@ -115,7 +126,7 @@ def compile_kernel(dims: Tuple[int, ...], regchol: int, *, verbose: bool = False
                 obj = Path(tmp) / "k.hsaco"
                 flags = [f for f in _build.FILE_FLAGS.get("k_physics.hip", []) if not f.startswith("-DMPPO_REGCHOL_MAX_NV")]
                 cmd = [_build.HIPCC, *_build.FLAGS, *flags, f"-DMPPO_REGCHOL_MAX_NV={regchol}", "--cuda-device-only", "--no-gpu-bundle-output", "-DMPPO_JIT_ONLY",
-                       f'-DMPPO_SPEC_INC="{inc}"', "-c", str(_build.CSRC / "k_physics.hip"), "-o", str(obj)]
+                       f'-DMPPO_SPEC_INC="{inc}"', *_extra_flags(), "-c", str(_build.CSRC / "k_physics.hip"), "-o", str(obj)]
                 try:
                     r = subprocess.run(cmd, capture_output=True, text=True, timeout=1800)
                 except FileNotFoundError as e:
@@ -154,7 +165,7 @@ def specialize(lib, handle, cm, *, verbose: bool = False) -> int:
     first = _regchol_of_build()
     tries = [first] + ([32] if first > 32 and nv > 32 else [])
     for regchol in tries:
-        bad = cache_dir() / f"failed_{hashlib.sha256(f'{sources_key()}|{dims}|{regchol}'.encode()).hexdigest()[:24]}"
+        bad = cache_dir() / f"failed_{_key(dims, regchol)}"
         if bad.exists():
             continue  # (this variant failed the device check before)
         path = compile_kernel(dims, regchol, verbose=verbose)

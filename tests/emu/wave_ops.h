@@ -155,6 +155,11 @@ inline bool emu_any(bool pred, int width) {
 }
 inline bool wave_any(bool pred) { return emu_any(pred, 64); }
 inline bool group16_any(bool pred) { return emu_any(pred, 16); }
+// (csrc/wave_ops.h: the wave's ballot as the carrier of a per-environment flag; here a lane simply keeps its row's verdict)
+typedef bool group16_flags_t;
+inline group16_flags_t group16_flags(bool pred) { return emu_any(pred, 16); }
+inline group16_flags_t group16_flags_or(group16_flags_t a, group16_flags_t b) { return a || b; }
+inline bool group16_flag_set(group16_flags_t m) { return m; }
 inline float wave_sum(float x) {
   float* s = reinterpret_cast<float*>(emu::g_xchg);
   const int t = emu::tid();
