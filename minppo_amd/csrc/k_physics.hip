@@ -740,8 +740,12 @@ __global__ void __launch_bounds__(64 * kMaxWavesPerBlock) env_kernel(ModelView m
   // flag that only an any-reduction reads is live in all sixteen lanes across the second factorisation, and in a kernel that spills (three matrix rows per
   // lane, 93 bodies: 250 spilled registers) the compiler saved and restored it inside divergent code - the lanes inactive there came back with garbage, every
   // episode "ended" at its first step (round 6; only on hardware, only in that instantiation; found by mppo_model_open's comparison with the run-time-sized
-  // kernel).  A scalar is saved whole whatever lanes are active.
+  // kernel).  A scalar is saved whole whatever lanes are active.  Only the kernels that spill vector registers carry the flag that way - the model-specialised ones
+  // beyond 32 dofs with their factors in registers (every other instantiation: 0 spilled vector registers, -Rpass-analysis=kernel-resource-usage): two more live
+  // scalars cost the BASELINE kernels, which are short of scalar registers, 1.3 us per step (measured), and a per-lane register that is never spilled is safe.
+  constexpr bool kFlagAsBallot = kRegChol && kDims && kSD.nv > 2 * kGroupLanes;
   group16_flags_t bad_mid = group16_flags(false);
+  int bad_lane = 0;
 
   float new_comx = 0.f;
   const int frames = MODE == 1 ? a.n_frames : 1;
@@ -1322,7 +1326,6 @@ __global__ void __launch_bounds__(64 * kMaxWavesPerBlock) env_kernel(ModelView m
     SYNC();
     PT(8);
     // ---- qfrc_bias, passive, actuation -> qfrc_smooth -------------------------------------------------
-    int badm = 0;  // this frame's NaN flags of qfrc_actuator, cinert, cvel (per lane; folded into bad_mid below)
     FOR_G(d, nv) {
       float f[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
       for (int w = 0; w < (nb > 64 ? 2 : 1); ++w) {
@@ -1361,7 +1364,7 @@ __global__ void __launch_bounds__(64 * kMaxWavesPerBlock) env_kernel(ModelView m
       }
       qfs[d] = passive - bias + act;
       // qfrc_actuator is part of the new record / observation (env.py:252) and of the NaN guard, not of the solver: it leaves here
-      badm |= (int)isnan(act);
+      bad_lane |= (int)isnan(act);
       if (MODE != 2 && frame == frames - 1 && valid) {
         recw[o_qa + d] = act;
         if (MODE == 0) { if (env == 0 && a.reset_out) a.reset_out[o_qa + d] = act; if (a.obs) a.obs[(size_t)env * a.obs_ld + o_qa + d] = act; }
@@ -1374,21 +1377,25 @@ __global__ void __launch_bounds__(64 * kMaxWavesPerBlock) env_kernel(ModelView m
     }
     // cinert and cvel have done their work in the dynamics (RNE above was the last reader); what remains is their place in the
     // new state record / observation (env.py:246-259) and the NaN guard: both are served here, and their LDS goes to the Jacobian
-    FOR_G(i, 10 * nb) badm |= (int)isnan(cinert[i]);
-    FOR_G(i, 6 * nb) badm |= (int)isnan(cvel[i]);
-    bad_mid = group16_flags_or(bad_mid, group16_flags(badm != 0));
+    // (where the values leave for the record anyway, the NaN test rides on that read: the world body's entries are zeros by construction)
     if (MODE != 2 && frame == frames - 1 && mv.include_c && valid) {
       FOR_G(i, 10 * (nb - 1)) {
         const float v = cinert[10 + i];
+        bad_lane |= (int)isnan(v);
         recw[o_ci + i] = v;
         if (MODE == 0) { if (env == 0 && a.reset_out) a.reset_out[o_ci + i] = v; if (a.obs) a.obs[(size_t)env * a.obs_ld + o_ci + i] = v; }
       }
       FOR_G(i, 6 * (nb - 1)) {
         const float v = cvel[6 + i];
+        bad_lane |= (int)isnan(v);
         recw[o_cv + i] = v;
         if (MODE == 0) { if (env == 0 && a.reset_out) a.reset_out[o_cv + i] = v; if (a.obs) a.obs[(size_t)env * a.obs_ld + o_cv + i] = v; }
       }
+    } else {
+      FOR_G(i, 10 * nb) bad_lane |= (int)isnan(cinert[i]);
+      FOR_G(i, 6 * nb) bad_lane |= (int)isnan(cvel[i]);
     }
+    if (kFlagAsBallot) { bad_mid = group16_flags_or(bad_mid, group16_flags(bad_lane != 0)); bad_lane = 0; }
     if (MODE == 2 && valid) {
       if (a.probe.cinert) FOR_G(i, nb * 10) a.probe.cinert[(size_t)env * nb * 10 + i] = cinert[i];
       if (a.probe.cvel) FOR_G(i, nb * 6) a.probe.cvel[(size_t)env * nb * 6 + i] = cvel[i];
@@ -1879,12 +1886,12 @@ __global__ void __launch_bounds__(64 * kMaxWavesPerBlock) env_kernel(ModelView m
   // cvel were checked when they left LDS)
   const float z = qpos[2];
   // (bitwise accumulation: a short-circuit || would put every load behind its own branch)
-  int badi = 0;
+  int badi = kFlagAsBallot ? 0 : bad_lane;
   FOR_G(i, nq) badi |= (int)isnan(qpos[i]);
   FOR_G(i, nv) badi |= (int)isnan(qvel[i]) | (int)isnan(warm[i]);  // (qfrc_actuator was checked when it left for the record)
   badi |= (int)isnan(new_comx);
   const bool bad = badi != 0;
-  const bool done = (bool)((int)!((rc.height_min_z < z) & (z < rc.height_max_z)) | (int)group16_any(bad) | (int)group16_flag_set(bad_mid));
+  const bool done = (bool)((int)!((rc.height_min_z < z) & (z < rc.height_max_z)) | (int)group16_any(bad) | (int)(kFlagAsBallot && group16_flag_set(bad_mid)));
   // The new record: qpos, qvel, the warm start, com_x and the time from LDS (cinert / cvel / qfrc_actuator are in place already) - or,
   // when the episode ended, the reset record, which is also the observation to emit (env.py:179-180).  Ended episodes are rare: the
   // reset record is not even loaded otherwise.
