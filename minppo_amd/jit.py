@@ -84,7 +84,8 @@ def kernel_symbols(image: bytes) -> List[str]:
     out = []
     for mode in range(3):
         tail = f"EELi{mode}EEEvNS_9ModelViewE"
-        hits = sorted(n for n in names if "env_kernel" in n and "StaticModel" in n and tail in n)
+        # (the kernels themselves: `_ZN4mppo10env_kernelI...`; a lambda of the kernel that the compiler did not inline is a function `_ZZN4mppo10env_kernelI...`)
+        hits = sorted(n for n in names if n.startswith("_ZN4mppo10env_kernelINS_11StaticModelI") and n.endswith(tail + "NS_7EnvArgsENS_7PhysLdsE"))
         if len(hits) != 1:
             raise ValueError(f"code object holds {len(hits)} environment kernels of mode {mode} (expected one)")
         out.append(hits[0])

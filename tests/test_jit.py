@@ -38,6 +38,12 @@ def test_code_object_holds_the_three_kernels_of_the_robot(can_object):
         assert "env_kernel" in n and f"StaticModelI{dims}EELi{mode}EEEv" in n
     # cached: a second request is the same file, not a second compile
     assert jit.compile_kernel(jit.dims_of(cm), 48).read_bytes() == image
+    # a robot whose kernel keeps a lambda as a function of its own (40 dofs, three rows per lane: the solve is not inlined): the function's symbol
+    # carries the kernel's name inside its own - it is not one of the three
+    from test_kernels_physics import _many_dof_robot
+
+    big = jit.compile_kernel(jit.dims_of(_many_dof_robot()), 48).read_bytes()
+    assert all(n.startswith("_ZN4mppo10env_kernelI") for n in jit.kernel_symbols(big))
     with pytest.raises(ValueError):
         jit.kernel_symbols(b"\x7fELF" + bytes(200))
     with pytest.raises(ValueError):

@@ -41,6 +41,8 @@ f32 = np.float32
 def _NOT_IN_THE_LIBRARY(be):
     """mppo_model_is_specialized of a robot the library has no instantiation for: 0 (run-time-sized kernel) - or 2 in a GPU run with
     MPPO_TEST_JIT=1, where tests/backends.py gives every robot the kernel compiled for it at start-up (minppo_amd/jit.py)."""
+    if os.environ.get("MPPO_ENV_GENERIC") == "1" or os.environ.get("MPPO_ENV_SPILL"):
+        return 0  # (the switches that force the run-time-sized kernel)
     return 2 if (os.environ.get("MPPO_TEST_JIT") == "1" and be.name == "hip") else 0
 
 
