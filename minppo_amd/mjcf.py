@@ -31,7 +31,8 @@ Subset
             decimated by hand); everything else under <asset> is visual and ignored
   <actuator>: <position joint kp kv gear ctrlrange forcerange>, <motor joint gear ctrlrange forcerange>, <velocity joint kv ...>,
             <general joint gainprm biastype="none|affine" biasprm ...> (dyntype none, gaintype fixed)
-  <contact><exclude body1 body2/>: no contacts between the geoms of these two bodies (<contact><pair> is an error)
+  <contact><exclude body1 body2/>: no contacts between the geoms of these two bodies; <pair geom1 geom2 friction solref solimp/>: an explicit
+            geom pair (or a geom with the ground plane) with a sliding friction of its own, whatever masks / kinship / excludes say
 Contacts: geom-vs-ground-plane, and the geom pairs between bodies that MuJoCo would test (contype / conaffinity masks, same-body and
 parent-child pairs filtered, <exclude>d body pairs dropped): sphere / capsule among themselves, and a sphere or capsule against a box
 or a mesh hull of another body (MJX sphere_convex / capsule_convex); a box or mesh that the masks pair with another box or mesh is an
@@ -450,13 +451,14 @@ def parse_mjcf(xml: str, name: str = "mjcf", base_dir: Optional[Path] = None) ->
     bodies: List[BodySpec] = []
     plane: Optional[Dict[str, object]] = None
     solrefs = {"limit": set(), "contact": set()}
+    paired_names = {el.get(k) for sec in root.findall("contact") for el in sec.findall("pair") for k in ("geom1", "geom2")}
     free_z: List[float] = []
 
     def geom_spec(a: Dict[str, str], what: str):
         """-> (kind, GeomSpec or None, inertia part or None); kind in {'plane', 'collide', 'inert'}"""
         gtype = a.get("type", "sphere")
         contype, conaff = int(a.get("contype", "1")), int(a.get("conaffinity", "1"))
-        collides = (contype | conaff) != 0
+        collides = (contype | conaff) != 0 or (a.get("name") is not None and a.get("name") in paired_names)  # (an explicit pair needs no masks)
         if collides and int(a.get("priority", "0")) != 0:
             raise ValueError(f"{what}: geom priority is not supported (a pair's friction is the larger of the two geoms', MuJoCo's rule for equal priorities)")
         quat = comp.orientation(a, what)
@@ -489,7 +491,7 @@ def parse_mjcf(xml: str, name: str = "mjcf", base_dir: Optional[Path] = None) ->
             fr = tuple((_floats(a["friction"]) + [0.005, 0.0001])[:3]) if "friction" in a else (1.0, 0.005, 0.0001)
             # MuJoCo re-centres a mesh on its centre of mass and principal axes and compensates in the geom's pose: the shape in the
             # body frame is unchanged, so the hull is kept in the file's own mesh frame under the geom's pos / quat as written
-            gs = GeomSpec(GEOM_MESH, (), pos=tuple(pos), quat=tuple(quat), friction=fr, contype=contype, conaffinity=conaff,
+            gs = GeomSpec(GEOM_MESH, (), pos=tuple(pos), quat=tuple(quat), friction=fr, contype=contype, conaffinity=conaff, name=a.get("name", ""),
                           vertices=tuple(map(tuple, convex_hull_vertices(meshes[mname], f"mesh {mname}", mesh_maxhull.get(mname, -1)))))
             return "collide", gs, None
         need = {"sphere": 1, "capsule": 2, "cylinder": 2, "box": 3, "ellipsoid": 3}.get(gtype)
@@ -514,7 +516,7 @@ def parse_mjcf(xml: str, name: str = "mjcf", base_dir: Optional[Path] = None) ->
             raise ValueError(f"{what}: condim {a['condim']} (only 3: pyramidal sliding friction)")
         fr = tuple((_floats(a["friction"]) + [0.005, 0.0001])[:3]) if "friction" in a else (1.0, 0.005, 0.0001)
         gs = GeomSpec({"sphere": GEOM_SPHERE, "capsule": GEOM_CAPSULE, "cylinder": GEOM_CYLINDER, "box": GEOM_BOX}[gtype], tuple(size[:need]), pos=tuple(pos), quat=tuple(quat), friction=fr,
-                      contype=contype, conaffinity=conaff)
+                      contype=contype, conaffinity=conaff, name=a.get("name", ""))
         return "collide", gs, part
 
     def walk(el: ET.Element, parent: str, childclass: Optional[str]) -> None:
@@ -729,6 +731,7 @@ def parse_mjcf(xml: str, name: str = "mjcf", base_dir: Optional[Path] = None) ->
         spec_kw["plane_z"] = plane["z"]
         spec_kw["plane_friction"] = plane["friction"]
         spec_kw["plane_contype"], spec_kw["plane_conaffinity"] = plane["contype"], plane["conaffinity"]
+        spec_kw["plane_name"] = plane["a"].get("name", "")
         for k in ("solref", "solimp"):
             if k in plane["a"] and (k, tuple(_floats(plane["a"][k]))) not in solrefs["contact"]:
                 logger.warning("ground plane %s is ignored: contact parameters are taken from the robot's geoms (MuJoCo mixes both by solmix)", k)
@@ -736,19 +739,50 @@ def parse_mjcf(xml: str, name: str = "mjcf", base_dir: Optional[Path] = None) ->
         spec_kw["has_plane"] = False
         logger.warning("MJCF has no ground plane: only geom-geom contacts will be generated")
     # <contact>: <exclude body1 body2/> removes every geom pair between two bodies (what exports use where neighbouring collision shapes overlap
-    # at rest); explicit <pair geom1 geom2 ...> elements carry contact parameters of their own and are not supported
+    # at rest); <pair geom1 geom2 friction .../> adds a geom pair whatever masks, kinship or excludes say, with contact parameters of its OWN
+    # (MuJoCo does not look at the geoms' for an explicit pair): condim 3, no margin / gap, one sliding friction for both tangents, and the
+    # model's one contact solref / solimp - anything else is a loud error
     known = {b.name for b in bodies}
     excludes: List[Tuple[str, str]] = []
+    pairs: List[Tuple[str, str, Optional[float]]] = []
     for sec in root.findall("contact"):
         for el in sec:
+            if el.tag == "pair":
+                g1, g2 = el.get("geom1"), el.get("geom2")
+                what = f"<contact><pair geom1={g1!r} geom2={g2!r}>"
+                if not g1 or not g2:
+                    raise ValueError("<contact><pair> needs geom1 and geom2")
+                for k in el.attrib:
+                    if k not in ("name", "class", "geom1", "geom2", "condim", "friction", "solref", "solimp", "margin", "gap", "solreffriction"):
+                        raise ValueError(f"{what}: attribute {k!r} is outside the supported MJCF subset")
+                if "class" in el.attrib or "solreffriction" in el.attrib:
+                    raise ValueError(f"{what}: class / solreffriction are not supported")
+                if int(el.get("condim", "3")) != 3:
+                    raise ValueError(f"{what}: condim {el.get('condim')} (only 3: pyramidal sliding friction)")
+                if float(el.get("margin", "0")) != 0 or float(el.get("gap", "0")) != 0:
+                    raise ValueError(f"{what}: contact margin / gap are not supported")
+                fr5 = (_floats(el.get("friction", "")) + [1.0, 1.0, 0.005, 0.0001, 0.0001][len(_floats(el.get("friction", ""))):])[:5] if el.get("friction") else [1.0, 1.0, 0.005, 0.0001, 0.0001]
+                if fr5[0] != fr5[1]:
+                    raise ValueError(f"{what}: friction {fr5[0]} / {fr5[1]} - the two tangent directions of a contact share one coefficient here")
+                want_ref = tuple(spec_kw.get("contact_solref", _MJ_SOLREF))
+                want_imp = tuple(spec_kw.get("contact_solimp", _MJ_SOLIMP))
+                got_ref = tuple(_floats(el.get("solref"))) if el.get("solref") else _MJ_SOLREF
+                got_imp = tuple(_floats(el.get("solimp")) + list(_MJ_SOLIMP[len(_floats(el.get("solimp"))):])) if el.get("solimp") else _MJ_SOLIMP
+                if tuple(got_ref) != want_ref or tuple(got_imp) != want_imp:
+                    raise ValueError(f"{what}: solref / solimp {got_ref} / {got_imp} (MuJoCo's defaults where the pair gives none: a pair does not take the geoms') differ from "
+                                     f"the model's contact values {want_ref} / {want_imp}; the engine keeps one contact solref / solimp per model")
+                pairs.append((g1, g2, float(fr5[0])))
+                continue
             if el.tag != "exclude":
-                raise ValueError(f"<contact><{el.tag}> is outside the supported MJCF subset (only <exclude body1 body2/>)")
+                raise ValueError(f"<contact><{el.tag}> is outside the supported MJCF subset (only <exclude body1 body2/> and <pair geom1 geom2/>)")
             b1, b2 = el.get("body1"), el.get("body2")
             if b1 not in known or b2 not in known:
                 raise ValueError(f"<contact><exclude body1={b1!r} body2={b2!r}>: unknown body")
             excludes.append((b1, b2))
     if excludes:
         spec_kw["contact_excludes"] = excludes
+    if pairs:
+        spec_kw["contact_pairs"] = pairs
     return ModelSpec(name=name, bodies=bodies, actuators=acts, free_root_z=free_root_z, **spec_kw)
 
 
@@ -810,10 +844,10 @@ def to_mjcf(spec: ModelSpec) -> str:
         for gi, g in enumerate(b.geoms):
             if g.type == GEOM_MESH:
                 ET.SubElement(e, "geom", type="mesh", mesh=f"{b.name}_mesh{gi}", pos=_fmt(g.pos), quat=_fmt(g.quat), friction=_fmt(g.friction), contype=str(g.contype),
-                              conaffinity=str(g.conaffinity))
+                              conaffinity=str(g.conaffinity), **({"name": g.name} if g.name else {}))
                 continue
             ET.SubElement(e, "geom", type={GEOM_SPHERE: "sphere", GEOM_CAPSULE: "capsule", GEOM_CYLINDER: "cylinder", GEOM_BOX: "box"}[g.type], size=_fmt(g.size), pos=_fmt(g.pos), quat=_fmt(g.quat), friction=_fmt(g.friction),
-                          contype=str(g.contype), conaffinity=str(g.conaffinity))
+                          contype=str(g.contype), conaffinity=str(g.conaffinity), **({"name": g.name} if g.name else {}))
     act = ET.SubElement(root, "actuator")
     for a in spec.actuators:
         kw = dict(joint=a.joint, gear=repr(float(a.gear)))
@@ -827,9 +861,12 @@ def to_mjcf(spec: ModelSpec) -> str:
             ET.SubElement(act, "position", kp=repr(float(a.kp)), kv=repr(float(a.kv)), **kw)
         else:
             ET.SubElement(act, "motor", **kw)
-    if spec.contact_excludes:
+    if spec.contact_excludes or spec.contact_pairs:
         con = ET.SubElement(root, "contact")
         for b1, b2 in spec.contact_excludes:
             ET.SubElement(con, "exclude", body1=b1, body2=b2)
+        for g1, g2, mu in spec.contact_pairs:
+            ET.SubElement(con, "pair", geom1=g1, geom2=g2, solref=_fmt(spec.contact_solref), solimp=_fmt(spec.contact_solimp),
+                          **({} if mu is None else {"friction": _fmt([mu, mu, 0.005, 0.0001, 0.0001])}))
     ET.indent(root)
     return ET.tostring(root, encoding="unicode")

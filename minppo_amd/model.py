@@ -78,6 +78,7 @@ class GeomSpec:
     # GEOM_MESH: the vertices of the mesh's CONVEX HULL in the geom's own frame ([V, 3]; `size` is unused).  A mesh collides as its
     # convex hull, like in MuJoCo / MJX: with the ground plane, and with the spheres and capsules of other bodies (not with boxes / meshes).
     vertices: Optional[Sequence[Sequence[float]]] = None
+    name: str = ""  # (what an explicit contact pair - ModelSpec.contact_pairs - refers to)
 
 
 @dataclass
@@ -133,6 +134,12 @@ class ModelSpec:
     free_root_z: float = 1.0  # qpos0[2] of the (first) free joint
     meaninertia: Optional[float] = None  # MJCF <statistic meaninertia>: overrides the value derived from M(qpos0) (it scales the solver's tolerance)
     contact_excludes: List[Tuple[str, str]] = field(default_factory=list)  # MJCF <contact><exclude body1 body2/>: no geom pairs between these bodies
+    # MJCF <contact><pair geom1 geom2 friction/>: geom pairs that collide whatever their masks, their bodies' kinship or an <exclude> say, with
+    # a sliding friction of their own (MuJoCo: an explicit pair's parameters are its own, the geoms' are not used - the MJCF loader passes the pair's value or MuJoCo's
+    # pair default, 1; None here: the larger of the two geoms' values, as for a generated pair).
+    # One of the two may be the ground plane (`plane_name`): the geom then gets its ground contact slots.
+    contact_pairs: List[Tuple[str, str, Optional[float]]] = field(default_factory=list)
+    plane_name: str = ""
 
 
 # ---------------------------------------------------------------------------
@@ -399,7 +406,7 @@ def compile_model(spec: ModelSpec) -> CompiledModel:
                 if len(g.vertices) > MAX_CONVEX_VERTS:
                     raise ValueError(f"body {b.name}: a mesh collider with {len(g.vertices)} hull vertices (limit {MAX_CONVEX_VERTS}: decimate the collision mesh)")
             geoms.append((g.type, bi, list(g.pos), list(_normalize(g.quat)), size, list(g.friction), int(g.contype), int(g.conaffinity),
-                          None if g.vertices is None else np.asarray(g.vertices, np.float64).reshape(-1, 3)))
+                          None if g.vertices is None else np.asarray(g.vertices, np.float64).reshape(-1, 3), g.name))
 
     njnt = len(jnt_type)
     # dof_parentid: previous dof in the same body, else last dof of the nearest ancestor with dofs
@@ -508,12 +515,34 @@ def compile_model(spec: ModelSpec) -> CompiledModel:
 
     con_bodyid, con_lpos, con_radius, con_friction, con_axis, con_cvx = [], [], [], [], [], []
     cvx_body, cvx_vadr, cvx_vert = [], [0], []
-    for (gt, bi, gpos, gquat, gsize, gfri, gct, gca, gverts) in geoms:
+    # explicit pairs (MJCF <contact><pair>): by geom name; with the ground plane or between two geoms of different bodies
+    geom_index = {g[9]: k for k, g in enumerate(geoms) if g[9]}
+    pair_with_plane: Dict[int, Optional[float]] = {}
+    pair_of_geoms: Dict[frozenset, Optional[float]] = {}
+    for n1, n2, mu in spec.contact_pairs:
+        for n in (n1, n2):
+            if n not in geom_index and not (spec.has_plane and spec.plane_name and n == spec.plane_name):
+                raise ValueError(f"contact pair ({n1!r}, {n2!r}): unknown geom {n!r} (a pair names collision geoms of bodies, or the ground plane)")
+        if mu is not None and not (mu >= 0):
+            raise ValueError(f"contact pair ({n1!r}, {n2!r}): friction {mu}")
+        on_plane = [n for n in (n1, n2) if n not in geom_index]
+        if len(on_plane) == 2 or n1 == n2:
+            raise ValueError(f"contact pair ({n1!r}, {n2!r}): a pair needs two different geoms, at most one of them the ground plane")
+        if on_plane:
+            pair_with_plane[geom_index[n2 if on_plane[0] == n1 else n1]] = mu
+        else:
+            i_, j_ = geom_index[n1], geom_index[n2]
+            if geoms[i_][1] == geoms[j_][1]:
+                raise ValueError(f"contact pair ({n1!r}, {n2!r}): both geoms belong to the same body")
+            pair_of_geoms[frozenset((i_, j_))] = mu
+    for gk, (gt, bi, gpos, gquat, gsize, gfri, gct, gca, gverts, _gname) in enumerate(geoms):
         if gt not in (GEOM_SPHERE, GEOM_CAPSULE, GEOM_CYLINDER, GEOM_BOX, GEOM_MESH):
             raise ValueError(f"unsupported geom type {gt}")
-        if not spec.has_plane or not _masks_match(spec.plane_contype, spec.plane_conaffinity, gct, gca):
+        if not spec.has_plane or not (_masks_match(spec.plane_contype, spec.plane_conaffinity, gct, gca) or gk in pair_with_plane):
             continue
         fri = np.maximum(np.asarray(gfri), np.asarray(spec.plane_friction))
+        if pair_with_plane.get(gk) is not None:
+            fri = np.asarray([pair_with_plane[gk], fri[1], fri[2]])  # (an explicit pair's sliding friction is its own)
         axis_l = np.zeros(3)
         if gt in (GEOM_MESH, GEOM_BOX):
             # a convex hull against the plane, MJX collision_convex.plane_convex: FOUR slots per geom; which hull vertices fill them
@@ -577,21 +606,24 @@ def compile_model(spec: ModelSpec) -> CompiledModel:
             if gi[0] > gj[0]:
                 gi, gj = gj, gi
             w1, w2 = weld[gi[1]], weld[gj[1]]
-            if w1 == w2 or frozenset((gi[1], gj[1])) in excluded:
-                continue
-            if w1 != 0 and w2 != 0 and (w1 == weld[body_parent[w2]] or w2 == weld[body_parent[w1]]):
-                continue
-            if not _masks_match(gi[6], gi[7], gj[6], gj[7]):
-                continue
+            key = frozenset((i, j))
+            if key not in pair_of_geoms:  # (an explicit pair passes every filter - MuJoCo adds it to the dynamically generated ones, in their place if it is among them)
+                if w1 == w2 or frozenset((gi[1], gj[1])) in excluded:
+                    continue
+                if w1 != 0 and w2 != 0 and (w1 == weld[body_parent[w2]] or w2 == weld[body_parent[w1]]):
+                    continue
+                if not _masks_match(gi[6], gi[7], gj[6], gj[7]):
+                    continue
+            mu_pair = pair_of_geoms.get(key)
             if GEOM_CYLINDER in (gi[0], gj[0]):
                 raise ValueError("a cylinder geom can only collide with the ground plane (MJX pairs it through signed-distance functions: not built): "
                                  "exclude it from geom-geom pairs with contype / conaffinity")
-            pair_rows.append(((gi[0], gj[0]), gi, gj, 0))
+            pair_rows.append(((gi[0], gj[0]), gi, gj, 0, mu_pair))
             if gj[0] in (GEOM_BOX, GEOM_MESH) and gi[0] == GEOM_CAPSULE:
-                pair_rows.append(((gi[0], gj[0]), gi, gj, 1))  # capsule_convex fills two contact slots
+                pair_rows.append(((gi[0], gj[0]), gi, gj, 1, mu_pair))  # capsule_convex fills two contact slots
             if gi[0] in (GEOM_BOX, GEOM_MESH):  # box / mesh against box / mesh (round 6; MJX convex_convex): a manifold of four contact slots
                 for slot_ in (1, 2, 3):
-                    pair_rows.append(((gi[0], gj[0]), gi, gj, slot_))
+                    pair_rows.append(((gi[0], gj[0]), gi, gj, slot_, mu_pair))
     pair_rows.sort(key=lambda r: r[0])  # stable: geom order inside a group, a pair's two slots next to each other
     pair_body, pair_geom = [], []
     # hull section: the convex geoms that take part in a pair, vertices / normals in the BODY frame
@@ -634,7 +666,7 @@ def compile_model(spec: ModelSpec) -> CompiledModel:
             hull_vadr.append(len(hull_vert)); hull_fadr.append(len(hull_fnormal)); hull_eadr.append(len(hull_edge))
         return hull_of[id(gx)]
 
-    for _, gi, gj, slot in pair_rows:
+    for _, gi, gj, slot, mu_pair in pair_rows:
         pair_body += [gi[1], gj[1]]
         hid = hull_id(gj) if gj[0] in (GEOM_BOX, GEOM_MESH) else -1
         hid1 = hull_id(gi) if gi[0] in (GEOM_BOX, GEOM_MESH) else -1
@@ -645,7 +677,10 @@ def compile_model(spec: ModelSpec) -> CompiledModel:
         con_bodyid.append(gj[1])
         con_lpos.append([0.0, 0.0, 0.0])
         con_radius.append(0.0)
-        con_friction.append(list(np.maximum(np.asarray(gi[5]), np.asarray(gj[5]))))
+        fri_pair = np.maximum(np.asarray(gi[5]), np.asarray(gj[5]))
+        if mu_pair is not None:
+            fri_pair = np.asarray([mu_pair, fri_pair[1], fri_pair[2]])
+        con_friction.append(list(fri_pair))
         con_axis.append([0.0, 0.0, 0.0])
         con_cvx.append(-1)
     npair = len(pair_rows)

@@ -422,11 +422,13 @@ def test_export_style_layout_includes_defaults_meshdir(caplog):
     assert cm.t["pair_body"].tolist() == [[5, 12], [5, 14], [5, 14], [12, 7], [12, 7]]
     s.contact_excludes = []
     assert int(compile_model(s).t["npair"]) == 9
-    # the writer keeps the excludes; anything else under <contact> is an error
+    # the writer keeps the excludes; anything but <exclude> and <pair> under <contact> is an error
     s.contact_excludes = [("l_shin", "l_foot"), ("r_shin", "r_foot")]
     assert compile_model(mjcf.parse_mjcf(mjcf.to_mjcf(s))).t["pair_body"].tolist() == cm.t["pair_body"].tolist()
     with pytest.raises(ValueError, match="only <exclude"):
-        mjcf.parse_mjcf(HAND.replace("<actuator>", '<contact><pair geom1="a" geom2="b"/></contact><actuator>'))
+        mjcf.parse_mjcf(HAND.replace("<actuator>", '<contact><tendonpair a="b"/></contact><actuator>'))
+    with pytest.raises(ValueError, match="unknown geom"):  # (explicit pairs: test_explicit_contact_pairs)
+        compile_model(mjcf.parse_mjcf(HAND.replace("<actuator>", '<contact><pair geom1="a" geom2="b"/></contact><actuator>')))
     with pytest.raises(ValueError, match="unknown body"):
         mjcf.parse_mjcf(HAND.replace("<actuator>", '<contact><exclude body1="base" body2="nobody"/></contact><actuator>'))
 
@@ -478,3 +480,90 @@ def test_statistic_meaninertia_overrides_the_derived_value():
     cm = compile_model(s)
     assert float(cm.t["meaninertia"]) == 0.37 != float(derived.t["meaninertia"])
     assert float(compile_model(mjcf.parse_mjcf(mjcf.to_mjcf(s))).t["meaninertia"]) == 0.37
+
+
+PAIR_XML = """<mujoco model="pairs"><compiler angle="radian"/><option timestep="0.002"/>
+  <default><geom solref="0.02 1" solimp="0.9 0.95 0.001 0.5 2"/></default>
+  <worldbody><geom name="floor" type="plane" size="0 0 1" friction="0.6 0.005 0.0001"/>
+    <body name="a" pos="0 0 0.5"><freejoint name="ra"/><inertial pos="0 0 0" mass="1" diaginertia="0.01 0.01 0.01"/>
+      <geom name="ga" type="sphere" size="0.1" contype="0" conaffinity="0" friction="0.3 0.005 0.0001"/>
+      <body name="a2" pos="0 0 0.3"><joint name="ja" type="hinge" axis="0 1 0"/><inertial pos="0 0 0" mass="0.5" diaginertia="0.004 0.004 0.004"/>
+        <geom name="ga2" type="capsule" size="0.05 0.1" contype="0" conaffinity="0"/></body></body>
+    <body name="b" pos="0.5 0 0.5"><freejoint name="rb"/><inertial pos="0 0 0" mass="1" diaginertia="0.01 0.01 0.01"/>
+      <geom name="gb" type="sphere" size="0.12" contype="0" conaffinity="0" friction="0.4 0.005 0.0001"/></body></worldbody>
+  <contact>{contact}</contact></mujoco>"""
+
+
+def test_explicit_contact_pairs():
+    """SURVEY 8 f1, `<contact><pair>`: geom pairs that collide whatever masks, kinship or excludes say, with a sliding friction of their own
+    (MuJoCo does not use the geoms' parameters for an explicit pair; its pair default is 1); one of the two may be the ground plane."""
+    none = compile_model(mjcf.parse_mjcf(PAIR_XML.format(contact="")))
+    assert none.ncon == 0  # every mask is zero: nothing collides
+    cm = compile_model(mjcf.parse_mjcf(PAIR_XML.format(contact='<pair geom1="ga" geom2="gb" friction="0.8 0.8 0.005 0.0001 0.0001"/><pair geom1="floor" geom2="gb"/>'
+                                                               '<pair geom1="ga2" geom2="ga"/><exclude body1="a" body2="b"/>')))
+    # gb on the ground (one slot, the pair's default friction 1 - not max(0.4, 0.6)); ga-gb in spite of the exclude (0.8); ga2-ga in spite of parent and child (1.0)
+    assert (cm.ncon, int(cm.t["npair"])) == (3, 2)
+    fr = np.asarray(cm.t["con_friction"])[:, 0]
+    np.testing.assert_allclose(sorted(fr), [0.8, 1.0, 1.0])
+    np.testing.assert_allclose(fr[0], 1.0)  # (ground slots come first)
+    pb = np.asarray(cm.t["pair_body"]).reshape(-1, 2)
+    names = ["world", "a", "a2", "b"]
+    assert {frozenset((names[i], names[j])) for i, j in pb} == {frozenset(("a", "b")), frozenset(("a", "a2"))}
+    # a pair that the masks generate anyway is there once, with the pair's friction
+    xml = PAIR_XML.format(contact='<pair geom1="gb" geom2="ga" friction="0.25 0.25"/>')
+    xml = xml.replace('name="ga" type="sphere" size="0.1" contype="0" conaffinity="0"', 'name="ga" type="sphere" size="0.1" contype="2" conaffinity="0"')
+    xml = xml.replace('name="gb" type="sphere" size="0.12" contype="0" conaffinity="0"', 'name="gb" type="sphere" size="0.12" contype="0" conaffinity="2"')
+    cm2 = compile_model(mjcf.parse_mjcf(xml))
+    assert int(cm2.t["npair"]) == 1 and cm2.ncon == 1
+    np.testing.assert_allclose(np.asarray(cm2.t["con_friction"])[0, 0], 0.25)
+    # round trip through the writer
+    spec = mjcf.parse_mjcf(PAIR_XML.format(contact='<pair geom1="ga" geom2="gb" friction="0.8 0.8"/><pair geom1="floor" geom2="gb"/>'))
+    cm3, cm4 = compile_model(spec), compile_model(mjcf.parse_mjcf(mjcf.to_mjcf(spec)))
+    for k in ("con_friction", "pair_body", "pair_geom", "con_bodyid"):
+        np.testing.assert_allclose(cm3.t[k], cm4.t[k], atol=1e-12, err_msg=k)
+
+
+@pytest.mark.parametrize("contact,msg", [
+    ('<pair geom1="ga" geom2="nope"/>', "unknown geom"),
+    ('<pair geom1="ga" geom2="gb" condim="4"/>', "condim 4"),
+    ('<pair geom1="ga" geom2="gb" margin="0.01"/>', "margin / gap"),
+    ('<pair geom1="ga" geom2="gb" friction="0.5 0.7"/>', "share one coefficient"),
+    ('<pair geom1="ga" geom2="gb" solref="0.01 1"/>', "one contact solref"),
+    ('<pair geom1="floor" geom2="floor"/>', "two different geoms"),
+    ('<pair geom1="ga" geom2="ga"/>', "two different geoms"),
+    ('<pair geom1="ga"/>', "needs geom1 and geom2"),
+])
+def test_explicit_contact_pairs_outside_the_subset_are_loud_errors(contact, msg):
+    with pytest.raises(ValueError, match=msg):
+        compile_model(mjcf.parse_mjcf(PAIR_XML.format(contact=contact)))
+
+
+def test_kernel_follows_the_oracle_on_explicit_pairs(be):
+    """The scene of test_explicit_contact_pairs through the environment kernel (emulator / MI355X) against the float64 oracle: two spheres pressed together
+    by an explicit pair while every mask is zero, one of them on the ground through its pair with the plane."""
+    from test_kernels_physics import _probe
+    from test_model_fuzz import Physics, PhysState, f32, f64
+
+    cm = compile_model(mjcf.parse_mjcf(PAIR_XML.format(contact='<pair geom1="ga" geom2="gb" friction="0.8 0.8"/><pair geom1="floor" geom2="gb"/><pair geom1="ga2" geom2="ga"/>')))
+    h, dims, _keep = be.model(cm)
+    N = 6
+    rng = np.random.default_rng(5)
+    qpos = np.tile(np.asarray(cm.t["qpos0"], f64), (N, 1))
+    qpos[:, 0:3] = [0.0, 0.0, 0.14]    # body a (free): sphere of 0.1
+    qpos[:, 8:11] = [0.2, 0.0, 0.10]   # body b (free; a: 7 + hinge 1): sphere of 0.12, 0.02 into the ground, 0.02 into ga
+    qpos[:, 0:3] += 0.004 * rng.standard_normal((N, 3))
+    qpos[:, 7] = 0.2 * rng.standard_normal(N)
+    qvel = 0.1 * rng.standard_normal((N, cm.nv))
+    q32 = [x.astype(f32) for x in (qpos, qvel, np.zeros((N, 1)), np.zeros((N, cm.nv)))]
+    d = PhysState(qpos=q32[0].astype(f64), qvel=q32[1].astype(f64), ctrl=np.zeros((N, 0)), qacc_warmstart=np.zeros((N, cm.nv)), time=np.zeros(N))
+    Physics(cm.t, f64).forward(d)
+    got = _probe(be, h, cm, *q32)
+    act = d.efc_D > 0
+    assert act[:, :4].all() and act[:, 4:8].all() and not act[:, 8:12].any()  # ground slot of gb, the ga-gb pair; the capsule stays clear of its parent's sphere
+    assert ((got["efc_D"].reshape(N, -1) > 0) == act).all()
+    for k, tol in dict(efc_D=1e-3, efc_aref=1e-3, efc_J=5e-4, qacc=0.3).items():  # (qacc: six CG iterations of an unconverged solver - the envelope of tests/test_kernels_physics.py)
+        r, g = np.asarray(d[k]), got[k].reshape(np.asarray(d[k]).shape)
+        assert np.abs(g - r).max() <= tol * (np.abs(r).max() + 1e-6), (k, np.abs(g - r).max() / (np.abs(r).max() + 1e-6))
+    # the pair's friction is the pyramid's: rows of the ga-gb contact carry mu = 0.8 (the geoms' own 0.3 / 0.4 are not used)
+    np.testing.assert_allclose(np.asarray(cm.t["con_friction"])[:, 0], [1.0, 0.8, 1.0])
+    be.lib.model_close(h)
