@@ -159,3 +159,32 @@ def test_engine_with_a_kernel_compiled_at_start_up(tmp_path, monkeypatch):
         tr.close()
     assert res[0].size > 0 and np.isfinite(res[0]).all()
     assert np.array_equal(res[0].view(np.uint8), res[1].view(np.uint8))
+
+
+@pytest.mark.gpu
+def test_environment_wrapper_with_a_kernel_compiled_at_start_up(tmp_path, monkeypatch):
+    """`HumanoidEnv` (the reference's env.py surface) with `environment.jit_kernel`: the robot gets its own kernel when the wrapper opens the model,
+    and reset / step return the same bits as the wrapper on the run-time-sized kernel."""
+    import torch
+
+    from minppo_amd.config import load_config_from_cli
+    from minppo_amd.env import HumanoidEnv
+
+    monkeypatch.setenv(jit.CACHE_ENV, str(tmp_path))
+    outs = []
+    for flag in ("false", "true"):
+        cfg = load_config_from_cli(["stompy_pro", f"environment.model={ROBOT}", f"environment.jit_kernel={flag}"])
+        env = HumanoidEnv(cfg)
+        kind = C.c_int32(-1)
+        env.lib.model_is_specialized(env._model, C.byref(kind))
+        assert kind.value == (2 if flag == "true" else 0)
+        es = env.reset(num_envs=37)
+        rng = np.random.default_rng(0)
+        rec = [es.obs.cpu().numpy().copy()]
+        for _ in range(5):
+            a = torch.from_numpy((0.5 * rng.standard_normal((37, env.action_size))).astype(np.float32)).cuda()
+            es = env.step(es, a)
+            rec += [es.obs.cpu().numpy().copy(), es.reward.cpu().numpy().copy(), es.done.cpu().numpy().copy()]
+        outs.append(rec)
+    for x, y in zip(*outs):
+        assert np.array_equal(x.view(np.uint8), y.view(np.uint8))
