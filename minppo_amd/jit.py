@@ -17,6 +17,7 @@ compiler spilled inside divergent code, since carried as the wave's ballot, DESI
     used = jit.specialize(lib, model_handle, compiled_model)      # 0: run-time-sized kernel stays, 1: the library's own, 2: attached
 
 `environment.jit_kernel=true` makes the trainer and the environment wrapper call it.  Needs hipcc on the machine (the image has it).
+`python -m minppo_amd.jit robot.xml` compiles ahead of time (no GPU needed: hipcc cross-compiles), into the same cache.
 """
 
 from __future__ import annotations
@@ -177,3 +178,27 @@ def specialize(lib, handle, cm, *, verbose: bool = False) -> int:
             return state.value
         bad.write_text("mppo_model_attach_kernel did not take this code object (see stderr of the run that wrote this file)\n")
     return 0
+
+
+def main(argv: Optional[List[str]] = None) -> int:
+    """python -m minppo_amd.jit <robot.xml | built-in name> [...]: compiles (and caches) the robots' environment kernels ahead of time - no GPU needed,
+    hipcc cross-compiles - so that the first training start does not have to.  Prints the cache entry of each."""
+    from minppo_amd.model import load_model
+
+    names = list(sys.argv[1:] if argv is None else argv)
+    if not names:
+        print(main.__doc__, file=sys.stderr)
+        return 2
+    for name in names:
+        cm = load_model(name)
+        dims = dims_of(cm)
+        regchol = _regchol_of_build()
+        path = compile_kernel(dims, regchol, verbose=True)
+        print(f"{name}: dims {dims} -> {path}")
+        if regchol > 32 and dims[1] > 32:  # (the variant specialize() falls back to if the device check refuses the first)
+            print(f"{name}: fallback variant -> {compile_kernel(dims, 32, verbose=True)}")
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

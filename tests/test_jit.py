@@ -50,6 +50,16 @@ def test_code_object_holds_the_three_kernels_of_the_robot(can_object):
         jit.kernel_symbols(b"not a code object")
 
 
+def test_kernels_can_be_compiled_ahead_of_time(can_object, capsys):
+    """`python -m minppo_amd.jit <robot>`: the cache entry a later `jit.specialize` finds (here: the fixture's own, found again)."""
+    cm, image = can_object
+    assert jit.main([ROBOT]) == 0
+    out = capsys.readouterr().out
+    path = out.strip().split(" -> ")[-1]
+    assert open(path, "rb").read() == image
+    assert jit.main([]) == 2
+
+
 def test_library_refuses_what_is_not_this_robots_kernel(can_object):
     cm, image = can_object
     be = get_backend("emu")
