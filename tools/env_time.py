@@ -23,6 +23,10 @@ for model, N in cases:
         from test_model_fuzz import random_model
         from minppo_amd.model import compile_model
         cm = compile_model(random_model(int(model[6:])))
+    elif model == "forty_dof":  # the 40-dof / 34-actuator robot of tests/test_kernels_physics.py (three matrix rows per lane when it gets a kernel of its own)
+        sys.path.insert(0, str(Path(__file__).resolve().parents[1] / "tests"))
+        from test_kernels_physics import _many_dof_robot
+        cm = _many_dof_robot()
     else:
         cm = load_model(model)
     blob = np.frombuffer(cm.to_blob(), np.uint8)
